@@ -1,0 +1,250 @@
+/* include/meshclust2_hip.h
+ *
+ * C ABI of libmeshclust2_hip.so: the MI355X (gfx950) replacement for MeShClust2's alignment-free
+ * pairwise-identity hot path. Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * The reference (BioinformaticsToolsmith/MeShClust2 v2.3.0) has no FFI layer: the path is reached through
+ * C++ template member calls. Each entry point below names the reference call site(s) it replaces
+ * (file:line relative to the reference's src/). INTEGRATION.md shows the shim a maintainer would add on
+ * the reference side.
+ *
+ * Conventions
+ *   - every function returns MSC_OK (0) or a negative msc_status; msc_last_error(ctx) has the message.
+ *     Nothing throws across the ABI (the reference throws std::exception / const char* / int).
+ *   - a msc_ctx owns one HIP device + one stream and is NOT thread-safe: use one ctx per host thread
+ *     (the reference calls compute()/classify() from OpenMP workers on shared read-only state,
+ *     cluster/Trainer.cpp:41,84).
+ *   - calls are synchronous: results are valid when the call returns.
+ *   - histograms live in HBM inside a msc_hist_set from the moment they are built; the host sees
+ *     slot indices, flags and scalars. `dtype` is the reference's --datatype: 8, 16, 32 or 64
+ *     (cluster/CRunner.cpp:108-126), fixed per set.
+ *   - there is NO CPU fallback: msc_create() fails with MSC_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MESHCLUST2_HIP_H
+#define MESHCLUST2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSC_ABI_VERSION 1
+
+typedef enum {
+	MSC_OK = 0,
+	MSC_ERR_INVALID_ARG = -1,
+	MSC_ERR_NO_DEVICE = -2,       /* no usable gfx950 device / HIP runtime error at init */
+	MSC_ERR_HIP = -3,             /* a HIP call failed; message has hipGetErrorString */
+	MSC_ERR_OOM = -4,
+	MSC_ERR_INVALID_INPUT = -5,   /* InvalidInputException: character outside the IUPAC map (nonltr/ChromosomeOneDigit.cpp:86-94) */
+	MSC_ERR_ZERO_LENGTH = -6,     /* `throw 123`: length_difference on a zero-length point (predict/Feature.cpp:878-886) */
+	MSC_ERR_NAN = -7,             /* normalize_cache found NaN (predict/Feature.cpp:143-146) */
+	MSC_ERR_UNSUPPORTED = -8,     /* feature flag outside the 11 in-scope statistics, k out of range, ... */
+	MSC_ERR_IO = -9
+} msc_status;
+
+/* Single-feature bits: identical values to FEAT_* in predict/Feature.h:31-64. */
+#define MSC_FEAT_MANHATTAN          (1ULL << 2)
+#define MSC_FEAT_EUCLIDEAN          (1ULL << 3)
+#define MSC_FEAT_NORMALIZED_VECTORS (1ULL << 5)
+#define MSC_FEAT_JEFFEREY_DIV       (1ULL << 7)
+#define MSC_FEAT_PEARSON_COEFF      (1ULL << 9)
+#define MSC_FEAT_INTERSECTION       (1ULL << 13)
+#define MSC_FEAT_EMD                (1ULL << 18)
+#define MSC_FEAT_LENGTHD            (1ULL << 21)
+#define MSC_FEAT_KULCZYNSKI2        (1ULL << 27)
+#define MSC_FEAT_SIMRATIO           (1ULL << 28)
+#define MSC_FEAT_JENSEN_SHANNON     (1ULL << 29)
+/* PRED_FEAT_FAST / PRED_FEAT_DIV, predict/Predictor.h:23-24 (`--feat fast` = FAST, `--feat slow` = FAST|DIV) */
+#define MSC_FEAT_FAST (MSC_FEAT_EUCLIDEAN | MSC_FEAT_MANHATTAN | MSC_FEAT_INTERSECTION | MSC_FEAT_KULCZYNSKI2 | \
+                       MSC_FEAT_SIMRATIO | MSC_FEAT_NORMALIZED_VECTORS | MSC_FEAT_PEARSON_COEFF | MSC_FEAT_EMD | MSC_FEAT_LENGTHD)
+#define MSC_FEAT_DIV  (MSC_FEAT_JEFFEREY_DIV | MSC_FEAT_JENSEN_SHANNON)
+#define MSC_FEAT_SLOW (MSC_FEAT_FAST | MSC_FEAT_DIV)
+
+/* Combo codes as written in the weights file (predict/Predictor.cpp:96-110). */
+#define MSC_COMBO_XY   0
+#define MSC_COMBO_XY2  1
+#define MSC_COMBO_X2Y  2
+#define MSC_COMBO_X2Y2 3
+
+#define MSC_MAX_SINGLES 16
+#define MSC_MAX_COMBOS  8
+
+/* Argument order of a scored pair. All 11 statistics are symmetric EXCEPT the reference's uint32_t
+ * simratio (its wrapped difference), so the order is part of the contract:
+ *   MSC_ORDER_CAND_FIRST : f(candidate, query)  -- Trainer::get_close, merge (cluster/Trainer.cpp:49,93)
+ *   MSC_ORDER_QUERY_FIRST: f(query, candidate)  -- Trainer::filter -> classify(p, pt) (cluster/Trainer.cpp:133) */
+#define MSC_ORDER_CAND_FIRST  0
+#define MSC_ORDER_QUERY_FIRST 1
+
+typedef struct msc_ctx msc_ctx;
+typedef struct msc_hist_set msc_hist_set;
+typedef struct msc_model msc_model;
+
+/* Scalar members of one DivergencePoint<T> (clutil/DivergencePoint.h:81-87) plus derived sums the kernels use. */
+typedef struct {
+	uint64_t mag;          /* DivergencePoint::mag as the reference holds it (stale after hist_assign) */
+	uint64_t length;       /* effective length (Chromosome::getEffectiveSize) */
+	uint64_t sum;          /* true sum of the bins */
+	uint64_t sum_sq;       /* sum of squared bins */
+	uint64_t max_count;    /* largest bin */
+	uint64_t one_mers[4];  /* k=1 table with pseudocount 1 (clutil/Loader.cpp:143-153) */
+	double   stddev;       /* clutil/Loader.cpp:158-171 */
+	int32_t  overflow;     /* 1 if some bin saturated at max(T) (nonltr/KmerHashTable.cpp:248-252) */
+	int32_t  pad_;
+	uint64_t id;
+} msc_hist_info;
+
+/* ------------------------------------------------------------------ context */
+int         msc_abi_version(void);
+/* device >= 0: HIP ordinal. Fails (MSC_ERR_NO_DEVICE) if HIP cannot initialise that device. */
+int         msc_create(int device, msc_ctx** out);
+void        msc_destroy(msc_ctx* ctx);
+const char* msc_last_error(const msc_ctx* ctx);     /* ctx may be NULL: last error of a failed msc_create */
+int         msc_device_name(const msc_ctx* ctx, char* buf, size_t cap);
+int         msc_synchronize(msc_ctx* ctx);
+/* Wall-clock of the dominant kernel (pair_tiles) of the LAST scoring call, from HIP events on the ctx stream (ms). */
+int         msc_last_kernel_ms(const msc_ctx* ctx, float* pair_tiles_ms, float* total_ms);
+
+/* ------------------------------------------------------------------ a1: sequence encoding (host byte work)
+ * Replaces Chromosome::help / removeAmbiguous / mergeSegments / makeSegmentList + ChromosomeOneDigit::encode
+ * (nonltr/Chromosome.cpp:130-154,263-385; nonltr/ChromosomeOneDigit.cpp:79-133).
+ * codes_out[len]: 0..3 where the reference encodes, raw 'N' elsewhere. segs_out: inclusive [s,e] pairs. */
+int msc_encode(const char* seq, size_t len, uint8_t* codes_out, int64_t* segs_out, size_t max_segs,
+               size_t* n_segs, uint64_t* eff_len);
+
+/* ------------------------------------------------------------------ a2-a4: histogram sets */
+/* A set holds `capacity` slots of 4^k bins of `dtype` bits in HBM (tile-permuted layout). */
+int      msc_hist_set_create(msc_ctx* ctx, int k, int dtype, uint64_t capacity, msc_hist_set** out);
+void     msc_hist_set_destroy(msc_hist_set* set);
+uint64_t msc_hist_set_capacity(const msc_hist_set* set);
+int      msc_hist_set_k(const msc_hist_set* set);
+int      msc_hist_set_dtype(const msc_hist_set* set);
+uint64_t msc_hist_set_bytes(const msc_hist_set* set);              /* HBM footprint */
+
+/* Replaces Loader<T>::get_point (clutil/Loader.cpp:112-179; callers cluster/CRunner.cpp:526,
+ * predict/Predictor.cpp:799,858, fastcar/FC_Runner.cpp:501) for n_seqs sequences at once.
+ *   seqs[i]/lens[i] : raw ASCII sequence i (FASTA body, no header, no newlines).
+ *   strip_non_acgt  : 1 = the std::string overload (drops every char that is not upper-case ACGT first,
+ *                     Loader.cpp:115-121); 0 = the ChromosomeOneDigit overload used by the clustering CLI.
+ * Slots first_slot .. first_slot+n_seqs-1 are overwritten. Host encodes + packs to 2 bits/base, the GPU
+ * counts. MSC_ERR_INVALID_INPUT if a sequence holds a character outside the IUPAC map. */
+int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs,
+                   const char* const* seqs, const uint64_t* lens, int strip_non_acgt);
+
+/* Same, from already-encoded input (what a caller with its own FASTA reader hands over):
+ *   packed        : 2-bit codes, base b at bits [2*(b%4), 2*(b%4)+1] of byte b/4, all sequences concatenated
+ *   seg_seq/start/end : n_segs segments; seg_seq[j] = sequence ordinal, [start,end] inclusive GLOBAL base offsets
+ *                    (the reference's segment list, nonltr/Chromosome.cpp:355-385); only k-mers fully inside a
+ *                    segment are counted (clutil/Loader.cpp:53-54)
+ *   eff_len[i], one_mers[4*i..] : per-sequence effective length and k=1 counts (pseudocount included) */
+int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs,
+                          const uint8_t* packed, uint64_t n_bases,
+                          const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs,
+                          const uint64_t* eff_len, const uint64_t* one_mers);
+
+/* Debug / parity: bins in NATURAL k-mer order (first base most significant), 4^k * dtype/8 bytes. */
+int msc_hist_download(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, void* bins_out);
+int msc_hist_upload(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, const void* bins, uint64_t length,
+                    const uint64_t* one_mers /* 4 or NULL */);       /* DivergencePoint(pts, len) ctor: mag recomputed */
+int msc_hist_info_get(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, msc_hist_info* out);
+int msc_hist_set_id(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, uint64_t id);
+
+/* DivergencePoint::clone (clutil/DivergencePoint.h:35-43): full copy, mag re-summed. Used by Center (cluster/Center.h:13-40). */
+int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
+/* DivergencePoint::set (clutil/DivergencePoint.cpp:182-190; caller cluster/ClusterFactory.cpp:328,331):
+ * bins, length and id are copied, `mag` is NOT. */
+int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
+
+/* ------------------------------------------------------------------ a5/a7: model (Feature<T> + GLM weights) */
+/* Mirrors the state Predictor::read_from builds (predict/Predictor.cpp:125-185): combos are replayed through
+ * Feature::add_feature (predict/Feature.cpp:102-128) so single-feature order == order of first appearance.
+ *   combo_kind[c] in MSC_COMBO_*, combo_flags[c] = OR of its 1-2 single bits, weights[0] = intercept.
+ *   single_flags/mins/maxs: the n_singles lines of the file (any order).
+ *   bias: Predictor::set_bias global (predict/Predictor.cpp:307-313), default 0. */
+int  msc_model_create(msc_ctx* ctx, int k, int n_combos, const int* combo_kind, const uint64_t* combo_flags,
+                      const double* weights, int n_singles, const uint64_t* single_flags, const double* mins,
+                      const double* maxs, double bias, msc_model** out);
+/* Reads a `--dump` / weights.txt file (predict/Predictor.cpp:28-44,47-121). block 0 = classification, 1 = regression. */
+int  msc_model_load(msc_ctx* ctx, const char* path, int block, msc_model** out);
+int  msc_model_parse(msc_ctx* ctx, const char* text, int block, msc_model** out);
+void msc_model_destroy(msc_model* m);
+int  msc_model_k(const msc_model* m);
+int  msc_model_n_singles(const msc_model* m);
+int  msc_model_n_combos(const msc_model* m);
+int  msc_model_single_flags(const msc_model* m, uint64_t* flags_out /* n_singles */);
+void msc_model_set_bias(msc_model* m, double bias);
+
+/* ------------------------------------------------------------------ a5/a6: pair scoring, 1 query x m candidates */
+/* Raw statistics (predict/Feature.cpp, the 11 functions of SURVEY 8a-a6) of (cands[cand_slots[i]], q) for every
+ * bit in feat_mask. raw_out is m x popcount(feat_mask), row i = candidate i, columns in ascending bit order.
+ * Replaces Feature<T>::<raw fn> call sites predict/Feature.cpp:156-171 and FeatureSelector's table
+ * (predict/FeatureSelector.cpp:23-33). cand_slots == NULL means slots 0..m-1. */
+int msc_pair_features_raw(msc_ctx* ctx, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                          const msc_hist_set* qset, uint64_t q_slot, int order, uint64_t feat_mask, double* raw_out);
+
+/* Feature::compute + operator() + weighted sum (predict/Feature.h:197-239; cluster/Trainer.cpp:112-120;
+ * predict/Predictor.cpp:284-333). Any output pointer may be NULL.
+ *   singles_out : m x n_singles normalised values (the `cache` vector)
+ *   combos_out  : m x n_combos
+ *   sum_out     : m, s = w0 + sum_c w_c * combo_c
+ *   csum_out    : m, classify_sum = logistic(s) + bias
+ * Rows of candidates for which the reference would throw hold NaN and the call returns MSC_ERR_ZERO_LENGTH/NAN. */
+int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+              const msc_hist_set* qset, uint64_t q_slot, int order,
+              double* singles_out, double* combos_out, double* sum_out, double* csum_out);
+
+/* ------------------------------------------------------------------ a8/a9: Trainer operators */
+/* Trainer<T>::get_close (cluster/Trainer.cpp:23-71; caller cluster/ClusterFactory.cpp:566).
+ * The window [istart, iend) is cand_slots[0..m). Candidates outside floor(len_q*cutoff) <= len <= floor(len_q/cutoff)
+ * are skipped. close_flags[i] = 1 where the reference sets (*i).second = true. best_pos = index INTO cand_slots of the
+ * arg-max of combo 0 (first maximum in window order = OMP_NUM_THREADS=1 order), -1 if nothing passed the length
+ * filter (then best_sim = -1). is_min = no candidate was close. `cutoff` is Trainer::cutoff as given (not get_id()). */
+int msc_get_close(msc_ctx* ctx, const msc_model* model, double cutoff,
+                  const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                  const msc_hist_set* qset, uint64_t q_slot,
+                  uint8_t* close_flags, int64_t* best_pos, double* best_sim, int* is_min);
+
+/* Trainer<T>::filter (cluster/Trainer.cpp:123-141; caller cluster/ClusterFactory.cpp:312): keep[i] = 1 iff point i
+ * is inside the length window of the centre (get_id() form of cutoff) AND round(classify(centre, point)) != 0. */
+int msc_filter(msc_ctx* ctx, const msc_model* model, double cutoff,
+               const msc_hist_set* centre_set, uint64_t centre_slot,
+               const msc_hist_set* pts, const uint32_t* pt_slots, uint64_t m, uint8_t* keep, uint64_t* n_kept);
+
+/* Trainer<T>::merge (cluster/Trainer.cpp:74-109; caller cluster/ClusterFactory.cpp:387): among centres
+ * centre_slots[begin..last] inside the length window of centre_slots[current] with round(classify_sum) == 1,
+ * the index with the largest combo 0 (later index wins ties; initial best (0, DBL_MIN)). */
+int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff,
+              const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+              int64_t current, int64_t begin, int64_t last, int64_t* best_out);
+
+/* Predictor::close + similarity for one query against m database entries (fastcar/FC_Runner.cpp:426-471 work()):
+ * close_out[i] = p_close (classification block), sim_out[i] = p_predict (regression block, clamped to [0,1]). */
+int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg,
+               const msc_hist_set* db, const uint32_t* db_slots, uint64_t m,
+               const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_out, double* sim_out);
+
+/* ------------------------------------------------------------------ a4/a10: mean-shift metric */
+/* get_mean (cluster/ClusterFactory.cpp:338-380), the mean part of mean_shift_update (:297-326) and Trainer::closest
+ * (cluster/Trainer.cpp:144-157): FP64 column mean of the m members, DivergencePoint::distance_d
+ * (clutil/DivergencePoint.cpp:55-66) of every member to it, first arg-min.
+ * dist_out (m) and mean_out (4^k doubles, natural order) may be NULL. */
+int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m,
+                     int64_t* nearest_pos, double* dist_out, double* mean_out);
+
+/* ------------------------------------------------------------------ multi-GPU plumbing
+ * Raw device views so that a caller that owns an RCCL communicator (torch.distributed / rccl.h) can broadcast a
+ * query or all-gather centroid histograms between the per-GPU processes without a host bounce.
+ *   slot_bytes  : bytes of one slot's bins region; slot i starts at bins + i*slot_bytes
+ *   scalar_bytes: bytes of one slot's scalar record; slot i at scalars + i*scalar_bytes
+ * After writing a slot's two regions from a peer's copy, call msc_hist_import_done() for those slots. */
+int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slot_bytes,
+                             void** scalars, uint64_t* scalar_bytes);
+int msc_hist_import_done(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHCLUST2_HIP_H */

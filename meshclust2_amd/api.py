@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI.
+
+Names follow the reference: Loader::get_point -> HistogramSet.build, Feature::compute ->
+Feature.compute / raw, Trainer::get_close / filter / merge / closest -> Trainer.*, Predictor::close /
+similarity -> Predictor.*. Everything here is plumbing (ctypes marshalling); the work happens in
+libmeshclust2_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import FEAT, FEAT_FAST, FEAT_SLOW, MscError, ORDER_CAND_FIRST, ORDER_QUERY_FIRST  # noqa: F401
+
+NP_T = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream (msc_ctx). Not thread-safe: one per host thread."""
+
+    def __init__(self, device=0):
+        self.lib = _capi.load_library()
+        h = C.c_void_p()
+        rc = self.lib.msc_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MscError(rc, self.lib.msc_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise MscError(rc, self.lib.msc_last_error(self.h).decode())
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.msc_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        self.check(self.lib.msc_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        """(pair_tiles ms, whole device pipeline ms) of the last scoring call, from HIP events on the ctx stream."""
+        a, b = C.c_float(), C.c_float()
+        self.check(self.lib.msc_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.msc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode(seq):
+    """Chromosome::help + ChromosomeOneDigit::encode -> (codes, [(s, e)...], effective length)."""
+    lib = _capi.load_library()
+    seq = seq if isinstance(seq, bytes) else seq.encode()
+    codes = np.zeros(max(len(seq), 1), dtype=np.uint8)
+    max_segs = len(seq) // 2 + 2
+    segs = np.zeros(2 * max_segs, dtype=np.int64)
+    n, eff = C.c_size_t(), C.c_uint64()
+    rc = lib.msc_encode(seq, len(seq), codes.ctypes.data_as(C.POINTER(C.c_uint8)), segs.ctypes.data_as(C.POINTER(C.c_int64)),
+                        max_segs, C.byref(n), C.byref(eff))
+    if rc != 0:
+        raise MscError(rc, "invalid nucleotide")
+    return codes[:len(seq)].tobytes(), [(int(segs[2 * i]), int(segs[2 * i + 1])) for i in range(n.value)], eff.value
+
+
+class HistogramSet:
+    """Device-resident k-mer histograms (the `points` vector of DivergencePoint<T>*)."""
+
+    def __init__(self, ctx, k, dtype, capacity):
+        self.ctx, self.k, self.dtype, self.capacity = ctx, int(k), int(dtype), int(capacity)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msc_hist_set_create(ctx.h, self.k, self.dtype, self.capacity, C.byref(h)))
+        self.h = h
+        self.nbins = 4 ** self.k
+
+    def nbytes(self):
+        return self.ctx.lib.msc_hist_set_bytes(self.h)
+
+    def build(self, seqs, first_slot=0, strip=False):
+        """Loader<T>::get_point for a batch (clutil/Loader.cpp:112-179)."""
+        seqs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        n = len(seqs)
+        arr = (C.c_char_p * max(n, 1))(*seqs)
+        lens = (C.c_uint64 * max(n, 1))(*[len(s) for s in seqs])
+        self.ctx.check(self.ctx.lib.msc_hist_build(self.ctx.h, self.h, first_slot, n, arr, lens, 1 if strip else 0))
+
+    def build_packed(self, first_slot, n_seqs, packed, n_bases, seg_seq, seg_start, seg_end, eff_len, one_mers):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        seg_seq = np.ascontiguousarray(seg_seq, dtype=np.uint32)
+        seg_start = np.ascontiguousarray(seg_start, dtype=np.uint64)
+        seg_end = np.ascontiguousarray(seg_end, dtype=np.uint64)
+        eff_len = np.ascontiguousarray(eff_len, dtype=np.uint64)
+        one_mers = np.ascontiguousarray(one_mers, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.msc_hist_build_packed(self.ctx.h, self.h, first_slot, n_seqs, _ptr(packed), int(n_bases), _ptr(seg_seq),
+                                                          _ptr(seg_start), _ptr(seg_end), len(seg_seq), _ptr(eff_len), _ptr(one_mers)))
+
+    def download(self, slot):
+        out = np.zeros(self.nbins, dtype=NP_T[self.dtype])
+        self.ctx.check(self.ctx.lib.msc_hist_download(self.ctx.h, self.h, slot, _ptr(out)))
+        return out
+
+    def upload(self, slot, bins, length, one_mers=None):
+        bins = np.ascontiguousarray(bins, dtype=NP_T[self.dtype])
+        assert bins.size == self.nbins
+        om = None if one_mers is None else (C.c_uint64 * 4)(*one_mers)
+        self.ctx.check(self.ctx.lib.msc_hist_upload(self.ctx.h, self.h, slot, _ptr(bins), int(length), om))
+
+    def info(self, slot):
+        hi = _capi.HistInfo()
+        self.ctx.check(self.ctx.lib.msc_hist_info_get(self.ctx.h, self.h, slot, C.byref(hi)))
+        return dict(mag=hi.mag, length=hi.length, sum=hi.sum, sum_sq=hi.sum_sq, max_count=hi.max_count,
+                    one_mers=list(hi.one_mers), stddev=hi.stddev, overflow=hi.overflow, id=hi.id)
+
+    def set_id(self, slot, id_):
+        self.ctx.check(self.ctx.lib.msc_hist_set_id(self.ctx.h, self.h, slot, id_))
+
+    def clone_from(self, dst_slot, src, src_slot):
+        """DivergencePoint::clone"""
+        self.ctx.check(self.ctx.lib.msc_hist_clone(self.ctx.h, self.h, dst_slot, src.h, src_slot))
+
+    def assign_from(self, dst_slot, src, src_slot):
+        """DivergencePoint::set (mag is NOT copied)"""
+        self.ctx.check(self.ctx.lib.msc_hist_assign(self.ctx.h, self.h, dst_slot, src.h, src_slot))
+
+    def device_view(self):
+        b, s = C.c_void_p(), C.c_void_p()
+        sb, ss = C.c_uint64(), C.c_uint64()
+        self.ctx.check(self.ctx.lib.msc_hist_set_device_view(self.h, C.byref(b), C.byref(sb), C.byref(s), C.byref(ss)))
+        return b.value, sb.value, s.value, ss.value
+
+    def import_done(self, first_slot, n):
+        self.ctx.check(self.ctx.lib.msc_hist_import_done(self.ctx.h, self.h, first_slot, n))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.msc_hist_set_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _slots(slots, m=None):
+    if slots is None:
+        return None, int(m)
+    a = np.ascontiguousarray(slots, dtype=np.uint32)
+    return a, a.size
+
+
+class Feature:
+    """Feature<T> + GLM weights of one weights-file block (msc_model)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        self.k = ctx.lib.msc_model_k(handle)
+        self.n_singles = ctx.lib.msc_model_n_singles(handle)
+        self.n_combos = ctx.lib.msc_model_n_combos(handle)
+
+    @classmethod
+    def from_file(cls, ctx, path, block=0):
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msc_model_load(ctx.h, path.encode(), block, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_text(cls, ctx, text, block=0):
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msc_model_parse(ctx.h, text.encode() if isinstance(text, str) else text, block, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def create(cls, ctx, k, combos, weights, singles, bias=0.0):
+        """combos: [(kind, flags)], weights: [w0, w1..], singles: [(flag, min, max)]"""
+        nc, ns = len(combos), len(singles)
+        kinds = (C.c_int * max(nc, 1))(*[c[0] for c in combos])
+        flags = (C.c_uint64 * max(nc, 1))(*[c[1] for c in combos])
+        w = (C.c_double * (nc + 1))(*weights)
+        sf = (C.c_uint64 * max(ns, 1))(*[s[0] for s in singles])
+        mn = (C.c_double * max(ns, 1))(*[s[1] for s in singles])
+        mx = (C.c_double * max(ns, 1))(*[s[2] for s in singles])
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msc_model_create(ctx.h, k, nc, kinds, flags, w, ns, sf, mn, mx, bias, C.byref(h)))
+        return cls(ctx, h)
+
+    def single_flags(self):
+        out = (C.c_uint64 * max(self.n_singles, 1))()
+        self.ctx.check(self.ctx.lib.msc_model_single_flags(self.h, out))
+        return list(out[:self.n_singles])
+
+    def set_bias(self, b):
+        self.ctx.lib.msc_model_set_bias(self.h, b)
+
+    def compute(self, cands, cand_slots, qset, q_slot, order=ORDER_CAND_FIRST, m=None):
+        """Feature::compute + operator() + weighted sum for 1 query x m candidates.
+        -> dict(singles [m,n_singles], combos [m,n_combos], sum [m], csum [m])"""
+        sl, m = _slots(cand_slots, m)
+        singles = np.zeros((m, self.n_singles))
+        combos = np.zeros((m, self.n_combos))
+        s = np.zeros(m)
+        cs = np.zeros(m)
+        self.ctx.check(self.ctx.lib.msc_score(self.ctx.h, self.h, cands.h, _ptr(sl), m, qset.h, q_slot, order,
+                                              _ptr(singles), _ptr(combos), _ptr(s), _ptr(cs)))
+        return dict(singles=singles, combos=combos, sum=s, csum=cs)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.msc_model_destroy(self.h)
+            self.h = None
+
+
+def pair_features_raw(ctx, cands, cand_slots, qset, q_slot, feat_mask=FEAT_FAST, order=ORDER_CAND_FIRST, m=None):
+    """The raw statistics of predict/Feature.cpp for 1 query x m candidates -> [m, popcount(mask)], ascending bit order."""
+    sl, m = _slots(cand_slots, m)
+    nf = bin(feat_mask).count("1")
+    out = np.zeros((m, nf))
+    ctx.check(ctx.lib.msc_pair_features_raw(ctx.h, cands.h, _ptr(sl), m, qset.h, q_slot, order, feat_mask, _ptr(out)))
+    return out
+
+
+class Trainer:
+    """The pair-scoring operators of cluster/Trainer.{h,cpp} (scoring half only; training is host work out of scope)."""
+
+    def __init__(self, ctx, feat, cutoff):
+        self.ctx, self.feat, self.cutoff = ctx, feat, float(cutoff)
+
+    def get_close(self, points, cand_slots, qset, q_slot, m=None):
+        """-> (close_flags[m], best_pos, best_sim, is_min)"""
+        sl, m = _slots(cand_slots, m)
+        flags = np.zeros(max(m, 1), dtype=np.uint8)
+        bp, bs, im = C.c_int64(), C.c_double(), C.c_int()
+        self.ctx.check(self.ctx.lib.msc_get_close(self.ctx.h, self.feat.h, self.cutoff, points.h, _ptr(sl), m, qset.h, q_slot,
+                                                  _ptr(flags), C.byref(bp), C.byref(bs), C.byref(im)))
+        return flags[:m], bp.value, bs.value, bool(im.value)
+
+    def filter(self, centre_set, centre_slot, points, pt_slots, m=None):
+        """-> keep[m] (1 = survives Trainer::filter)"""
+        sl, m = _slots(pt_slots, m)
+        keep = np.zeros(max(m, 1), dtype=np.uint8)
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.msc_filter(self.ctx.h, self.feat.h, self.cutoff, centre_set.h, centre_slot, points.h, _ptr(sl), m,
+                                               _ptr(keep), C.byref(n)))
+        return keep[:m]
+
+    def merge(self, centres, centre_slots, current, begin, last, n=None):
+        sl, n = _slots(centre_slots, n)
+        out = C.c_int64()
+        self.ctx.check(self.ctx.lib.msc_merge(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(sl), n, current, begin, last, C.byref(out)))
+        return out.value
+
+    def closest(self, points, member_slots, m=None, want_mean=False):
+        """get_mean / closest: -> (nearest_pos, dists[m], mean or None)"""
+        sl, m = _slots(member_slots, m)
+        d = np.zeros(m)
+        mean = np.zeros(points.nbins) if want_mean else None
+        pos = C.c_int64()
+        self.ctx.check(self.ctx.lib.msc_mean_nearest(self.ctx.h, points.h, _ptr(sl), m, C.byref(pos), _ptr(d), _ptr(mean)))
+        return pos.value, d, mean
+
+
+def mean_nearest(ctx, points, member_slots, m=None, want_mean=False):
+    return Trainer(ctx, None, 1.0).closest(points, member_slots, m, want_mean)
+
+
+class Predictor:
+    """Predictor::close / similarity (predict/Predictor.cpp:255-333) for one query against a database."""
+
+    def __init__(self, ctx, cls_feat, reg_feat=None):
+        self.ctx, self.cls, self.reg = ctx, cls_feat, reg_feat
+
+    @classmethod
+    def from_file(cls, ctx, path):
+        c = Feature.from_file(ctx, path, 0)
+        try:
+            r = Feature.from_file(ctx, path, 1)
+        except MscError:
+            r = None
+        return cls(ctx, c, r)
+
+    def search(self, db, db_slots, qset, q_slot, m=None):
+        sl, m = _slots(db_slots, m)
+        close = np.zeros(max(m, 1), dtype=np.uint8)
+        sim = np.zeros(max(m, 1)) if self.reg is not None else None
+        self.ctx.check(self.ctx.lib.msc_search(self.ctx.h, self.cls.h, self.reg.h if self.reg else None, db.h, _ptr(sl), m, qset.h, q_slot,
+                                               _ptr(close), _ptr(sim)))
+        return close[:m], (sim[:m] if sim is not None else None)

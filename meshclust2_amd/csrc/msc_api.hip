@@ -1,0 +1,1023 @@
+// msc_api.hip -- the C ABI of libmeshclust2_hip.so (include/meshclust2_hip.h) and the host logic behind it:
+// sequence encoding, 2-bit packing, weights-file parsing, launch sequencing, result read-back.
+// All compute on histograms happens in the gfx950 kernels (hist_build.hip, pair_features.hip); there is no CPU
+// fallback: without a usable HIP device msc_create() fails and nothing else can be called.
+#include <algorithm>
+#include <cctype>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "msc_internal.h"
+
+// ================================================================================================ objects
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+};
+
+struct msc_ctx {
+	int device = -1;
+	int num_cus = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
+	bool have_timing = false;
+	float tiles_ms_accum = 0.f;
+	std::string err;
+	char dev_name[128] = {0};
+	// growable device scratch
+	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
+	    floor_sum, mean;
+	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
+};
+
+struct msc_hist_set {
+	msc_ctx* ctx = nullptr;
+	int k = 0, dtype = 0;
+	uint64_t capacity = 0;
+	MscLayout L;
+	uint64_t scalar_stride = 0;
+	uint8_t* bins = nullptr;
+	uint8_t* scalars = nullptr;
+	// host-side bounds over every slot ever written (monotone; used to pick the kernels' integer range)
+	uint64_t max_count = 0, max_sum = 0;
+};
+
+struct msc_model {
+	msc_ctx* ctx = nullptr;
+	int k = 0;
+	MscDevModel h;
+	MscDevModel* d = nullptr;
+};
+
+static thread_local std::string g_create_error;
+
+// largest bin for which 32-bit per-lane partial sums of p*q cannot overflow: R * max^2 < 2^32 with R <= 64
+static const uint64_t kNarrowMaxCount = 8191;
+static const uint64_t kNarrowMaxSum = (1ull << 31) - 1;
+
+static int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (ctx) ctx->err = buf; else g_create_error = buf;
+	return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                 \
+	do {                                                                                                   \
+		hipError_t e_ = (expr);                                                                            \
+		if (e_ != hipSuccess)                                                                              \
+			return fail(ctx, e_ == hipErrorOutOfMemory ? MSC_ERR_OOM : MSC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+			            hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+	} while (0)
+
+static int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
+	if (bytes <= b.cap) return MSC_OK;
+	if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+	size_t cap = std::max<size_t>(bytes, 4096);
+	cap = (cap + 4095) / 4096 * 4096;
+	HIP_TRY(ctx, hipMalloc(&b.p, cap));
+	b.cap = cap;
+	return MSC_OK;
+}
+
+static void release(DevBuf& b) {
+	if (b.p) (void)hipFree(b.p);
+	b.p = nullptr;
+	b.cap = 0;
+}
+
+// ================================================================================================ context
+extern "C" int msc_abi_version(void) { return MSC_ABI_VERSION; }
+
+extern "C" int msc_create(int device, msc_ctx** out) {
+	if (!out) return fail(nullptr, MSC_ERR_INVALID_ARG, "msc_create: out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(nullptr, MSC_ERR_NO_DEVICE, "msc_create: no HIP device available (%s); this library has no CPU fallback",
+		            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	if (device < 0 || device >= n) return fail(nullptr, MSC_ERR_NO_DEVICE, "msc_create: device %d out of range (0..%d)", device, n - 1);
+	e = hipSetDevice(device);
+	if (e != hipSuccess) return fail(nullptr, MSC_ERR_NO_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess) return fail(nullptr, MSC_ERR_NO_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(nullptr, MSC_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+	msc_ctx* ctx = new msc_ctx();
+	ctx->device = device;
+	ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->num_cus);
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev_tiles0) != hipSuccess ||
+	    hipEventCreate(&ctx->ev_tiles1) != hipSuccess || hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess) {
+		delete ctx;
+		return fail(nullptr, MSC_ERR_HIP, "msc_create: stream/event creation failed");
+	}
+	*out = ctx;
+	return MSC_OK;
+}
+
+extern "C" void msc_destroy(msc_ctx* ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
+	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
+	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean};
+	for (DevBuf* b : bufs) release(*b);
+	(void)hipEventDestroy(ctx->ev_tiles0);
+	(void)hipEventDestroy(ctx->ev_tiles1);
+	(void)hipEventDestroy(ctx->ev_all0);
+	(void)hipEventDestroy(ctx->ev_all1);
+	(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" const char* msc_last_error(const msc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int msc_device_name(const msc_ctx* ctx, char* buf, size_t cap) {
+	if (!ctx || !buf || cap == 0) return MSC_ERR_INVALID_ARG;
+	snprintf(buf, cap, "%s", ctx->dev_name);
+	return MSC_OK;
+}
+
+extern "C" int msc_synchronize(msc_ctx* ctx) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_last_kernel_ms(const msc_ctx* ctx, float* tiles_ms, float* total_ms) {
+	if (!ctx || !ctx->have_timing) return MSC_ERR_INVALID_ARG;
+	if (tiles_ms) *tiles_ms = ctx->tiles_ms_accum;
+	if (total_ms) {
+		float t = 0;
+		if (hipEventElapsedTime(&t, ctx->ev_all0, ctx->ev_all1) != hipSuccess) return MSC_ERR_HIP;
+		*total_ms = t;
+	}
+	return MSC_OK;
+}
+
+// ================================================================================================ a1: encoding (host)
+// Restates Chromosome::help (nonltr/Chromosome.cpp:130-154): toUpperCase, removeAmbiguous (:263-291),
+// mergeSegments (:298-353, only when the sequence is longer than 20), makeSegmentList (:355-385, 1 Mb fragments),
+// then ChromosomeOneDigit::encode with the DNA code table (nonltr/ChromosomeOneDigit.cpp:79-133,
+// nonltr/ChromosomeOneDigitDna.cpp:48-68).
+namespace {
+
+struct Seg { int64_t s, e; };
+
+struct CodeTable {
+	int8_t t[256];
+	CodeTable() {
+		for (int i = 0; i < 256; i++) t[i] = -1;
+		const char* zero = "AMV"; const char* one = "CYHN"; const char* two = "GRSX"; const char* three = "TKWBD";
+		for (const char* p = zero; *p; p++) t[(unsigned char)*p] = 0;
+		for (const char* p = one; *p; p++) t[(unsigned char)*p] = 1;
+		for (const char* p = two; *p; p++) t[(unsigned char)*p] = 2;
+		for (const char* p = three; *p; p++) t[(unsigned char)*p] = 3;
+	}
+};
+const CodeTable kCodes;
+
+// returns false on a character outside the table
+bool encode_sequence(const char* seq, size_t len, std::vector<uint8_t>& codes, std::vector<Seg>& segs, uint64_t& eff_len) {
+	const int64_t n = (int64_t)len;
+	codes.resize(len);
+	for (int64_t i = 0; i < n; i++) codes[i] = (uint8_t)toupper((unsigned char)seq[i]);
+
+	// maximal runs of non-'N'. A run that begins on the very last character is dropped, exactly like the
+	// reference's if / else-if chain (the "start" branch and the "close at end" branch are exclusive).
+	std::vector<Seg> runs;
+	int64_t start = -1;
+	for (int64_t i = 0; i < n; i++) {
+		const bool is_n = codes[i] == 'N';
+		if (!is_n && start < 0) start = i;
+		else if (is_n && start >= 0) { runs.push_back({start, i - 1}); start = -1; }
+		else if (i == n - 1 && !is_n && start >= 0) { runs.push_back({start, i}); start = -1; }
+	}
+
+	// join runs separated by fewer than 10 positions, drop joined runs shorter than 20
+	if (n > 20 && !runs.empty()) {
+		std::vector<Seg> merged;
+		Seg cur = runs[0];
+		for (size_t i = 1; i < runs.size(); i++) {
+			if (runs[i].s - cur.e < 10) cur.e = runs[i].e;
+			else { if (cur.e - cur.s + 1 >= 20) merged.push_back(cur); cur = runs[i]; }
+		}
+		if (cur.e - cur.s + 1 >= 20) merged.push_back(cur);
+		runs.swap(merged);
+	}
+
+	// cut runs longer than 1,000,000 into floor(len/1e6) fragments, the last one taking the remainder
+	const int64_t frag = 1000000;
+	segs.clear();
+	for (const Seg& r : runs) {
+		const int64_t l = r.e - r.s + 1;
+		if (l > frag) {
+			const int64_t nf = l / frag;
+			for (int64_t h = 0; h < nf; h++) {
+				const int64_t fs = r.s + h * frag;
+				segs.push_back({fs, h == nf - 1 ? r.e : fs + frag - 1});
+			}
+		} else segs.push_back(r);
+	}
+	eff_len = 0;
+	for (const Seg& s : segs) eff_len += (uint64_t)(s.e - s.s + 1);
+
+	// digits inside segments (every char must map); outside segments everything but 'N' is mapped too and must be valid
+	std::vector<uint8_t> in_seg;   // cheap marker only when needed
+	size_t si = 0;
+	for (int64_t i = 0; i < n; i++) {
+		while (si < segs.size() && segs[si].e < i) si++;
+		const bool inside = si < segs.size() && segs[si].s <= i;
+		const uint8_t c = codes[i];
+		if (inside) {
+			const int8_t d = kCodes.t[c];
+			if (d < 0) return false;
+			codes[i] = (uint8_t)d;
+		} else if (c != 'N') {
+			if (segs.empty()) continue;           // the reference only walks the gaps when at least one segment exists
+			const int8_t d = kCodes.t[c];
+			if (d < 0) return false;
+			codes[i] = (uint8_t)d;
+		}
+	}
+	return true;
+}
+
+}  // namespace
+
+extern "C" int msc_encode(const char* seq, size_t len, uint8_t* codes_out, int64_t* segs_out, size_t max_segs, size_t* n_segs,
+                          uint64_t* eff_len) {
+	if (!seq && len) return MSC_ERR_INVALID_ARG;
+	std::vector<uint8_t> codes;
+	std::vector<Seg> segs;
+	uint64_t eff = 0;
+	if (!encode_sequence(seq, len, codes, segs, eff)) return MSC_ERR_INVALID_INPUT;
+	if (codes_out && len) memcpy(codes_out, codes.data(), len);
+	for (size_t i = 0; i < segs.size() && i < max_segs && segs_out; i++) { segs_out[2 * i] = segs[i].s; segs_out[2 * i + 1] = segs[i].e; }
+	if (n_segs) *n_segs = segs.size();
+	if (eff_len) *eff_len = eff;
+	return MSC_OK;
+}
+
+// ================================================================================================ histogram sets
+static bool valid_dtype(int d) { return d == 8 || d == 16 || d == 32 || d == 64; }
+
+extern "C" int msc_hist_set_create(msc_ctx* ctx, int k, int dtype, uint64_t capacity, msc_hist_set** out) {
+	if (!ctx || !out) return MSC_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (!valid_dtype(dtype)) return fail(ctx, MSC_ERR_INVALID_ARG, "dtype must be 8, 16, 32 or 64 (got %d)", dtype);
+	if (k < 1 || k > 13) return fail(ctx, MSC_ERR_UNSUPPORTED, "dense histograms support 1 <= k <= 13 (got %d)", k);
+	if (capacity == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "capacity must be > 0");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	msc_hist_set* s = new msc_hist_set();
+	s->ctx = ctx;
+	s->k = k;
+	s->dtype = dtype;
+	s->capacity = capacity;
+	s->L = msc_make_layout(k, dtype);
+	s->scalar_stride = msc_scalar_stride(s->L.S);
+	hipError_t e = hipMalloc((void**)&s->bins, s->L.slot_bytes * capacity);
+	if (e == hipSuccess) e = hipMalloc((void**)&s->scalars, s->scalar_stride * capacity);
+	if (e != hipSuccess) {
+		if (s->bins) (void)hipFree(s->bins);
+		delete s;
+		return fail(ctx, MSC_ERR_OOM, "hipMalloc of %llu slots x %llu bytes failed: %s", (unsigned long long)capacity,
+		            (unsigned long long)s->L.slot_bytes, hipGetErrorString(e));
+	}
+	e = hipMemsetAsync(s->scalars, 0, s->scalar_stride * capacity, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) { (void)hipFree(s->bins); (void)hipFree(s->scalars); delete s; return fail(ctx, MSC_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+	*out = s;
+	return MSC_OK;
+}
+
+extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
+	if (!s) return;
+	(void)hipSetDevice(s->ctx->device);
+	(void)hipStreamSynchronize(s->ctx->stream);
+	if (s->bins) (void)hipFree(s->bins);
+	if (s->scalars) (void)hipFree(s->scalars);
+	delete s;
+}
+
+extern "C" uint64_t msc_hist_set_capacity(const msc_hist_set* s) { return s ? s->capacity : 0; }
+extern "C" int msc_hist_set_k(const msc_hist_set* s) { return s ? s->k : 0; }
+extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype : 0; }
+extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) { return s ? (s->L.slot_bytes + s->scalar_stride) * s->capacity : 0; }
+
+// pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
+static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
+	std::vector<MscSlotScalars> h(n);
+	HIP_TRY(ctx, hipMemcpy2DAsync(h.data(), sizeof(MscSlotScalars), s->scalars + first * s->scalar_stride, s->scalar_stride,
+	                              sizeof(MscSlotScalars), n, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	for (const auto& r : h) {
+		s->max_count = std::max(s->max_count, r.max_count);
+		s->max_sum = std::max(s->max_sum, r.sum);
+	}
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const uint8_t* packed,
+                                     uint64_t n_bases, const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end,
+                                     uint64_t n_segs, const uint64_t* eff_len, const uint64_t* one_mers) {
+	if (!ctx || !set || set->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (first_slot + n_seqs > set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "slots %llu..%llu exceed capacity %llu",
+	                                                     (unsigned long long)first_slot, (unsigned long long)(first_slot + n_seqs), (unsigned long long)set->capacity);
+	if (n_seqs == 0) return MSC_OK;
+	if ((n_segs && (!seg_seq || !seg_start || !seg_end)) || !eff_len || (n_bases && !packed)) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL input array");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const int k = set->k;
+	const MscLayout& L = set->L;
+
+	// k-mer ordinal of each segment's first k-mer (segments shorter than k contribute none, clutil/Loader.cpp:53-54)
+	std::vector<uint64_t> koff(n_segs + 1, 0);
+	std::vector<uint64_t> kmers_per_seq(n_seqs, 0);
+	for (uint64_t j = 0; j < n_segs; j++) {
+		if (seg_seq[j] >= n_seqs || seg_end[j] < seg_start[j] || seg_end[j] >= n_bases)
+			return fail(ctx, MSC_ERR_INVALID_ARG, "segment %llu is malformed", (unsigned long long)j);
+		const uint64_t len = seg_end[j] - seg_start[j] + 1;
+		const uint64_t nk = len >= (uint64_t)k ? len - k + 1 : 0;
+		koff[j + 1] = koff[j] + nk;
+		kmers_per_seq[seg_seq[j]] += nk;
+	}
+	const uint64_t total_kmers = koff[n_segs];
+	uint64_t tmax = set->dtype == 64 ? ~0ull : ((1ull << set->dtype) - 1);
+	bool saturating = false;
+	for (uint64_t i = 0; i < n_seqs; i++) if (kmers_per_seq[i] >= tmax) saturating = true;
+
+	// scalar records: length, k=1 table, overflow cleared
+	std::vector<MscSlotScalars> sc(n_seqs);
+	memset(sc.data(), 0, sizeof(MscSlotScalars) * n_seqs);
+	for (uint64_t i = 0; i < n_seqs; i++) {
+		sc[i].length = eff_len[i];
+		for (int b = 0; b < 4; b++) sc[i].one_mers[b] = one_mers ? one_mers[4 * i + b] : 0;
+		sc[i].n_kmers = kmers_per_seq[i];
+	}
+	HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + first_slot * set->scalar_stride, set->scalar_stride, sc.data(), sizeof(MscSlotScalars),
+	                              sizeof(MscSlotScalars), n_seqs, hipMemcpyHostToDevice, ctx->stream));
+
+	// packed stream (+8 bytes so the kernel's 64-bit window never reads past the end)
+	const size_t packed_bytes = (size_t)((n_bases + 3) / 4);
+	const size_t padded_bytes = (packed_bytes + 3) / 4 * 4 + 8;
+	int r;
+	if ((r = ensure(ctx, ctx->packed, padded_bytes)) != MSC_OK) return r;
+	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + (padded_bytes - 12), 0, 12, ctx->stream));
+	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+	if (n_segs) {
+		if ((r = ensure(ctx, ctx->seg_seq, n_segs * sizeof(uint32_t))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->seg_start, n_segs * sizeof(uint64_t))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->kmer_off, (n_segs + 1) * sizeof(uint64_t))) != MSC_OK) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_seq.p, seg_seq, n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_start.p, seg_start, n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->kmer_off.p, koff.data(), (n_segs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	HIP_TRY(ctx, msc_launch_fill(ctx->stream, set->bins, L, first_slot, n_seqs));
+	HIP_TRY(ctx, msc_launch_count(ctx->stream, set->bins, set->scalars, L, k, set->dtype, first_slot, (const uint32_t*)ctx->packed.p,
+	                              (const uint32_t*)ctx->seg_seq.p, (const uint64_t*)ctx->seg_start.p, (const uint64_t*)ctx->kmer_off.p,
+	                              n_segs, total_kmers, saturating));
+	HIP_TRY(ctx, msc_launch_finalize(ctx->stream, set->bins, set->scalars, L, set->dtype, first_slot, n_seqs, false));
+	return refresh_bounds(ctx, set, first_slot, n_seqs);
+}
+
+extern "C" int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const char* const* seqs,
+                              const uint64_t* lens, int strip) {
+	if (!ctx || !set || set->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (n_seqs && (!seqs || !lens)) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL sequence array");
+	std::vector<uint8_t> packed;
+	std::vector<uint32_t> seg_seq;
+	std::vector<uint64_t> seg_start, seg_end, eff(n_seqs), ones(4 * n_seqs);
+	uint64_t n_bases = 0;
+	std::vector<uint8_t> codes;
+	std::vector<Seg> segs;
+	std::string stripped;
+	for (uint64_t i = 0; i < n_seqs; i++) {
+		const char* s = seqs[i];
+		size_t len = (size_t)lens[i];
+		if (strip) {       // Loader<T>::get_point(std::string...) keeps upper-case A/C/G/T only (clutil/Loader.cpp:115-121)
+			stripped.clear();
+			for (size_t j = 0; j < len; j++) { const char c = s[j]; if (c == 'A' || c == 'C' || c == 'G' || c == 'T') stripped.push_back(c); }
+			s = stripped.data();
+			len = stripped.size();
+		}
+		uint64_t e = 0;
+		if (!encode_sequence(s, len, codes, segs, e))
+			return fail(ctx, MSC_ERR_INVALID_INPUT, "sequence %llu holds a character outside the IUPAC nucleotide map", (unsigned long long)i);
+		eff[i] = e;
+		uint64_t om[4] = {1, 1, 1, 1};   // KmerHashTable<unsigned long,uint64_t> table_k1(1, 1), clutil/Loader.cpp:143
+		for (const Seg& sg : segs) {
+			for (int64_t p = sg.s; p <= sg.e; p++) om[codes[p] & 3]++;
+			seg_seq.push_back((uint32_t)i);
+			seg_start.push_back(n_bases + (uint64_t)sg.s);
+			seg_end.push_back(n_bases + (uint64_t)sg.e);
+		}
+		for (int b = 0; b < 4; b++) ones[4 * i + b] = om[b];
+		packed.resize((size_t)((n_bases + len + 3) / 4), 0);
+		for (size_t p = 0; p < len; p++) {
+			const uint64_t g = n_bases + p;
+			packed[g >> 2] |= (uint8_t)((codes[p] & 3) << (2 * (g & 3)));
+		}
+		n_bases += len;
+	}
+	return msc_hist_build_packed(ctx, set, first_slot, n_seqs, packed.data(), n_bases, seg_seq.data(), seg_start.data(), seg_end.data(),
+	                             seg_seq.size(), eff.data(), ones.data());
+}
+
+static int check_slot(msc_ctx* ctx, const msc_hist_set* s, uint64_t slot) {
+	if (!ctx || !s || s->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (slot >= s->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "slot %llu out of range (capacity %llu)", (unsigned long long)slot, (unsigned long long)s->capacity);
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_download(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, void* bins_out) {
+	int r = check_slot(ctx, set, slot);
+	if (r) return r;
+	if (!bins_out) return MSC_ERR_INVALID_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const MscLayout& L = set->L;
+	if ((r = ensure(ctx, ctx->nat, L.slot_bytes)) != MSC_OK) return r;
+	HIP_TRY(ctx, msc_launch_permute(ctx->stream, set->bins + slot * L.slot_bytes, ctx->nat.p, L, set->dtype, false));
+	HIP_TRY(ctx, hipMemcpyAsync(bins_out, ctx->nat.p, L.nbins * L.esz, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_upload(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, const void* bins, uint64_t length, const uint64_t* one_mers) {
+	int r = check_slot(ctx, set, slot);
+	if (r) return r;
+	if (!bins) return MSC_ERR_INVALID_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const MscLayout& L = set->L;
+	if ((r = ensure(ctx, ctx->nat, L.slot_bytes)) != MSC_OK) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->nat.p, bins, L.nbins * L.esz, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_permute(ctx->stream, ctx->nat.p, set->bins + slot * L.slot_bytes, L, set->dtype, true));
+	MscSlotScalars sc;
+	memset(&sc, 0, sizeof sc);
+	sc.length = length;
+	if (one_mers) for (int b = 0; b < 4; b++) sc.one_mers[b] = one_mers[b];
+	HIP_TRY(ctx, hipMemcpyAsync(set->scalars + slot * set->scalar_stride, &sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // sc is on the stack
+	HIP_TRY(ctx, msc_launch_finalize(ctx->stream, set->bins, set->scalars, L, set->dtype, slot, 1, false));
+	return refresh_bounds(ctx, set, slot, 1);
+}
+
+extern "C" int msc_hist_info_get(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, msc_hist_info* out) {
+	int r = check_slot(ctx, set, slot);
+	if (r) return r;
+	if (!out) return MSC_ERR_INVALID_ARG;
+	MscSlotScalars sc;
+	HIP_TRY(ctx, hipMemcpyAsync(&sc, set->scalars + slot * set->scalar_stride, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	out->mag = sc.mag; out->length = sc.length; out->sum = sc.sum; out->sum_sq = sc.sum_sq; out->max_count = sc.max_count;
+	for (int b = 0; b < 4; b++) out->one_mers[b] = sc.one_mers[b];
+	out->stddev = sc.stddev; out->overflow = (int32_t)(sc.overflow != 0); out->pad_ = 0; out->id = sc.id;
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_set_id(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, uint64_t id) {
+	int r = check_slot(ctx, set, slot);
+	if (r) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(set->scalars + slot * set->scalar_stride + offsetof(MscSlotScalars, id), &id, sizeof id, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+static int copy_common(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
+	int r = check_slot(ctx, dst, ds);
+	if (r) return r;
+	if ((r = check_slot(ctx, src, ss))) return r;
+	if (dst->k != src->k || dst->dtype != src->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k or dtype");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(dst->bins + ds * dst->L.slot_bytes, src->bins + ss * src->L.slot_bytes, src->L.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
+	int r = copy_common(ctx, dst, ds, src, ss);
+	if (r) return r;
+	uint8_t* d = dst->scalars + ds * dst->scalar_stride;
+	const uint8_t* s = src->scalars + ss * src->scalar_stride;
+	HIP_TRY(ctx, hipMemcpyAsync(d, s, dst->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
+	// the (pts, len) ctor re-sums mag from the bins (clutil/DivergencePoint.cpp:99-110)
+	HIP_TRY(ctx, hipMemcpyAsync(d + offsetof(MscSlotScalars, mag), s + offsetof(MscSlotScalars, sum), 8, hipMemcpyDeviceToDevice, ctx->stream));
+	return refresh_bounds(ctx, dst, ds, 1);
+}
+
+extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
+	int r = copy_common(ctx, dst, ds, src, ss);
+	if (r) return r;
+	uint8_t* d = dst->scalars + ds * dst->scalar_stride;
+	const uint8_t* s = src->scalars + ss * src->scalar_stride;
+	// points, length, id -- NOT mag, NOT stddev (clutil/DivergencePoint.cpp:182-190); the derived sums follow the bins
+	const size_t a0 = offsetof(MscSlotScalars, length), a1 = offsetof(MscSlotScalars, one_mers);
+	HIP_TRY(ctx, hipMemcpyAsync(d + a0, s + a0, a1 - a0, hipMemcpyDeviceToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(d + offsetof(MscSlotScalars, id), s + offsetof(MscSlotScalars, id), 8, hipMemcpyDeviceToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(d + sizeof(MscSlotScalars), s + sizeof(MscSlotScalars), 8ull * dst->L.S, hipMemcpyDeviceToDevice, ctx->stream));
+	return refresh_bounds(ctx, dst, ds, 1);
+}
+
+extern "C" int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slot_bytes, void** scalars, uint64_t* scalar_bytes) {
+	if (!set) return MSC_ERR_INVALID_ARG;
+	if (bins) *bins = set->bins;
+	if (slot_bytes) *slot_bytes = set->L.slot_bytes;
+	if (scalars) *scalars = set->scalars;
+	if (scalar_bytes) *scalar_bytes = set->scalar_stride;
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_import_done(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n) {
+	if (!ctx || !set || set->ctx != ctx || first_slot + n > set->capacity) return MSC_ERR_INVALID_ARG;
+	if (n == 0) return MSC_OK;
+	return refresh_bounds(ctx, set, first_slot, n);
+}
+
+// ================================================================================================ model
+static int feat_is_sim(uint64_t f) {      // Feature<T>::feat_is_sim, predict/Feature.cpp:549-663
+	switch (f) {
+	case MSC_FEAT_NORMALIZED_VECTORS: case MSC_FEAT_PEARSON_COEFF: case MSC_FEAT_INTERSECTION: case MSC_FEAT_KULCZYNSKI2: case MSC_FEAT_SIMRATIO:
+		return 1;
+	case MSC_FEAT_MANHATTAN: case MSC_FEAT_EUCLIDEAN: case MSC_FEAT_EMD: case MSC_FEAT_LENGTHD:
+		return 0;
+	default:
+		return -1;     // JEFFEREY_DIV / JENSEN_SHANNON: not yet on the GPU path; everything else is out of scope
+	}
+}
+
+static int model_index_of(const MscDevModel& m, uint64_t f) {
+	for (int i = 0; i < m.n_singles; i++) if (m.single_flag[i] == f) return i;
+	return -1;
+}
+
+extern "C" int msc_model_create(msc_ctx* ctx, int k, int n_combos, const int* combo_kind, const uint64_t* combo_flags, const double* weights,
+                                int n_singles, const uint64_t* single_flags, const double* mins, const double* maxs, double bias,
+                                msc_model** out) {
+	if (!ctx || !out) return MSC_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (n_combos < 0 || n_combos > MSC_MAX_COMBOS) return fail(ctx, MSC_ERR_UNSUPPORTED, "n_combos %d exceeds %d", n_combos, MSC_MAX_COMBOS);
+	if ((n_combos && (!combo_kind || !combo_flags)) || !weights || (n_singles && (!single_flags || !mins || !maxs))) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL model array");
+	MscDevModel h;
+	memset(&h, 0, sizeof h);
+	h.bias = bias;
+	h.weights[0] = weights[0];
+	// replay Feature::add_feature (predict/Feature.cpp:102-128): singles in ascending-bit order of first appearance
+	for (int c = 0; c < n_combos; c++) {
+		if (combo_kind[c] < 0 || combo_kind[c] > 3) return fail(ctx, MSC_ERR_INVALID_ARG, "combo %d has kind %d", c, combo_kind[c]);
+		h.combo_kind[c] = combo_kind[c];
+		h.weights[c + 1] = weights[c + 1];
+		int n = 0;
+		for (uint64_t f = 1; f != 0 && f <= combo_flags[c]; f <<= 1) {
+			if (!(combo_flags[c] & f)) continue;
+			if (model_index_of(h, f) < 0) {
+				const int sim = feat_is_sim(f);
+				if (sim < 0) return fail(ctx, MSC_ERR_UNSUPPORTED, "single feature 2^%d is not supported by the GPU path", (int)log2((double)f));
+				if (h.n_singles >= MSC_MAX_SINGLES) return fail(ctx, MSC_ERR_UNSUPPORTED, "too many single features");
+				const int i = h.n_singles++;
+				h.single_flag[i] = f;
+				h.mins[i] = DBL_MAX;
+				h.maxs[i] = DBL_MIN;
+				h.is_sim[i] = sim;
+			}
+			if (n >= 2) return fail(ctx, MSC_ERR_UNSUPPORTED, "combo %d joins more than two single features", c);
+			h.combo_idx[c][n++] = model_index_of(h, f);
+		}
+		if (n == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "combo %d has no feature bits", c);
+		if (n == 1 && (combo_kind[c] == MSC_COMBO_XY2 || combo_kind[c] == MSC_COMBO_X2Y))
+			return fail(ctx, MSC_ERR_INVALID_ARG, "combo %d: xy2/x2y need two features (Feature.h:220-233 throws)", c);
+		h.combo_n[c] = n;
+	}
+	h.n_combos = n_combos;
+	for (int i = 0; i < n_singles; i++) {       // Feature::set_normal, predict/Feature.cpp:173-180
+		const int idx = model_index_of(h, single_flags[i]);
+		if (idx < 0) return fail(ctx, MSC_ERR_INVALID_ARG, "n_singles line for feature %llu that no combo uses", (unsigned long long)single_flags[i]);
+		h.mins[idx] = mins[i];
+		h.maxs[idx] = maxs[i];
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	msc_model* m = new msc_model();
+	m->ctx = ctx;
+	m->k = k;
+	m->h = h;
+	hipError_t e = hipMalloc((void**)&m->d, sizeof(MscDevModel));
+	if (e == hipSuccess) e = hipMemcpy(m->d, &m->h, sizeof(MscDevModel), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { delete m; return fail(ctx, MSC_ERR_HIP, "model upload: %s", hipGetErrorString(e)); }
+	*out = m;
+	return MSC_OK;
+}
+
+// Predictor<T>::Predictor(filename) + read_from, predict/Predictor.cpp:47-79,125-185 (`in >> token` semantics)
+extern "C" int msc_model_parse(msc_ctx* ctx, const char* text, int block, msc_model** out) {
+	if (!ctx || !text || !out) return MSC_ERR_INVALID_ARG;
+	std::istringstream in(text);
+	std::string buf, datatype;
+	int k = 0, max_feat = 0;
+	unsigned mode = 0;
+	double id = 0;
+	uint64_t feats = 0;
+	in >> buf >> k >> buf >> mode >> buf >> max_feat >> buf >> id >> buf >> datatype >> buf >> feats;
+	if (!in) return fail(ctx, MSC_ERR_IO, "weights file: malformed header");
+	const bool want_reg = block == 1;
+	if (want_reg && !(mode & 2)) return fail(ctx, MSC_ERR_INVALID_ARG, "weights file has no regression block (mode %u)", mode);
+	if (!want_reg && !(mode & 1)) return fail(ctx, MSC_ERR_INVALID_ARG, "weights file has no classification block (mode %u)", mode);
+	const int skip = (want_reg && (mode & 1)) ? 1 : 0;
+	for (int b = 0; b <= skip; b++) {
+		int nc = 0, ns = 0;
+		in >> buf >> nc;
+		if (!in || nc < 0 || nc > 64) return fail(ctx, MSC_ERR_IO, "weights file: bad n_combos");
+		std::vector<int> kinds(nc);
+		std::vector<uint64_t> flags(nc);
+		std::vector<double> w(nc + 1);
+		in >> w[0];
+		for (int i = 0; i < nc; i++) in >> kinds[i] >> flags[i] >> w[i + 1];
+		in >> buf >> ns;
+		if (!in || ns < 0 || ns > 64) return fail(ctx, MSC_ERR_IO, "weights file: bad n_singles");
+		std::vector<uint64_t> sf(ns);
+		std::vector<double> mn(ns), mx(ns);
+		for (int i = 0; i < ns; i++) in >> sf[i] >> mn[i] >> mx[i];
+		if (!in) return fail(ctx, MSC_ERR_IO, "weights file: truncated block");
+		if (b == skip) return msc_model_create(ctx, k, nc, kinds.data(), flags.data(), w.data(), ns, sf.data(), mn.data(), mx.data(), 0.0, out);
+	}
+	return MSC_ERR_IO;
+}
+
+extern "C" int msc_model_load(msc_ctx* ctx, const char* path, int block, msc_model** out) {
+	if (!ctx || !path || !out) return MSC_ERR_INVALID_ARG;
+	std::ifstream f(path);
+	if (!f) return fail(ctx, MSC_ERR_IO, "cannot open %s", path);
+	std::stringstream ss;
+	ss << f.rdbuf();
+	return msc_model_parse(ctx, ss.str().c_str(), block, out);
+}
+
+extern "C" void msc_model_destroy(msc_model* m) {
+	if (!m) return;
+	if (m->d) (void)hipFree(m->d);
+	delete m;
+}
+extern "C" int msc_model_k(const msc_model* m) { return m ? m->k : 0; }
+extern "C" int msc_model_n_singles(const msc_model* m) { return m ? m->h.n_singles : 0; }
+extern "C" int msc_model_n_combos(const msc_model* m) { return m ? m->h.n_combos : 0; }
+extern "C" int msc_model_single_flags(const msc_model* m, uint64_t* out) {
+	if (!m || !out) return MSC_ERR_INVALID_ARG;
+	for (int i = 0; i < m->h.n_singles; i++) out[i] = m->h.single_flag[i];
+	return MSC_OK;
+}
+extern "C" void msc_model_set_bias(msc_model* m, double bias) {
+	if (!m) return;
+	m->h.bias = bias;
+	(void)hipMemcpy(m->d, &m->h, sizeof(MscDevModel), hipMemcpyHostToDevice);
+}
+
+// ================================================================================================ scoring driver
+namespace {
+
+struct ScoreRequest {
+	const msc_model* model = nullptr;
+	const msc_hist_set* cands = nullptr;
+	const uint32_t* cand_slots = nullptr;   // host
+	uint64_t m = 0;
+	const msc_hist_set* qset = nullptr;
+	uint64_t q_slot = 0;
+	int order = MSC_ORDER_CAND_FIRST;
+	int use_window = 0;
+	uint64_t min_len = 0, max_len = 0;
+	uint64_t feat_mask = 0;
+	// host outputs (nullable)
+	double* raw_out = nullptr;
+	double* singles_out = nullptr;
+	double* combos_out = nullptr;
+	double* sum_out = nullptr;
+	double* csum_out = nullptr;
+	double* combo0_out = nullptr;
+	int32_t* status_out = nullptr;
+	uint8_t* flags_out = nullptr;
+	int reduce_mode = -1;                   // <0: no reduce kernel
+	int64_t reduce_begin = 0;
+	MscReduceOut* reduce_host = nullptr;
+	bool only_tiles = false;                // msc_mean_nearest reuses the streaming kernel and folds partials itself
+};
+
+int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* qset, uint64_t q_slot, const uint32_t* slots, uint64_t m) {
+	if (!ctx || !cands || !qset || cands->ctx != ctx || qset->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (cands->k != qset->k || cands->dtype != qset->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "query and candidate sets differ in k or dtype");
+	if (q_slot >= qset->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "query slot out of range");
+	if (m > 0xfffffff0ull) return fail(ctx, MSC_ERR_INVALID_ARG, "too many candidates in one call");
+	if (slots) { for (uint64_t i = 0; i < m; i++) if (slots[i] >= cands->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "candidate slot %u out of range", slots[i]); }
+	else if (m > cands->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "m exceeds capacity");
+	// integer range of the streaming kernel (see pair_features.hip header)
+	const uint64_t mc = std::max(cands->max_count, qset->max_count), ms = std::max(cands->max_sum, qset->max_sum);
+	if (mc > kNarrowMaxCount || ms > kNarrowMaxSum)
+		return fail(ctx, MSC_ERR_UNSUPPORTED, "histogram counts up to %llu / sums up to %llu exceed the 32-bit streaming path (limits %llu / %llu)",
+		            (unsigned long long)mc, (unsigned long long)ms, (unsigned long long)kNarrowMaxCount, (unsigned long long)kNarrowMaxSum);
+	return MSC_OK;
+}
+
+// Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
+int run_score(msc_ctx* ctx, ScoreRequest& rq) {
+	int r = validate_pair(ctx, rq.cands, rq.qset, rq.q_slot, rq.cand_slots, rq.m);
+	if (r) return r;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const msc_hist_set* cs = rq.cands;
+	const MscLayout& L = cs->L;
+	const uint64_t m = rq.m;
+	const int nf = __builtin_popcountll(rq.feat_mask);
+	const int ns = rq.model ? rq.model->h.n_singles : 0;
+	const int nc = rq.model ? rq.model->h.n_combos : 0;
+	ctx->tiles_ms_accum = 0.f;
+	ctx->have_timing = false;
+	if (m == 0) {
+		if (rq.reduce_host) { rq.reduce_host->best_pos = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1 : 0; rq.reduce_host->best_sim = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1.0 : DBL_MIN;
+		                      rq.reduce_host->any_close = 0; rq.reduce_host->n_close = 0; rq.reduce_host->first_error = 0; }
+		return MSC_OK;
+	}
+	uint64_t chunk = (256ull << 20) / ((uint64_t)L.S * sizeof(MscPartial));
+	chunk = std::max<uint64_t>(chunk, 1024);
+	if (rq.reduce_mode >= 0 || rq.only_tiles) chunk = m;      // reductions run over the whole window in one piece
+	chunk = std::min(chunk, m);
+
+	if ((r = ensure(ctx, ctx->partials, chunk * L.S * sizeof(MscPartial))) != MSC_OK) return r;
+	if (rq.cand_slots) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t))) != MSC_OK) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, rq.cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	if (!rq.only_tiles) {
+		if ((r = ensure(ctx, ctx->pair_out, chunk * sizeof(MscPairOut))) != MSC_OK) return r;
+		if (rq.raw_out && (r = ensure(ctx, ctx->raw, chunk * nf * sizeof(double))) != MSC_OK) return r;
+		if (rq.singles_out && (r = ensure(ctx, ctx->singles, chunk * ns * sizeof(double))) != MSC_OK) return r;
+		if (rq.combos_out && (r = ensure(ctx, ctx->combos, chunk * nc * sizeof(double))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->flags, chunk)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut))) != MSC_OK) return r;
+	}
+	const uint8_t* q_bins = rq.qset->bins + rq.q_slot * rq.qset->L.slot_bytes;
+	const uint8_t* q_scal = rq.qset->scalars + rq.q_slot * rq.qset->scalar_stride;
+	std::vector<MscPairOut> po_host;
+	int first_err = 0;
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+	for (uint64_t off = 0; off < m; off += chunk) {
+		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
+		const uint32_t* d_slots = rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
+		const uint8_t* c_bins = cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
+		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		HIP_TRY(ctx, msc_launch_pair_tiles(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
+		                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (rq.only_tiles) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+			break;
+		}
+		MscEpilogueArgs ea;
+		memset(&ea, 0, sizeof ea);
+		ea.partials = (const MscPartial*)ctx->partials.p;
+		ea.S = L.S;
+		ea.m = mc;
+		ea.cand_scalars = c_scal;
+		ea.cand_scalar_stride = cs->scalar_stride;
+		ea.cand_slots = d_slots;
+		ea.q_scalars = q_scal;
+		ea.nbins = L.nbins;
+		ea.dtype = cs->dtype;
+		ea.order = rq.order;
+		ea.use_window = rq.use_window;
+		ea.min_len = rq.min_len;
+		ea.max_len = rq.max_len;
+		ea.feat_mask = rq.feat_mask;
+		ea.raw_out = rq.raw_out ? (double*)ctx->raw.p : nullptr;
+		ea.model = rq.model ? rq.model->d : nullptr;
+		ea.singles_out = rq.singles_out ? (double*)ctx->singles.p : nullptr;
+		ea.combos_out = rq.combos_out ? (double*)ctx->combos.p : nullptr;
+		ea.pair_out = (MscPairOut*)ctx->pair_out.p;
+		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		if (rq.reduce_mode >= 0) {
+			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
+			                               (uint8_t*)ctx->flags.p, (MscReduceOut*)ctx->reduce_out.p));
+			HIP_TRY(ctx, hipMemcpyAsync(rq.reduce_host, ctx->reduce_out.p, sizeof(MscReduceOut), hipMemcpyDeviceToHost, ctx->stream));
+			if (rq.flags_out) HIP_TRY(ctx, hipMemcpyAsync(rq.flags_out, ctx->flags.p, mc, hipMemcpyDeviceToHost, ctx->stream));
+		}
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		if (rq.singles_out) HIP_TRY(ctx, hipMemcpyAsync(rq.singles_out + off * ns, ctx->singles.p, (size_t)mc * ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		if (rq.combos_out) HIP_TRY(ctx, hipMemcpyAsync(rq.combos_out + off * nc, ctx->combos.p, (size_t)mc * nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		const bool need_po = rq.sum_out || rq.csum_out || rq.combo0_out || rq.status_out || (rq.flags_out && rq.reduce_mode < 0) || rq.reduce_mode < 0;
+		if (need_po) {
+			po_host.resize(mc);
+			HIP_TRY(ctx, hipMemcpyAsync(po_host.data(), ctx->pair_out.p, (size_t)mc * sizeof(MscPairOut), hipMemcpyDeviceToHost, ctx->stream));
+		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		float t = 0;
+		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->have_timing = true; }
+		if (need_po) {
+			for (uint32_t i = 0; i < mc; i++) {
+				const MscPairOut& p = po_host[i];
+				if (rq.sum_out) rq.sum_out[off + i] = p.sum;
+				if (rq.csum_out) rq.csum_out[off + i] = p.csum;
+				if (rq.combo0_out) rq.combo0_out[off + i] = p.combo0;
+				if (rq.status_out) rq.status_out[off + i] = p.status;
+				if (rq.flags_out && rq.reduce_mode < 0) rq.flags_out[off + i] = (p.status == 0 && p.close) ? 1 : 0;
+				if (p.status < 0 && p.status < first_err) first_err = p.status;
+			}
+		}
+	}
+	if (rq.only_tiles) return MSC_OK;
+	if (rq.reduce_host && rq.reduce_host->first_error < first_err) first_err = rq.reduce_host->first_error;
+	if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+	if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+	if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+	return MSC_OK;
+}
+
+const uint64_t kSupportedFeats = MSC_FEAT_FAST;
+
+double trainer_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }      // cluster/Trainer.h:35
+
+}  // namespace
+
+extern "C" int msc_pair_features_raw(msc_ctx* ctx, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m, const msc_hist_set* qset,
+                                     uint64_t q_slot, int order, uint64_t feat_mask, double* raw_out) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	if (!raw_out && m) return fail(ctx, MSC_ERR_INVALID_ARG, "raw_out is NULL");
+	if (feat_mask == 0 || (feat_mask & ~kSupportedFeats))
+		return fail(ctx, MSC_ERR_UNSUPPORTED, "feat_mask 0x%llx holds statistics outside the GPU path (supported 0x%llx)", (unsigned long long)feat_mask,
+		            (unsigned long long)kSupportedFeats);
+	ScoreRequest rq;
+	rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot; rq.order = order;
+	rq.feat_mask = feat_mask; rq.raw_out = raw_out;
+	return run_score(ctx, rq);
+}
+
+extern "C" int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                         const msc_hist_set* qset, uint64_t q_slot, int order, double* singles_out, double* combos_out, double* sum_out,
+                         double* csum_out) {
+	if (!ctx || !model || model->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	ScoreRequest rq;
+	rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot; rq.order = order;
+	rq.singles_out = singles_out; rq.combos_out = combos_out; rq.sum_out = sum_out; rq.csum_out = csum_out;
+	return run_score(ctx, rq);
+}
+
+extern "C" int msc_get_close(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* cands, const uint32_t* cand_slots,
+                             uint64_t m, const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_flags, int64_t* best_pos, double* best_sim,
+                             int* is_min) {
+	if (!ctx || !model || model->ctx != ctx || !qset) return MSC_ERR_INVALID_ARG;
+	if (m && !close_flags) return fail(ctx, MSC_ERR_INVALID_ARG, "close_flags is NULL");
+	int r = check_slot(ctx, qset, q_slot);
+	if (r) return r;
+	msc_hist_info qi;
+	if ((r = msc_hist_info_get(ctx, qset, q_slot, &qi))) return r;
+	ScoreRequest rq;
+	rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot;
+	rq.order = MSC_ORDER_CAND_FIRST;                              // feat->compute(*pt, *p), cluster/Trainer.cpp:49
+	rq.use_window = 1;
+	rq.min_len = (uint64_t)((double)qi.length * cutoff);          // uint64_t min_len = p->get_length() * cutoff;  :39
+	rq.max_len = (uint64_t)((double)qi.length / cutoff);          // uint64_t max_len = p->get_length() / cutoff;  :40
+	rq.flags_out = close_flags;
+	rq.reduce_mode = MSC_REDUCE_GET_CLOSE;
+	MscReduceOut ro;
+	memset(&ro, 0, sizeof ro);
+	rq.reduce_host = &ro;
+	if ((r = run_score(ctx, rq))) return r;
+	if (best_pos) *best_pos = ro.best_pos;
+	if (best_sim) *best_sim = ro.best_sim;
+	if (is_min) *is_min = ro.any_close ? 0 : 1;
+	return MSC_OK;
+}
+
+extern "C" int msc_filter(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centre_set, uint64_t centre_slot,
+                          const msc_hist_set* pts, const uint32_t* pt_slots, uint64_t m, uint8_t* keep, uint64_t* n_kept) {
+	if (!ctx || !model || model->ctx != ctx || !centre_set) return MSC_ERR_INVALID_ARG;
+	if (m && !keep) return fail(ctx, MSC_ERR_INVALID_ARG, "keep is NULL");
+	int r = check_slot(ctx, centre_set, centre_slot);
+	if (r) return r;
+	msc_hist_info ci;
+	if ((r = msc_hist_info_get(ctx, centre_set, centre_slot, &ci))) return r;
+	ScoreRequest rq;
+	rq.model = model; rq.cands = pts; rq.cand_slots = pt_slots; rq.m = m; rq.qset = centre_set; rq.q_slot = centre_slot;
+	rq.order = MSC_ORDER_QUERY_FIRST;                             // classify(p, pt.first), cluster/Trainer.cpp:133
+	rq.use_window = 1;
+	rq.min_len = (uint64_t)((double)ci.length * trainer_get_id(cutoff));      // :126-127
+	rq.max_len = (uint64_t)((double)ci.length / trainer_get_id(cutoff));
+	rq.flags_out = keep;                                          // kept  <=>  in window && round(classify) != 0
+	if ((r = run_score(ctx, rq))) return r;
+	if (n_kept) { uint64_t n = 0; for (uint64_t i = 0; i < m; i++) n += keep[i]; *n_kept = n; }
+	return MSC_OK;
+}
+
+extern "C" int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                         uint64_t n, int64_t current, int64_t begin, int64_t last, int64_t* best_out) {
+	if (!ctx || !model || model->ctx != ctx || !centres || !best_out) return MSC_ERR_INVALID_ARG;
+	if (current < 0 || (uint64_t)current >= n) return fail(ctx, MSC_ERR_INVALID_ARG, "current out of range");
+	*best_out = 0;
+	if (begin > last) return MSC_OK;
+	if (begin < 0 || (uint64_t)last >= n) return fail(ctx, MSC_ERR_INVALID_ARG, "[begin,last] out of range");
+	const uint64_t cur_slot = centre_slots ? centre_slots[current] : (uint64_t)current;
+	int r = check_slot(ctx, centres, cur_slot);
+	if (r) return r;
+	msc_hist_info ci;
+	if ((r = msc_hist_info_get(ctx, centres, cur_slot, &ci))) return r;
+	std::vector<uint32_t> slots((size_t)(last - begin + 1));
+	for (int64_t i = begin; i <= last; i++) slots[(size_t)(i - begin)] = centre_slots ? centre_slots[i] : (uint32_t)i;
+	std::vector<uint8_t> flags(slots.size());
+	ScoreRequest rq;
+	rq.model = model; rq.cands = centres; rq.cand_slots = slots.data(); rq.m = slots.size(); rq.qset = centres; rq.q_slot = cur_slot;
+	rq.order = MSC_ORDER_CAND_FIRST;                              // feat->compute(*cen, *p), cluster/Trainer.cpp:93
+	rq.use_window = 1;
+	rq.min_len = (uint64_t)((double)ci.length * trainer_get_id(cutoff));
+	rq.max_len = (uint64_t)((double)ci.length / trainer_get_id(cutoff));
+	rq.flags_out = flags.data();
+	rq.reduce_mode = MSC_REDUCE_MERGE;
+	rq.reduce_begin = begin;
+	MscReduceOut ro;
+	memset(&ro, 0, sizeof ro);
+	rq.reduce_host = &ro;
+	if ((r = run_score(ctx, rq))) return r;
+	*best_out = ro.best_pos;
+	return MSC_OK;
+}
+
+extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg, const msc_hist_set* db, const uint32_t* db_slots,
+                          uint64_t m, const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_out, double* sim_out) {
+	if (!ctx || !cls || cls->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	// pred->close(pts[i], query) then pred->similarity(pts[i], query): fastcar/FC_Runner.cpp:449-455
+	ScoreRequest a;
+	a.model = cls; a.cands = db; a.cand_slots = db_slots; a.m = m; a.qset = qset; a.q_slot = q_slot; a.order = MSC_ORDER_CAND_FIRST;
+	a.flags_out = close_out;
+	int r = run_score(ctx, a);
+	if (r) return r;
+	if (reg && sim_out) {
+		ScoreRequest b;
+		b.model = reg; b.cands = db; b.cand_slots = db_slots; b.m = m; b.qset = qset; b.q_slot = q_slot; b.order = MSC_ORDER_CAND_FIRST;
+		b.sum_out = sim_out;
+		if ((r = run_score(ctx, b))) return r;
+		for (uint64_t i = 0; i < m; i++) {           // p_predict clamps to [0,1], predict/Predictor.cpp:293-298
+			if (sim_out[i] < 0) sim_out[i] = 0; else if (sim_out[i] > 1) sim_out[i] = 1;
+		}
+	}
+	return MSC_OK;
+}
+
+// ================================================================================================ mean + nearest
+extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, int64_t* nearest_pos,
+                                double* dist_out, double* mean_out) {
+	if (!ctx || !set || set->ctx != ctx || !nearest_pos) return MSC_ERR_INVALID_ARG;
+	if (m == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "N cannot be 0 (cluster/ClusterFactory.cpp:346-348 throws)");
+	if (m > 0xfffffff0ull) return MSC_ERR_INVALID_ARG;
+	if (member_slots) { for (uint64_t i = 0; i < m; i++) if (member_slots[i] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "member slot out of range"); }
+	else if (m > set->capacity) return MSC_ERR_INVALID_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int r;
+	if (!ctx->scratch_set || ctx->scratch_set->k != set->k || ctx->scratch_set->dtype != set->dtype) {
+		if (ctx->scratch_set) { msc_hist_set_destroy(ctx->scratch_set); ctx->scratch_set = nullptr; }
+		if ((r = msc_hist_set_create(ctx, set->k, set->dtype, 1, &ctx->scratch_set))) return r;
+	}
+	msc_hist_set* rs = ctx->scratch_set;
+	const MscLayout& L = set->L;
+	if ((r = ensure(ctx, ctx->floor_sum, 8))) return r;
+	if (mean_out && (r = ensure(ctx, ctx->mean, L.padded_bins * sizeof(double)))) return r;
+	if (member_slots) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, member_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	const uint32_t* d_slots = member_slots ? (const uint32_t*)ctx->slots.p : nullptr;
+	HIP_TRY(ctx, msc_launch_colsum(ctx->stream, L, set->dtype, set->bins, d_slots, (uint32_t)m, rs->bins, mean_out ? (double*)ctx->mean.p : nullptr,
+	                               (uint64_t*)ctx->floor_sum.p, nullptr));
+	HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, sizeof(MscSlotScalars), ctx->stream));
+	HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, set->dtype, 0, 1, false));
+	if ((r = refresh_bounds(ctx, rs, 0, 1))) return r;
+	// members vs the rounded mean through the streaming kernel (only the |p - r| reduction is used)
+	ScoreRequest rq;
+	rq.cands = set; rq.cand_slots = member_slots; rq.m = m; rq.qset = rs; rq.q_slot = 0; rq.only_tiles = true;
+	if ((r = run_score(ctx, rq))) return r;
+	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
+	if (dist_out && (r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
+	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
+	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, dist_out ? (double*)ctx->raw.p : nullptr,
+	                                   (MscReduceOut*)ctx->reduce_out.p));
+	MscReduceOut ro;
+	HIP_TRY(ctx, hipMemcpyAsync(&ro, ctx->reduce_out.p, sizeof ro, hipMemcpyDeviceToHost, ctx->stream));
+	if (dist_out) HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->raw.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	if (mean_out) {
+		if ((r = ensure(ctx, ctx->nat, L.padded_bins * sizeof(double)))) return r;
+		MscLayout L64 = L;       // move 8-byte elements through the same bin permutation
+		HIP_TRY(ctx, msc_launch_permute(ctx->stream, ctx->mean.p, ctx->nat.p, L64, 64, false));
+		HIP_TRY(ctx, hipMemcpyAsync(mean_out, ctx->nat.p, L.nbins * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	float t = 0;
+	if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->have_timing = true; }
+	*nearest_pos = ro.best_pos;
+	return MSC_OK;
+}

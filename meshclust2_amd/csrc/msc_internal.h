@@ -1,0 +1,101 @@
+// msc_internal.h -- declarations shared between the C-ABI translation unit and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/meshclust2_hip.h"
+#include "msc_layout.h"
+
+// ---------------------------------------------------------------- model, as the epilogue kernel sees it
+struct MscDevModel {
+	int32_t  n_singles;
+	int32_t  n_combos;
+	uint64_t single_flag[MSC_MAX_SINGLES];
+	double   mins[MSC_MAX_SINGLES];
+	double   maxs[MSC_MAX_SINGLES];
+	int32_t  is_sim[MSC_MAX_SINGLES];
+	int32_t  combo_kind[MSC_MAX_COMBOS];
+	int32_t  combo_n[MSC_MAX_COMBOS];
+	int32_t  combo_idx[MSC_MAX_COMBOS][2];
+	double   weights[MSC_MAX_COMBOS + 1];
+	double   bias;
+};
+
+// One partial record per (candidate, tile): integer reductions of the streaming pass.
+struct MscPartial {
+	uint64_t manh;   // sum |p - q|
+	uint64_t dot;    // sum p * q
+	uint64_t emd;    // sum |prefix(p) - prefix(q)|
+};
+
+// Per-candidate result of the epilogue kernel.
+struct MscPairOut {
+	double  sum;       // weighted sum s
+	double  csum;      // logistic(s) + bias
+	double  combo0;    // first combo ("similarity" used for the arg-max)
+	int32_t status;    // 0 ok, 1 skipped by the length window, MSC_ERR_* (negative) if the reference would throw
+	int32_t close;     // round(csum) > 0
+};
+
+struct MscReduceOut {
+	double  best_sim;
+	int64_t best_pos;
+	int32_t any_close;
+	int32_t first_error;   // most negative status seen (0 if none)
+	uint64_t n_close;
+};
+
+enum { MSC_REDUCE_GET_CLOSE = 0, MSC_REDUCE_MERGE = 1 };
+
+// epilogue request
+struct MscEpilogueArgs {
+	const MscPartial* partials;       // [m][S]
+	uint32_t S;
+	uint32_t m;
+	const uint8_t* cand_scalars;      // scalar records of the candidate set
+	uint64_t cand_scalar_stride;
+	const uint32_t* cand_slots;       // nullable -> identity
+	const uint8_t* q_scalars;         // scalar record of the query (already offset to its slot)
+	uint64_t nbins;
+	int32_t  dtype;
+	int32_t  order;                   // MSC_ORDER_*
+	int32_t  use_window;              // skip candidates outside [min_len, max_len]
+	uint64_t min_len, max_len;
+	// raw feature output
+	uint64_t feat_mask;               // bits to emit in ascending order
+	double*  raw_out;                 // [m][popcount(feat_mask)] or null
+	// model output
+	const MscDevModel* model;         // device pointer or null
+	double*  singles_out;             // [m][n_singles] or null
+	double*  combos_out;              // [m][n_combos] or null
+	MscPairOut* pair_out;             // [m] or null
+};
+
+// ---------------------------------------------------------------- launchers (defined in the .hip kernel files)
+hipError_t msc_launch_fill(hipStream_t st, void* bins, const MscLayout& L, uint64_t first_slot, uint64_t n_slots);
+hipError_t msc_launch_count(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype,
+                            uint64_t first_slot, const uint32_t* packed_words, const uint32_t* seg_seq,
+                            const uint64_t* seg_start, const uint64_t* kmer_off, uint64_t n_segs,
+                            uint64_t total_kmers, bool saturating);
+hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,
+                               uint64_t first_slot, uint64_t n_slots, bool keep_mag);
+hipError_t msc_launch_permute(hipStream_t st, const void* src, void* dst, const MscLayout& L, int dtype, bool to_physical);
+
+hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype,
+                                 const uint8_t* cand_bins, const uint8_t* cand_scalars, const uint32_t* cand_slots,
+                                 uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
+                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials,
+                                 int num_cus);
+hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
+hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
+                             uint8_t* flags_out, MscReduceOut* out);
+
+hipError_t msc_launch_colsum(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins,
+                             const uint32_t* member_slots, uint32_t m, void* rounded_out /*T, physical*/,
+                             double* mean_out /*physical, nullable*/, uint64_t* floor_sum_out, uint64_t* scratch);
+hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t m,
+                                 const uint8_t* scalars, uint64_t scalar_stride, const uint32_t* member_slots,
+                                 const uint8_t* r_scalars, const uint64_t* floor_sum, double* dist_out,
+                                 MscReduceOut* out);

@@ -1,0 +1,580 @@
+// pair_features.hip -- the pairwise-statistics kernels (1 query x m candidates), gfx950.
+//
+// Replaces Feature<T>::compute_all_raw and the raw statistics it calls (predict/Feature.cpp:156-171 and
+// :682-695,764-777,795-811,829-841,859-871,1113-1124,1171-1184,1505-1518), normalize_cache (:137-154),
+// Feature::operator() (predict/Feature.h:205-239), Trainer::classify (cluster/Trainer.cpp:112-120) and the
+// pmax / && reductions of Trainer::get_close (cluster/Trainer.cpp:41-64).
+//
+// The reference makes one full pass over both histograms PER statistic (9-11 passes, twice per get_close
+// pair). Here ONE streaming pass produces three integer reductions per (candidate, tile):
+//     manh = sum |p-q|      dot = sum p*q      emd = sum |prefix(p) - prefix(q)|
+// and every in-scope statistic is a closed form of those plus per-histogram constants (sum, sum of squares,
+// stored mag, length) that hist_build keeps beside each slot:
+//     sum min(p,q) = (sum p + sum q - manh)/2        sum (p-q)^2 = sum p^2 + sum q^2 - 2 dot
+// so the kernel is pure HBM streaming: each candidate byte is read exactly once, the query tile lives in
+// registers for the whole launch. Memory-bound integer work: no MFMA, no LDS.
+//
+// k_pair_tiles   : wave w owns tile s = w % S of the query and walks candidates g, g+G, ... (G = waves / S),
+//                  reading LPT coalesced 16-byte loads per lane per candidate, software-pipelined one candidate ahead.
+//                  The tile-permuted layout (msc_layout.h) gives each lane R consecutive bins, so the prefix
+//                  statistic is a register scan + one 6-step DPP wave scan per tile.
+// k_pair_epilogue: one wave (S > 4) or one thread per candidate folds the S partial records and evaluates the
+//                  statistics / normalisation / combos / GLM in FP64 with the reference's expression order.
+// k_pair_reduce  : single workgroup; arg-max of combo 0 with the serial tie order, close flags, counts.
+//
+// Integer ranges ("narrow" path, checked on the host before launch): largest bin <= MSC_NARROW_MAX_COUNT,
+// bin sum < 2^31. Within that range every 32-bit product of the reference is exact, so results are
+// bit-identical to the reference's integer accumulators.
+#include "msc_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// ---------------------------------------------------------------------------------------- wave primitives (DPP)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15 / 31 (gfx9 DPP)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+	v = dpp_add<0x111, 0xf>(v);
+	v = dpp_add<0x112, 0xf>(v);
+	v = dpp_add<0x114, 0xf>(v);
+	v = dpp_add<0x118, 0xf>(v);
+	v = dpp_add<0x142, 0xa>(v);
+	v = dpp_add<0x143, 0xc>(v);
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {      // valid in every lane (SGPR broadcast)
+	return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+// per-lane values < 2^32 whose wave total may exceed 32 bits: add the 16-bit halves separately
+__device__ __forceinline__ uint64_t wave_total_u64(uint32_t v) {
+	const uint32_t lo = wave_total_u32(v & 0xffffu);
+	const uint32_t hi = wave_total_u32(v >> 16);
+	return (uint64_t)lo + ((uint64_t)hi << 16);
+}
+
+template <typename T> struct ElemOps;
+template <> struct ElemOps<uint8_t> {
+	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+};
+template <> struct ElemOps<uint16_t> {
+	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return (w[r >> 1] >> (16 * (r & 1))) & 0xffffu; }
+};
+template <> struct ElemOps<uint32_t> {
+	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return w[r]; }
+};
+template <> struct ElemOps<uint64_t> {   // narrow path: the high dword is zero by the host-side range check
+	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return w[2 * r]; }
+};
+
+// ---------------------------------------------------------------------------------------- streaming kernel
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int LPT>
+struct TileRegs {
+	u32x4 v[LPT];
+};
+
+// LPT coalesced 16-byte loads per lane (1 KiB per wave-instruction); candidates are read exactly once -> nontemporal
+template <int LPT>
+__device__ __forceinline__ void load_tile(TileRegs<LPT>& t, const uint8_t* tile_base, uint32_t lane) {
+	const u32x4* p = reinterpret_cast<const u32x4*>(tile_base) + lane;
+#pragma unroll
+	for (int l = 0; l < LPT; l++) t.v[l] = __builtin_nontemporal_load(p + 64 * l);
+}
+
+template <typename T, int LPT, bool PADDED>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_bins, const uint8_t* __restrict__ q_scalars,
+    uint32_t S, uint32_t G, uint32_t nvalid /* bins of the (single) tile that are real */,
+    int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials) {
+	constexpr int E = 16 / sizeof(T);
+	constexpr int R = LPT * E;
+	constexpr int NW = 4 * LPT;
+	constexpr uint32_t tile_bytes = 1024u * LPT;
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	const uint32_t s = W % S;
+	const uint32_t g = W / S;
+	if (g >= G) return;
+
+	// ---- query tile: registers for the whole launch
+	TileRegs<LPT> qt;
+	load_tile<LPT>(qt, q_bins + (uint64_t)s * tile_bytes, lane);
+	const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qt);
+	const uint64_t* q_prefix = reinterpret_cast<const uint64_t*>(q_scalars + sizeof(MscSlotScalars));
+	uint32_t tq = 0;
+#pragma unroll
+	for (int r = 0; r < R; r++) tq += ElemOps<T>::get(qw, r);
+	const uint32_t cq0 = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;     // prefix(q) just before this lane's run
+	(void)NW;
+
+	auto slot_of = [&](uint32_t c) -> uint32_t { return cand_slots ? cand_slots[c] : c; };
+	auto in_window = [&](uint32_t slot) -> bool {
+		if (!use_window) return true;
+		const uint64_t len = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride)->length;
+		return len >= min_len && len <= max_len;
+	};
+
+	// ---- software pipeline, one candidate ahead
+	TileRegs<LPT> nxt;
+	uint32_t nxt_carry = 0;
+	bool nxt_ok = false;
+	uint32_t c = g;
+	if (c < m) {
+		const uint32_t slot = slot_of(c);
+		nxt_ok = in_window(slot);
+		if (nxt_ok) {
+			load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
+			nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+		}
+	}
+	for (; c < m; c += G) {
+		const TileRegs<LPT> cur = nxt;
+		const uint32_t carry = nxt_carry;
+		const bool ok = nxt_ok;
+		const uint32_t cn = c + G;
+		if (cn < m) {
+			const uint32_t slot = slot_of(cn);
+			nxt_ok = in_window(slot);
+			if (nxt_ok) {
+				load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
+				nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+			}
+		}
+		if (!ok) continue;
+
+		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
+		uint32_t tp = 0;
+#pragma unroll
+		for (int r = 0; r < R; r++) tp += ElemOps<T>::get(pw, r);
+		uint32_t cp = carry + wave_incl_scan(tp) - tp;
+		uint32_t cq = cq0;
+		uint32_t manh = 0, dot = 0, emd = 0;
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t p = ElemOps<T>::get(pw, r);
+			const uint32_t q = ElemOps<T>::get(qw, r);
+			cp += p;
+			cq += q;
+			if constexpr (PADDED) {
+				const uint32_t d = cp > cq ? cp - cq : cq - cp;
+				emd += (lane * R + r < nvalid) ? d : 0u;
+			} else {
+				emd = __usad(cp, cq, emd);
+			}
+			manh = __usad(p, q, manh);
+			dot = __umul24(p, q) + dot;
+		}
+		const uint32_t manh_t = wave_total_u32(manh);
+		const uint64_t dot_t = wave_total_u64(dot);
+		const uint64_t emd_t = wave_total_u64(emd);
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = manh_t;
+			out.dot = dot_t;
+			out.emd = emd_t;
+			partials[(uint64_t)c * S + s] = out;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- epilogue
+struct PairTotals {
+	uint64_t manh, dot, emd;
+};
+
+struct Side {
+	uint64_t mag, len, sum, sq;
+};
+
+// One raw statistic from the integer reductions. `a` is the FIRST argument of the reference call, `b` the second.
+__device__ double raw_stat(uint64_t flag, const PairTotals& t, const Side& a, const Side& b, uint64_t nbins, int dtype, int* err) {
+	const double N = (double)nbins;
+	switch (flag) {
+	case MSC_FEAT_MANHATTAN:           // `int sum`, predict/Feature.cpp:864-870
+		return (double)(int32_t)(uint32_t)t.manh;
+	case MSC_FEAT_EUCLIDEAN:           // :1118-1123
+		return sqrt((double)(a.sq + b.sq - 2 * t.dot));
+	case MSC_FEAT_NORMALIZED_VECTORS:  // :1176-1183, d1*d2 in uintmax_t
+		return (double)t.dot / sqrt((double)(a.sq * b.sq));
+	case MSC_FEAT_PEARSON_COEFF: {     // :800-810 with dap/daq from the STORED mag
+		const double dap = (double)a.mag / N;
+		const double daq = (double)b.mag / N;
+		const double np = (double)a.sq - 2.0 * dap * (double)a.sum + N * dap * dap;
+		const double nq = (double)b.sq - 2.0 * daq * (double)b.sum + N * daq * daq;
+		const double dt = (double)t.dot - daq * (double)a.sum - dap * (double)b.sum + N * dap * daq;
+		return dt / sqrt(np * nq);
+	}
+	case MSC_FEAT_INTERSECTION: {      // :769-776
+		const uint64_t min_sum = (a.sum + b.sum - t.manh) >> 1;
+		return (double)(2 * min_sum) / (double)(a.mag + b.mag);
+	}
+	case MSC_FEAT_EMD:                 // :1510-1517
+		return (double)t.emd;
+	case MSC_FEAT_LENGTHD:             // :878-886
+		if (a.len == 0 || b.len == 0) { *err = MSC_ERR_ZERO_LENGTH; return NAN; }
+		return (double)(a.len > b.len ? a.len - b.len : b.len - a.len);
+	case MSC_FEAT_KULCZYNSKI2: {       // :686-694
+		const uint64_t min_sum = (a.sum + b.sum - t.manh) >> 1;
+		const double ap = (double)a.mag / N;
+		const double aq = (double)b.mag / N;
+		const double coeff = N * (ap + aq) / (2 * ap * aq);
+		return coeff * (double)min_sum;
+	}
+	case MSC_FEAT_SIMRATIO: {          // :834-840
+		uint64_t norm2 = a.sq + b.sq - 2 * t.dot;
+		if (dtype == 32) {
+			// `intmax_t diff = p - q` wraps mod 2^32 for uint32_t bins BEFORE widening: every bin with
+			// p < q contributes (2^32 - (q-p))^2 = (q-p)^2 - 2^33 (q-p)  (mod 2^64). Reproduced exactly:
+			const int64_t sdiff = (int64_t)a.sum - (int64_t)b.sum;             // sum(p-q)
+			const uint64_t neg = (uint64_t)(((int64_t)t.manh - sdiff) >> 1);   // sum over p<q of (q-p)
+			norm2 -= neg << 33;
+		}
+		return (double)t.dot / ((double)t.dot + sqrt((double)norm2));
+	}
+	default:
+		*err = MSC_ERR_UNSUPPORTED;
+		return NAN;
+	}
+}
+
+__device__ __forceinline__ uint64_t shfl_sum_u64(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t) {
+	const uint32_t slot = a.cand_slots ? a.cand_slots[c] : c;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride);
+	const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
+	Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
+	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
+	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
+	const Side& second = a.order == MSC_ORDER_CAND_FIRST ? qry : cand;
+
+	MscPairOut po;
+	po.sum = NAN; po.csum = NAN; po.combo0 = NAN; po.status = 0; po.close = 0;
+	const bool skipped = a.use_window && (cand.len < a.min_len || cand.len > a.max_len);
+	int nf = __popcll(a.feat_mask);
+	if (skipped) {
+		po.status = 1;
+		if (a.raw_out) for (int i = 0; i < nf; i++) a.raw_out[(uint64_t)c * nf + i] = NAN;
+		if (a.model && a.singles_out) for (int i = 0; i < a.model->n_singles; i++) a.singles_out[(uint64_t)c * a.model->n_singles + i] = NAN;
+		if (a.model && a.combos_out) for (int i = 0; i < a.model->n_combos; i++) a.combos_out[(uint64_t)c * a.model->n_combos + i] = NAN;
+		if (a.pair_out) a.pair_out[c] = po;
+		return;
+	}
+	int err = 0;
+	if (a.raw_out) {
+		int i = 0;
+		for (uint64_t f = a.feat_mask; f; f &= f - 1, i++) {
+			const uint64_t bit = f & (~f + 1);
+			a.raw_out[(uint64_t)c * nf + i] = raw_stat(bit, t, first, second, a.nbins, a.dtype, &err);
+		}
+	}
+	if (a.model) {
+		const MscDevModel& md = *a.model;
+		double v[MSC_MAX_SINGLES];
+		for (int i = 0; i < md.n_singles; i++) v[i] = raw_stat(md.single_flag[i], t, first, second, a.nbins, a.dtype, &err);
+		// Feature::normalize_cache, predict/Feature.cpp:137-154
+		for (int i = 0; i < md.n_singles; i++) {
+			double val = (v[i] - md.mins[i]) / (md.maxs[i] - md.mins[i]);
+			if (isnan(val) && err == 0) err = MSC_ERR_NAN;
+			v[i] = md.is_sim[i] ? val : 1 - val;
+			if (a.singles_out) a.singles_out[(uint64_t)c * md.n_singles + i] = v[i];
+		}
+		// Feature::operator(), predict/Feature.h:205-239 + Trainer::classify, cluster/Trainer.cpp:112-120
+		double sum = md.weights[0];
+		for (int col = 0; col < md.n_combos; col++) {
+			const int i0 = md.combo_idx[col][0], i1 = md.combo_idx[col][1], n = md.combo_n[col];
+			double d;
+			switch (md.combo_kind[col]) {
+			case MSC_COMBO_XY: { d = 1; d *= v[i0]; if (n == 2) d *= v[i1]; } break;
+			case MSC_COMBO_X2Y2: { d = 1; d *= v[i0] * v[i0]; if (n == 2) d *= v[i1] * v[i1]; } break;
+			case MSC_COMBO_XY2: d = v[i0] * v[i1] * v[i1]; break;
+			default: d = v[i0] * v[i0] * v[i1]; break;
+			}
+			if (col == 0) po.combo0 = d;
+			if (a.combos_out) a.combos_out[(uint64_t)c * md.n_combos + col] = d;
+			sum += md.weights[col + 1] * d;
+		}
+		po.sum = sum;
+		po.csum = 1.0 / (1 + exp(-sum)) + md.bias;      // GLM::logistic + _bias, predict/GLM.cpp:26-29, Predictor.cpp:315-320
+		po.close = round(po.csum) > 0 ? 1 : 0;
+		if (err) { po.sum = NAN; po.csum = NAN; po.combo0 = NAN; po.close = 0; }
+	}
+	po.status = err;
+	if (a.pair_out) a.pair_out[c] = po;
+}
+
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogueArgs a) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+	if (c >= a.m) return;
+	PairTotals t{0, 0, 0};
+	for (uint32_t s = lane; s < a.S; s += 64) {
+		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
+		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+	}
+	t.manh = shfl_sum_u64(t.manh);
+	t.dot = shfl_sum_u64(t.dot);
+	t.emd = shfl_sum_u64(t.emd);
+	if (lane == 0) epilogue_one(a, c, t);
+}
+
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= a.m) return;
+	PairTotals t{0, 0, 0};
+	for (uint32_t s = 0; s < a.S; s++) {
+		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
+		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+	}
+	epilogue_one(a, c, t);
+}
+
+// ---------------------------------------------------------------------------------------- reduce
+// get_close: arg-max of combo0 over candidates that were scored, strict '>' in window order (first maximum wins),
+//            starting from (-1, none)                                  cluster/Trainer.cpp:26-37,59
+// merge    : among close candidates, later index wins ties, starting from (0, DBL_MIN)   cluster/Trainer.cpp:76-79,103-105
+struct Best { double sim; int64_t pos; };
+
+__device__ __forceinline__ Best better(Best x, Best y, int mode) {
+	if (mode == MSC_REDUCE_GET_CLOSE) {
+		if (y.sim > x.sim || (y.sim == x.sim && y.pos >= 0 && (x.pos < 0 || y.pos < x.pos))) return y;
+		return x;
+	}
+	if (y.pos < 0) return x;
+	if (x.pos < 0) return y;
+	if (y.sim > x.sim || (y.sim == x.sim && y.pos > x.pos)) return y;
+	return x;
+}
+
+__global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restrict__ po, uint32_t m, int mode, int64_t begin,
+                                                      uint8_t* __restrict__ flags_out, MscReduceOut* __restrict__ out) {
+	__shared__ Best s_best[1024];
+	__shared__ unsigned long long s_nclose;
+	__shared__ int s_err;
+	if (threadIdx.x == 0) { s_nclose = 0; s_err = 0; }
+	__syncthreads();
+	Best b{mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0, -1};
+	unsigned long long nclose = 0;
+	int err = 0;
+	for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+		const MscPairOut p = po[i];
+		const bool scored = p.status == 0;
+		if (p.status < 0 && p.status < err) err = p.status;
+		if (flags_out) flags_out[i] = (scored && p.close) ? 1 : 0;
+		if (!scored) continue;
+		nclose += p.close ? 1 : 0;
+		if (mode == MSC_REDUCE_GET_CLOSE) {
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)i}, mode);
+		} else {
+			// best = best.second > dist ? best : (i, dist), starting at DBL_MIN
+			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)i}, mode);
+		}
+	}
+	s_best[threadIdx.x] = b;
+	if (nclose) atomicAdd(&s_nclose, nclose);
+	if (err) atomicMin(&s_err, err);
+	__syncthreads();
+	for (int stride = 512; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) s_best[threadIdx.x] = better(s_best[threadIdx.x], s_best[threadIdx.x + stride], mode);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		MscReduceOut r;
+		r.best_sim = s_best[0].pos >= 0 ? s_best[0].sim : (mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 2.2250738585072014e-308);
+		r.best_pos = s_best[0].pos >= 0 ? s_best[0].pos : (mode == MSC_REDUCE_GET_CLOSE ? -1 : 0);
+		r.any_close = s_nclose > 0;
+		r.n_close = s_nclose;
+		r.first_error = s_err;
+		*out = r;
+	}
+}
+
+// distance_d for the m members against the rounded mean (clutil/DivergencePoint.cpp:55-66):
+//   dist = sum 2*min(p, (T)round(c))  =  sum p + sum r - manh(p, r)
+//   mag  = sum_i floor-accumulated (p_i + c_i) = sum p + sum floor(c_i)      (uint64 += double truncates every step)
+__global__ void __launch_bounds__(1024) k_distance_d(const MscPartial* __restrict__ partials, uint32_t S, uint32_t m,
+                                                     const uint8_t* __restrict__ scalars, uint64_t scalar_stride,
+                                                     const uint32_t* __restrict__ member_slots, const uint8_t* __restrict__ r_scalars,
+                                                     const uint64_t* __restrict__ floor_sum, double* __restrict__ dist_out,
+                                                     MscReduceOut* __restrict__ out) {
+	__shared__ Best s_best[1024];
+	const MscSlotScalars* rs = reinterpret_cast<const MscSlotScalars*>(r_scalars);
+	Best b{0.0, -1};
+	for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+		uint64_t manh = 0;
+		for (uint32_t s = 0; s < S; s++) manh += partials[(uint64_t)i * S + s].manh;
+		const uint32_t slot = member_slots ? member_slots[i] : i;
+		const MscSlotScalars* ps = reinterpret_cast<const MscSlotScalars*>(scalars + (uint64_t)slot * scalar_stride);
+		const uint64_t dist = ps->sum + rs->sum - manh;
+		const uint64_t mag = ps->sum + *floor_sum;
+		const double frac = (double)dist / (double)mag;
+		const double d = 10000.0 * (1.0 - frac * frac);
+		if (dist_out) dist_out[i] = d;
+		// first minimum wins (cluster/Trainer.cpp:150-153, ClusterFactory.cpp:369-373 serial order)
+		if (b.pos < 0 || d < b.sim) b = Best{d, (int64_t)i};
+	}
+	s_best[threadIdx.x] = b;
+	__syncthreads();
+	for (int stride = 512; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) {
+			Best x = s_best[threadIdx.x], y = s_best[threadIdx.x + stride];
+			if (y.pos >= 0 && (x.pos < 0 || y.sim < x.sim || (y.sim == x.sim && y.pos < x.pos))) s_best[threadIdx.x] = y;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		MscReduceOut r;
+		r.best_sim = s_best[0].sim;
+		r.best_pos = s_best[0].pos;
+		r.any_close = 0;
+		r.n_close = 0;
+		r.first_error = 0;
+		*out = r;
+	}
+}
+
+// ---------------------------------------------------------------------------------------- column sums (mean)
+// get_mean / mean_shift_update mean (cluster/ClusterFactory.cpp:338-357,297-326): mean_i = (sum_members p_i) / m in FP64.
+// Sums of integers are exact below 2^53, so integer column sums + one division reproduce the reference's
+// sequential double accumulation bit for bit. Emits r = (T)round(mean) in the same tile-permuted layout (it is
+// scored against the members by k_pair_tiles), the FP64 mean, and sum floor(mean_i) over the REAL bins.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_colsum(const T* __restrict__ bins, uint64_t slot_elems, const uint32_t* __restrict__ member_slots,
+                                                   uint32_t m, uint64_t padded, uint64_t nbins, uint32_t R, T* __restrict__ rounded,
+                                                   double* __restrict__ mean_out, unsigned long long* __restrict__ floor_sum) {
+	constexpr uint32_t E = 16 / sizeof(T);
+	const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long fl = 0;
+	if (chunk * E < padded) {
+		uint64_t acc[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) acc[j] = 0;
+		for (uint32_t i = 0; i < m; i++) {
+			const uint32_t slot = member_slots ? member_slots[i] : i;
+			const uint4 v = *reinterpret_cast<const uint4*>(bins + (uint64_t)slot * slot_elems + chunk * E);
+			const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+			for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+		}
+		// logical index of element j of this chunk (to exclude the zero pad bins of tiny histograms)
+		const uint32_t tile_bins = 64 * R;
+		const uint64_t tile = (chunk * E) / tile_bins;
+		const uint32_t in_tile = (uint32_t)((chunk * E) % tile_bins);
+		const uint32_t t = in_tile / (64 * E), lane = (in_tile % (64 * E)) / E;
+		T rv[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) {
+			const uint64_t logical = tile * tile_bins + (uint64_t)lane * R + t * E + j;
+			const double mean = (double)acc[j] / (double)m;
+			if (mean_out) mean_out[chunk * E + j] = mean;
+			rv[j] = (T)round(mean);
+			if (logical < nbins) fl += (unsigned long long)floor(mean);
+		}
+		*reinterpret_cast<uint4*>(rounded + chunk * E) = *reinterpret_cast<const uint4*>(rv);
+	}
+	fl = shfl_sum_u64(fl);
+	if ((threadIdx.x & 63) == 0 && fl) atomicAdd(floor_sum, fl);
+}
+
+}  // namespace
+
+// ======================================================================================== launchers
+template <typename T, int LPT>
+static hipError_t launch_tiles_t(hipStream_t st, const MscLayout& L, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                 const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins, const uint8_t* q_scalars,
+                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+	const uint32_t S = L.S;
+	// enough waves to fill the chip (8 per SIMD), at least one candidate group, at most one group per candidate
+	const uint64_t target_waves = (uint64_t)num_cus * 32;
+	uint64_t G = (target_waves + S - 1) / S;
+	if (G < 1) G = 1;
+	if (G > m) G = m;
+	const uint64_t waves = (uint64_t)S * G;
+	const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+	const bool padded = L.nbins < L.padded_bins;
+	const uint64_t stride = msc_scalar_stride(S);
+	if (padded) {
+		hipLaunchKernelGGL((k_pair_tiles<T, LPT, true>), dim3(blocks), dim3(kBlock), 0, st, cand_bins, L.slot_bytes, cand_scalars, stride,
+		                   cand_slots, m, q_bins, q_scalars, S, (uint32_t)G, (uint32_t)L.nbins, use_window, min_len, max_len, partials);
+	} else {
+		hipLaunchKernelGGL((k_pair_tiles<T, LPT, false>), dim3(blocks), dim3(kBlock), 0, st, cand_bins, L.slot_bytes, cand_scalars, stride,
+		                   cand_slots, m, q_bins, q_scalars, S, (uint32_t)G, (uint32_t)L.tile_bins, use_window, min_len, max_len, partials);
+	}
+	return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_tiles_lpt(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, uint32_t m,
+                                   const uint8_t* qb, const uint8_t* qs, int uw, uint64_t mn, uint64_t mx, MscPartial* p, int cus) {
+	switch (L.LPT) {
+	case 1: return launch_tiles_t<T, 1>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
+	case 2: return launch_tiles_t<T, 2>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
+	default: return launch_tiles_t<T, 4>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
+	}
+}
+
+hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                 const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
+                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+	if (m == 0) return hipSuccess;
+	switch (dtype) {
+	case 8: return launch_tiles_lpt<uint8_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
+	case 16: return launch_tiles_lpt<uint16_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
+	case 32: return launch_tiles_lpt<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
+	default: return launch_tiles_lpt<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
+	}
+}
+
+hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
+	if (a.m == 0) return hipSuccess;
+	if (a.S > 4) {
+		const unsigned blocks = (a.m + kWavesPerBlock - 1) / kWavesPerBlock;
+		hipLaunchKernelGGL(k_pair_epilogue_wave, dim3(blocks), dim3(kBlock), 0, st, a);
+	} else {
+		const unsigned blocks = (a.m + kBlock - 1) / kBlock;
+		hipLaunchKernelGGL(k_pair_epilogue_thread, dim3(blocks), dim3(kBlock), 0, st, a);
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin, uint8_t* flags_out,
+                             MscReduceOut* out) {
+	hipLaunchKernelGGL(k_pair_reduce, dim3(1), dim3(1024), 0, st, pair_out, m, mode, begin, flags_out, out);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_colsum(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots,
+                             uint32_t m, void* rounded_out, double* mean_out, uint64_t* floor_sum_out, uint64_t* scratch) {
+	(void)scratch;
+	hipError_t e = hipMemsetAsync(floor_sum_out, 0, sizeof(uint64_t), st);
+	if (e != hipSuccess) return e;
+	const uint64_t chunks = L.padded_bins / L.E;
+	const unsigned blocks = (unsigned)((chunks + kBlock - 1) / kBlock);
+	switch (dtype) {
+	case 8: hipLaunchKernelGGL(k_colsum<uint8_t>, dim3(blocks), dim3(kBlock), 0, st, (const uint8_t*)bins, L.padded_bins, member_slots, m, L.padded_bins, L.nbins, L.R, (uint8_t*)rounded_out, mean_out, (unsigned long long*)floor_sum_out); break;
+	case 16: hipLaunchKernelGGL(k_colsum<uint16_t>, dim3(blocks), dim3(kBlock), 0, st, (const uint16_t*)bins, L.padded_bins, member_slots, m, L.padded_bins, L.nbins, L.R, (uint16_t*)rounded_out, mean_out, (unsigned long long*)floor_sum_out); break;
+	case 32: hipLaunchKernelGGL(k_colsum<uint32_t>, dim3(blocks), dim3(kBlock), 0, st, (const uint32_t*)bins, L.padded_bins, member_slots, m, L.padded_bins, L.nbins, L.R, (uint32_t*)rounded_out, mean_out, (unsigned long long*)floor_sum_out); break;
+	default: hipLaunchKernelGGL(k_colsum<uint64_t>, dim3(blocks), dim3(kBlock), 0, st, (const uint64_t*)bins, L.padded_bins, member_slots, m, L.padded_bins, L.nbins, L.R, (uint64_t*)rounded_out, mean_out, (unsigned long long*)floor_sum_out); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t m, const uint8_t* scalars,
+                                 uint64_t scalar_stride, const uint32_t* member_slots, const uint8_t* r_scalars,
+                                 const uint64_t* floor_sum, double* dist_out, MscReduceOut* out) {
+	hipLaunchKernelGGL(k_distance_d, dim3(1), dim3(1024), 0, st, partials, S, m, scalars, scalar_stride, member_slots, r_scalars,
+	                   floor_sum, dist_out, out);
+	return hipGetLastError();
+}

@@ -1,0 +1,207 @@
+"""oracle/oracle_py.py -- TEST INFRASTRUCTURE ONLY (ctypes view of oracle/libmsc_oracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (meshclust2_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmsc_oracle.so")
+
+FEAT = {
+    "manhattan": 1 << 2, "euclidean": 1 << 3, "normalized_vectors": 1 << 5, "jefferey_divergence": 1 << 7,
+    "pearson": 1 << 9, "intersection": 1 << 13, "emd": 1 << 18, "length_difference": 1 << 21,
+    "kulczynski2": 1 << 27, "simratio": 1 << 28, "jensen_shannon": 1 << 29,
+}
+FEAT_FAST = sum(FEAT[n] for n in ("euclidean", "manhattan", "intersection", "kulczynski2", "simratio",
+                                  "normalized_vectors", "pearson", "emd", "length_difference"))
+FEAT_DIV = FEAT["jefferey_divergence"] | FEAT["jensen_shannon"]
+NP_T = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+MAX_SINGLES, MAX_COMBOS = 34, 16
+
+
+class Hist(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("k", C.c_int), ("nbins", C.c_uint64), ("bins", C.c_void_p),
+                ("mag", C.c_uint64), ("length", C.c_uint64), ("stddev", C.c_double),
+                ("one_mers", C.c_uint64 * 4), ("overflow", C.c_int), ("id", C.c_uint64)]
+
+    def array(self):
+        n = int(self.nbins)
+        buf = (C.c_uint8 * (n * self.dtype // 8)).from_address(self.bins)
+        return np.frombuffer(buf, dtype=NP_T[self.dtype]).copy()
+
+
+class Model(C.Structure):
+    _fields_ = [("k", C.c_int), ("n_singles", C.c_int), ("single_flag", C.c_uint64 * MAX_SINGLES),
+                ("mins", C.c_double * MAX_SINGLES), ("maxs", C.c_double * MAX_SINGLES),
+                ("is_sim", C.c_int * MAX_SINGLES), ("n_combos", C.c_int), ("combo_kind", C.c_int * MAX_COMBOS),
+                ("combo_n", C.c_int * MAX_COMBOS), ("combo_idx", (C.c_int * MAX_SINGLES) * MAX_COMBOS),
+                ("combo_flags", C.c_uint64 * MAX_COMBOS), ("weights", C.c_double * (MAX_COMBOS + 1))]
+
+
+class Predictor(C.Structure):
+    _fields_ = [("k", C.c_int), ("mode", C.c_int), ("max_features", C.c_int), ("id", C.c_double),
+                ("datatype", C.c_char * 16), ("feature_set", C.c_uint64), ("cls", Model), ("reg", Model),
+                ("bias", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("msc_oracle.c", "msc_oracle.h", "msc_oracle_t.inc")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        HP = C.POINTER(Hist)
+        L.orc_encode.restype = C.c_int
+        L.orc_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int64), C.c_size_t, C.POINTER(C.c_uint64)]
+        L.orc_hist_build.restype = C.c_int
+        L.orc_hist_build.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, HP]
+        L.orc_hist_free.argtypes = [HP]
+        L.orc_hist_clone.argtypes = [HP, HP]
+        L.orc_hist_set.argtypes = [HP, HP]
+        L.orc_raw_feature.restype = C.c_double
+        L.orc_raw_feature.argtypes = [C.c_uint64, HP, HP, C.POINTER(C.c_int)]
+        L.orc_predictor_parse.argtypes = [C.c_char_p, C.POINTER(Predictor)]
+        L.orc_predictor_format.argtypes = [C.POINTER(Predictor), C.c_char_p, C.c_size_t]
+        L.orc_compute.argtypes = [C.POINTER(Model), HP, HP, C.POINTER(C.c_double)]
+        L.orc_combo.restype = C.c_double
+        L.orc_combo.argtypes = [C.POINTER(Model), C.c_int, C.POINTER(C.c_double)]
+        L.orc_weighted_sum.restype = C.c_double
+        L.orc_weighted_sum.argtypes = [C.POINTER(Model), C.POINTER(C.c_double)]
+        L.orc_classify.restype = C.c_double
+        L.orc_classify.argtypes = [C.POINTER(Predictor), HP, HP]
+        L.orc_p_close.argtypes = [C.POINTER(Predictor), HP, HP]
+        L.orc_p_predict.restype = C.c_double
+        L.orc_p_predict.argtypes = [C.POINTER(Predictor), HP, HP]
+        gc_args = [C.POINTER(Predictor), C.c_double, HP, C.POINTER(HP), C.c_size_t, C.POINTER(C.c_uint8),
+                   C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_get_close.argtypes = gc_args
+        L.orc_get_close_omp.argtypes = gc_args
+        L.orc_filter.argtypes = [C.POINTER(Predictor), C.c_double, HP, C.POINTER(HP), C.c_size_t, C.POINTER(C.c_uint8)]
+        L.orc_merge.restype = C.c_long
+        L.orc_merge.argtypes = [C.POINTER(Predictor), C.c_double, C.POINTER(HP), C.c_size_t, C.c_long, C.c_long, C.c_long]
+        L.orc_distance_d.restype = C.c_double
+        L.orc_distance_d.argtypes = [HP, C.POINTER(C.c_double)]
+        L.orc_distance.restype = C.c_uint64
+        L.orc_distance.argtypes = [HP, HP]
+        L.orc_mean_nearest.argtypes = [C.POINTER(HP), C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _b(s):
+    return s if isinstance(s, bytes) else s.encode()
+
+
+def encode(seq):
+    """-> (codes bytes, segments [(s,e)...], effective_length) or raises ValueError."""
+    seq = _b(seq)
+    out = C.create_string_buffer(len(seq) + 1)
+    max_segs = len(seq) // 2 + 2
+    segs = (C.c_int64 * (2 * max_segs))()
+    eff = C.c_uint64()
+    n = lib().orc_encode(seq, len(seq), out, segs, max_segs, C.byref(eff))
+    if n < 0:
+        raise ValueError("invalid nucleotide")
+    return out.raw[:len(seq)], [(segs[2 * i], segs[2 * i + 1]) for i in range(n)], eff.value
+
+
+def hist(seq, k, dtype, strip=False):
+    seq = _b(seq)
+    h = Hist()
+    r = lib().orc_hist_build(seq, len(seq), k, dtype, 1 if strip else 0, C.byref(h))
+    if r != 0:
+        raise ValueError("orc_hist_build failed: %d" % r)
+    return h
+
+
+def raw_feature(flag, a, b):
+    err = C.c_int()
+    v = lib().orc_raw_feature(flag, C.byref(a), C.byref(b), C.byref(err))
+    if err.value:
+        raise ValueError("feature error %d" % err.value)
+    return v
+
+
+def predictor(text):
+    p = Predictor()
+    if lib().orc_predictor_parse(_b(text), C.byref(p)) != 0:
+        raise ValueError("bad weights file")
+    return p
+
+
+def predictor_format(p):
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().orc_predictor_format(C.byref(p), buf, len(buf))
+    return buf.raw[:n].decode()
+
+
+def compute(model, a, b):
+    out = (C.c_double * MAX_SINGLES)()
+    r = lib().orc_compute(C.byref(model), C.byref(a), C.byref(b), out)
+    if r != 0:
+        raise ValueError("orc_compute failed %d" % r)
+    return np.array(out[:model.n_singles])
+
+
+def score(model, a, b):
+    """-> (singles, combos, weighted sum)"""
+    s = compute(model, a, b)
+    arr = (C.c_double * MAX_SINGLES)(*s)
+    combos = np.array([lib().orc_combo(C.byref(model), c, arr) for c in range(model.n_combos)])
+    return s, combos, lib().orc_weighted_sum(C.byref(model), arr)
+
+
+def _harr(hs):
+    HP = C.POINTER(Hist)
+    return (HP * len(hs))(*[C.pointer(h) for h in hs])
+
+
+def get_close(pred, cutoff, query, cands, omp=False):
+    m = len(cands)
+    flags = (C.c_uint8 * max(m, 1))()
+    bp, bs, im = C.c_int64(), C.c_double(), C.c_int()
+    fn = lib().orc_get_close_omp if omp else lib().orc_get_close
+    r = fn(C.byref(pred), cutoff, C.byref(query), _harr(cands), m, flags, C.byref(bp), C.byref(bs), C.byref(im))
+    if r != 0:
+        raise ValueError("orc_get_close failed")
+    return np.array(flags[:m], dtype=np.uint8), bp.value, bs.value, bool(im.value)
+
+
+def filter_(pred, cutoff, centre, pts):
+    m = len(pts)
+    keep = (C.c_uint8 * max(m, 1))()
+    lib().orc_filter(C.byref(pred), cutoff, C.byref(centre), _harr(pts), m, keep)
+    return np.array(keep[:m], dtype=np.uint8)
+
+
+def merge(pred, cutoff, centres, current, begin, last):
+    return lib().orc_merge(C.byref(pred), cutoff, _harr(centres), len(centres), current, begin, last)
+
+
+def mean_nearest(pts):
+    m = len(pts)
+    n = int(pts[0].nbins)
+    mean = np.zeros(n, dtype=np.float64)
+    d = np.zeros(m, dtype=np.float64)
+    nearest = C.c_int64()
+    lib().orc_mean_nearest(_harr(pts), m, mean.ctypes.data_as(C.POINTER(C.c_double)),
+                           d.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nearest))
+    return mean, d, nearest.value

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Regenerates every fixture in tests/golden/ from the REAL reference (oracle/_ref, built by `make -C oracle ref`
+from /root/reference). Run in the build container only:  python tests/golden/gen_golden.py
+
+What is stored is DATA (inputs + the reference's outputs), never reference source:
+  weights_k5_u16.txt     model trained by the reference's own `meshclust2 --dump`-style run (weights.txt) on the cfg1
+                         synthetic set (classification block) + a hand-assembled regression block (the reference's
+                         fastcar --dump aborts with std::bad_cast in this build, so no reference-trained one exists)
+  weights_k9_u32.txt     same for k=9 / uint32_t (cfg2's model)
+  cfg1.clstr             the reference CLI's CLSTR output for cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16, 1 thread)
+  vectors_*.npz          sequences, histograms (sparse: bins != 1), scalars, the 11 raw statistics for all ordered
+                         pairs, model outputs, Trainer::get_close / filter / merge results, mean + distance_d
+  kat_appendix_d.json    the k=2 known answers of SURVEY.md Appendix D, re-derived from the reference
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from meshclust2_amd import synth  # noqa: E402
+from oracle import ref_py  # noqa: E402
+
+FEATS = [("manhattan", 2), ("euclidean", 3), ("normalized_vectors", 5), ("jefferey_divergence", 7), ("pearson", 9),
+         ("intersection", 13), ("emd", 18), ("length_difference", 21), ("kulczynski2", 27), ("simratio", 28), ("jensen_shannon", 29)]
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "meshclust2")
+
+REG_BLOCK_K5 = """
+n_combos: 3
+0.05
+0 32 0.9
+1 8196 0.08
+2 262148 -0.06
+
+n_singles: 4
+32 0.55 1
+4 0 900
+8192 0.3 1
+262144 0 60000
+"""
+
+REG_BLOCK_K9 = """
+n_combos: 3
+0.02
+0 8192 0.95
+1 268435464 0.05
+3 262144 -0.04
+
+n_singles: 4
+8192 0.99 1
+8 0 70
+268435456 0.9 1
+262144 0 40000000
+"""
+
+
+def run_reference_cli(fasta, args, workdir):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([REF_BIN, fasta] + args, cwd=workdir, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+    return out.stdout.decode(errors="replace")
+
+
+def make_weights(name, seed, n, length, k, dtype, reg_block, clstr_name=None):
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = synth.families(seed, n, length)
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    run_reference_cli(fa, ["--id", "0.9", "--kmer", str(k), "--datatype", str(dtype), "--threads", "1", "--output", "out.clstr"], tmp)
+    text = open(os.path.join(tmp, "weights.txt")).read()
+    text = text.replace("mode: 1", "mode: 3") + reg_block
+    open(os.path.join(HERE, name), "w").write(text)
+    if clstr_name:
+        shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, clstr_name))
+    shutil.rmtree(tmp)
+    print("wrote", name)
+
+
+def sparse(bins):
+    idx = np.nonzero(bins != 1)[0]
+    return idx.astype(np.uint32), bins[idx]
+
+
+def make_vectors(name, weights, seed, n, length, k, dtype, extra=()):
+    seqs, _ = synth.families(seed, n, length, family=max(2, n // 3))
+    seqs = list(seqs) + list(extra)
+    n = len(seqs)
+    pts = [ref_py.Point(dtype, s, k) for s in seqs]
+    model = ref_py.Model(dtype, os.path.join(HERE, weights))
+    out = {"k": k, "dtype": dtype, "n": n}
+    out["seqs"] = np.array(seqs, dtype=object)
+    metas = [p.meta() for p in pts]
+    out["mag"] = np.array([m["mag"] for m in metas], dtype=np.uint64)
+    out["length"] = np.array([m["length"] for m in metas], dtype=np.uint64)
+    out["stddev"] = np.array([m["stddev"] for m in metas])
+    out["one_mers"] = np.array([m["one_mers"] for m in metas], dtype=np.uint64)
+    for i, p in enumerate(pts):
+        ix, v = sparse(p.bins())
+        out["bins_idx_%d" % i] = ix
+        out["bins_val_%d" % i] = v
+    raw = np.zeros((n, n, len(FEATS)))
+    for i in range(n):
+        for j in range(n):
+            for f, (_, bit) in enumerate(FEATS):
+                raw[i, j, f] = ref_py.raw_feature(1 << bit, pts[i], pts[j])      # f(first=i, second=j)
+    out["raw"] = raw
+    ns = len(model.score(pts[0], pts[1])[0])
+    singles = np.zeros((n, n, ns))
+    sums = np.zeros((n, n))
+    csums = np.zeros((n, n))
+    pred = np.zeros((n, n))
+    close = np.zeros((n, n), dtype=np.uint8)
+    for i in range(n):
+        for j in range(n):
+            s, _, w, cs = model.score(pts[i], pts[j])
+            singles[i, j] = s
+            sums[i, j] = w
+            csums[i, j] = cs
+            pred[i, j] = model.predict(pts[i], pts[j])
+            close[i, j] = model.close(pts[i], pts[j])
+    out.update(singles=singles, sums=sums, csums=csums, predict=pred, close=close)
+    # Trainer operators: every point as the query against all the others, two cut-offs
+    for ci, cutoff in enumerate((0.9, 0.6)):
+        gc_flags = np.zeros((n, n - 1), dtype=np.uint8)
+        gc_best = np.zeros((n, 3))
+        flt = np.zeros((n, n - 1), dtype=np.uint8)
+        mrg = np.zeros(n, dtype=np.int64)
+        for q in range(n):
+            cands = [pts[c] for c in range(n) if c != q]
+            f, bp, bs, im = model.get_close(cutoff, pts[q], cands)
+            gc_flags[q] = f
+            gc_best[q] = (bp, bs, im)
+            flt[q] = model.filter(cutoff, pts[q], cands)
+            mrg[q] = model.merge(cutoff, pts, q, q + 1, min(n - 1, q + 6)) if q + 1 < n else 0
+        out["get_close_flags_%d" % ci] = gc_flags
+        out["get_close_best_%d" % ci] = gc_best
+        out["filter_%d" % ci] = flt
+        out["merge_%d" % ci] = mrg
+    out["cutoffs"] = np.array([0.9, 0.6])
+    members = list(range(0, n, 2))
+    mean, d, near = ref_py.mean_nearest([pts[i] for i in members])
+    out.update(mean_members=np.array(members), mean=mean, mean_dist=d, mean_nearest=near)
+    # stale-mag centre: clone of 0, then set(5)
+    c = pts[0].clone()
+    c.set(pts[min(5, n - 1)])
+    out["stale_mag"] = np.uint64(c.meta()["mag"])
+    out["stale_raw"] = np.array([ref_py.raw_feature(1 << bit, c, pts[min(3, n - 1)]) for _, bit in FEATS])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+def make_kat():
+    a, b = "ACGTACGTTTGACCAGTACGATCGATCGAT", "ACGTACGATTGACCAGTTCGATCGGATCGATAA"
+    out = {"A": a, "B": b, "k": 2}
+    for dt in (8, 16, 32, 64):
+        pa, pb = ref_py.Point(dt, a, 2), ref_py.Point(dt, b, 2)
+        out["u%d" % dt] = {
+            "hist_A": pa.bins().tolist(), "hist_B": pb.bins().tolist(), "one_mers_A": pa.meta()["one_mers"],
+            "raw": {nm: ref_py.raw_feature(1 << bit, pa, pb) for nm, bit in FEATS},
+            "distance": int(ref_py.lib().ref_distance(dt, pa.h, pb.h)),
+        }
+    json.dump(out, open(os.path.join(HERE, "kat_appendix_d.json"), "w"), indent=1)
+    print("wrote kat_appendix_d.json")
+
+
+NASTY = [
+    b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT" * 6,
+    b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat" * 9,
+]
+
+if __name__ == "__main__":
+    if not ref_py.available():
+        sys.exit("oracle/_ref is not built: run `make -C oracle ref` (needs /root/reference)")
+    make_kat()
+    make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
+    make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
+    make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)
+    make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)
+    make_vectors("vectors_k4_u8.npz", "weights_k5_u16.txt", 13, 10, 150, 4, 8)
+    make_vectors("vectors_k6_u64.npz", "weights_k5_u16.txt", 14, 8, 1500, 6, 64)

@@ -1,0 +1,35 @@
+"""Shared helpers for the golden fixtures in tests/golden/ (generated from the real reference by gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FEATS = [("manhattan", 2), ("euclidean", 3), ("normalized_vectors", 5), ("jefferey_divergence", 7), ("pearson", 9),
+         ("intersection", 13), ("emd", 18), ("length_difference", 21), ("kulczynski2", 27), ("simratio", 28), ("jensen_shannon", 29)]
+FEAT_BIT = dict(FEATS)
+# statistics whose value is an exact integer reduction pushed through the same FP64 expression: compared bitwise
+EXACT = {"manhattan", "euclidean", "normalized_vectors", "intersection", "emd", "length_difference", "kulczynski2", "simratio"}
+FAST = [f for f in FEATS if f[0] not in ("jefferey_divergence", "jensen_shannon")]
+VECTOR_SETS = [("vectors_k5_u16.npz", "weights_k5_u16.txt"), ("vectors_k9_u32.npz", "weights_k9_u32.txt"),
+               ("vectors_k4_u8.npz", "weights_k5_u16.txt"), ("vectors_k6_u64.npz", "weights_k5_u16.txt")]
+NP_T = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+
+def load_vectors(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=True)
+    return {k: z[k] for k in z.files}
+
+
+def dense_bins(v, i):
+    bins = np.ones(4 ** int(v["k"]), dtype=NP_T[int(v["dtype"])])
+    bins[v["bins_idx_%d" % i]] = v["bins_val_%d" % i]
+    return bins
+
+
+def weights_text(name):
+    return open(os.path.join(GOLDEN, name)).read()
+
+
+def kat():
+    return json.load(open(os.path.join(GOLDEN, "kat_appendix_d.json")))

@@ -1,0 +1,149 @@
+"""Pins oracle/msc_oracle.c (the travelling CPU restatement) against the REAL reference compiled from
+/root/reference (oracle/_ref/libmsc_ref.so). Runs only where that build exists (this container)."""
+import os
+
+import numpy as np
+import pytest
+
+from meshclust2_amd import synth
+
+pytestmark = pytest.mark.ref
+
+FEATS = ["manhattan", "euclidean", "normalized_vectors", "jefferey_divergence", "pearson", "intersection", "emd",
+         "length_difference", "kulczynski2", "simratio", "jensen_shannon"]
+WEIGHTS_K5 = os.path.join(os.path.dirname(__file__), "golden", "weights_k5_u16.txt")
+
+
+def _rand_seq(rng, n, alphabet=b"ACGT"):
+    return bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n))
+
+
+NASTY = [
+    b"ACGTACGTTTGACCAGTACGATCGATCGAT",
+    b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT",
+    b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat",
+    b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNN",
+    b"ACGTACGTACGTACGTACGTACGTNNNNNNNNNNNNNNNNNNNNNNA",       # run starting on the last char is lost
+    b"ACGTACGTACGTACGTACGTNNNNNNNNNNNNNNNACGTACGTACGTAC",      # second run shorter than 20 is dropped
+    b"ACGTACGTACGTACGTACGTACGNNNNNNNNNACGTACGTACGTACGTACGTACGT",   # gap of 9 N: merged, N -> C
+    b"ACGTNNACGTNNACGTNN",                                   # <= 20 chars: no merging
+    b"A" * 300,
+    b"ACGT" * 5 + b"N" + b"TTGCA" * 7 + b"N" * 10 + b"GATTACA" * 9,
+]
+
+
+@pytest.mark.parametrize("seq", NASTY)
+def test_encode_matches_reference(oracle, ref, seq):
+    oc, osegs, oeff = oracle.encode(seq)
+    rc, rsegs, reff = ref.encode(seq)
+    assert osegs == rsegs
+    assert oeff == reff
+    assert oc == rc
+
+
+def test_encode_invalid_char_rejected(oracle, ref):
+    bad = b"ACGTACGTACGTACGTACGTACGT-ACGTACGTACGT"
+    with pytest.raises(ValueError):
+        ref.encode(bad)
+    with pytest.raises(ValueError):
+        oracle.encode(bad)
+
+
+@pytest.mark.parametrize("dtype", [8, 16, 32, 64])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7])
+def test_histogram_bit_exact(oracle, ref, dtype, k):
+    rng = np.random.default_rng(100 * dtype + k)
+    seqs = NASTY + [_rand_seq(rng, n) for n in (25, 100, 1000, 3000)] + [_rand_seq(rng, 400, b"ACGTN")] + [b"AC" * 400]
+    for s in seqs:
+        for strip in (False, True):
+            h = oracle.hist(s, k, dtype, strip)
+            p = ref.Point(dtype, s, k, strip=strip)
+            assert np.array_equal(h.array(), p.bins()), (s[:30], strip)
+            m = p.meta()
+            assert (h.mag, h.length, list(h.one_mers)) == (m["mag"], m["length"], m["one_mers"])
+            assert h.stddev == pytest.approx(m["stddev"], rel=1e-14, abs=1e-300)
+            oracle.lib().orc_hist_free(h)
+
+
+@pytest.mark.parametrize("dtype,k,n,length", [(16, 5, 24, 1000), (32, 5, 12, 600), (8, 4, 12, 150), (64, 6, 10, 2000), (32, 9, 6, 1000), (8, 9, 4, 1000)])
+def test_raw_features_match_reference(oracle, ref, dtype, k, n, length):
+    seqs, _ = synth.families(7 + dtype + k, n, length, family=4)
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    rp = [ref.Point(dtype, s, k) for s in seqs]
+    for i in range(n):
+        for j in range(n):
+            for name in FEATS:
+                f = oracle.FEAT[name]
+                a = oracle.raw_feature(f, oh[i], oh[j])
+                b = ref.raw_feature(f, rp[i], rp[j])
+                if name in ("manhattan", "euclidean", "normalized_vectors", "intersection", "emd", "length_difference", "kulczynski2", "simratio"):
+                    assert a == b, (name, i, j)           # integer accumulators + same FP64 expression: bitwise
+                else:
+                    assert a == pytest.approx(b, rel=1e-11, abs=1e-15), (name, i, j)
+
+
+def test_simratio_u32_bug_is_reproduced(oracle, ref):
+    """`intmax_t diff = p - q` wraps for uint32_t bins; the oracle restates it literally."""
+    a, b = b"ACGTACGTTTGACCAGTACGATCGATCGAT", b"ACGTACGATTGACCAGTTCGATCGGATCGATAA"
+    vals = {}
+    for dt in (16, 32, 64):
+        vals[dt] = oracle.raw_feature(oracle.FEAT["simratio"], oracle.hist(a, 2, dt), oracle.hist(b, 2, dt))
+        assert vals[dt] == ref.raw_feature(oracle.FEAT["simratio"], ref.Point(dt, a, 2), ref.Point(dt, b, 2))
+    assert vals[16] == vals[64] == pytest.approx(0.98467525965178482, rel=1e-15)
+    assert vals[32] < 1e-6
+
+
+def test_model_scoring_and_trainer_ops(oracle, ref):
+    text = open(WEIGHTS_K5).read()
+    pred = oracle.predictor(text)
+    rm = ref.Model(16, WEIGHTS_K5)
+    seqs, _ = synth.families(99, 40, 1000, family=8)
+    # some different lengths so that the length windows bite
+    seqs += [s[:700] for s in seqs[:4]] + [s + s[:300] for s in seqs[4:8]]
+    oh = [oracle.hist(s, 5, 16) for s in seqs]
+    rp = [ref.Point(16, s, 5) for s in seqs]
+    n = len(seqs)
+    for i in range(0, n, 5):
+        for j in range(n):
+            s, c, w = oracle.score(pred.cls, oh[j], oh[i])
+            rs, rc, rw, rcs = rm.score(rp[j], rp[i])
+            assert np.allclose(s, rs, rtol=1e-12, atol=1e-15)
+            assert w == pytest.approx(rw, rel=1e-11, abs=1e-13)
+            assert oracle.lib().orc_classify(pred, oh[j], oh[i]) == pytest.approx(rcs, rel=1e-12)
+            assert oracle.lib().orc_p_predict(pred, oh[j], oh[i]) == pytest.approx(rm.predict(rp[j], rp[i]), rel=1e-11, abs=1e-13)
+            assert bool(oracle.lib().orc_p_close(pred, oh[j], oh[i])) == rm.close(rp[j], rp[i])
+    for cutoff in (0.9, 0.6):
+        for q in (0, 7, 13, 41, 45):
+            cands = [x for x in range(n) if x != q]
+            of, obp, obs, omin = oracle.get_close(pred, cutoff, oh[q], [oh[c] for c in cands])
+            rf, rbp, rbs, rmin = rm.get_close(cutoff, rp[q], [rp[c] for c in cands])
+            assert np.array_equal(of, rf) and obp == rbp and omin == rmin
+            assert obs == pytest.approx(rbs, rel=1e-12)
+            of2, obp2, obs2, omin2 = oracle.get_close(pred, cutoff, oh[q], [oh[c] for c in cands], omp=True)
+            assert np.array_equal(of, of2) and (obp, obs, omin) == (obp2, obs2, omin2)
+            ok = oracle.filter_(pred, cutoff, oh[q], [oh[c] for c in cands])
+            rk = rm.filter(cutoff, rp[q], [rp[c] for c in cands])
+            assert np.array_equal(ok, rk)
+        for cur in (0, 3, 10):
+            last = min(n - 1, cur + 12)
+            assert oracle.merge(pred, cutoff, oh, cur, cur + 1, last) == rm.merge(cutoff, rp, cur, cur + 1, last)
+
+
+@pytest.mark.parametrize("dtype,k", [(16, 5), (32, 6), (8, 4)])
+def test_mean_nearest_and_stale_mag(oracle, ref, dtype, k):
+    seqs, _ = synth.families(5, 17, 800, family=17)
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    rp = [ref.Point(dtype, s, k) for s in seqs]
+    om, od, onear = oracle.mean_nearest(oh)
+    rmn, rd, rnear = ref.mean_nearest(rp)
+    assert np.array_equal(om, rmn) and np.allclose(od, rd, rtol=1e-12, atol=0) and onear == rnear
+    # Center = clone (mag re-summed), then centre->set(*next) copies bins but not mag
+    oc = oracle.Hist()
+    oracle.lib().orc_hist_clone(oh[0], oc)
+    rc = rp[0].clone()
+    oracle.lib().orc_hist_set(oc, oh[5])
+    rc.set(rp[5])
+    assert oc.mag == rc.meta()["mag"] == rp[0].meta()["mag"]
+    for name in ("intersection", "pearson", "kulczynski2", "jefferey_divergence", "jensen_shannon"):
+        f = oracle.FEAT[name]
+        assert oracle.raw_feature(f, oc, oh[9]) == pytest.approx(ref.raw_feature(f, rc, rp[9]), rel=1e-11)
