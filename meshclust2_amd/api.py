@@ -6,6 +6,7 @@ similarity -> Predictor.*. Everything here is plumbing (ctypes marshalling); the
 libmeshclust2_hip.so on the GPU.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -30,6 +31,10 @@ class Context:
             raise MscError(rc, self.lib.msc_last_error(None).decode())
         self.h = h
         self.device = device
+        self._children = []          # weakrefs to sets / models so that close() can release them before the ctx
+
+    def _adopt(self, obj):
+        self._children.append(weakref.ref(obj))
 
     def check(self, rc):
         if rc != 0:
@@ -51,6 +56,11 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in self._children:
+                obj = ref()
+                if obj is not None:
+                    obj.close()
+            self._children = []
             self.lib.msc_destroy(self.h)
             self.h = None
 
@@ -85,6 +95,7 @@ class HistogramSet:
         ctx.check(ctx.lib.msc_hist_set_create(ctx.h, self.k, self.dtype, self.capacity, C.byref(h)))
         self.h = h
         self.nbins = 4 ** self.k
+        ctx._adopt(self)
 
     def nbytes(self):
         return self.ctx.lib.msc_hist_set_bytes(self.h)
@@ -145,9 +156,9 @@ class HistogramSet:
         self.ctx.check(self.ctx.lib.msc_hist_import_done(self.ctx.h, self.h, first_slot, n))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
             self.ctx.lib.msc_hist_set_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -171,6 +182,7 @@ class Feature:
         self.k = ctx.lib.msc_model_k(handle)
         self.n_singles = ctx.lib.msc_model_n_singles(handle)
         self.n_combos = ctx.lib.msc_model_n_combos(handle)
+        ctx._adopt(self)
 
     @classmethod
     def from_file(cls, ctx, path, block=0):
@@ -219,9 +231,15 @@ class Feature:
         return dict(singles=singles, combos=combos, sum=s, csum=cs)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
             self.ctx.lib.msc_model_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pair_features_raw(ctx, cands, cand_slots, qset, q_slot, feat_mask=FEAT_FAST, order=ORDER_CAND_FIRST, m=None):

@@ -1,0 +1,209 @@
+"""GPU parity proper: libmeshclust2_hip.so (through the C ABI) against the CPU oracle on the same seeded inputs and
+against the committed golden fixtures (reference outputs). Integer work is compared bit-exact; FP64 scores to 1e-9
+relative (the north-star bar is 1e-5)."""
+import numpy as np
+import pytest
+
+from golden_util import EXACT, FAST, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors, weights_text
+from meshclust2_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+FAST_MASK = sum(1 << b for _, b in FAST)
+FAST_COLS = [i for i, (n, _) in enumerate(FEATS) if n not in ("jefferey_divergence", "jensen_shannon")]
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def test_context_is_gfx950(ctx):
+    assert "gfx950" in ctx.device_name()
+
+
+def test_appendix_d_known_answers(ctx):
+    k = kat()
+    for dt in (8, 16, 32, 64):
+        g = k["u%d" % dt]
+        hs = api.HistogramSet(ctx, 2, dt, 2)
+        hs.build([k["A"], k["B"]])
+        assert hs.download(0).tolist() == g["hist_A"] and hs.download(1).tolist() == g["hist_B"]
+        assert hs.info(0)["one_mers"] == g["one_mers_A"]
+        raw = api.pair_features_raw(ctx, hs, [0], hs, 1, FAST_MASK, api.ORDER_CAND_FIRST)[0]
+        for col, (name, _) in zip(raw, FAST):
+            assert col == pytest.approx(g["raw"][name], rel=1e-13), (dt, name)
+
+
+@pytest.mark.parametrize("vec,wts", VECTOR_SETS)
+def test_golden_vectors(ctx, vec, wts):
+    v = load_vectors(vec)
+    k, dt, n = int(v["k"]), int(v["dtype"]), int(v["n"])
+    hs = api.HistogramSet(ctx, k, dt, n + 2)
+    hs.build([bytes(s) for s in v["seqs"]])
+    for i in range(n):
+        assert np.array_equal(hs.download(i), dense_bins(v, i)), i           # bit-exact k-mer counts
+        inf = hs.info(i)
+        assert (inf["mag"], inf["length"], inf["one_mers"]) == (int(v["mag"][i]), int(v["length"][i]), v["one_mers"][i].tolist())
+        assert inf["stddev"] == pytest.approx(float(v["stddev"][i]), rel=1e-10)
+    everyone = np.arange(n, dtype=np.uint32)
+    for q in range(n):
+        for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+            raw = api.pair_features_raw(ctx, hs, everyone, hs, q, FAST_MASK, order)
+            exp = v["raw"][:, q, :] if order == api.ORDER_CAND_FIRST else v["raw"][q, :, :]
+            for c, col in enumerate(FAST_COLS):
+                name = FEATS[col][0]
+                if name in EXACT and name not in ("kulczynski2",):
+                    assert np.array_equal(raw[:, c], exp[:, col]), (name, q, order)
+                else:
+                    assert np.allclose(raw[:, c], exp[:, col], rtol=RTOL, atol=1e-13), (name, q, order)
+    feat = api.Feature.from_text(ctx, weights_text(wts), 0)
+    reg = api.Feature.from_text(ctx, weights_text(wts), 1)
+    for q in range(n):
+        r = feat.compute(hs, everyone, hs, q, api.ORDER_CAND_FIRST)
+        assert np.allclose(r["singles"], v["singles"][:, q, :], rtol=RTOL, atol=1e-12)
+        assert np.allclose(r["sum"], v["sums"][:, q], rtol=1e-8, atol=1e-10)
+        assert np.allclose(r["csum"], v["csums"][:, q], rtol=RTOL)
+        close, sim = api.Predictor(ctx, feat, reg).search(hs, everyone, hs, q)
+        assert np.array_equal(close, v["close"][:, q])
+        assert np.allclose(sim, v["predict"][:, q], rtol=1e-8, atol=1e-10)
+    for ci, cutoff in enumerate(v["cutoffs"]):
+        trn = api.Trainer(ctx, feat, float(cutoff))
+        for q in range(n):
+            cands = np.array([c for c in range(n) if c != q], dtype=np.uint32)
+            flags, bp, bs, im = trn.get_close(hs, cands, hs, q)
+            assert np.array_equal(flags, v["get_close_flags_%d" % ci][q]), (cutoff, q)
+            gbp, gbs, gim = v["get_close_best_%d" % ci][q]
+            assert (bp, im) == (int(gbp), bool(gim)) and bs == pytest.approx(gbs, rel=RTOL)
+            assert np.array_equal(trn.filter(hs, q, hs, cands), v["filter_%d" % ci][q]), (cutoff, q)
+            if q + 1 < n:
+                assert trn.merge(hs, everyone, q, q + 1, min(n - 1, q + 6)) == int(v["merge_%d" % ci][q])
+    pos, d, mean = api.mean_nearest(ctx, hs, v["mean_members"].astype(np.uint32), want_mean=True)
+    assert np.array_equal(mean, v["mean"]) and pos == int(v["mean_nearest"])
+    assert np.allclose(d, v["mean_dist"], rtol=1e-12, atol=0)
+    # Center semantics: clone re-sums mag, set() keeps the stale one
+    hs.clone_from(n, hs, 0)
+    hs.assign_from(n, hs, min(5, n - 1))
+    assert hs.info(n)["mag"] == int(v["stale_mag"])
+    assert np.array_equal(hs.download(n), dense_bins(v, min(5, n - 1)))
+    raw = api.pair_features_raw(ctx, hs, [n], hs, min(3, n - 1), FAST_MASK, api.ORDER_CAND_FIRST)[0]
+    assert np.allclose(raw, v["stale_raw"][FAST_COLS], rtol=RTOL, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype,k,n,length", [(32, 9, 48, 1000), (16, 5, 200, 1000), (8, 9, 24, 1000), (8, 3, 16, 60), (16, 1, 8, 30),
+                                              (32, 2, 12, 40), (64, 7, 12, 3000), (16, 8, 16, 5000), (32, 11, 4, 20000)])
+def test_against_oracle_seeded(ctx, oracle, dtype, k, n, length):
+    seqs, _ = synth.families(1000 + 7 * k + dtype, n, length, family=8)
+    seqs = list(seqs) + [seqs[0][: max(length // 2, 25)], seqs[1] + seqs[2][: length // 3]]
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n)
+    hs.build(seqs)
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    for i in range(n):
+        assert np.array_equal(hs.download(i), oh[i].array())
+        inf = hs.info(i)
+        assert (inf["mag"], inf["length"], inf["one_mers"], inf["overflow"]) == (oh[i].mag, oh[i].length, list(oh[i].one_mers), oh[i].overflow)
+    rng = np.random.default_rng(k)
+    cands = rng.permutation(n).astype(np.uint32)
+    for q in (0, n - 1, n // 2):
+        raw = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, api.ORDER_CAND_FIRST)
+        for i, c in enumerate(cands):
+            for col, (name, bit) in zip(raw[i], FAST):
+                exp = oracle.raw_feature(1 << bit, oh[c], oh[q])
+                if name in EXACT and name != "kulczynski2":
+                    assert col == exp, (name, c, q)
+                else:
+                    assert col == pytest.approx(exp, rel=RTOL, abs=1e-13), (name, c, q)
+    # identity m = None (slots 0..m-1) path
+    raw2 = api.pair_features_raw(ctx, hs, None, hs, 0, FAST_MASK, api.ORDER_CAND_FIRST, m=n)
+    raw3 = api.pair_features_raw(ctx, hs, np.arange(n, dtype=np.uint32), hs, 0, FAST_MASK, api.ORDER_CAND_FIRST)
+    assert np.array_equal(raw2, raw3)
+    mem = np.arange(0, n, 2, dtype=np.uint32)
+    pos, d, mean = api.mean_nearest(ctx, hs, mem, want_mean=True)
+    om, od, onear = oracle.mean_nearest([oh[i] for i in mem])
+    assert np.array_equal(mean, om) and pos == onear and np.allclose(d, od, rtol=1e-12, atol=0)
+
+
+def test_saturation_and_overflow_flag(ctx, oracle):
+    seqs = [b"A" * 700 + b"C" * 30, b"ACGT" * 200, b"AC" * 40000]
+    for dtype, k in ((8, 3), (16, 2), (8, 6)):
+        hs = api.HistogramSet(ctx, k, dtype, len(seqs))
+        hs.build(seqs)
+        for i, s in enumerate(seqs):
+            o = oracle.hist(s, k, dtype)
+            assert np.array_equal(hs.download(i), o.array())
+            assert hs.info(i)["overflow"] == o.overflow
+            assert hs.info(i)["mag"] == o.mag
+
+
+def test_encoding_edge_cases_through_build(ctx, oracle):
+    nasty = [
+        b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT",
+        b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat",
+        b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNN", b"", b"ACG",
+        b"ACGTACGTACGTACGTACGTACGTNNNNNNNNNNNNNNNNNNNNNNA",
+        b"ACGTACGTACGTACGTACGTNNNNNNNNNNNNNNNACGTACGTACGTAC",
+        b"ACGTACGTACGTACGTACGTACGNNNNNNNNNACGTACGTACGTACGTACGTACGT",
+        b"ACGTNNACGTNNACGTNN",
+    ]
+    for strip in (False, True):
+        hs = api.HistogramSet(ctx, 4, 16, len(nasty))
+        hs.build(nasty, strip=strip)
+        for i, s in enumerate(nasty):
+            o = oracle.hist(s, 4, 16, strip)
+            assert np.array_equal(hs.download(i), o.array()), (i, strip)
+            assert hs.info(i)["length"] == o.length
+    for s in nasty:
+        assert api.encode(s) == oracle.encode(s)
+    with pytest.raises(api.MscError) as e:
+        api.HistogramSet(ctx, 4, 16, 1).build([b"ACGTACGTACGTACGTACGTAC-GTACGTACGTACGTACGT"])
+    assert e.value.code == -5
+
+
+def test_zero_length_point_is_an_error(ctx):
+    txt = weights_text("weights_k5_u16.txt")
+    feat = api.Feature.from_text(ctx, txt, 0)
+    hs = api.HistogramSet(ctx, 5, 16, 2)
+    hs.build([b"ACGT" * 50, b"N" * 40])
+    with pytest.raises(api.MscError) as e:
+        feat.compute(hs, [1], hs, 0)
+    assert e.value.code == -6        # the reference throws 123 (predict/Feature.cpp:878-886)
+
+
+def test_unsupported_inputs_fail_loudly(ctx):
+    with pytest.raises(api.MscError):
+        api.HistogramSet(ctx, 14, 32, 1)
+    hs = api.HistogramSet(ctx, 3, 32, 2)
+    hs.build([b"ACGT" * 10, b"ACGT" * 10])
+    with pytest.raises(api.MscError):
+        api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 1)          # hellinger: out of scope
+    with pytest.raises(api.MscError):
+        api.Feature.create(ctx, 3, [(0, 1 << 12)], [0.0, 1.0], [(1 << 12, 0.0, 1.0)])    # markov
+
+
+def test_upload_round_trip_and_properties(ctx):
+    """Size-independent properties: symmetric statistics, self-pair identities, checksum of checksums."""
+    rng = np.random.default_rng(3)
+    k, dt, n = 7, 32, 6
+    hs = api.HistogramSet(ctx, k, dt, n)
+    data = [rng.integers(1, 40, size=4 ** k).astype(np.uint32) for _ in range(n)]
+    for i, b in enumerate(data):
+        hs.upload(i, b, 1000 + i)
+        assert np.array_equal(hs.download(i), b)
+        assert hs.info(i)["sum"] == int(b.sum()) and hs.info(i)["sum_sq"] == int((b.astype(np.uint64) ** 2).sum())
+    ev = np.arange(n, dtype=np.uint32)
+    m = np.stack([api.pair_features_raw(ctx, hs, ev, hs, q, FAST_MASK & ~(1 << 28)) for q in range(n)])    # [q, c, f]
+    assert np.array_equal(m, m.transpose(1, 0, 2))                       # symmetric (simratio/u32 excluded: SURVEY Q3)
+    names = [nm for nm, b in FAST if b != 28]
+    for q in range(n):
+        row = dict(zip(names, m[q, q]))
+        assert row["manhattan"] == 0 and row["euclidean"] == 0 and row["emd"] == 0 and row["intersection"] == 1.0
+        assert row["normalized_vectors"] == pytest.approx(1.0, abs=1e-15) and row["pearson"] == pytest.approx(1.0, abs=1e-12)
+    for q in range(n):
+        for c in range(n):
+            d = data[q].astype(np.int64) - data[c].astype(np.int64)
+            assert m[q, c, names.index("manhattan")] == np.abs(d).sum()
+            assert m[q, c, names.index("emd")] == np.abs(np.cumsum(d)).sum()
