@@ -34,7 +34,7 @@ struct msc_ctx {
 	char dev_name[128] = {0};
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
-	    floor_sum, mean;
+	    floor_sum, mean, div_tables, div_partials;
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 };
 
@@ -135,7 +135,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
-	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean};
+	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
+	                  &ctx->div_tables, &ctx->div_partials};
 	for (DevBuf* b : bufs) release(*b);
 	(void)hipEventDestroy(ctx->ev_tiles0);
 	(void)hipEventDestroy(ctx->ev_tiles1);
@@ -551,10 +552,11 @@ static int feat_is_sim(uint64_t f) {      // Feature<T>::feat_is_sim, predict/Fe
 	switch (f) {
 	case MSC_FEAT_NORMALIZED_VECTORS: case MSC_FEAT_PEARSON_COEFF: case MSC_FEAT_INTERSECTION: case MSC_FEAT_KULCZYNSKI2: case MSC_FEAT_SIMRATIO:
 		return 1;
-	case MSC_FEAT_MANHATTAN: case MSC_FEAT_EUCLIDEAN: case MSC_FEAT_EMD: case MSC_FEAT_LENGTHD:
+	case MSC_FEAT_MANHATTAN: case MSC_FEAT_EUCLIDEAN: case MSC_FEAT_EMD: case MSC_FEAT_LENGTHD: case MSC_FEAT_JEFFEREY_DIV:
+	case MSC_FEAT_JENSEN_SHANNON:
 		return 0;
 	default:
-		return -1;     // JEFFEREY_DIV / JENSEN_SHANNON: not yet on the GPU path; everything else is out of scope
+		return -1;     // the other 23 statistics of predict/Feature.h are `extraslow` only: out of scope
 	}
 }
 
@@ -737,6 +739,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const int nf = __builtin_popcountll(rq.feat_mask);
 	const int ns = rq.model ? rq.model->h.n_singles : 0;
 	const int nc = rq.model ? rq.model->h.n_combos : 0;
+	uint64_t want = rq.feat_mask;
+	if (rq.model) for (int i = 0; i < ns; i++) want |= rq.model->h.single_flag[i];
+	const bool need_div = (want & MSC_FEAT_DIV) != 0 && !rq.only_tiles;
+	const int tb = msc_div_table_dim(L);
 	ctx->tiles_ms_accum = 0.f;
 	ctx->have_timing = false;
 	if (m == 0) {
@@ -753,6 +759,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	if (rq.cand_slots) {
 		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t))) != MSC_OK) return r;
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, rq.cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	if (need_div) {
+		if ((r = ensure(ctx, ctx->div_tables, chunk * tb * tb * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_partials, chunk * L.S * 16)) != MSC_OK) return r;
 	}
 	if (!rq.only_tiles) {
 		if ((r = ensure(ctx, ctx->pair_out, chunk * sizeof(MscPairOut))) != MSC_OK) return r;
@@ -774,7 +784,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		HIP_TRY(ctx, msc_launch_pair_tiles(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
-		                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_tables.p : nullptr,
+		                                   need_div ? ctx->div_partials.p : nullptr, rq.order));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (rq.only_tiles) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
@@ -783,6 +794,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
+		ea.div_partials = need_div ? ctx->div_partials.p : nullptr;
 		ea.S = L.S;
 		ea.m = mc;
 		ea.cand_scalars = c_scal;
@@ -840,7 +852,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	return MSC_OK;
 }
 
-const uint64_t kSupportedFeats = MSC_FEAT_FAST;
+const uint64_t kSupportedFeats = MSC_FEAT_SLOW;
 
 double trainer_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }      // cluster/Trainer.h:35
 

@@ -52,6 +52,7 @@ enum { MSC_REDUCE_GET_CLOSE = 0, MSC_REDUCE_MERGE = 1 };
 // epilogue request
 struct MscEpilogueArgs {
 	const MscPartial* partials;       // [m][S]
+	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
 	uint32_t m;
 	const uint8_t* cand_scalars;      // scalar records of the candidate set
@@ -87,7 +88,8 @@ hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype,
                                  const uint8_t* cand_bins, const uint8_t* cand_scalars, const uint32_t* cand_slots,
                                  uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
                                  int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials,
-                                 int num_cus);
+                                 int num_cus, void* div_tables /*nullable*/, void* div_partials, int order);
+int msc_div_table_dim(const MscLayout& L);      // 8 or 16: side of the per-candidate (count, count) term table
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out);

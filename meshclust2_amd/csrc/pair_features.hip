@@ -87,22 +87,73 @@ __device__ __forceinline__ void load_tile(TileRegs<LPT>& t, const uint8_t* tile_
 	for (int l = 0; l < LPT; l++) t.v[l] = __builtin_nontemporal_load(p + 64 * l);
 }
 
-template <typename T, int LPT, bool PADDED>
+// ---- divergence statistics (`--feat slow`: jefferey_divergence, jensen_shannon; predict/Feature.cpp:1231-1263,984-1009)
+// Both are sums over bins of a function of the two COUNTS (a, b) and of the two stored magnitudes only. Counts are
+// small integers, so per candidate a TB x TB table of the exact per-bin terms is evaluated once (k_div_tables, 2-3
+// FP64 logs per entry instead of per bin) and the streaming pass turns each bin into one LDS lookup + two FP64 adds.
+// Bins with a count >= TB (rare) are re-read from memory and evaluated directly with the same expression.
+struct DivTerm {
+	double jd, js;
+};
+
+__device__ __forceinline__ DivTerm div_term(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {
+	DivTerm t{0.0, 0.0};
+	if (cand_count == 0 || q_count == 0) return t;        // pad bins of tiny histograms
+	const bool cf = order == MSC_ORDER_CAND_FIRST;
+	const double pp = cf ? (double)cand_count / cand_mag : (double)q_count / q_mag;     // (double)p.points[i] / mp
+	const double pq = cf ? (double)q_count / q_mag : (double)cand_count / cand_mag;
+	const double diff = pp - pq;
+	t.jd = diff * log(pp / pq);
+	const double avg = 0.5 * (pp + pq);
+	t.js = pp * log(pp / avg) + pq * log(pq / avg);
+	return t;
+}
+
+template <int TB>
+__global__ void __launch_bounds__(TB * TB) k_div_tables(const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                       const uint32_t* __restrict__ cand_slots, uint32_t m,
+                                                       const uint8_t* __restrict__ q_scalars, int order, DivTerm* __restrict__ tables) {
+	const uint32_t c = blockIdx.x;
+	if (c >= m) return;
+	const uint32_t slot = cand_slots ? cand_slots[c] : c;
+	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride)->mag;
+	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	const uint32_t j = threadIdx.x;
+	tables[(uint64_t)c * TB * TB + j] = div_term(j / TB, j % TB, cm, qm, order);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+struct MscPartialDiv {
+	double jd, js;
+};
+
+template <typename T, int LPT, bool PADDED, int TB>
 __global__ void __launch_bounds__(kBlock) k_pair_tiles(
     const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
     const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_bins, const uint8_t* __restrict__ q_scalars,
     uint32_t S, uint32_t G, uint32_t nvalid /* bins of the (single) tile that are real */,
-    int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials) {
+    int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials,
+    const DivTerm* __restrict__ div_tables, MscPartialDiv* __restrict__ div_partials, int order) {
 	constexpr int E = 16 / sizeof(T);
 	constexpr int R = LPT * E;
-	constexpr int NW = 4 * LPT;
 	constexpr uint32_t tile_bytes = 1024u * LPT;
+	constexpr bool DIV = TB > 0;
+	constexpr int TPL = DIV ? (TB * TB) / 64 : 1;          // table entries per lane
+
+	__shared__ DivTerm s_tbl[DIV ? kWavesPerBlock * TB * TB : 1];
 
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	const uint32_t wave_in_block = threadIdx.x >> 6;
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block);
 	const uint32_t s = W % S;
 	const uint32_t g = W / S;
 	if (g >= G) return;
+	DivTerm* my_tbl = s_tbl + (DIV ? wave_in_block * TB * TB : 0);
 
 	// ---- query tile: registers for the whole launch
 	TileRegs<LPT> qt;
@@ -113,7 +164,6 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 #pragma unroll
 	for (int r = 0; r < R; r++) tq += ElemOps<T>::get(qw, r);
 	const uint32_t cq0 = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;     // prefix(q) just before this lane's run
-	(void)NW;
 
 	auto slot_of = [&](uint32_t c) -> uint32_t { return cand_slots ? cand_slots[c] : c; };
 	auto in_window = [&](uint32_t slot) -> bool {
@@ -124,30 +174,36 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 
 	// ---- software pipeline, one candidate ahead
 	TileRegs<LPT> nxt;
-	uint32_t nxt_carry = 0;
+	DivTerm nxt_tbl[TPL];
+	uint32_t nxt_carry = 0, nxt_slot = 0;
 	bool nxt_ok = false;
-	uint32_t c = g;
-	if (c < m) {
-		const uint32_t slot = slot_of(c);
+	auto prefetch = [&](uint32_t cand) {
+		const uint32_t slot = slot_of(cand);
+		nxt_slot = slot;
 		nxt_ok = in_window(slot);
 		if (nxt_ok) {
 			load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
 			nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+			if constexpr (DIV) {
+#pragma unroll
+				for (int i = 0; i < TPL; i++) nxt_tbl[i] = div_tables[(uint64_t)cand * TB * TB + i * 64 + lane];
+			}
 		}
-	}
+	};
+	uint32_t c = g;
+	if (c < m) prefetch(c);
 	for (; c < m; c += G) {
 		const TileRegs<LPT> cur = nxt;
 		const uint32_t carry = nxt_carry;
+		const uint32_t cur_slot = nxt_slot;
 		const bool ok = nxt_ok;
-		const uint32_t cn = c + G;
-		if (cn < m) {
-			const uint32_t slot = slot_of(cn);
-			nxt_ok = in_window(slot);
-			if (nxt_ok) {
-				load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
-				nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+		if constexpr (DIV) {
+			if (ok) {
+#pragma unroll
+				for (int i = 0; i < TPL; i++) my_tbl[i * 64 + lane] = nxt_tbl[i];      // wave-private: LDS ops of one wave are ordered
 			}
 		}
+		if (c + G < m) prefetch(c + G);
 		if (!ok) continue;
 
 		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
@@ -157,6 +213,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 		uint32_t cp = carry + wave_incl_scan(tp) - tp;
 		uint32_t cq = cq0;
 		uint32_t manh = 0, dot = 0, emd = 0;
+		double jd = 0.0, js = 0.0;
+		uint32_t any_big = 0;
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			const uint32_t p = ElemOps<T>::get(pw, r);
@@ -171,16 +229,48 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 			}
 			manh = __usad(p, q, manh);
 			dot = __umul24(p, q) + dot;
+			if constexpr (DIV) {
+				const uint32_t big = (p | q) >= (uint32_t)TB ? 1u : 0u;
+				const DivTerm t = my_tbl[big ? 0u : p * TB + q];          // entry (0,0) is {0,0}
+				jd += t.jd;
+				js += t.js;
+				any_big |= big;
+			}
+		}
+		if constexpr (DIV) {
+			if (__any(any_big)) {
+				// rare: some count >= TB. Re-read this lane's run from memory (no dynamic register indexing) and
+				// evaluate those bins directly with the reference's expression.
+				const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)cur_slot * scalar_stride)->mag;
+				const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+				const T* pt = reinterpret_cast<const T*>(cand_bins + (uint64_t)cur_slot * slot_bytes + (uint64_t)s * tile_bytes);
+				const T* qtp = reinterpret_cast<const T*>(q_bins + (uint64_t)s * tile_bytes);
+#pragma unroll 1
+				for (int r = 0; r < R; r++) {
+					const uint32_t off = (uint32_t)(r / E) * (64 * E) + lane * E + (uint32_t)(r % E);
+					const uint32_t p = (uint32_t)pt[off], q = (uint32_t)qtp[off];
+					if ((p | q) >= (uint32_t)TB) {
+						const DivTerm t = div_term(p, q, cm, qm, order);
+						jd += t.jd;
+						js += t.js;
+					}
+				}
+			}
 		}
 		const uint32_t manh_t = wave_total_u32(manh);
 		const uint64_t dot_t = wave_total_u64(dot);
 		const uint64_t emd_t = wave_total_u64(emd);
+		if constexpr (DIV) {
+			jd = wave_sum_f64(jd);
+			js = wave_sum_f64(js);
+		}
 		if (lane == 0) {
 			MscPartial out;
 			out.manh = manh_t;
 			out.dot = dot_t;
 			out.emd = emd_t;
 			partials[(uint64_t)c * S + s] = out;
+			if constexpr (DIV) div_partials[(uint64_t)c * S + s] = MscPartialDiv{jd, js};
 		}
 	}
 }
@@ -188,6 +278,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 // ---------------------------------------------------------------------------------------- epilogue
 struct PairTotals {
 	uint64_t manh, dot, emd;
+	double jd, js;
 };
 
 struct Side {
@@ -239,6 +330,10 @@ __device__ double raw_stat(uint64_t flag, const PairTotals& t, const Side& a, co
 		}
 		return (double)t.dot / ((double)t.dot + sqrt((double)norm2));
 	}
+	case MSC_FEAT_JEFFEREY_DIV:        // :1235-1262
+		return t.jd;
+	case MSC_FEAT_JENSEN_SHANNON:      // :988-1008, `return sum / 2`
+		return t.js / 2;
 	default:
 		*err = MSC_ERR_UNSUPPORTED;
 		return NAN;
@@ -319,24 +414,33 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogue
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
 	if (c >= a.m) return;
-	PairTotals t{0, 0, 0};
+	PairTotals t{0, 0, 0, 0.0, 0.0};
 	for (uint32_t s = lane; s < a.S; s += 64) {
 		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
 		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		if (a.div_partials) {
+			const MscPartialDiv d = reinterpret_cast<const MscPartialDiv*>(a.div_partials)[(uint64_t)c * a.S + s];
+			t.jd += d.jd; t.js += d.js;
+		}
 	}
 	t.manh = shfl_sum_u64(t.manh);
 	t.dot = shfl_sum_u64(t.dot);
 	t.emd = shfl_sum_u64(t.emd);
+	if (a.div_partials) { t.jd = wave_sum_f64(t.jd); t.js = wave_sum_f64(t.js); }
 	if (lane == 0) epilogue_one(a, c, t);
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= a.m) return;
-	PairTotals t{0, 0, 0};
+	PairTotals t{0, 0, 0, 0.0, 0.0};
 	for (uint32_t s = 0; s < a.S; s++) {
 		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
 		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		if (a.div_partials) {
+			const MscPartialDiv d = reinterpret_cast<const MscPartialDiv*>(a.div_partials)[(uint64_t)c * a.S + s];
+			t.jd += d.jd; t.js += d.js;
+		}
 	}
 	epilogue_one(a, c, t);
 }
@@ -491,10 +595,11 @@ __global__ void __launch_bounds__(kBlock) k_colsum(const T* __restrict__ bins, u
 }  // namespace
 
 // ======================================================================================== launchers
-template <typename T, int LPT>
+template <typename T, int LPT, int TB>
 static hipError_t launch_tiles_t(hipStream_t st, const MscLayout& L, const uint8_t* cand_bins, const uint8_t* cand_scalars,
                                  const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins, const uint8_t* q_scalars,
-                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus,
+                                 void* div_tables, void* div_partials, int order) {
 	const uint32_t S = L.S;
 	// enough waves to fill the chip (8 per SIMD), at least one candidate group, at most one group per candidate
 	const uint64_t target_waves = (uint64_t)num_cus * 32;
@@ -505,35 +610,53 @@ static hipError_t launch_tiles_t(hipStream_t st, const MscLayout& L, const uint8
 	const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
 	const bool padded = L.nbins < L.padded_bins;
 	const uint64_t stride = msc_scalar_stride(S);
+	if constexpr (TB > 0) {
+		k_div_tables<TB><<<dim3(m), dim3(TB * TB), 0, st>>>(cand_scalars, stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
 	if (padded) {
-		hipLaunchKernelGGL((k_pair_tiles<T, LPT, true>), dim3(blocks), dim3(kBlock), 0, st, cand_bins, L.slot_bytes, cand_scalars, stride,
-		                   cand_slots, m, q_bins, q_scalars, S, (uint32_t)G, (uint32_t)L.nbins, use_window, min_len, max_len, partials);
+		k_pair_tiles<T, LPT, true, TB><<<dim3(blocks), dim3(kBlock), 0, st>>>(cand_bins, L.slot_bytes, cand_scalars, stride, cand_slots, m, q_bins,
+		    q_scalars, S, (uint32_t)G, (uint32_t)L.nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (MscPartialDiv*)div_partials, order);
 	} else {
-		hipLaunchKernelGGL((k_pair_tiles<T, LPT, false>), dim3(blocks), dim3(kBlock), 0, st, cand_bins, L.slot_bytes, cand_scalars, stride,
-		                   cand_slots, m, q_bins, q_scalars, S, (uint32_t)G, (uint32_t)L.tile_bins, use_window, min_len, max_len, partials);
+		k_pair_tiles<T, LPT, false, TB><<<dim3(blocks), dim3(kBlock), 0, st>>>(cand_bins, L.slot_bytes, cand_scalars, stride, cand_slots, m, q_bins,
+		    q_scalars, S, (uint32_t)G, (uint32_t)L.tile_bins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (MscPartialDiv*)div_partials, order);
 	}
 	return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t launch_tiles_lpt(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, uint32_t m,
-                                   const uint8_t* qb, const uint8_t* qs, int uw, uint64_t mn, uint64_t mx, MscPartial* p, int cus) {
+                                   const uint8_t* qb, const uint8_t* qs, int uw, uint64_t mn, uint64_t mx, MscPartial* p, int cus,
+                                   int tb, void* dt, void* dp, int order) {
+	if (tb == 0) {
+		switch (L.LPT) {
+		case 1: return launch_tiles_t<T, 1, 0>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+		case 2: return launch_tiles_t<T, 2, 0>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+		default: return launch_tiles_t<T, 4, 0>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+		}
+	}
+	if (tb == 8) return launch_tiles_t<T, 4, 8>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
 	switch (L.LPT) {
-	case 1: return launch_tiles_t<T, 1>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
-	case 2: return launch_tiles_t<T, 2>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
-	default: return launch_tiles_t<T, 4>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus);
+	case 1: return launch_tiles_t<T, 1, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+	case 2: return launch_tiles_t<T, 2, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+	default: return launch_tiles_t<T, 4, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
 	}
 }
 
+int msc_div_table_dim(const MscLayout& L) { return (L.LPT == 4 && L.S >= 4) ? 8 : 16; }
+
 hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
                                  const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
-                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+                                 int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus,
+                                 void* div_tables, void* div_partials, int order) {
 	if (m == 0) return hipSuccess;
+	const int tb = div_tables ? msc_div_table_dim(L) : 0;
 	switch (dtype) {
-	case 8: return launch_tiles_lpt<uint8_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
-	case 16: return launch_tiles_lpt<uint16_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
-	case 32: return launch_tiles_lpt<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
-	default: return launch_tiles_lpt<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus);
+	case 8: return launch_tiles_lpt<uint8_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
+	case 16: return launch_tiles_lpt<uint16_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
+	case 32: return launch_tiles_lpt<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
+	default: return launch_tiles_lpt<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
 	}
 }
 

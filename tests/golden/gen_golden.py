@@ -46,6 +46,19 @@ n_singles: 4
 262144 0 60000
 """
 
+REG_BLOCK_K5_SLOW = """
+n_combos: 3
+0.05
+0 536870912 0.9
+1 8320 0.08
+3 128 -0.06
+
+n_singles: 3
+536870912 0 0.02
+128 0 0.2
+8192 0.3 1
+"""
+
 REG_BLOCK_K9 = """
 n_combos: 3
 0.02
@@ -67,12 +80,12 @@ def run_reference_cli(fasta, args, workdir):
     return out.stdout.decode(errors="replace")
 
 
-def make_weights(name, seed, n, length, k, dtype, reg_block, clstr_name=None):
+def make_weights(name, seed, n, length, k, dtype, reg_block, clstr_name=None, extra_args=()):
     tmp = tempfile.mkdtemp()
     seqs, hdrs = synth.families(seed, n, length)
     fa = os.path.join(tmp, "in.fa")
     synth.write_fasta(fa, seqs, hdrs)
-    run_reference_cli(fa, ["--id", "0.9", "--kmer", str(k), "--datatype", str(dtype), "--threads", "1", "--output", "out.clstr"], tmp)
+    run_reference_cli(fa, ["--id", "0.9", "--kmer", str(k), "--datatype", str(dtype), "--threads", "1", "--output", "out.clstr"] + list(extra_args), tmp)
     text = open(os.path.join(tmp, "weights.txt")).read()
     text = text.replace("mode: 1", "mode: 3") + reg_block
     open(os.path.join(HERE, name), "w").write(text)
@@ -180,6 +193,8 @@ if __name__ == "__main__":
     make_kat()
     make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
+    make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])
+    make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
     make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)
     make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)
     make_vectors("vectors_k4_u8.npz", "weights_k5_u16.txt", 13, 10, 150, 4, 8)

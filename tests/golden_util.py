@@ -11,7 +11,7 @@ FEAT_BIT = dict(FEATS)
 # statistics whose value is an exact integer reduction pushed through the same FP64 expression: compared bitwise
 EXACT = {"manhattan", "euclidean", "normalized_vectors", "intersection", "emd", "length_difference", "kulczynski2", "simratio"}
 FAST = [f for f in FEATS if f[0] not in ("jefferey_divergence", "jensen_shannon")]
-VECTOR_SETS = [("vectors_k5_u16.npz", "weights_k5_u16.txt"), ("vectors_k9_u32.npz", "weights_k9_u32.txt"),
+VECTOR_SETS = [("vectors_k5_u16.npz", "weights_k5_u16.txt"), ("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt"), ("vectors_k9_u32.npz", "weights_k9_u32.txt"),
                ("vectors_k4_u8.npz", "weights_k5_u16.txt"), ("vectors_k6_u64.npz", "weights_k5_u16.txt")]
 NP_T = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
 

@@ -4,13 +4,15 @@ relative (the north-star bar is 1e-5)."""
 import numpy as np
 import pytest
 
-from golden_util import EXACT, FAST, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors, weights_text
+from golden_util import EXACT, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors, weights_text
 from meshclust2_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-FAST_MASK = sum(1 << b for _, b in FAST)
-FAST_COLS = [i for i, (n, _) in enumerate(FEATS) if n not in ("jefferey_divergence", "jensen_shannon")]
+# all 11 in-scope statistics (`--feat slow`); the names FAST_* are kept for the column bookkeeping below
+FAST = FEATS
+FAST_MASK = sum(1 << b for _, b in FEATS)
+FAST_COLS = list(range(len(FEATS)))
 RTOL = 1e-9
 
 
@@ -179,7 +181,7 @@ def test_unsupported_inputs_fail_loudly(ctx):
     hs = api.HistogramSet(ctx, 3, 32, 2)
     hs.build([b"ACGT" * 10, b"ACGT" * 10])
     with pytest.raises(api.MscError):
-        api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 1)          # hellinger: out of scope
+        api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 1)          # hellinger: out of scope (extraslow only)
     with pytest.raises(api.MscError):
         api.Feature.create(ctx, 3, [(0, 1 << 12)], [0.0, 1.0], [(1 << 12, 0.0, 1.0)])    # markov
 
@@ -196,12 +198,16 @@ def test_upload_round_trip_and_properties(ctx):
         assert hs.info(i)["sum"] == int(b.sum()) and hs.info(i)["sum_sq"] == int((b.astype(np.uint64) ** 2).sum())
     ev = np.arange(n, dtype=np.uint32)
     m = np.stack([api.pair_features_raw(ctx, hs, ev, hs, q, FAST_MASK & ~(1 << 28)) for q in range(n)])    # [q, c, f]
-    assert np.array_equal(m, m.transpose(1, 0, 2))                       # symmetric (simratio/u32 excluded: SURVEY Q3)
     names = [nm for nm, b in FAST if b != 28]
+    div = [names.index("jefferey_divergence"), names.index("jensen_shannon")]
+    rest = [i for i in range(len(names)) if i not in div]
+    assert np.array_equal(m[:, :, rest], m.transpose(1, 0, 2)[:, :, rest])      # symmetric (simratio/u32 excluded: SURVEY Q3)
+    assert np.allclose(m[:, :, div], m.transpose(1, 0, 2)[:, :, div], rtol=1e-12, atol=0)
     for q in range(n):
         row = dict(zip(names, m[q, q]))
         assert row["manhattan"] == 0 and row["euclidean"] == 0 and row["emd"] == 0 and row["intersection"] == 1.0
         assert row["normalized_vectors"] == pytest.approx(1.0, abs=1e-15) and row["pearson"] == pytest.approx(1.0, abs=1e-12)
+        assert row["jefferey_divergence"] == 0 and row["jensen_shannon"] == 0
     for q in range(n):
         for c in range(n):
             d = data[q].astype(np.int64) - data[c].astype(np.int64)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Folds rocprofv3 CSV output (gpurun_out/<dir>) into the small per-round summaries committed under profiles/.
+
+  python tools/summarize_profiles.py r01 gpurun_out/prof_r1 gpurun_out/pmc_fetch gpurun_out/pmc_write
+
+PMC correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE (KiB) reports exactly half of the bytes of a wide
+coalesced streaming read, WRITE_SIZE is exact for 16-byte streaming stores -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def one(pattern):
+    f = glob.glob(pattern, recursive=True)
+    if not f:
+        raise SystemExit("no file matches " + pattern)
+    return f[0]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return name.split("(")[0]
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "**", "*kernel_stats.csv")))))
+    with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
+        f.write("kernel,calls,total_ns,average_ns,percentage,min_ns,max_ns\n")
+        for r in rows:
+            f.write("%s,%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
+    pmc = {}
+    for ctr, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(one(os.path.join(d, "**", "*counter_collection.csv")))):
+            if r["Counter_Name"] == ctr:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc.setdefault(k, {})[ctr] = {"launches": len(v), "mean_kib": sum(v) / len(v)}
+    for k, d in pmc.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"]["mean_kib"] + d["WRITE_SIZE"]["mean_kib"]) * 1024
+    json.dump(pmc, open(os.path.join(out_dir, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
+    print("wrote profiles/%s_kernel_stats.csv and profiles/%s_pmc_hbm.json" % (tag, tag))
+
+
+if __name__ == "__main__":
+    main()
