@@ -1,0 +1,95 @@
+"""Sharding of the 1 x M scoring pass over ranks (one process per GPU) -- SURVEY.md 8(e).
+
+Pairs are independent, so candidates are dealt to ranks and a pass needs only two tiny exchanges:
+  1. the query histogram (bins + scalar record) is BROADCAST from the rank that owns it,
+  2. one 24-byte record (n_close, best_sim, best_global_index) per rank is ALL-GATHERED and folded with the
+     reference's serial arg-max rule (strict '>' in window order: the smallest global index among equal maxima,
+     cluster/Trainer.cpp:26-37,59 at OMP_NUM_THREADS=1).
+Histograms sorted by length are dealt block-cyclically (block = one bvec bin of 1000, cluster/CRunner.cpp:585) so
+every length window is balanced over the ranks.
+
+The module is backend-agnostic: `backend` supplies export_query / import_query / score_local. bench.py plugs in the
+GPU library (payload = device tensors, collectives over RCCL); tests/test_shard_gloo.py plugs in CPU tensors over gloo.
+"""
+import numpy as np
+
+
+class ShardPlan:
+    """global index (position in the length-sorted order) <-> (rank, local slot), block-cyclic."""
+
+    def __init__(self, n_total, world, block=1000):
+        self.n_total, self.world, self.block = int(n_total), int(world), int(block)
+
+    def owner(self, g):
+        return (g // self.block) % self.world
+
+    def local(self, g):
+        b = g // self.block
+        return (b // self.world) * self.block + g % self.block
+
+    def global_index(self, rank, local):
+        b_local, off = divmod(local, self.block)
+        return (b_local * self.world + rank) * self.block + off
+
+    def local_count(self, rank):
+        full, rem = divmod(self.n_total, self.block)
+        n = (full // self.world) * self.block
+        extra = full % self.world
+        if rank < extra:
+            n += self.block
+        elif rank == extra:
+            n += rem
+        return n
+
+    def local_globals(self, rank):
+        return np.array([self.global_index(rank, i) for i in range(self.local_count(rank))], dtype=np.int64)
+
+
+def fold_records(records):
+    """records: iterable of (n_close, best_sim, best_global_index or -1) -> (n_close_total, best_sim, best_global, is_min)"""
+    n_close = 0
+    best_sim, best_g = -1.0, -1
+    for n, sim, g in records:
+        n_close += int(n)
+        g = int(g)
+        if g < 0:
+            continue
+        if sim > best_sim or (sim == best_sim and (best_g < 0 or g < best_g)):
+            best_sim, best_g = float(sim), g
+    return n_close, best_sim, best_g, n_close == 0
+
+
+class ShardedTrainer:
+    """Trainer::get_close over sharded candidates.
+
+    backend.export_query(local_slot) -> list of torch tensors holding the query payload (owner only)
+    backend.query_buffers()          -> list of torch tensors every rank receives the payload into (same shapes)
+    backend.import_query()           -> called after the broadcast landed in query_buffers()
+    backend.score_local()            -> (close_flags[np.uint8, local_count], best_local_pos or -1, best_sim)
+    """
+
+    def __init__(self, dist, plan, backend, rank, device="cpu"):
+        self.dist, self.plan, self.backend, self.rank, self.device = dist, plan, backend, rank, device
+
+    def get_close(self, query_global):
+        import torch
+        owner = self.plan.owner(query_global)
+        bufs = self.backend.query_buffers()
+        if self.rank == owner:
+            for dst, src in zip(bufs, self.backend.export_query(self.plan.local(query_global))):
+                dst.copy_(src)
+        if self.plan.world > 1:
+            for b in bufs:
+                self.dist.broadcast(b, src=owner)
+        self.backend.import_query()
+        flags, best_local, best_sim = self.backend.score_local()
+        best_g = self.plan.global_index(self.rank, best_local) if best_local >= 0 else -1
+        rec = torch.tensor([float(flags.sum()), float(best_sim), float(best_g)], dtype=torch.float64, device=self.device)
+        if self.plan.world > 1:
+            out = torch.zeros(3 * self.plan.world, dtype=torch.float64, device=self.device)
+            self.dist.all_gather_into_tensor(out, rec)
+            recs = out.cpu().numpy().reshape(self.plan.world, 3)
+        else:
+            recs = rec.cpu().numpy().reshape(1, 3)
+        n_close, sim, g, is_min = fold_records(recs)
+        return flags, g, sim, is_min, n_close
