@@ -86,9 +86,9 @@ class ShardedTrainer:
         best_g = self.plan.global_index(self.rank, best_local) if best_local >= 0 else -1
         rec = torch.tensor([float(flags.sum()), float(best_sim), float(best_g)], dtype=torch.float64, device=self.device)
         if self.plan.world > 1:
-            out = torch.zeros(3 * self.plan.world, dtype=torch.float64, device=self.device)
-            self.dist.all_gather_into_tensor(out, rec)
-            recs = out.cpu().numpy().reshape(self.plan.world, 3)
+            out = [torch.zeros(3, dtype=torch.float64, device=self.device) for _ in range(self.plan.world)]
+            self.dist.all_gather(out, rec)
+            recs = torch.stack(out).cpu().numpy()
         else:
             recs = rec.cpu().numpy().reshape(1, 3)
         n_close, sim, g, is_min = fold_records(recs)

@@ -213,3 +213,44 @@ def test_upload_round_trip_and_properties(ctx):
             d = data[q].astype(np.int64) - data[c].astype(np.int64)
             assert m[q, c, names.index("manhattan")] == np.abs(d).sum()
             assert m[q, c, names.index("emd")] == np.abs(np.cumsum(d)).sum()
+
+
+_TORCH_VIEW_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                      # torch first: one HIP runtime per process, like bench.py
+sys.path.insert(0, sys.argv[1])
+from meshclust2_amd import api, synth
+ctx = api.Context(0)
+seqs, _ = synth.families(3, 4, 500, family=4)
+hs = api.HistogramSet(ctx, 6, 16, 5)
+hs.build(seqs)
+bins_ptr, slot_bytes, scal_ptr, scal_bytes = hs.device_view()
+class View:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+b = torch.as_tensor(View(bins_ptr, slot_bytes * 5), device="cuda")
+s = torch.as_tensor(View(scal_ptr, scal_bytes * 5), device="cuda")
+b[4 * slot_bytes:5 * slot_bytes].copy_(b[2 * slot_bytes:3 * slot_bytes])
+s[4 * scal_bytes:5 * scal_bytes].copy_(s[2 * scal_bytes:3 * scal_bytes])
+torch.cuda.synchronize()
+hs.import_done(4, 1)
+assert np.array_equal(hs.download(4), hs.download(2)) and hs.info(4) == hs.info(2)
+mask = sum(1 << x for x in (2, 3, 5, 9, 13, 18, 21, 27, 28))
+a = api.pair_features_raw(ctx, hs, [0, 1, 3], hs, 4, mask)
+c = api.pair_features_raw(ctx, hs, [0, 1, 3], hs, 2, mask)
+assert np.array_equal(a, c)
+print("TORCH_VIEW_OK")
+"""
+
+
+def test_device_view_is_usable_from_torch():
+    """The multi-GPU path hands raw device regions to torch.distributed (RCCL) through __cuda_array_interface__:
+    copy a slot with torch, call import_done, and the library must see the new histogram."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _TORCH_VIEW_SCRIPT, root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert b"TORCH_VIEW_OK" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
