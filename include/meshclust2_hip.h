@@ -107,6 +107,8 @@ int         msc_device_name(const msc_ctx* ctx, char* buf, size_t cap);
 int         msc_synchronize(msc_ctx* ctx);
 /* Wall-clock of the dominant kernel (pair_tiles) of the LAST scoring call, from HIP events on the ctx stream (ms). */
 int         msc_last_kernel_ms(const msc_ctx* ctx, float* pair_tiles_ms, float* total_ms);
+/* Number of streaming-kernel launches that pair_tiles_ms sums over (large calls are chunked). */
+int         msc_last_kernel_launches(const msc_ctx* ctx);
 
 /* ------------------------------------------------------------------ a1: sequence encoding (host byte work)
  * Replaces Chromosome::help / removeAmbiguous / mergeSegments / makeSegmentList + ChromosomeOneDigit::encode
@@ -195,6 +197,15 @@ int msc_pair_features_raw(msc_ctx* ctx, const msc_hist_set* cands, const uint32_
 int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
               const msc_hist_set* qset, uint64_t q_slot, int order,
               double* singles_out, double* combos_out, double* sum_out, double* csum_out);
+
+/* n_q queries x m candidates in ONE pass over the candidates (the all-pairs shape: fastcar work(),
+ * fastcar/FC_Runner.cpp:426-471; the training table, predict/FeatureSelector.cpp:23-33). Every candidate tile read from
+ * HBM is scored against several query tiles held in registers. Outputs are query-major: [n_q][m] (raw_out
+ * [n_q][m][popcount(feat_mask)]). Any output pointer may be NULL; model may be NULL when only raw_out is wanted.
+ * close_out[q][i] = round(classify_sum) > 0. */
+int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                    const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order,
+                    double* sum_out, double* csum_out, uint8_t* close_out, uint64_t feat_mask, double* raw_out);
 
 /* ------------------------------------------------------------------ a8/a9: Trainer operators */
 /* Trainer<T>::get_close (cluster/Trainer.cpp:23-71; caller cluster/ClusterFactory.cpp:566).

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "msc_device_name": (_int, [_vp, C.c_char_p, C.c_size_t]),
     "msc_synchronize": (_int, [_vp]),
     "msc_last_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "msc_last_kernel_launches": (_int, [_vp]),
     "msc_encode": (_int, [C.c_char_p, C.c_size_t, _pu8, _pi64, C.c_size_t, C.POINTER(C.c_size_t), _pu64]),
     "msc_hist_set_create": (_int, [_vp, _int, _int, _u64, C.POINTER(_vp)]),
     "msc_hist_set_destroy": (None, [_vp]),
@@ -69,6 +70,7 @@ PROTOTYPES = {
     "msc_model_set_bias": (None, [_vp, _dbl]),
     "msc_pair_features_raw": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _int, _u64, _vp]),
     "msc_score": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp, _vp]),
+    "msc_score_multi": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _u64, _int, _vp, _vp, _vp, _u64, _vp]),
     "msc_get_close": (_int, [_vp, _vp, _dbl, _vp, _vp, _u64, _vp, _u64, _vp, _pi64, _pdbl, C.POINTER(_int)]),
     "msc_filter": (_int, [_vp, _vp, _dbl, _vp, _u64, _vp, _vp, _u64, _vp, _pu64]),
     "msc_merge": (_int, [_vp, _vp, _dbl, _vp, _vp, _u64, _i64, _i64, _i64, _pi64]),

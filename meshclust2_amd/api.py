@@ -54,6 +54,9 @@ class Context:
         self.check(self.lib.msc_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_kernel_launches(self):
+        return self.lib.msc_last_kernel_launches(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             for ref in self._children:
@@ -249,6 +252,22 @@ def pair_features_raw(ctx, cands, cand_slots, qset, q_slot, feat_mask=FEAT_FAST,
     out = np.zeros((m, nf))
     ctx.check(ctx.lib.msc_pair_features_raw(ctx.h, cands.h, _ptr(sl), m, qset.h, q_slot, order, feat_mask, _ptr(out)))
     return out
+
+
+def score_multi(ctx, feat, cands, cand_slots, qset, q_slots, order=ORDER_CAND_FIRST, m=None, feat_mask=0, want=("sum", "csum", "close")):
+    """n_q queries x m candidates in one pass over the candidates (all-pairs shape).
+    -> dict(sum [n_q,m], csum [n_q,m], close [n_q,m], raw [n_q,m,nf] or None); `want` limits what is copied back"""
+    sl, m = _slots(cand_slots, m)
+    qs = np.ascontiguousarray(q_slots, dtype=np.uint32)
+    nq = qs.size
+    nf = bin(feat_mask).count("1")
+    s = np.zeros((nq, m)) if feat is not None and "sum" in want else None
+    cs = np.zeros((nq, m)) if feat is not None and "csum" in want else None
+    close = np.zeros((nq, m), dtype=np.uint8) if feat is not None and "close" in want else None
+    raw = np.zeros((nq, m, nf)) if nf else None
+    ctx.check(ctx.lib.msc_score_multi(ctx.h, feat.h if feat is not None else None, cands.h, _ptr(sl), m, qset.h, _ptr(qs), nq, order,
+                                      _ptr(s), _ptr(cs), _ptr(close), feat_mask, _ptr(raw)))
+    return dict(sum=s, csum=cs, close=close, raw=raw)
 
 
 class Trainer:

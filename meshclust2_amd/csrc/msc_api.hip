@@ -30,11 +30,12 @@ struct msc_ctx {
 	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
 	bool have_timing = false;
 	float tiles_ms_accum = 0.f;
+	int tiles_launches = 0;
 	std::string err;
 	char dev_name[128] = {0};
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
-	    floor_sum, mean, div_tables, div_partials;
+	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word;
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 };
 
@@ -136,7 +137,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
-	                  &ctx->div_tables, &ctx->div_partials};
+	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
+	                  &ctx->err_word};
 	for (DevBuf* b : bufs) release(*b);
 	(void)hipEventDestroy(ctx->ev_tiles0);
 	(void)hipEventDestroy(ctx->ev_tiles1);
@@ -159,6 +161,8 @@ extern "C" int msc_synchronize(msc_ctx* ctx) {
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return MSC_OK;
 }
+
+extern "C" int msc_last_kernel_launches(const msc_ctx* ctx) { return ctx && ctx->have_timing ? ctx->tiles_launches : 0; }
 
 extern "C" int msc_last_kernel_ms(const msc_ctx* ctx, float* tiles_ms, float* total_ms) {
 	if (!ctx || !ctx->have_timing) return MSC_ERR_INVALID_ARG;
@@ -744,6 +748,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool need_div = (want & MSC_FEAT_DIV) != 0 && !rq.only_tiles;
 	const int tb = msc_div_table_dim(L);
 	ctx->tiles_ms_accum = 0.f;
+	ctx->tiles_launches = 0;
 	ctx->have_timing = false;
 	if (m == 0) {
 		if (rq.reduce_host) { rq.reduce_host->best_pos = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1 : 0; rq.reduce_host->best_sim = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1.0 : DBL_MIN;
@@ -831,7 +836,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;
-		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->have_timing = true; }
+		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
 		if (need_po) {
 			for (uint32_t i = 0; i < mc; i++) {
 				const MscPairOut& p = po_host[i];
@@ -879,6 +884,115 @@ extern "C" int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_se
 	rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot; rq.order = order;
 	rq.singles_out = singles_out; rq.combos_out = combos_out; rq.sum_out = sum_out; rq.csum_out = csum_out;
 	return run_score(ctx, rq);
+}
+
+extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                               const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
+                               uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
+	if (!ctx || !cands || !qset || !q_slots) return MSC_ERR_INVALID_ARG;
+	if (model && model->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (raw_out && (feat_mask == 0 || (feat_mask & ~kSupportedFeats))) return fail(ctx, MSC_ERR_UNSUPPORTED, "feat_mask holds statistics outside the GPU path");
+	if (!raw_out) feat_mask = 0;
+	if (n_q == 0 || m == 0) return MSC_OK;
+	for (uint64_t i = 0; i < n_q; i++) if (q_slots[i] >= qset->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "query slot out of range");
+	int r = validate_pair(ctx, cands, qset, q_slots[0], cand_slots, m);
+	if (r) return r;
+	const MscLayout& L = cands->L;
+	const int nf = __builtin_popcountll(feat_mask);
+	uint64_t want = feat_mask;
+	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
+	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1;
+	if (!simple) {
+		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
+		for (uint64_t q = 0; q < n_q; q++) {
+			ScoreRequest rq;
+			rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slots[q]; rq.order = order;
+			rq.feat_mask = feat_mask; rq.raw_out = raw_out ? raw_out + q * m * nf : nullptr;
+			rq.sum_out = sum_out ? sum_out + q * m : nullptr; rq.csum_out = csum_out ? csum_out + q * m : nullptr;
+			rq.flags_out = close_out ? close_out + q * m : nullptr;
+			if ((r = run_score(ctx, rq))) return r;
+		}
+		return MSC_OK;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ctx->tiles_ms_accum = 0.f;
+	ctx->tiles_launches = 0;
+	ctx->have_timing = false;
+	uint64_t chunk = (4096ull << 20) / ((uint64_t)L.S * sizeof(MscPartial) * n_q);      // partial records <= 4 GiB per launch
+	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
+	if ((r = ensure(ctx, ctx->partials, n_q * chunk * L.S * sizeof(MscPartial)))) return r;
+	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
+	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
+	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
+	if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
+	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
+	if ((r = ensure(ctx, ctx->qslots, n_q * sizeof(uint32_t)))) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+	if (cand_slots) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	int tq = n_q >= 4 ? 4 : 2;                     // TQ = 4 keeps the 32-bit kernel HBM-bound; MSC_MULTI_TQ=8 trades that for ~25 % more pairs/s
+	if (const char* e = getenv("MSC_MULTI_TQ")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) tq = v; }
+	if (tq > (int)n_q && n_q >= 2) tq = n_q >= 4 ? 4 : 2;
+	// wave totals of the per-lane 32-bit partial sums fit 32 bits when 64*R*max^2 and 64*R*max|prefix difference| do
+	const uint64_t mc_ = std::max(cands->max_count, qset->max_count), ms_ = std::max(cands->max_sum, qset->max_sum);
+	const bool compact = 64ull * L.R * mc_ * mc_ < (1ull << 32) && 64ull * L.R * ms_ < (1ull << 32);
+	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+	for (uint64_t off = 0; off < m; off += chunk) {
+		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
+		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
+		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
+		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
+		                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		MscEpilogueArgs ea;
+		memset(&ea, 0, sizeof ea);
+		ea.partials = (const MscPartial*)ctx->partials.p;
+		ea.S = L.S;
+		ea.m = (uint32_t)(n_q * mc);
+		ea.cand_scalars = c_scal;
+		ea.cand_scalar_stride = cands->scalar_stride;
+		ea.cand_slots = d_slots;
+		ea.n_queries = (uint32_t)n_q;
+		ea.m_per_query = mc;
+		ea.q_slots = (const uint32_t*)ctx->qslots.p;
+		ea.qset_scalars = qset->scalars;
+		ea.q_scalar_stride = qset->scalar_stride;
+		ea.q_scalars = qset->scalars + (uint64_t)q_slots[0] * qset->scalar_stride;
+		ea.nbins = L.nbins;
+		ea.dtype = cands->dtype;
+		ea.order = order;
+		ea.feat_mask = feat_mask;
+		ea.raw_out = raw_out ? (double*)ctx->raw.p : nullptr;
+		ea.model = model ? model->d : nullptr;
+		ea.sum_soa = sum_out ? (double*)ctx->soa_sum.p : nullptr;
+		ea.csum_soa = csum_out ? (double*)ctx->soa_csum.p : nullptr;
+		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
+		ea.error_word = (int32_t*)ctx->err_word.p;
+		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
+		const size_t rows = (size_t)n_q;
+		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (csum_out) HIP_TRY(ctx, hipMemcpy2DAsync(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, ctx->soa_close.p, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		float t = 0;
+		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
+		(void)whole;
+	}
+	int32_t first_err = 0;
+	HIP_TRY(ctx, hipMemcpy(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost));
+	if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+	if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+	if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+	return MSC_OK;
 }
 
 extern "C" int msc_get_close(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* cands, const uint32_t* cand_slots,
@@ -1029,7 +1143,7 @@ extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uin
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	float t = 0;
-	if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->have_timing = true; }
+	if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = 1; ctx->have_timing = true; }
 	*nearest_pos = ro.best_pos;
 	return MSC_OK;
 }

@@ -59,6 +59,11 @@ struct MscEpilogueArgs {
 	uint64_t cand_scalar_stride;
 	const uint32_t* cand_slots;       // nullable -> identity
 	const uint8_t* q_scalars;         // scalar record of the query (already offset to its slot)
+	// several queries in one launch (virtual candidate index = qi * m_per_query + ci); n_queries <= 1 -> q_scalars above
+	uint32_t n_queries, m_per_query;
+	const uint32_t* q_slots;          // device, [n_queries]
+	const uint8_t* qset_scalars;
+	uint64_t q_scalar_stride;
 	uint64_t nbins;
 	int32_t  dtype;
 	int32_t  order;                   // MSC_ORDER_*
@@ -72,6 +77,11 @@ struct MscEpilogueArgs {
 	double*  singles_out;             // [m][n_singles] or null
 	double*  combos_out;              // [m][n_combos] or null
 	MscPairOut* pair_out;             // [m] or null
+	// structure-of-arrays outputs (device, nullable): what the all-pairs path copies back instead of pair_out
+	double*  sum_soa;
+	double*  csum_soa;
+	uint8_t* close_soa;
+	int32_t* error_word;              // atomicMin of negative statuses
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip kernel files)
@@ -89,6 +99,10 @@ hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype,
                                  uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
                                  int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials,
                                  int num_cus, void* div_tables /*nullable*/, void* div_partials, int order);
+hipError_t msc_launch_pair_tiles_multi(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                       const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
+                                       const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q,
+                                       int tq, bool compact, MscPartial* partials, int num_cus);
 int msc_div_table_dim(const MscLayout& L);      // 8 or 16: side of the per-candidate (count, count) term table
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,

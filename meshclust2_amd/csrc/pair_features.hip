@@ -57,19 +57,58 @@ __device__ __forceinline__ uint64_t wave_total_u64(uint32_t v) {
 	return (uint64_t)lo + ((uint64_t)hi << 16);
 }
 
-template <typename T> struct ElemOps;
-template <> struct ElemOps<uint8_t> {
-	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return (w[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+// |a - b| + c in ONE VALU op. hipcc lowers __usad to v_max/v_min/v_sub/v_add, so the instruction is named explicitly.
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Arithmetic on the PACKED 32-bit words a lane holds after its 16-byte loads. NW words cover the lane's R bins in
+// logical order; bins are never unpacked for the order-independent reductions (v_sad_u8/u16, v_dot4/dot2 work on the
+// packed word), only the prefix statistic touches single bins (byte/half selects fold into SDWA operands).
+template <typename T> struct Packed;
+template <> struct Packed<uint8_t> {
+	static constexpr int EPW = 4, STEP = 1;
+	static __device__ __forceinline__ uint32_t elem(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
+	static __device__ __forceinline__ uint32_t sum(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
+	static __device__ __forceinline__ uint32_t manh(uint32_t p, uint32_t q, uint32_t acc) { return __builtin_amdgcn_sad_u8(p, q, acc); }
+	static __device__ __forceinline__ uint32_t dot(uint32_t p, uint32_t q, uint32_t acc) { return __builtin_amdgcn_udot4(p, q, acc, false); }
 };
-template <> struct ElemOps<uint16_t> {
-	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return (w[r >> 1] >> (16 * (r & 1))) & 0xffffu; }
+template <> struct Packed<uint16_t> {
+	static constexpr int EPW = 2, STEP = 1;
+	static __device__ __forceinline__ uint32_t elem(uint32_t w, int i) { return (w >> (16 * i)) & 0xffffu; }
+	static __device__ __forceinline__ uint32_t sum(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u16(w, 0u, acc); }
+	static __device__ __forceinline__ uint32_t manh(uint32_t p, uint32_t q, uint32_t acc) { return __builtin_amdgcn_sad_u16(p, q, acc); }
+	static __device__ __forceinline__ uint32_t dot(uint32_t p, uint32_t q, uint32_t acc) {
+		return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p), __builtin_bit_cast(u16x2, q), acc, false);
+	}
 };
-template <> struct ElemOps<uint32_t> {
-	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return w[r]; }
+template <> struct Packed<uint32_t> {
+	static constexpr int EPW = 1, STEP = 1;
+	static __device__ __forceinline__ uint32_t elem(uint32_t w, int) { return w; }
+	static __device__ __forceinline__ uint32_t sum(uint32_t w, uint32_t acc) { return acc + w; }
+	static __device__ __forceinline__ uint32_t manh(uint32_t p, uint32_t q, uint32_t acc) { return sad_u32(p, q, acc); }
+	static __device__ __forceinline__ uint32_t dot(uint32_t p, uint32_t q, uint32_t acc) { return __umul24(p, q) + acc; }
 };
-template <> struct ElemOps<uint64_t> {   // narrow path: the high dword is zero by the host-side range check
-	static __device__ __forceinline__ uint32_t get(const uint32_t* w, int r) { return w[2 * r]; }
+template <> struct Packed<uint64_t> {   // narrow path: the high dword is zero by the host-side range check -> every other word
+	static constexpr int EPW = 1, STEP = 2;
+	static __device__ __forceinline__ uint32_t elem(uint32_t w, int) { return w; }
+	static __device__ __forceinline__ uint32_t sum(uint32_t w, uint32_t acc) { return acc + w; }
+	static __device__ __forceinline__ uint32_t manh(uint32_t p, uint32_t q, uint32_t acc) { return sad_u32(p, q, acc); }
+	static __device__ __forceinline__ uint32_t dot(uint32_t p, uint32_t q, uint32_t acc) { return __umul24(p, q) + acc; }
 };
+
+// sum of the lane's run
+template <typename T, int NW>
+__device__ __forceinline__ uint32_t run_sum(const uint32_t* w) {
+	uint32_t t = 0;
+#pragma unroll
+	for (int i = 0; i < NW; i += Packed<T>::STEP) t = Packed<T>::sum(w[i], t);
+	return t;
+}
 
 // ---------------------------------------------------------------------------------------- streaming kernel
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -158,11 +197,11 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 	// ---- query tile: registers for the whole launch
 	TileRegs<LPT> qt;
 	load_tile<LPT>(qt, q_bins + (uint64_t)s * tile_bytes, lane);
-	const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qt);
+	const uint32_t* qw0 = reinterpret_cast<const uint32_t*>(&qt);
 	const uint64_t* q_prefix = reinterpret_cast<const uint64_t*>(q_scalars + sizeof(MscSlotScalars));
-	uint32_t tq = 0;
-#pragma unroll
-	for (int r = 0; r < R; r++) tq += ElemOps<T>::get(qw, r);
+	constexpr int NW = 4 * LPT;
+	using P = Packed<T>;
+	const uint32_t tq = run_sum<T, NW>(qw0);
 	const uint32_t cq0 = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;     // prefix(q) just before this lane's run
 
 	auto slot_of = [&](uint32_t c) -> uint32_t { return cand_slots ? cand_slots[c] : c; };
@@ -207,34 +246,44 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 		if (!ok) continue;
 
 		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
-		uint32_t tp = 0;
-#pragma unroll
-		for (int r = 0; r < R; r++) tp += ElemOps<T>::get(pw, r);
+		const uint32_t tp = run_sum<T, NW>(pw);
 		uint32_t cp = carry + wave_incl_scan(tp) - tp;
 		uint32_t cq = cq0;
+		// launder the packed query words of sub-dword types: otherwise the compiler unpacks all R query bins (and
+		// their running prefix) into registers once per launch; in place, the byte/half selects are free SDWA operands
+		uint32_t qw[NW];
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			qw[w] = qw0[w];
+			if constexpr (sizeof(T) < 4) asm volatile("" : "+v"(qw[w]));
+		}
 		uint32_t manh = 0, dot = 0, emd = 0;
 		double jd = 0.0, js = 0.0;
 		uint32_t any_big = 0;
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			const uint32_t p = ElemOps<T>::get(pw, r);
-			const uint32_t q = ElemOps<T>::get(qw, r);
-			cp += p;
-			cq += q;
-			if constexpr (PADDED) {
-				const uint32_t d = cp > cq ? cp - cq : cq - cp;
-				emd += (lane * R + r < nvalid) ? d : 0u;
-			} else {
-				emd = __usad(cp, cq, emd);
-			}
-			manh = __usad(p, q, manh);
-			dot = __umul24(p, q) + dot;
-			if constexpr (DIV) {
-				const uint32_t big = (p | q) >= (uint32_t)TB ? 1u : 0u;
-				const DivTerm t = my_tbl[big ? 0u : p * TB + q];          // entry (0,0) is {0,0}
-				jd += t.jd;
-				js += t.js;
-				any_big |= big;
+		for (int w = 0; w < NW; w += P::STEP) {
+			manh = P::manh(pw[w], qw[w], manh);
+			dot = P::dot(pw[w], qw[w], dot);
+#pragma unroll
+			for (int i = 0; i < P::EPW; i++) {
+				const uint32_t p = P::elem(pw[w], i);
+				const uint32_t q = P::elem(qw[w], i);
+				cp += p;
+				cq += q;
+				if constexpr (PADDED) {
+					const int r = (w / P::STEP) * P::EPW + i;
+					const uint32_t e2 = sad_u32(cp, cq, emd);
+					emd = (lane * R + r < nvalid) ? e2 : emd;
+				} else {
+					emd = sad_u32(cp, cq, emd);
+				}
+				if constexpr (DIV) {
+					const uint32_t big = (p | q) >= (uint32_t)TB ? 1u : 0u;
+					const DivTerm t = my_tbl[big ? 0u : p * TB + q];          // entry (0,0) is {0,0}
+					jd += t.jd;
+					js += t.js;
+					any_big |= big;
+				}
 			}
 		}
 		if constexpr (DIV) {
@@ -271,6 +320,234 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 			out.emd = emd_t;
 			partials[(uint64_t)c * S + s] = out;
 			if constexpr (DIV) div_partials[(uint64_t)c * S + s] = MscPartialDiv{jd, js};
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- Q x M streaming kernel
+// All-pairs shape (fastcar work(), fastcar/FC_Runner.cpp:426-471; the training table, predict/FeatureSelector.cpp:23-33):
+// a wave keeps the SAME tile of TQ different queries in registers and scores every candidate tile it loads against all
+// of them, so a candidate byte read from HBM serves TQ pairs (algorithmic floor N*sizeof(T)/TQ bytes per pair).
+template <typename T, int LPT, int TQ, bool COMPACT>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles_multi(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ qset_bins, uint64_t q_slot_bytes,
+    const uint8_t* __restrict__ qset_scalars, uint64_t q_scalar_stride, const uint32_t* __restrict__ q_slots, uint32_t n_q,
+    uint32_t S, uint32_t G, MscPartial* __restrict__ partials) {
+	constexpr int E = 16 / sizeof(T);
+	constexpr int R = LPT * E;
+	constexpr uint32_t tile_bytes = 1024u * LPT;
+	constexpr bool HOIST = R <= 32;          // keep prefix(p) of the candidate run in registers, shared by the TQ queries
+	constexpr int NW = 4 * LPT;
+	using P = Packed<T>;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	const uint32_t s = W % S;
+	const uint32_t rest = W / S;
+	const uint32_t g = rest % G;
+	const uint32_t qb = rest / G;
+	if (qb * TQ >= n_q) return;
+
+	TileRegs<LPT> qt[TQ];
+	uint32_t cq0[TQ];
+	bool qvalid[TQ];
+#pragma unroll
+	for (int j = 0; j < TQ; j++) {
+		const uint32_t qi = qb * TQ + j;
+		qvalid[j] = qi < n_q;
+		const uint32_t qslot = q_slots[qvalid[j] ? qi : qb * TQ];
+		load_tile<LPT>(qt[j], qset_bins + (uint64_t)qslot * q_slot_bytes + (uint64_t)s * tile_bytes, lane);
+		const uint32_t tq = run_sum<T, NW>(reinterpret_cast<const uint32_t*>(&qt[j]));
+		const uint64_t* q_prefix = reinterpret_cast<const uint64_t*>(qset_scalars + (uint64_t)qslot * q_scalar_stride + sizeof(MscSlotScalars));
+		cq0[j] = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;
+	}
+
+	TileRegs<LPT> nxt;
+	uint32_t nxt_carry = 0;
+	auto prefetch = [&](uint32_t cand) {
+		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
+		load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
+		nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+	};
+	uint32_t c = g;
+	if (c < m) prefetch(c);
+	for (; c < m; c += G) {
+		const TileRegs<LPT> cur = nxt;
+		const uint32_t carry = nxt_carry;
+		if (c + G < m) prefetch(c + G);
+		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
+		const uint32_t tp = run_sum<T, NW>(pw);
+		const uint32_t cp0 = carry + wave_incl_scan(tp) - tp;
+		uint32_t cpv[HOIST ? R : 1];
+		if constexpr (HOIST) {
+			uint32_t run = cp0;
+#pragma unroll
+			for (int w = 0; w < NW; w += P::STEP) {
+#pragma unroll
+				for (int i = 0; i < P::EPW; i++) { run += P::elem(pw[w], i); cpv[(w / P::STEP) * P::EPW + i] = run; }
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < TQ; j++) {
+			// launder the packed query words: stops the compiler from hoisting per-bin unpacking / running prefixes of all
+			// TQ query tiles out of the candidate loop (R*TQ live registers)
+			uint32_t qw[NW];
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				qw[w] = reinterpret_cast<const uint32_t*>(&qt[j])[w];
+				asm volatile("" : "+v"(qw[w]));
+			}
+			uint32_t cp = cp0, cq = cq0[j];
+			uint32_t manh = 0, dot = 0, emd = 0;
+#pragma unroll
+			for (int w = 0; w < NW; w += P::STEP) {
+				manh = P::manh(pw[w], qw[w], manh);
+				dot = P::dot(pw[w], qw[w], dot);
+#pragma unroll
+				for (int i = 0; i < P::EPW; i++) {
+					cq += P::elem(qw[w], i);
+					if constexpr (HOIST) {
+						emd = sad_u32(cpv[(w / P::STEP) * P::EPW + i], cq, emd);
+					} else {
+						cp += P::elem(pw[w], i);
+						emd = sad_u32(cp, cq, emd);
+					}
+				}
+			}
+			const uint32_t manh_t = wave_total_u32(manh);
+			uint64_t dot_t, emd_t;
+			if constexpr (COMPACT) {          // host checked that the wave totals fit 32 bits
+				dot_t = wave_total_u32(dot);
+				emd_t = wave_total_u32(emd);
+			} else {
+				dot_t = wave_total_u64(dot);
+				emd_t = wave_total_u64(emd);
+			}
+			if (lane == 0 && qvalid[j]) {
+				MscPartial out;
+				out.manh = manh_t;
+				out.dot = dot_t;
+				out.emd = emd_t;
+				partials[((uint64_t)(qb * TQ + j) * m + c) * S + s] = out;
+			}
+			__builtin_amdgcn_sched_barrier(0);      // one query at a time: keeps the live set (and the VGPR count) small
+		}
+	}
+}
+
+// 32/64-bit bins (narrow range: every count < 2^16): the query side is kept PRE-DIGESTED in registers -- per query the
+// absolute prefix of its run (R registers) and its bins re-packed two per word (R/2 registers). Per (candidate, query)
+// that leaves one v_sad_u32 per bin for the prefix statistic and one v_sad_u16 + one v_dot2_u32_u16 per TWO bins for
+// manhattan / dot: 2 VALU ops per bin instead of 4.
+template <typename T, int LPT, int TQ, bool COMPACT>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles_multi32(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ qset_bins, uint64_t q_slot_bytes,
+    const uint8_t* __restrict__ qset_scalars, uint64_t q_scalar_stride, const uint32_t* __restrict__ q_slots, uint32_t n_q,
+    uint32_t S, uint32_t G, MscPartial* __restrict__ partials) {
+	static_assert(sizeof(T) >= 4, "32/64-bit bins only");
+	constexpr int E = 16 / sizeof(T);
+	constexpr int R = LPT * E;
+	constexpr int NW = 4 * LPT;
+	constexpr int STEP = sizeof(T) / 4;
+	constexpr uint32_t tile_bytes = 1024u * LPT;
+	static_assert(R % 2 == 0, "bins are packed in pairs");
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	const uint32_t s = W % S;
+	const uint32_t rest = W / S;
+	const uint32_t g = rest % G;
+	const uint32_t qb = rest / G;
+	if (qb * TQ >= n_q) return;
+
+	uint32_t cqv[TQ][R];        // absolute inclusive prefix of each query's run
+	uint32_t qpk[TQ][R / 2];    // bins 2i | 2i+1 << 16
+	bool qvalid[TQ];
+#pragma unroll
+	for (int j = 0; j < TQ; j++) {
+		const uint32_t qi = qb * TQ + j;
+		qvalid[j] = qi < n_q;
+		const uint32_t qslot = q_slots[qvalid[j] ? qi : qb * TQ];
+		TileRegs<LPT> qt;
+		load_tile<LPT>(qt, qset_bins + (uint64_t)qslot * q_slot_bytes + (uint64_t)s * tile_bytes, lane);
+		const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qt);
+		const uint32_t tq = run_sum<T, NW>(qw);
+		const uint64_t* q_prefix = reinterpret_cast<const uint64_t*>(qset_scalars + (uint64_t)qslot * q_scalar_stride + sizeof(MscSlotScalars));
+		uint32_t run = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;
+#pragma unroll
+		for (int r = 0; r < R; r++) { run += qw[r * STEP]; cqv[j][r] = run; }
+#pragma unroll
+		for (int r = 0; r < R / 2; r++) qpk[j][r] = qw[2 * r * STEP] | (qw[(2 * r + 1) * STEP] << 16);
+	}
+
+	TileRegs<LPT> nxt;
+	uint32_t nxt_carry = 0;
+	auto prefetch = [&](uint32_t cand) {
+		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
+		load_tile<LPT>(nxt, cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes, lane);
+		nxt_carry = (uint32_t)reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s];
+	};
+	uint32_t c = g;
+	if (c < m) prefetch(c);
+	for (; c < m; c += G) {
+		const TileRegs<LPT> cur = nxt;
+		const uint32_t carry = nxt_carry;
+		if (c + G < m) prefetch(c + G);
+		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
+		const uint32_t tp = run_sum<T, NW>(pw);
+		uint32_t run = carry + wave_incl_scan(tp) - tp;
+		uint32_t cpv[R], ppk[R / 2];
+#pragma unroll
+		for (int r = 0; r < R; r++) { run += pw[r * STEP]; cpv[r] = run; }
+#pragma unroll
+		for (int r = 0; r < R / 2; r++) ppk[r] = pw[2 * r * STEP] | (pw[(2 * r + 1) * STEP] << 16);
+		// per-lane sums for a group of QG queries first, then their 3*QG wave reductions back to back: the DPP chains are
+		// independent, so their latency overlaps instead of stalling a wave that has only 1-2 partners on its SIMD
+		constexpr int QG = TQ < 4 ? TQ : 4;
+#pragma unroll
+		for (int j0 = 0; j0 < TQ; j0 += QG) {
+			uint32_t manh[QG], dot[QG], emd[QG];
+#pragma unroll
+			for (int jj = 0; jj < QG; jj++) {
+				const int j = j0 + jj;
+				manh[jj] = 0; dot[jj] = 0; emd[jj] = 0;
+#pragma unroll
+				for (int r = 0; r < R / 2; r++) {
+					manh[jj] = __builtin_amdgcn_sad_u16(ppk[r], qpk[j][r], manh[jj]);
+					dot[jj] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, ppk[r]), __builtin_bit_cast(u16x2, qpk[j][r]), dot[jj], false);
+					emd[jj] = sad_u32(cpv[2 * r], cqv[j][2 * r], emd[jj]);
+					emd[jj] = sad_u32(cpv[2 * r + 1], cqv[j][2 * r + 1], emd[jj]);
+				}
+			}
+			uint32_t manh_t[QG];
+			uint64_t dot_t[QG], emd_t[QG];
+			if constexpr (COMPACT) {
+				uint32_t a[QG], b[QG], d[QG];
+#pragma unroll
+				for (int jj = 0; jj < QG; jj++) { a[jj] = wave_incl_scan(manh[jj]); b[jj] = wave_incl_scan(dot[jj]); d[jj] = wave_incl_scan(emd[jj]); }
+#pragma unroll
+				for (int jj = 0; jj < QG; jj++) {
+					manh_t[jj] = (uint32_t)__builtin_amdgcn_readlane((int)a[jj], 63);
+					dot_t[jj] = (uint32_t)__builtin_amdgcn_readlane((int)b[jj], 63);
+					emd_t[jj] = (uint32_t)__builtin_amdgcn_readlane((int)d[jj], 63);
+				}
+			} else {
+#pragma unroll
+				for (int jj = 0; jj < QG; jj++) { manh_t[jj] = wave_total_u32(manh[jj]); dot_t[jj] = wave_total_u64(dot[jj]); emd_t[jj] = wave_total_u64(emd[jj]); }
+			}
+			if (lane == 0) {
+#pragma unroll
+				for (int jj = 0; jj < QG; jj++) {
+					if (qvalid[j0 + jj]) {
+						MscPartial out;
+						out.manh = manh_t[jj];
+						out.dot = dot_t[jj];
+						out.emd = emd_t[jj];
+						partials[((uint64_t)(qb * TQ + j0 + jj) * m + c) * S + s] = out;
+					}
+				}
+			}
+			if constexpr (TQ > QG) __builtin_amdgcn_sched_barrier(0);
 		}
 	}
 }
@@ -347,9 +624,14 @@ __device__ __forceinline__ uint64_t shfl_sum_u64(uint64_t v) {
 }
 
 __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t) {
-	const uint32_t slot = a.cand_slots ? a.cand_slots[c] : c;
+	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
+	uint32_t ci = c, qi = 0;
+	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
+	const uint32_t slot = a.cand_slots ? a.cand_slots[ci] : ci;
 	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride);
-	const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
+	const MscSlotScalars* qs = a.n_queries > 1
+	    ? reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)a.q_slots[qi] * a.q_scalar_stride)
+	    : reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
 	Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
 	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
@@ -365,6 +647,9 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 		if (a.model && a.singles_out) for (int i = 0; i < a.model->n_singles; i++) a.singles_out[(uint64_t)c * a.model->n_singles + i] = NAN;
 		if (a.model && a.combos_out) for (int i = 0; i < a.model->n_combos; i++) a.combos_out[(uint64_t)c * a.model->n_combos + i] = NAN;
 		if (a.pair_out) a.pair_out[c] = po;
+		if (a.sum_soa) a.sum_soa[c] = NAN;
+		if (a.csum_soa) a.csum_soa[c] = NAN;
+		if (a.close_soa) a.close_soa[c] = 0;
 		return;
 	}
 	int err = 0;
@@ -408,6 +693,10 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	}
 	po.status = err;
 	if (a.pair_out) a.pair_out[c] = po;
+	if (a.sum_soa) a.sum_soa[c] = po.sum;
+	if (a.csum_soa) a.csum_soa[c] = po.csum;
+	if (a.close_soa) a.close_soa[c] = (uint8_t)(err == 0 && po.close);
+	if (err < 0 && a.error_word) atomicMin(a.error_word, err);
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogueArgs a) {
@@ -658,6 +947,72 @@ hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype, 
 	case 32: return launch_tiles_lpt<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
 	default: return launch_tiles_lpt<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, tb, div_tables, div_partials, order);
 	}
+}
+
+template <typename T, int TQ, bool COMPACT>
+static hipError_t launch_multi_t(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, uint32_t m,
+                                 const uint8_t* qb, uint64_t qsb, const uint8_t* qs, uint64_t qss, const uint32_t* qslots, uint32_t nq,
+                                 MscPartial* partials, int num_cus) {
+	const uint32_t S = L.S;
+	const uint32_t nqb = (nq + TQ - 1) / TQ;
+	// Grid policy. "round" (default): exactly ONE resident round of equal-length waves, sized from the kernel's real
+	// occupancy, so no partially filled tail round exists. "fine": ~8 rounds of short waves (>= 32 candidates each).
+	int blocks_per_cu = 0;
+	const void* fn = nullptr;
+	if constexpr (sizeof(T) >= 4) { if (L.LPT == 4) fn = (const void*)k_pair_tiles_multi32<T, 4, TQ, COMPACT>; }
+	if (!fn) {
+		if constexpr (TQ <= 4) {
+			fn = L.LPT == 1 ? (const void*)k_pair_tiles_multi<T, 1, TQ, COMPACT> : L.LPT == 2 ? (const void*)k_pair_tiles_multi<T, 2, TQ, COMPACT>
+			                                                                                   : (const void*)k_pair_tiles_multi<T, 4, TQ, COMPACT>;
+		}
+	}
+	if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, 0) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 2;
+	static const int policy = [] { const char* e = getenv("MSC_MULTI_GRID"); return e && e[0] == 'f' ? 1 : e && e[0] == 'o' ? 2 : 0; }();
+	uint64_t target_waves = (uint64_t)num_cus * blocks_per_cu * kWavesPerBlock;
+	if (policy == 1) target_waves = (uint64_t)num_cus * 12 * 8;
+	if (policy == 2) target_waves = (uint64_t)num_cus * 16;
+	uint64_t G = target_waves / ((uint64_t)S * nqb);
+	if (policy == 1 && G > (m + 31) / 32) G = (m + 31) / 32;
+	if (G < 1) G = 1;
+	if (G > m) G = m;
+	const uint64_t waves = (uint64_t)S * G * nqb;
+	const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+	const uint64_t stride = msc_scalar_stride(S);
+	if constexpr (sizeof(T) >= 4) {
+		if (L.LPT == 4) {
+			k_pair_tiles_multi32<T, 4, TQ, COMPACT><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qsb, qs, qss, qslots, nq, S, (uint32_t)G, partials);
+			return hipGetLastError();
+		}
+	}
+	if constexpr (TQ > 4) return hipErrorInvalidValue;       // the generic form keeps raw query tiles in registers: TQ <= 4
+	else
+	switch (L.LPT) {
+	case 1: k_pair_tiles_multi<T, 1, TQ, COMPACT><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qsb, qs, qss, qslots, nq, S, (uint32_t)G, partials); break;
+	case 2: k_pair_tiles_multi<T, 2, TQ, COMPACT><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qsb, qs, qss, qslots, nq, S, (uint32_t)G, partials); break;
+	default: k_pair_tiles_multi<T, 4, TQ, COMPACT><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qsb, qs, qss, qslots, nq, S, (uint32_t)G, partials); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_pair_tiles_multi(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                       const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
+                                       const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q,
+                                       int tq, bool compact, MscPartial* partials, int num_cus) {
+	if (m == 0 || n_q == 0) return hipSuccess;
+#define MSC_MULTI_ARGS st, L, cand_bins, cand_scalars, cand_slots, m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, q_slots, n_q, partials, num_cus
+#define MSC_MULTI(T)                                                                                          \
+	((tq >= 8 && sizeof(T) >= 4 && L.LPT == 4)                                                                      \
+	     ? (compact ? launch_multi_t<T, 8, true>(MSC_MULTI_ARGS) : launch_multi_t<T, 8, false>(MSC_MULTI_ARGS))  \
+	 : tq >= 4 ? (compact ? launch_multi_t<T, 4, true>(MSC_MULTI_ARGS) : launch_multi_t<T, 4, false>(MSC_MULTI_ARGS)) \
+	           : (compact ? launch_multi_t<T, 2, true>(MSC_MULTI_ARGS) : launch_multi_t<T, 2, false>(MSC_MULTI_ARGS)))
+	switch (dtype) {
+	case 8: return MSC_MULTI(uint8_t);
+	case 16: return MSC_MULTI(uint16_t);
+	case 32: return MSC_MULTI(uint32_t);
+	default: return MSC_MULTI(uint64_t);
+	}
+#undef MSC_MULTI
+#undef MSC_MULTI_ARGS
 }
 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {

@@ -93,3 +93,36 @@ class ShardedTrainer:
             recs = rec.cpu().numpy().reshape(1, 3)
         n_close, sim, g, is_min = fold_records(recs)
         return flags, g, sim, is_min, n_close
+
+
+class ShardedBlockScorer:
+    """n_q queries x every candidate of every rank in one pass per rank (the all-pairs shape, fastcar work()).
+
+    backend.query_buffers(j) / export_query(local) as above but per query slot j; backend.import_queries(n_q);
+    backend.score_block(n_q) -> close flags [n_q, local_count] (np.uint8). Per block the only exchanges are the n_q query
+    broadcasts and one all-gather of the per-query close counts."""
+
+    def __init__(self, dist, plan, backend, rank, device="cpu"):
+        self.dist, self.plan, self.backend, self.rank, self.device = dist, plan, backend, rank, device
+
+    def score_block(self, query_globals):
+        import torch
+        for j, qg in enumerate(query_globals):
+            owner = self.plan.owner(qg)
+            bufs = self.backend.query_buffers(j)
+            if self.rank == owner:
+                for dst, src in zip(bufs, self.backend.export_query(self.plan.local(qg))):
+                    dst.copy_(src)
+            if self.plan.world > 1:
+                for b in bufs:
+                    self.dist.broadcast(b, src=owner)
+        self.backend.import_queries(len(query_globals))
+        close = self.backend.score_block(len(query_globals))
+        counts = torch.tensor(close.sum(axis=1).astype(np.float64), dtype=torch.float64, device=self.device)
+        if self.plan.world > 1:
+            out = [torch.zeros_like(counts) for _ in range(self.plan.world)]
+            self.dist.all_gather(out, counts)
+            total = torch.stack(out).sum(dim=0).cpu().numpy()
+        else:
+            total = counts.cpu().numpy()
+        return close, total

@@ -254,3 +254,23 @@ def test_device_view_is_usable_from_torch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", _TORCH_VIEW_SCRIPT, root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert b"TORCH_VIEW_OK" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
+
+
+@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 5), (16, 5, 7), (8, 9, 4), (16, 7, 2), (64, 6, 3), (8, 3, 3)])
+def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
+    """msc_score_multi (candidate tiles reused across several query tiles) == nq independent 1 x M passes, bit for bit."""
+    seqs, _ = synth.families(500 + k, 40, 1000 if k > 3 else 60, family=10)
+    hs = api.HistogramSet(ctx, k, dtype, len(seqs))
+    hs.build(seqs)
+    wts = "weights_k9_u32.txt" if dtype == 32 else "weights_k5_u16_slow.txt" if k == 7 else "weights_k5_u16.txt"
+    feat = api.Feature.from_text(ctx, weights_text(wts), 0)
+    cands = np.arange(3, len(seqs), dtype=np.uint32)
+    qs = np.arange(nq, dtype=np.uint32) * 2
+    mask = FAST_MASK if k == 7 else (FAST_MASK & ~((1 << 7) | (1 << 29)))
+    multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+    for i, q in enumerate(qs):
+        single = feat.compute(hs, cands, hs, int(q))
+        raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), mask)
+        assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
+        assert np.array_equal(multi["raw"][i], raw)
+        assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))

@@ -43,8 +43,9 @@ def main():
         for k, v in agg.items():
             pmc.setdefault(k, {})[ctr] = {"launches": len(v), "mean_kib": sum(v) / len(v)}
     for k, d in pmc.items():
-        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        if isinstance(d, dict) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"]["mean_kib"] + d["WRITE_SIZE"]["mean_kib"]) * 1024
+    pmc["_config"] = sys.argv[5] if len(sys.argv) > 5 else ""
     json.dump(pmc, open(os.path.join(out_dir, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
     print("wrote profiles/%s_kernel_stats.csv and profiles/%s_pmc_hbm.json" % (tag, tag))
 
