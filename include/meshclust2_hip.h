@@ -160,6 +160,10 @@ int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc
  * bins, length and id are copied, `mag` is NOT. */
 int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
 
+/* Exact slot copy: bins and EVERY scalar (incl. a stale mag). What a host container of Center objects needs when it
+ * relocates them without going through clone() (std::vector growth of the device-side centre store). */
+int msc_hist_copy(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
+
 /* ------------------------------------------------------------------ a5/a7: model (Feature<T> + GLM weights) */
 /* Mirrors the state Predictor::read_from builds (predict/Predictor.cpp:125-185): combos are replayed through
  * Feature::add_feature (predict/Feature.cpp:102-128) so single-feature order == order of first appearance.

@@ -523,6 +523,13 @@ extern "C" int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, cons
 	return refresh_bounds(ctx, dst, ds, 1);
 }
 
+extern "C" int msc_hist_copy(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
+	int r = copy_common(ctx, dst, ds, src, ss);
+	if (r) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(dst->scalars + ds * dst->scalar_stride, src->scalars + ss * src->scalar_stride, dst->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
+	return refresh_bounds(ctx, dst, ds, 1);
+}
+
 extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
 	int r = copy_common(ctx, dst, ds, src, ss);
 	if (r) return r;

@@ -76,6 +76,7 @@ public:
 	// Center(c) takes c->clone(); centre->set(*next) keeps the stale magnitude (clutil/DivergencePoint.cpp:182-190)
 	void clone(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_clone(ctx_.get(), h_, dst, src.h_, src_slot)); }
 	void set(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_assign(ctx_.get(), h_, dst, src.h_, src_slot)); }
+	void copy(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_copy(ctx_.get(), h_, dst, src.h_, src_slot)); }
 private:
 	Context& ctx_;
 	msc_hist_set* h_ = nullptr;

@@ -1,0 +1,437 @@
+// msc_cluster.cpp -- mean-shift driver + CD-HIT .clstr writer over the GPU hot path.
+//
+// The reference's clustering logic (cluster/ClusterFactory.cpp MS / accumulate / mean_shift_update / merge /
+// print_output, cluster/bvec.cpp, cluster/CRunner.cpp do_run) is host control flow AROUND the hot path. It is written
+// here from scratch against meshclust2_host.hpp so that "identical CLSTR output" can be produced and checked on the GPU
+// box, where only this repository exists. Histograms never leave HBM: the driver handles slots, lengths, flags, scalars.
+//
+// Behaviour reproduced on purpose (SURVEY.md findings): the exclusive use of an inclusive end index in the scoring
+// window (Q6), DivergencePoint::set keeping the stale magnitude of a moved centre (Q7), the OMP_NUM_THREADS=1 order of
+// every reduction and of remove_available (Q10), the unstable std::sort orders (same libstdc++, same comparator, same
+// input order => same permutation), bvec::insert's "middle of the least-filled bins" rule and the quirks of
+// index_of / inner_index_of when a bin is empty.
+//
+// Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
+//   msc_cluster <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64]
+//               [--output output.clstr] [--delta 5] [--iterations 15] [--device 0]
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "meshclust2_host.hpp"
+
+namespace {
+
+struct Pt {                      // host shadow of one Point<T>: everything the clustering logic reads
+	std::string header;          // full header line including '>'
+	uint64_t length = 0;         // effective length
+	uint64_t id = 0;
+	uint32_t slot = 0;           // slot in the device point set
+};
+
+// ------------------------------------------------------------------ FASTA (nonltr/ChromListMaker.cpp:24-48,117-165)
+bool safe_getline(std::istream& is, std::string& t) {
+	t.clear();
+	std::streambuf* sb = is.rdbuf();
+	for (;;) {
+		int c = sb->sbumpc();
+		if (c == '\n') return true;
+		if (c == '\r') { if (sb->sgetc() == '\n') sb->sbumpc(); return true; }
+		if (c == std::streambuf::traits_type::eof()) { if (t.empty()) { is.setstate(std::ios::eofbit); return false; } return true; }
+		t += (char)c;
+	}
+}
+
+void read_fasta(const std::string& path, std::vector<std::string>& headers, std::vector<std::string>& seqs) {
+	std::ifstream in(path.c_str());
+	if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(1); }
+	std::string line;
+	bool have = false;
+	while (in.good()) {
+		if (!safe_getline(in, line)) break;
+		if (!line.empty() && line[0] == '>') {
+			headers.push_back(line);
+			seqs.emplace_back();
+			have = true;
+		} else if (!line.empty() && (line[0] == ' ' || line[0] == '\t')) {
+			continue;
+		} else if (have) {
+			seqs.back() += line;
+		}
+	}
+}
+
+// ------------------------------------------------------------------ bvec (cluster/bvec.{h,cpp})
+struct BIdx { size_t first = 0, second = 0; bool is_empty = false; };
+using Entry = std::pair<Pt*, bool>;
+
+class BVec {
+public:
+	BVec(std::vector<uint64_t> lengths, uint64_t bin_size = 1000) {
+		std::sort(lengths.begin(), lengths.end());
+		for (uint64_t i = 0; i < lengths.size(); i += bin_size) begin_bounds.push_back(lengths[i]);
+		data.resize(begin_bounds.size());
+	}
+	void insert(Pt* p) {                                   // bvec.cpp:150-184
+		size_t front = 0, back = 0;
+		index_of(p->length, &front, &back);
+		std::vector<size_t> mins;
+		size_t minimum = std::numeric_limits<size_t>::max();
+		for (size_t i = front; i <= back; i++) {
+			size_t sz = data[i].size();
+			if (sz < minimum) { minimum = sz; mins.clear(); mins.push_back(i); }
+			else if (sz == minimum) mins.push_back(i);
+		}
+		if (mins.empty()) { std::fprintf(stderr, "error: no bins to insert into\n"); std::exit(1); }
+		data.at(mins[mins.size() / 2]).push_back(std::make_pair(p, false));
+	}
+	void insert_finalize() {                               // bvec.cpp:216-233
+		for (auto& bin : data) std::sort(bin.begin(), bin.end(), [](const Entry a, const Entry b) { return a.first->length < b.first->length; });
+	}
+	Pt* pop() {                                            // bvec.cpp:27-37
+		for (auto& bin : data) if (!bin.empty()) { Pt* p = bin[0].first; bin.erase(bin.begin()); return p; }
+		return nullptr;
+	}
+	bool index_of(uint64_t point, size_t* pfront, size_t* pback) const {      // bvec.cpp:123-147
+		size_t low = begin_bounds.size() - 1, high = 0;
+		for (size_t i = 1; i < begin_bounds.size(); i++) {
+			const uint64_t prev = begin_bounds[i - 1];
+			if (point >= prev && point < begin_bounds[i]) { low = std::min(low, i - 1); high = std::max(high, i - 1); }
+		}
+		if (point >= begin_bounds[begin_bounds.size() - 1]) high = std::max(high, begin_bounds.size() - 1);
+		if (pfront) *pfront = low;
+		if (pback) *pback = high;
+		return true;
+	}
+	bool inner_index_of(uint64_t length, size_t& idx, size_t* pfront, size_t* pback) const {   // bvec.cpp:52-120
+		if (data.at(idx).empty()) {
+			if (pfront) for (size_t i = 0; i < data.size(); i++) if (!data[i].empty()) { idx = i; *pfront = 0; break; }
+			if (pback) for (long i = (long)data.size() - 1; i >= 0; i--) if (!data[i].empty()) { idx = (size_t)i; *pback = 0; break; }
+			return true;
+		}
+		const auto& bin = data[idx];
+		size_t front = 0, back = 0;
+		size_t low = 0, high = bin.size() - 1;
+		if (length < bin[low].first->length && pfront) *pfront = low;
+		if (length > bin[high].first->length && pback) *pback = high;
+		for (; low <= high;) {
+			size_t mid = (low + high) / 2;
+			uint64_t d = bin[mid].first->length;
+			if (d == length) { front = mid; back = mid; break; }
+			else if (length < d) high = mid;
+			else low = mid + 1;
+			if (low == high) { front = low; back = high; break; }
+		}
+		if (pfront) {
+			for (long i = (long)front; i >= 0 && bin[i].first->length == length; i--) front = (size_t)i;
+			*pfront = front;
+		}
+		if (pback) {
+			for (size_t i = back; i < bin.size() && bin[i].first->length == length; i++) back = i;
+			*pback = back;
+		}
+		return true;
+	}
+	std::pair<BIdx, BIdx> get_range(uint64_t begin_len, uint64_t end_len) const {             // bvec.cpp:261-330
+		BIdx front, back;
+		back.first = data.size() - 1;
+		back.second = data[back.first].size() - 1;
+		index_of(begin_len, &front.first, nullptr);
+		index_of(end_len, nullptr, &back.first);
+		inner_index_of(begin_len, front.first, &front.second, nullptr);
+		inner_index_of(end_len, back.first, nullptr, &back.second);
+		if (back.first == (size_t)-1 || back.second == (size_t)-1) back.is_empty = true;
+		return std::make_pair(front, back);
+	}
+	void erase(size_t r, size_t c) { data.at(r).erase(data.at(r).begin() + (long)c); }
+	void remove_available(BIdx begin, BIdx end, std::vector<Pt*>& available) {                // bvec.cpp:342-384, one thread
+		if (begin.is_empty || end.is_empty) return;
+		for (size_t i = begin.first; i <= end.first && i < data.size(); i++) {
+			for (auto& kv : data[i]) if (kv.second) available.push_back(kv.first);
+			data[i].erase(std::remove_if(data[i].begin(), data[i].end(), [](const Entry d) { return d.second; }), data[i].end());
+		}
+	}
+	std::vector<std::vector<Entry>> data;
+	std::vector<uint64_t> begin_bounds;
+};
+
+// bvec_iterator (cluster/bvec_iterator.{h,cpp})
+struct BIter {
+	size_t r, c;
+	std::vector<std::vector<Entry>>* col;
+	void next() {
+		if (r != col->size()) {
+			if (c + 1 < col->at(r).size()) c++;
+			else { r++; c = 0; while (r < col->size() && col->at(r).empty()) r++; }
+		} else { std::fprintf(stderr, "tried incrementing null iterator\n"); std::exit(1); }
+	}
+	bool less(const BIter& o) const { return r < o.r || (r == o.r && c < o.c); }
+	// operator- (bvec_iterator.h:57-76): what the reference's `#pragma omp parallel for` uses as the trip count
+	int64_t minus(const BIter& rhs) const {
+		if (less(rhs)) return -1 * rhs.minus(*this);
+		if (r == rhs.r) return (int64_t)(c - rhs.c);
+		int64_t sum = (int64_t)c;
+		sum += (int64_t)(col->at(rhs.r).size() - rhs.c);
+		for (size_t i = rhs.r + 1; i < r; i++) sum += (int64_t)col->at(i).size();
+		return sum;
+	}
+};
+
+// ------------------------------------------------------------------ centres (cluster/Center.h)
+struct Centre {
+	uint32_t cslot = 0;          // slot in the device centre store (a clone of a point, possibly moved by set())
+	std::string header;
+	uint64_t id = 0, length = 0;
+	std::vector<Pt*> points;
+	bool to_delete = false;
+};
+
+struct Driver {
+	msc::Context& ctx;
+	msc::PointSet& points;
+	msc::Trainer& trn;
+	int k, dtype;
+	std::unique_ptr<msc::PointSet> centres;
+	uint64_t n_centres = 0;
+
+	Driver(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt) : ctx(c), points(p), trn(t), k(k_), dtype(dt) {
+		centres.reset(new msc::PointSet(ctx, k, dtype, 256));
+	}
+	uint32_t new_centre_slot() {
+		if (n_centres == centres->capacity()) {        // grow without touching any scalar (stale mags survive)
+			std::unique_ptr<msc::PointSet> bigger(new msc::PointSet(ctx, k, dtype, centres->capacity() * 2));
+			for (uint64_t i = 0; i < n_centres; i++) bigger->copy(i, *centres, i);
+			centres.swap(bigger);
+		}
+		return (uint32_t)n_centres++;
+	}
+	// Center(Point* c, pts): center(c->clone())
+	Centre make_centre(Pt* c, const std::vector<Pt*>& pts) {
+		Centre ce;
+		ce.cslot = new_centre_slot();
+		centres->clone(ce.cslot, points, c->slot);
+		ce.header = c->header; ce.id = c->id; ce.length = c->length;
+		ce.points = pts;
+		return ce;
+	}
+	// center->set(*next): bins, length, header, id -- not mag
+	void centre_set(Centre& ce, Pt* next) {
+		centres->set(ce.cslot, points, next->slot);
+		ce.header = next->header; ce.id = next->id; ce.length = next->length;
+	}
+
+	static std::vector<uint32_t> slots_of(const std::vector<Pt*>& v) {
+		std::vector<uint32_t> s(v.size());
+		for (size_t i = 0; i < v.size(); i++) s[i] = v[i]->slot;
+		return s;
+	}
+
+	// get_mean (cluster/ClusterFactory.cpp:338-380): member nearest to the FP64 mean
+	Pt* get_mean(const std::vector<Pt*>& available) {
+		if (available.empty()) { std::fprintf(stderr, "N cannot be 0, bad\n"); std::exit(1); }
+		int64_t pos = trn.closest(points, slots_of(available));
+		return available[(size_t)pos];
+	}
+
+	// accumulate (cluster/ClusterFactory.cpp:553-610)
+	size_t accumulate(Pt** last_ptr, BVec& bv, std::vector<Centre>& part, double sim) {
+		Pt* last = *last_ptr;
+		std::vector<Pt*> current = {last};
+		bool is_min = false;
+		while (!is_min) {
+			const uint64_t len = last->length;
+			auto bounds = bv.get_range((uint64_t)(len * sim), (uint64_t)(len / sim));
+			// the window [iter(first), iter(second)) -- `i < iend` with an inclusive end index
+			std::vector<uint32_t> window;
+			std::vector<std::pair<size_t, size_t>> where;
+			BIter it{bounds.first.first, bounds.first.second, &bv.data}, end{bounds.second.first, bounds.second.second, &bv.data};
+			// OpenMP turns `for (i = istart; i < iend; ++i)` into (iend - istart) iterations of istart + n
+			const int64_t trips = end.minus(it);
+			for (int64_t n = 0; n < trips; n++) {
+				window.push_back(bv.data.at(it.r).at(it.c).first->slot);
+				where.emplace_back(it.r, it.c);
+				if (n + 1 < trips) it.next();
+			}
+			auto res = trn.get_close(points, window, points, last->slot, is_min);
+			const auto& flags = std::get<2>(res);
+			for (size_t j = 0; j < flags.size(); j++) if (flags[j]) bv.data[where[j].first][where[j].second].second = true;
+			if (is_min) {
+				const int64_t pos = std::get<0>(res);
+				if (pos < 0) {
+					*last_ptr = bv.pop();
+				} else {
+					*last_ptr = bv.data[where[(size_t)pos].first][where[(size_t)pos].second].first;
+					bv.erase(where[(size_t)pos].first, where[(size_t)pos].second);
+				}
+				std::vector<Pt*> none;
+				bv.remove_available(bounds.first, bounds.second, none);
+			} else {
+				bv.remove_available(bounds.first, bounds.second, current);
+				last = get_mean(current);
+			}
+		}
+		part.push_back(make_centre(last, current));
+		return current.size();
+	}
+
+	// mean_shift_update (cluster/ClusterFactory.cpp:288-335)
+	void mean_shift_update(std::vector<Centre>& part, int j, int delta) {
+		Centre& ce = part[(size_t)j];
+		const int i_begin = std::max(0, j - delta);
+		const int i_end = std::min(j + delta, (int)part.size() - 1);
+		std::vector<Pt*> good;
+		for (int i = i_begin; i <= i_end; i++) for (Pt* p : part[(size_t)i].points) good.push_back(p);
+		std::vector<uint32_t> slots = slots_of(good);
+		// trn.filter(center, good): keep what classifies close to the centre
+		{
+			std::vector<uint8_t> keep(slots.size());
+			uint64_t n = 0;
+			ctx.check(msc_filter(ctx.get(), trn.feature().get(), cutoff, centres->get(), ce.cslot, points.get(), slots.data(), slots.size(), keep.data(), &n));
+			std::vector<Pt*> g2;
+			for (size_t i = 0; i < good.size(); i++) if (keep[i]) g2.push_back(good[i]);
+			good.swap(g2);
+		}
+		if (!good.empty()) {
+			int64_t pos = trn.closest(points, slots_of(good));
+			centre_set(ce, good[(size_t)pos]);
+		} else if (delta == 0) {
+			centre_set(ce, ce.points[0]);
+		}
+	}
+
+	// merge (cluster/ClusterFactory.cpp:383-401)
+	bool merge(std::vector<Centre>& centers, int delta) {
+		int num_merge = 0;
+		for (int i = 0; i < (int)centers.size(); i++) {
+			std::vector<uint32_t> cs(centers.size());
+			for (size_t c = 0; c < centers.size(); c++) cs[c] = centers[c].cslot;
+			long ret = trn.merge(*centres, cs, i, i + 1, std::min((int)centers.size() - 1, i + delta));
+			if (ret > i) {
+				num_merge++;
+				auto& to_add = centers[(size_t)ret].points;
+				auto& to_del = centers[(size_t)i].points;
+				to_add.insert(to_add.end(), to_del.begin(), to_del.end());
+				centers[(size_t)i].to_delete = true;
+			}
+		}
+		centers.erase(std::remove_if(centers.begin(), centers.end(), [](const Centre& c) { return c.to_delete; }), centers.end());
+		return num_merge > 0;
+	}
+
+	// print_output (cluster/ClusterFactory.cpp:404-435)
+	static void print_output(const std::string& output, const std::vector<Centre>& partition) {
+		std::ofstream ofs(output.c_str());
+		int counter = 0;
+		for (const auto& cen : partition) {
+			if (cen.points.empty()) continue;
+			ofs << ">Cluster " << counter << std::endl;
+			int pt = 0;
+			for (Pt* p : cen.points) {
+				ofs << pt << "\t" << p->length << "nt, " << p->header << "... ";
+				if (p->id == cen.id) ofs << "*";
+				ofs << std::endl;
+				pt++;
+			}
+			counter++;
+		}
+	}
+
+	// ClusterFactory<T>::MS (cluster/ClusterFactory.cpp:621-656)
+	void MS(BVec& bv, double sim, const std::string& output, int iter, int delta) {
+		std::vector<Centre> part;
+		Pt* last = bv.pop();
+		while (last != nullptr) accumulate(&last, bv, part, sim);
+		std::cout << "Number of clusters before update: " << part.size() << std::endl;
+		std::vector<size_t> num_clusters;
+		for (int i = 0; i < iter; i++) {
+			if (i >= 3 && part.size() == num_clusters[(size_t)i - 3]) break;
+			for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, delta);
+			merge(part, delta);
+			num_clusters.push_back(part.size());
+		}
+		for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, 0);
+		print_output(output, part);
+		std::cout << "Number of clusters: " << part.size() << std::endl;
+	}
+
+	double cutoff = 0.9;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+	std::vector<std::string> files;
+	std::string weights, output = "output.clstr";
+	double similarity = 0.90;
+	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
+		if (a == "--id") similarity = std::atof(need("--id").c_str());
+		else if (a == "--kmer" || a == "-k") k = std::atoi(need("--kmer").c_str());
+		else if (a == "--datatype") { std::string v = need("--datatype"); dtype = v == "uint8_t" ? 8 : v == "uint16_t" ? 16 : v == "uint32_t" ? 32 : v == "uint64_t" ? 64 : std::atoi(v.c_str()); }
+		else if (a == "--recover" || a == "-r") weights = need("--recover");
+		else if (a == "--output" || a == "-o") output = need("--output");
+		else if (a == "--delta" || a == "-d") delta = std::atoi(need("--delta").c_str());
+		else if (a == "--iterations" || a == "-i" || a == "--iter") iterations = std::atoi(need("--iterations").c_str());
+		else if (a == "--threads" || a == "-t") need("--threads");
+		else if (a == "--device") device = std::atoi(need("--device").c_str());
+		else files.push_back(a);
+	}
+	if (files.empty() || weights.empty()) {
+		std::fprintf(stderr, "usage: %s <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64] [--output out.clstr] [--delta 5] [--iterations 15]\n", argv[0]);
+		return 1;
+	}
+	try {
+		msc::Context ctx(device);
+		msc::Trainer trn(ctx, weights, similarity);
+		if (k < 0) k = msc_model_k(trn.feature().get());
+		if (dtype == 0) {      // "Datatype:" line of the weights file
+			std::ifstream in(weights.c_str());
+			std::string tok;
+			while (in >> tok) if (tok == "Datatype:") { in >> tok; dtype = tok == "uint8_t" ? 8 : tok == "uint16_t" ? 16 : tok == "uint32_t" ? 32 : 64; break; }
+		}
+		std::vector<std::string> headers, seqs;
+		for (const auto& f : files) read_fasta(f, headers, seqs);
+		const size_t n = seqs.size();
+		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
+		msc::PointSet points(ctx, k, dtype, n);
+		const size_t chunk = 8192;
+		for (size_t off = 0; off < n; off += chunk) {
+			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(n, off + chunk));
+			points.get_points(off, part);
+		}
+		std::vector<Pt> store(n);
+		std::vector<Pt*> pts(n);
+		for (size_t i = 0; i < n; i++) {
+			store[i].header = headers[i];
+			store[i].slot = (uint32_t)i;
+			store[i].length = points.get_length(i);
+			pts[i] = &store[i];
+		}
+		seqs.clear();
+		// get_points: sort by header, then by length, both unstable std::sort (cluster/CRunner.cpp:538-539)
+		std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->header < b->header; });
+		std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->length < b->length; });
+		std::vector<uint64_t> lengths;
+		for (Pt* p : pts) lengths.push_back(p->length);
+		BVec bv(lengths, 1000);
+		uint64_t idx = 0;
+		for (Pt* p : pts) { p->id = idx++; bv.insert(p); }
+		bv.insert_finalize();
+		Driver drv(ctx, points, trn, k, dtype);
+		drv.cutoff = similarity;
+		drv.MS(bv, similarity, output, iterations, delta);
+	} catch (const msc::Error& e) {
+		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());
+		return 3;
+	}
+	return 0;
+}

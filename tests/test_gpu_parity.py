@@ -274,3 +274,24 @@ def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
         assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
         assert np.array_equal(multi["raw"][i], raw)
         assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))
+
+
+def test_cluster_driver_reproduces_reference_clstr(tmp_path):
+    """the from-scratch mean-shift driver over the GPU path, fed the model the reference trained, writes
+    the SAME .clstr bytes as the reference CLI did for cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16, 1 thread)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_cluster")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "meshclust2_amd", "host")])
+    seqs, hdrs = synth.families(20260001, 1000, 1000)
+    fa = str(tmp_path / "cfg1.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([exe, fa, "--recover", os.path.join(golden, "weights_k5_u16.txt"), "--id", "0.9", "--kmer", "5", "--datatype", "16", "--output", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "cfg1.clstr"), "rb").read()
+    assert got == exp, "CLSTR differs: %d vs %d bytes\n%s" % (len(got), len(exp), r.stdout.decode(errors="replace")[-500:])
