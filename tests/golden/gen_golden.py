@@ -182,6 +182,29 @@ def make_kat():
     print("wrote kat_appendix_d.json")
 
 
+def mixed_length_set():
+    """2400 sequences in three length groups (~600 / ~1000 / ~1500 bp, +-120 per family): three bvec bins, real length windows"""
+    seqs, hdrs = [], []
+    for gi, (n, length, seed) in enumerate(((800, 600, 31), (800, 1000, 32), (800, 1500, 33))):
+        s, h = synth.families(seed, n, length, length_jitter=120)
+        seqs += s
+        hdrs += [">m%d_%s" % (gi, x[1:]) for x in h]
+    return seqs, hdrs
+
+
+def make_mixed_clstr():
+    """reference CLI end to end (train + cluster, 1 thread) on the mixed-length set: its weights.txt and its .clstr"""
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = mixed_length_set()
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    run_reference_cli(fa, ["--id", "0.8", "--kmer", "6", "--datatype", "16", "--threads", "1", "--output", "out.clstr"], tmp)
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_mixed_k6_u16.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "mixed.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote mixed.clstr")
+
+
 NASTY = [
     b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT" * 6,
     b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat" * 9,
@@ -191,6 +214,7 @@ if __name__ == "__main__":
     if not ref_py.available():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` (needs /root/reference)")
     make_kat()
+    make_mixed_clstr()
     make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])

@@ -295,3 +295,28 @@ def test_cluster_driver_reproduces_reference_clstr(tmp_path):
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "cfg1.clstr"), "rb").read()
     assert got == exp, "CLSTR differs: %d vs %d bytes\n%s" % (len(got), len(exp), r.stdout.decode(errors="replace")[-500:])
+
+
+def test_cluster_driver_mixed_lengths(tmp_path):
+    """Same, on 2400 sequences in three length groups (--id 0.8 --kmer 6): several bvec bins, length windows that prune,
+    the inclusive-end window quirk and stale-magnitude centres (Q7) all in play."""
+    import os
+    import subprocess
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(sys_path_root, "meshclust2_amd", "host", "msc_cluster")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(sys_path_root, "meshclust2_amd", "host")])
+    seqs, hdrs = [], []
+    for gi, (n, length, seed) in enumerate(((800, 600, 31), (800, 1000, 32), (800, 1500, 33))):
+        s_, h_ = synth.families(seed, n, length, length_jitter=120)
+        seqs += s_
+        hdrs += [">m%d_%s" % (gi, x[1:]) for x in h_]
+    fa = str(tmp_path / "mixed.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    golden = os.path.join(sys_path_root, "tests", "golden")
+    r = subprocess.run([exe, fa, "--recover", os.path.join(golden, "weights_mixed_k6_u16.txt"), "--id", "0.8", "--kmer", "6", "--datatype", "16", "--output", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "mixed.clstr"), "rb").read()
+    assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
