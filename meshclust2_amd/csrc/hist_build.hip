@@ -201,6 +201,87 @@ __global__ void __launch_bounds__(64) k_prefix(uint8_t* __restrict__ scalars, ui
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ small k: one fused LDS pass
+// 4^k <= 16384 bins (k <= 7): the whole histogram lives in LDS as 32-bit counters. One workgroup per sequence streams
+// its packed 2-bit k-mers, counts them with LDS atomics, then writes the slot ONCE in the tile-permuted layout
+// (pseudocount added, saturated at max(T)) while folding sum / sum of squares / max / tile sums with wave reductions.
+// No fill pass, no global atomics, no finalize re-read: N*sizeof(T) bytes written + L/4 read per sequence.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_lds(T* __restrict__ bins, uint8_t* __restrict__ scalars, uint64_t scalar_stride,
+                                                     uint64_t slot_elems, uint64_t first_slot, int k, uint32_t E, uint32_t R, uint32_t S,
+                                                     uint64_t nbins, const uint32_t* __restrict__ packed,
+                                                     const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ kmer_off,
+                                                     const uint64_t* __restrict__ seq_seg_begin) {
+	extern __shared__ uint32_t s_cnt[];                  // nbins counters
+	__shared__ uint64_t s_tile[16];
+	__shared__ uint64_t s_red[3][kBlock / 64];
+	const uint32_t seq = blockIdx.x;
+	const uint64_t slot = first_slot + seq;
+	for (uint32_t i = threadIdx.x; i < nbins; i += kBlock) s_cnt[i] = 0;
+	if (threadIdx.x < 16) s_tile[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t sb = seq_seg_begin[seq], se = seq_seg_begin[seq + 1];
+	for (uint64_t j = sb; j < se; j++) {
+		const uint64_t nk = kmer_off[j + 1] - kmer_off[j];
+		const uint64_t base = seg_start[j];
+		for (uint64_t t = threadIdx.x; t < nk; t += kBlock) {
+			const uint64_t pos = base + t;
+			const uint64_t w = pos >> 4;
+			const uint32_t sh = (uint32_t)(pos & 15) * 2;
+			const uint64_t window = (uint64_t)packed[w] | ((uint64_t)packed[w + 1] << 32);
+			uint32_t bits = (uint32_t)(window >> sh);
+			bits &= (1u << (2 * k)) - 1u;
+			atomicAdd(&s_cnt[rev2(bits) >> (32 - 2 * k)], 1u);
+		}
+	}
+	__syncthreads();
+	// write-out in physical order, 16 bytes per thread-iteration
+	constexpr uint32_t EL = 16 / sizeof(T);
+	const uint64_t tmax = sizeof(T) == 8 ? ~0ull : ((1ull << (8 * sizeof(T))) - 1);
+	const uint32_t tile_bins = 64 * R;
+	uint64_t sum = 0, sq = 0, mx = 0, ovf = 0;
+	T* out = bins + slot * slot_elems;
+	for (uint32_t c = threadIdx.x; c < slot_elems / EL; c += kBlock) {
+		const uint32_t tile = (c * EL) / tile_bins;
+		const uint32_t in_tile = (c * EL) % tile_bins;
+		const uint32_t t = in_tile / (64 * E), lane = (in_tile % (64 * E)) / E;
+		T v[EL];
+		uint64_t ts = 0;
+#pragma unroll
+		for (uint32_t e = 0; e < EL; e++) {
+			const uint64_t logical = (uint64_t)tile * tile_bins + (uint64_t)lane * R + t * E + e;
+			uint64_t val = 0;
+			if (logical < nbins) {
+				val = 1ull + s_cnt[logical];                          // pseudocount 1 + occurrences
+				if (val > tmax) { val = tmax; ovf = 1; }              // wholesaleIncrementNoOverflow stops at max(T)
+			}
+			v[e] = (T)val;
+			ts += val; sq += val * val; mx = val > mx ? val : mx;
+		}
+		*reinterpret_cast<uint4*>(out + (uint64_t)c * EL) = *reinterpret_cast<const uint4*>(v);
+		sum += ts;
+		ts = wave_sum_u64(ts);      // a wave's 64 consecutive chunks never straddle a tile (tiles are >= 64 chunks)
+		if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&s_tile[tile], (unsigned long long)ts);
+	}
+	sum = wave_sum_u64(sum); sq = wave_sum_u64(sq); mx = wave_max_u64(mx); ovf = wave_max_u64(ovf);
+	const uint32_t wave = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) { s_red[0][wave] = sum; s_red[1][wave] = sq; s_red[2][wave] = mx | (ovf << 63); }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t a = 0, b = 0, cmx = 0, o = 0;
+		for (int i = 0; i < kBlock / 64; i++) { a += s_red[0][i]; b += s_red[1][i]; const uint64_t m_ = s_red[2][i] & ~(1ull << 63); cmx = m_ > cmx ? m_ : cmx; o |= s_red[2][i] >> 63; }
+		MscSlotScalars* sc = reinterpret_cast<MscSlotScalars*>(scalars + slot * scalar_stride);
+		sc->sum = a; sc->sum_sq = b; sc->max_count = cmx; sc->mag = a; sc->overflow = o;
+		const double N = (double)nbins;
+		const double aq = (double)a / N;
+		const double var = ((double)b - 2.0 * aq * (double)a + N * aq * aq) / N;
+		sc->stddev = sqrt(var > 0 ? var : 0);
+		uint64_t* prefix = reinterpret_cast<uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
+		uint64_t run = 0;
+		for (uint32_t i = 0; i < S; i++) { prefix[i] = run; run += s_tile[i]; }
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ permute (upload / download)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_permute(const T* __restrict__ src, T* __restrict__ dst, uint64_t nbins, uint64_t padded,
@@ -260,6 +341,22 @@ hipError_t msc_launch_count(hipStream_t st, void* bins, uint8_t* scalars, const 
 		else
 			k_count<T, false><<<dim3(grid), dim3(kBlock), 0, st>>>((T*)bins, scalars, stride, L.padded_bins, first_slot, k, L.E, L.R,
 			                                                        packed_words, seg_seq, seg_start, kmer_off, n_segs, total_kmers);
+	});
+	return hipGetLastError();
+}
+
+bool msc_lds_build_supported(const MscLayout& L) { return L.nbins <= 16384 && L.S <= 16; }
+
+hipError_t msc_launch_build_lds(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype, uint64_t first_slot,
+                                uint64_t n_seqs, const uint32_t* packed_words, const uint64_t* seg_start, const uint64_t* kmer_off,
+                                const uint64_t* seq_seg_begin) {
+	if (n_seqs == 0) return hipSuccess;
+	const uint64_t stride = msc_scalar_stride(L.S);
+	by_dtype(dtype, [&](auto tag) {
+		using T = decltype(tag);
+		k_build_lds<T><<<dim3((unsigned)n_seqs), dim3(kBlock), L.nbins * sizeof(uint32_t), st>>>((T*)bins, scalars, stride, L.padded_bins, first_slot, k,
+		                                                                                         L.E, L.R, L.S, L.nbins, packed_words, seg_start, kmer_off,
+		                                                                                         seq_seg_begin);
 	});
 	return hipGetLastError();
 }

@@ -35,7 +35,7 @@ struct msc_ctx {
 	char dev_name[128] = {0};
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
-	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word;
+	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg;
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 };
 
@@ -138,7 +138,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
-	                  &ctx->err_word};
+	                  &ctx->err_word, &ctx->seq_seg};
 	for (DevBuf* b : bufs) release(*b);
 	(void)hipEventDestroy(ctx->ev_tiles0);
 	(void)hipEventDestroy(ctx->ev_tiles1);
@@ -391,6 +391,25 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_seq.p, seg_seq, n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_start.p, seg_start, n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->kmer_off.p, koff.data(), (n_segs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	// small k: one fused LDS pass per sequence (needs the segments grouped by ascending sequence, as msc_hist_build emits them)
+	bool grouped = true;
+	for (uint64_t j = 1; j < n_segs; j++) if (seg_seq[j] < seg_seq[j - 1]) grouped = false;
+	static const bool no_lds = getenv("MSC_NO_LDS_BUILD") != nullptr;
+	if (msc_lds_build_supported(L) && grouped && !no_lds) {
+		std::vector<uint64_t> sbeg(n_seqs + 1, 0);
+		for (uint64_t j = 0; j < n_segs; j++) sbeg[seg_seq[j] + 1]++;
+		for (uint64_t i = 0; i < n_seqs; i++) sbeg[i + 1] += sbeg[i];
+		if ((r = ensure(ctx, ctx->seq_seg, (n_seqs + 1) * sizeof(uint64_t))) != MSC_OK) return r;
+		if (n_segs == 0) {      // the kernel still reads kmer_off / seg_start pointers only inside empty loops
+			if ((r = ensure(ctx, ctx->seg_start, 8)) != MSC_OK) return r;
+			if ((r = ensure(ctx, ctx->kmer_off, 8)) != MSC_OK) return r;
+		}
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seq_seg.p, sbeg.data(), (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_build_lds(ctx->stream, set->bins, set->scalars, L, k, set->dtype, first_slot, n_seqs, (const uint32_t*)ctx->packed.p,
+		                                  (const uint64_t*)ctx->seg_start.p, (const uint64_t*)ctx->kmer_off.p, (const uint64_t*)ctx->seq_seg.p));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // sbeg lives on this stack frame
+		return refresh_bounds(ctx, set, first_slot, n_seqs);
 	}
 	HIP_TRY(ctx, msc_launch_fill(ctx->stream, set->bins, L, first_slot, n_seqs));
 	HIP_TRY(ctx, msc_launch_count(ctx->stream, set->bins, set->scalars, L, k, set->dtype, first_slot, (const uint32_t*)ctx->packed.p,

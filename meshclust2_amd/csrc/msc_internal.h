@@ -92,6 +92,10 @@ hipError_t msc_launch_count(hipStream_t st, void* bins, uint8_t* scalars, const 
                             uint64_t total_kmers, bool saturating);
 hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,
                                uint64_t first_slot, uint64_t n_slots, bool keep_mag);
+bool msc_lds_build_supported(const MscLayout& L);
+hipError_t msc_launch_build_lds(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype, uint64_t first_slot,
+                                uint64_t n_seqs, const uint32_t* packed_words, const uint64_t* seg_start, const uint64_t* kmer_off,
+                                const uint64_t* seq_seg_begin);
 hipError_t msc_launch_permute(hipStream_t st, const void* src, void* dst, const MscLayout& L, int dtype, bool to_physical);
 
 hipError_t msc_launch_pair_tiles(hipStream_t st, const MscLayout& L, int dtype,
