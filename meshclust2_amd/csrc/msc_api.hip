@@ -743,6 +743,12 @@ struct ScoreRequest {
 	bool only_tiles = false;                // msc_mean_nearest reuses the streaming kernel and folds partials itself
 };
 
+// integer range of the fast streaming kernels (pair_features.hip header); outside it the 64-bit kernel runs
+bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) {
+	const uint64_t mc = std::max(a->max_count, b->max_count), ms = std::max(a->max_sum, b->max_sum);
+	return mc > kNarrowMaxCount || ms > kNarrowMaxSum;
+}
+
 int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* qset, uint64_t q_slot, const uint32_t* slots, uint64_t m) {
 	if (!ctx || !cands || !qset || cands->ctx != ctx || qset->ctx != ctx) return MSC_ERR_INVALID_ARG;
 	if (cands->k != qset->k || cands->dtype != qset->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "query and candidate sets differ in k or dtype");
@@ -750,11 +756,6 @@ int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* q
 	if (m > 0xfffffff0ull) return fail(ctx, MSC_ERR_INVALID_ARG, "too many candidates in one call");
 	if (slots) { for (uint64_t i = 0; i < m; i++) if (slots[i] >= cands->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "candidate slot %u out of range", slots[i]); }
 	else if (m > cands->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "m exceeds capacity");
-	// integer range of the streaming kernel (see pair_features.hip header)
-	const uint64_t mc = std::max(cands->max_count, qset->max_count), ms = std::max(cands->max_sum, qset->max_sum);
-	if (mc > kNarrowMaxCount || ms > kNarrowMaxSum)
-		return fail(ctx, MSC_ERR_UNSUPPORTED, "histogram counts up to %llu / sums up to %llu exceed the 32-bit streaming path (limits %llu / %llu)",
-		            (unsigned long long)mc, (unsigned long long)ms, (unsigned long long)kNarrowMaxCount, (unsigned long long)kNarrowMaxSum);
 	return MSC_OK;
 }
 
@@ -773,6 +774,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	if (rq.model) for (int i = 0; i < ns; i++) want |= rq.model->h.single_flag[i];
 	const bool need_div = (want & MSC_FEAT_DIV) != 0 && !rq.only_tiles;
 	const int tb = msc_div_table_dim(L);
+	const bool wide = needs_wide(rq.cands, rq.qset);
 	ctx->tiles_ms_accum = 0.f;
 	ctx->tiles_launches = 0;
 	ctx->have_timing = false;
@@ -814,9 +816,14 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_bins = cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		HIP_TRY(ctx, msc_launch_pair_tiles(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
-		                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_tables.p : nullptr,
-		                                   need_div ? ctx->div_partials.p : nullptr, rq.order));
+		if (wide) {
+			HIP_TRY(ctx, msc_launch_pair_tiles_wide(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
+			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_partials.p : nullptr, rq.order));
+		} else {
+			HIP_TRY(ctx, msc_launch_pair_tiles(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
+			                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_tables.p : nullptr,
+			                                   need_div ? ctx->div_partials.p : nullptr, rq.order));
+		}
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (rq.only_tiles) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
@@ -885,6 +892,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 
 const uint64_t kSupportedFeats = MSC_FEAT_SLOW;
 
+
 double trainer_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }      // cluster/Trainer.h:35
 
 }  // namespace
@@ -927,7 +935,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const int nf = __builtin_popcountll(feat_mask);
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
-	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1;
+	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset);
 	if (!simple) {
 		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
 		for (uint64_t q = 0; q < n_q; q++) {

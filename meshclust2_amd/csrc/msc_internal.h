@@ -107,6 +107,10 @@ hipError_t msc_launch_pair_tiles_multi(hipStream_t st, const MscLayout& L, int d
                                        const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
                                        const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q,
                                        int tq, bool compact, MscPartial* partials, int num_cus);
+hipError_t msc_launch_pair_tiles_wide(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                      const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
+                                      int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus,
+                                      void* div_partials /*nullable*/, int order);
 int msc_div_table_dim(const MscLayout& L);      // 8 or 16: side of the per-candidate (count, count) term table
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,

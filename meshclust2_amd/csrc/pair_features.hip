@@ -69,6 +69,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // Arithmetic on the PACKED 32-bit words a lane holds after its 16-byte loads. NW words cover the lane's R bins in
 // logical order; bins are never unpacked for the order-independent reductions (v_sad_u8/u16, v_dot4/dot2 work on the
 // packed word), only the prefix statistic touches single bins (byte/half selects fold into SDWA operands).
+__device__ __forceinline__ uint64_t shfl_sum_u64_early(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
 template <typename T> struct Packed;
 template <> struct Packed<uint8_t> {
 	static constexpr int EPW = 4, STEP = 1;
@@ -318,6 +324,84 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 			out.manh = manh_t;
 			out.dot = dot_t;
 			out.emd = emd_t;
+			partials[(uint64_t)c * S + s] = out;
+			if constexpr (DIV) div_partials[(uint64_t)c * S + s] = MscPartialDiv{jd, js};
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- wide (64-bit) streaming kernel
+// Fallback for histograms outside the 32-bit range of k_pair_tiles (a bin > 8191 or a bin sum >= 2^31: long
+// homopolymer / microsatellite sequences). Same work decomposition and the same three reductions, but every bin is
+// widened to 64 bits and every accumulator is 64-bit (mathematical values mod 2^64; the reference's own 32-bit
+// products wrap in this range). Rolled loops straight from memory: correctness path, not tuned.
+__device__ __forceinline__ uint64_t wave_excl_scan_u64(uint64_t v, uint32_t lane) {
+	uint64_t inc = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint64_t o = __shfl_up(inc, off, 64);
+		if ((int)lane >= off) inc += o;
+	}
+	return inc - v;
+}
+
+template <typename T, int LPT, bool DIV>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles_wide(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_bins, const uint8_t* __restrict__ q_scalars,
+    uint32_t S, uint32_t G, uint32_t nvalid, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials,
+    MscPartialDiv* __restrict__ div_partials, int order) {
+	constexpr int E = 16 / sizeof(T);
+	constexpr int R = LPT * E;
+	constexpr uint32_t tile_bytes = 1024u * LPT;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t W = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+	const uint32_t s = W % S;
+	const uint32_t g = W / S;
+	if (g >= G) return;
+	const T* qt = reinterpret_cast<const T*>(q_bins + (uint64_t)s * tile_bytes);
+	auto off_of = [&](int r) -> uint32_t { return (uint32_t)(r / E) * (64 * E) + lane * E + (uint32_t)(r % E); };
+	uint64_t tq = 0;
+	for (int r = 0; r < R; r++) tq += (uint64_t)qt[off_of(r)];
+	const uint64_t cq0 = reinterpret_cast<const uint64_t*>(q_scalars + sizeof(MscSlotScalars))[s] + wave_excl_scan_u64(tq, lane);
+	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	for (uint32_t c = g; c < m; c += G) {
+		const uint32_t slot = cand_slots ? cand_slots[c] : c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const T* pt = reinterpret_cast<const T*>(cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes);
+		uint64_t tp = 0;
+		for (int r = 0; r < R; r++) tp += (uint64_t)pt[off_of(r)];
+		uint64_t cp = reinterpret_cast<const uint64_t*>(cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars))[s] + wave_excl_scan_u64(tp, lane);
+		uint64_t cq = cq0, manh = 0, dot = 0, emd = 0;
+		double jd = 0.0, js = 0.0;
+		const double cm = (double)cs->mag;
+#pragma unroll 1
+		for (int r = 0; r < R; r++) {
+			const uint64_t p = (uint64_t)pt[off_of(r)], q = (uint64_t)qt[off_of(r)];
+			cp += p;
+			cq += q;
+			if (lane * R + r < nvalid) emd += cp > cq ? cp - cq : cq - cp;
+			manh += p > q ? p - q : q - p;
+			dot += p * q;
+			if constexpr (DIV) {
+				if (p != 0 && q != 0) {
+					const bool cf = order == MSC_ORDER_CAND_FIRST;
+					const double pp = cf ? (double)p / cm : (double)q / qm;
+					const double pq = cf ? (double)q / qm : (double)p / cm;
+					jd += (pp - pq) * log(pp / pq);
+					const double avg = 0.5 * (pp + pq);
+					js += pp * log(pp / avg) + pq * log(pq / avg);
+				}
+			}
+		}
+		manh = shfl_sum_u64_early(manh);
+		dot = shfl_sum_u64_early(dot);
+		emd = shfl_sum_u64_early(emd);
+		if constexpr (DIV) { jd = wave_sum_f64(jd); js = wave_sum_f64(js); }
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = manh; out.dot = dot; out.emd = emd;
 			partials[(uint64_t)c * S + s] = out;
 			if constexpr (DIV) div_partials[(uint64_t)c * S + s] = MscPartialDiv{jd, js};
 		}
@@ -930,6 +1014,43 @@ static hipError_t launch_tiles_lpt(hipStream_t st, const MscLayout& L, const uin
 	case 1: return launch_tiles_t<T, 1, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
 	case 2: return launch_tiles_t<T, 2, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
 	default: return launch_tiles_t<T, 4, 16>(st, L, cb, cs, sl, m, qb, qs, uw, mn, mx, p, cus, dt, dp, order);
+	}
+}
+
+template <typename T>
+static hipError_t launch_wide_t(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, uint32_t m,
+                                const uint8_t* qb, const uint8_t* qs, int uw, uint64_t mn, uint64_t mx, MscPartial* p, int cus, void* dp, int order) {
+	const uint32_t S = L.S;
+	uint64_t G = ((uint64_t)cus * 32 + S - 1) / S;
+	if (G < 1) G = 1;
+	if (G > m) G = m;
+	const unsigned blocks = (unsigned)(((uint64_t)S * G + kWavesPerBlock - 1) / kWavesPerBlock);
+	const uint64_t stride = msc_scalar_stride(S);
+	const uint32_t nvalid = L.nbins < L.padded_bins ? (uint32_t)L.nbins : L.tile_bins;
+#define MSC_WIDE(LPTV)                                                                                                                         \
+	(dp ? k_pair_tiles_wide<T, LPTV, true><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qs, S, (uint32_t)G,   \
+	                                                                              nvalid, uw, mn, mx, p, (MscPartialDiv*)dp, order)          \
+	    : k_pair_tiles_wide<T, LPTV, false><<<dim3(blocks), dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, m, qb, qs, S, (uint32_t)G,  \
+	                                                                               nvalid, uw, mn, mx, p, (MscPartialDiv*)dp, order))
+	switch (L.LPT) {
+	case 1: MSC_WIDE(1); break;
+	case 2: MSC_WIDE(2); break;
+	default: MSC_WIDE(4); break;
+	}
+#undef MSC_WIDE
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_pair_tiles_wide(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                      const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins_slot, const uint8_t* q_scalars_slot,
+                                      int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus,
+                                      void* div_partials, int order) {
+	if (m == 0) return hipSuccess;
+	switch (dtype) {
+	case 8: return launch_wide_t<uint8_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, div_partials, order);
+	case 16: return launch_wide_t<uint16_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, div_partials, order);
+	case 32: return launch_wide_t<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, div_partials, order);
+	default: return launch_wide_t<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, m, q_bins_slot, q_scalars_slot, use_window, min_len, max_len, partials, num_cus, div_partials, order);
 	}
 }
 

@@ -320,3 +320,48 @@ def test_cluster_driver_mixed_lengths(tmp_path):
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "mixed.clstr"), "rb").read()
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
+
+
+@pytest.mark.parametrize("dtype,k,hi", [(64, 5, 3_000_000), (32, 6, 60_000), (16, 5, 60_000), (64, 7, 9_000)])
+def test_wide_counts_take_the_64bit_kernel(ctx, oracle, dtype, k, hi):
+    """Bins above the 32-bit fast path's range (> 8191) run through k_pair_tiles_wide. With 64-bit bins the reference's
+    arithmetic is exact, so every statistic is compared with the oracle; for narrower bins the statistics whose
+    reference accumulators stay exact (manhattan, intersection, emd, kulczynski2, pearson, divergences) are."""
+    import ctypes as C
+    rng = np.random.default_rng(k + dtype)
+    n = 6
+    hs = api.HistogramSet(ctx, k, dtype, n + 1)
+    data = []
+    for i in range(n):
+        b = rng.integers(1, 40, size=4 ** k).astype(np.uint64)
+        b[rng.integers(0, 4 ** k, size=25)] = rng.integers(hi // 2, hi, size=25)
+        data.append(b.astype(api.NP_T[dtype]))
+        hs.upload(i, data[-1], 5000 + 37 * i)
+        assert np.array_equal(hs.download(i), data[-1])
+
+    def ohist(bins, length):
+        h = oracle.Hist()
+        h.dtype, h.k, h.nbins = dtype, k, 4 ** k
+        h._keep = np.ascontiguousarray(bins)
+        h.bins = h._keep.ctypes.data_as(C.c_void_p).value
+        h.mag, h.length = int(bins.astype(np.uint64).sum()), length
+        return h
+    oh = [ohist(d, 5000 + 37 * i) for i, d in enumerate(data)]
+    exact_ok = {"manhattan", "intersection", "emd", "length_difference", "kulczynski2"}
+    approx_ok = {"pearson", "jefferey_divergence", "jensen_shannon"}
+    cands = np.arange(n, dtype=np.uint32)
+    for q in range(n):
+        raw = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK)
+        for c in range(n):
+            for col, (name, bit) in zip(raw[c], FEATS):
+                exp = oracle.raw_feature(1 << bit, oh[c], oh[q])
+                if dtype == 64 or name in exact_ok:
+                    if name in EXACT and name != "kulczynski2":
+                        assert col == exp, (name, c, q)
+                    else:
+                        assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c, q)
+                elif name in approx_ok:
+                    assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c, q)
+    pos, d, _ = api.mean_nearest(ctx, hs, cands)
+    _, od, onear = oracle.mean_nearest(oh)
+    assert pos == onear and np.allclose(d, od, rtol=1e-12, atol=0)
