@@ -69,6 +69,29 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // Arithmetic on the PACKED 32-bit words a lane holds after its 16-byte loads. NW words cover the lane's R bins in
 // logical order; bins are never unpacked for the order-independent reductions (v_sad_u8/u16, v_dot4/dot2 work on the
 // packed word), only the prefix statistic touches single bins (byte/half selects fold into SDWA operands).
+// Four wave sums for the price of ~1.7: the two gfx950 lane-swap instructions fold the values pairwise ("transposed"
+// reduction), so one register ends up holding all four results in its four 16-lane rows.
+//   v_permlane32_swap a, b : a[32..63] <-> b[0..31]      -> a+b = [a_lo+a_hi | b_lo+b_hi]
+//   v_permlane16_swap x, y : x rows 1,3 <-> y rows 0,2   -> x+y = rows [x0+x1 | y0+y1 | x2+x3 | y2+y3]
+// then 4 row_shr DPP adds leave each row's total in its last lane: lane 15 = sum(a), 31 = sum(c), 47 = sum(b), 63 = sum(d).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wave_sum4_rows(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+	const u32x2 ab = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+	const u32x2 cd = __builtin_amdgcn_permlane32_swap(c, d, false, false);
+	const uint32_t x = ab.x + ab.y, y = cd.x + cd.y;
+	const u32x2 xy = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+	uint32_t v = xy.x + xy.y;
+	v = dpp_add<0x111, 0xf>(v);
+	v = dpp_add<0x112, 0xf>(v);
+	v = dpp_add<0x114, 0xf>(v);
+	v = dpp_add<0x118, 0xf>(v);
+	return v;
+}
+#define MSC_ROW_A(v) ((uint32_t)__builtin_amdgcn_readlane((int)(v), 15))
+#define MSC_ROW_C(v) ((uint32_t)__builtin_amdgcn_readlane((int)(v), 31))
+#define MSC_ROW_B(v) ((uint32_t)__builtin_amdgcn_readlane((int)(v), 47))
+#define MSC_ROW_D(v) ((uint32_t)__builtin_amdgcn_readlane((int)(v), 63))
+
 __device__ __forceinline__ uint64_t shfl_sum_u64_early(uint64_t v) {
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -605,7 +628,14 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles_multi32(
 			}
 			uint32_t manh_t[QG];
 			uint64_t dot_t[QG], emd_t[QG];
-			if constexpr (COMPACT) {
+			if constexpr (COMPACT && QG == 4) {
+				const uint32_t ra = wave_sum4_rows(manh[0], manh[1], manh[2], manh[3]);
+				const uint32_t rb = wave_sum4_rows(dot[0], dot[1], dot[2], dot[3]);
+				const uint32_t rd = wave_sum4_rows(emd[0], emd[1], emd[2], emd[3]);
+				manh_t[0] = MSC_ROW_A(ra); manh_t[1] = MSC_ROW_B(ra); manh_t[2] = MSC_ROW_C(ra); manh_t[3] = MSC_ROW_D(ra);
+				dot_t[0] = MSC_ROW_A(rb); dot_t[1] = MSC_ROW_B(rb); dot_t[2] = MSC_ROW_C(rb); dot_t[3] = MSC_ROW_D(rb);
+				emd_t[0] = MSC_ROW_A(rd); emd_t[1] = MSC_ROW_B(rd); emd_t[2] = MSC_ROW_C(rd); emd_t[3] = MSC_ROW_D(rd);
+			} else if constexpr (COMPACT) {
 				uint32_t a[QG], b[QG], d[QG];
 #pragma unroll
 				for (int jj = 0; jj < QG; jj++) { a[jj] = wave_incl_scan(manh[jj]); b[jj] = wave_incl_scan(dot[jj]); d[jj] = wave_incl_scan(emd[jj]); }

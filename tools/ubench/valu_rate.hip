@@ -1,0 +1,51 @@
+// valu_rate.hip -- issue rate of the integer VALU ops the pair kernels lean on (run on the GPU box).
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define REP 64
+template <int OP>
+__global__ void k(unsigned* out, int iters, unsigned seed) {
+	unsigned a[8], b = seed + threadIdx.x, c = seed * 3 + 1;
+	for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int r = 0; r < REP; r++) {
+			unsigned& x = a[r & 7];      // 8 independent chains
+			if (OP == 0) asm volatile("v_add_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 1) asm volatile("v_sad_u32 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 2) asm volatile("v_sad_u16 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 3) asm volatile("v_sad_u8 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 4) asm volatile("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 5) asm volatile("v_dot4_u32_u8 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 6) asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 7) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 8) asm volatile("v_max_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 9) asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(x) : "v"(b), "v"(x));
+			if (OP == 10) asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 11) asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 12) asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 13) asm volatile("v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 14) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(x) : "v"(b), "v"(x));
+		}
+	}
+	unsigned s = 0;
+	for (int i = 0; i < 8; i++) s += a[i];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int OP> void run(const char* name, unsigned* d) {
+	const int iters = 2000, blocks = 256 * 8, threads = 256;     // 8 waves per SIMD
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	k<OP><<<blocks, threads>>>(d, 10, 1); hipDeviceSynchronize();
+	hipEventRecord(e0); k<OP><<<blocks, threads>>>(d, iters, 1); hipEventRecord(e1); hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	double insts_per_simd = (double)iters * REP * (blocks * threads / 64) / (256.0 * 4);
+	printf("%-16s %8.3f ms  -> %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / insts_per_simd);
+}
+int main() {
+	unsigned* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+	run<0>("v_add_u32", d); run<1>("v_sad_u32", d); run<2>("v_sad_u16", d); run<3>("v_sad_u8", d); run<4>("v_dot2_u32_u16", d);
+	run<5>("v_dot4_u32_u8", d); run<6>("v_mad_u32_u24", d); run<7>("v_add3_u32", d); run<8>("v_max_u32", d); run<9>("v_lshl_or_b32", d);
+	run<10>("v_pk_add_u16", d); run<11>("v_pk_max_u16", d); run<12>("v_pk_mad_u16", d); run<13>("v_add_u32_dpp", d); run<14>("v_add_u32_sdwa", d);
+	return 0;
+}
