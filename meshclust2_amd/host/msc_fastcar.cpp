@@ -1,0 +1,173 @@
+// msc_fastcar.cpp -- query x database identity search over the GPU hot path.
+//
+// The second caller of the path in the reference: fastcar (fastcar/FC_Runner.cpp). For every query, the database
+// sequences inside its length window that the classification model calls "close" are reported with the regression
+// model's identity estimate:  <query> \t <db> \t <100 * similarity>.  The loop structure, the per-chunk unstable
+// std::sort by length, bin_search, format_header and the output formatting follow fastcar/FC_Runner.cpp:389-471,
+// 560-611 at one thread (one output file "<prefix>0"); training is out of scope, a two-block weights file is required.
+//
+//   msc_fastcar <db.fa> --query <q.fa> --recover weights.txt [--output output] [--chunk 10000] [--no-format] [--device 0]
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "meshclust2_host.hpp"
+
+namespace {
+
+struct Rec { std::string header, seq; };
+
+bool safe_getline(std::istream& is, std::string& t) {
+	t.clear();
+	std::streambuf* sb = is.rdbuf();
+	for (;;) {
+		int c = sb->sbumpc();
+		if (c == '\n') return true;
+		if (c == '\r') { if (sb->sgetc() == '\n') sb->sbumpc(); return true; }
+		if (c == std::streambuf::traits_type::eof()) { if (t.empty()) { is.setstate(std::ios::eofbit); return false; } return true; }
+		t += (char)c;
+	}
+}
+
+// SingleFileLoader::next (clutil/SingleFileLoader.cpp:45-83): continuation lines that start with blank extend the header
+std::vector<Rec> read_fasta(const std::string& path) {
+	std::ifstream in(path.c_str());
+	if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(1); }
+	std::vector<Rec> out;
+	std::string line;
+	while (in.good()) {
+		if (!safe_getline(in, line)) break;
+		if (line.empty()) continue;
+		if (line[0] == '>') out.push_back({line, ""});
+		else if (out.empty()) continue;
+		else if (line[0] == ' ' || line[0] == '\t') {
+			bool all = true;
+			for (char c : line) if (c != ' ' && c != '\t') all = false;
+			if (!all) out.back().header += line;
+		} else out.back().seq += line;
+	}
+	return out;
+}
+
+struct Pt { std::string header; uint64_t length; uint32_t slot; };
+
+long bin_search(const std::vector<Pt*>& points, size_t begin, size_t last, size_t length) {      // FC_Runner.cpp:389-407
+	if (last < begin) return 0;
+	size_t idx = begin + (last - begin) / 2;
+	if (points.at(idx)->length == length) {
+		while (idx > 0 && points[idx - 1]->length == length) idx--;
+		return (long)idx;
+	} else if (points.at(idx)->length > length) {
+		if (begin == idx) return (long)idx;
+		return bin_search(points, begin, idx - 1, length);
+	}
+	return bin_search(points, idx + 1, last, length);
+}
+
+std::string format_header(const std::string& hdr) {                                              // FC_Runner.cpp:409-424
+	long len = (long)hdr.length(), b = 0;
+	if (!hdr.empty() && hdr[0] == '>') b++;
+	for (long i = b; i < len; i++) if (hdr[(size_t)i] == ' ' || hdr[(size_t)i] == '\t') { len = i + 1; break; }
+	return hdr.substr((size_t)b, (size_t)(len - b));
+}
+
+void load_chunk(msc::PointSet& set, const std::vector<Rec>& recs, size_t off, size_t n, std::vector<Pt>& pts) {
+	std::vector<std::string> seqs;
+	for (size_t i = 0; i < n; i++) seqs.push_back(recs[off + i].seq);
+	set.get_points(0, seqs, /*strip=*/true);               // Loader<T>::get_point(header, base, ...): the string overload
+	pts.resize(n);
+	for (size_t i = 0; i < n; i++) pts[i] = Pt{recs[off + i].header, set.get_length(i), (uint32_t)i};
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+	std::vector<std::string> files, qfiles;
+	std::string weights, output = "output";
+	size_t chunk = 10000;
+	bool format = true;
+	int device = 0;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto need = [&](const char* w) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", w); std::exit(1); } return std::string(argv[++i]); };
+		if (a == "--query" || a == "-q") qfiles.push_back(need("--query"));
+		else if (a == "--recover" || a == "-r") weights = need("--recover");
+		else if (a == "--output" || a == "-o") output = need("--output");
+		else if (a == "--chunk" || a == "-c") chunk = (size_t)std::atol(need("--chunk").c_str());
+		else if (a == "--no-format" || a == "--noformat") format = false;
+		else if (a == "--threads" || a == "-t") need("--threads");
+		else if (a == "--device") device = std::atoi(need("--device").c_str());
+		else files.push_back(a);
+	}
+	if (files.empty() || qfiles.empty() || weights.empty()) {
+		std::fprintf(stderr, "usage: %s <db.fa> --query <q.fa> --recover weights.txt [--output prefix] [--chunk 10000] [--no-format]\n", argv[0]);
+		return 1;
+	}
+	try {
+		int k = 0, dtype = 16;
+		double similarity = 0.9;
+		{
+			std::ifstream in(weights.c_str());
+			std::string tok;
+			while (in >> tok) {
+				if (tok == "k:") in >> k;
+				else if (tok == "ID:") in >> similarity;
+				else if (tok == "Datatype:") { in >> tok; dtype = tok == "uint8_t" ? 8 : tok == "uint16_t" ? 16 : tok == "uint32_t" ? 32 : 64; }
+				else if (tok == "n_combos:") break;
+			}
+		}
+		msc::Context ctx(device);
+		msc::Predictor pred(ctx, weights);
+		std::vector<Rec> db, queries;
+		for (const auto& f : files) { auto r = read_fasta(f); db.insert(db.end(), r.begin(), r.end()); }
+		for (const auto& f : qfiles) { auto r = read_fasta(f); queries.insert(queries.end(), r.begin(), r.end()); }
+		msc::PointSet qset(ctx, k, dtype, std::max<size_t>(1, std::min(chunk, queries.size())));
+		msc::PointSet dset(ctx, k, dtype, std::max<size_t>(1, std::min(chunk, db.size())));
+		const std::string delim = format ? "\t" : "!";
+		std::ofstream out((output + "0").c_str());
+		uint64_t num_pred_pos = 0;
+		for (size_t qo = 0; qo < queries.size(); qo += chunk) {
+			std::vector<Pt> qp;
+			load_chunk(qset, queries, qo, std::min(chunk, queries.size() - qo), qp);
+			for (size_t d0 = 0; d0 < db.size(); d0 += chunk) {
+				std::vector<Pt> dp;
+				load_chunk(dset, db, d0, std::min(chunk, db.size() - d0), dp);
+				std::vector<Pt*> pts;
+				for (auto& p : dp) pts.push_back(&p);
+				std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->length < b->length; });      // FC_Runner.cpp:590-592
+				if (pts.empty()) continue;
+				for (const Pt& query : qp) {                                                                 // work(), :426-471
+					const size_t q_len = query.length;
+					const size_t begin_length = (size_t)(q_len * similarity);
+					const size_t end_length = (size_t)(q_len / similarity);
+					const size_t start = (size_t)bin_search(pts, 0, pts.size() - 1, begin_length);
+					std::vector<uint32_t> window;
+					std::vector<Pt*> who;
+					for (size_t i = start; i < pts.size() && pts[i]->length <= end_length; i++) { window.push_back(pts[i]->slot); who.push_back(pts[i]); }
+					if (window.empty()) continue;
+					std::vector<uint8_t> close;
+					std::vector<double> sim;
+					pred.search(dset, window, qset, query.slot, close, sim);        // pred->close(pts[i], query) / similarity(pts[i], query)
+					for (size_t i = 0; i < window.size(); i++) {
+						if (!close[i]) continue;
+						num_pred_pos++;
+						if (sim[i] > 0) {
+							if (format) out << format_header(query.header) << delim << format_header(who[i]->header) << delim << 100 * sim[i] << std::endl;
+							else out << query.header << delim << who[i]->header << delim << 100 * sim[i] << std::endl;
+						}
+					}
+				}
+			}
+		}
+		std::cout << "# of predicted positive: " << num_pred_pos << std::endl;
+	} catch (const msc::Error& e) {
+		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());
+		return 3;
+	}
+	return 0;
+}

@@ -205,6 +205,27 @@ def make_mixed_clstr():
     print("wrote mixed.clstr")
 
 
+def fastcar_sets():
+    db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
+    q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
+    q = [x[:len(x) - 7] for x in q]
+    return db, h, q, [x.replace(">seq", ">qry") for x in hq]
+
+
+def make_fastcar_output():
+    """reference fastcar (query x database search) with --recover on the cfg1 model, one thread -> its output file"""
+    tmp = tempfile.mkdtemp()
+    db, h, q, hq = fastcar_sets()
+    synth.write_fasta(os.path.join(tmp, "db.fa"), db, h)
+    synth.write_fasta(os.path.join(tmp, "q.fa"), q, hq)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fastcar"), "db.fa", "--query", "q.fa", "--recover", os.path.join(HERE, "weights_k5_u16.txt"),
+                    "--output", "fc_out", "--threads", "1"], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, check=True)
+    shutil.copy(os.path.join(tmp, "fc_out0"), os.path.join(HERE, "fastcar_k5_u16.out"))
+    shutil.rmtree(tmp)
+    print("wrote fastcar_k5_u16.out")
+
+
 NASTY = [
     b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT" * 6,
     b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat" * 9,
@@ -219,6 +240,7 @@ if __name__ == "__main__":
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])
     make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
+    make_fastcar_output()
     make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)
     make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)
     make_vectors("vectors_k4_u8.npz", "weights_k5_u16.txt", 13, 10, 150, 4, 8)

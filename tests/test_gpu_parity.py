@@ -365,3 +365,26 @@ def test_wide_counts_take_the_64bit_kernel(ctx, oracle, dtype, k, hi):
     pos, d, _ = api.mean_nearest(ctx, hs, cands)
     _, od, onear = oracle.mean_nearest(oh)
     assert pos == onear and np.allclose(d, od, rtol=1e-12, atol=0)
+
+
+def test_fastcar_search_reproduces_reference_output(tmp_path):
+    """SURVEY 8(f4): query x database search (Predictor::close + similarity per pair) written like fastcar does; the file
+    must equal what the reference's fastcar produced with --recover on the same model (tests/golden/fastcar_k5_u16.out)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_fastcar")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "meshclust2_amd", "host")])
+    db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
+    q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
+    q = [x[:len(x) - 7] for x in q]
+    synth.write_fasta(str(tmp_path / "db.fa"), db, h)
+    synth.write_fasta(str(tmp_path / "q.fa"), q, [x.replace(">seq", ">qry") for x in hq])
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([exe, "db.fa", "--query", "q.fa", "--recover", os.path.join(golden, "weights_k5_u16.txt"), "--output", "fc_out"],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got = open(str(tmp_path / "fc_out0"), "rb").read()
+    exp = open(os.path.join(golden, "fastcar_k5_u16.out"), "rb").read()
+    assert got == exp, "fastcar output differs (%d vs %d bytes)" % (len(got), len(exp))
