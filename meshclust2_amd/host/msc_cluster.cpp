@@ -13,7 +13,7 @@
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
 //   msc_cluster <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64]
-//               [--output output.clstr] [--delta 5] [--iterations 15] [--device 0]
+//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--device 0]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -49,7 +49,9 @@ bool safe_getline(std::istream& is, std::string& t) {
 	}
 }
 
-void read_fasta(const std::string& path, std::vector<std::string>& headers, std::vector<std::string>& seqs) {
+// single_file (--single-file, nonltr/ChromListMaker.cpp:123-147): the whole file is ONE sequence -- the first header, and
+// the records joined by 50 'N'
+void read_fasta(const std::string& path, std::vector<std::string>& headers, std::vector<std::string>& seqs, bool single_file) {
 	std::ifstream in(path.c_str());
 	if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(1); }
 	std::string line;
@@ -57,6 +59,7 @@ void read_fasta(const std::string& path, std::vector<std::string>& headers, std:
 	while (in.good()) {
 		if (!safe_getline(in, line)) break;
 		if (!line.empty() && line[0] == '>') {
+			if (single_file && have) { seqs.back() += std::string(50, 'N'); continue; }
 			headers.push_back(line);
 			seqs.emplace_back();
 			have = true;
@@ -371,6 +374,7 @@ int main(int argc, char** argv) {
 	std::string weights, output = "output.clstr";
 	double similarity = 0.90;
 	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
+	bool single_file = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
@@ -383,6 +387,7 @@ int main(int argc, char** argv) {
 		else if (a == "--iterations" || a == "-i" || a == "--iter") iterations = std::atoi(need("--iterations").c_str());
 		else if (a == "--threads" || a == "-t") need("--threads");
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
+		else if (a == "--single-file") single_file = true;
 		else files.push_back(a);
 	}
 	if (files.empty() || weights.empty()) {
@@ -399,7 +404,7 @@ int main(int argc, char** argv) {
 			while (in >> tok) if (tok == "Datatype:") { in >> tok; dtype = tok == "uint8_t" ? 8 : tok == "uint16_t" ? 16 : tok == "uint32_t" ? 32 : 64; break; }
 		}
 		std::vector<std::string> headers, seqs;
-		for (const auto& f : files) read_fasta(f, headers, seqs);
+		for (const auto& f : files) read_fasta(f, headers, seqs, single_file);
 		const size_t n = seqs.size();
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		msc::PointSet points(ctx, k, dtype, n);

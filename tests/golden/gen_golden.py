@@ -205,6 +205,32 @@ def make_mixed_clstr():
     print("wrote mixed.clstr")
 
 
+def single_file_set():
+    """48 FASTA files of 3 records each (members of one family); with --single-file every file is one sequence"""
+    files = []
+    for i in range(48):
+        t = i // 4
+        tmpl = synth.template(77, t, 420)
+        recs = [synth.to_ascii(synth.member(77, t, 3 * (i % 4) + j, tmpl)) for j in range(3)]
+        files.append(("g%02d.fa" % i, [">genome%d_contig%d template_%d" % (i, j, t) for j in range(3)], recs))
+    return files
+
+
+def make_single_file_clstr():
+    tmp = tempfile.mkdtemp()
+    names = []
+    for name, hdrs, recs in single_file_set():
+        synth.write_fasta(os.path.join(tmp, name), recs, hdrs)
+        names.append(name)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([REF_BIN] + names + ["--single-file", "--id", "0.85", "--kmer", "5", "--datatype", "16", "--threads", "1", "--output", "out.clstr"],
+                   cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, check=True)
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_single_file_k5_u16.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "single_file.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote single_file.clstr")
+
+
 def fastcar_sets():
     db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
     q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
@@ -241,6 +267,7 @@ if __name__ == "__main__":
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])
     make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
     make_fastcar_output()
+    make_single_file_clstr()
     make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)
     make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)
     make_vectors("vectors_k4_u8.npz", "weights_k5_u16.txt", 13, 10, 150, 4, 8)

@@ -33,3 +33,15 @@ def weights_text(name):
 
 def kat():
     return json.load(open(os.path.join(GOLDEN, "kat_appendix_d.json")))
+
+
+def single_file_set():
+    """48 FASTA files of 3 records each (same generator as tests/golden/gen_golden.py)"""
+    from meshclust2_amd import synth
+    files = []
+    for i in range(48):
+        t = i // 4
+        tmpl = synth.template(77, t, 420)
+        recs = [synth.to_ascii(synth.member(77, t, 3 * (i % 4) + j, tmpl)) for j in range(3)]
+        files.append(("g%02d.fa" % i, [">genome%d_contig%d template_%d" % (i, j, t) for j in range(3)], recs))
+    return files

@@ -388,3 +388,22 @@ def test_fastcar_search_reproduces_reference_output(tmp_path):
     got = open(str(tmp_path / "fc_out0"), "rb").read()
     exp = open(os.path.join(golden, "fastcar_k5_u16.out"), "rb").read()
     assert got == exp, "fastcar output differs (%d vs %d bytes)" % (len(got), len(exp))
+
+
+def test_cluster_driver_single_file_mode(tmp_path):
+    """--single-file (each FASTA file is one sequence, records joined by 50 N): 48 three-record files,
+    .clstr byte-identical to the reference CLI's."""
+    import os
+    import subprocess
+    from golden_util import single_file_set
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_cluster")
+    names = []
+    for name, hdrs, recs in single_file_set():
+        synth.write_fasta(str(tmp_path / name), recs, hdrs)
+        names.append(name)
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([exe] + names + ["--single-file", "--recover", os.path.join(golden, "weights_single_file_k5_u16.txt"), "--id", "0.85", "--kmer", "5",
+                                        "--datatype", "16", "--output", "out.clstr"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert open(str(tmp_path / "out.clstr"), "rb").read() == open(os.path.join(golden, "single_file.clstr"), "rb").read()
