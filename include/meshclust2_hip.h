@@ -126,6 +126,16 @@ int      msc_hist_set_k(const msc_hist_set* set);
 int      msc_hist_set_dtype(const msc_hist_set* set);
 uint64_t msc_hist_set_bytes(const msc_hist_set* set);              /* HBM footprint */
 
+/* SPARSE layout: a slot stores only the bins above the pseudocount, as a sorted (bin, value) list.
+ * Same semantics and the same results as a dense set for msc_hist_build*, msc_hist_download (expanded on the host),
+ * msc_hist_info_get, clone / assign / copy, msc_pair_features_raw, msc_score(_multi), msc_get_close, msc_filter, msc_merge and
+ * msc_search; it is what makes k = 11..15 possible (a dense k = 13 histogram is 64-512 MiB) and it reads 12 bytes per
+ * stored bin instead of 4^k * dtype/8 per histogram. max_entries = total stored bins the set can hold (sum over slots, <= the
+ * total number of k-mers). Needs 4^k * dtype/8 >= 64 KiB. msc_mean_nearest / msc_hist_upload are not available on sparse sets. */
+int      msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64_t capacity, uint64_t max_entries, msc_hist_set** out);
+int      msc_hist_set_is_sparse(const msc_hist_set* set);
+uint64_t msc_hist_set_entries(const msc_hist_set* set, uint64_t slot);     /* stored bins of one slot */
+
 /* Replaces Loader<T>::get_point (clutil/Loader.cpp:112-179; callers cluster/CRunner.cpp:526,
  * predict/Predictor.cpp:799,858, fastcar/FC_Runner.cpp:501) for n_seqs sequences at once.
  *   seqs[i]/lens[i] : raw ASCII sequence i (FASTA body, no header, no newlines).

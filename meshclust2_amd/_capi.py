@@ -46,6 +46,9 @@ PROTOTYPES = {
     "msc_last_kernel_launches": (_int, [_vp]),
     "msc_encode": (_int, [C.c_char_p, C.c_size_t, _pu8, _pi64, C.c_size_t, C.POINTER(C.c_size_t), _pu64]),
     "msc_hist_set_create": (_int, [_vp, _int, _int, _u64, C.POINTER(_vp)]),
+    "msc_hist_set_create_sparse": (_int, [_vp, _int, _int, _u64, _u64, C.POINTER(_vp)]),
+    "msc_hist_set_is_sparse": (_int, [_vp]),
+    "msc_hist_set_entries": (_u64, [_vp, _u64]),
     "msc_hist_set_destroy": (None, [_vp]),
     "msc_hist_set_capacity": (_u64, [_vp]),
     "msc_hist_set_k": (_int, [_vp]),

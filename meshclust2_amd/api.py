@@ -92,16 +92,23 @@ def encode(seq):
 class HistogramSet:
     """Device-resident k-mer histograms (the `points` vector of DivergencePoint<T>*)."""
 
-    def __init__(self, ctx, k, dtype, capacity):
+    def __init__(self, ctx, k, dtype, capacity, sparse_entries=0):
+        """sparse_entries > 0 -> sparse layout able to hold that many stored bins in total (msc_hist_set_create_sparse)"""
         self.ctx, self.k, self.dtype, self.capacity = ctx, int(k), int(dtype), int(capacity)
         h = C.c_void_p()
-        ctx.check(ctx.lib.msc_hist_set_create(ctx.h, self.k, self.dtype, self.capacity, C.byref(h)))
+        if sparse_entries:
+            ctx.check(ctx.lib.msc_hist_set_create_sparse(ctx.h, self.k, self.dtype, self.capacity, int(sparse_entries), C.byref(h)))
+        else:
+            ctx.check(ctx.lib.msc_hist_set_create(ctx.h, self.k, self.dtype, self.capacity, C.byref(h)))
         self.h = h
         self.nbins = 4 ** self.k
         ctx._adopt(self)
 
     def nbytes(self):
         return self.ctx.lib.msc_hist_set_bytes(self.h)
+
+    def entries(self, slot):
+        return self.ctx.lib.msc_hist_set_entries(self.h, slot)
 
     def build(self, seqs, first_slot=0, strip=False):
         """Loader<T>::get_point for a batch (clutil/Loader.cpp:112-179)."""

@@ -37,6 +37,8 @@ struct msc_ctx {
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
 	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg;
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
+	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
+	DevBuf sp_counts, sp_cumbase;
 };
 
 struct msc_hist_set {
@@ -49,6 +51,13 @@ struct msc_hist_set {
 	uint8_t* scalars = nullptr;
 	// host-side bounds over every slot ever written (monotone; used to pick the kernels' integer range)
 	uint64_t max_count = 0, max_sum = 0;
+	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
+	bool sparse = false;
+	uint2* ent = nullptr;
+	uint32_t* cum = nullptr;
+	MscSparseHdr* hdr = nullptr;          // device, [capacity]
+	std::vector<MscSparseHdr> hdr_host;   // mirror
+	uint64_t ent_capacity = 0, ent_used = 0;
 };
 
 struct msc_model {
@@ -135,6 +144,9 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
+	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
+	release(ctx->sp_counts);
+	release(ctx->sp_cumbase);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
@@ -311,19 +323,64 @@ extern "C" int msc_hist_set_create(msc_ctx* ctx, int k, int dtype, uint64_t capa
 	return MSC_OK;
 }
 
+extern "C" int msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64_t capacity, uint64_t max_entries, msc_hist_set** out) {
+	if (!ctx || !out) return MSC_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (!valid_dtype(dtype)) return fail(ctx, MSC_ERR_INVALID_ARG, "dtype must be 8, 16, 32 or 64 (got %d)", dtype);
+	if (k < 1 || k > 15) return fail(ctx, MSC_ERR_UNSUPPORTED, "sparse histograms support k <= 15 (got %d)", k);
+	if (capacity == 0 || max_entries == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "capacity and max_entries must be > 0");
+	const MscLayout L = msc_make_layout(k, dtype);
+	if (L.S % MSC_SPARSE_SUB != 0) return fail(ctx, MSC_ERR_UNSUPPORTED, "sparse layout needs 4^k*sizeof(T) >= 64 KiB (k=%d, dtype=%d): use a dense set", k, dtype);
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	msc_hist_set* s = new msc_hist_set();
+	s->ctx = ctx; s->k = k; s->dtype = dtype; s->capacity = capacity; s->L = L;
+	s->sparse = true;
+	s->scalar_stride = msc_scalar_stride(L.S);        // same record as a dense slot of this shape (tile prefixes unused)
+	s->scalar_stride = sizeof(MscSlotScalars);
+	s->ent_capacity = max_entries;
+	hipError_t e = hipMalloc((void**)&s->scalars, s->scalar_stride * capacity);
+	if (e == hipSuccess) e = hipMalloc((void**)&s->ent, max_entries * sizeof(uint2));
+	if (e == hipSuccess) e = hipMalloc((void**)&s->cum, max_entries * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc((void**)&s->hdr, capacity * sizeof(MscSparseHdr));
+	if (e == hipSuccess) e = hipMemsetAsync(s->scalars, 0, s->scalar_stride * capacity, ctx->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(s->hdr, 0, capacity * sizeof(MscSparseHdr), ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) {
+		if (s->scalars) (void)hipFree(s->scalars);
+		if (s->ent) (void)hipFree(s->ent);
+		if (s->cum) (void)hipFree(s->cum);
+		if (s->hdr) (void)hipFree(s->hdr);
+		delete s;
+		return fail(ctx, MSC_ERR_OOM, "sparse set allocation failed: %s", hipGetErrorString(e));
+	}
+	s->hdr_host.assign(capacity, MscSparseHdr{});
+	*out = s;
+	return MSC_OK;
+}
+
+extern "C" int msc_hist_set_is_sparse(const msc_hist_set* s) { return s && s->sparse ? 1 : 0; }
+extern "C" uint64_t msc_hist_set_entries(const msc_hist_set* s, uint64_t slot) { return s && s->sparse && slot < s->capacity ? s->hdr_host[slot].nnz : 0; }
+
 extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (!s) return;
 	(void)hipSetDevice(s->ctx->device);
 	(void)hipStreamSynchronize(s->ctx->stream);
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
+	if (s->ent) (void)hipFree(s->ent);
+	if (s->cum) (void)hipFree(s->cum);
+	if (s->hdr) (void)hipFree(s->hdr);
 	delete s;
 }
 
 extern "C" uint64_t msc_hist_set_capacity(const msc_hist_set* s) { return s ? s->capacity : 0; }
 extern "C" int msc_hist_set_k(const msc_hist_set* s) { return s ? s->k : 0; }
 extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype : 0; }
-extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) { return s ? (s->L.slot_bytes + s->scalar_stride) * s->capacity : 0; }
+extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
+	if (!s) return 0;
+	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
+	return (s->L.slot_bytes + s->scalar_stride) * s->capacity;
+}
 
 // pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
 static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
@@ -338,6 +395,73 @@ static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_
 	return MSC_OK;
 }
 
+
+// Sparse build: dense-build a batch into scratch slots (the validated builder, bit-exact counts and saturation), then
+// compact each scratch slot in index order into the set's entry arena (sparse.hip).
+static int build_sparse(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const uint8_t* packed, uint64_t n_bases,
+                        const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs, const uint64_t* eff_len,
+                        const uint64_t* one_mers) {
+	const MscLayout& L = set->L;
+	// scratch capacity: <= 8 GiB of dense slots
+	uint64_t B = (8ull << 30) / L.slot_bytes;
+	B = std::max<uint64_t>(1, std::min<uint64_t>(B, std::min<uint64_t>(n_seqs, 4096)));
+	int r;
+	if (!ctx->sparse_scratch || ctx->sparse_scratch->k != set->k || ctx->sparse_scratch->dtype != set->dtype || ctx->sparse_scratch->capacity < B) {
+		if (ctx->sparse_scratch) { msc_hist_set_destroy(ctx->sparse_scratch); ctx->sparse_scratch = nullptr; }
+		if ((r = msc_hist_set_create(ctx, set->k, set->dtype, B, &ctx->sparse_scratch))) return r;
+	}
+	msc_hist_set* sc = ctx->sparse_scratch;
+	// segments grouped by sequence (msc_hist_build emits them so); slice them per batch
+	for (uint64_t j = 1; j < n_segs; j++) if (seg_seq[j] < seg_seq[j - 1]) return fail(ctx, MSC_ERR_INVALID_ARG, "sparse build needs segments ordered by sequence");
+	std::vector<uint64_t> sbeg(n_seqs + 1, 0);
+	for (uint64_t j = 0; j < n_segs; j++) sbeg[seg_seq[j] + 1]++;
+	for (uint64_t i = 0; i < n_seqs; i++) sbeg[i + 1] += sbeg[i];
+	if ((r = ensure(ctx, ctx->sp_counts, B * MSC_SPARSE_SUB * 2 * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->sp_cumbase, B * MSC_SPARSE_SUB * sizeof(uint64_t)))) return r;
+	std::vector<uint64_t> counts, cumbase;
+	for (uint64_t b0 = 0; b0 < n_seqs; b0 += B) {
+		const uint64_t nb = std::min(B, n_seqs - b0);
+		const uint64_t s0 = sbeg[b0], s1 = sbeg[b0 + nb];
+		std::vector<uint32_t> sseq(s1 - s0);
+		for (uint64_t j = s0; j < s1; j++) sseq[j - s0] = seg_seq[j] - (uint32_t)b0;
+		if ((r = msc_hist_build_packed(ctx, sc, 0, nb, packed, n_bases, sseq.data(), seg_start + s0, seg_end + s0, s1 - s0, eff_len + b0,
+		                               one_mers ? one_mers + 4 * b0 : nullptr)))
+			return r;
+		HIP_TRY(ctx, msc_launch_sparse_count(ctx->stream, sc->bins, L, set->dtype, (uint32_t)nb, (uint64_t*)ctx->sp_counts.p));
+		counts.resize(nb * MSC_SPARSE_SUB * 2);
+		HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		cumbase.assign(nb * MSC_SPARSE_SUB, 0);
+		for (uint64_t i = 0; i < nb; i++) {
+			MscSparseHdr h{};
+			uint64_t n = 0, ex = 0;
+			for (int w = 0; w < MSC_SPARSE_SUB; w++) {
+				h.split[w] = (uint32_t)n;
+				cumbase[i * MSC_SPARSE_SUB + w] = ex;
+				n += counts[(i * MSC_SPARSE_SUB + w) * 2];
+				ex += counts[(i * MSC_SPARSE_SUB + w) * 2 + 1];
+			}
+			h.split[MSC_SPARSE_SUB] = (uint32_t)n;
+			h.nnz = (uint32_t)n;
+			if (set->ent_used + n > set->ent_capacity)
+				return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, slot %llu needs %llu)",
+				            (unsigned long long)set->ent_used, (unsigned long long)set->ent_capacity, (unsigned long long)(first_slot + b0 + i), (unsigned long long)n);
+			h.off = set->ent_used;
+			set->ent_used += n;
+			set->hdr_host[first_slot + b0 + i] = h;
+		}
+		HIP_TRY(ctx, hipMemcpyAsync(set->hdr + first_slot + b0, set->hdr_host.data() + first_slot + b0, nb * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_cumbase.p, cumbase.data(), cumbase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_sparse_write(ctx->stream, sc->bins, L, set->dtype, (uint32_t)nb, set->hdr, first_slot + b0, (const uint64_t*)ctx->sp_cumbase.p,
+		                                     set->ent, set->cum));
+		// the scalar record (mag, length, sums, max, 1-mers, stddev, overflow) is the dense slot's
+		HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + (first_slot + b0) * set->scalar_stride, set->scalar_stride, sc->scalars, sc->scalar_stride,
+		                              sizeof(MscSlotScalars), nb, hipMemcpyDeviceToDevice, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return refresh_bounds(ctx, set, first_slot, n_seqs);
+}
+
 extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const uint8_t* packed,
                                      uint64_t n_bases, const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end,
                                      uint64_t n_segs, const uint64_t* eff_len, const uint64_t* one_mers) {
@@ -347,6 +471,7 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 	if (n_seqs == 0) return MSC_OK;
 	if ((n_segs && (!seg_seq || !seg_start || !seg_end)) || !eff_len || (n_bases && !packed)) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL input array");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (set->sparse) return build_sparse(ctx, set, first_slot, n_seqs, packed, n_bases, seg_seq, seg_start, seg_end, n_segs, eff_len, one_mers);
 	const int k = set->k;
 	const MscLayout& L = set->L;
 
@@ -474,6 +599,19 @@ extern "C" int msc_hist_download(msc_ctx* ctx, const msc_hist_set* set, uint64_t
 	if (!bins_out) return MSC_ERR_INVALID_ARG;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const MscLayout& L = set->L;
+	if (set->sparse) {          // expand on the host: every bin is 1 except the stored entries
+		if (L.nbins * L.esz > (4ull << 30)) return fail(ctx, MSC_ERR_UNSUPPORTED, "dense download of a %llu-byte histogram refused", (unsigned long long)(L.nbins * L.esz));
+		const MscSparseHdr& h = set->hdr_host[slot];
+		std::vector<uint2> e(h.nnz);
+		if (h.nnz) HIP_TRY(ctx, hipMemcpy(e.data(), set->ent + h.off, h.nnz * sizeof(uint2), hipMemcpyDeviceToHost));
+		for (uint64_t i = 0; i < L.nbins; i++) {
+			switch (set->dtype) { case 8: ((uint8_t*)bins_out)[i] = 1; break; case 16: ((uint16_t*)bins_out)[i] = 1; break; case 32: ((uint32_t*)bins_out)[i] = 1; break; default: ((uint64_t*)bins_out)[i] = 1; }
+		}
+		for (const uint2& x : e) {
+			switch (set->dtype) { case 8: ((uint8_t*)bins_out)[x.x] = (uint8_t)x.y; break; case 16: ((uint16_t*)bins_out)[x.x] = (uint16_t)x.y; break; case 32: ((uint32_t*)bins_out)[x.x] = x.y; break; default: ((uint64_t*)bins_out)[x.x] = x.y; }
+		}
+		return MSC_OK;
+	}
 	if ((r = ensure(ctx, ctx->nat, L.slot_bytes)) != MSC_OK) return r;
 	HIP_TRY(ctx, msc_launch_permute(ctx->stream, set->bins + slot * L.slot_bytes, ctx->nat.p, L, set->dtype, false));
 	HIP_TRY(ctx, hipMemcpyAsync(bins_out, ctx->nat.p, L.nbins * L.esz, hipMemcpyDeviceToHost, ctx->stream));
@@ -485,6 +623,7 @@ extern "C" int msc_hist_upload(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, c
 	int r = check_slot(ctx, set, slot);
 	if (r) return r;
 	if (!bins) return MSC_ERR_INVALID_ARG;
+	if (set->sparse) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_hist_upload is not available for sparse sets");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const MscLayout& L = set->L;
 	if ((r = ensure(ctx, ctx->nat, L.slot_bytes)) != MSC_OK) return r;
@@ -525,8 +664,23 @@ static int copy_common(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_h
 	int r = check_slot(ctx, dst, ds);
 	if (r) return r;
 	if ((r = check_slot(ctx, src, ss))) return r;
-	if (dst->k != src->k || dst->dtype != src->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k or dtype");
+	if (dst->k != src->k || dst->dtype != src->dtype || dst->sparse != src->sparse) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k, dtype or layout");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (src->sparse) {          // the bins of a sparse slot are its entry list: append a copy to dst's arena
+		const MscSparseHdr sh = src->hdr_host[ss];
+		if (dst->ent_used + sh.nnz > dst->ent_capacity) return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted");
+		MscSparseHdr dh = sh;
+		dh.off = dst->ent_used;
+		dst->ent_used += sh.nnz;
+		if (sh.nnz) {
+			HIP_TRY(ctx, hipMemcpyAsync(dst->ent + dh.off, src->ent + sh.off, sh.nnz * sizeof(uint2), hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(dst->cum + dh.off, src->cum + sh.off, sh.nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+		}
+		dst->hdr_host[ds] = dh;
+		HIP_TRY(ctx, hipMemcpyAsync(dst->hdr + ds, &dst->hdr_host[ds], sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return MSC_OK;
+	}
 	HIP_TRY(ctx, hipMemcpyAsync(dst->bins + ds * dst->L.slot_bytes, src->bins + ss * src->L.slot_bytes, src->L.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
 	return MSC_OK;
 }
@@ -558,12 +712,12 @@ extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, con
 	const size_t a0 = offsetof(MscSlotScalars, length), a1 = offsetof(MscSlotScalars, one_mers);
 	HIP_TRY(ctx, hipMemcpyAsync(d + a0, s + a0, a1 - a0, hipMemcpyDeviceToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(d + offsetof(MscSlotScalars, id), s + offsetof(MscSlotScalars, id), 8, hipMemcpyDeviceToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(d + sizeof(MscSlotScalars), s + sizeof(MscSlotScalars), 8ull * dst->L.S, hipMemcpyDeviceToDevice, ctx->stream));
+	if (!dst->sparse) HIP_TRY(ctx, hipMemcpyAsync(d + sizeof(MscSlotScalars), s + sizeof(MscSlotScalars), 8ull * dst->L.S, hipMemcpyDeviceToDevice, ctx->stream));
 	return refresh_bounds(ctx, dst, ds, 1);
 }
 
 extern "C" int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slot_bytes, void** scalars, uint64_t* scalar_bytes) {
-	if (!set) return MSC_ERR_INVALID_ARG;
+	if (!set || set->sparse) return MSC_ERR_INVALID_ARG;
 	if (bins) *bins = set->bins;
 	if (slot_bytes) *slot_bytes = set->L.slot_bytes;
 	if (scalars) *scalars = set->scalars;
@@ -751,7 +905,8 @@ bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) {
 
 int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* qset, uint64_t q_slot, const uint32_t* slots, uint64_t m) {
 	if (!ctx || !cands || !qset || cands->ctx != ctx || qset->ctx != ctx) return MSC_ERR_INVALID_ARG;
-	if (cands->k != qset->k || cands->dtype != qset->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "query and candidate sets differ in k or dtype");
+	if (cands->k != qset->k || cands->dtype != qset->dtype || cands->sparse != qset->sparse)
+		return fail(ctx, MSC_ERR_INVALID_ARG, "query and candidate sets differ in k, dtype or layout");
 	if (q_slot >= qset->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "query slot out of range");
 	if (m > 0xfffffff0ull) return fail(ctx, MSC_ERR_INVALID_ARG, "too many candidates in one call");
 	if (slots) { for (uint64_t i = 0; i < m; i++) if (slots[i] >= cands->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "candidate slot %u out of range", slots[i]); }
@@ -783,19 +938,22 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		                      rq.reduce_host->any_close = 0; rq.reduce_host->n_close = 0; rq.reduce_host->first_error = 0; }
 		return MSC_OK;
 	}
-	uint64_t chunk = (256ull << 20) / ((uint64_t)L.S * sizeof(MscPartial));
+	const bool sp = cs->sparse;
+	const uint32_t PS = sp ? MSC_SPARSE_SUB : L.S;          // partial records per candidate
+	if (sp && rq.only_tiles) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_mean_nearest is not available for sparse sets yet");
+	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
 	if (rq.reduce_mode >= 0 || rq.only_tiles) chunk = m;      // reductions run over the whole window in one piece
 	chunk = std::min(chunk, m);
 
-	if ((r = ensure(ctx, ctx->partials, chunk * L.S * sizeof(MscPartial))) != MSC_OK) return r;
+	if ((r = ensure(ctx, ctx->partials, chunk * PS * sizeof(MscPartial))) != MSC_OK) return r;
 	if (rq.cand_slots) {
 		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t))) != MSC_OK) return r;
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, rq.cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
 	if (need_div) {
-		if ((r = ensure(ctx, ctx->div_tables, chunk * tb * tb * 16)) != MSC_OK) return r;
-		if ((r = ensure(ctx, ctx->div_partials, chunk * L.S * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_tables, chunk * (sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_partials, chunk * PS * 16)) != MSC_OK) return r;
 	}
 	if (!rq.only_tiles) {
 		if ((r = ensure(ctx, ctx->pair_out, chunk * sizeof(MscPairOut))) != MSC_OK) return r;
@@ -805,7 +963,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if ((r = ensure(ctx, ctx->flags, chunk)) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut))) != MSC_OK) return r;
 	}
-	const uint8_t* q_bins = rq.qset->bins + rq.q_slot * rq.qset->L.slot_bytes;
+	const uint8_t* q_bins = sp ? nullptr : rq.qset->bins + rq.q_slot * rq.qset->L.slot_bytes;
 	const uint8_t* q_scal = rq.qset->scalars + rq.q_slot * rq.qset->scalar_stride;
 	std::vector<MscPairOut> po_host;
 	int first_err = 0;
@@ -813,10 +971,15 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	for (uint64_t off = 0; off < m; off += chunk) {
 		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
 		const uint32_t* d_slots = rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
-		const uint8_t* c_bins = cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
+		const uint8_t* c_bins = sp ? nullptr : cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (wide) {
+		if (sp) {
+			HIP_TRY(ctx, msc_launch_pair_sparse(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
+			                                    rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,
+			                                    (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr,
+			                                    need_div ? ctx->div_partials.p : nullptr, rq.order));
+		} else if (wide) {
 			HIP_TRY(ctx, msc_launch_pair_tiles_wide(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
 			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_partials.p : nullptr, rq.order));
 		} else {
@@ -833,7 +996,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
 		ea.div_partials = need_div ? ctx->div_partials.p : nullptr;
-		ea.S = L.S;
+		ea.S = PS;
+		ea.sparse_base = sp ? L.nbins : 0;
 		ea.m = mc;
 		ea.cand_scalars = c_scal;
 		ea.cand_scalar_stride = cs->scalar_stride;
@@ -935,7 +1099,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const int nf = __builtin_popcountll(feat_mask);
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
-	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset);
+	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
 	if (!simple) {
 		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
 		for (uint64_t q = 0; q < n_q; q++) {
@@ -1133,6 +1297,7 @@ extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* r
 extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, int64_t* nearest_pos,
                                 double* dist_out, double* mean_out) {
 	if (!ctx || !set || set->ctx != ctx || !nearest_pos) return MSC_ERR_INVALID_ARG;
+	if (set->sparse) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_mean_nearest is not available for sparse sets yet");
 	if (m == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "N cannot be 0 (cluster/ClusterFactory.cpp:346-348 throws)");
 	if (m > 0xfffffff0ull) return MSC_ERR_INVALID_ARG;
 	if (member_slots) { for (uint64_t i = 0; i < m; i++) if (member_slots[i] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "member slot out of range"); }

@@ -8,6 +8,16 @@
 #include "../../include/meshclust2_hip.h"
 #include "msc_layout.h"
 
+// ---------------------------------------------------------------- sparse slots (sparse.hip)
+#define MSC_SPARSE_SUB 16
+struct MscSparseHdr {
+	uint64_t off;                       // first entry of this slot in the set's entry arena
+	uint32_t nnz;                       // entries (bins with value >= 2)
+	uint32_t split[MSC_SPARSE_SUB + 1]; // entry offsets (relative to off) of the 16 equal index sub-ranges; split[16] == nnz
+	uint32_t pad_[2];
+};
+static_assert(sizeof(MscSparseHdr) == 88, "sparse header layout");
+
 // ---------------------------------------------------------------- model, as the epilogue kernel sees it
 struct MscDevModel {
 	int32_t  n_singles;
@@ -82,6 +92,7 @@ struct MscEpilogueArgs {
 	double*  csum_soa;
 	uint8_t* close_soa;
 	int32_t* error_word;              // atomicMin of negative statuses
+	uint64_t sparse_base;             // 4^k when the partials come from k_pair_sparse (sums over the union only), else 0
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip kernel files)
@@ -116,6 +127,13 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out);
 
+hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts);
+hipError_t msc_launch_sparse_write(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, const MscSparseHdr* hdr,
+                                   uint64_t first_slot, const uint64_t* cum_base, void* ent, uint32_t* cum);
+hipError_t msc_launch_pair_sparse(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                  uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                  const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
+                                  uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order);
 hipError_t msc_launch_colsum(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins,
                              const uint32_t* member_slots, uint32_t m, void* rounded_out /*T, physical*/,
                              double* mean_out /*physical, nullable*/, uint64_t* floor_sum_out, uint64_t* scratch);

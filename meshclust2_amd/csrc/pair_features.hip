@@ -737,7 +737,8 @@ __device__ __forceinline__ uint64_t shfl_sum_u64(uint64_t v) {
 	return v;
 }
 
-__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t) {
+__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t_in) {
+	PairTotals t = t_in;
 	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
 	uint32_t ci = c, qi = 0;
 	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
@@ -750,6 +751,16 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
 	const Side& second = a.order == MSC_ORDER_CAND_FIRST ? qry : cand;
+	if (a.sparse_base) {
+		// k_pair_sparse summed over the union of stored bins only; every other bin is (1, 1)
+		t.dot += a.sparse_base;
+		if (a.div_partials) {
+			const double pp = 1.0 / (double)first.mag, pq = 1.0 / (double)second.mag;
+			const double avg = 0.5 * (pp + pq);
+			t.jd += (double)a.sparse_base * ((pp - pq) * log(pp / pq));
+			t.js += (double)a.sparse_base * (pp * log(pp / avg) + pq * log(pq / avg));
+		}
+	}
 
 	MscPairOut po;
 	po.sum = NAN; po.csum = NAN; po.combo0 = NAN; po.status = 0; po.close = 0;
