@@ -38,7 +38,9 @@ struct msc_ctx {
 	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg;
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum;
+	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
+	uint64_t sp_acc_bins = 0;
 };
 
 struct msc_hist_set {
@@ -145,8 +147,12 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
+	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
 	release(ctx->sp_counts);
 	release(ctx->sp_cumbase);
+	release(ctx->sp_acc);
+	release(ctx->sp_chunk_off);
+	release(ctx->sp_chunk_cum);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
@@ -940,7 +946,6 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	}
 	const bool sp = cs->sparse;
 	const uint32_t PS = sp ? MSC_SPARSE_SUB : L.S;          // partial records per candidate
-	if (sp && rq.only_tiles) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_mean_nearest is not available for sparse sets yet");
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
 	if (rq.reduce_mode >= 0 || rq.only_tiles) chunk = m;      // reductions run over the whole window in one piece
@@ -1060,6 +1065,12 @@ const uint64_t kSupportedFeats = MSC_FEAT_SLOW;
 double trainer_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }      // cluster/Trainer.h:35
 
 }  // namespace
+
+static int run_score_fwd(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, const msc_hist_set* rs) {
+	ScoreRequest rq;
+	rq.cands = set; rq.cand_slots = member_slots; rq.m = m; rq.qset = rs; rq.q_slot = 0; rq.only_tiles = true;
+	return run_score(ctx, rq);
+}
 
 extern "C" int msc_pair_features_raw(msc_ctx* ctx, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m, const msc_hist_set* qset,
                                      uint64_t q_slot, int order, uint64_t feat_mask, double* raw_out) {
@@ -1294,11 +1305,95 @@ extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* r
 }
 
 // ================================================================================================ mean + nearest
+
+// msc_mean_nearest for sparse members (kernels and the derivation in sparse.hip)
+static int run_score_fwd(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, const msc_hist_set* rs);
+static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, int64_t* nearest_pos, double* dist_out,
+                               double* mean_out) {
+	if (mean_out) return fail(ctx, MSC_ERR_UNSUPPORTED, "mean_out is not available for sparse sets");
+	if (m > 0xfffffff0ull) return MSC_ERR_INVALID_ARG;
+	if (member_slots) { for (uint64_t i = 0; i < m; i++) if (member_slots[i] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "member slot out of range"); }
+	else if (m > set->capacity) return MSC_ERR_INVALID_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const MscLayout& L = set->L;
+	int r;
+	if (ctx->sp_acc_bins != L.nbins) {          // dense u32 accumulator, zero between calls
+		if ((r = ensure(ctx, ctx->sp_acc, L.nbins * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->sp_acc.p, 0, L.nbins * sizeof(uint32_t), ctx->stream));
+		ctx->sp_acc_bins = L.nbins;
+	}
+	uint64_t upper = 0;                           // the rounded mean cannot have more stored bins than the members together
+	for (uint64_t i = 0; i < m; i++) upper += set->hdr_host[member_slots ? member_slots[i] : i].nnz;
+	upper = std::min<uint64_t>(upper, L.nbins);
+	if (!ctx->sparse_mean_set || ctx->sparse_mean_set->k != set->k || ctx->sparse_mean_set->dtype != set->dtype || ctx->sparse_mean_set->ent_capacity < upper + 1) {
+		if (ctx->sparse_mean_set) { msc_hist_set_destroy(ctx->sparse_mean_set); ctx->sparse_mean_set = nullptr; }
+		if ((r = msc_hist_set_create_sparse(ctx, set->k, set->dtype, 1, std::max<uint64_t>(upper + 1, 1 << 16), &ctx->sparse_mean_set))) return r;
+	}
+	msc_hist_set* rs = ctx->sparse_mean_set;
+	if (member_slots) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, member_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	const uint32_t* d_slots = member_slots ? (const uint32_t*)ctx->slots.p : nullptr;
+	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // multiple of 16 for every k >= 6
+	const uint64_t chunk_bins = L.nbins / n_chunks;
+	if ((r = ensure(ctx, ctx->sp_counts, std::max<size_t>(n_chunks * 3 * sizeof(uint64_t), ctx->sp_counts.cap)))) return r;
+	if ((r = ensure(ctx, ctx->sp_chunk_off, n_chunks * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->sp_chunk_cum, n_chunks * sizeof(uint64_t)))) return r;
+	HIP_TRY(ctx, msc_launch_sparse_scatter(ctx->stream, set->ent, set->hdr, d_slots, (uint32_t)m, (uint32_t*)ctx->sp_acc.p));
+	HIP_TRY(ctx, msc_launch_sparse_mean_count(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (uint64_t*)ctx->sp_counts.p));
+	std::vector<uint64_t> counts(n_chunks * 3), off(n_chunks), cb(n_chunks);
+	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	MscSparseHdr h{};
+	uint64_t n = 0, ex = 0, fl = 0;
+	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
+	for (uint32_t c = 0; c < n_chunks; c++) {
+		if (c % per_sub == 0) h.split[c / per_sub] = (uint32_t)n;
+		off[c] = n;
+		cb[c] = ex;
+		n += counts[c * 3ull]; ex += counts[c * 3ull + 1]; fl += counts[c * 3ull + 2];
+	}
+	h.split[MSC_SPARSE_SUB] = (uint32_t)n;
+	h.nnz = (uint32_t)n;
+	h.off = 0;
+	rs->ent_used = n;
+	rs->hdr_host[0] = h;
+	MscSlotScalars sc;
+	memset(&sc, 0, sizeof sc);
+	sc.sum = L.nbins + ex;          // sum of the rounded mean's bins
+	sc.mag = sc.sum;
+	sc.length = 1;
+	const uint64_t floor_sum = L.nbins + fl;
+	if ((r = ensure(ctx, ctx->floor_sum, 8))) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(rs->hdr, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(rs->scalars, &sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->floor_sum.p, &floor_sum, 8, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_mean_write(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (const uint64_t*)ctx->sp_chunk_off.p,
+	                                          (const uint64_t*)ctx->sp_chunk_cum.p, rs->ent, rs->cum));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // h, sc, floor_sum, off, cb live on this frame
+	// members vs the rounded mean: only the |p - r| reduction of the merge kernel is used
+	if ((r = run_score_fwd(ctx, set, member_slots, m, rs))) return r;
+	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
+	if (dist_out && (r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
+	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, MSC_SPARSE_SUB, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
+	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, dist_out ? (double*)ctx->raw.p : nullptr,
+	                                   (MscReduceOut*)ctx->reduce_out.p));
+	MscReduceOut ro;
+	HIP_TRY(ctx, hipMemcpyAsync(&ro, ctx->reduce_out.p, sizeof ro, hipMemcpyDeviceToHost, ctx->stream));
+	if (dist_out) HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->raw.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	*nearest_pos = ro.best_pos;
+	return MSC_OK;
+}
+
 extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, int64_t* nearest_pos,
                                 double* dist_out, double* mean_out) {
 	if (!ctx || !set || set->ctx != ctx || !nearest_pos) return MSC_ERR_INVALID_ARG;
-	if (set->sparse) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_mean_nearest is not available for sparse sets yet");
 	if (m == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "N cannot be 0 (cluster/ClusterFactory.cpp:346-348 throws)");
+	if (set->sparse) return mean_nearest_sparse(ctx, set, member_slots, m, nearest_pos, dist_out, mean_out);
 	if (m > 0xfffffff0ull) return MSC_ERR_INVALID_ARG;
 	if (member_slots) { for (uint64_t i = 0; i < m; i++) if (member_slots[i] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "member slot out of range"); }
 	else if (m > set->capacity) return MSC_ERR_INVALID_ARG;

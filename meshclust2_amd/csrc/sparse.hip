@@ -222,6 +222,78 @@ __global__ void __launch_bounds__(256) k_pair_sparse(
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ mean of sparse members
+// get_mean / closest on sparse slots (cluster/ClusterFactory.cpp:338-380, cluster/Trainer.cpp:144-157). Outside the union of
+// the members' stored bins every member holds 1, so the FP64 mean is exactly 1 there; inside, the column sum is m + (sum of
+// excesses). The excesses are scatter-added into a dense u32 accumulator (4 * 4^k bytes, kept zero between calls), which is
+// then swept in index order: chunk counts -> host prefix -> ordered write of the rounded mean as a sparse slot.
+__global__ void __launch_bounds__(256) k_sparse_scatter(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
+                                                        const uint32_t* __restrict__ slots, uint32_t m, uint32_t* __restrict__ acc) {
+	const uint32_t j = blockIdx.x;
+	if (j >= m) return;
+	const MscSparseHdr h = hdr[slots ? slots[j] : j];
+	for (uint32_t t = threadIdx.x; t < h.nnz; t += blockDim.x) {
+		const uint2 e = ent[h.off + t];
+		atomicAdd(&acc[e.x], e.y - 1u);
+	}
+}
+
+struct MeanBin { uint32_t r; uint64_t fl; };
+template <typename T>
+__device__ __forceinline__ MeanBin mean_bin(uint32_t E, uint32_t m) {
+	MeanBin b;
+	const double mean = (double)((uint64_t)m + E) / (double)m;       // (sum of the m bins) / m, cluster/ClusterFactory.cpp:349-357
+	b.r = (uint32_t)(T)round(mean);                                   // (T)round(c.points[i]), clutil/DivergencePoint.cpp:61
+	b.fl = (uint64_t)floor(mean);                                     // uint64 += double truncates every step (:62)
+	return b;
+}
+
+// one wave per chunk of bins; counts[chunk] = {entries with r >= 2, sum (r-1), sum (floor-1)}
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_count(const uint32_t* __restrict__ acc, uint64_t chunk_bins, uint32_t m,
+                                                          uint64_t* __restrict__ counts) {
+	const uint64_t base = (uint64_t)blockIdx.x * chunk_bins;
+	uint64_t n = 0, ex = 0, fl = 0;
+	for (uint64_t i = threadIdx.x; i < chunk_bins; i += 64) {
+		const uint32_t E = acc[base + i];
+		if (E) {
+			const MeanBin b = mean_bin<T>(E, m);
+			if (b.r >= 2) { n++; ex += b.r - 1; }
+			fl += b.fl - 1;
+		}
+	}
+	n = wave_sum_u64(n); ex = wave_sum_u64(ex); fl = wave_sum_u64(fl);
+	if (threadIdx.x == 0) { counts[blockIdx.x * 3ull] = n; counts[blockIdx.x * 3ull + 1] = ex; counts[blockIdx.x * 3ull + 2] = fl; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_write(uint32_t* __restrict__ acc, uint64_t chunk_bins, uint32_t m,
+                                                          const uint64_t* __restrict__ chunk_off, const uint64_t* __restrict__ chunk_cum,
+                                                          uint2* __restrict__ ent, uint32_t* __restrict__ cum) {
+	const uint64_t base = (uint64_t)blockIdx.x * chunk_bins;
+	uint64_t o = chunk_off[blockIdx.x];
+	uint32_t run = (uint32_t)chunk_cum[blockIdx.x];
+	const uint32_t lane = threadIdx.x;
+	for (uint64_t i0 = 0; i0 < chunk_bins; i0 += 64) {
+		const uint64_t i = i0 + lane;
+		uint32_t E = 0;
+		if (i < chunk_bins) { E = acc[base + i]; if (E) acc[base + i] = 0; }       // leave the accumulator clean for the next call
+		uint32_t r = 1;
+		if (E) r = mean_bin<T>(E, m).r;
+		const bool emit = r >= 2;
+		const unsigned long long mask = __ballot(emit);
+		const uint32_t ex = emit ? r - 1 : 0;
+		const uint32_t ex_incl = wave_incl_scan(ex);
+		if (emit) {
+			const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+			ent[o + rank] = make_uint2((uint32_t)(base + i), r);
+			cum[o + rank] = run + ex_incl;
+		}
+		o += (uint64_t)__popcll(mask);
+		run += (uint32_t)__builtin_amdgcn_readlane((int)ex_incl, 63);
+	}
+}
+
 // ================================================================================================ launchers
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts) {
 	if (n == 0) return hipSuccess;
@@ -264,6 +336,33 @@ hipError_t msc_launch_pair_sparse(hipStream_t st, const void* c_ent, const uint3
 		k_pair_sparse<false><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                         q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr,
 		                                                         nullptr, order);
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_scatter(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, uint32_t m, uint32_t* acc) {
+	if (m == 0) return hipSuccess;
+	k_sparse_scatter<<<dim3(m), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, m, acc);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_mean_count(hipStream_t st, int dtype, const uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m, uint64_t* counts) {
+	switch (dtype) {
+	case 8: k_sparse_mean_count<uint8_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, counts); break;
+	case 16: k_sparse_mean_count<uint16_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, counts); break;
+	case 32: k_sparse_mean_count<uint32_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, counts); break;
+	default: k_sparse_mean_count<uint64_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, counts); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_mean_write(hipStream_t st, int dtype, uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m,
+                                        const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum) {
+	switch (dtype) {
+	case 8: k_sparse_mean_write<uint8_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	case 16: k_sparse_mean_write<uint16_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	case 32: k_sparse_mean_write<uint32_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	default: k_sparse_mean_write<uint64_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	}
 	return hipGetLastError();
 }

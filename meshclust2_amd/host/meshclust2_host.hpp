@@ -45,8 +45,10 @@ private:
 // The `points` vector of the reference (cluster/CRunner.cpp:505-544), resident in HBM.
 class PointSet {
 public:
-	PointSet(Context& ctx, int k, int datatype_bits, uint64_t capacity) : ctx_(ctx) {
-		ctx_.check(msc_hist_set_create(ctx_.get(), k, datatype_bits, capacity, &h_));
+	// sparse_entries > 0: sparse layout (sorted (bin, value) lists) able to hold that many stored bins in total
+	PointSet(Context& ctx, int k, int datatype_bits, uint64_t capacity, uint64_t sparse_entries = 0) : ctx_(ctx) {
+		if (sparse_entries) ctx_.check(msc_hist_set_create_sparse(ctx_.get(), k, datatype_bits, capacity, sparse_entries, &h_));
+		else ctx_.check(msc_hist_set_create(ctx_.get(), k, datatype_bits, capacity, &h_));
 	}
 	~PointSet() { msc_hist_set_destroy(h_); }
 	PointSet(const PointSet&) = delete;

@@ -13,7 +13,7 @@
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
 //   msc_cluster <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64]
-//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--device 0]
+//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--device 0]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -204,29 +204,43 @@ struct Driver {
 	std::unique_ptr<msc::PointSet> centres;
 	uint64_t n_centres = 0;
 
-	Driver(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt) : ctx(c), points(p), trn(t), k(k_), dtype(dt) {
-		centres.reset(new msc::PointSet(ctx, k, dtype, 256));
+	uint64_t centre_arena = 0;      // > 0: sparse centre store with that many entries
+
+	Driver(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt, uint64_t sparse_arena) : ctx(c), points(p), trn(t), k(k_), dtype(dt) {
+		centre_arena = sparse_arena;
+		centres.reset(new msc::PointSet(ctx, k, dtype, 256, centre_arena));
+	}
+	// relocate every live centre into a fresh store (exact copies: stale mags survive). Used to grow the slot count and,
+	// for the sparse layout, to compact the append-only entry arena.
+	void rebuild_centres(uint64_t capacity) {
+		std::unique_ptr<msc::PointSet> fresh(new msc::PointSet(ctx, k, dtype, capacity, centre_arena));
+		for (uint64_t i = 0; i < n_centres; i++) fresh->copy(i, *centres, i);
+		centres.swap(fresh);
 	}
 	uint32_t new_centre_slot() {
-		if (n_centres == centres->capacity()) {        // grow without touching any scalar (stale mags survive)
-			std::unique_ptr<msc::PointSet> bigger(new msc::PointSet(ctx, k, dtype, centres->capacity() * 2));
-			for (uint64_t i = 0; i < n_centres; i++) bigger->copy(i, *centres, i);
-			centres.swap(bigger);
-		}
+		if (n_centres == centres->capacity()) rebuild_centres(centres->capacity() * 2);
 		return (uint32_t)n_centres++;
+	}
+	template <class F> void with_arena_retry(F&& f) {      // sparse store: compact once when the arena runs out
+		try { f(); }
+		catch (const msc::Error& e) {
+			if (e.code != MSC_ERR_OOM || centre_arena == 0) throw;
+			rebuild_centres(centres->capacity());
+			f();
+		}
 	}
 	// Center(Point* c, pts): center(c->clone())
 	Centre make_centre(Pt* c, const std::vector<Pt*>& pts) {
 		Centre ce;
 		ce.cslot = new_centre_slot();
-		centres->clone(ce.cslot, points, c->slot);
+		with_arena_retry([&] { centres->clone(ce.cslot, points, c->slot); });
 		ce.header = c->header; ce.id = c->id; ce.length = c->length;
 		ce.points = pts;
 		return ce;
 	}
 	// center->set(*next): bins, length, header, id -- not mag
 	void centre_set(Centre& ce, Pt* next) {
-		centres->set(ce.cslot, points, next->slot);
+		with_arena_retry([&] { centres->set(ce.cslot, points, next->slot); });
 		ce.header = next->header; ce.id = next->id; ce.length = next->length;
 	}
 
@@ -374,7 +388,7 @@ int main(int argc, char** argv) {
 	std::string weights, output = "output.clstr";
 	double similarity = 0.90;
 	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
-	bool single_file = false;
+	bool single_file = false, sparse = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
@@ -388,6 +402,7 @@ int main(int argc, char** argv) {
 		else if (a == "--threads" || a == "-t") need("--threads");
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
 		else if (a == "--single-file") single_file = true;
+		else if (a == "--sparse") sparse = true;         // sparse histogram layout (required for k >= 13)
 		else files.push_back(a);
 	}
 	if (files.empty() || weights.empty()) {
@@ -407,7 +422,9 @@ int main(int argc, char** argv) {
 		for (const auto& f : files) read_fasta(f, headers, seqs, single_file);
 		const size_t n = seqs.size();
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
-		msc::PointSet points(ctx, k, dtype, n);
+		uint64_t total_bases = 0, longest = 0;
+		for (const auto& sq : seqs) { total_bases += sq.size(); longest = std::max<uint64_t>(longest, sq.size()); }
+		msc::PointSet points(ctx, k, dtype, n, sparse ? total_bases + 1024 : 0);
 		const size_t chunk = 8192;
 		for (size_t off = 0; off < n; off += chunk) {
 			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(n, off + chunk));
@@ -431,7 +448,7 @@ int main(int argc, char** argv) {
 		uint64_t idx = 0;
 		for (Pt* p : pts) { p->id = idx++; bv.insert(p); }
 		bv.insert_finalize();
-		Driver drv(ctx, points, trn, k, dtype);
+		Driver drv(ctx, points, trn, k, dtype, sparse ? std::max<uint64_t>(total_bases / 2, 64 * longest) + (1 << 20) : 0);
 		drv.cutoff = similarity;
 		drv.MS(bv, similarity, output, iterations, delta);
 	} catch (const msc::Error& e) {

@@ -231,6 +231,28 @@ def make_single_file_clstr():
     print("wrote single_file.clstr")
 
 
+def k8_set():
+    """640 sequences of ~2 kb in two length groups: k = 8, 16-bit bins (128 KiB histograms: also valid for the sparse layout)"""
+    seqs, hdrs = [], []
+    for gi, (n, length, seed) in enumerate(((320, 1800, 51), (320, 2400, 52))):
+        s, h = synth.families(seed, n, length, family=16, length_jitter=150)
+        seqs += s
+        hdrs += [">e%d_%s" % (gi, x[1:]) for x in h]
+    return seqs, hdrs
+
+
+def make_k8_clstr():
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = k8_set()
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    run_reference_cli(fa, ["--id", "0.85", "--kmer", "8", "--datatype", "16", "--threads", "1", "--output", "out.clstr"], tmp)
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_k8_u16.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "k8.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote k8.clstr")
+
+
 def fastcar_sets():
     db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
     q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
@@ -267,6 +289,7 @@ if __name__ == "__main__":
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])
     make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
     make_fastcar_output()
+    make_k8_clstr()
     make_single_file_clstr()
     make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)
     make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)

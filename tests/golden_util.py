@@ -45,3 +45,14 @@ def single_file_set():
         recs = [synth.to_ascii(synth.member(77, t, 3 * (i % 4) + j, tmpl)) for j in range(3)]
         files.append(("g%02d.fa" % i, [">genome%d_contig%d template_%d" % (i, j, t) for j in range(3)], recs))
     return files
+
+
+def k8_set():
+    """640 sequences of ~2 kb in two length groups (same generator as tests/golden/gen_golden.py)"""
+    from meshclust2_amd import synth
+    seqs, hdrs = [], []
+    for gi, (n, length, seed) in enumerate(((320, 1800, 51), (320, 2400, 52))):
+        s, h = synth.families(seed, n, length, family=16, length_jitter=150)
+        seqs += s
+        hdrs += [">e%d_%s" % (gi, x[1:]) for x in h]
+    return seqs, hdrs

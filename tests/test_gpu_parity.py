@@ -450,6 +450,11 @@ def test_sparse_sets_equal_dense_sets(ctx, dtype, k, length):
         c1, s1 = api.Predictor(ctx, fs, rs).search(sparse, cands, sparse, 3)
         c2, s2 = api.Predictor(ctx, fd, rd).search(dense, cands, dense, 3)
         assert np.array_equal(c1, c2) and np.allclose(s1, s2, rtol=1e-9, atol=1e-12)
+    # get_mean / closest on sparse members
+    for mem in (np.arange(0, n, 2, dtype=np.uint32), np.arange(n, dtype=np.uint32), np.array([3], dtype=np.uint32), np.array([4, 4, 9], dtype=np.uint32)):
+        p1, d1, _ = api.mean_nearest(ctx, sparse, mem)
+        p2, d2, _ = api.mean_nearest(ctx, dense, mem)
+        assert p1 == p2 and np.array_equal(d1, d2), mem
     # Center semantics on sparse slots
     sparse.clone_from(n, sparse, 0)
     sparse.assign_from(n, sparse, 5)
@@ -491,3 +496,24 @@ def test_sparse_k13_against_the_oracle(ctx, oracle):
                 assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c)
     for h in oh:
         oracle.lib().orc_hist_free(h)
+
+
+@pytest.mark.parametrize("layout", ["dense", "sparse"])
+def test_cluster_driver_k8_dense_and_sparse_layouts(tmp_path, layout):
+    """k = 8 / 16-bit bins, 640 sequences: the driver writes the reference's .clstr bytes with the dense layout AND with the
+    sparse one (--sparse: sorted (bin, value) lists, merge kernel, sparse mean/closest, sparse centre store)."""
+    import os
+    import subprocess
+    from golden_util import k8_set
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_cluster")
+    seqs, hdrs = k8_set()
+    fa = str(tmp_path / "k8.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    golden = os.path.join(root, "tests", "golden")
+    args = [exe, fa, "--recover", os.path.join(golden, "weights_k8_u16.txt"), "--id", "0.85", "--kmer", "8", "--datatype", "16", "--output", "out.clstr"]
+    if layout == "sparse":
+        args.append("--sparse")
+    r = subprocess.run(args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert open(str(tmp_path / "out.clstr"), "rb").read() == open(os.path.join(golden, "k8.clstr"), "rb").read()
