@@ -402,12 +402,73 @@ static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_
 }
 
 
+
+// Direct sparse build (k_sparse_build_sort): returns 1 when the batch does not qualify (a sequence with > 32768 k-mers,
+// segments not grouped by sequence, or MSC_NO_SORT_BUILD set) and the scratch + compaction path must be used instead.
+static int build_sparse_sort(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const uint8_t* packed, uint64_t n_bases,
+                             const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs, const uint64_t* eff_len,
+                             const uint64_t* one_mers) {
+	static const bool disabled = getenv("MSC_NO_SORT_BUILD") != nullptr;
+	if (disabled) return 1;
+	const int k = set->k;
+	for (uint64_t j = 1; j < n_segs; j++) if (seg_seq[j] < seg_seq[j - 1]) return 1;
+	std::vector<uint64_t> koff(n_segs + 1, 0), per_seq(n_seqs, 0), sbeg(n_seqs + 1, 0), aoff(n_seqs, 0);
+	for (uint64_t j = 0; j < n_segs; j++) {
+		if (seg_seq[j] >= n_seqs || seg_end[j] < seg_start[j] || seg_end[j] >= n_bases) return fail(ctx, MSC_ERR_INVALID_ARG, "segment %llu is malformed", (unsigned long long)j);
+		const uint64_t len = seg_end[j] - seg_start[j] + 1;
+		const uint64_t nk = len >= (uint64_t)k ? len - k + 1 : 0;
+		koff[j + 1] = koff[j] + nk;
+		per_seq[seg_seq[j]] += nk;
+		sbeg[seg_seq[j] + 1]++;
+	}
+	for (uint64_t i = 0; i < n_seqs; i++) sbeg[i + 1] += sbeg[i];
+	uint64_t longest = 0, need = 0;
+	for (uint64_t i = 0; i < n_seqs; i++) { longest = std::max(longest, per_seq[i]); aoff[i] = set->ent_used + need; need += per_seq[i]; }
+	if (longest > 32768) return 1;
+	if (set->ent_used + need > set->ent_capacity)
+		return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, this build may need %llu)", (unsigned long long)set->ent_used,
+		            (unsigned long long)set->ent_capacity, (unsigned long long)need);
+	uint32_t P = 64;
+	while (P < longest) P <<= 1;
+	int r;
+	std::vector<MscSlotScalars> sc(n_seqs);
+	memset(sc.data(), 0, sizeof(MscSlotScalars) * n_seqs);
+	for (uint64_t i = 0; i < n_seqs; i++) {
+		sc[i].length = eff_len[i];
+		for (int b = 0; b < 4; b++) sc[i].one_mers[b] = one_mers ? one_mers[4 * i + b] : 0;
+		sc[i].n_kmers = per_seq[i];
+	}
+	HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + first_slot * set->scalar_stride, set->scalar_stride, sc.data(), sizeof(MscSlotScalars), sizeof(MscSlotScalars), n_seqs,
+	                              hipMemcpyHostToDevice, ctx->stream));
+	const size_t packed_bytes = (size_t)((n_bases + 3) / 4), padded_bytes = (packed_bytes + 3) / 4 * 4 + 8;
+	if ((r = ensure(ctx, ctx->packed, padded_bytes))) return r;
+	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + (padded_bytes - 12), 0, 12, ctx->stream));
+	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+	if ((r = ensure(ctx, ctx->seg_start, std::max<size_t>(n_segs, 1) * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->kmer_off, (n_segs + 1) * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->seq_seg, (n_seqs + 1) * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->sp_cumbase, std::max<size_t>(n_seqs * sizeof(uint64_t), ctx->sp_cumbase.cap)))) return r;
+	if (n_segs) HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_start.p, seg_start, n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->kmer_off.p, koff.data(), (n_segs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->seq_seg.p, sbeg.data(), (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_cumbase.p, aoff.data(), n_seqs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_build_sort(ctx->stream, k, set->dtype, set->L.nbins, first_slot, (uint32_t)n_seqs, (const uint32_t*)ctx->packed.p,
+	                                          (const uint64_t*)ctx->seg_start.p, (const uint64_t*)ctx->kmer_off.p, (const uint64_t*)ctx->seq_seg.p,
+	                                          (const uint64_t*)ctx->sp_cumbase.p, P, set->scalars, set->scalar_stride, set->hdr, set->ent, set->cum));
+	set->ent_used += need;
+	HIP_TRY(ctx, hipMemcpyAsync(set->hdr_host.data() + first_slot, set->hdr + first_slot, n_seqs * sizeof(MscSparseHdr), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return refresh_bounds(ctx, set, first_slot, n_seqs);
+}
+
 // Sparse build: dense-build a batch into scratch slots (the validated builder, bit-exact counts and saturation), then
 // compact each scratch slot in index order into the set's entry arena (sparse.hip).
 static int build_sparse(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const uint8_t* packed, uint64_t n_bases,
                         const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs, const uint64_t* eff_len,
                         const uint64_t* one_mers) {
 	const MscLayout& L = set->L;
+	int r0;
+	if ((r0 = build_sparse_sort(ctx, set, first_slot, n_seqs, packed, n_bases, seg_seq, seg_start, seg_end, n_segs, eff_len, one_mers)) != 1) return r0;
 	// scratch capacity: <= 8 GiB of dense slots
 	uint64_t B = (8ull << 30) / L.slot_bytes;
 	B = std::max<uint64_t>(1, std::min<uint64_t>(B, std::min<uint64_t>(n_seqs, 4096)));

@@ -125,6 +125,135 @@ __global__ void __launch_bounds__(kBlockC) k_sparse_write(const T* __restrict__ 
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ direct sparse build (sort)
+// One workgroup per sequence: its k-mer indices go to LDS, are bitonic-sorted there, and the runs of equal indices become
+// the (bin, value) entries -- no dense scratch slot at all (a k = 13 scratch slot is 64-512 MiB). Sequences with more than
+// 32768 k-mers fall back to the scratch + compaction path above.
+__device__ __forceinline__ uint32_t rev2_sp(uint32_t x) {
+	x = __brev(x);
+	return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+constexpr int kSortBlock = 256;
+__global__ void __launch_bounds__(kSortBlock) k_sparse_build_sort(
+    int k, int dtype, uint64_t nbins, uint64_t first_slot, const uint32_t* __restrict__ packed, const uint64_t* __restrict__ seg_start,
+    const uint64_t* __restrict__ kmer_off, const uint64_t* __restrict__ seq_seg_begin, const uint64_t* __restrict__ seq_arena_off,
+    uint32_t P /* LDS keys, power of two >= k-mers of the longest sequence of the launch */, uint8_t* __restrict__ scalars, uint64_t scalar_stride,
+    MscSparseHdr* __restrict__ hdr, uint2* __restrict__ ent, uint32_t* __restrict__ cum) {
+	extern __shared__ uint32_t keys[];                 // P keys
+	__shared__ uint64_t s_cnt[kSortBlock], s_ex[kSortBlock];
+	__shared__ uint64_t s_red[4][kSortBlock / 64];
+	__shared__ uint32_t s_split[MSC_SPARSE_SUB + 1];
+	const uint32_t seq = blockIdx.x, tid = threadIdx.x;
+	const uint64_t slot = first_slot + seq;
+	// 1. this sequence's k-mer indices
+	const uint64_t sb = seq_seg_begin[seq], se = seq_seg_begin[seq + 1];
+	const uint64_t k0 = kmer_off[sb];
+	const uint32_t n = (uint32_t)(kmer_off[se] - k0);
+	for (uint64_t j = sb; j < se; j++) {
+		const uint64_t nk = kmer_off[j + 1] - kmer_off[j], base = seg_start[j];
+		const uint32_t o = (uint32_t)(kmer_off[j] - k0);
+		for (uint64_t t = tid; t < nk; t += kSortBlock) {
+			const uint64_t pos = base + t;
+			const uint64_t window = (uint64_t)packed[pos >> 4] | ((uint64_t)packed[(pos >> 4) + 1] << 32);
+			uint32_t bits = (uint32_t)(window >> ((pos & 15) * 2));
+			if (2 * k < 32) bits &= (1u << (2 * k)) - 1u;
+			keys[o + t] = rev2_sp(bits) >> (32 - 2 * k);
+		}
+	}
+	for (uint32_t i = n + tid; i < P; i += kSortBlock) keys[i] = 0xffffffffu;
+	__syncthreads();
+	// 2. bitonic sort of P keys
+	for (uint32_t size = 2; size <= P; size <<= 1) {
+		for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+			for (uint32_t t = tid; t < P / 2; t += kSortBlock) {
+				const uint32_t lo = 2 * t - (t & (stride - 1));
+				const uint32_t hi = lo + stride;
+				const bool up = (lo & size) == 0;
+				const uint32_t a = keys[lo], b = keys[hi];
+				if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+			}
+			__syncthreads();
+		}
+	}
+	// 3. runs of equal keys -> entries. Thread t owns the consecutive chunk [t*C, (t+1)*C) of the sorted array.
+	const uint64_t tmax = dtype == 64 ? ~0ull : ((1ull << dtype) - 1);
+	const uint32_t C = P / kSortBlock > 0 ? P / kSortBlock : 1;
+	const uint32_t c0 = tid * C, c1 = c0 + C < n ? c0 + C : (c0 < n ? n : c0);
+	auto run_len = [&](uint32_t i) -> uint32_t {          // i is a run head: length = upper_bound(keys[i]) - i
+		const uint32_t key = keys[i];
+		uint32_t lo = i + 1, hi = n;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
+		return lo - i;
+	};
+	uint64_t cnt = 0, ex = 0, sq = 0, mx = 0, ovf = 0;
+	for (uint32_t i = c0; i < c1; i++) {
+		if (i == 0 || keys[i] != keys[i - 1]) {
+			uint64_t v = 1ull + run_len(i);
+			if (v > tmax) { v = tmax; ovf = 1; }
+			cnt++; ex += v - 1; sq += v * v - 1; mx = v > mx ? v : mx;
+		}
+	}
+	s_cnt[tid] = cnt;
+	s_ex[tid] = ex;
+	__syncthreads();
+	if (tid == 0) {                                       // 256-element exclusive scans: serial is fine
+		uint64_t a = 0, b = 0;
+		for (int i = 0; i < kSortBlock; i++) { const uint64_t x = s_cnt[i], y = s_ex[i]; s_cnt[i] = a; s_ex[i] = b; a += x; b += y; }
+		s_red[0][0] = a;                                  // total entries
+		s_red[1][0] = b;                                  // total excess
+	}
+	__syncthreads();
+	const uint64_t arena = seq_arena_off[seq];
+	{
+		uint64_t o = arena + s_cnt[tid];
+		uint32_t run = (uint32_t)s_ex[tid];
+		for (uint32_t i = c0; i < c1; i++) {
+			if (i == 0 || keys[i] != keys[i - 1]) {
+				uint64_t v = 1ull + run_len(i);
+				if (v > tmax) v = tmax;
+				run += (uint32_t)(v - 1);
+				ent[o] = make_uint2(keys[i], (uint32_t)v);
+				cum[o] = run;
+				o++;
+			}
+		}
+	}
+	// 4. sub-range offsets: entries with index < w * N/16  ==  run heads before the first key >= that boundary
+	if (tid <= MSC_SPARSE_SUB) {
+		const uint64_t bound = nbins / MSC_SPARSE_SUB * tid;
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)keys[mid] < bound) lo = mid + 1; else hi = mid; }
+		const uint32_t owner = lo / C < (uint32_t)kSortBlock ? lo / C : kSortBlock - 1;
+		uint32_t heads = (uint32_t)s_cnt[owner];
+		for (uint32_t i = owner * C; i < lo; i++) if (i == 0 || keys[i] != keys[i - 1]) heads++;
+		s_split[tid] = tid == MSC_SPARSE_SUB ? (uint32_t)s_red[0][0] : heads;
+	}
+	// 5. block reductions for the scalar record
+	sq = wave_sum_u64(sq);
+	uint64_t m2 = mx, o2 = ovf;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) { const uint64_t a = __shfl_xor(m2, off, 64); m2 = a > m2 ? a : m2; o2 |= __shfl_xor(o2, off, 64); }
+	if ((tid & 63) == 0) { s_red[2][tid >> 6] = sq; s_red[3][tid >> 6] = m2 | (o2 << 63); }
+	__syncthreads();
+	if (tid == 0) {
+		uint64_t sqt = 0, mxt = 1, ov = 0;
+		for (int i = 0; i < kSortBlock / 64; i++) { sqt += s_red[2][i]; const uint64_t m_ = s_red[3][i] & ~(1ull << 63); mxt = m_ > mxt ? m_ : mxt; ov |= s_red[3][i] >> 63; }
+		MscSlotScalars* sc = reinterpret_cast<MscSlotScalars*>(scalars + slot * scalar_stride);
+		const uint64_t sum = nbins + s_red[1][0], sum_sq = nbins + sqt;
+		sc->sum = sum; sc->sum_sq = sum_sq; sc->max_count = mxt; sc->mag = sum; sc->overflow = ov;
+		const double N = (double)nbins, aq = (double)sum / N;
+		const double var = ((double)sum_sq - 2.0 * aq * (double)sum + N * aq * aq) / N;
+		sc->stddev = sqrt(var > 0 ? var : 0);
+		MscSparseHdr h;
+		h.off = arena;
+		h.nnz = (uint32_t)s_red[0][0];
+		for (int w = 0; w <= MSC_SPARSE_SUB; w++) h.split[w] = s_split[w];
+		h.pad_[0] = h.pad_[1] = 0;
+		hdr[slot] = h;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ pair kernel
 struct DivTerm { double jd, js; };
 __device__ __forceinline__ DivTerm div_term_sp(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {
@@ -364,5 +493,21 @@ hipError_t msc_launch_sparse_mean_write(hipStream_t st, int dtype, uint32_t* acc
 	case 32: k_sparse_mean_write<uint32_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	default: k_sparse_mean_write<uint64_t><<<dim3(n_chunks), dim3(64), 0, st>>>(acc, chunk_bins, m, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_build_sort(hipStream_t st, int k, int dtype, uint64_t nbins, uint64_t first_slot, uint32_t n_seqs, const uint32_t* packed,
+                                        const uint64_t* seg_start, const uint64_t* kmer_off, const uint64_t* seq_seg_begin, const uint64_t* seq_arena_off,
+                                        uint32_t P, uint8_t* scalars, uint64_t scalar_stride, MscSparseHdr* hdr, void* ent, uint32_t* cum) {
+	if (n_seqs == 0) return hipSuccess;
+	const size_t lds = (size_t)P * sizeof(uint32_t);
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void*)k_sparse_build_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	k_sparse_build_sort<<<dim3(n_seqs), dim3(kSortBlock), lds, st>>>(k, dtype, nbins, first_slot, packed, seg_start, kmer_off, seq_seg_begin, seq_arena_off, P, scalars,
+	                                                                   scalar_stride, hdr, (uint2*)ent, cum);
 	return hipGetLastError();
 }
