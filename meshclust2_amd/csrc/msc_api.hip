@@ -29,6 +29,7 @@ struct msc_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
 	bool have_timing = false;
+	uint32_t last_partial_stride = 0;        // partial records per candidate written by the last run_score
 	float tiles_ms_accum = 0.f;
 	int tiles_launches = 0;
 	std::string err;
@@ -60,6 +61,7 @@ struct msc_hist_set {
 	MscSparseHdr* hdr = nullptr;          // device, [capacity]
 	std::vector<MscSparseHdr> hdr_host;   // mirror
 	uint64_t ent_capacity = 0, ent_used = 0;
+	uint32_t max_nnz = 0;                 // longest entry list ever stored (monotone)
 };
 
 struct msc_model {
@@ -398,6 +400,7 @@ static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_
 		s->max_count = std::max(s->max_count, r.max_count);
 		s->max_sum = std::max(s->max_sum, r.sum);
 	}
+	if (s->sparse) for (uint64_t i = first; i < first + n; i++) s->max_nnz = std::max(s->max_nnz, s->hdr_host[i].nnz);
 	return MSC_OK;
 }
 
@@ -1006,7 +1009,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		return MSC_OK;
 	}
 	const bool sp = cs->sparse;
-	const uint32_t PS = sp ? MSC_SPARSE_SUB : L.S;          // partial records per candidate
+	// LDS-staged merge kernel: lists must fit the LDS budget and the 32-bit arithmetic range; one record per candidate
+	static const bool no_sp_lds = getenv("MSC_SPARSE_NO_LDS") != nullptr;
+	const bool sp_lds = sp && !no_sp_lds && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 && L.nbins >= 64 &&
+	                    ((size_t)(rq.qset->hdr_host[rq.q_slot].nnz + 128) + 4ull * (cs->max_nnz + 128)) * 8 <= 96 * 1024;
+	const uint32_t PS = sp ? (sp_lds ? 1 : MSC_SPARSE_SUB) : L.S;          // partial records per candidate
+	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
 	if (rq.reduce_mode >= 0 || rq.only_tiles) chunk = m;      // reductions run over the whole window in one piece
@@ -1040,7 +1048,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (sp) {
+		if (sp_lds) {
+			HIP_TRY(ctx, msc_launch_pair_sparse_lds(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
+			                                        rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.qset->hdr_host[rq.q_slot].nnz,
+			                                        cs->max_nnz, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p,
+			                                        need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order, ctx->num_cus));
+		} else if (sp) {
 			HIP_TRY(ctx, msc_launch_pair_sparse(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
 			                                    rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,
 			                                    (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr,
@@ -1439,7 +1452,7 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	if ((r = run_score_fwd(ctx, set, member_slots, m, rs))) return r;
 	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
 	if (dist_out && (r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
-	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, MSC_SPARSE_SUB, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
+	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, ctx->last_partial_stride, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
 	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, dist_out ? (double*)ctx->raw.p : nullptr,
 	                                   (MscReduceOut*)ctx->reduce_out.p));
 	MscReduceOut ro;

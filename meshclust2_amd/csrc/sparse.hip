@@ -20,6 +20,8 @@
 // Build: the dense builder (hist_build.hip) fills a scratch slot per sequence of the batch, then k_sparse_count /
 // k_sparse_write compact it IN INDEX ORDER: in the tile-permuted layout every lane already holds a logically consecutive
 // run, so one wave scan per tile yields ordered output with coalesced reads.
+#include <algorithm>
+
 #include "msc_internal.h"
 
 namespace {
@@ -423,6 +425,105 @@ __global__ void __launch_bounds__(64) k_sparse_mean_write(uint32_t* __restrict__
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged merge kernel
+// k_pair_sparse is bound by the texture-address unit: 64 lanes chase 64 private pointers, ~30 cache lines per wave load.
+// Here a WAVE owns one candidate: its entry list is staged into LDS with coalesced loads (the query list once per
+// workgroup), lane r merges the index sub-range [r, r+1) * 4^k / 64 out of LDS, and the 64 partial results are folded in
+// the wave, so one record per candidate reaches the epilogue. 32-bit running values (counts < 2^16, sums < 2^31: the host
+// checks and otherwise keeps the general kernel). Lists longer than the LDS capacity also stay on the general kernel.
+__device__ __forceinline__ uint32_t lower_bound_lds(const uint2* l, uint32_t n, uint32_t key) {
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (l[mid].x < key) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+template <bool DIV>
+__global__ void __launch_bounds__(256) k_pair_sparse_lds(
+    const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
+    const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
+    const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
+    const uint8_t* __restrict__ q_scalars, uint64_t nbins, uint32_t qcap, uint32_t ccap, int use_window, uint64_t min_len, uint64_t max_len,
+    MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order) {
+	extern __shared__ uint2 s_lists[];                  // [qcap] query entries | 4 x [ccap] candidate entries
+	__shared__ uint32_t s_qsplit[65];
+	__shared__ uint32_t s_qcum0[64];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const MscSparseHdr qh = *q_hdr_p;
+	uint2* qlist = s_lists;
+	uint2* clist = s_lists + qcap + (size_t)wave * ccap;
+	for (uint32_t t = threadIdx.x; t < qh.nnz; t += blockDim.x) qlist[t] = q_ent[qh.off + t];
+	__syncthreads();
+	const uint32_t sub = (uint32_t)(nbins / 64);
+	if (threadIdx.x <= 64) {
+		const uint32_t pos = threadIdx.x == 64 ? qh.nnz : lower_bound_lds(qlist, qh.nnz, threadIdx.x * sub);
+		s_qsplit[threadIdx.x] = pos;
+		if (threadIdx.x < 64) s_qcum0[threadIdx.x] = pos ? q_cum[qh.off + pos - 1] : 0u;
+	}
+	__syncthreads();
+	const uint32_t j0 = s_qsplit[lane], j1 = s_qsplit[lane + 1];
+	const uint32_t cq0 = s_qcum0[lane];
+	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
+	const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
+	for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave; c < m; c += total_waves) {
+		const uint32_t slot = cand_slots ? cand_slots[c] : c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const MscSparseHdr ch = c_hdr[slot];
+		__builtin_amdgcn_wave_barrier();                 // every lane is done reading the previous candidate's list
+		for (uint32_t t = lane; t < ch.nnz; t += 64) clist[t] = c_ent[ch.off + t];       // coalesced: 512 B per wave load
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();                 // LDS operations of one wave complete in order: the reads below see the writes
+		const uint32_t i0 = lower_bound_lds(clist, ch.nnz, lane * sub);
+		uint32_t i1 = __shfl_down(i0, 1, 64);
+		if (lane == 63) i1 = ch.nnz;
+		uint32_t i = i0, j = j0;
+		int32_t D = (int32_t)(i ? c_cum[ch.off + i - 1] : 0u) - (int32_t)cq0;           // prefix difference entering the sub-range
+		uint32_t pos = lane * sub, manh = 0;
+		uint64_t dotx = 0, emd = 0;
+		double jd = 0.0, js = 0.0, cm = 0.0;
+		DivTerm t11{0.0, 0.0};
+		if constexpr (DIV) { cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order); }
+		const uint32_t kInf = 0xffffffffu;
+		uint2 a = i < i1 ? clist[i] : make_uint2(kInf, 1u);
+		uint2 b = j < j1 ? qlist[j] : make_uint2(kInf, 1u);
+		while (i < i1 || j < j1) {
+			const uint32_t e = a.x < b.x ? a.x : b.x;
+			const bool ta = a.x == e, tb = b.x == e;
+			const uint32_t absD = (uint32_t)(D < 0 ? -D : D);
+			emd += (uint64_t)absD * (e - pos);
+			const uint32_t pv = ta ? a.y : 1u, qv = tb ? b.y : 1u;
+			manh += pv > qv ? pv - qv : qv - pv;
+			dotx += (uint64_t)(pv * qv - 1u);               // counts < 2^16: the product fits 32 bits
+			D += (int32_t)pv - (int32_t)qv;
+			if constexpr (DIV) {
+				DivTerm tt;
+				if ((pv | qv) < 16u) tt = div_tables[(uint64_t)c * 256 + pv * 16 + qv];
+				else tt = div_term_sp(pv, qv, cm, qm, order);
+				jd += tt.jd - t11.jd;
+				js += tt.js - t11.js;
+			}
+			pos = e;
+			if (ta) { i++; a = i < i1 ? clist[i] : make_uint2(kInf, 1u); }
+			if (tb) { j++; b = j < j1 ? qlist[j] : make_uint2(kInf, 1u); }
+		}
+		{
+			const uint32_t absD = (uint32_t)(D < 0 ? -D : D);
+			emd += (uint64_t)absD * ((lane + 1) * sub - pos);
+		}
+		const uint64_t manh_t = wave_sum_u64(manh), dot_t = wave_sum_u64(dotx), emd_t = wave_sum_u64(emd);
+		if constexpr (DIV) {
+#pragma unroll
+			for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+		}
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = manh_t; out.dot = dot_t; out.emd = emd_t;
+			partials[c] = out;
+			if constexpr (DIV) { div_partials[2ull * c] = jd; div_partials[2ull * c + 1] = js; }
+		}
+	}
+}
+
 // ================================================================================================ launchers
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts) {
 	if (n == 0) return hipSuccess;
@@ -509,5 +610,41 @@ hipError_t msc_launch_sparse_build_sort(hipStream_t st, int k, int dtype, uint64
 	}
 	k_sparse_build_sort<<<dim3(n_seqs), dim3(kSortBlock), lds, st>>>(k, dtype, nbins, first_slot, packed, seg_start, kmer_off, seq_seg_begin, seq_arena_off, P, scalars,
 	                                                                   scalar_stride, hdr, (uint2*)ent, cum);
+	return hipGetLastError();
+}
+
+// returns hipErrorInvalidValue when the lists do not fit the LDS budget (caller then uses msc_launch_pair_sparse)
+hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                      uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                      const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, uint32_t q_nnz, uint32_t max_c_nnz, int use_window,
+                                      uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus) {
+	if (m == 0) return hipSuccess;
+	const uint32_t qcap = (q_nnz + 63) / 64 * 64 + 64, ccap = (max_c_nnz + 63) / 64 * 64 + 64;
+	const size_t lds = ((size_t)qcap + 4ull * ccap) * sizeof(uint2);
+	if (lds > 96 * 1024 || nbins < 64) return hipErrorInvalidValue;
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void*)k_pair_sparse_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pair_sparse_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	// resident workgroups: LDS-limited (160 KiB per CU), at most 8 per CU; each wave then walks several candidates
+	uint32_t per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / (lds + 1024));
+	if (per_cu < 1) per_cu = 1;
+	uint32_t blocks = (uint32_t)num_cus * per_cu;
+	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+	if (div_tables) {
+		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		k_pair_sparse_lds<true><<<dim3(blocks), dim3(256), lds, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                               q_cum, q_hdr, q_scalars, nbins, qcap, ccap, use_window, min_len, max_len, partials,
+		                                                               (const DivTerm*)div_tables, (double*)div_partials, order);
+	} else {
+		k_pair_sparse_lds<false><<<dim3(blocks), dim3(256), lds, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                                q_cum, q_hdr, q_scalars, nbins, qcap, ccap, use_window, min_len, max_len, partials, nullptr,
+		                                                                nullptr, order);
+	}
 	return hipGetLastError();
 }
