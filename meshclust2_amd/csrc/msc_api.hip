@@ -1222,6 +1222,16 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// wave totals of the per-lane 32-bit partial sums fit 32 bits when 64*R*max^2 and 64*R*max|prefix difference| do
 	const uint64_t mc_ = std::max(cands->max_count, qset->max_count), ms_ = std::max(cands->max_sum, qset->max_sum);
 	const bool compact = 64ull * L.R * mc_ * mc_ < (1ull << 32) && 64ull * L.R * ms_ < (1ull << 32);
+	// LDS-DMA ring form: 32/64-bit bins, compact totals, query groups of four; records are 16 bytes and cover the padded query count
+	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
+	const bool ring = !no_ring && compact && L.LPT == 4 && (cands->dtype == 32 || cands->dtype == 64) && (tq == 4 || tq == 8) && n_q >= 4;
+	// every prefix of excess counts (count - 1) is at most the histogram's k-mer total = sum - 4^k: 16-bit prefix form when that fits
+	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
+	const bool prefix16 = ring && !no_p16 && ms_ >= L.nbins && ms_ - L.nbins < 65536;
+	if (ring) {
+		const uint64_t nq_pad = (n_q + tq - 1) / tq * tq;
+		if ((r = ensure(ctx, ctx->partials, nq_pad * chunk * L.S * 16))) return r;
+	}
 	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
@@ -1230,12 +1240,17 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
-		                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		if (ring)
+			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
+			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
+		else
+			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
+			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
+		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.S = L.S;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;

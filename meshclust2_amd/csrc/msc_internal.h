@@ -62,6 +62,7 @@ enum { MSC_REDUCE_GET_CLOSE = 0, MSC_REDUCE_MERGE = 1 };
 // epilogue request
 struct MscEpilogueArgs {
 	const MscPartial* partials;       // [m][S]
+	const void* partials16;           // or: [m][S] records of four u32 {manh, dot, emd, 0} (ring kernel); partials is then unused
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
 	uint32_t m;
@@ -123,6 +124,11 @@ hipError_t msc_launch_pair_tiles_wide(hipStream_t st, const MscLayout& L, int dt
                                       int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus,
                                       void* div_partials /*nullable*/, int order);
 int msc_div_table_dim(const MscLayout& L);      // 8 or 16: side of the per-candidate (count, count) term table
+// Q x M streaming through the LDS-DMA ring (32/64-bit bins, LPT 4, compact totals, tq 4 or 8). hipErrorInvalidValue = not applicable.
+hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                            const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
+                                            const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q, int tq,
+                                            bool prefix16, void* partials16, int num_cus);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out);

@@ -666,6 +666,190 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles_multi32(
 	}
 }
 
+// ---------------------------------------------------------------------------------------- Q x M kernel, LDS-DMA ring
+// Same arithmetic as k_pair_tiles_multi32<.., COMPACT = true>, different data movement. With the query digests in
+// registers a wave has room for one candidate tile in flight (2-3 waves per SIMD -> 8-12 KiB in flight per SIMD, which
+// does not cover the HBM latency). Here the candidate tiles arrive by LDS-DMA (global_load_lds_dwordx4: no destination
+// VGPRs) into a wave-private ring of NB slots, NB-1 tiles ahead of the one being scored; the wave never shares its ring,
+// so there is no barrier, only a counted s_waitcnt. Vector-memory operations retire in issue order (loads, stores and
+// LDS-DMA on one counter), so "tile i has landed" == "at most YOUNGER(i) operations outstanding", where YOUNGER counts
+// the DMA pieces issued after tile i's pieces. They are issued from inline asm in a fixed number per iteration (tail
+// iterations re-fetch the last tile instead of skipping the fetch), which keeps that count exact; the compiler sees
+// no vector load in the loop, so it adds no wait of its own. Partial records are 16 bytes here (three u32 totals + pad): one store per group of four queries, issued by
+// the four lanes that own the row totals after wave_sum4_rows.
+constexpr int kRingPieces = 5;          // VM operations per tile fetch: 4 x 1 KiB of bins + the tile's prefix carry
+constexpr uint32_t kRingSlotBytes = 4096 + 256;
+
+__device__ __forceinline__ void ring_fetch(const uint8_t* lane_src, const uint8_t* carry_src, uint32_t lds_slot) {
+	uint32_t keep;      // m0 is the compiler's: saved and restored around the DMA pieces
+	asm volatile(
+	    "s_mov_b32 %0, m0\n\t"
+	    "s_mov_b32 m0, %3\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dwordx4 %1, off\n\t"
+	    "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+	    "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+	    "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+	    "s_add_u32 m0, m0, 4096\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dword %2, off\n\t"
+	    "s_mov_b32 m0, %0"
+	    : "=&s"(keep)
+	    : "v"(lane_src), "v"(carry_src), "s"(lds_slot)
+	    : "memory", "scc");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int TQ, int NB, bool P16>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles_multi32_ring(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ qset_bins, uint64_t q_slot_bytes,
+    const uint8_t* __restrict__ qset_scalars, uint64_t q_scalar_stride, const uint32_t* __restrict__ q_slots, uint32_t n_q,
+    uint32_t S, uint32_t G, uint32_t nqb, u32x4* __restrict__ partials16) {
+	static_assert(sizeof(T) >= 4 && TQ % 4 == 0 && NB >= 2 && NB <= 4, "32/64-bit bins, query groups of four, ramp-up waits written for <= 3 tiles ahead");
+	constexpr int LPT = 4;
+	constexpr int E = 16 / sizeof(T);
+	constexpr int R = LPT * E;
+	constexpr int NW = 4 * LPT;
+	constexpr int STEP = sizeof(T) / 4;
+	constexpr uint32_t tile_bytes = 4096;
+	constexpr int D = NB - 1;                          // tiles in flight ahead of the one being scored
+	constexpr int SPI = TQ / 4;                        // partial stores per iteration
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_ring[];      // [waves per block][NB][kRingSlotBytes]
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);
+	// query blocks fastest: the waves that stream the SAME candidate tiles (one per query block) sit side by side in one
+	// workgroup, so the second one finds the tile in the CU's L1 / the XCD's L2 instead of fetching it from HBM again;
+	// the follower runs faster than the leader (hits instead of misses), which keeps the two from drifting apart
+	const uint32_t qb = W % nqb;
+	const uint32_t rest = W / nqb;
+	const uint32_t s = rest % S;
+	const uint32_t g = rest / S;
+	if (g >= G) return;
+
+	// prefix statistic: |prefix(candidate) - prefix(query)| per bin. The pseudocount baseline (bin index + 1) is common to
+	// both sides, so the prefixes of the EXCESS counts (count - 1) give the same differences; they are bounded by the
+	// number of k-mers of the sequence, and when that is < 2^16 for every histogram involved (P16, host-checked) two of
+	// them share a register and one v_sad_u16 covers two bins.
+	constexpr int NP = P16 ? R / 2 : R;
+	uint32_t cqv[TQ][NP];       // inclusive prefix of each query's run: absolute (32-bit) or excess, packed 2i | 2i+1 << 16
+	uint32_t qpk[TQ][R / 2];    // bins 2i | 2i+1 << 16
+#pragma unroll
+	for (int j = 0; j < TQ; j++) {
+		const uint32_t qi = qb * TQ + j;
+		const uint32_t qslot = q_slots[qi < n_q ? qi : qb * TQ];       // padded queries score a valid slot; their records are ignored
+		TileRegs<LPT> qt;
+		load_tile<LPT>(qt, qset_bins + (uint64_t)qslot * q_slot_bytes + (uint64_t)s * tile_bytes, lane);
+		const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qt);
+		const uint32_t tq = run_sum<T, NW>(qw);
+		const uint64_t* q_prefix = reinterpret_cast<const uint64_t*>(qset_scalars + (uint64_t)qslot * q_scalar_stride + sizeof(MscSlotScalars));
+		uint32_t run = (uint32_t)q_prefix[s] + wave_incl_scan(tq) - tq;
+		if constexpr (P16) {
+			run -= s * (uint32_t)(64 * R) + lane * R;      // bins before this lane's run: the baseline they contribute
+			uint32_t ev[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) { run += qw[r * STEP] - 1u; ev[r] = run; }
+#pragma unroll
+			for (int r = 0; r < R / 2; r++) cqv[j][r] = ev[2 * r] | (ev[2 * r + 1] << 16);
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; r++) { run += qw[r * STEP]; cqv[j][r] = run; }
+		}
+#pragma unroll
+		for (int r = 0; r < R / 2; r++) qpk[j][r] = qw[2 * r * STEP] | (qw[(2 * r + 1) * STEP] << 16);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below start from an empty queue
+
+	uint8_t* my_ring = s_ring + (size_t)wib * NB * kRingSlotBytes;
+	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)my_ring);
+	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
+	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
+		uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;          // past the end: re-fetch the last tile (keeps the count fixed)
+		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
+		const uint8_t* src = cand_bins + (uint64_t)slot * slot_bytes + (uint64_t)s * tile_bytes + lane * 16u;
+		const uint8_t* csrc = cand_scalars + (uint64_t)slot * scalar_stride + sizeof(MscSlotScalars) + 8ull * s;
+		ring_fetch(src, csrc, ring_lds + slot_idx * kRingSlotBytes);
+	};
+#pragma unroll
+	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
+
+	// the four lanes holding row totals after wave_sum4_rows: lane 15 -> query 0, 31 -> 2, 47 -> 1, 63 -> 3 of a group
+	const uint32_t row = lane >> 4;
+	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
+	const bool owner = (lane & 15) == 15;
+	u32x4* out_ptr[SPI];
+#pragma unroll
+	for (int gq = 0; gq < SPI; gq++) out_ptr[gq] = partials16 + ((uint64_t)(qb * TQ + gq * 4 + jrow) * m + g) * S + s;
+	const uint64_t out_step = (uint64_t)G * S;
+
+	uint32_t slot_idx = 0, fetch_idx = D % NB;
+	for (uint32_t it = 0; it < n_iter; it++) {
+		fetch(it + D, fetch_idx);                 // overwrites the slot scored in the previous iteration (its reads are complete)
+		fetch_idx = fetch_idx + 1 == NB ? 0 : fetch_idx + 1;
+		// Tile `it` has landed once at most D * kRingPieces operations are outstanding: D fetches were issued after it and
+		// operations retire in issue order. The partial-record stores issued in between are left out of the count, which
+		// keeps it valid however many records an iteration writes (and during ramp-up); the price is that up to D * SPI
+		// pieces of the NEXT tile are waited for as well -- pieces requested a whole iteration ago.
+		wait_vm<D * kRingPieces>();
+		const uint8_t* slot_base = my_ring + slot_idx * kRingSlotBytes;
+		slot_idx = slot_idx + 1 == NB ? 0 : slot_idx + 1;
+		TileRegs<LPT> cur;
+#pragma unroll
+		for (int l = 0; l < LPT; l++) cur.v[l] = reinterpret_cast<const u32x4*>(slot_base)[64 * l + lane];
+		const uint32_t carry = reinterpret_cast<const uint32_t*>(slot_base + 4096)[lane];
+		const uint32_t* pw = reinterpret_cast<const uint32_t*>(&cur);
+		const uint32_t tp = run_sum<T, NW>(pw);
+		uint32_t run = carry + wave_incl_scan(tp) - tp;
+		uint32_t cpv[NP], ppk[R / 2];
+		if constexpr (P16) {
+			run -= s * (uint32_t)(64 * R) + lane * R;
+			uint32_t ev[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) { run += pw[r * STEP] - 1u; ev[r] = run; }
+#pragma unroll
+			for (int r = 0; r < R / 2; r++) cpv[r] = ev[2 * r] | (ev[2 * r + 1] << 16);
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; r++) { run += pw[r * STEP]; cpv[r] = run; }
+		}
+#pragma unroll
+		for (int r = 0; r < R / 2; r++) ppk[r] = pw[2 * r * STEP] | (pw[(2 * r + 1) * STEP] << 16);
+#pragma unroll
+		for (int gq = 0; gq < SPI; gq++) {
+			uint32_t manh[4], dot[4], emd[4];
+#pragma unroll
+			for (int jj = 0; jj < 4; jj++) {
+				const int j = gq * 4 + jj;
+				manh[jj] = 0; dot[jj] = 0; emd[jj] = 0;
+#pragma unroll
+				for (int r = 0; r < R / 2; r++) {
+					manh[jj] = __builtin_amdgcn_sad_u16(ppk[r], qpk[j][r], manh[jj]);
+					dot[jj] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, ppk[r]), __builtin_bit_cast(u16x2, qpk[j][r]), dot[jj], false);
+					if constexpr (P16) {
+						emd[jj] = __builtin_amdgcn_sad_u16(cpv[r], cqv[j][r], emd[jj]);
+					} else {
+						emd[jj] = sad_u32(cpv[2 * r], cqv[j][2 * r], emd[jj]);
+						emd[jj] = sad_u32(cpv[2 * r + 1], cqv[j][2 * r + 1], emd[jj]);
+					}
+				}
+			}
+			u32x4 rec;
+			rec.x = wave_sum4_rows(manh[0], manh[1], manh[2], manh[3]);
+			rec.y = wave_sum4_rows(dot[0], dot[1], dot[2], dot[3]);
+			rec.z = wave_sum4_rows(emd[0], emd[1], emd[2], emd[3]);
+			rec.w = 0;
+			// s_nop: a store of more than 8 bytes reads its data registers after issue; the compiler's hazard recognizer does
+			// not look inside an asm statement and may overwrite `rec` in the very next instruction
+			if (owner) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out_ptr[gq]), "v"(rec) : "memory");
+			out_ptr[gq] += out_step;
+			if constexpr (SPI > 1) __builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
+}
+
 // ---------------------------------------------------------------------------------------- epilogue
 struct PairTotals {
 	uint64_t manh, dot, emd;
@@ -830,8 +1014,13 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogue
 	if (c >= a.m) return;
 	PairTotals t{0, 0, 0, 0.0, 0.0};
 	for (uint32_t s = lane; s < a.S; s += 64) {
-		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
-		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		if (a.partials16) {
+			const u32x4 p = reinterpret_cast<const u32x4*>(a.partials16)[(uint64_t)c * a.S + s];
+			t.manh += p.x; t.dot += p.y; t.emd += p.z;
+		} else {
+			const MscPartial p = a.partials[(uint64_t)c * a.S + s];
+			t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		}
 		if (a.div_partials) {
 			const MscPartialDiv d = reinterpret_cast<const MscPartialDiv*>(a.div_partials)[(uint64_t)c * a.S + s];
 			t.jd += d.jd; t.js += d.js;
@@ -849,8 +1038,13 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilog
 	if (c >= a.m) return;
 	PairTotals t{0, 0, 0, 0.0, 0.0};
 	for (uint32_t s = 0; s < a.S; s++) {
-		const MscPartial p = a.partials[(uint64_t)c * a.S + s];
-		t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		if (a.partials16) {
+			const u32x4 p = reinterpret_cast<const u32x4*>(a.partials16)[(uint64_t)c * a.S + s];
+			t.manh += p.x; t.dot += p.y; t.emd += p.z;
+		} else {
+			const MscPartial p = a.partials[(uint64_t)c * a.S + s];
+			t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+		}
 		if (a.div_partials) {
 			const MscPartialDiv d = reinterpret_cast<const MscPartialDiv*>(a.div_partials)[(uint64_t)c * a.S + s];
 			t.jd += d.jd; t.js += d.js;
@@ -1175,6 +1369,52 @@ hipError_t msc_launch_pair_tiles_multi(hipStream_t st, const MscLayout& L, int d
 	}
 #undef MSC_MULTI
 #undef MSC_MULTI_ARGS
+}
+
+template <typename T, int TQ, int NB, bool P16>
+static hipError_t launch_multi_ring_t(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, uint32_t m,
+                                      const uint8_t* qb, uint64_t qsb, const uint8_t* qs, uint64_t qss, const uint32_t* qslots, uint32_t nq,
+                                      void* partials16, int num_cus) {
+	const uint32_t S = L.S;
+	const uint32_t nqb = (nq + TQ - 1) / TQ;
+	const size_t lds = (size_t)kWavesPerBlock * NB * kRingSlotBytes;
+	const void* fn = (const void*)k_pair_tiles_multi32_ring<T, TQ, NB, P16>;
+	static bool attr_done = false;
+	if (!attr_done) {
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_done = true;
+	}
+	int blocks_per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
+	// one resident round of equal-length waves (same policy as launch_multi_t)
+	uint64_t G = (uint64_t)num_cus * blocks_per_cu * kWavesPerBlock / ((uint64_t)S * nqb);
+	if (G < 1) G = 1;
+	if (G > m) G = m;
+	const uint64_t waves = (uint64_t)S * G * nqb;
+	const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+	k_pair_tiles_multi32_ring<T, TQ, NB, P16><<<dim3(blocks), dim3(kBlock), lds, st>>>(cb, L.slot_bytes, cs, msc_scalar_stride(S), sl, m, qb, qsb, qs, qss, qslots, nq, S,
+	                                                                               (uint32_t)G, nqb, (u32x4*)partials16);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                            const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
+                                            const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q, int tq,
+                                            bool prefix16, void* partials16, int num_cus) {
+	if (m == 0 || n_q == 0) return hipSuccess;
+	if (L.LPT != 4 || (dtype != 32 && dtype != 64) || (tq != 4 && tq != 8)) return hipErrorInvalidValue;
+	static const int nb_env = [] { const char* e = getenv("MSC_RING_SLOTS"); return e ? atoi(e) : 0; }();
+#define MSC_RING_ARGS st, L, cand_bins, cand_scalars, cand_slots, m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, q_slots, n_q, partials16, num_cus
+#define MSC_RING_NB(T, Q, P)                                                                                     \
+	(nb_env == 2 ? launch_multi_ring_t<T, Q, 2, P>(MSC_RING_ARGS) : nb_env == 3 ? launch_multi_ring_t<T, Q, 3, P>(MSC_RING_ARGS) \
+	                                                                          : launch_multi_ring_t<T, Q, 4, P>(MSC_RING_ARGS))
+#define MSC_RING(T)                                                                                              \
+	(tq == 8 ? (prefix16 ? MSC_RING_NB(T, 8, true) : MSC_RING_NB(T, 8, false)) : (prefix16 ? MSC_RING_NB(T, 4, true) : MSC_RING_NB(T, 4, false)))
+	return dtype == 32 ? MSC_RING(uint32_t) : MSC_RING(uint64_t);
+#undef MSC_RING_NB
+#undef MSC_RING
+#undef MSC_RING_ARGS
 }
 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {

@@ -1,0 +1,65 @@
+"""Helper run as a subprocess by test_gpu_parity.py::test_multi_ring_variants (the library reads MSC_MULTI_TQ /
+MSC_RING_SLOTS once per process): the LDS-DMA ring form of the Q x M kernel == independent 1 x M passes, bit for bit."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from meshclust2_amd import api, synth  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from golden_util import FAST  # noqa: E402
+
+FAST_MASK = sum(1 << b for _, b in FAST)
+
+
+def main():
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ctx = api.Context(0)
+    for dtype, k, n, length in ((32, 9, 330, 1000), (64, 6, 700, 300)):
+        seqs, _ = synth.families(900 + k, n, length, family=10)
+        hs = api.HistogramSet(ctx, k, dtype, len(seqs))
+        hs.build(seqs)
+        feat = api.Feature.from_text(ctx, open(os.path.join(golden, "weights_k9_u32.txt")).read(), 0)
+        mask = FAST_MASK
+        for nq, cands in ((4, np.arange(n, dtype=np.uint32)), (9, np.arange(5, n, dtype=np.uint32)), (16, np.arange(n - 1, -1, -1, dtype=np.uint32)),
+                          (8, np.array([7], dtype=np.uint32)), (5, np.array([3, 9, 4], dtype=np.uint32))):
+            qs = (np.arange(nq, dtype=np.uint32) * 3) % n
+            multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+            for i, q in enumerate(qs):
+                single = feat.compute(hs, cands, hs, int(q))
+                raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), mask)
+                assert np.array_equal(multi["sum"][i], single["sum"]), (dtype, k, nq, i)
+                assert np.array_equal(multi["raw"][i], raw), (dtype, k, nq, i)
+                assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))
+    # one long sequence (70 kb: more k-mers than a 16-bit prefix of excess counts holds) switches the whole pass to 32-bit prefixes
+    seqs, _ = synth.families(977, 40, 1000, family=10)
+    long_seqs, _ = synth.families(978, 2, 70000, family=2)
+    seqs = list(seqs) + list(long_seqs)
+    hs = api.HistogramSet(ctx, 9, 32, len(seqs))
+    hs.build(seqs)
+    feat = api.Feature.from_text(ctx, open(os.path.join(golden, "weights_k9_u32.txt")).read(), 0)
+    qs = np.array([41, 0, 40, 7, 9, 11, 13, 15], dtype=np.uint32)
+    multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=len(seqs), feat_mask=FAST_MASK)
+    for i, q in enumerate(qs):
+        raw = api.pair_features_raw(ctx, hs, None, hs, int(q), FAST_MASK, m=len(seqs))
+        assert np.array_equal(multi["raw"][i], raw), ("long", i)
+    # HBM-resident stage: 6000 x 1 MiB histograms (past L2 and the memory-side cache), every wave runs hundreds of iterations
+    n, k, dtype = 6000, 9, 32
+    codes = [synth.member(5, t // 20, t % 20, synth.template(5, t // 20, 1000)) for t in range(2000)]
+    b = synth.pack_batch(codes)
+    hs = api.HistogramSet(ctx, k, dtype, n)
+    for done in range(0, n, 2000):
+        hs.build_packed(done, 2000, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
+    feat = api.Feature.from_text(ctx, open(os.path.join(golden, "weights_k9_u32.txt")).read(), 0)
+    qs = np.array([0, 21, 45, 77, 1999, 1033, 512, 5, 300, 1500, 20, 40, 60, 81, 101, 1234], dtype=np.uint32)
+    multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, want=("sum",))
+    for i, q in enumerate(qs):
+        single = feat.compute(hs, None, hs, int(q), m=n)
+        assert np.array_equal(multi["sum"][i], single["sum"]), ("big", i)
+    print("RING_VARIANT_OK")
+
+
+if __name__ == "__main__":
+    main()

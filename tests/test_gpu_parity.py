@@ -276,6 +276,24 @@ def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
         assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))
 
 
+@pytest.mark.parametrize("tq,slots,p16", [(4, 2, 1), (4, 3, 0), (4, 3, 1), (4, 4, 1), (8, 2, 0), (8, 3, 1), (8, 4, 0), (8, 4, 1)])
+def test_multi_ring_variants(tq, slots, p16):
+    """The LDS-DMA ring form of the Q x M kernel (query tile 4 or 8, 2-4 ring slots per wave, the deepest one past 64 KiB of
+    LDS per workgroup) == independent 1 x M passes, bit for bit, including padded query groups, reversed slot lists and
+    windows shorter than the ring is deep; with the packed 16-bit prefix form (p16) and the 32-bit one."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MSC_MULTI_TQ=str(tq), MSC_RING_SLOTS=str(slots))
+    env.pop("MSC_MULTI_NO_RING", None)
+    env.pop("MSC_RING_NO_P16", None)
+    if not p16:
+        env["MSC_RING_NO_P16"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(here, "ring_variant_check.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
+
+
 def test_cluster_driver_reproduces_reference_clstr(tmp_path):
     """the from-scratch mean-shift driver over the GPU path, fed the model the reference trained, writes
     the SAME .clstr bytes as the reference CLI did for cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16, 1 thread)."""
