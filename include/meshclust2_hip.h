@@ -109,6 +109,9 @@ int         msc_synchronize(msc_ctx* ctx);
 int         msc_last_kernel_ms(const msc_ctx* ctx, float* pair_tiles_ms, float* total_ms);
 /* Number of streaming-kernel launches that pair_tiles_ms sums over (large calls are chunked). */
 int         msc_last_kernel_launches(const msc_ctx* ctx);
+/* Which streaming kernel the LAST scoring call ran (its name is copied to buf) and how many queries one HBM read of a
+ * candidate tile served in it (1 for the 1 x M passes): the figure the algorithmic bytes of a Q x M launch divide by. */
+int         msc_last_kernel_info(const msc_ctx* ctx, char* buf, size_t cap, int* queries_per_candidate_read);
 
 /* ------------------------------------------------------------------ a1: sequence encoding (host byte work)
  * Replaces Chromosome::help / removeAmbiguous / mergeSegments / makeSegmentList + ChromosomeOneDigit::encode

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "msc_synchronize": (_int, [_vp]),
     "msc_last_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "msc_last_kernel_launches": (_int, [_vp]),
+    "msc_last_kernel_info": (_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_int)]),
     "msc_encode": (_int, [C.c_char_p, C.c_size_t, _pu8, _pi64, C.c_size_t, C.POINTER(C.c_size_t), _pu64]),
     "msc_hist_set_create": (_int, [_vp, _int, _int, _u64, C.POINTER(_vp)]),
     "msc_hist_set_create_sparse": (_int, [_vp, _int, _int, _u64, _u64, C.POINTER(_vp)]),

@@ -57,6 +57,13 @@ class Context:
     def last_kernel_launches(self):
         return self.lib.msc_last_kernel_launches(self.h)
 
+    def last_kernel_info(self):
+        """-> (name of the streaming kernel the last scoring call ran, queries served per HBM read of a candidate tile)"""
+        buf = C.create_string_buffer(128)
+        n = C.c_int()
+        self.check(self.lib.msc_last_kernel_info(self.h, buf, 128, C.byref(n)))
+        return buf.value.decode(), n.value
+
     def close(self):
         if getattr(self, "h", None):
             for ref in self._children:

@@ -32,6 +32,8 @@ struct msc_ctx {
 	uint32_t last_partial_stride = 0;        // partial records per candidate written by the last run_score
 	float tiles_ms_accum = 0.f;
 	int tiles_launches = 0;
+	const char* last_kernel = "";            // streaming kernel of the last scoring call
+	int last_query_tile = 1;                 // queries one HBM read of a candidate tile served in it
 	std::string err;
 	char dev_name[128] = {0};
 	// growable device scratch
@@ -54,6 +56,10 @@ struct msc_hist_set {
 	uint8_t* scalars = nullptr;
 	// host-side bounds over every slot ever written (monotone; used to pick the kernels' integer range)
 	uint64_t max_count = 0, max_sum = 0;
+	// digest mirror (pair_digest.hip), allocated on the first Q x M pass that can use it; slots [dg_lo, dg_hi) are stale
+	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
+	mutable uint64_t dg_lo = 0, dg_hi = 0;
+	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
 	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
 	bool sparse = false;
 	uint2* ent = nullptr;
@@ -183,6 +189,13 @@ extern "C" int msc_synchronize(msc_ctx* ctx) {
 }
 
 extern "C" int msc_last_kernel_launches(const msc_ctx* ctx) { return ctx && ctx->have_timing ? ctx->tiles_launches : 0; }
+
+extern "C" int msc_last_kernel_info(const msc_ctx* ctx, char* buf, size_t cap, int* queries_per_candidate_read) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	if (buf && cap) snprintf(buf, cap, "%s", ctx->last_kernel);
+	if (queries_per_candidate_read) *queries_per_candidate_read = ctx->last_query_tile;
+	return MSC_OK;
+}
 
 extern "C" int msc_last_kernel_ms(const msc_ctx* ctx, float* tiles_ms, float* total_ms) {
 	if (!ctx || !ctx->have_timing) return MSC_ERR_INVALID_ARG;
@@ -375,6 +388,7 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	(void)hipStreamSynchronize(s->ctx->stream);
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
+	if (s->digest) (void)hipFree(s->digest);
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
 	if (s->hdr) (void)hipFree(s->hdr);
@@ -387,11 +401,15 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes * (s->digest ? 2 : 1) + s->scalar_stride) * s->capacity;
 }
 
 // pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
 static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
+	if (s->digest && n) {         // every writer of slots ends here: the digest of these slots is stale now
+		if (s->dg_lo >= s->dg_hi) { s->dg_lo = first; s->dg_hi = first + n; }
+		else { s->dg_lo = std::min(s->dg_lo, first); s->dg_hi = std::max(s->dg_hi, first + n); }
+	}
 	std::vector<MscSlotScalars> h(n);
 	HIP_TRY(ctx, hipMemcpy2DAsync(h.data(), sizeof(MscSlotScalars), s->scalars + first * s->scalar_stride, s->scalar_stride,
 	                              sizeof(MscSlotScalars), n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1003,6 +1021,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	ctx->tiles_ms_accum = 0.f;
 	ctx->tiles_launches = 0;
 	ctx->have_timing = false;
+	ctx->last_kernel = cs->sparse ? "k_pair_sparse" : wide ? "k_pair_tiles_wide" : "k_pair_tiles";
+	ctx->last_query_tile = 1;
 	if (m == 0) {
 		if (rq.reduce_host) { rq.reduce_host->best_pos = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1 : 0; rq.reduce_host->best_sim = rq.reduce_mode == MSC_REDUCE_GET_CLOSE ? -1.0 : DBL_MIN;
 		                      rq.reduce_host->any_close = 0; rq.reduce_host->n_close = 0; rq.reduce_host->first_error = 0; }
@@ -1169,6 +1189,28 @@ extern "C" int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_se
 	return run_score(ctx, rq);
 }
 
+// The digest mirror of a dense 32-bit set (pair_digest.hip): allocated on first use, refreshed for the slots written since.
+// Returns MSC_OK with set->digest == nullptr when the mirror cannot be had (no memory): the caller then streams the raw bins.
+static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
+	if (set->sparse || set->dtype != 32 || set->L.LPT != 4 || set->digest_unavailable) return MSC_OK;
+	if (!set->digest) {
+		void* p = nullptr;
+		if (hipMalloc(&p, set->L.slot_bytes * set->capacity) != hipSuccess) {
+			(void)hipGetLastError();
+			set->digest_unavailable = true;
+			return MSC_OK;
+		}
+		set->digest = (uint8_t*)p;
+		set->dg_lo = 0;
+		set->dg_hi = set->capacity;
+	}
+	if (set->dg_lo < set->dg_hi) {
+		HIP_TRY(ctx, msc_launch_digest_build(ctx->stream, set->L, set->bins, set->scalars, set->digest, set->dg_lo, set->dg_hi - set->dg_lo));
+		set->dg_lo = set->dg_hi = 0;
+	}
+	return MSC_OK;
+}
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
@@ -1201,14 +1243,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	ctx->tiles_ms_accum = 0.f;
 	ctx->tiles_launches = 0;
 	ctx->have_timing = false;
-	uint64_t chunk = (4096ull << 20) / ((uint64_t)L.S * sizeof(MscPartial) * n_q);      // partial records <= 4 GiB per launch
-	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
-	if ((r = ensure(ctx, ctx->partials, n_q * chunk * L.S * sizeof(MscPartial)))) return r;
-	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
-	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
-	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
 	if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
-	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
 	if ((r = ensure(ctx, ctx->qslots, n_q * sizeof(uint32_t)))) return r;
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
@@ -1216,22 +1251,43 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
-	int tq = n_q >= 4 ? 4 : 2;                     // TQ = 4 keeps the 32-bit kernel HBM-bound; MSC_MULTI_TQ=8 trades that for ~25 % more pairs/s
+	int tq = n_q >= 4 ? 4 : 2;                     // TQ = 4 keeps the 32-bit register kernel HBM-bound
 	if (const char* e = getenv("MSC_MULTI_TQ")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) tq = v; }
 	if (tq > (int)n_q && n_q >= 2) tq = n_q >= 4 ? 4 : 2;
 	// wave totals of the per-lane 32-bit partial sums fit 32 bits when 64*R*max^2 and 64*R*max|prefix difference| do
 	const uint64_t mc_ = std::max(cands->max_count, qset->max_count), ms_ = std::max(cands->max_sum, qset->max_sum);
 	const bool compact = 64ull * L.R * mc_ * mc_ < (1ull << 32) && 64ull * L.R * ms_ < (1ull << 32);
-	// LDS-DMA ring form: 32/64-bit bins, compact totals, query groups of four; records are 16 bytes and cover the padded query count
-	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
-	const bool ring = !no_ring && compact && L.LPT == 4 && (cands->dtype == 32 || cands->dtype == 64) && (tq == 4 || tq == 8) && n_q >= 4;
 	// every prefix of excess counts (count - 1) is at most the histogram's k-mer total = sum - 4^k: 16-bit prefix form when that fits
-	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
-	const bool prefix16 = ring && !no_p16 && ms_ >= L.nbins && ms_ - L.nbins < 65536;
-	if (ring) {
-		const uint64_t nq_pad = (n_q + tq - 1) / tq * tq;
-		if ((r = ensure(ctx, ctx->partials, nq_pad * chunk * L.S * 16))) return r;
+	const bool excess16 = ms_ >= L.nbins && ms_ - L.nbins < 65536;
+	// Digest form (pair_digest.hip): 32-bit sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen
+	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
+	static const bool no_digest = getenv("MSC_MULTI_NO_DIGEST") != nullptr;
+	bool digest = !no_digest && compact && excess16 && cands->dtype == 32 && L.LPT == 4 && mc_ < 65536 && n_q >= 4 && !getenv("MSC_MULTI_TQ");
+	if (digest) {
+		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
+		digest = cands->digest && qset->digest;
 	}
+	// LDS-DMA ring form over the raw bins: 32/64-bit bins, compact totals, query groups of four or eight
+	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
+	if (!digest && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
+	const bool ring = !digest && !no_ring && compact && L.LPT == 4 && (cands->dtype == 32 || cands->dtype == 64) && (tq == 4 || tq == 8) && n_q >= 4;
+	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
+	const bool prefix16 = ring && !no_p16 && excess16;
+	// partial records of one launch are capped at 4 GiB: equal candidate chunks
+	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
+	const uint64_t q_rows = digest ? (n_q + 3) / 4 * 4 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
+	uint64_t chunk = (4096ull << 20) / ((uint64_t)L.S * rec_bytes * q_rows);
+	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
+	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
+	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * L.S * rec_bytes))) return r;
+	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
+	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
+	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
+	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
+	ctx->last_kernel = digest ? (mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>") : ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
+	// the digest kernel's workgroup scores up to 16 queries per candidate tile it fetches; the ring kernel's co-located query
+	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
+	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 16) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
 	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
@@ -1240,7 +1296,10 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (ring)
+		if (digest)
+			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * L.slot_bytes), d_slots, mc, qset->digest, qset->L.slot_bytes,
+			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, ctx->partials.p, ctx->num_cus));
+		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
 		else
@@ -1250,7 +1309,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
-		ea.partials16 = ring ? ctx->partials.p : nullptr;
+		ea.partials16 = digest || ring ? ctx->partials.p : nullptr;
 		ea.S = L.S;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;

@@ -1,0 +1,247 @@
+// pair_digest.hip -- the "digest" mirror of a 32-bit histogram set and the Q x M kernel that streams it (gfx950).
+//
+// Same arithmetic as k_pair_tiles_multi32_ring (pair_features.hip): per (candidate, tile, query) three integer reductions
+//     manh = sum |p-q|      dot = sum p*q      emd = sum |prefix(p) - prefix(q)|
+// from which the epilogue derives every statistic of predict/Feature.cpp that is in scope (see pair_features.hip).
+// Different data: the ring kernel spends 2/3 of its VALU issue slots turning each raw 32-bit tile into the form the
+// reductions want (run sums, a wave scan, 16 dependent prefix adds, re-packing two bins per word) -- once per candidate
+// tile PER QUERY GROUP -- and measured 69 % VALU-busy at 2.6 TB/s of HBM traffic: VALU-bound, not memory-bound. The
+// digest stores that form in HBM instead, built once per histogram (k_digest_build, one pass) and reused by every pass
+// of the all-pairs matrix. It is a lossless re-encoding with the SAME 4 bytes per bin:
+//
+//   digest tile = 1024 bins = 64 lanes x 16 words (4 KiB), word w of lane l at byte (w/4)*1024 + l*16 + (w%4)*4
+//     words 0..7  : the lane's 16 consecutive bins, two per word        (bin 2i | bin 2i+1 << 16)
+//     words 8..15 : inclusive prefix of the EXCESS counts (count - 1) over the whole histogram up to and including
+//                   bin 2i | bin 2i+1 << 16. Both histograms carry the same pseudocount baseline (bin index + 1), so
+//                   prefix differences are unchanged; an excess prefix is at most the sequence's k-mer count.
+//   valid while every count and every excess prefix fits 16 bits (host-checked per set; otherwise the raw kernels run).
+//
+// k_pair_digest_multi: one workgroup = one tile index s, one candidate group g, SIXTEEN queries (4 waves x TQ = 4 query
+// digests held in registers for the whole launch). The four waves share ONE copy of each candidate tile: every wave
+// moves a quarter of it (1 KiB) by LDS-DMA into a ring of NB slots, NB-1 tiles ahead; one s_barrier per iteration
+// publishes the tile to all four. So a candidate byte is fetched from HBM once per 16 queries, the loop body is
+// 4 ds_read_b128 + 16 (8-bit counts) or 24 (16-bit counts) VALU ops per query + one transposed wave reduction per
+// four queries, and nothing else.
+#include "msc_internal.h"
+#include "msc_wave.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kTileBytes = 4096;
+constexpr uint32_t kPieceBytes = kTileBytes / kWaves;
+
+// ---------------------------------------------------------------------------------------- digest build
+__global__ void __launch_bounds__(kBlock) k_digest_build(const uint8_t* __restrict__ bins, uint64_t slot_bytes, const uint8_t* __restrict__ scalars,
+                                                         uint64_t scalar_stride, uint8_t* __restrict__ digest, uint64_t first_slot, uint64_t n_slots,
+                                                         uint32_t S) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t W = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+	if (W >= n_slots * S) return;
+	const uint64_t slot = first_slot + W / S;
+	const uint32_t s = (uint32_t)(W % S);
+	const u32x4* src = reinterpret_cast<const u32x4*>(bins + slot * slot_bytes + (uint64_t)s * kTileBytes) + lane;
+	u32x4 v[4];
+#pragma unroll
+	for (int l = 0; l < 4; l++) v[l] = __builtin_nontemporal_load(src + 64 * l);
+	const uint32_t* w = reinterpret_cast<const uint32_t*>(v);      // the lane's 16 logically consecutive bins (msc_layout.h)
+	uint32_t t = 0;
+#pragma unroll
+	for (int r = 0; r < 16; r++) t += w[r];
+	const uint64_t* prefix = reinterpret_cast<const uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
+	uint32_t run = (uint32_t)prefix[s] + wave_incl_scan(t) - t;     // sum of every bin before this lane's run
+	run -= s * 1024u + lane * 16u;                                   // minus the pseudocount baseline -> excess
+	uint32_t ev[16];
+#pragma unroll
+	for (int r = 0; r < 16; r++) { run += w[r] - 1u; ev[r] = run; }
+	u32x4 o[4];
+	uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+#pragma unroll
+	for (int r = 0; r < 8; r++) ow[r] = (w[2 * r] & 0xffffu) | (w[2 * r + 1] << 16);
+#pragma unroll
+	for (int r = 0; r < 8; r++) ow[8 + r] = (ev[2 * r] & 0xffffu) | (ev[2 * r + 1] << 16);
+	u32x4* dst = reinterpret_cast<u32x4*>(digest + slot * slot_bytes + (uint64_t)s * kTileBytes) + lane;
+#pragma unroll
+	for (int l = 0; l < 4; l++) dst[64 * l] = o[l];
+}
+
+// ---------------------------------------------------------------------------------------- Q x M kernel
+// one wave's quarter of a tile: 64 lanes x 16 bytes from global memory straight into LDS (no destination VGPRs)
+__device__ __forceinline__ void dma_piece(const uint8_t* lane_src, uint32_t lds_dst) {
+	uint32_t keep;      // m0 is the compiler's: saved and restored
+	asm volatile(
+	    "s_mov_b32 %0, m0\n\t"
+	    "s_mov_b32 m0, %2\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dwordx4 %1, off\n\t"
+	    "s_mov_b32 m0, %0"
+	    : "=&s"(keep)
+	    : "v"(lane_src), "s"(lds_dst)
+	    : "memory");
+}
+
+// bytes 0 and 2 of `lo` and of `hi`: four 16-bit counts (< 256) -> four bytes
+__device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
+
+template <int NB, bool U8>
+__global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
+    const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
+    const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t S, uint32_t G,
+    uint32_t nqg, u32x4* __restrict__ partials16) {
+	static_assert(NB >= 2 && NB <= 8, "ring depth");
+	constexpr int TQ = 4;
+	constexpr int D = NB - 1;                 // tiles in flight ahead of the one being scored
+	constexpr int NC = U8 ? 4 : 8;            // count words per lane
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_ring[];      // [NB][4096], shared by the four waves
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// blocks b and b + 8 share an XCD (round-robin dispatch): the query groups that stream the same candidate tiles are
+	// placed 8 apart so the second one finds the tile in that XCD's L2. Speed only; any placement is correct.
+	const uint32_t lo = blockIdx.x & 7, hi = blockIdx.x >> 3;
+	const uint32_t qg = hi % nqg;
+	const uint32_t rest = (hi / nqg) * 8 + lo;
+	const uint32_t s = rest % S, g = rest / S;
+	if (g >= G) return;                       // whole workgroup
+	const uint32_t q0 = (qg * kWaves + wib) * TQ;
+	const bool active = q0 < n_q;             // a wave without queries still moves its quarter of every tile
+
+	uint32_t qc[TQ][NC], qp[TQ][8];
+#pragma unroll
+	for (int j = 0; j < TQ; j++) {
+		const uint32_t qi = q0 + j < n_q ? q0 + j : n_q - 1;      // padded queries score a valid slot; their records are ignored
+		const u32x4* p = reinterpret_cast<const u32x4*>(q_dg + (uint64_t)q_slots[qi] * q_slot_bytes + (uint64_t)s * kTileBytes) + lane;
+		const u32x4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
+		if constexpr (U8) {
+			qc[j][0] = pack_u8(v0.x, v0.y); qc[j][1] = pack_u8(v0.z, v0.w); qc[j][2] = pack_u8(v1.x, v1.y); qc[j][3] = pack_u8(v1.z, v1.w);
+		} else {
+			qc[j][0] = v0.x; qc[j][1] = v0.y; qc[j][2] = v0.z; qc[j][3] = v0.w; qc[j][4] = v1.x; qc[j][5] = v1.y; qc[j][6] = v1.z; qc[j][7] = v1.w;
+		}
+		qp[j][0] = v2.x; qp[j][1] = v2.y; qp[j][2] = v2.z; qp[j][3] = v2.w; qp[j][4] = v3.x; qp[j][5] = v3.y; qp[j][6] = v3.z; qp[j][7] = v3.w;
+	}
+	// The compiler must see the query loads complete HERE: a wait of its own inside the loop (its scoreboard knows nothing
+	// of the DMA pieces issued from inline asm) would drain the whole ring every iteration.
+#pragma unroll
+	for (int j = 0; j < TQ; j++) {
+#pragma unroll
+		for (int i = 0; i < NC; i++) asm volatile("" : "+v"(qc[j][i]));
+#pragma unroll
+		for (int i = 0; i < 8; i++) asm volatile("" : "+v"(qp[j][i]));
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below start from an empty queue
+
+	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring) + wib * kPieceBytes;
+	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
+	const uint64_t src_off = (uint64_t)s * kTileBytes + wib * kPieceBytes + lane * 16u;
+	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
+		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;      // past the end: re-fetch the last tile (keeps the count fixed)
+		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
+		dma_piece(cand_dg + (uint64_t)slot * slot_bytes + src_off, ring_lds + slot_idx * kTileBytes);
+	};
+#pragma unroll
+	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
+
+	// the four lanes holding row totals after wave_sum4_rows: lane 15 -> query 0, 31 -> 2, 47 -> 1, 63 -> 3
+	const uint32_t row = lane >> 4;
+	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
+	const bool owner = (lane & 15) == 15;
+	u32x4* out_ptr = partials16 + ((uint64_t)(q0 + jrow) * m + g) * S + s;
+	const uint64_t out_step = (uint64_t)G * S;
+
+	uint32_t rd = 0, wr = D % NB;
+	for (uint32_t it = 0; it < n_iter; it++) {
+		// Vector-memory operations retire in issue order. Younger than this wave's piece of tile `it`: the pieces of tiles
+		// it+1 .. it+D-1 and, for a scoring wave past ramp-up, D record stores (2D-1 in all); fewer stores during ramp-up.
+		if (active && it >= (uint32_t)D) wait_vm<2 * D - 1>(); else wait_vm<D - 1>();
+		// all four quarters of tile `it` have landed, and every wave has consumed tile it-1 (its slot is refilled next)
+		__builtin_amdgcn_s_barrier();
+		fetch(it + D, wr);
+		wr = wr + 1 == NB ? 0 : wr + 1;
+		if (active) {
+			const u32x4* sl = reinterpret_cast<const u32x4*>(s_ring + rd * kTileBytes) + lane;
+			const u32x4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+			uint32_t cc[NC];
+			if constexpr (U8) {
+				cc[0] = pack_u8(v0.x, v0.y); cc[1] = pack_u8(v0.z, v0.w); cc[2] = pack_u8(v1.x, v1.y); cc[3] = pack_u8(v1.z, v1.w);
+			} else {
+				cc[0] = v0.x; cc[1] = v0.y; cc[2] = v0.z; cc[3] = v0.w; cc[4] = v1.x; cc[5] = v1.y; cc[6] = v1.z; cc[7] = v1.w;
+			}
+			const uint32_t cp[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+			uint32_t manh[TQ], dot[TQ], emd[TQ];
+#pragma unroll
+			for (int j = 0; j < TQ; j++) {
+				manh[j] = 0; dot[j] = 0; emd[j] = 0;
+#pragma unroll
+				for (int i = 0; i < NC; i++) {
+					if constexpr (U8) {
+						manh[j] = __builtin_amdgcn_sad_u8(cc[i], qc[j][i], manh[j]);
+						dot[j] = __builtin_amdgcn_udot4(cc[i], qc[j][i], dot[j], false);
+					} else {
+						manh[j] = __builtin_amdgcn_sad_u16(cc[i], qc[j][i], manh[j]);
+						dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][i]), dot[j], false);
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][i], emd[j]);
+			}
+			u32x4 rec;
+			rec.x = wave_sum4_rows(manh[0], manh[1], manh[2], manh[3]);
+			rec.y = wave_sum4_rows(dot[0], dot[1], dot[2], dot[3]);
+			rec.z = wave_sum4_rows(emd[0], emd[1], emd[2], emd[3]);
+			rec.w = 0;
+			// s_nop: a store of more than 8 bytes reads its data registers after issue; the hazard recognizer does not look
+			// inside an asm statement and may overwrite `rec` in the very next instruction
+			if (owner) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out_ptr), "v"(rec) : "memory");
+			out_ptr += out_step;
+		}
+		rd = rd + 1 == NB ? 0 : rd + 1;
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
+}
+
+template <int NB, bool U8>
+hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_dg, uint64_t slot_bytes, const uint32_t* cand_slots, uint32_t m,
+                               const uint8_t* q_dg, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, void* partials16, int num_cus) {
+	const size_t lds = (size_t)NB * kTileBytes;
+	const void* fn = (const void*)k_pair_digest_multi<NB, U8>;
+	int blocks_per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
+	const uint32_t nqg = (n_q + 4 * kWaves - 1) / (4 * kWaves);
+	// one resident round of equal-length workgroups
+	uint64_t G = (uint64_t)num_cus * blocks_per_cu / ((uint64_t)S * nqg);
+	if (G < 1) G = 1;
+	if (G > m) G = m;
+	const uint64_t rest_pad = ((uint64_t)S * G + 7) / 8 * 8;
+	const unsigned blocks = (unsigned)(rest_pad * nqg);
+	k_pair_digest_multi<NB, U8><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, S, (uint32_t)G, nqg,
+	                                                                       (u32x4*)partials16);
+	return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uint8_t* bins, const uint8_t* scalars, uint8_t* digest, uint64_t first_slot,
+                                   uint64_t n_slots) {
+	if (n_slots == 0) return hipSuccess;
+	if (L.LPT != 4 || L.esz != 4) return hipErrorInvalidValue;
+	const uint64_t waves = n_slots * L.S;
+	const unsigned blocks = (unsigned)((waves + kWaves - 1) / kWaves);
+	k_digest_build<<<dim3(blocks), dim3(kBlock), 0, st>>>(bins, L.slot_bytes, scalars, msc_scalar_stride(L.S), digest, first_slot, n_slots, L.S);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
+                                        const uint8_t* q_digest, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
+                                        void* partials16, int num_cus) {
+	if (m == 0 || n_q == 0) return hipSuccess;
+	if (L.LPT != 4 || L.esz != 4) return hipErrorInvalidValue;
+	static const int nb_env = [] { const char* e = getenv("MSC_DIGEST_SLOTS"); return e ? atoi(e) : 0; }();
+#define MSC_DG_ARGS st, L.S, cand_digest, L.slot_bytes, cand_slots, m, q_digest, q_slot_bytes, q_slots, n_q, partials16, num_cus
+#define MSC_DG(U8)                                                                                              \
+	(nb_env == 2 ? launch_digest_multi<2, U8>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8>(MSC_DG_ARGS) \
+	 : nb_env == 6 ? launch_digest_multi<6, U8>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8>(MSC_DG_ARGS) \
+	                                                                      : launch_digest_multi<4, U8>(MSC_DG_ARGS))
+	return counts_fit_u8 ? MSC_DG(true) : MSC_DG(false);
+#undef MSC_DG
+#undef MSC_DG_ARGS
+}

@@ -45,6 +45,25 @@ def main():
     for i, q in enumerate(qs):
         raw = api.pair_features_raw(ctx, hs, None, hs, int(q), FAST_MASK, m=len(seqs))
         assert np.array_equal(multi["raw"][i], raw), ("long", i)
+    # counts above 255 (a 400-base homopolymer run) switch the digest kernel to its 16-bit count form; 20 queries = two query
+    # groups of 16, the second one partly padded; then slots are overwritten and the next pass must see the new contents
+    seqs, _ = synth.families(981, 60, 1000, family=10)
+    seqs = list(seqs)
+    seqs[7] = seqs[7][:300] + (b"A" if isinstance(seqs[7], bytes) else "A") * 400 + seqs[7][300:]
+    hs = api.HistogramSet(ctx, 9, 32, len(seqs))
+    hs.build(seqs)
+    assert hs.download(7).max() >= 256
+    qs = (np.arange(20, dtype=np.uint32) * 7) % len(seqs)
+    for rnd in range(2):
+        multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=len(seqs), feat_mask=FAST_MASK)
+        for i, q in enumerate(qs):
+            raw = api.pair_features_raw(ctx, hs, None, hs, int(q), FAST_MASK, m=len(seqs))
+            single = feat.compute(hs, None, hs, int(q), m=len(seqs))
+            assert np.array_equal(multi["raw"][i], raw), ("wide counts", rnd, i)
+            assert np.array_equal(multi["sum"][i], single["sum"]), ("wide counts", rnd, i)
+        # overwrite a candidate slot and a query slot (any cached re-encoding of them is stale now)
+        hs.build(seqs[20:22], first_slot=3)
+        hs.assign_from(int(qs[1]), hs, 30)
     # HBM-resident stage: 6000 x 1 MiB histograms (past L2 and the memory-side cache), every wave runs hundreds of iterations
     n, k, dtype = 6000, 9, 32
     codes = [synth.member(5, t // 20, t % 20, synth.template(5, t // 20, 1000)) for t in range(2000)]

@@ -294,6 +294,22 @@ def test_multi_ring_variants(tq, slots, p16):
     assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
 
 
+@pytest.mark.parametrize("slots", [2, 3, 4, 6, 8])
+def test_multi_digest_variants(slots):
+    """The digest form of the Q x M kernel (pair_digest.hip: 16 queries per workgroup, one LDS copy of each candidate tile
+    shared by four waves, ring of 2-8 slots) == independent 1 x M passes, bit for bit: 8- and 16-bit count forms, padded
+    query groups, slot lists, windows shorter than the ring, stale-digest refresh after slots are overwritten."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MSC_DIGEST_SLOTS=str(slots))
+    for k in ("MSC_MULTI_TQ", "MSC_MULTI_NO_DIGEST", "MSC_MULTI_NO_RING", "MSC_RING_NO_P16", "MSC_RING_SLOTS"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(here, "ring_variant_check.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
+
+
 def test_cluster_driver_reproduces_reference_clstr(tmp_path):
     """the from-scratch mean-shift driver over the GPU path, fed the model the reference trained, writes
     the SAME .clstr bytes as the reference CLI did for cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16, 1 thread)."""
