@@ -1275,7 +1275,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const bool prefix16 = ring && !no_p16 && excess16;
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
 	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
-	const uint64_t q_rows = digest ? (n_q + 3) / 4 * 4 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
+	const uint64_t q_rows = digest ? (n_q + 15) / 16 * 16 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)L.S * rec_bytes * q_rows);
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
@@ -1309,7 +1309,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
-		ea.partials16 = digest || ring ? ctx->partials.p : nullptr;
+		ea.partials16 = ring ? ctx->partials.p : nullptr;
+		ea.partials_cq = digest ? ctx->partials.p : nullptr;
 		ea.S = L.S;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;

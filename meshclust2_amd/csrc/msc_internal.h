@@ -63,6 +63,7 @@ enum { MSC_REDUCE_GET_CLOSE = 0, MSC_REDUCE_MERGE = 1 };
 struct MscEpilogueArgs {
 	const MscPartial* partials;       // [m][S]
 	const void* partials16;           // or: [m][S] records of four u32 {manh, dot, emd, 0} (ring kernel); partials is then unused
+	const void* partials_cq;          // or: [m_per_query][ceil(n_queries/16)][S][16] such records (digest kernel: one 256-byte run per workgroup step)
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
 	uint32_t m;

@@ -145,8 +145,9 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 	const uint32_t row = lane >> 4;
 	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
 	const bool owner = (lane & 15) == 15;
-	u32x4* out_ptr = partials16 + ((uint64_t)(q0 + jrow) * m + g) * S + s;
-	const uint64_t out_step = (uint64_t)G * S;
+	// records: [candidate][query group][tile][query in group] -- the four waves of a workgroup write one 256-byte run per step
+	u32x4* out_ptr = partials16 + (((uint64_t)g * nqg + qg) * S + s) * 16 + wib * TQ + jrow;
+	const uint64_t out_step = (uint64_t)G * nqg * S * 16;
 
 	uint32_t rd = 0, wr = D % NB;
 	for (uint32_t it = 0; it < n_iter; it++) {

@@ -964,6 +964,30 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogue
 	if (lane == 0) epilogue_one(a, c, t);
 }
 
+// Records laid out [candidate][query group of 16][tile][query in group] (k_pair_digest_multi): one wave per (candidate,
+// query group); a wave load covers four tiles x sixteen queries = 1 KiB contiguous, lane l always sees query l % 16.
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueArgs a) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+	const uint32_t nqg = (a.n_queries + 15) / 16;
+	if (w >= a.m_per_query * nqg) return;
+	const uint32_t ci = w / nqg, qg = w % nqg;
+	const u32x4* rec = reinterpret_cast<const u32x4*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 16;
+	PairTotals t{0, 0, 0, 0.0, 0.0};
+	for (uint32_t i = lane; i < a.S * 16; i += 64) {
+		const u32x4 p = rec[i];
+		t.manh += p.x; t.dot += p.y; t.emd += p.z;
+	}
+#pragma unroll
+	for (int off = 16; off <= 32; off <<= 1) {
+		t.manh += __shfl_xor(t.manh, off, 64);
+		t.dot += __shfl_xor(t.dot, off, 64);
+		t.emd += __shfl_xor(t.emd, off, 64);
+	}
+	const uint32_t q = qg * 16 + lane;
+	if (lane < 16 && q < a.n_queries) epilogue_one(a, q * a.m_per_query + ci, t);
+}
+
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= a.m) return;
@@ -1350,7 +1374,10 @@ hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, 
 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.m == 0) return hipSuccess;
-	if (a.S > 4) {
+	if (a.partials_cq) {
+		const unsigned waves = a.m_per_query * ((a.n_queries + 15) / 16);
+		hipLaunchKernelGGL(k_pair_epilogue_cq, dim3((waves + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, a);
+	} else if (a.S > 4) {
 		const unsigned blocks = (a.m + kWavesPerBlock - 1) / kWavesPerBlock;
 		hipLaunchKernelGGL(k_pair_epilogue_wave, dim3(blocks), dim3(kBlock), 0, st, a);
 	} else {

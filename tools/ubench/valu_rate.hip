@@ -26,6 +26,21 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
 			if (OP == 11) asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
 			if (OP == 12) asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
 			if (OP == 13) asm volatile("v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 15) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(b));
+			if (OP == 16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(b));
+			if (OP == 17) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(x), "v"(c));
+			if (OP == 18) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b));
+			if (OP == 19) asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 20) asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(x) : "v"(x));
+			if (OP == 21) asm volatile("v_sub_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 22) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(x));
+			if (OP == 23) asm volatile("v_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 24) asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 25) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 26) asm volatile("v_min_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(b));
+			if (OP == 27) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(b));
+			if (OP == 28) asm volatile("v_add_u32 %0, %1, %2" : "=v"(x) : "v"(b), "v"(c));
+			if (OP == 29) asm volatile("v_sad_u8 %0, %1, %2, %3" : "=v"(x) : "v"(b), "v"(c), "v"(b));
 			if (OP == 14) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(x) : "v"(b), "v"(x));
 		}
 	}
@@ -47,5 +62,8 @@ int main() {
 	run<0>("v_add_u32", d); run<1>("v_sad_u32", d); run<2>("v_sad_u16", d); run<3>("v_sad_u8", d); run<4>("v_dot2_u32_u16", d);
 	run<5>("v_dot4_u32_u8", d); run<6>("v_mad_u32_u24", d); run<7>("v_add3_u32", d); run<8>("v_max_u32", d); run<9>("v_lshl_or_b32", d);
 	run<10>("v_pk_add_u16", d); run<11>("v_pk_max_u16", d); run<12>("v_pk_mad_u16", d); run<13>("v_add_u32_dpp", d); run<14>("v_add_u32_sdwa", d);
+	run<15>("v_permlane32_swap", d); run<16>("v_permlane16_swap", d); run<17>("v_perm_b32", d); run<18>("v_mov_b32_dpp", d); run<19>("v_and_b32", d);
+	run<20>("v_lshlrev_b32", d); run<21>("v_sub_u32", d); run<22>("v_fma_f32", d); run<23>("v_add_f32", d); run<24>("v_mul_u32_u24", d);
+	run<25>("v_xor_b32", d); run<26>("v_min_u32", d); run<27>("v_mov_b32", d); run<28>("v_add_u32 (no dep)", d); run<29>("v_sad_u8 (no dep)", d);
 	return 0;
 }
