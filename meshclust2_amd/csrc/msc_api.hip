@@ -1274,12 +1274,14 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
 	const bool prefix16 = ring && !no_p16 && excess16;
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
+	const int tps = digest ? msc_digest_tiles_per_step(L, mc_) : 1;          // the digest kernel writes one record per step of tps tiles
+	const uint32_t n_rec = L.S / tps;
 	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
 	const uint64_t q_rows = digest ? (n_q + 15) / 16 * 16 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
-	uint64_t chunk = (4096ull << 20) / ((uint64_t)L.S * rec_bytes * q_rows);
+	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
-	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * L.S * rec_bytes))) return r;
+	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * n_rec * rec_bytes))) return r;
 	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
@@ -1298,7 +1300,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * L.slot_bytes), d_slots, mc, qset->digest, qset->L.slot_bytes,
-			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, ctx->partials.p, ctx->num_cus));
+			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, ctx->partials.p, ctx->num_cus));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
@@ -1311,7 +1313,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.partials = (const MscPartial*)ctx->partials.p;
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
-		ea.S = L.S;
+		ea.S = n_rec;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;
 		ea.cand_scalar_stride = cands->scalar_stride;

@@ -84,16 +84,17 @@ __device__ __forceinline__ void dma_piece(const uint8_t* lane_src, uint32_t lds_
 // bytes 0 and 2 of `lo` and of `hi`: four 16-bit counts (< 256) -> four bytes
 __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
-template <int NB, bool U8>
+template <int NB, bool U8, int TPI>
 __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
-    const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t S, uint32_t G,
+    const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
     uint32_t nqg, u32x4* __restrict__ partials16) {
-	static_assert(NB >= 2 && NB <= 8, "ring depth");
+	static_assert(NB >= 2 && NB <= 8 && (TPI == 1 || TPI == 2), "ring depth, tiles per step");
 	constexpr int TQ = 4;
-	constexpr int D = NB - 1;                 // tiles in flight ahead of the one being scored
-	constexpr int NC = U8 ? 4 : 8;            // count words per lane
-	extern __shared__ __attribute__((aligned(16))) uint8_t s_ring[];      // [NB][4096], shared by the four waves
+	constexpr int D = NB - 1;                 // steps in flight ahead of the one being scored
+	constexpr int NC = U8 ? 4 : 8;            // count words per lane per tile
+	constexpr uint32_t kStepBytes = TPI * kTileBytes;      // a step = TPI consecutive tiles of one candidate (ST = S / TPI steps per histogram)
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_ring[];      // [NB][kStepBytes], shared by the four waves
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	// blocks b and b + 8 share an XCD (round-robin dispatch): the query groups that stream the same candidate tiles are
@@ -101,42 +102,52 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 	const uint32_t lo = blockIdx.x & 7, hi = blockIdx.x >> 3;
 	const uint32_t qg = hi % nqg;
 	const uint32_t rest = (hi / nqg) * 8 + lo;
-	const uint32_t s = rest % S, g = rest / S;
+	const uint32_t s = rest % ST, g = rest / ST;
 	if (g >= G) return;                       // whole workgroup
 	const uint32_t q0 = (qg * kWaves + wib) * TQ;
 	const bool active = q0 < n_q;             // a wave without queries still moves its quarter of every tile
 
-	uint32_t qc[TQ][NC], qp[TQ][8];
+	uint32_t qc[TQ][TPI][NC], qp[TQ][TPI][8];
 #pragma unroll
 	for (int j = 0; j < TQ; j++) {
 		const uint32_t qi = q0 + j < n_q ? q0 + j : n_q - 1;      // padded queries score a valid slot; their records are ignored
-		const u32x4* p = reinterpret_cast<const u32x4*>(q_dg + (uint64_t)q_slots[qi] * q_slot_bytes + (uint64_t)s * kTileBytes) + lane;
-		const u32x4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
-		if constexpr (U8) {
-			qc[j][0] = pack_u8(v0.x, v0.y); qc[j][1] = pack_u8(v0.z, v0.w); qc[j][2] = pack_u8(v1.x, v1.y); qc[j][3] = pack_u8(v1.z, v1.w);
-		} else {
-			qc[j][0] = v0.x; qc[j][1] = v0.y; qc[j][2] = v0.z; qc[j][3] = v0.w; qc[j][4] = v1.x; qc[j][5] = v1.y; qc[j][6] = v1.z; qc[j][7] = v1.w;
+#pragma unroll
+		for (int u = 0; u < TPI; u++) {
+			const u32x4* p = reinterpret_cast<const u32x4*>(q_dg + (uint64_t)q_slots[qi] * q_slot_bytes + (uint64_t)s * kStepBytes + u * kTileBytes) + lane;
+			const u32x4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
+			if constexpr (U8) {
+				qc[j][u][0] = pack_u8(v0.x, v0.y); qc[j][u][1] = pack_u8(v0.z, v0.w); qc[j][u][2] = pack_u8(v1.x, v1.y); qc[j][u][3] = pack_u8(v1.z, v1.w);
+			} else {
+				qc[j][u][0] = v0.x; qc[j][u][1] = v0.y; qc[j][u][2] = v0.z; qc[j][u][3] = v0.w;
+				qc[j][u][4] = v1.x; qc[j][u][5] = v1.y; qc[j][u][6] = v1.z; qc[j][u][7] = v1.w;
+			}
+			qp[j][u][0] = v2.x; qp[j][u][1] = v2.y; qp[j][u][2] = v2.z; qp[j][u][3] = v2.w;
+			qp[j][u][4] = v3.x; qp[j][u][5] = v3.y; qp[j][u][6] = v3.z; qp[j][u][7] = v3.w;
 		}
-		qp[j][0] = v2.x; qp[j][1] = v2.y; qp[j][2] = v2.z; qp[j][3] = v2.w; qp[j][4] = v3.x; qp[j][5] = v3.y; qp[j][6] = v3.z; qp[j][7] = v3.w;
 	}
 	// The compiler must see the query loads complete HERE: a wait of its own inside the loop (its scoreboard knows nothing
 	// of the DMA pieces issued from inline asm) would drain the whole ring every iteration.
 #pragma unroll
 	for (int j = 0; j < TQ; j++) {
 #pragma unroll
-		for (int i = 0; i < NC; i++) asm volatile("" : "+v"(qc[j][i]));
+		for (int u = 0; u < TPI; u++) {
 #pragma unroll
-		for (int i = 0; i < 8; i++) asm volatile("" : "+v"(qp[j][i]));
+			for (int i = 0; i < NC; i++) asm volatile("" : "+v"(qc[j][u][i]));
+#pragma unroll
+			for (int i = 0; i < 8; i++) asm volatile("" : "+v"(qp[j][u][i]));
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below start from an empty queue
 
 	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring) + wib * kPieceBytes;
 	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
-	const uint64_t src_off = (uint64_t)s * kTileBytes + wib * kPieceBytes + lane * 16u;
+	const uint64_t src_off = (uint64_t)s * kStepBytes + wib * kPieceBytes + lane * 16u;
 	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
-		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;      // past the end: re-fetch the last tile (keeps the count fixed)
+		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;      // past the end: re-fetch the last step (keeps the count fixed)
 		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
-		dma_piece(cand_dg + (uint64_t)slot * slot_bytes + src_off, ring_lds + slot_idx * kTileBytes);
+#pragma unroll
+		for (int u = 0; u < TPI; u++)
+			dma_piece(cand_dg + (uint64_t)slot * slot_bytes + src_off + u * kTileBytes, ring_lds + slot_idx * kStepBytes + u * kTileBytes);
 	};
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
@@ -145,45 +156,49 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 	const uint32_t row = lane >> 4;
 	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
 	const bool owner = (lane & 15) == 15;
-	// records: [candidate][query group][tile][query in group] -- the four waves of a workgroup write one 256-byte run per step
-	u32x4* out_ptr = partials16 + (((uint64_t)g * nqg + qg) * S + s) * 16 + wib * TQ + jrow;
-	const uint64_t out_step = (uint64_t)G * nqg * S * 16;
+	// records: [candidate][query group][step][query in group] -- the four waves of a workgroup write one 256-byte run per step
+	u32x4* out_ptr = partials16 + (((uint64_t)g * nqg + qg) * ST + s) * 16 + wib * TQ + jrow;
+	const uint64_t out_step = (uint64_t)G * nqg * ST * 16;
 
 	uint32_t rd = 0, wr = D % NB;
 	for (uint32_t it = 0; it < n_iter; it++) {
-		// Vector-memory operations retire in issue order. Younger than this wave's piece of tile `it`: the pieces of tiles
-		// it+1 .. it+D-1 and, for a scoring wave past ramp-up, D record stores (2D-1 in all); fewer stores during ramp-up.
-		if (active && it >= (uint32_t)D) wait_vm<2 * D - 1>(); else wait_vm<D - 1>();
-		// all four quarters of tile `it` have landed, and every wave has consumed tile it-1 (its slot is refilled next)
+		// Vector-memory operations retire in issue order. Younger than this wave's last piece of step `it`: the TPI pieces of
+		// each of the steps it+1 .. it+D-1 and, for a scoring wave past ramp-up, D record stores; fewer stores during ramp-up.
+		if (active && it >= (uint32_t)D) wait_vm<(TPI + 1) * (D - 1) + 1>(); else wait_vm<TPI * (D - 1)>();
+		// all four quarters of every tile of step `it` have landed, and every wave has consumed step it-1 (its slot is refilled next)
 		__builtin_amdgcn_s_barrier();
 		fetch(it + D, wr);
 		wr = wr + 1 == NB ? 0 : wr + 1;
 		if (active) {
-			const u32x4* sl = reinterpret_cast<const u32x4*>(s_ring + rd * kTileBytes) + lane;
-			const u32x4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
-			uint32_t cc[NC];
-			if constexpr (U8) {
-				cc[0] = pack_u8(v0.x, v0.y); cc[1] = pack_u8(v0.z, v0.w); cc[2] = pack_u8(v1.x, v1.y); cc[3] = pack_u8(v1.z, v1.w);
-			} else {
-				cc[0] = v0.x; cc[1] = v0.y; cc[2] = v0.z; cc[3] = v0.w; cc[4] = v1.x; cc[5] = v1.y; cc[6] = v1.z; cc[7] = v1.w;
-			}
-			const uint32_t cp[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 			uint32_t manh[TQ], dot[TQ], emd[TQ];
 #pragma unroll
-			for (int j = 0; j < TQ; j++) {
-				manh[j] = 0; dot[j] = 0; emd[j] = 0;
+			for (int j = 0; j < TQ; j++) { manh[j] = 0; dot[j] = 0; emd[j] = 0; }
 #pragma unroll
-				for (int i = 0; i < NC; i++) {
-					if constexpr (U8) {
-						manh[j] = __builtin_amdgcn_sad_u8(cc[i], qc[j][i], manh[j]);
-						dot[j] = __builtin_amdgcn_udot4(cc[i], qc[j][i], dot[j], false);
-					} else {
-						manh[j] = __builtin_amdgcn_sad_u16(cc[i], qc[j][i], manh[j]);
-						dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][i]), dot[j], false);
-					}
+			for (int u = 0; u < TPI; u++) {
+				const u32x4* sl = reinterpret_cast<const u32x4*>(s_ring + rd * kStepBytes + u * kTileBytes) + lane;
+				const u32x4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+				uint32_t cc[NC];
+				if constexpr (U8) {
+					cc[0] = pack_u8(v0.x, v0.y); cc[1] = pack_u8(v0.z, v0.w); cc[2] = pack_u8(v1.x, v1.y); cc[3] = pack_u8(v1.z, v1.w);
+				} else {
+					cc[0] = v0.x; cc[1] = v0.y; cc[2] = v0.z; cc[3] = v0.w; cc[4] = v1.x; cc[5] = v1.y; cc[6] = v1.z; cc[7] = v1.w;
 				}
+				const uint32_t cp[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
-				for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][i], emd[j]);
+				for (int j = 0; j < TQ; j++) {
+#pragma unroll
+					for (int i = 0; i < NC; i++) {
+						if constexpr (U8) {
+							manh[j] = __builtin_amdgcn_sad_u8(cc[i], qc[j][u][i], manh[j]);
+							dot[j] = __builtin_amdgcn_udot4(cc[i], qc[j][u][i], dot[j], false);
+						} else {
+							manh[j] = __builtin_amdgcn_sad_u16(cc[i], qc[j][u][i], manh[j]);
+							dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][u][i]), dot[j], false);
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][u][i], emd[j]);
+				}
 			}
 			u32x4 rec;
 			rec.x = wave_sum4_rows(manh[0], manh[1], manh[2], manh[3]);
@@ -200,22 +215,23 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
 }
 
-template <int NB, bool U8>
+template <int NB, bool U8, int TPI>
 hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_dg, uint64_t slot_bytes, const uint32_t* cand_slots, uint32_t m,
                                const uint8_t* q_dg, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, void* partials16, int num_cus) {
-	const size_t lds = (size_t)NB * kTileBytes;
-	const void* fn = (const void*)k_pair_digest_multi<NB, U8>;
+	const size_t lds = (size_t)NB * TPI * kTileBytes;
+	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI>;
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
 	const uint32_t nqg = (n_q + 4 * kWaves - 1) / (4 * kWaves);
+	const uint32_t ST = S / TPI;
 	// one resident round of equal-length workgroups
-	uint64_t G = (uint64_t)num_cus * blocks_per_cu / ((uint64_t)S * nqg);
+	uint64_t G = (uint64_t)num_cus * blocks_per_cu / ((uint64_t)ST * nqg);
 	if (G < 1) G = 1;
 	if (G > m) G = m;
-	const uint64_t rest_pad = ((uint64_t)S * G + 7) / 8 * 8;
+	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
-	k_pair_digest_multi<NB, U8><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, S, (uint32_t)G, nqg,
-	                                                                       (u32x4*)partials16);
+	k_pair_digest_multi<NB, U8, TPI><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
+	                                                                            (u32x4*)partials16);
 	return hipGetLastError();
 }
 
@@ -231,18 +247,27 @@ hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uin
 	return hipGetLastError();
 }
 
+int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
+	static const int env = [] { const char* e = getenv("MSC_DIGEST_TPI"); return e ? atoi(e) : 0; }();
+	// two tiles per step halve the wave reductions and the partial records per byte streamed; per-lane sums then cover 32 bins
+	const bool fits = L.S % 2 == 0 && 64ull * 32 * max_count * max_count < (1ull << 32);
+	if (env == 1 || !fits) return 1;
+	return 2;
+}
+
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        void* partials16, int num_cus) {
+                                        int tiles_per_step, void* partials16, int num_cus) {
 	if (m == 0 || n_q == 0) return hipSuccess;
-	if (L.LPT != 4 || L.esz != 4) return hipErrorInvalidValue;
+	if (L.LPT != 4 || L.esz != 4 || (tiles_per_step != 1 && tiles_per_step != 2) || L.S % tiles_per_step) return hipErrorInvalidValue;
 	static const int nb_env = [] { const char* e = getenv("MSC_DIGEST_SLOTS"); return e ? atoi(e) : 0; }();
 #define MSC_DG_ARGS st, L.S, cand_digest, L.slot_bytes, cand_slots, m, q_digest, q_slot_bytes, q_slots, n_q, partials16, num_cus
-#define MSC_DG(U8)                                                                                              \
-	(nb_env == 2 ? launch_digest_multi<2, U8>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8>(MSC_DG_ARGS) \
-	 : nb_env == 6 ? launch_digest_multi<6, U8>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8>(MSC_DG_ARGS) \
-	                                                                      : launch_digest_multi<4, U8>(MSC_DG_ARGS))
-	return counts_fit_u8 ? MSC_DG(true) : MSC_DG(false);
-#undef MSC_DG
+#define MSC_DG_NB(U8, TPI)                                                                                                \
+	(nb_env == 2 ? launch_digest_multi<2, U8, TPI>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8, TPI>(MSC_DG_ARGS) \
+	 : nb_env == 6 ? launch_digest_multi<6, U8, TPI>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8, TPI>(MSC_DG_ARGS) \
+	                                                                            : launch_digest_multi<4, U8, TPI>(MSC_DG_ARGS))
+	if (tiles_per_step == 2) return counts_fit_u8 ? MSC_DG_NB(true, 2) : MSC_DG_NB(false, 2);
+	return counts_fit_u8 ? MSC_DG_NB(true, 1) : MSC_DG_NB(false, 1);
+#undef MSC_DG_NB
 #undef MSC_DG_ARGS
 }
