@@ -107,6 +107,7 @@ class ShardedBlockScorer:
 
     def score_block(self, query_globals):
         import torch
+        pending = []
         for j, qg in enumerate(query_globals):
             owner = self.plan.owner(qg)
             bufs = self.backend.query_buffers(j)
@@ -114,8 +115,10 @@ class ShardedBlockScorer:
                 for dst, src in zip(bufs, self.backend.export_query(self.plan.local(qg))):
                     dst.copy_(src)
             if self.plan.world > 1:
-                for b in bufs:
-                    self.dist.broadcast(b, src=owner)
+                # all 2 * n_q broadcasts are issued before any is waited for: the collectives queue back to back
+                pending += [self.dist.broadcast(b, src=owner, async_op=True) for b in bufs]
+        for w in pending:
+            w.wait()
         self.backend.import_queries(len(query_globals))
         close = self.backend.score_block(len(query_globals))
         counts = torch.tensor(close.sum(axis=1).astype(np.float64), dtype=torch.float64, device=self.device)

@@ -551,3 +551,57 @@ def test_cluster_driver_k8_dense_and_sparse_layouts(tmp_path, layout):
     r = subprocess.run(args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     assert open(str(tmp_path / "out.clstr"), "rb").read() == open(os.path.join(golden, "k8.clstr"), "rb").read()
+
+
+def test_full_size_cfg2_properties(oracle):
+    """BASELINE.json configs[1] at FULL size (100 000 x 1 kb, k = 9, datatype 32: 98 GiB of histograms + the digest mirror),
+    checked through size-independent properties: sampled histograms against the oracle; the Q x M digest kernel against the
+    independent 1 x M raw-bin kernel bit for bit over all 100 000 candidates; symmetry of the score; the self pair; the
+    family structure of the synthetic set (20 relatives per template, ~96 % identical) in the close flags."""
+    ctx = api.Context(0)
+    n, k, dtype, fam = 100000, 9, 32, 20
+    seed = 20260002
+    hs = api.HistogramSet(ctx, k, dtype, n)
+    keep = {}
+    for done in range(0, n, 20000):
+        codes = []
+        for t in range(done // fam, (done + 20000) // fam):
+            tmpl = synth.template(seed, t, 1000)
+            codes += [synth.member(seed, t, j, tmpl) for j in range(fam)]
+        for i in (0, 7777, 19999):
+            keep[done + i] = codes[i]
+        b = synth.pack_batch(codes)
+        hs.build_packed(done, 20000, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
+    # sampled histograms == oracle (codes 0..3 -> ACGT)
+    for slot, code in keep.items():
+        seq = synth.to_ascii(code)
+        oh = oracle.hist(seq, k, dtype)
+        assert np.array_equal(hs.download(slot), oh.array()), slot
+        inf = hs.info(slot)
+        assert inf["sum"] == len(seq) - k + 1 + 4 ** k and inf["mag"] == oh.mag and inf["length"] == len(seq)
+    feat = api.Feature.from_text(ctx, weights_text("weights_k9_u32.txt"), 0)
+    qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
+    fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
+    multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
+    assert ctx.last_kernel_info()[0].startswith("k_pair_digest_multi")
+    # independent kernel, same answers (every candidate, three of the queries)
+    for i in (0, 5, 15):
+        single = feat.compute(hs, None, hs, int(qs[i]), m=n)
+        assert ctx.last_kernel_info()[0] == "k_pair_tiles"
+        assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
+        assert int(multi["close"][i].sum()) == int((np.round(single["csum"]) > 0).sum())
+    # symmetry of the symmetric statistics: stat(query a, candidate b) == stat(query b, candidate a). (The model score itself is
+    # NOT symmetric for uint32_t bins: the reference's simratio wraps `p - q` before widening, SURVEY Q3, reproduced here.)
+    for i in range(16):
+        for j in range(i + 1, 16):
+            assert np.array_equal(multi["raw"][i][qs[j]], multi["raw"][j][qs[i]])
+    for i, q in enumerate(qs):
+        # the self pair: manhattan 0, intersection 1 (whether the trained model calls it close is the model's business)
+        assert multi["raw"][i][q][0] == 0.0 and multi["raw"][i][q][1] == 1.0
+        # every relative of the query's template (20 per family, ~96 % identical) shares more k-mers with it than any stranger
+        f0 = (int(q) // fam) * fam
+        inter = multi["raw"][i][:, 1]
+        strangers = np.concatenate([inter[:f0], inter[f0 + fam:]])
+        assert inter[f0:f0 + fam].min() > strangers.max(), (i, inter[f0:f0 + fam].min(), strangers.max())
+    assert fast_mask
+    ctx.close()
