@@ -24,6 +24,7 @@
 // four queries, and nothing else.
 #include "msc_internal.h"
 #include "msc_wave.h"
+#include <type_traits>
 
 namespace {
 
@@ -67,25 +68,59 @@ __global__ void __launch_bounds__(kBlock) k_digest_build(const uint8_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------- Q x M kernel
-// one wave's quarter of a tile: 64 lanes x 16 bytes from global memory straight into LDS (no destination VGPRs)
-__device__ __forceinline__ void dma_piece(const uint8_t* lane_src, uint32_t lds_dst) {
+// one wave's quarter of a tile: 64 lanes x 16 bytes from global memory (wave-uniform base in SGPRs + per-lane byte offset)
+// straight into LDS (no destination VGPRs, no 64-bit vector address arithmetic)
+__device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uint32_t lds_dst) {
 	uint32_t keep;      // m0 is the compiler's: saved and restored
 	asm volatile(
 	    "s_mov_b32 %0, m0\n\t"
-	    "s_mov_b32 m0, %2\n\t"
+	    "s_mov_b32 m0, %3\n\t"
 	    "s_nop 0\n\t"
-	    "global_load_lds_dwordx4 %1, off\n\t"
+	    "global_load_lds_dwordx4 %1, %2\n\t"
 	    "s_mov_b32 m0, %0"
 	    : "=&s"(keep)
-	    : "v"(lane_src), "s"(lds_dst)
+	    : "v"(lane_off), "s"(sbase), "s"(lds_dst)
 	    : "memory");
+}
+
+// Transposed reduction of 4 queries x 3 sums over the 64 lanes into ONE register.
+//   v_permlane32_swap a, b : a[32..63] <-> b[0..31]     -> a + b = [a_lo + a_hi | b_lo + b_hi]            (12 -> 6 registers)
+//   v_permlane16_swap x, y : x rows 1,3 <-> y rows 0,2  -> x + y = rows [x0+x1 | y0+y1 | x2+x3 | y2+y3]   ( 6 -> 3 registers)
+// fed (q0, q2) and (q1, q3), row r then holds 16 partial sums of query r; the three registers (manh, dot, emd) are folded
+// inside the 16-lane rows with DPP, bank masks merging them into one register on the way: row_ror:8 pairs lanes (l, l^8),
+// row_half_mirror pairs (l, 7-l), two quad_perms finish the quads. Result: every lane of bank 0 holds the row's manh total,
+// bank 1 dot, bank 2 emd (bank 3: emd again). 9 swaps + 9 adds + 9 DPP operations for the 12 sums.
+__device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint32_t (&dot)[4], const uint32_t (&emd)[4]) {
+	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
+	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
+	auto dpp = [](uint32_t old, uint32_t v, auto ctrl, auto bank) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, decltype(ctrl)::value, 0xf, decltype(bank)::value, false); };
+	using std::integral_constant;
+	const uint32_t A = fold16(fold32(manh[0], manh[2]), fold32(manh[1], manh[3]));
+	const uint32_t B = fold16(fold32(emd[0], emd[2]), fold32(emd[1], emd[3]));
+	const uint32_t C = fold16(fold32(dot[0], dot[2]), fold32(dot[1], dot[3]));
+	const integral_constant<int, 0x128> ror8;
+	const integral_constant<int, 0x141> half_mirror;
+	const integral_constant<int, 0xe4> ident;
+	const integral_constant<int, 0xb1> swap1;
+	const integral_constant<int, 0x4e> swap2;
+	const integral_constant<int, 0xf> all;
+	const uint32_t Xa = A + dpp(0, A, ror8, all);
+	const uint32_t Yb = B + dpp(0, B, ror8, all);
+	const uint32_t Zc = C + dpp(0, C, ror8, all);
+	uint32_t P = dpp(Xa, Yb, ident, integral_constant<int, 0xc>());      // lanes 8-15 of every row <- emd
+	P += dpp(0, P, half_mirror, all);
+	const uint32_t Z2 = Zc + dpp(0, Zc, half_mirror, all);
+	P = dpp(P, Z2, ident, integral_constant<int, 0x2>());                 // lanes 4-7 <- dot
+	P += dpp(0, P, swap1, all);
+	P += dpp(0, P, swap2, all);
+	return P;
 }
 
 // bytes 0 and 2 of `lo` and of `hi`: four 16-bit counts (< 256) -> four bytes
 __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
 template <int NB, bool U8, int TPI>
-__global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
+__global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
     uint32_t nqg, u32x4* __restrict__ partials16) {
@@ -141,24 +176,23 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 
 	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring) + wib * kPieceBytes;
 	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
-	const uint64_t src_off = (uint64_t)s * kStepBytes + wib * kPieceBytes + lane * 16u;
+	const uint64_t src_off = (uint64_t)s * kStepBytes + wib * kPieceBytes;
+	const uint32_t lane16 = lane * 16u;
 	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
 		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;      // past the end: re-fetch the last step (keeps the count fixed)
 		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
+		const uint64_t base = (uint64_t)cand_dg + (uint64_t)slot * slot_bytes + src_off;      // wave-uniform: scalar arithmetic
 #pragma unroll
-		for (int u = 0; u < TPI; u++)
-			dma_piece(cand_dg + (uint64_t)slot * slot_bytes + src_off + u * kTileBytes, ring_lds + slot_idx * kStepBytes + u * kTileBytes);
+		for (int u = 0; u < TPI; u++) dma_piece(base + u * kTileBytes, lane16, ring_lds + slot_idx * kStepBytes + u * kTileBytes);
 	};
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
 
-	// the four lanes holding row totals after wave_sum4_rows: lane 15 -> query 0, 31 -> 2, 47 -> 1, 63 -> 3
-	const uint32_t row = lane >> 4;
-	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
-	const bool owner = (lane & 15) == 15;
-	// records: [candidate][query group][step][query in group] -- the four waves of a workgroup write one 256-byte run per step
-	u32x4* out_ptr = partials16 + (((uint64_t)g * nqg + qg) * ST + s) * 16 + wib * TQ + jrow;
-	const uint64_t out_step = (uint64_t)G * nqg * ST * 16;
+	const bool owner = (lane & 3) == 0;       // first lane of every quad: stores one word of a record (see fold12 below)
+	// records: [candidate][query group][step][query in group] -- the four waves of a workgroup write one 256-byte run per step;
+	// wave-uniform base in SGPRs, advanced per step, + the owner lanes' constant offset
+	uint64_t out_base = (uint64_t)partials16 + ((((uint64_t)g * nqg + qg) * ST + s) * 16 + wib * TQ) * sizeof(u32x4);
+	const uint64_t out_step = (uint64_t)G * nqg * ST * 16 * sizeof(u32x4);
 
 	uint32_t rd = 0, wr = D % NB;
 	for (uint32_t it = 0; it < n_iter; it++) {
@@ -200,15 +234,18 @@ __global__ void __launch_bounds__(kBlock) k_pair_digest_multi(
 					for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][u][i], emd[j]);
 				}
 			}
-			u32x4 rec;
-			rec.x = wave_sum4_rows(manh[0], manh[1], manh[2], manh[3]);
-			rec.y = wave_sum4_rows(dot[0], dot[1], dot[2], dot[3]);
-			rec.z = wave_sum4_rows(emd[0], emd[1], emd[2], emd[3]);
-			rec.w = 0;
-			// s_nop: a store of more than 8 bytes reads its data registers after issue; the hazard recognizer does not look
-			// inside an asm statement and may overwrite `rec` in the very next instruction
-			if (owner) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out_ptr), "v"(rec) : "memory");
-			out_ptr += out_step;
+			// 12 per-lane sums -> 4 records of (manh, dot, emd, -): row r of the wave ends up holding query r, its bank b
+			// (lanes 4b .. 4b+3 of the row) word b of that query's record; the first lane of each quad stores its word, so the
+			// wave writes its 64 bytes of the workgroup's 256-byte run with one dword store
+			const uint32_t word = fold12(manh, dot, emd);
+			if (owner) {
+				// byte offset = 16 * row + 4 * bank = lane & 0x3c, recomputed from lane * 16 (live anyway) instead of kept in a
+				// register across the loop: the kernel stays within 128 VGPRs
+				uint32_t off;
+				asm volatile("v_lshrrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x3c, %0\n\tglobal_store_dword %0, %2, %3"
+				             : "=&v"(off) : "v"(lane16), "v"(word), "s"(out_base) : "memory");
+			}
+			out_base += out_step;
 		}
 		rd = rd + 1 == NB ? 0 : rd + 1;
 	}

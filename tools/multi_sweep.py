@@ -17,7 +17,7 @@ while done < n:
     hs.build_packed(done, m, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
     done += m
 feat = api.Feature.from_text(ctx, open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "weights_k9_u32.txt")).read(), 0)
-for nq in (1, 2, 4, 8, 16):
+for nq in [int(x) for x in os.environ.get("MSC_SWEEP_NQ", "1,2,4,8,16").split(",")]:
     qs = np.arange(nq, dtype=np.uint32) * 3
     ts = []
     for it in range(4):
