@@ -401,7 +401,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes * (s->digest ? 2 : 1) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + s->scalar_stride) * s->capacity;
 }
 
 // pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
@@ -1192,10 +1192,10 @@ extern "C" int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_se
 // The digest mirror of a dense 32-bit set (pair_digest.hip): allocated on first use, refreshed for the slots written since.
 // Returns MSC_OK with set->digest == nullptr when the mirror cannot be had (no memory): the caller then streams the raw bins.
 static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
-	if (set->sparse || set->dtype != 32 || set->L.LPT != 4 || set->digest_unavailable) return MSC_OK;
+	if (set->sparse || !msc_digest_supported(set->L) || set->digest_unavailable) return MSC_OK;
 	if (!set->digest) {
 		void* p = nullptr;
-		if (hipMalloc(&p, set->L.slot_bytes * set->capacity) != hipSuccess) {
+		if (hipMalloc(&p, msc_digest_slot_bytes(set->L) * set->capacity) != hipSuccess) {
 			(void)hipGetLastError();
 			set->digest_unavailable = true;
 			return MSC_OK;
@@ -1262,7 +1262,11 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// Digest form (pair_digest.hip): 32-bit sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen
 	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
 	static const bool no_digest = getenv("MSC_MULTI_NO_DIGEST") != nullptr;
-	bool digest = !no_digest && compact && excess16 && cands->dtype == 32 && L.LPT == 4 && mc_ < 65536 && n_q >= 4 && !getenv("MSC_MULTI_TQ");
+	// (one digest tile per lane-run of 16 bins: wave totals of 1024 * max^2 must fit 32 bits)
+	// The mirror streams 4 bytes per bin: against 8/16-bit raw bins it pays once enough queries share each candidate read
+	// (measured crossovers at k = 9: 7 queries for uint8_t, 5-6 for uint16_t, 4 for uint32_t)
+	const uint64_t dg_min_q = cands->dtype == 8 ? 8 : cands->dtype == 16 ? 6 : 4;
+	bool digest = !no_digest && excess16 && msc_digest_supported(L) && mc_ < 2048 && n_q >= dg_min_q && !getenv("MSC_MULTI_TQ");
 	if (digest) {
 		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
 		digest = cands->digest && qset->digest;
@@ -1275,7 +1279,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const bool prefix16 = ring && !no_p16 && excess16;
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
 	const int tps = digest ? msc_digest_tiles_per_step(L, mc_) : 1;          // the digest kernel writes one record per step of tps tiles
-	const uint32_t n_rec = L.S / tps;
+	const uint32_t n_rec = digest ? (uint32_t)(L.nbins / 1024) / tps : L.S;
 	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
 	const uint64_t q_rows = digest ? (n_q + 15) / 16 * 16 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
@@ -1299,7 +1303,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
-			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * L.slot_bytes), d_slots, mc, qset->digest, qset->L.slot_bytes,
+			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, ctx->partials.p, ctx->num_cus));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,

@@ -130,12 +130,15 @@ hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, 
                                             const uint32_t* cand_slots, uint32_t m, const uint8_t* qset_bins, uint64_t q_slot_bytes,
                                             const uint8_t* qset_scalars, uint64_t q_scalar_stride, const uint32_t* q_slots, uint32_t n_q, int tq,
                                             bool prefix16, void* partials16, int num_cus);
-// digest mirror of a 32-bit set (pair_digest.hip): build for slots [first, first+n), and the Q x M pass that streams it
+// digest mirror of an 8/16/32-bit set (pair_digest.hip): 4 bytes per bin whatever the bin type; build for slots [first, first+n),
+// and the Q x M pass that streams it
+bool msc_digest_supported(const MscLayout& L);
+uint64_t msc_digest_slot_bytes(const MscLayout& L);
 hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uint8_t* bins, const uint8_t* scalars, uint8_t* digest, uint64_t first_slot,
                                    uint64_t n_slots);
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count);      // 1 or 2 consecutive tiles scored per loop step
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
-                                        const uint8_t* q_digest, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
+                                        const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
                                         int tiles_per_step, void* partials16, int num_cus);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,

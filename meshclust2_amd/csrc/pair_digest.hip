@@ -1,4 +1,4 @@
-// pair_digest.hip -- the "digest" mirror of a 32-bit histogram set and the Q x M kernel that streams it (gfx950).
+// pair_digest.hip -- the "digest" mirror of an 8/16/32-bit histogram set and the Q x M kernel that streams it (gfx950).
 //
 // Same arithmetic as k_pair_tiles_multi32_ring (pair_features.hip): per (candidate, tile, query) three integer reductions
 //     manh = sum |p-q|      dot = sum p*q      emd = sum |prefix(p) - prefix(q)|
@@ -7,7 +7,8 @@
 // reductions want (run sums, a wave scan, 16 dependent prefix adds, re-packing two bins per word) -- once per candidate
 // tile PER QUERY GROUP -- and measured 69 % VALU-busy at 2.6 TB/s of HBM traffic: VALU-bound, not memory-bound. The
 // digest stores that form in HBM instead, built once per histogram (k_digest_build, one pass) and reused by every pass
-// of the all-pairs matrix. It is a lossless re-encoding with the SAME 4 bytes per bin:
+// of the all-pairs matrix. It is a lossless re-encoding with 4 bytes per bin (the size of a 32-bit set; an 8/16-bit set pays
+// 4x / 2x its own bytes for it and uses it from 8 / 6 queries per pass up):
 //
 //   digest tile = 1024 bins = 64 lanes x 16 words (4 KiB), word w of lane l at byte (w/4)*1024 + l*16 + (w%4)*4
 //     words 0..7  : the lane's 16 consecutive bins, two per word        (bin 2i | bin 2i+1 << 16)
@@ -34,9 +35,15 @@ constexpr uint32_t kTileBytes = 4096;
 constexpr uint32_t kPieceBytes = kTileBytes / kWaves;
 
 // ---------------------------------------------------------------------------------------- digest build
+// One wave per RAW tile (64 lanes x R = 64 / 32 / 16 bins of uint8 / uint16 / uint32 in the layout of msc_layout.h): each
+// lane scans its run, one wave scan stitches the runs, and the lane emits R / 16 digest runs of 16 bins. A digest tile
+// always covers 1024 bins, whatever the bin type of the set.
+template <typename T>
 __global__ void __launch_bounds__(kBlock) k_digest_build(const uint8_t* __restrict__ bins, uint64_t slot_bytes, const uint8_t* __restrict__ scalars,
-                                                         uint64_t scalar_stride, uint8_t* __restrict__ digest, uint64_t first_slot, uint64_t n_slots,
-                                                         uint32_t S) {
+                                                         uint64_t scalar_stride, uint8_t* __restrict__ digest, uint64_t dg_slot_bytes, uint64_t first_slot,
+                                                         uint64_t n_slots, uint32_t S) {
+	constexpr int R = 64 / sizeof(T);         // bins per lane per raw tile (LPT = 4)
+	constexpr int NR = R / 16;                // digest runs per lane
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t W = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
 	if (W >= n_slots * S) return;
@@ -46,25 +53,30 @@ __global__ void __launch_bounds__(kBlock) k_digest_build(const uint8_t* __restri
 	u32x4 v[4];
 #pragma unroll
 	for (int l = 0; l < 4; l++) v[l] = __builtin_nontemporal_load(src + 64 * l);
-	const uint32_t* w = reinterpret_cast<const uint32_t*>(v);      // the lane's 16 logically consecutive bins (msc_layout.h)
+	const T* w = reinterpret_cast<const T*>(v);      // the lane's R logically consecutive bins
 	uint32_t t = 0;
 #pragma unroll
-	for (int r = 0; r < 16; r++) t += w[r];
+	for (int r = 0; r < R; r++) t += (uint32_t)w[r];
 	const uint64_t* prefix = reinterpret_cast<const uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
 	uint32_t run = (uint32_t)prefix[s] + wave_incl_scan(t) - t;     // sum of every bin before this lane's run
-	run -= s * 1024u + lane * 16u;                                   // minus the pseudocount baseline -> excess
-	uint32_t ev[16];
+	const uint32_t first_bin = s * (64u * R) + lane * R;
+	run -= first_bin;                                                // minus the pseudocount baseline -> excess
 #pragma unroll
-	for (int r = 0; r < 16; r++) { run += w[r] - 1u; ev[r] = run; }
-	u32x4 o[4];
-	uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+	for (int n = 0; n < NR; n++) {
+		uint32_t ev[16];
 #pragma unroll
-	for (int r = 0; r < 8; r++) ow[r] = (w[2 * r] & 0xffffu) | (w[2 * r + 1] << 16);
+		for (int r = 0; r < 16; r++) { run += (uint32_t)w[16 * n + r] - 1u; ev[r] = run; }
+		u32x4 o[4];
+		uint32_t* ow = reinterpret_cast<uint32_t*>(o);
 #pragma unroll
-	for (int r = 0; r < 8; r++) ow[8 + r] = (ev[2 * r] & 0xffffu) | (ev[2 * r + 1] << 16);
-	u32x4* dst = reinterpret_cast<u32x4*>(digest + slot * slot_bytes + (uint64_t)s * kTileBytes) + lane;
+		for (int r = 0; r < 8; r++) ow[r] = ((uint32_t)w[16 * n + 2 * r] & 0xffffu) | ((uint32_t)w[16 * n + 2 * r + 1] << 16);
 #pragma unroll
-	for (int l = 0; l < 4; l++) dst[64 * l] = o[l];
+		for (int r = 0; r < 8; r++) ow[8 + r] = (ev[2 * r] & 0xffffu) | (ev[2 * r + 1] << 16);
+		const uint32_t bin = first_bin + 16 * n;                     // first bin of this digest run
+		u32x4* dst = reinterpret_cast<u32x4*>(digest + slot * dg_slot_bytes + (uint64_t)(bin >> 10) * kTileBytes) + ((bin >> 4) & 63);
+#pragma unroll
+		for (int l = 0; l < 4; l++) dst[64 * l] = o[l];
+	}
 }
 
 // ---------------------------------------------------------------------------------------- Q x M kernel
@@ -274,31 +286,39 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 
 }  // namespace
 
+uint64_t msc_digest_slot_bytes(const MscLayout& L) { return L.nbins * 4; }
+bool msc_digest_supported(const MscLayout& L) { return L.LPT == 4 && L.esz <= 4 && L.nbins % 1024 == 0; }
+
 hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uint8_t* bins, const uint8_t* scalars, uint8_t* digest, uint64_t first_slot,
                                    uint64_t n_slots) {
 	if (n_slots == 0) return hipSuccess;
-	if (L.LPT != 4 || L.esz != 4) return hipErrorInvalidValue;
+	if (!msc_digest_supported(L)) return hipErrorInvalidValue;
 	const uint64_t waves = n_slots * L.S;
 	const unsigned blocks = (unsigned)((waves + kWaves - 1) / kWaves);
-	k_digest_build<<<dim3(blocks), dim3(kBlock), 0, st>>>(bins, L.slot_bytes, scalars, msc_scalar_stride(L.S), digest, first_slot, n_slots, L.S);
+	const uint64_t ss = msc_scalar_stride(L.S), db = msc_digest_slot_bytes(L);
+	if (L.esz == 1) k_digest_build<uint8_t><<<dim3(blocks), dim3(kBlock), 0, st>>>(bins, L.slot_bytes, scalars, ss, digest, db, first_slot, n_slots, L.S);
+	else if (L.esz == 2) k_digest_build<uint16_t><<<dim3(blocks), dim3(kBlock), 0, st>>>(bins, L.slot_bytes, scalars, ss, digest, db, first_slot, n_slots, L.S);
+	else k_digest_build<uint32_t><<<dim3(blocks), dim3(kBlock), 0, st>>>(bins, L.slot_bytes, scalars, ss, digest, db, first_slot, n_slots, L.S);
 	return hipGetLastError();
 }
 
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
 	static const int env = [] { const char* e = getenv("MSC_DIGEST_TPI"); return e ? atoi(e) : 0; }();
 	// two tiles per step halve the wave reductions and the partial records per byte streamed; per-lane sums then cover 32 bins
-	const bool fits = L.S % 2 == 0 && 64ull * 32 * max_count * max_count < (1ull << 32);
+	const bool fits = (L.nbins / 1024) % 2 == 0 && 64ull * 32 * max_count * max_count < (1ull << 32);
 	if (env == 1 || !fits) return 1;
 	return 2;
 }
 
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
-                                        const uint8_t* q_digest, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
+                                        const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
                                         int tiles_per_step, void* partials16, int num_cus) {
 	if (m == 0 || n_q == 0) return hipSuccess;
-	if (L.LPT != 4 || L.esz != 4 || (tiles_per_step != 1 && tiles_per_step != 2) || L.S % tiles_per_step) return hipErrorInvalidValue;
+	const uint32_t n_tiles = (uint32_t)(L.nbins / 1024);
+	if (!msc_digest_supported(L) || (tiles_per_step != 1 && tiles_per_step != 2) || n_tiles % tiles_per_step) return hipErrorInvalidValue;
+	const uint64_t db = msc_digest_slot_bytes(L);
 	static const int nb_env = [] { const char* e = getenv("MSC_DIGEST_SLOTS"); return e ? atoi(e) : 0; }();
-#define MSC_DG_ARGS st, L.S, cand_digest, L.slot_bytes, cand_slots, m, q_digest, q_slot_bytes, q_slots, n_q, partials16, num_cus
+#define MSC_DG_ARGS st, n_tiles, cand_digest, db, cand_slots, m, q_digest, db, q_slots, n_q, partials16, num_cus
 #define MSC_DG_NB(U8, TPI)                                                                                                \
 	(nb_env == 2 ? launch_digest_multi<2, U8, TPI>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8, TPI>(MSC_DG_ARGS) \
 	 : nb_env == 6 ? launch_digest_multi<6, U8, TPI>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8, TPI>(MSC_DG_ARGS) \

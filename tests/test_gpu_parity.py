@@ -256,7 +256,7 @@ def test_device_view_is_usable_from_torch():
     assert b"TORCH_VIEW_OK" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
 
 
-@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 5), (16, 5, 7), (8, 9, 4), (16, 7, 2), (64, 6, 3), (8, 3, 3)])
+@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 5), (16, 5, 7), (8, 9, 4), (16, 7, 2), (64, 6, 3), (8, 3, 3), (16, 9, 6), (8, 6, 9), (16, 6, 19), (8, 8, 16)])
 def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
     """msc_score_multi (candidate tiles reused across several query tiles) == nq independent 1 x M passes, bit for bit."""
     seqs, _ = synth.families(500 + k, 40, 1000 if k > 3 else 60, family=10)

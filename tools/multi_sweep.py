@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meshclust2_amd import api, synth
 ctx = api.Context(0)
-k, dt, n = 9, 32, int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+k, dt, n = 9, int(os.environ.get("MSC_SWEEP_DT", "32")), int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 codes = [synth.member(5, t // 20, t % 20, synth.template(5, t // 20, 1000)) for t in range(4000)]
 hs = api.HistogramSet(ctx, k, dt, n)
 b = synth.pack_batch(codes)
@@ -26,4 +26,4 @@ for nq in [int(x) for x in os.environ.get("MSC_SWEEP_NQ", "1,2,4,8,16").split(",
         ts.append((time.perf_counter() - t0, ctx.last_kernel_ms()[0]))
     wall = np.median([a for a, _ in ts[1:]]); tiles = np.median([b_ for _, b_ in ts[1:]])
     print(json.dumps({"n_q": nq, "m": n, "wall_ms": round(wall * 1e3, 2), "tiles_ms": round(float(tiles), 3), "pairs_per_s_wall": round(nq * n / wall),
-                      "pairs_per_s_kernel": round(nq * n / tiles * 1e3), "cand_GBps": round(n * 2 ** 20 / tiles / 1e6, 1)}), flush=True)
+                      "pairs_per_s_kernel": round(nq * n / tiles * 1e3), "cand_GBps": round(n * 4 ** k * dt / 8 / tiles / 1e6, 1)}), flush=True)
