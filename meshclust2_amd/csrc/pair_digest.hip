@@ -82,17 +82,28 @@ __global__ void __launch_bounds__(kBlock) k_digest_build(const uint8_t* __restri
 // ---------------------------------------------------------------------------------------- Q x M kernel
 // one wave's quarter of a tile: 64 lanes x 16 bytes from global memory (wave-uniform base in SGPRs + per-lane byte offset)
 // straight into LDS (no destination VGPRs, no 64-bit vector address arithmetic)
-__device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uint32_t lds_dst) {
+__device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uint32_t lds_dst, bool stream_once) {
 	uint32_t keep;      // m0 is the compiler's: saved and restored
-	asm volatile(
-	    "s_mov_b32 %0, m0\n\t"
-	    "s_mov_b32 m0, %3\n\t"
-	    "s_nop 0\n\t"
-	    "global_load_lds_dwordx4 %1, %2\n\t"
-	    "s_mov_b32 m0, %0"
-	    : "=&s"(keep)
-	    : "v"(lane_off), "s"(sbase), "s"(lds_dst)
-	    : "memory");
+	if (stream_once)    // nontemporal: the bare DMA loop streams 6.3-6.7 TB/s with it against 5.7-6.1 without (tools/ubench/digest_exp.hip)
+		asm volatile(
+		    "s_mov_b32 %0, m0\n\t"
+		    "s_mov_b32 m0, %3\n\t"
+		    "s_nop 0\n\t"
+		    "global_load_lds_dwordx4 %1, %2 nt\n\t"
+		    "s_mov_b32 m0, %0"
+		    : "=&s"(keep)
+		    : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+		    : "memory");
+	else
+		asm volatile(
+		    "s_mov_b32 %0, m0\n\t"
+		    "s_mov_b32 m0, %3\n\t"
+		    "s_nop 0\n\t"
+		    "global_load_lds_dwordx4 %1, %2\n\t"
+		    "s_mov_b32 m0, %0"
+		    : "=&s"(keep)
+		    : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+		    : "memory");
 }
 
 // Transposed reduction of 4 queries x 3 sums over the 64 lanes into ONE register.
@@ -135,7 +146,7 @@ template <int NB, bool U8, int TPI>
 __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
-    uint32_t nqg, u32x4* __restrict__ partials16) {
+    uint32_t nqg, bool stream_once, u32x4* __restrict__ partials16) {
 	static_assert(NB >= 2 && NB <= 8 && (TPI == 1 || TPI == 2), "ring depth, tiles per step");
 	constexpr int TQ = 4;
 	constexpr int D = NB - 1;                 // steps in flight ahead of the one being scored
@@ -190,12 +201,13 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
 	const uint64_t src_off = (uint64_t)s * kStepBytes + wib * kPieceBytes;
 	const uint32_t lane16 = lane * 16u;
+	// stream_once (host: a single query group, nobody else will want these candidate bytes from L2): nontemporal loads
 	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
 		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;      // past the end: re-fetch the last step (keeps the count fixed)
 		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
 		const uint64_t base = (uint64_t)cand_dg + (uint64_t)slot * slot_bytes + src_off;      // wave-uniform: scalar arithmetic
 #pragma unroll
-		for (int u = 0; u < TPI; u++) dma_piece(base + u * kTileBytes, lane16, ring_lds + slot_idx * kStepBytes + u * kTileBytes);
+		for (int u = 0; u < TPI; u++) dma_piece(base + u * kTileBytes, lane16, ring_lds + slot_idx * kStepBytes + u * kTileBytes, stream_once);
 	};
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
@@ -279,8 +291,9 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 	if (G > m) G = m;
 	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
+	static const bool no_nt = getenv("MSC_DIGEST_NO_NT") != nullptr;
 	k_pair_digest_multi<NB, U8, TPI><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
-	                                                                            (u32x4*)partials16);
+	                                                                            nqg == 1 && !no_nt, (u32x4*)partials16);
 	return hipGetLastError();
 }
 

@@ -13,9 +13,13 @@ namespace {
 constexpr int kBlock = 256, kWaves = 4;
 constexpr uint32_t kTileBytes = 4096, kPieceBytes = 1024;
 
+template <bool NT>
 __device__ __forceinline__ void dma_piece(const uint8_t* lane_src, uint32_t lds_dst) {
 	uint32_t keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_src), "s"(lds_dst) : "memory");
+	if constexpr (NT)
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_src), "s"(lds_dst) : "memory");
+	else
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(lane_src), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
@@ -51,29 +55,29 @@ __global__ void __launch_bounds__(kBlock, WPS) k_exp(const uint8_t* __restrict__
 	const uint64_t src_off = (uint64_t)s * kTileBytes + wib * kPieceBytes + lane * 16u;
 	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
 		const uint32_t cand = g + (it < n_iter ? it : n_iter - 1) * G;
-		dma_piece(cand_dg + (uint64_t)cand * slot_bytes + src_off, ring_lds + slot_idx * kTileBytes);
+		dma_piece<(EXP >= 10)>(cand_dg + (uint64_t)cand * slot_bytes + src_off, ring_lds + slot_idx * kTileBytes);
 	};
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
 	const uint32_t row = lane >> 4;
 	const uint32_t jrow = ((row & 1) << 1) | (row >> 1);
 	const bool owner = (lane & 15) == 15;
-	u32x4* out_ptr = EXP == 6 ? partials16 + ((uint64_t)g * S + s) * 16 + q0 + jrow : partials16 + ((uint64_t)(q0 + jrow) * m + g) * S + s;
-	const uint64_t out_step = EXP == 6 ? (uint64_t)G * S * 16 : (uint64_t)G * S;
+	u32x4* out_ptr = (EXP == 6 || EXP == 10) ? partials16 + ((uint64_t)g * S + s) * 16 + q0 + jrow : partials16 + ((uint64_t)(q0 + jrow) * m + g) * S + s;
+	const uint64_t out_step = (EXP == 6 || EXP == 10) ? (uint64_t)G * S * 16 : (uint64_t)G * S;
 	// EXP 5: after the folded reduction lane (16*r + 4*t + 3) of row r holds value t (0 manh, 1 dot, 2 emd) of query jrow(r)... see below
 	const uint32_t bank = (lane >> 2) & 3;                 // record word: bank 0 manh -> 0, bank 1 emd -> 2, bank 2 dot -> 1
 	uint32_t* out32 = reinterpret_cast<uint32_t*>(partials16 + ((uint64_t)(q0 + jrow) * m + g) * S + s) + (bank == 0 ? 0 : bank == 1 ? 2 : 1);
 	const bool owner5 = (lane & 3) == 0 && bank < 3;
 	uint32_t rd = 0, wr = D % NB;
 	for (uint32_t it = 0; it < n_iter; it++) {
-		constexpr int STORES = (EXP == 3 || EXP == 4) ? 0 : 1;
+		constexpr int STORES = (EXP == 3 || EXP == 4 || EXP == 14) ? 0 : 1;
 		if (it >= (uint32_t)D) wait_vm<D - 1 + D * STORES>(); else wait_vm<D - 1>();
 		if constexpr (EXP != 2) __builtin_amdgcn_s_barrier();
 		fetch(it + D, wr);
 		wr = wr + 1 == NB ? 0 : wr + 1;
 		const u32x4* sl = reinterpret_cast<const u32x4*>(s_ring + rd * kTileBytes) + lane;
 		const u32x4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
-		if constexpr (EXP == 4) {
+		if constexpr (EXP == 4 || EXP == 14) {
 			u32x4 t = v0 + v1 + v2 + v3;
 			if (t.x == 0x12345678u && t.y == 77u) out_ptr[0] = t;      // practically never
 		} else {
@@ -182,6 +186,10 @@ int main(int argc, char** argv) {
 	run<8, 4, 1>("no arithmetic (DMA+barrier+LDS reads)", cand, q, m, partials);
 	run<4, 6, 1>("records [cand][tile][query]: 256 B runs", cand, q, m, partials);
 	run<8, 6, 1>("records [cand][tile][query]: 256 B runs", cand, q, m, partials);
+	run<4, 10, 1>("256 B runs + nt loads", cand, q, m, partials);
+	run<8, 10, 1>("256 B runs + nt loads", cand, q, m, partials);
+	run<4, 14, 1>("no arithmetic + nt loads", cand, q, m, partials);
+	run<8, 14, 1>("no arithmetic + nt loads", cand, q, m, partials);
 	run<4, 5, 1>("folded DPP reduction, dword stores", cand, q, m, partials);
 	run<8, 5, 1>("folded DPP reduction, dword stores", cand, q, m, partials);
 	return 0;
