@@ -262,6 +262,22 @@ int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg,
 int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m,
                      int64_t* nearest_pos, double* dist_out, double* mean_out);
 
+/* The whole update stage of one mean-shift round in three launches: for centre c (slot centre_slots[c] of `centres`) and its
+ * neighbourhood list pt_slots[offsets[c] .. offsets[c+1]) of `pts`: Trainer::filter, the FP64 mean of the survivors and
+ * the survivor nearest that mean -- mean_shift_update, cluster/ClusterFactory.cpp:288-335, which the reference runs for all
+ * centres of a round under `omp parallel for` (:639). nearest_pos[c] = position INSIDE centre c's list of the new centre
+ * point, or -1 when nothing survives the filter; n_kept[c] (nullable) = survivors. Same results as msc_filter followed by
+ * msc_mean_nearest per centre (which is also what runs for sparse sets, divergence statistics and the wide range). */
+int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                       uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
+                       uint64_t* n_kept);
+
+/* Every Trainer::merge call of the serial merge loop (cluster/ClusterFactory.cpp:383-401: centre i against centres i+1 ..
+ * min(n-1, i+delta), i = 0 .. n-1) in one launch; best_out[i] = what msc_merge returns for (current = i, begin = i + 1,
+ * last = min(n - 1, i + delta)). No merge call changes a histogram, so the calls are independent. */
+int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+                  int delta, int64_t* best_out);
+
 /* ------------------------------------------------------------------ multi-GPU plumbing
  * Raw device views so that a caller that owns an RCCL communicator (torch.distributed / rccl.h) can broadcast a
  * query or all-gather centroid histograms between the per-GPU processes without a host bounce.

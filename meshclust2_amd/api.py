@@ -314,6 +314,26 @@ class Trainer:
         self.ctx.check(self.ctx.lib.msc_merge(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(sl), n, current, begin, last, C.byref(out)))
         return out.value
 
+    def merge_all(self, centres, centre_slots, delta):
+        """every Trainer::merge call of ClusterFactory's merge loop at once -> best[n] (what merge(i, i+1, min(n-1, i+delta)) returns)"""
+        sl = np.ascontiguousarray(centre_slots, dtype=np.uint32)
+        best = np.zeros(sl.size, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.msc_merge_all(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(sl), sl.size, int(delta), _ptr(best)))
+        return best
+
+    def update_centres(self, centres, centre_slots, points, lists):
+        """mean_shift_update for many centres: lists[c] = point slots of centre c's neighbourhood.
+        -> (nearest_pos[n] (position inside lists[c], -1 if nothing survives the filter), n_kept[n])"""
+        cs = np.ascontiguousarray(centre_slots, dtype=np.uint32)
+        offsets = np.zeros(cs.size + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(x) for x in lists])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists]) if len(lists) else np.zeros(0), dtype=np.uint32)
+        nearest = np.zeros(cs.size, dtype=np.int64)
+        kept = np.zeros(cs.size, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.msc_update_centres(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(cs), cs.size, points.h, _ptr(flat), _ptr(offsets),
+                                                       _ptr(nearest), _ptr(kept)))
+        return nearest, kept
+
     def closest(self, points, member_slots, m=None, want_mean=False):
         """get_mean / closest: -> (nearest_pos, dists[m], mean or None)"""
         sl, m = _slots(member_slots, m)

@@ -43,6 +43,8 @@ struct msc_ctx {
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
 	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
+	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
+	DevBuf segs, pair_seg, dist;
 	uint64_t sp_acc_bins = 0;
 };
 
@@ -156,6 +158,10 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
+	if (ctx->batch_scratch) msc_hist_set_destroy(ctx->batch_scratch);
+	release(ctx->segs);
+	release(ctx->pair_seg);
+	release(ctx->dist);
 	release(ctx->sp_counts);
 	release(ctx->sp_cumbase);
 	release(ctx->sp_acc);
@@ -1594,5 +1600,305 @@ extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uin
 	float t = 0;
 	if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = 1; ctx->have_timing = true; }
 	*nearest_pos = ro.best_pos;
+	return MSC_OK;
+}
+
+// ================================================================================================ batched update stage
+// mean_shift_update for MANY centres in three launches instead of ~6 launches and ~5 host round trips per centre
+// (cluster/ClusterFactory.cpp:288-335; the reference runs the centres of a round under `omp parallel for`, :639, so they are
+// independent by construction): Trainer::filter of every centre's neighbourhood list, the FP64 mean of the survivors, and the
+// survivor nearest that mean (Trainer::closest). Results are those of msc_filter + msc_mean_nearest per centre.
+static int update_centres_one_by_one(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                                     uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
+                                     uint64_t* n_kept) {
+	std::vector<uint8_t> keep;
+	std::vector<uint32_t> kept;
+	std::vector<uint64_t> where;
+	for (uint64_t c = 0; c < n_centres; c++) {
+		const uint64_t m = offsets[c + 1] - offsets[c];
+		keep.assign(m, 0);
+		uint64_t n = 0;
+		int r = msc_filter(ctx, model, cutoff, centres, centre_slots[c], pts, pt_slots + offsets[c], m, keep.data(), &n);
+		if (r) return r;
+		kept.clear();
+		where.clear();
+		for (uint64_t i = 0; i < m; i++) if (keep[i]) { kept.push_back(pt_slots[offsets[c] + i]); where.push_back(i); }
+		if (n_kept) n_kept[c] = kept.size();
+		nearest_pos[c] = -1;
+		if (!kept.empty()) {
+			int64_t pos = -1;
+			if ((r = msc_mean_nearest(ctx, pts, kept.data(), kept.size(), &pos, nullptr, nullptr))) return r;
+			nearest_pos[c] = (int64_t)where[(size_t)pos];
+		}
+	}
+	return MSC_OK;
+}
+
+extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                                  uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
+                                  uint64_t* n_kept) {
+	if (!ctx || !model || model->ctx != ctx || !centres || !pts || centres->ctx != ctx || pts->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (n_centres == 0) return MSC_OK;
+	if (!centre_slots || !offsets || !nearest_pos) return MSC_ERR_INVALID_ARG;
+	if (centres->k != pts->k || centres->dtype != pts->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k or dtype");
+	const uint64_t total = offsets[n_centres];
+	if (total && !pt_slots) return MSC_ERR_INVALID_ARG;
+	for (uint64_t c = 0; c < n_centres; c++) {
+		if (centre_slots[c] >= centres->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "centre slot out of range");
+		if (offsets[c + 1] < offsets[c] || offsets[c + 1] - offsets[c] > 0x7fffffffull) return fail(ctx, MSC_ERR_INVALID_ARG, "offsets must be non-decreasing");
+	}
+	for (uint64_t i = 0; i < total; i++) if (pt_slots[i] >= pts->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "point slot out of range");
+	uint64_t want = 0;
+	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
+	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
+	if (no_batch || pts->sparse || centres->sparse || (want & MSC_FEAT_DIV) || needs_wide(pts, centres))
+		return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
+
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const MscLayout& L = pts->L;
+	int r;
+	// lengths of every centre slot in one strided copy (Trainer::filter's window is relative to the centre's length)
+	std::vector<uint64_t> clen(centres->capacity);
+	HIP_TRY(ctx, hipMemcpy2DAsync(clen.data(), 8, centres->scalars + offsetof(MscSlotScalars, length), centres->scalar_stride, 8, centres->capacity,
+	                              hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const double id = trainer_get_id(cutoff);
+	// chunks of centres: their rounded means share one scratch set (<= 4 GiB) and their pair counts stay 32-bit
+	const uint64_t max_chunk_centres = std::max<uint64_t>(1, (4096ull << 20) / L.slot_bytes);
+	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)L.S * sizeof(MscPartial)));
+	std::vector<MscBatchSeg> segs;
+	std::vector<uint32_t> pair_seg, members, where;
+	std::vector<uint8_t> keep;
+	std::vector<double> dist;
+	for (uint64_t c0 = 0; c0 < n_centres;) {
+		uint64_t c1 = c0;
+		while (c1 < n_centres && c1 - c0 < max_chunk_centres && (c1 == c0 || offsets[c1 + 1] - offsets[c0] <= max_chunk_pairs)) c1++;
+		const uint64_t nc = c1 - c0, base = offsets[c0], P = offsets[c1] - base;
+		// ---- 1. filter: every centre against its list
+		segs.resize(nc);
+		pair_seg.resize(P);
+		uint32_t max_m = 0;
+		for (uint64_t c = c0; c < c1; c++) {
+			MscBatchSeg& sg = segs[c - c0];
+			sg.q_slot = centre_slots[c];
+			sg.first = (uint32_t)(offsets[c] - base);
+			sg.m = (uint32_t)(offsets[c + 1] - offsets[c]);
+			sg.pad_ = 0;
+			const uint64_t len = clen[centre_slots[c]];
+			sg.min_len = (uint64_t)((double)len * id);      // cluster/Trainer.cpp:126-127
+			sg.max_len = (uint64_t)((double)len / id);
+			max_m = std::max(max_m, sg.m);
+			for (uint32_t i = 0; i < sg.m; i++) pair_seg[sg.first + i] = (uint32_t)(c - c0);
+		}
+		keep.assign(P, 0);
+		if (P) {
+			if ((r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) || (r = ensure(ctx, ctx->pair_seg, P * sizeof(uint32_t))) ||
+			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * L.S * sizeof(MscPartial))) ||
+			    (r = ensure(ctx, ctx->soa_close, P)) || (r = ensure(ctx, ctx->err_word, sizeof(int32_t))))
+				return r;
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, pt_slots + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
+			                                         (uint32_t)nc, max_m, centres->bins, centres->L.slot_bytes, centres->scalars, centres->scalar_stride, 1,
+			                                         (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST));
+			MscEpilogueArgs ea;
+			memset(&ea, 0, sizeof ea);
+			ea.partials = (const MscPartial*)ctx->partials.p;
+			ea.S = L.S;
+			ea.m = (uint32_t)P;
+			ea.cand_scalars = pts->scalars;
+			ea.cand_scalar_stride = pts->scalar_stride;
+			ea.cand_slots = (const uint32_t*)ctx->slots.p;
+			ea.q_scalars = centres->scalars;
+			ea.qset_scalars = centres->scalars;
+			ea.q_scalar_stride = centres->scalar_stride;
+			ea.nbins = L.nbins;
+			ea.dtype = pts->dtype;
+			ea.order = MSC_ORDER_QUERY_FIRST;      // classify(p, pt.first), cluster/Trainer.cpp:133
+			ea.use_window = 1;
+			ea.model = model->d;
+			ea.close_soa = (uint8_t*)ctx->soa_close.p;
+			ea.error_word = (int32_t*)ctx->err_word.p;
+			ea.segs = (const MscBatchSeg*)ctx->segs.p;
+			ea.pair_seg = (const uint32_t*)ctx->pair_seg.p;
+			HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+			int32_t first_err = 0;
+			HIP_TRY(ctx, hipMemcpyAsync(keep.data(), ctx->soa_close.p, P, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+			if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+			if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+		}
+		// ---- 2. survivors per centre
+		members.clear();
+		where.clear();
+		pair_seg.clear();
+		uint32_t max_m2 = 0;
+		for (uint64_t c = c0; c < c1; c++) {
+			MscBatchSeg& sg = segs[c - c0];
+			const uint32_t first_old = sg.first, m_old = sg.m;
+			sg.q_slot = (uint32_t)(c - c0);               // slot of this centre's rounded mean in the scratch set
+			sg.first = (uint32_t)members.size();
+			for (uint32_t i = 0; i < m_old; i++)
+				if (keep[first_old + i]) { members.push_back(pt_slots[base + first_old + i]); where.push_back(i); pair_seg.push_back((uint32_t)(c - c0)); }
+			sg.m = (uint32_t)members.size() - sg.first;
+			sg.min_len = 0;
+			sg.max_len = ~0ull;
+			max_m2 = std::max(max_m2, sg.m);
+			if (n_kept) n_kept[c] = sg.m;
+			nearest_pos[c] = -1;
+		}
+		const uint64_t P2 = members.size();
+		if (P2 == 0) { c0 = c1; continue; }
+		// ---- 3. means of the survivors (exact integer column sums), rounded means as slots of a scratch set, distance_d of every survivor
+		if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc) {
+			if (ctx->batch_scratch) { msc_hist_set_destroy(ctx->batch_scratch); ctx->batch_scratch = nullptr; }
+			if ((r = msc_hist_set_create(ctx, pts->k, pts->dtype, std::min<uint64_t>(max_chunk_centres, std::max<uint64_t>(nc, 256)), &ctx->batch_scratch))) return r;
+		}
+		msc_hist_set* rs = ctx->batch_scratch;
+		if ((r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) ||
+		    (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P2 * L.S * sizeof(MscPartial))) ||
+		    (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
+			return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_colsum_batch(ctx->stream, L, pts->dtype, pts->bins, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc,
+		                                     rs->bins, (uint64_t*)ctx->floor_sum.p));
+		HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, rs->scalar_stride * nc, ctx->stream));
+		HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, pts->dtype, 0, nc, false));
+		HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
+		                                         (uint32_t)nc, max_m2, rs->bins, rs->L.slot_bytes, rs->scalars, rs->scalar_stride, 0, (MscPartial*)ctx->partials.p,
+		                                         MSC_ORDER_CAND_FIRST));
+		HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)P2, pts->scalars, pts->scalar_stride,
+		                                       (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, rs->scalars, rs->scalar_stride,
+		                                       (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
+		dist.resize(P2);
+		HIP_TRY(ctx, hipMemcpyAsync(dist.data(), ctx->dist.p, P2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		// first minimum wins (cluster/Trainer.cpp:150-153)
+		for (uint64_t c = c0; c < c1; c++) {
+			const MscBatchSeg& sg = segs[c - c0];
+			if (sg.m == 0) continue;
+			uint32_t best = 0;
+			for (uint32_t i = 1; i < sg.m; i++) if (dist[sg.first + i] < dist[sg.first + best]) best = i;
+			nearest_pos[c] = (int64_t)where[sg.first + best];
+		}
+		c0 = c1;
+	}
+	return MSC_OK;
+}
+
+// Trainer::merge for EVERY centre of the serial merge loop in one launch (cluster/ClusterFactory.cpp:383-401 calls
+// trn.merge(centers, i, i + 1, min(n - 1, i + delta)) for i = 0 .. n-1; no call changes a histogram, so the calls are independent).
+// best_out[i] = what msc_merge(..., current = i, begin = i + 1, last = min(n - 1, i + delta)) returns.
+extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+                             int delta, int64_t* best_out) {
+	if (!ctx || !model || model->ctx != ctx || !centres || centres->ctx != ctx || (n && (!centre_slots || !best_out)) || delta < 0) return MSC_ERR_INVALID_ARG;
+	if (n == 0) return MSC_OK;
+	for (uint64_t i = 0; i < n; i++) if (centre_slots[i] >= centres->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "centre slot out of range");
+	uint64_t want = 0;
+	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
+	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
+	if (no_batch || centres->sparse || (want & MSC_FEAT_DIV) || needs_wide(centres, centres) || n > 0x7fffffffull) {
+		for (uint64_t i = 0; i < n; i++) {
+			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[i]);
+			if (r) return r;
+		}
+		return MSC_OK;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const MscLayout& L = centres->L;
+	int r;
+	std::vector<uint64_t> clen(centres->capacity);
+	HIP_TRY(ctx, hipMemcpy2DAsync(clen.data(), 8, centres->scalars + offsetof(MscSlotScalars, length), centres->scalar_stride, 8, centres->capacity,
+	                              hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const double id = trainer_get_id(cutoff);
+	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)L.S * sizeof(MscPartial)));
+	std::vector<MscBatchSeg> segs;
+	std::vector<uint32_t> pair_seg, cand;
+	std::vector<MscPairOut> po;
+	for (uint64_t c0 = 0; c0 < n;) {
+		segs.clear(); pair_seg.clear(); cand.clear();
+		uint64_t c1 = c0;
+		uint32_t max_m = 0;
+		while (c1 < n && (c1 == c0 || cand.size() + (uint64_t)delta <= max_chunk_pairs)) {
+			MscBatchSeg sg;
+			sg.q_slot = centre_slots[c1];
+			sg.first = (uint32_t)cand.size();
+			const uint64_t last = std::min<uint64_t>(n - 1, c1 + (uint64_t)delta);
+			for (uint64_t j = c1 + 1; j <= last; j++) { cand.push_back(centre_slots[j]); pair_seg.push_back((uint32_t)(c1 - c0)); }
+			sg.m = (uint32_t)cand.size() - sg.first;
+			sg.pad_ = 0;
+			const uint64_t len = clen[centre_slots[c1]];
+			sg.min_len = (uint64_t)((double)len * id);      // cluster/Trainer.cpp:80-81
+			sg.max_len = (uint64_t)((double)len / id);
+			max_m = std::max(max_m, sg.m);
+			segs.push_back(sg);
+			c1++;
+		}
+		const uint64_t nc = c1 - c0, P = cand.size();
+		for (uint64_t i = c0; i < c1; i++) best_out[i] = 0;
+		if (P) {
+			if ((r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) || (r = ensure(ctx, ctx->pair_seg, P * sizeof(uint32_t))) ||
+			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * L.S * sizeof(MscPartial))) ||
+			    (r = ensure(ctx, ctx->pair_out, P * sizeof(MscPairOut))) || (r = ensure(ctx, ctx->err_word, sizeof(int32_t))))
+				return r;
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, centres->dtype, centres->bins, centres->scalars, (const uint32_t*)ctx->slots.p,
+			                                         (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc, max_m, centres->bins, L.slot_bytes, centres->scalars,
+			                                         centres->scalar_stride, 1, (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST));
+			MscEpilogueArgs ea;
+			memset(&ea, 0, sizeof ea);
+			ea.partials = (const MscPartial*)ctx->partials.p;
+			ea.S = L.S;
+			ea.m = (uint32_t)P;
+			ea.cand_scalars = centres->scalars;
+			ea.cand_scalar_stride = centres->scalar_stride;
+			ea.cand_slots = (const uint32_t*)ctx->slots.p;
+			ea.q_scalars = centres->scalars;
+			ea.qset_scalars = centres->scalars;
+			ea.q_scalar_stride = centres->scalar_stride;
+			ea.nbins = L.nbins;
+			ea.dtype = centres->dtype;
+			ea.order = MSC_ORDER_CAND_FIRST;       // feat->compute(*cen, *p), cluster/Trainer.cpp:93
+			ea.use_window = 1;
+			ea.model = model->d;
+			ea.pair_out = (MscPairOut*)ctx->pair_out.p;
+			ea.error_word = (int32_t*)ctx->err_word.p;
+			ea.segs = (const MscBatchSeg*)ctx->segs.p;
+			ea.pair_seg = (const uint32_t*)ctx->pair_seg.p;
+			HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+			po.resize(P);
+			int32_t first_err = 0;
+			HIP_TRY(ctx, hipMemcpyAsync(po.data(), ctx->pair_out.p, P * sizeof(MscPairOut), hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+			if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+			if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+			// best = best.second > dist ? best : (i, dist), from (0, DBL_MIN): among in-window centres that classify close, the
+			// largest combo 0, the LATER index on ties (cluster/Trainer.cpp:79-105)
+			for (uint64_t c = c0; c < c1; c++) {
+				const MscBatchSeg& sg = segs[c - c0];
+				double best_sim = 2.2250738585072014e-308;
+				int64_t best = 0;
+				for (uint32_t i = 0; i < sg.m; i++) {
+					const MscPairOut& p = po[sg.first + i];
+					if (p.status != 0 || !p.close) continue;
+					if (!(best_sim > p.combo0)) { best_sim = p.combo0; best = (int64_t)(c + 1 + i); }
+				}
+				best_out[c] = best;
+			}
+		}
+		c0 = c1;
+	}
 	return MSC_OK;
 }

@@ -33,6 +33,13 @@ struct MscDevModel {
 	double   bias;
 };
 
+// One 1 x M problem of a batched launch (k_pair_tiles_batch, k_colsum_batch): query slot, its candidates' positions in the
+// concatenated slot list, and the length window of Trainer::filter (ignored when the launch does not use a window).
+struct MscBatchSeg {
+	uint32_t q_slot, first, m, pad_;
+	uint64_t min_len, max_len;
+};
+
 // One partial record per (candidate, tile): integer reductions of the streaming pass.
 struct MscPartial {
 	uint64_t manh;   // sum |p - q|
@@ -94,6 +101,9 @@ struct MscEpilogueArgs {
 	double*  csum_soa;
 	uint8_t* close_soa;
 	int32_t* error_word;              // atomicMin of negative statuses
+	// batched launch (k_pair_tiles_batch): candidate c belongs to segment pair_seg[c]; query slot and window come from it
+	const MscBatchSeg* segs;
+	const uint32_t* pair_seg;
 	uint64_t sparse_base;             // 4^k when the partials come from k_pair_sparse (sums over the union only), else 0
 };
 
@@ -169,3 +179,13 @@ hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uin
                                  const uint8_t* scalars, uint64_t scalar_stride, const uint32_t* member_slots,
                                  const uint8_t* r_scalars, const uint64_t* floor_sum, double* dist_out,
                                  MscReduceOut* out);
+// batched forms for msc_update_centres: one (query, candidate list) problem per segment
+hipError_t msc_launch_pair_tiles_batch(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                       const uint32_t* cand_slots, const MscBatchSeg* segs, uint32_t n_segs, uint32_t max_m, const uint8_t* qset_bins,
+                                       uint64_t q_slot_bytes, const uint8_t* qset_scalars, uint64_t q_scalar_stride, int use_window, MscPartial* partials,
+                                       int order);
+hipError_t msc_launch_colsum_batch(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots, const MscBatchSeg* segs,
+                                   uint32_t n_segs, void* rounded_out, uint64_t* floor_sum_out);
+hipError_t msc_launch_distance_batch(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t n, const uint8_t* scalars, uint64_t scalar_stride,
+                                     const uint32_t* member_slots, const uint32_t* pair_seg, const uint8_t* r_scalars, uint64_t r_stride, const uint64_t* floor_sum,
+                                     double* dist_out);

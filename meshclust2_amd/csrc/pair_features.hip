@@ -133,13 +133,15 @@ struct MscPartialDiv {
 	double jd, js;
 };
 
+// body shared by the 1 x M kernel and its batched form (one list of candidates per query, k_pair_tiles_batch); W = the wave's
+// index inside its own (query, candidate list) problem
 template <typename T, int LPT, bool PADDED, int TB>
-__global__ void __launch_bounds__(kBlock) k_pair_tiles(
+__device__ __forceinline__ void pair_tiles_body(
     const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
     const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_bins, const uint8_t* __restrict__ q_scalars,
     uint32_t S, uint32_t G, uint32_t nvalid /* bins of the (single) tile that are real */,
     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials,
-    const DivTerm* __restrict__ div_tables, MscPartialDiv* __restrict__ div_partials, int order) {
+    const DivTerm* __restrict__ div_tables, MscPartialDiv* __restrict__ div_partials, int order, uint32_t W) {
 	constexpr int E = 16 / sizeof(T);
 	constexpr int R = LPT * E;
 	constexpr uint32_t tile_bytes = 1024u * LPT;
@@ -150,7 +152,6 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave_in_block = threadIdx.x >> 6;
-	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave_in_block);
 	const uint32_t s = W % S;
 	const uint32_t g = W / S;
 	if (g >= G) return;
@@ -284,6 +285,34 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles(
 			if constexpr (DIV) div_partials[(uint64_t)c * S + s] = MscPartialDiv{jd, js};
 		}
 	}
+}
+
+template <typename T, int LPT, bool PADDED, int TB>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_bins, const uint8_t* __restrict__ q_scalars,
+    uint32_t S, uint32_t G, uint32_t nvalid, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials,
+    const DivTerm* __restrict__ div_tables, MscPartialDiv* __restrict__ div_partials, int order) {
+	const uint32_t W = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	pair_tiles_body<T, LPT, PADDED, TB>(cand_bins, slot_bytes, cand_scalars, scalar_stride, cand_slots, m, q_bins, q_scalars, S, G, nvalid, use_window, min_len,
+	                                    max_len, partials, div_tables, div_partials, order, W);
+}
+
+// Many small 1 x M problems in one launch (the update stage of the mean-shift driver: every centre against the points of
+// its neighbouring clusters, cluster/ClusterFactory.cpp:288-335). Segment i = {query slot, first candidate, count, window};
+// `bps` consecutive workgroups serve one segment. Partials are indexed by the candidate's position in the concatenated list.
+template <typename T, int LPT, bool PADDED>
+__global__ void __launch_bounds__(kBlock) k_pair_tiles_batch(
+    const uint8_t* __restrict__ cand_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, const MscBatchSeg* __restrict__ segs, uint32_t bps, const uint8_t* __restrict__ qset_bins,
+    uint64_t q_slot_bytes, const uint8_t* __restrict__ qset_scalars, uint64_t q_scalar_stride, uint32_t S, uint32_t G, uint32_t nvalid,
+    int use_window, MscPartial* __restrict__ partials, int order) {
+	const MscBatchSeg seg = segs[blockIdx.x / bps];
+	if (seg.m == 0) return;
+	const uint32_t W = __builtin_amdgcn_readfirstlane((blockIdx.x % bps) * kWavesPerBlock + (threadIdx.x >> 6));
+	pair_tiles_body<T, LPT, PADDED, 0>(cand_bins, slot_bytes, cand_scalars, scalar_stride, cand_slots + seg.first, seg.m, qset_bins + (uint64_t)seg.q_slot * q_slot_bytes,
+	                                   qset_scalars + (uint64_t)seg.q_slot * q_scalar_stride, S, G < seg.m ? G : seg.m, nvalid, use_window, seg.min_len, seg.max_len,
+	                                   partials + (uint64_t)seg.first * S, nullptr, nullptr, order, W);
 }
 
 // ---------------------------------------------------------------------------------------- wide (64-bit) streaming kernel
@@ -859,9 +888,16 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
 	const uint32_t slot = a.cand_slots ? a.cand_slots[ci] : ci;
 	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride);
+	uint64_t min_len = a.min_len, max_len = a.max_len;
 	const MscSlotScalars* qs = a.n_queries > 1
 	    ? reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)a.q_slots[qi] * a.q_scalar_stride)
 	    : reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
+	if (a.segs) {
+		const MscBatchSeg sg = a.segs[a.pair_seg[c]];
+		qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)sg.q_slot * a.q_scalar_stride);
+		min_len = sg.min_len;
+		max_len = sg.max_len;
+	}
 	Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
 	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
@@ -879,7 +915,7 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 
 	MscPairOut po;
 	po.sum = NAN; po.csum = NAN; po.combo0 = NAN; po.status = 0; po.close = 0;
-	const bool skipped = a.use_window && (cand.len < a.min_len || cand.len > a.max_len);
+	const bool skipped = a.use_window && (cand.len < min_len || cand.len > max_len);
 	int nf = __popcll(a.feat_mask);
 	if (skipped) {
 		po.status = 1;
@@ -1155,6 +1191,65 @@ __global__ void __launch_bounds__(kBlock) k_colsum(const T* __restrict__ bins, u
 	if ((threadIdx.x & 63) == 0 && fl) atomicAdd(floor_sum, fl);
 }
 
+// k_colsum for many member lists at once: `cpb` consecutive workgroups serve segment i (members = member_slots[first .. first+m)),
+// whose rounded mean goes to slot i of `rounded` and whose floor sum to floor_sum[i] (zeroed by the caller).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_colsum_batch(const T* __restrict__ bins, uint64_t slot_elems, const uint32_t* __restrict__ member_slots,
+                                                         const MscBatchSeg* __restrict__ segs, uint32_t cpb, uint64_t padded, uint64_t nbins, uint32_t R,
+                                                         T* __restrict__ rounded, unsigned long long* __restrict__ floor_sum) {
+	constexpr uint32_t E = 16 / sizeof(T);
+	const uint32_t si = blockIdx.x / cpb;
+	const MscBatchSeg seg = segs[si];
+	if (seg.m == 0) return;
+	const uint64_t chunk = (uint64_t)(blockIdx.x % cpb) * blockDim.x + threadIdx.x;
+	unsigned long long fl = 0;
+	if (chunk * E < padded) {
+		uint64_t acc[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) acc[j] = 0;
+		for (uint32_t i = 0; i < seg.m; i++) {
+			const uint32_t slot = member_slots[seg.first + i];
+			const uint4 v = *reinterpret_cast<const uint4*>(bins + (uint64_t)slot * slot_elems + chunk * E);
+			const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+			for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+		}
+		const uint32_t tile_bins = 64 * R;
+		const uint64_t tile = (chunk * E) / tile_bins;
+		const uint32_t in_tile = (uint32_t)((chunk * E) % tile_bins);
+		const uint32_t t = in_tile / (64 * E), lane = (in_tile % (64 * E)) / E;
+		T rv[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) {
+			const uint64_t logical = tile * tile_bins + (uint64_t)lane * R + t * E + j;
+			const double mean = (double)acc[j] / (double)seg.m;
+			rv[j] = (T)round(mean);
+			if (logical < nbins) fl += (unsigned long long)floor(mean);
+		}
+		*reinterpret_cast<uint4*>(rounded + (uint64_t)si * slot_elems + chunk * E) = *reinterpret_cast<const uint4*>(rv);
+	}
+	fl = shfl_sum_u64(fl);
+	if ((threadIdx.x & 63) == 0 && fl) atomicAdd(floor_sum + si, fl);
+}
+
+// distance_d of every member to the rounded mean of ITS segment (see k_distance_d); the per-segment arg-min is left to the host
+__global__ void __launch_bounds__(kBlock) k_distance_batch(const MscPartial* __restrict__ partials, uint32_t S, uint32_t n, const uint8_t* __restrict__ scalars,
+                                                           uint64_t scalar_stride, const uint32_t* __restrict__ member_slots, const uint32_t* __restrict__ pair_seg,
+                                                           const uint8_t* __restrict__ r_scalars, uint64_t r_stride, const uint64_t* __restrict__ floor_sum,
+                                                           double* __restrict__ dist_out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint64_t manh = 0;
+	for (uint32_t s = 0; s < S; s++) manh += partials[(uint64_t)i * S + s].manh;
+	const uint32_t sg = pair_seg[i];
+	const MscSlotScalars* ps = reinterpret_cast<const MscSlotScalars*>(scalars + (uint64_t)member_slots[i] * scalar_stride);
+	const MscSlotScalars* rs = reinterpret_cast<const MscSlotScalars*>(r_scalars + (uint64_t)sg * r_stride);
+	const uint64_t dist = ps->sum + rs->sum - manh;
+	const uint64_t mag = ps->sum + floor_sum[sg];
+	const double frac = (double)dist / (double)mag;
+	dist_out[i] = 10000.0 * (1.0 - frac * frac);
+}
+
 }  // namespace
 
 // ======================================================================================== launchers
@@ -1414,5 +1509,69 @@ hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uin
                                  const uint64_t* floor_sum, double* dist_out, MscReduceOut* out) {
 	hipLaunchKernelGGL(k_distance_d, dim3(1), dim3(1024), 0, st, partials, S, m, scalars, scalar_stride, member_slots, r_scalars,
 	                   floor_sum, dist_out, out);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- batched launchers (msc_update_centres)
+bool msc_batch_tiles_supported(const MscLayout& L, int dtype) { (void)L; return dtype == 8 || dtype == 16 || dtype == 32 || dtype == 64; }
+
+template <typename T>
+static hipError_t launch_tiles_batch_t(hipStream_t st, const MscLayout& L, const uint8_t* cb, const uint8_t* cs, const uint32_t* sl, const MscBatchSeg* segs,
+                                       uint32_t n_segs, uint32_t max_m, const uint8_t* qb, uint64_t qsb, const uint8_t* qs, uint64_t qss, int use_window,
+                                       MscPartial* partials, int order) {
+	const uint32_t S = L.S;
+	// short lists: a few candidate groups per segment are enough to cover the latency; every segment gets the same grid slice
+	uint32_t G = max_m < 4 ? (max_m ? max_m : 1) : 4;
+	const uint32_t bps = (S * G + kWavesPerBlock - 1) / kWavesPerBlock;
+	const bool padded = L.nbins < L.padded_bins;
+	const uint64_t stride = msc_scalar_stride(S);
+	const uint32_t nvalid = padded ? (uint32_t)L.nbins : L.tile_bins;
+	const dim3 grid((unsigned)((uint64_t)n_segs * bps));
+#define MSC_TB(LPTV, PAD) k_pair_tiles_batch<T, LPTV, PAD><<<grid, dim3(kBlock), 0, st>>>(cb, L.slot_bytes, cs, stride, sl, segs, bps, qb, qsb, qs, qss, S, G, nvalid, use_window, partials, order)
+	switch (L.LPT) {
+	case 1: if (padded) MSC_TB(1, true); else MSC_TB(1, false); break;
+	case 2: if (padded) MSC_TB(2, true); else MSC_TB(2, false); break;
+	default: if (padded) MSC_TB(4, true); else MSC_TB(4, false); break;
+	}
+#undef MSC_TB
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_pair_tiles_batch(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* cand_bins, const uint8_t* cand_scalars,
+                                       const uint32_t* cand_slots, const MscBatchSeg* segs, uint32_t n_segs, uint32_t max_m, const uint8_t* qset_bins,
+                                       uint64_t q_slot_bytes, const uint8_t* qset_scalars, uint64_t q_scalar_stride, int use_window, MscPartial* partials,
+                                       int order) {
+	if (n_segs == 0) return hipSuccess;
+	switch (dtype) {
+	case 8: return launch_tiles_batch_t<uint8_t>(st, L, cand_bins, cand_scalars, cand_slots, segs, n_segs, max_m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, use_window, partials, order);
+	case 16: return launch_tiles_batch_t<uint16_t>(st, L, cand_bins, cand_scalars, cand_slots, segs, n_segs, max_m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, use_window, partials, order);
+	case 32: return launch_tiles_batch_t<uint32_t>(st, L, cand_bins, cand_scalars, cand_slots, segs, n_segs, max_m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, use_window, partials, order);
+	default: return launch_tiles_batch_t<uint64_t>(st, L, cand_bins, cand_scalars, cand_slots, segs, n_segs, max_m, qset_bins, q_slot_bytes, qset_scalars, q_scalar_stride, use_window, partials, order);
+	}
+}
+
+hipError_t msc_launch_colsum_batch(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots, const MscBatchSeg* segs,
+                                   uint32_t n_segs, void* rounded_out, uint64_t* floor_sum_out) {
+	if (n_segs == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(floor_sum_out, 0, sizeof(uint64_t) * n_segs, st);
+	if (e != hipSuccess) return e;
+	const uint64_t chunks = L.slot_bytes / 16;
+	const uint32_t cpb = (uint32_t)((chunks + kBlock - 1) / kBlock);
+	const dim3 grid((unsigned)((uint64_t)n_segs * cpb));
+	unsigned long long* fs = reinterpret_cast<unsigned long long*>(floor_sum_out);
+	switch (dtype) {
+	case 8: k_colsum_batch<uint8_t><<<grid, dim3(kBlock), 0, st>>>((const uint8_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint8_t*)rounded_out, fs); break;
+	case 16: k_colsum_batch<uint16_t><<<grid, dim3(kBlock), 0, st>>>((const uint16_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint16_t*)rounded_out, fs); break;
+	case 32: k_colsum_batch<uint32_t><<<grid, dim3(kBlock), 0, st>>>((const uint32_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint32_t*)rounded_out, fs); break;
+	default: k_colsum_batch<uint64_t><<<grid, dim3(kBlock), 0, st>>>((const uint64_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint64_t*)rounded_out, fs); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_distance_batch(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t n, const uint8_t* scalars, uint64_t scalar_stride,
+                                     const uint32_t* member_slots, const uint32_t* pair_seg, const uint8_t* r_scalars, uint64_t r_stride, const uint64_t* floor_sum,
+                                     double* dist_out) {
+	if (n == 0) return hipSuccess;
+	k_distance_batch<<<dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st>>>(partials, S, n, scalars, scalar_stride, member_slots, pair_seg, r_scalars, r_stride, floor_sum, dist_out);
 	return hipGetLastError();
 }

@@ -13,8 +13,9 @@
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
 //   msc_cluster <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64]
-//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--device 0]
+//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--device 0]
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -323,13 +324,42 @@ struct Driver {
 		}
 	}
 
+	// the `omp parallel for` over mean_shift_update of one round (cluster/ClusterFactory.cpp:639,648) as ONE call: the centres of a
+	// round are independent (each reads its own histogram and the member lists of its neighbours, none of which change during
+	// the round), so filter + mean + closest of all of them are batched on the device (msc_update_centres)
+	void mean_shift_update_all(std::vector<Centre>& part, int delta) {
+		const size_t n = part.size();
+		if (n == 0) return;
+		std::vector<uint32_t> cslots(n), slots;
+		std::vector<uint64_t> offsets(n + 1, 0);
+		std::vector<Pt*> good;
+		for (size_t j = 0; j < n; j++) {
+			cslots[j] = part[j].cslot;
+			const int i_begin = std::max(0, (int)j - delta);
+			const int i_end = std::min((int)j + delta, (int)n - 1);
+			for (int i = i_begin; i <= i_end; i++) for (Pt* p : part[(size_t)i].points) { good.push_back(p); slots.push_back(p->slot); }
+			offsets[j + 1] = slots.size();
+		}
+		std::vector<int64_t> nearest(n, -1);
+		ctx.check(msc_update_centres(ctx.get(), trn.feature().get(), cutoff, centres->get(), cslots.data(), n, points.get(), slots.data(), offsets.data(),
+		                             nearest.data(), nullptr));
+		for (size_t j = 0; j < n; j++) {
+			Centre& ce = part[j];
+			if (nearest[j] >= 0) centre_set(ce, good[(size_t)(offsets[j] + (uint64_t)nearest[j])]);
+			else if (delta == 0) centre_set(ce, ce.points[0]);
+		}
+	}
+
 	// merge (cluster/ClusterFactory.cpp:383-401)
 	bool merge(std::vector<Centre>& centers, int delta) {
 		int num_merge = 0;
+		std::vector<uint32_t> cs(centers.size());
+		for (size_t c = 0; c < centers.size(); c++) cs[c] = centers[c].cslot;
+		// every trn.merge(centers, i, i + 1, min(n - 1, i + delta)) of the loop at once: none of them changes a centre
+		std::vector<int64_t> best(centers.size(), 0);
+		if (batch_update) ctx.check(msc_merge_all(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, best.data()));
 		for (int i = 0; i < (int)centers.size(); i++) {
-			std::vector<uint32_t> cs(centers.size());
-			for (size_t c = 0; c < centers.size(); c++) cs[c] = centers[c].cslot;
-			long ret = trn.merge(*centres, cs, i, i + 1, std::min((int)centers.size() - 1, i + delta));
+			long ret = batch_update ? (long)best[(size_t)i] : trn.merge(*centres, cs, i, i + 1, std::min((int)centers.size() - 1, i + delta));
 			if (ret > i) {
 				num_merge++;
 				auto& to_add = centers[(size_t)ret].points;
@@ -360,25 +390,37 @@ struct Driver {
 		}
 	}
 
+	// Clock::stamp (clutil/Clock.cpp:12-19): same stage names as the reference's driver
+	static void stamp(const char* desc) {
+		static const auto t0 = std::chrono::steady_clock::now();
+		std::cout << "timestamp " << desc << " " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+	}
+
 	// ClusterFactory<T>::MS (cluster/ClusterFactory.cpp:621-656)
 	void MS(BVec& bv, double sim, const std::string& output, int iter, int delta) {
 		std::vector<Centre> part;
 		Pt* last = bv.pop();
 		while (last != nullptr) accumulate(&last, bv, part, sim);
+		stamp("accumulate");
 		std::cout << "Number of clusters before update: " << part.size() << std::endl;
 		std::vector<size_t> num_clusters;
 		for (int i = 0; i < iter; i++) {
 			if (i >= 3 && part.size() == num_clusters[(size_t)i - 3]) break;
-			for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, delta);
+			if (batch_update) mean_shift_update_all(part, delta);
+			else for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, delta);
 			merge(part, delta);
 			num_clusters.push_back(part.size());
 		}
-		for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, 0);
+		if (batch_update) mean_shift_update_all(part, 0);
+		else for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, 0);
+		stamp("update");
 		print_output(output, part);
 		std::cout << "Number of clusters: " << part.size() << std::endl;
+		stamp("done");
 	}
 
 	double cutoff = 0.9;
+	bool batch_update = true;       // --serial-update: one centre at a time (the order the reference would take with one thread)
 };
 
 }  // namespace
@@ -388,7 +430,7 @@ int main(int argc, char** argv) {
 	std::string weights, output = "output.clstr";
 	double similarity = 0.90;
 	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
-	bool single_file = false, sparse = false;
+	bool single_file = false, sparse = false, serial_update = false;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
@@ -402,6 +444,7 @@ int main(int argc, char** argv) {
 		else if (a == "--threads" || a == "-t") need("--threads");
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
 		else if (a == "--single-file") single_file = true;
+		else if (a == "--serial-update") serial_update = true;
 		else if (a == "--sparse") sparse = true;         // sparse histogram layout (required for k >= 13)
 		else files.push_back(a);
 	}
@@ -448,8 +491,10 @@ int main(int argc, char** argv) {
 		uint64_t idx = 0;
 		for (Pt* p : pts) { p->id = idx++; bv.insert(p); }
 		bv.insert_finalize();
+		Driver::stamp("read_in_points");
 		Driver drv(ctx, points, trn, k, dtype, sparse ? std::max<uint64_t>(total_bases / 2, 64 * longest) + (1 << 20) : 0);
 		drv.cutoff = similarity;
+		drv.batch_update = !serial_update;
 		drv.MS(bv, similarity, output, iterations, delta);
 	} catch (const msc::Error& e) {
 		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());

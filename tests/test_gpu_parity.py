@@ -605,3 +605,60 @@ def test_full_size_cfg2_properties(oracle):
         assert inter[f0:f0 + fam].min() > strangers.max(), (i, inter[f0:f0 + fam].min(), strangers.max())
     assert fast_mask
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype,k,wts", [(16, 5, "weights_k5_u16.txt"), (32, 9, "weights_k9_u32.txt"), (16, 5, "weights_k5_u16_slow.txt"), (8, 3, "weights_k5_u16.txt")])
+def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts):
+    """msc_update_centres / msc_merge_all (one launch per stage for all centres of a round) == msc_filter + msc_mean_nearest /
+    msc_merge centre by centre: ragged and empty lists, lists nothing survives, the divergence-statistics fallback, padded tiny
+    histograms."""
+    rng = np.random.default_rng(11 * k + dtype)
+    seqs, _ = synth.families(4100 + k, 120, 600 if k > 3 else 80, family=6)
+    seqs = [s[: len(s) - int(rng.integers(0, len(s) // 3))] for s in seqs]      # mixed lengths: the length window matters
+    n = len(seqs)
+    pts = api.HistogramSet(ctx, k, dtype, n)
+    pts.build(seqs)
+    feat = api.Feature.from_text(ctx, weights_text(wts), 0)
+    trn = api.Trainer(ctx, feat, 0.9)
+    nc = 37
+    cen = api.HistogramSet(ctx, k, dtype, nc)
+    owners = rng.permutation(n)[:nc]
+    for c, o in enumerate(owners):
+        cen.clone_from(c, pts, int(o))
+    cslots = rng.permutation(nc).astype(np.uint32)
+    lists = [rng.permutation(n)[: int(rng.integers(0, 40))].astype(np.uint32) for _ in range(nc)]
+    lists[3] = np.zeros(0, dtype=np.uint32)
+    nearest, kept = trn.update_centres(cen, cslots, pts, lists)
+    for c in range(nc):
+        keep = trn.filter(cen, int(cslots[c]), pts, lists[c]) if len(lists[c]) else np.zeros(0, dtype=np.uint8)
+        idx = np.flatnonzero(keep)
+        assert kept[c] == idx.size, c
+        if idx.size == 0:
+            assert nearest[c] == -1, c
+        else:
+            pos, _, _ = trn.closest(pts, lists[c][idx])
+            assert nearest[c] == idx[pos], c
+    for delta in (0, 1, 5):
+        best = trn.merge_all(cen, cslots, delta)
+        for i in range(nc):
+            exp = trn.merge(cen, cslots, i, i + 1, min(nc - 1, i + delta))
+            assert best[i] == exp, (delta, i)
+
+
+def test_cluster_driver_batched_update_equals_serial(tmp_path):
+    """The driver's batched update stage (msc_update_centres + msc_merge_all per round) writes the same .clstr bytes as the
+    centre-by-centre order (--serial-update) on a 3000-sequence set that ends in ~1900 clusters."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, headers = synth.families(777, 3000, 1000)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, headers)
+    outs = []
+    for extra in ([], ["--serial-update"]):
+        out = str(tmp_path / ("o%d.clstr" % len(outs)))
+        r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(root, "tests", "golden", "weights_k5_u16.txt"),
+                            "--id", "0.9", "--kmer", "5", "--datatype", "16", "--output", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b">Cluster") > 1000
