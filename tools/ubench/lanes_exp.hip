@@ -28,56 +28,53 @@ __global__ void __launch_bounds__(W * 64) k_lanes(const uint8_t* __restrict__ ca
                                                     uint32_t qpad, uint32_t n_chunks, uint32_t P, u32x4* __restrict__ records) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];      // [2][64][kCandStride]
 	constexpr int CPW = 64 / W;                  // candidates each wave moves per stage
+	constexpr int GW = TQ * QW;                  // dwords of this wave's query stream per group
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t part = blockIdx.x % P, cg = blockIdx.x / P;
 	const uint32_t nk = n_chunks / P, k0 = part * nk;
 	const uint32_t q0 = wib * TQ;
-	cptr_t qsd = (cptr_t)qsd_g;
+	(void)qpad;
+	// query stream of THIS wave: [wave][group][TQ][QW] dwords, contiguous per wave
+	cptr_t qw = (cptr_t)qsd_g + ((uint64_t)wib * (n_chunks * 16) + (QMODE == 1 ? 0u : k0 * 16u)) * GW;
 	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_stage);
-	uint64_t base[CPW];
-#pragma unroll
-	for (int i = 0; i < CPW; i++) {
-		uint32_t c = cg * 64 + wib * CPW + i;
-		c = c < m ? c : m - 1;
-		base[i] = (uint64_t)cand_dg + (uint64_t)c * slot_bytes + (uint64_t)k0 * kChunk;
-	}
 	const uint32_t voff = lane * 16;
-	auto fetch = [&](uint32_t buf) {
+	auto fetch = [&](uint32_t buf, uint32_t kk) {
 #pragma unroll
 		for (int i = 0; i < CPW; i++) {
-			dma_cand(base[i], voff, lds0 + buf * kStageBytes + (wib * CPW + i) * kCandStride);
-			base[i] += kChunk;
+			uint32_t c = cg * 64 + wib * CPW + i;
+			c = c < m ? c : m - 1;
+			asm volatile("" : "+s"(c));      // keep the 64-bit bases out of long-lived SGPRs: recomputed per stage (scalar ops are free here)
+			const uint64_t base = (uint64_t)cand_dg + (uint64_t)c * slot_bytes + (uint64_t)(k0 + kk) * kChunk;
+			dma_cand(base, voff, lds0 + buf * kStageBytes + (wib * CPW + i) * kCandStride);
 		}
 	};
 	uint32_t manh[TQ], dot[TQ], emd[TQ];
 #pragma unroll
 	for (int j = 0; j < TQ; j++) { manh[j] = 0; dot[j] = 0; emd[j] = 0; }
-	fetch(0);
+	fetch(0, 0);
 	for (uint32_t kk = 0; kk < nk; kk++) {
 		wait_vm<0>();
 		__builtin_amdgcn_s_barrier();
-		if (kk + 1 < nk) fetch((kk + 1) & 1);
+		if (kk + 1 < nk) fetch((kk + 1) & 1, kk + 1);
 		const u32x4* lp = reinterpret_cast<const u32x4*>(s_stage + (kk & 1) * kStageBytes + lane * kCandStride);
-		const uint32_t g0 = (k0 + kk) * 16;
-		// query stream of THIS wave: [wave][group][TQ][QW] dwords, contiguous per wave
-		cptr_t qw = qsd + ((uint64_t)wib * (n_chunks * 16) + (QMODE == 1 ? 0u : g0)) * (TQ * QW);
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
+			uint32_t sink = 0;
 			if constexpr (QMODE == 2) {
-				// touch every 64-byte line of the NEXT eight groups of this wave's stream: they are in the scalar cache when needed
-				uint32_t sink;
-				cptr_t nx = qw + (h + 1) * 8 * (TQ * QW);
+				// touch every 64-byte line of the eight groups AFTER the ones scored now: they sit in the scalar cache when their turn comes.
+				// All loads land in ONE scratch SGPR that stays reserved (it is an operand of the wait below) until they have returned.
+				cptr_t nx = qw + 8 * GW;
 #pragma unroll
-				for (int l = 0; l < (8 * TQ * QW * 4 + 63) / 64; l++) asm volatile("s_load_dword %0, %1, %2" : "=s"(sink) : "s"(nx), "n"(l * 64));
-				asm volatile("" ::"s"(sink));
+				for (int l = 0; l < (8 * GW * 4 + 63) / 64; l++) asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(nx), "n"(l * 64));
 			}
-#pragma unroll 4
-			for (int t = h * 8; t < h * 8 + 8; t++) {
-				const u32x4 v0 = lp[4 * t], v1 = lp[4 * t + 1], v2 = lp[4 * t + 2], v3 = lp[4 * t + 3];
+#pragma unroll 2
+			for (int t = 0; t < 8; t++) {
+				const int tt = h * 8 + t;
+				const u32x4 v0 = lp[4 * tt], v1 = lp[4 * tt + 1], v2 = lp[4 * tt + 2], v3 = lp[4 * tt + 3];
 				const uint32_t c8[4] = {pack_u8(v0.x, v0.y), pack_u8(v0.z, v0.w), pack_u8(v1.x, v1.y), pack_u8(v1.z, v1.w)};
 				const uint32_t cp[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-				cptr_t qs = qw + t * (TQ * QW);
+				cptr_t qs = qw + t * GW;
 #pragma unroll
 				for (int j = 0; j < TQ; j++) {
 #pragma unroll
@@ -89,6 +86,8 @@ __global__ void __launch_bounds__(W * 64) k_lanes(const uint8_t* __restrict__ ca
 					for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qs[j * QW + 4 + i], emd[j]);
 				}
 			}
+			if constexpr (QMODE == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(sink));
+			if constexpr (QMODE != 1) qw += 8 * GW;
 		}
 	}
 	const uint32_t c = cg * 64 + lane;
@@ -139,7 +138,6 @@ int main(int argc, char** argv) {
 	run<8, 2, 12, 0>("lanes", cand, qsd, m, 4, records);
 	run<8, 2, 12, 1>("lanes, query stream cached", cand, qsd, m, 4, records);
 	run<8, 2, 12, 2>("lanes, scalar-cache prefetch", cand, qsd, m, 4, records);
-	run<8, 2, 12, 2>("lanes, scalar-cache prefetch", cand, qsd, m, 8, records);
 	run<16, 1, 12, 2>("lanes, scalar-cache prefetch", cand, qsd, m, 4, records);
 	run<16, 2, 12, 2>("lanes (32 q), sc prefetch", cand, qsd, m, 4, records);
 	run<8, 4, 12, 2>("lanes (32 q), sc prefetch", cand, qsd, m, 4, records);
