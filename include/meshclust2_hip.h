@@ -278,6 +278,18 @@ int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, cons
 int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
                   int delta, int64_t* best_out);
 
+/* ------------------------------------------------------------------ f2: training on labelled pairs
+ * Replaces the feature-selection half of Predictor<T>::train (predict/Predictor.cpp:876-975): calculate_table,
+ * BestFirstSelector<T>::train_class and GLM::train (predict/BestFirstSelector.cpp:113-250, predict/GLM.cpp:20-23) on pairs
+ * (first_slots[i], second_slots[i]) of `pts` labelled vals[i] (identity in the unit of `id`); the first n_train pairs are the
+ * training set, the next n_test the testing set. feat_flags = the single statistics on offer (MSC_FEAT_FAST / MSC_FEAT_SLOW).
+ * The raw statistics come from the streaming kernels; selection and least squares are host work in the reference's evaluation
+ * order. text_out receives a complete weights file (Predictor::save, :28-44) that msc_model_parse accepts. The reference's own
+ * generation of the pairs (mutated templates, :519-710) is out of scope. */
+int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint32_t* first_slots, const uint32_t* second_slots, const double* vals,
+                    uint64_t n_train, uint64_t n_test, uint64_t feat_flags, int min_feat, int max_feat, double id, char* text_out, size_t cap,
+                    double* train_acc, double* test_acc);
+
 /* ------------------------------------------------------------------ multi-GPU plumbing
  * Raw device views so that a caller that owns an RCCL communicator (torch.distributed / rccl.h) can broadcast a
  * query or all-gather centroid histograms between the per-GPU processes without a host bounce.

@@ -826,7 +826,7 @@ extern "C" int msc_hist_import_done(msc_ctx* ctx, msc_hist_set* set, uint64_t fi
 }
 
 // ================================================================================================ model
-static int feat_is_sim(uint64_t f) {      // Feature<T>::feat_is_sim, predict/Feature.cpp:549-663
+int msc_feat_is_sim(uint64_t f) {      // Feature<T>::feat_is_sim, predict/Feature.cpp:549-663
 	switch (f) {
 	case MSC_FEAT_NORMALIZED_VECTORS: case MSC_FEAT_PEARSON_COEFF: case MSC_FEAT_INTERSECTION: case MSC_FEAT_KULCZYNSKI2: case MSC_FEAT_SIMRATIO:
 		return 1;
@@ -863,7 +863,7 @@ extern "C" int msc_model_create(msc_ctx* ctx, int k, int n_combos, const int* co
 		for (uint64_t f = 1; f != 0 && f <= combo_flags[c]; f <<= 1) {
 			if (!(combo_flags[c] & f)) continue;
 			if (model_index_of(h, f) < 0) {
-				const int sim = feat_is_sim(f);
+				const int sim = msc_feat_is_sim(f);
 				if (sim < 0) return fail(ctx, MSC_ERR_UNSUPPORTED, "single feature 2^%d is not supported by the GPU path", (int)log2((double)f));
 				if (h.n_singles >= MSC_MAX_SINGLES) return fail(ctx, MSC_ERR_UNSUPPORTED, "too many single features");
 				const int i = h.n_singles++;

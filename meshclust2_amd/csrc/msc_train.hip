@@ -1,0 +1,313 @@
+// msc_train.hip -- SURVEY.md 8(f2): model training on caller-supplied labelled pairs (host logic over the GPU feature table).
+//
+// Replaces the feature-selection half of Predictor<T>::train (predict/Predictor.cpp:876-975): the raw statistics of every
+// training/testing pair come from the streaming kernels (msc_pair_features_raw, one 1 x M pass per distinct second point) instead
+// of one CPU pass per statistic per pair (calculate_table, predict/BestFirstSelector.cpp:113-128); what remains is small host
+// work restated here in the reference's evaluation order so that the SAME model comes out:
+//   - min-max normalisation over the TRAINING pairs (calculate_table rebuilds the single features, so the training+testing
+//     normalisation of Predictor::train :889-894 is discarded), polarity per feat_is_sim (predict/Feature.cpp:137-154,216-268);
+//   - the candidate list of Predictor::add_feats (:201-220): every single and every pair of singles as xy / x2y2 (/ x2y / xy2);
+//   - best-first search over sets of candidates (predict/BestFirstSelector.cpp:28-53,146-250): a child toggles one candidate,
+//     children are scored by TEST accuracy of a least-squares fit on +-1 labels, the open list is a max-heap on accuracy;
+//   - GLM::train = normal equations through Matrix::pseudoInverse / gaussJordanInverse (predict/GLM.cpp:20-23,
+//     predict/Matrix.cpp:109-221), including its "not invertible -> hand back the input" behaviour;
+//   - the class block of the weights file as Predictor::save / write_to print it (:28-44,82-121).
+// Data generation (mutated templates with known identity, predict/Predictor.cpp:519-710) stays out of scope: pairs and labels are inputs.
+// std::set / std::priority_queue order the search exactly as the reference's own containers do (same libstdc++).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "msc_internal.h"
+
+int msc_feat_is_sim(uint64_t f);        // msc_api.hip
+
+namespace {
+
+// enum class Combo { xy, x2y2, xy2, x2y } -- this ORDER is the reference's (predict/Feature.h:66-71): sets of candidates sort by it
+enum Cmb { C_XY = 0, C_X2Y2 = 1, C_XY2 = 2, C_X2Y = 3 };
+typedef std::pair<uint64_t, int> Cand;          // (flags of one or two singles, Cmb)
+typedef std::set<Cand> CandSet;
+
+typedef std::vector<std::vector<double> > Mat;  // row major, [rows][cols]
+
+Mat mat(size_t r, size_t c) { return Mat(r, std::vector<double>(c, 0.0)); }
+
+// Matrix::operator* (predict/Matrix.cpp:76-96): plain triple loop, sum in k order
+Mat mul(const Mat& a, const Mat& b) {
+	const size_t n = a.size(), m = b.empty() ? 0 : b[0].size(), kk = b.size();
+	Mat out = mat(n, m);
+	for (size_t i = 0; i < n; i++)
+		for (size_t j = 0; j < m; j++) {
+			double s = 0;
+			for (size_t k = 0; k < kk; k++) s = s + a[i][k] * b[k][j];
+			out[i][j] = s;
+		}
+	return out;
+}
+
+Mat transpose(const Mat& a) {
+	const size_t n = a.size(), m = a.empty() ? 0 : a[0].size();
+	Mat t = mat(m, n);
+	for (size_t i = 0; i < n; i++) for (size_t j = 0; j < m; j++) t[j][i] = a[i][j];
+	return t;
+}
+
+// Matrix::gaussJordanInverse (predict/Matrix.cpp:109-207): no pivoting beyond "swap in the first non-zero row below a zero
+// pivot"; when that fails, or the reduced matrix is not exactly the identity, the ORIGINAL matrix is returned as the "inverse"
+Mat gauss_jordan_inverse(const Mat& original) {
+	const size_t n = original.size();
+	Mat a = original, inv = mat(n, n);
+	for (size_t i = 0; i < n; i++) inv[i][i] = 1;
+	for (size_t i = 0; i < n; i++) {
+		if (a[i][i] != 1) {
+			if (a[i][i] == 0) {
+				size_t row = i + 1;
+				while (row < n && a[row][i] == 0) row++;
+				if (row >= n) return original;
+				for (size_t j = 0; j < n; j++) { std::swap(a[i][j], a[row][j]); std::swap(inv[i][j], inv[row][j]); }
+			}
+			const double pv = a[i][i];
+			for (size_t j = 0; j < n; j++) { a[i][j] = a[i][j] / pv; inv[i][j] = inv[i][j] / pv; }
+		}
+		for (size_t below = i + 1; below < n; below++) {
+			if (a[below][i] != 0) {
+				const double pv = a[below][i];
+				for (size_t j = 0; j < n; j++) { a[below][j] = a[below][j] - pv * a[i][j]; inv[below][j] = inv[below][j] - pv * inv[i][j]; }
+			}
+		}
+	}
+	for (size_t ii = n; ii-- > 0;) {
+		for (size_t above = 0; above < ii; above++) {
+			if (a[above][ii] != 0) {
+				const double pv = a[above][ii];
+				for (size_t j = 0; j < n; j++) { a[above][j] = a[above][j] - pv * a[ii][j]; inv[above][j] = inv[above][j] - pv * inv[ii][j]; }
+			}
+		}
+	}
+	for (size_t i = 0; i < n; i++)
+		for (size_t j = 0; j < n; j++)
+			if ((i == j && a[i][j] != 1) || (i != j && a[i][j] != 0)) return original;
+	return inv;
+}
+
+// Matrix::pseudoInverse (:209-221) of a square matrix: (A^T A)^-1 A^T
+Mat pseudo_inverse(const Mat& a) {
+	const Mat t = transpose(a);
+	return mul(gauss_jordan_inverse(mul(t, a)), t);
+}
+
+struct Table {
+	std::vector<uint64_t> singles;            // ascending bit order == Feature::lookup after calculate_table
+	std::vector<double> mins, maxs;
+	std::vector<int> is_sim;
+	std::vector<std::vector<double> > norm;   // [pair][single]: normalised, polarity applied
+	std::vector<double> label;                // +1 / -1
+	size_t n_train = 0, n_test = 0;
+};
+
+int index_of(const Table& t, uint64_t f) { return (int)(std::find(t.singles.begin(), t.singles.end(), f) - t.singles.begin()); }
+
+// Feature::operator() (predict/Feature.h:205-239); singles of a candidate in ascending bit order
+double combo_value(const Table& t, size_t pair, const Cand& c) {
+	int idx[2], n = 0;
+	for (uint64_t f = 1; f <= c.first; f <<= 1) if (c.first & f) idx[n++] = index_of(t, f);
+	const std::vector<double>& v = t.norm[pair];
+	switch (c.second) {
+	case C_XY: { double p = 1; for (int i = 0; i < n; i++) p *= v[idx[i]]; return p; }
+	case C_X2Y2: { double p = 1; for (int i = 0; i < n; i++) p *= v[idx[i]] * v[idx[i]]; return p; }
+	case C_XY2: return v[idx[0]] * v[idx[1]] * v[idx[1]];
+	default: return v[idx[0]] * v[idx[0]] * v[idx[1]];
+	}
+}
+
+// generate_feat_mat (predict/FeatureSelector.cpp:10-38): [1, combo 0, combo 1, ...] per pair, combos in set order
+Mat feature_matrix(const Table& t, const CandSet& set, size_t first, size_t count) {
+	Mat x = mat(count, set.size() + 1);
+	for (size_t r = 0; r < count; r++) {
+		x[r][0] = 1;
+		size_t c = 1;
+		for (const Cand& cd : set) x[r][c++] = combo_value(t, first + r, cd);
+	}
+	return x;
+}
+
+// GLM::train (predict/GLM.cpp:20-23): weights = pinv(X^T X) * X^T * y, products taken left to right
+std::vector<double> glm_train(const Mat& x, const std::vector<double>& y) {
+	const Mat xt = transpose(x);
+	const Mat w0 = mul(xt, x);
+	Mat ycol = mat(y.size(), 1);
+	for (size_t i = 0; i < y.size(); i++) ycol[i][0] = y[i];
+	const Mat w = mul(mul(pseudo_inverse(w0), xt), ycol);
+	std::vector<double> out(w.size());
+	for (size_t i = 0; i < w.size(); i++) out[i] = w[i][0];
+	return out;
+}
+
+// GLM::predict + accuracy (predict/GLM.cpp:30-66, FeatureSelector::class_test :93-103): round(logistic(Xw)), 0 counted as -1
+double accuracy(const Mat& x, const std::vector<double>& w, const std::vector<double>& label, size_t first) {
+	size_t same = 0;
+	for (size_t r = 0; r < x.size(); r++) {
+		double s = 0;
+		for (size_t k = 0; k < w.size(); k++) s = s + x[r][k] * w[k];
+		double p = round(1.0 / (1 + exp(-s)));
+		if (p == 0) p = -1;
+		if (p == label[first + r]) same++;
+	}
+	return ((double)same * 100) / (double)x.size();
+}
+
+// feature_accuracy (predict/BestFirstSelector.cpp:129-143): fit on the training pairs, score on the testing pairs
+double set_accuracy(const Table& t, const CandSet& set) {
+	const Mat xtr = feature_matrix(t, set, 0, t.n_train);
+	const std::vector<double> ytr(t.label.begin(), t.label.begin() + (long)t.n_train);
+	const std::vector<double> w = glm_train(xtr, ytr);
+	return accuracy(feature_matrix(t, set, t.n_train, t.n_test), w, t.label, t.n_train);
+}
+
+struct HeapLess {
+	bool operator()(const std::pair<CandSet, double>& a, const std::pair<CandSet, double>& b) const { return a.second < b.second; }
+};
+typedef std::priority_queue<std::pair<CandSet, double>, std::vector<std::pair<CandSet, double> >, HeapLess> Heap;
+
+// children_of (:30-53): toggle each candidate in turn; keep what is non-empty and neither closed nor open
+std::vector<CandSet> children_of(const CandSet& cur, const std::vector<Cand>& all, const std::set<CandSet>& closed, const std::set<CandSet>& open) {
+	std::vector<CandSet> out;
+	for (const Cand& c : all) {
+		CandSet tmp = cur;
+		if (!tmp.erase(c)) tmp.insert(c);
+		if (!tmp.empty() && !closed.count(tmp) && !open.count(tmp)) out.push_back(tmp);
+	}
+	return out;
+}
+
+void evaluate(const Table& t, const std::vector<CandSet>& items, std::set<CandSet>& open, Heap& heap) {
+	for (const CandSet& it : items) {          // the reference's loop is an omp parallel for; this is its one-thread order
+		const double acc = set_accuracy(t, it);
+		open.insert(it);
+		heap.push(std::make_pair(it, acc));
+	}
+}
+
+std::string fmt15(double v) {
+	char b[64];
+	snprintf(b, sizeof b, "%.15g", v);      // out << std::setprecision(digits10) << v
+	return b;
+}
+
+}  // namespace
+
+extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint32_t* first_slots, const uint32_t* second_slots, const double* vals,
+                               uint64_t n_train, uint64_t n_test, uint64_t feat_flags, int min_feat, int max_feat, double id, char* text_out, size_t cap,
+                               double* train_acc, double* test_acc) {
+	if (!ctx || !pts || !first_slots || !second_slots || !vals || !text_out || n_train == 0 || n_test == 0 || min_feat < 1 || max_feat < min_feat)
+		return MSC_ERR_INVALID_ARG;
+	if (feat_flags == 0 || (feat_flags & ~(uint64_t)MSC_FEAT_SLOW)) return MSC_ERR_UNSUPPORTED;
+	const size_t n = (size_t)(n_train + n_test);
+	Table t;
+	t.n_train = (size_t)n_train;
+	t.n_test = (size_t)n_test;
+	for (uint64_t f = 1; f <= feat_flags; f <<= 1) if (feat_flags & f) { t.singles.push_back(f); t.is_sim.push_back(msc_feat_is_sim(f)); }
+	const size_t ns = t.singles.size();
+	// ---- raw statistics of every pair: func(*pair.first, *pair.second), one streaming pass per distinct second point
+	std::vector<std::vector<double> > raw(n, std::vector<double>(ns));
+	{
+		std::map<uint32_t, std::vector<size_t> > by_second;
+		for (size_t i = 0; i < n; i++) by_second[second_slots[i]].push_back(i);
+		std::vector<uint32_t> cands;
+		std::vector<double> out;
+		for (const auto& kv : by_second) {
+			cands.clear();
+			for (size_t i : kv.second) cands.push_back(first_slots[i]);
+			out.assign(cands.size() * ns, 0.0);
+			const int r = msc_pair_features_raw(ctx, pts, cands.data(), cands.size(), pts, kv.first, MSC_ORDER_CAND_FIRST, feat_flags, out.data());
+			if (r) return r;
+			for (size_t j = 0; j < kv.second.size(); j++) for (size_t s = 0; s < ns; s++) raw[kv.second[j]][s] = out[j * ns + s];
+		}
+	}
+	// ---- Feature::normalize over the training pairs (predict/Feature.cpp:216-268); the odd start values are the reference's
+	t.mins.assign(ns, DBL_MAX);
+	t.maxs.assign(ns, DBL_MIN);
+	for (size_t s = 0; s < ns; s++) {
+		for (size_t i = 0; i < t.n_train; i++) {
+			if (raw[i][s] < t.mins[s]) t.mins[s] = raw[i][s];
+			if (raw[i][s] > t.maxs[s]) t.maxs[s] = raw[i][s];
+		}
+		if (fabs(t.maxs[s] - t.mins[s]) <= 0.000000001 || std::isinf(t.maxs[s]) || std::isinf(t.mins[s])) return MSC_ERR_NAN;      // the reference throws
+	}
+	t.norm.assign(n, std::vector<double>(ns));
+	t.label.resize(n);
+	for (size_t i = 0; i < n; i++) {
+		for (size_t s = 0; s < ns; s++) {
+			const double v = (raw[i][s] - t.mins[s]) / (t.maxs[s] - t.mins[s]);      // normalize_cache, :137-154
+			if (std::isnan(v)) return MSC_ERR_NAN;
+			t.norm[i][s] = t.is_sim[s] ? v : 1 - v;
+		}
+		t.label[i] = vals[i] >= id ? 1 : -1;      // generate_feat_mat, predict/FeatureSelector.cpp:26-28
+	}
+	// ---- Predictor::add_feats (:201-220)
+	std::vector<Cand> all;
+	for (uint64_t i = 1; i <= feat_flags; i <<= 1) {
+		if (!(i & feat_flags)) continue;
+		for (uint64_t j = 1; j <= i; j <<= 1) {
+			if (!(j & feat_flags)) continue;
+			all.push_back(Cand(i | j, C_XY));
+			all.push_back(Cand(i | j, C_X2Y2));
+			if (i != j) { all.push_back(Cand(i | j, C_X2Y)); all.push_back(Cand(i | j, C_XY2)); }
+		}
+	}
+	// ---- BestFirstSelector::train_class (predict/BestFirstSelector.cpp:187-250)
+	CandSet cur, best;
+	std::set<CandSet> closed, open;
+	Heap heap;
+	long last_best_changed = 0;
+	double best_acc = -100;
+	evaluate(t, children_of(cur, all, closed, open), open, heap);
+	for (long iteration = 0; !open.empty(); iteration++) {
+		size_t biggest = 0;
+		for (const CandSet& s : open) biggest = std::max(biggest, s.size());
+		if ((long)biggest > max_feat || (iteration - last_best_changed >= 3 && (long)biggest > min_feat)) break;
+		cur = heap.top().first;
+		const double acc = heap.top().second;
+		heap.pop();
+		open.erase(cur);
+		closed.insert(cur);
+		if (acc > best_acc && (long)cur.size() >= min_feat && (long)cur.size() <= max_feat) { best = cur; best_acc = acc; last_best_changed = iteration; }
+		evaluate(t, children_of(cur, all, closed, open), open, heap);
+	}
+	if (best.empty()) return MSC_ERR_INVALID_ARG;
+	const Mat xtr = feature_matrix(t, best, 0, t.n_train);
+	const std::vector<double> ytr(t.label.begin(), t.label.begin() + (long)t.n_train);
+	const std::vector<double> w = glm_train(xtr, ytr);
+	if (train_acc) *train_acc = accuracy(xtr, w, t.label, 0);
+	if (test_acc) *test_acc = accuracy(feature_matrix(t, best, t.n_train, t.n_test), w, t.label, t.n_train);
+	// ---- Predictor::save + write_to (:28-44,82-121); singles in order of first appearance over the chosen candidates (load_feat, :77-111)
+	std::vector<uint64_t> lookup;
+	for (const Cand& c : best)
+		for (uint64_t f = 1; f <= c.first; f <<= 1)
+			if ((c.first & f) && std::find(lookup.begin(), lookup.end(), f) == lookup.end()) lookup.push_back(f);
+	static const int file_code[4] = {0, 3, 1, 2};      // xy 0, xy2 1, x2y 2, x2y2 3 in the file
+	char head[256];
+	snprintf(head, sizeof head, "k: %d\nmode: 1\nmax_features: %d\nID: %g\nDatatype: uint%d_t\nfeature_set: %llu\n", msc_hist_set_k(pts), max_feat, id,
+	         msc_hist_set_dtype(pts), (unsigned long long)feat_flags);
+	std::string text = head;
+	text += "\nn_combos: " + std::to_string(best.size()) + "\n" + fmt15(w[0]) + "\n";
+	size_t col = 1;
+	for (const Cand& c : best) text += std::to_string(file_code[c.second]) + " " + std::to_string((unsigned long long)c.first) + " " + fmt15(w[col++]) + "\n";
+	text += "\nn_singles: " + std::to_string(lookup.size()) + "\n";
+	for (uint64_t f : lookup) {
+		const int i = index_of(t, f);
+		text += std::to_string((unsigned long long)f) + " " + fmt15(t.mins[(size_t)i]) + " " + fmt15(t.maxs[(size_t)i]) + "\n";
+	}
+	if (text.size() + 1 > cap) return MSC_ERR_INVALID_ARG;
+	memcpy(text_out, text.c_str(), text.size() + 1);
+	return MSC_OK;
+}

@@ -39,6 +39,7 @@
 #include "predict/Feature.h"
 #include "predict/Predictor.h"
 #include "predict/GLM.h"
+#include "predict/BestFirstSelector.h"
 #include "cluster/Trainer.h"
 #include "cluster/bvec.h"
 #include "cluster/bvec_iterator.h"
@@ -267,6 +268,54 @@ template <class T> void* clone_point(void* a) { return (void*)((Point<T>*)a)->cl
 template <class T> void set_point(void* dst, void* src) { ((Point<T>*)dst)->set(*(Point<T>*)src); }
 template <class T> void free_point(void* a) { delete (Point<T>*)a; }
 
+// Predictor<T>::train() + train_class (predict/Predictor.cpp:876-975) on caller-supplied labelled pairs instead of the mutants
+// the reference generates itself: the single features of `feat_flags` are added and normalised over training, then testing
+// (:889-894), the candidate list is what Predictor<T>::add_feats enumerates (:201-220, forwarded to through a bare object),
+// BestFirstSelector<T>::train_class picks the combos and fits the GLM (predict/BestFirstSelector.cpp:187-250), and
+// Predictor<T>::write_to prints the block (:82-121). Returns the text length, or -1.
+template <class T>
+long train_class(void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int min_feat, int max_feat,
+                 double id, char* out, long cap, double* acc_out) {
+	std::vector<pra<T> > training, testing;
+	for (int i = 0; i < n_train + n_test; i++) {
+		pra<T> pr((Point<T>*)first[i], (Point<T>*)second[i], val[i]);
+		(i < n_train ? training : testing).push_back(pr);
+	}
+	std::vector<std::pair<uint64_t, Combo> > possible;
+	Predictor<T>* bare = static_cast<Predictor<T>*>(::operator new(sizeof(Predictor<T>)));      // add_feats touches no member
+	bare->add_feats(possible, feat_flags);
+	::operator delete(bare);
+	Feature<T> feat(k);
+	feat.set_save(true);
+	for (uint64_t i = 1; i <= feat_flags; i *= 2) if (i & feat_flags) feat.add_feature(i, Combo::xy);
+	feat.normalize(training);
+	feat.normalize(testing);
+	feat.finalize();
+	BestFirstSelector<T> sel(possible, min_feat, max_feat);
+	auto pr = sel.train_class(&feat, training, testing, id);
+	if (acc_out) {
+		auto tr = FeatureSelector<T>::class_test(training, *pr.first, pr.second, id);
+		auto te = FeatureSelector<T>::class_test(testing, *pr.first, pr.second, id);
+		acc_out[0] = std::get<0>(tr);
+		acc_out[1] = std::get<0>(te);
+	}
+	const std::string path = "/tmp/msc_ref_train_" + std::to_string((long)omp_get_wtime()) + "_" + std::to_string((long)(uintptr_t)out) + ".txt";
+	{
+		std::ofstream ofs(path);
+		Predictor<T>* writer = static_cast<Predictor<T>*>(::operator new(sizeof(Predictor<T>)));  // write_to touches no member either
+		writer->write_to(ofs, pr.first, pr.second);
+		::operator delete(writer);
+	}
+	std::ifstream ifs(path);
+	std::stringstream ss;
+	ss << ifs.rdbuf();
+	std::remove(path.c_str());
+	const std::string text = ss.str();
+	if ((long)text.size() + 1 > cap) return -1;
+	memcpy(out, text.c_str(), text.size() + 1);
+	return (long)text.size();
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, expr8, expr16, expr32, expr64) \
@@ -391,6 +440,17 @@ int ref_mean_nearest(int dtype, void** pts, int n, double* mean_out, double* dis
 }
 
 void ref_set_threads(int n) { omp_set_num_threads(n); }
+
+long ref_train_class(int dtype, void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int min_feat,
+                     int max_feat, double id, char* out, long cap, double* acc_out) {
+	try {
+		DISPATCH(dtype, return train_class<uint8_t>(first, second, val, n_train, n_test, k, feat_flags, min_feat, max_feat, id, out, cap, acc_out),
+		         return train_class<uint16_t>(first, second, val, n_train, n_test, k, feat_flags, min_feat, max_feat, id, out, cap, acc_out),
+		         return train_class<uint32_t>(first, second, val, n_train, n_test, k, feat_flags, min_feat, max_feat, id, out, cap, acc_out),
+		         return train_class<uint64_t>(first, second, val, n_train, n_test, k, feat_flags, min_feat, max_feat, id, out, cap, acc_out));
+	} catch (...) { return -2; }
+	return -2;
+}
 
 // Timed loop for bench.py's cpu_baseline (kind "reference"): all (i<j) pairs of n points through
 // Feature::compute + classify, under the reference's own OpenMP schedule (cluster/Trainer.cpp:41).

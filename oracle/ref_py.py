@@ -50,6 +50,9 @@ def lib():
         L.ref_merge.argtypes = [C.c_int, vp, C.c_double, C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_long]
         L.ref_mean_nearest.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.ref_set_threads.argtypes = [C.c_int]
+        L.ref_train_class.restype = C.c_long
+        L.ref_train_class.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                      C.c_double, C.c_char_p, C.c_long, C.POINTER(C.c_double)]
         L.ref_time_pairs.restype = C.c_double
         L.ref_time_pairs.argtypes = [C.c_int, vp, C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
@@ -156,3 +159,19 @@ def mean_nearest(pts):
     lib().ref_mean_nearest(pts[0].dtype, arr, m, mean.ctypes.data_as(C.POINTER(C.c_double)),
                            d.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nearest))
     return mean, d, nearest.value
+
+
+def train_class(dtype, k, first, second, vals, n_train, feat_flags, min_feat, max_feat, ident):
+    """BestFirstSelector::train_class on labelled pairs (first[i], second[i], vals[i]); the first n_train are the training set.
+    -> (class block of the weights file as text, training accuracy, testing accuracy)"""
+    n = len(first)
+    vp = C.c_void_p
+    fa = (vp * n)(*[p.h for p in first])
+    sa = (vp * n)(*[p.h for p in second])
+    va = (C.c_double * n)(*[float(v) for v in vals])
+    buf = C.create_string_buffer(1 << 16)
+    acc = (C.c_double * 2)()
+    r = lib().ref_train_class(dtype, fa, sa, va, n_train, n - n_train, k, feat_flags, min_feat, max_feat, ident, buf, len(buf), acc)
+    if r < 0:
+        raise RuntimeError("reference training failed (%d)" % r)
+    return buf.value.decode(), acc[0], acc[1]

@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 from meshclust2_amd import synth  # noqa: E402
 from oracle import ref_py  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from golden_util import training_set  # noqa: E402
 
 FEATS = [("manhattan", 2), ("euclidean", 3), ("normalized_vectors", 5), ("jefferey_divergence", 7), ("pearson", 9),
          ("intersection", 13), ("emd", 18), ("length_difference", 21), ("kulczynski2", 27), ("simratio", 28), ("jensen_shannon", 29)]
@@ -274,6 +276,24 @@ def make_fastcar_output():
     print("wrote fastcar_k5_u16.out")
 
 
+def make_training(name, seed, k, dtype, feat_flags, min_feat, max_feat, ident, n_templates=40, per_template=12, length=1000):
+    """BestFirstSelector::train_class of the REAL reference on labelled pairs -> tests/golden/<name> (inputs + the block it wrote)"""
+    import json
+    ref_py.lib().ref_set_threads(1)          # the canonical order of the open list (predict/BestFirstSelector.cpp:156-170)
+    seqs, pairs = training_set(seed, n_templates, per_template, length)
+    pts = [ref_py.Point(dtype, s_, k) for s_ in seqs]
+    n_train = len(pairs) // 2
+    text, atr, ate = ref_py.train_class(dtype, k, [pts[a] for a, b, v in pairs], [pts[b] for a, b, v in pairs], [v for a, b, v in pairs], n_train,
+                                        feat_flags, min_feat, max_feat, ident)
+    json.dump(dict(seed=seed, k=k, dtype=dtype, feat_flags=feat_flags, min_feat=min_feat, max_feat=max_feat, id=ident, n_templates=n_templates,
+                   per_template=per_template, length=length, n_train=n_train, pairs=[[a, b, v] for a, b, v in pairs], block=text, train_acc=atr,
+                   test_acc=ate), open(os.path.join(HERE, name), "w"))
+    print("wrote", name, "train/test accuracy", atr, ate)
+
+
+FAST_FLAGS = sum(1 << b for b in (2, 3, 5, 9, 13, 18, 21, 27, 28))
+SLOW_FLAGS = FAST_FLAGS | (1 << 7) | (1 << 29)
+
 NASTY = [
     b"ACGTNNNNACGTACGTACGTACGTAACCGGTTNNNNNNNNNNNNACGATCGATCGATCGATCGACTAGCTAGCTAGCATCGAT" * 6,
     b"acgtacgtnnacgtRYMKSWHBVDacgtacgtacgtagctagcatcgatcgatcgatcagctagcat" * 9,
@@ -283,6 +303,9 @@ if __name__ == "__main__":
     if not ref_py.available():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` (needs /root/reference)")
     make_kat()
+    make_training("train_k5_u16.json", 31, 5, 16, FAST_FLAGS, 4, 4, 0.9)
+    make_training("train_k7_u8_slow.json", 32, 7, 8, SLOW_FLAGS, 2, 3, 0.8, n_templates=30, per_template=10, length=600)
+    make_training("train_k9_u32.json", 33, 9, 32, FAST_FLAGS, 3, 4, 0.9, n_templates=24, per_template=10)
     make_mixed_clstr()
     make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)

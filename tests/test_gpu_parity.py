@@ -662,3 +662,33 @@ def test_cluster_driver_batched_update_equals_serial(tmp_path):
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b">Cluster") > 1000
+
+
+@pytest.mark.parametrize("fixture", ["train_k5_u16.json", "train_k7_u8_slow.json", "train_k9_u32.json"])
+def test_training_selects_the_reference_model(ctx, fixture):
+    """msc_train_class (GPU feature table + host best-first selection + normal equations) on the labelled pairs of
+    a fixture picks the SAME combos and single features, in the same order, as the reference's BestFirstSelector::train_class did,
+    with weights within 1e-6 relative, bounds within 1e-9 and identical accuracies; the text it writes loads as a model."""
+    import json
+    import os
+    from golden_util import GOLDEN, parse_class_block, training_set
+    fx = json.load(open(os.path.join(GOLDEN, fixture)))
+    seqs, pairs = training_set(fx["seed"], fx["n_templates"], fx["per_template"], fx["length"])
+    assert [[a, b] for a, b, _ in pairs] == [[a, b] for a, b, _ in fx["pairs"]]
+    pts = api.HistogramSet(ctx, fx["k"], fx["dtype"], len(seqs))
+    pts.build(seqs)
+    text, atr, ate = api.train_class(ctx, pts, [p[0] for p in fx["pairs"]], [p[1] for p in fx["pairs"]], [p[2] for p in fx["pairs"]], fx["n_train"],
+                                     fx["feat_flags"], fx["min_feat"], fx["max_feat"], fx["id"])
+    w0, combos, singles = parse_class_block(text)
+    ew0, ecombos, esingles = parse_class_block(fx["block"])
+    assert [(c, f) for c, f, _ in combos] == [(c, f) for c, f, _ in ecombos]
+    assert [f for f, _, _ in singles] == [f for f, _, _ in esingles]
+    assert w0 == pytest.approx(ew0, rel=1e-6)
+    for (_, _, w), (_, _, ew) in zip(combos, ecombos):
+        assert w == pytest.approx(ew, rel=1e-6)
+    for (_, lo, hi), (_, elo, ehi) in zip(singles, esingles):
+        assert lo == pytest.approx(elo, rel=1e-9, abs=1e-12) and hi == pytest.approx(ehi, rel=1e-9, abs=1e-12)
+    assert atr == pytest.approx(fx["train_acc"], abs=1e-9) and ate == pytest.approx(fx["test_acc"], abs=1e-9)
+    feat = api.Feature.from_text(ctx, text, 0)          # a complete weights file: header + class block
+    r = feat.compute(pts, np.arange(4, dtype=np.uint32), pts, 0)
+    assert np.all(np.isfinite(r["sum"]))

@@ -147,3 +147,19 @@ def test_mean_nearest_and_stale_mag(oracle, ref, dtype, k):
     for name in ("intersection", "pearson", "kulczynski2", "jefferey_divergence", "jensen_shannon"):
         f = oracle.FEAT[name]
         assert oracle.raw_feature(f, oc, oh[9]) == pytest.approx(ref.raw_feature(f, rc, rp[9]), rel=1e-11)
+
+
+def test_training_fixture_is_what_the_reference_writes(ref):
+    """tests/golden/train_k5_u16.json (the fixture msc_train_class is held to on the GPU) == the class block the compiled reference's
+    BestFirstSelector::train_class + Predictor::write_to produce for the same labelled pairs, byte for byte."""
+    import json
+    import os
+    from golden_util import GOLDEN, training_set
+    fx = json.load(open(os.path.join(GOLDEN, "train_k5_u16.json")))
+    seqs, pairs = training_set(fx["seed"], fx["n_templates"], fx["per_template"], fx["length"])
+    assert [[a, b, v] for a, b, v in pairs] == fx["pairs"]
+    ref.lib().ref_set_threads(1)
+    pts = [ref.Point(fx["dtype"], s, fx["k"]) for s in seqs]
+    text, atr, ate = ref.train_class(fx["dtype"], fx["k"], [pts[a] for a, b, v in pairs], [pts[b] for a, b, v in pairs], [v for a, b, v in pairs], fx["n_train"],
+                                     fx["feat_flags"], fx["min_feat"], fx["max_feat"], fx["id"])
+    assert text == fx["block"] and atr == fx["train_acc"] and ate == fx["test_acc"]
