@@ -170,6 +170,20 @@ public:
 		similarity.resize(slots.size());
 		ctx_.check(msc_search(ctx_.get(), cls_.get(), reg_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slot, close.data(), similarity.data()));
 	}
+	// the same for a block of queries in ONE pass over the database window (msc_score_multi: each candidate tile fetched from HBM
+	// serves 16 queries): close[q * slots.size() + i], similarity likewise. Values are bit-identical to search() per query.
+	void search_block(const PointSet& db, const std::vector<uint32_t>& slots, const PointSet& q, const std::vector<uint32_t>& q_slots,
+	                  std::vector<uint8_t>& close, std::vector<double>& similarity) const {
+		const size_t n = slots.size() * q_slots.size();
+		close.assign(n, 0);
+		similarity.assign(n, 0.0);
+		if (n == 0) return;
+		ctx_.check(msc_score_multi(ctx_.get(), cls_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
+		                           nullptr, nullptr, close.data(), 0, nullptr));
+		ctx_.check(msc_score_multi(ctx_.get(), reg_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
+		                           similarity.data(), nullptr, nullptr, 0, nullptr));
+		for (double& v : similarity) v = v < 0 ? 0 : (v > 1 ? 1 : v);      // p_predict clamps to [0,1], predict/Predictor.cpp:293-298
+	}
 private:
 	Context& ctx_;
 	Feature cls_, reg_;

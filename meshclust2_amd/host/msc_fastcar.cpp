@@ -89,7 +89,7 @@ void load_chunk(msc::PointSet& set, const std::vector<Rec>& recs, size_t off, si
 int main(int argc, char** argv) {
 	std::vector<std::string> files, qfiles;
 	std::string weights, output = "output";
-	size_t chunk = 10000;
+	size_t chunk = 10000, qblock = 16;
 	bool format = true;
 	int device = 0;
 	for (int i = 1; i < argc; i++) {
@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
 		else if (a == "--recover" || a == "-r") weights = need("--recover");
 		else if (a == "--output" || a == "-o") output = need("--output");
 		else if (a == "--chunk" || a == "-c") chunk = (size_t)std::atol(need("--chunk").c_str());
+		else if (a == "--query-block") qblock = std::max<size_t>(1, (size_t)std::atol(need("--query-block").c_str()));
 		else if (a == "--no-format" || a == "--noformat") format = false;
 		else if (a == "--threads" || a == "-t") need("--threads");
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
@@ -141,24 +142,60 @@ int main(int argc, char** argv) {
 				for (auto& p : dp) pts.push_back(&p);
 				std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->length < b->length; });      // FC_Runner.cpp:590-592
 				if (pts.empty()) continue;
-				for (const Pt& query : qp) {                                                                 // work(), :426-471
-					const size_t q_len = query.length;
+				// work() (:426-471) for every query of the chunk. Queries are taken in blocks of `qblock` neighbours in LENGTH order, so
+				// their length windows nearly coincide and one Q x M pass over the union window serves the block; each query then
+				// keeps only its own window, and the lines are written in the reference's order (query order, then window order).
+				struct Hit { size_t cand; double sim; };
+				std::vector<std::vector<Hit> > hits(qp.size());
+				std::vector<size_t> win_start(qp.size()), win_end(qp.size());
+				for (size_t qi = 0; qi < qp.size(); qi++) {
+					const size_t q_len = qp[qi].length;
 					const size_t begin_length = (size_t)(q_len * similarity);
 					const size_t end_length = (size_t)(q_len / similarity);
-					const size_t start = (size_t)bin_search(pts, 0, pts.size() - 1, begin_length);
+					size_t s0 = (size_t)bin_search(pts, 0, pts.size() - 1, begin_length), e0 = s0;
+					while (e0 < pts.size() && pts[e0]->length <= end_length) e0++;
+					win_start[qi] = s0;
+					win_end[qi] = e0;
+				}
+				std::vector<size_t> by_len(qp.size());
+				for (size_t i = 0; i < by_len.size(); i++) by_len[i] = i;
+				std::stable_sort(by_len.begin(), by_len.end(), [&](size_t a, size_t b) { return qp[a].length < qp[b].length; });
+				for (size_t b0 = 0; b0 < by_len.size(); b0 += qblock) {
+					const size_t nb = std::min(qblock, by_len.size() - b0);
+					size_t lo = pts.size(), hi = 0;
+					std::vector<uint32_t> q_slots;
+					std::vector<size_t> members;
+					for (size_t j = 0; j < nb; j++) {
+						const size_t qi = by_len[b0 + j];
+						if (win_start[qi] >= win_end[qi]) continue;
+						lo = std::min(lo, win_start[qi]);
+						hi = std::max(hi, win_end[qi]);
+						q_slots.push_back(qp[qi].slot);
+						members.push_back(qi);
+					}
+					if (members.empty()) continue;
 					std::vector<uint32_t> window;
-					std::vector<Pt*> who;
-					for (size_t i = start; i < pts.size() && pts[i]->length <= end_length; i++) { window.push_back(pts[i]->slot); who.push_back(pts[i]); }
-					if (window.empty()) continue;
+					for (size_t i = lo; i < hi; i++) window.push_back(pts[i]->slot);
 					std::vector<uint8_t> close;
 					std::vector<double> sim;
-					pred.search(dset, window, qset, query.slot, close, sim);        // pred->close(pts[i], query) / similarity(pts[i], query)
-					for (size_t i = 0; i < window.size(); i++) {
-						if (!close[i]) continue;
+					if (members.size() == 1) pred.search(dset, window, qset, q_slots[0], close, sim);      // pred->close / similarity, one query
+					else pred.search_block(dset, window, qset, q_slots, close, sim);
+					for (size_t j = 0; j < members.size(); j++) {
+						const size_t qi = members[j];
+						for (size_t i = win_start[qi]; i < win_end[qi]; i++) {
+							const size_t at = j * window.size() + (i - lo);
+							if (!close[at]) continue;
+							hits[qi].push_back(Hit{i, sim[at]});
+						}
+					}
+				}
+				for (size_t qi = 0; qi < qp.size(); qi++) {
+					const Pt& query = qp[qi];
+					for (const Hit& h : hits[qi]) {
 						num_pred_pos++;
-						if (sim[i] > 0) {
-							if (format) out << format_header(query.header) << delim << format_header(who[i]->header) << delim << 100 * sim[i] << std::endl;
-							else out << query.header << delim << who[i]->header << delim << 100 * sim[i] << std::endl;
+						if (h.sim > 0) {
+							if (format) out << format_header(query.header) << delim << format_header(pts[h.cand]->header) << delim << 100 * h.sim << std::endl;
+							else out << query.header << delim << pts[h.cand]->header << delim << 100 * h.sim << std::endl;
 						}
 					}
 				}

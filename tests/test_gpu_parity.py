@@ -692,3 +692,23 @@ def test_training_selects_the_reference_model(ctx, fixture):
     feat = api.Feature.from_text(ctx, text, 0)          # a complete weights file: header + class block
     r = feat.compute(pts, np.arange(4, dtype=np.uint32), pts, 0)
     assert np.all(np.isfinite(r["sum"]))
+
+
+def test_fastcar_query_blocks_agree(tmp_path):
+    """msc_fastcar scores queries in blocks of 16 length-neighbours through msc_score_multi (one pass over the union of their
+    length windows); the output is the same bytes as with one query per pass, and as with an odd block size."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, headers = synth.families(91, 3000, 1000, length_jitter=150)
+    db, q = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    synth.write_fasta(db, seqs, headers)
+    synth.write_fasta(q, seqs[5:905:3], headers[5:905:3])
+    outs = []
+    for qb in (1, 7, 16):
+        prefix = str(tmp_path / ("fc%d_" % qb))
+        r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_fastcar"), db, "--query", q, "--recover", os.path.join(root, "tests", "golden", "weights_k5_u16.txt"),
+                            "--output", prefix, "--query-block", str(qb)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        outs.append(open(prefix + "0", "rb").read())
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 1000
