@@ -256,7 +256,7 @@ def test_device_view_is_usable_from_torch():
     assert b"TORCH_VIEW_OK" in out.stdout, out.stdout.decode(errors="replace")[-2000:]
 
 
-@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 5), (16, 5, 7), (8, 9, 4), (16, 7, 2), (64, 6, 3), (8, 3, 3), (16, 9, 6), (8, 6, 9), (16, 6, 19), (8, 8, 16)])
+@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 5), (16, 5, 7), (8, 9, 4), (16, 7, 2), (64, 6, 3), (8, 3, 3), (16, 9, 6), (8, 6, 9), (16, 6, 19), (8, 8, 16), (32, 5, 8), (32, 6, 17), (32, 7, 20)])
 def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
     """msc_score_multi (candidate tiles reused across several query tiles) == nq independent 1 x M passes, bit for bit."""
     seqs, _ = synth.families(500 + k, 40, 1000 if k > 3 else 60, family=10)
@@ -712,3 +712,26 @@ def test_fastcar_query_blocks_agree(tmp_path):
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
         outs.append(open(prefix + "0", "rb").read())
     assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 1000
+
+
+def test_multi_query_pass_with_queries_from_another_set(ctx):
+    """Q x M with the queries in a DIFFERENT set from the candidates (fastcar's query / database chunks): both sets get their own
+    digest mirror; uploading into the query set afterwards refreshes just those slots."""
+    k, dtype = 8, 32
+    seqs, _ = synth.families(611, 90, 1000, family=9)
+    db = api.HistogramSet(ctx, k, dtype, 70)
+    db.build(seqs[:70])
+    qs_set = api.HistogramSet(ctx, k, dtype, 20)
+    qs_set.build(seqs[70:])
+    feat = api.Feature.from_text(ctx, weights_text("weights_k9_u32.txt"), 0)
+    q_slots = np.arange(20, dtype=np.uint32)[::-1].copy()
+    mask = FAST_MASK & ~((1 << 7) | (1 << 29))
+    for rnd in range(2):
+        multi = api.score_multi(ctx, feat, db, None, qs_set, q_slots, m=70, feat_mask=mask)
+        assert ctx.last_kernel_info()[0].startswith("k_pair_digest_multi")
+        for i, q in enumerate(q_slots):
+            raw = api.pair_features_raw(ctx, db, None, qs_set, int(q), mask, m=70)
+            single = feat.compute(db, None, qs_set, int(q), m=70)
+            assert np.array_equal(multi["raw"][i], raw) and np.array_equal(multi["sum"][i], single["sum"]), (rnd, i)
+        qs_set.upload(4, db.download(11), 1000)         # overwrite one query slot with a database histogram
+        qs_set.clone_from(9, db, 30)
