@@ -1284,6 +1284,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
 	const bool prefix16 = ring && !no_p16 && excess16;
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
+	const bool need_emd = ((want | feat_mask) & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
 	const int tps = digest ? msc_digest_tiles_per_step(L, mc_) : 1;          // the digest kernel writes one record per step of tps tiles
 	const uint32_t n_rec = digest ? (uint32_t)(L.nbins / 1024) / tps : L.S;
 	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
@@ -1296,7 +1297,10 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
-	ctx->last_kernel = digest ? (mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>") : ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
+	const bool count_only = digest && tps == 2 && !need_emd;
+	ctx->last_kernel = digest ? (count_only ? (mc_ < 256 ? "k_pair_digest_multi<u8 counts, no emd>" : "k_pair_digest_multi<u16 counts, no emd>")
+	                                        : (mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>"))
+	                          : ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
 	// the digest kernel's workgroup scores up to 16 queries per candidate tile it fetches; the ring kernel's co-located query
 	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
 	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 16) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
@@ -1310,7 +1314,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
-			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, ctx->partials.p, ctx->num_cus));
+			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, need_emd, ctx->partials.p, ctx->num_cus));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));

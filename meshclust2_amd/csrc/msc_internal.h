@@ -149,7 +149,7 @@ hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uin
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count);      // 1 or 2 consecutive tiles scored per loop step
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, void* partials16, int num_cus);
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out);

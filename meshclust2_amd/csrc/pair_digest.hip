@@ -113,13 +113,14 @@ __device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uin
 // inside the 16-lane rows with DPP, bank masks merging them into one register on the way: row_ror:8 pairs lanes (l, l^8),
 // row_half_mirror pairs (l, 7-l), two quad_perms finish the quads. Result: every lane of bank 0 holds the row's manh total,
 // bank 1 dot, bank 2 emd (bank 3: emd again). 9 swaps + 9 adds + 9 DPP operations for the 12 sums.
+// EMD = false: the emd sums are not reduced (banks 2 and 3 then hold manh partials nobody reads).
+template <bool EMD>
 __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint32_t (&dot)[4], const uint32_t (&emd)[4]) {
 	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
 	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
 	auto dpp = [](uint32_t old, uint32_t v, auto ctrl, auto bank) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, decltype(ctrl)::value, 0xf, decltype(bank)::value, false); };
 	using std::integral_constant;
 	const uint32_t A = fold16(fold32(manh[0], manh[2]), fold32(manh[1], manh[3]));
-	const uint32_t B = fold16(fold32(emd[0], emd[2]), fold32(emd[1], emd[3]));
 	const uint32_t C = fold16(fold32(dot[0], dot[2]), fold32(dot[1], dot[3]));
 	const integral_constant<int, 0x128> ror8;
 	const integral_constant<int, 0x141> half_mirror;
@@ -128,9 +129,13 @@ __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint
 	const integral_constant<int, 0x4e> swap2;
 	const integral_constant<int, 0xf> all;
 	const uint32_t Xa = A + dpp(0, A, ror8, all);
-	const uint32_t Yb = B + dpp(0, B, ror8, all);
 	const uint32_t Zc = C + dpp(0, C, ror8, all);
-	uint32_t P = dpp(Xa, Yb, ident, integral_constant<int, 0xc>());      // lanes 8-15 of every row <- emd
+	uint32_t P = Xa;
+	if constexpr (EMD) {
+		const uint32_t B = fold16(fold32(emd[0], emd[2]), fold32(emd[1], emd[3]));
+		const uint32_t Yb = B + dpp(0, B, ror8, all);
+		P = dpp(Xa, Yb, ident, integral_constant<int, 0xc>());         // lanes 8-15 of every row <- emd
+	}
 	P += dpp(0, P, half_mirror, all);
 	const uint32_t Z2 = Zc + dpp(0, Zc, half_mirror, all);
 	P = dpp(P, Z2, ident, integral_constant<int, 0x2>());                 // lanes 4-7 <- dot
@@ -142,12 +147,16 @@ __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint
 // bytes 0 and 2 of `lo` and of `hi`: four 16-bit counts (< 256) -> four bytes
 __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
-template <int NB, bool U8, int TPI>
+// EMD = false (the model and the requested statistics do not include the earth mover's distance -- Feature::compute evaluates
+// only the model's own single features too, predict/Feature.cpp:156-171): the prefix half of every tile is neither fetched nor
+// scored; a step is then two 1 KiB count pieces per tile, one DMA piece per wave, and 16 instead of 32 operations per query.
+template <int NB, bool U8, int TPI, bool EMD>
 __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
     uint32_t nqg, bool stream_once, u32x4* __restrict__ partials16) {
-	static_assert(NB >= 2 && NB <= 8 && (TPI == 1 || TPI == 2), "ring depth, tiles per step");
+	static_assert(NB >= 2 && NB <= 8 && (TPI == 1 || TPI == 2) && (EMD || TPI == 2), "ring depth, tiles per step; the count-only form moves 4 pieces per step");
+	constexpr int PF = EMD ? TPI : 1;         // DMA pieces each wave issues per step
 	constexpr int TQ = 4;
 	constexpr int D = NB - 1;                 // steps in flight ahead of the one being scored
 	constexpr int NC = U8 ? 4 : 8;            // count words per lane per tile
@@ -165,22 +174,27 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	const uint32_t q0 = (qg * kWaves + wib) * TQ;
 	const bool active = q0 < n_q;             // a wave without queries still moves its quarter of every tile
 
-	uint32_t qc[TQ][TPI][NC], qp[TQ][TPI][8];
+	uint32_t qc[TQ][TPI][NC], qp[TQ][TPI][EMD ? 8 : 1];
 #pragma unroll
 	for (int j = 0; j < TQ; j++) {
 		const uint32_t qi = q0 + j < n_q ? q0 + j : n_q - 1;      // padded queries score a valid slot; their records are ignored
 #pragma unroll
 		for (int u = 0; u < TPI; u++) {
 			const u32x4* p = reinterpret_cast<const u32x4*>(q_dg + (uint64_t)q_slots[qi] * q_slot_bytes + (uint64_t)s * kStepBytes + u * kTileBytes) + lane;
-			const u32x4 v0 = p[0], v1 = p[64], v2 = p[128], v3 = p[192];
+			const u32x4 v0 = p[0], v1 = p[64];
 			if constexpr (U8) {
 				qc[j][u][0] = pack_u8(v0.x, v0.y); qc[j][u][1] = pack_u8(v0.z, v0.w); qc[j][u][2] = pack_u8(v1.x, v1.y); qc[j][u][3] = pack_u8(v1.z, v1.w);
 			} else {
 				qc[j][u][0] = v0.x; qc[j][u][1] = v0.y; qc[j][u][2] = v0.z; qc[j][u][3] = v0.w;
 				qc[j][u][4] = v1.x; qc[j][u][5] = v1.y; qc[j][u][6] = v1.z; qc[j][u][7] = v1.w;
 			}
-			qp[j][u][0] = v2.x; qp[j][u][1] = v2.y; qp[j][u][2] = v2.z; qp[j][u][3] = v2.w;
-			qp[j][u][4] = v3.x; qp[j][u][5] = v3.y; qp[j][u][6] = v3.z; qp[j][u][7] = v3.w;
+			if constexpr (EMD) {
+				const u32x4 v2 = p[128], v3 = p[192];
+				qp[j][u][0] = v2.x; qp[j][u][1] = v2.y; qp[j][u][2] = v2.z; qp[j][u][3] = v2.w;
+				qp[j][u][4] = v3.x; qp[j][u][5] = v3.y; qp[j][u][6] = v3.z; qp[j][u][7] = v3.w;
+			} else {
+				qp[j][u][0] = 0;
+			}
 		}
 	}
 	// The compiler must see the query loads complete HERE: a wait of its own inside the loop (its scoreboard knows nothing
@@ -192,14 +206,16 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 #pragma unroll
 			for (int i = 0; i < NC; i++) asm volatile("" : "+v"(qc[j][u][i]));
 #pragma unroll
-			for (int i = 0; i < 8; i++) asm volatile("" : "+v"(qp[j][u][i]));
+			for (int i = 0; i < (EMD ? 8 : 1); i++) asm volatile("" : "+v"(qp[j][u][i]));
 		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below start from an empty queue
 
-	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring) + wib * kPieceBytes;
+	// which piece(s) of a step this wave moves: piece `wib` of each tile, or (count-only form) piece wib % 2 of tile wib / 2
+	const uint32_t my_piece = EMD ? wib * kPieceBytes : (wib >> 1) * kTileBytes + (wib & 1) * kPieceBytes;
+	const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_ring) + my_piece;
 	const uint32_t n_iter = (m - g + G - 1) / G;       // g < G <= m
-	const uint64_t src_off = (uint64_t)s * kStepBytes + wib * kPieceBytes;
+	const uint64_t src_off = (uint64_t)s * kStepBytes + my_piece;
 	const uint32_t lane16 = lane * 16u;
 	// stream_once (host: a single query group, nobody else will want these candidate bytes from L2): nontemporal loads
 	auto fetch = [&](uint32_t it, uint32_t slot_idx) {
@@ -207,7 +223,7 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 		const uint32_t slot = cand_slots ? cand_slots[cand] : cand;
 		const uint64_t base = (uint64_t)cand_dg + (uint64_t)slot * slot_bytes + src_off;      // wave-uniform: scalar arithmetic
 #pragma unroll
-		for (int u = 0; u < TPI; u++) dma_piece(base + u * kTileBytes, lane16, ring_lds + slot_idx * kStepBytes + u * kTileBytes, stream_once);
+		for (int u = 0; u < PF; u++) dma_piece(base + u * kTileBytes, lane16, ring_lds + slot_idx * kStepBytes + u * kTileBytes, stream_once);
 	};
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
@@ -222,7 +238,7 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	for (uint32_t it = 0; it < n_iter; it++) {
 		// Vector-memory operations retire in issue order. Younger than this wave's last piece of step `it`: the TPI pieces of
 		// each of the steps it+1 .. it+D-1 and, for a scoring wave past ramp-up, D record stores; fewer stores during ramp-up.
-		if (active && it >= (uint32_t)D) wait_vm<(TPI + 1) * (D - 1) + 1>(); else wait_vm<TPI * (D - 1)>();
+		if (active && it >= (uint32_t)D) wait_vm<(PF + 1) * (D - 1) + 1>(); else wait_vm<PF * (D - 1)>();
 		// all four quarters of every tile of step `it` have landed, and every wave has consumed step it-1 (its slot is refilled next)
 		__builtin_amdgcn_s_barrier();
 		fetch(it + D, wr);
@@ -234,14 +250,18 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 #pragma unroll
 			for (int u = 0; u < TPI; u++) {
 				const u32x4* sl = reinterpret_cast<const u32x4*>(s_ring + rd * kStepBytes + u * kTileBytes) + lane;
-				const u32x4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+				const u32x4 v0 = sl[0], v1 = sl[64];
 				uint32_t cc[NC];
 				if constexpr (U8) {
 					cc[0] = pack_u8(v0.x, v0.y); cc[1] = pack_u8(v0.z, v0.w); cc[2] = pack_u8(v1.x, v1.y); cc[3] = pack_u8(v1.z, v1.w);
 				} else {
 					cc[0] = v0.x; cc[1] = v0.y; cc[2] = v0.z; cc[3] = v0.w; cc[4] = v1.x; cc[5] = v1.y; cc[6] = v1.z; cc[7] = v1.w;
 				}
-				const uint32_t cp[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+				uint32_t cp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+				if constexpr (EMD) {
+					const u32x4 v2 = sl[128], v3 = sl[192];
+					cp[0] = v2.x; cp[1] = v2.y; cp[2] = v2.z; cp[3] = v2.w; cp[4] = v3.x; cp[5] = v3.y; cp[6] = v3.z; cp[7] = v3.w;
+				}
 #pragma unroll
 				for (int j = 0; j < TQ; j++) {
 #pragma unroll
@@ -254,14 +274,16 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 							dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][u][i]), dot[j], false);
 						}
 					}
+					if constexpr (EMD) {
 #pragma unroll
-					for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][u][i], emd[j]);
+						for (int i = 0; i < 8; i++) emd[j] = __builtin_amdgcn_sad_u16(cp[i], qp[j][u][i], emd[j]);
+					}
 				}
 			}
 			// 12 per-lane sums -> 4 records of (manh, dot, emd, -): row r of the wave ends up holding query r, its bank b
 			// (lanes 4b .. 4b+3 of the row) word b of that query's record; the first lane of each quad stores its word, so the
 			// wave writes its 64 bytes of the workgroup's 256-byte run with one dword store
-			const uint32_t word = fold12(manh, dot, emd);
+			const uint32_t word = fold12<EMD>(manh, dot, emd);
 			if (owner) {
 				// byte offset = 16 * row + 4 * bank = lane & 0x3c, recomputed from lane * 16 (live anyway) instead of kept in a
 				// register across the loop: the kernel stays within 128 VGPRs
@@ -276,11 +298,11 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
 }
 
-template <int NB, bool U8, int TPI>
+template <int NB, bool U8, int TPI, bool EMD = true>
 hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_dg, uint64_t slot_bytes, const uint32_t* cand_slots, uint32_t m,
                                const uint8_t* q_dg, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, void* partials16, int num_cus) {
 	const size_t lds = (size_t)NB * TPI * kTileBytes;
-	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI>;
+	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI, EMD>;
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
 	const uint32_t nqg = (n_q + 4 * kWaves - 1) / (4 * kWaves);
@@ -292,7 +314,7 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
 	static const bool no_nt = getenv("MSC_DIGEST_NO_NT") != nullptr;
-	k_pair_digest_multi<NB, U8, TPI><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
+	k_pair_digest_multi<NB, U8, TPI, EMD><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
 	                                                                            nqg == 1 && !no_nt, (u32x4*)partials16);
 	return hipGetLastError();
 }
@@ -325,7 +347,7 @@ int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
 
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, void* partials16, int num_cus) {
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	const uint32_t n_tiles = (uint32_t)(L.nbins / 1024);
 	if (!msc_digest_supported(L) || (tiles_per_step != 1 && tiles_per_step != 2) || n_tiles % tiles_per_step) return hipErrorInvalidValue;
@@ -336,6 +358,8 @@ hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, cons
 	(nb_env == 2 ? launch_digest_multi<2, U8, TPI>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8, TPI>(MSC_DG_ARGS) \
 	 : nb_env == 6 ? launch_digest_multi<6, U8, TPI>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8, TPI>(MSC_DG_ARGS) \
 	                                                                            : launch_digest_multi<4, U8, TPI>(MSC_DG_ARGS))
+	if (tiles_per_step == 2 && !need_emd && (nb_env == 0 || nb_env == 4))      // count-only form (ring of 4 only)
+		return counts_fit_u8 ? launch_digest_multi<4, true, 2, false>(MSC_DG_ARGS) : launch_digest_multi<4, false, 2, false>(MSC_DG_ARGS);
 	if (tiles_per_step == 2) return counts_fit_u8 ? MSC_DG_NB(true, 2) : MSC_DG_NB(false, 2);
 	return counts_fit_u8 ? MSC_DG_NB(true, 1) : MSC_DG_NB(false, 1);
 #undef MSC_DG_NB

@@ -735,3 +735,29 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
             assert np.array_equal(multi["raw"][i], raw) and np.array_equal(multi["sum"][i], single["sum"]), (rnd, i)
         qs_set.upload(4, db.download(11), 1000)         # overwrite one query slot with a database histogram
         qs_set.clone_from(9, db, 30)
+
+
+@pytest.mark.parametrize("dtype,k,nq", [(32, 9, 16), (8, 7, 9), (16, 8, 21), (32, 6, 5)])
+def test_multi_query_pass_without_emd(ctx, dtype, k, nq):
+    """When neither the model nor the requested statistics include the earth mover's distance, the Q x M pass runs its count-only
+    form (prefix half of the mirror neither fetched nor scored); every other statistic and the model score are unchanged."""
+    import json
+    import os
+    from golden_util import GOLDEN
+    seqs, _ = synth.families(700 + k, 60, 1000, family=10)
+    hs = api.HistogramSet(ctx, k, dtype, len(seqs))
+    hs.build(seqs)
+    fx = json.load(open(os.path.join(GOLDEN, "train_k7_u8_slow.json")))          # a reference-trained model without emd: euclidean, normalized_vectors, simratio
+    text = "k: %d\nmode: 1\nmax_features: 3\nID: 0.8\nDatatype: uint%d_t\nfeature_set: 0\n" % (k, dtype) + fx["block"]
+    feat = api.Feature.from_text(ctx, text, 0)
+    mask = FAST_MASK & ~((1 << 7) | (1 << 29) | (1 << 18))
+    cands = np.arange(2, len(seqs), dtype=np.uint32)
+    qs = (np.arange(nq, dtype=np.uint32) * 2) % len(seqs)
+    multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+    if nq >= (8 if dtype == 8 else 6 if dtype == 16 else 4) and k >= 6:
+        assert ctx.last_kernel_info()[0].endswith("no emd>")
+    for i, q in enumerate(qs):
+        single = feat.compute(hs, cands, hs, int(q))
+        raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), mask)
+        assert np.array_equal(multi["raw"][i], raw), i
+        assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"]), i

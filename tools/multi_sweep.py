@@ -16,7 +16,12 @@ while done < n:
         b = synth.pack_batch(codes[:m])
     hs.build_packed(done, m, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
     done += m
-feat = api.Feature.from_text(ctx, open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "weights_k9_u32.txt")).read(), 0)
+golden = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+if os.environ.get("MSC_SWEEP_NOEMD"):       # a reference-trained model without the earth mover's distance (euclidean, normalized_vectors, simratio)
+    blk = json.load(open(os.path.join(golden, "train_k7_u8_slow.json")))["block"]
+    feat = api.Feature.from_text(ctx, "k: %d\nmode: 1\nmax_features: 3\nID: 0.8\nDatatype: uint%d_t\nfeature_set: 0\n" % (k, dt) + blk, 0)
+else:
+    feat = api.Feature.from_text(ctx, open(os.path.join(golden, "weights_k9_u32.txt")).read(), 0)
 for nq in [int(x) for x in os.environ.get("MSC_SWEEP_NQ", "1,2,4,8,16").split(",")]:
     qs = np.arange(nq, dtype=np.uint32) * 3
     ts = []
@@ -26,4 +31,4 @@ for nq in [int(x) for x in os.environ.get("MSC_SWEEP_NQ", "1,2,4,8,16").split(",
         ts.append((time.perf_counter() - t0, ctx.last_kernel_ms()[0]))
     wall = np.median([a for a, _ in ts[1:]]); tiles = np.median([b_ for _, b_ in ts[1:]])
     print(json.dumps({"n_q": nq, "m": n, "wall_ms": round(wall * 1e3, 2), "tiles_ms": round(float(tiles), 3), "pairs_per_s_wall": round(nq * n / wall),
-                      "pairs_per_s_kernel": round(nq * n / tiles * 1e3), "cand_GBps": round(n * 4 ** k * dt / 8 / tiles / 1e6, 1)}), flush=True)
+                      "pairs_per_s_kernel": round(nq * n / tiles * 1e3), "cand_GBps": round(n * 4 ** k * dt / 8 / tiles / 1e6, 1), "kernel": ctx.last_kernel_info()[0]}), flush=True)
