@@ -12,9 +12,10 @@
 // index_of / inner_index_of when a bin is empty.
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
-//   msc_cluster <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64]
+//   msc_cluster <input.fa> [--recover weights.txt] [--id 0.9] [--kmer K] [--datatype 8|16|32|64]   (no --recover: trains first)
 //               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--device 0]
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -425,12 +426,106 @@ struct Driver {
 
 }  // namespace
 
+// ------------------------------------------------------------------ running without --recover
+// The reference then picks k (find_k, cluster/CRunner.cpp:479-502), the histogram type (:56-126) and trains a model on mutated
+// templates (predict/Predictor.cpp:519-710). k and the type are chosen by the same rules; the training pairs come from this
+// driver's OWN SplitMix64 mutator (substitutions + single-base indels at graded rates, labelled with the intended identity), not
+// from the reference's generator, so the model is not the one `meshclust2` would train; selection + GLM are msc_train_class.
+namespace {
+
+struct SplitMix {
+	uint64_t s;
+	uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+	double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+std::string acgt_only(const std::string& s) {
+	std::string o;
+	for (char c : s) { const char u = (char)std::toupper((unsigned char)c); if (u == 'A' || u == 'C' || u == 'G' || u == 'T') o.push_back(u); }
+	return o;
+}
+
+std::string mutate(const std::string& tmpl, double rate, SplitMix& rng) {
+	static const char B[4] = {'A', 'C', 'G', 'T'};
+	const double sub = rate * 0.8, del = rate * 0.1, ins = rate * 0.1;
+	std::string o;
+	for (char c : tmpl) {
+		const double u = rng.unit();
+		if (u < sub) { char n; do { n = B[rng.next() >> 62]; } while (n == c); o.push_back(n); }
+		else if (u < sub + del) { /* dropped */ }
+		else if (u < sub + del + ins) { o.push_back(c); o.push_back(B[rng.next() >> 62]); }
+		else o.push_back(c);
+	}
+	return o;
+}
+
+// cluster/CRunner.cpp:56-126: the narrowest type that holds the largest count (pseudocount included)
+int choose_datatype(msc::Context& ctx, int k, const std::vector<std::string>& seqs) {
+	auto largest = [&](int bits) {
+		msc::PointSet probe(ctx, k, bits, 4096);
+		uint64_t mx = 0;
+		for (size_t off = 0; off < seqs.size(); off += 4096) {
+			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(seqs.size(), off + 4096));
+			probe.get_points(0, part);
+			for (size_t i = 0; i < part.size(); i++) mx = std::max<uint64_t>(mx, probe.info(i).max_count);
+		}
+		return mx;
+	};
+	const uint64_t m16 = largest(16);
+	if (m16 <= 255) return 8;
+	if (m16 < 65535) return 16;
+	return largest(32) <= 65535 ? 16 : 32;
+}
+
+std::string train_model(msc::Context& ctx, int k, int dtype, double id, uint64_t feat_flags, int n_templates, int min_feat, int max_feat,
+                        const std::vector<std::string>& seqs) {
+	SplitMix rng{0xAAull};
+	std::vector<std::string> pts;
+	std::vector<uint32_t> first, second;
+	std::vector<double> val;
+	const double lo = std::max(0.35, id - 0.25);                 // negatives well below the cut-off (the reference's min_id, cluster/CRunner.h:41)
+	const size_t nt = std::min<size_t>((size_t)n_templates, seqs.size());
+	for (size_t t = 0; t < nt; t++) {
+		const std::string tmpl = acgt_only(seqs[t * seqs.size() / nt]);
+		if (tmpl.size() < 50) continue;
+		pts.push_back(tmpl);
+		const uint32_t ti = (uint32_t)pts.size() - 1;
+		for (int j = 0; j < 8; j++) {
+			const double target = j % 2 == 0 ? id + (1.0 - id) * rng.unit() : lo + (id - lo) * rng.unit();
+			pts.push_back(mutate(tmpl, 1.0 - target, rng));
+			first.push_back(ti); second.push_back((uint32_t)pts.size() - 1); val.push_back(target);
+		}
+	}
+	if (first.size() < 16) throw msc::Error(MSC_ERR_INVALID_ARG, "too few usable sequences to train on");
+	for (size_t i = first.size() - 1; i > 0; i--) {              // shuffle, then first half trains and second half tests
+		const size_t j = (size_t)(rng.next() % (i + 1));
+		std::swap(first[i], first[j]); std::swap(second[i], second[j]); std::swap(val[i], val[j]);
+	}
+	msc::PointSet set(ctx, k, dtype, pts.size());
+	for (size_t off = 0; off < pts.size(); off += 4096) {
+		std::vector<std::string> part(pts.begin() + (long)off, pts.begin() + (long)std::min(pts.size(), off + 4096));
+		set.get_points(off, part);
+	}
+	const uint64_t n_train = first.size() / 2;
+	std::vector<char> text(1 << 16);
+	double atr = 0, ate = 0;
+	ctx.check(msc_train_class(ctx.get(), set.get(), first.data(), second.data(), val.data(), n_train, first.size() - n_train, feat_flags, min_feat, max_feat, id,
+	                          text.data(), text.size(), &atr, &ate));
+	std::cout << "Training ACC: " << atr << std::endl << "Testing ACC: " << ate << std::endl;
+	return std::string(text.data());
+}
+
+}  // namespace
+
 int main(int argc, char** argv) {
 	std::vector<std::string> files;
 	std::string weights, output = "output.clstr";
 	double similarity = 0.90;
 	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
 	bool single_file = false, sparse = false, serial_update = false;
+	int n_templates = 300, min_feat = 4, max_feat = 4;      // cluster/CRunner.h:33-35
+	uint64_t feat_flags = MSC_FEAT_FAST;                    // the CLI default (cluster/CRunner.h:51)
+	std::string dump = "weights.txt";
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
@@ -443,17 +538,42 @@ int main(int argc, char** argv) {
 		else if (a == "--iterations" || a == "-i" || a == "--iter") iterations = std::atoi(need("--iterations").c_str());
 		else if (a == "--threads" || a == "-t") need("--threads");
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
+		else if (a == "--feat" || a == "-f") { const std::string v = need("--feat"); feat_flags = v == "slow" ? MSC_FEAT_SLOW : MSC_FEAT_FAST; }
+		else if (a == "--num-templates") n_templates = std::atoi(need("--num-templates").c_str());
+		else if (a == "--min-feat" || a == "--min") min_feat = std::atoi(need("--min-feat").c_str());
+		else if (a == "--max-feat" || a == "--max") max_feat = std::atoi(need("--max-feat").c_str());
+		else if (a == "--dump") dump = need("--dump");
 		else if (a == "--single-file") single_file = true;
 		else if (a == "--serial-update") serial_update = true;
 		else if (a == "--sparse") sparse = true;         // sparse histogram layout (required for k >= 13)
 		else files.push_back(a);
 	}
-	if (files.empty() || weights.empty()) {
-		std::fprintf(stderr, "usage: %s <input.fa> --recover weights.txt [--id 0.9] [--kmer K] [--datatype 8|16|32|64] [--output out.clstr] [--delta 5] [--iterations 15]\n", argv[0]);
+	if (files.empty()) {
+		std::fprintf(stderr, "usage: %s <input.fa> [--recover weights.txt] [--id 0.9] [--kmer K] [--datatype 8|16|32|64] [--output out.clstr] [--delta 5] [--iterations 15]\n"
+		                     "       without --recover a model is trained first (--feat fast|slow, --num-templates 300, --min-feat 4, --max-feat 4) and written to --dump (weights.txt)\n", argv[0]);
 		return 1;
 	}
 	try {
 		msc::Context ctx(device);
+		std::vector<std::string> headers, seqs;
+		for (const auto& f : files) read_fasta(f, headers, seqs, single_file);
+		const size_t n = seqs.size();
+		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
+		if (weights.empty()) {
+			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average effective length)) - 1
+				unsigned long long length = 0;
+				for (const auto& sq : seqs) length += acgt_only(sq).size();
+				length /= n;
+				k = (int)std::ceil(std::log((double)length) / std::log(4.0)) - 1;
+				std::cout << "avg length: " << length << std::endl << "Recommended K: " << k << std::endl;
+			}
+			if (dtype == 0) { dtype = choose_datatype(ctx, k, seqs); std::cout << "Using " << dtype << " bit histograms" << std::endl; }
+			const double id = similarity > 1 ? similarity / 100.0 : similarity;
+			const std::string text = train_model(ctx, k, dtype, id, feat_flags, n_templates, min_feat, max_feat, seqs);
+			std::ofstream(dump.c_str()) << text;       // the reference always leaves weights.txt behind (cluster/Trainer.cpp:188-190)
+			weights = dump;
+			Driver::stamp("GLM");
+		}
 		msc::Trainer trn(ctx, weights, similarity);
 		if (k < 0) k = msc_model_k(trn.feature().get());
 		if (dtype == 0) {      // "Datatype:" line of the weights file
@@ -461,10 +581,6 @@ int main(int argc, char** argv) {
 			std::string tok;
 			while (in >> tok) if (tok == "Datatype:") { in >> tok; dtype = tok == "uint8_t" ? 8 : tok == "uint16_t" ? 16 : tok == "uint32_t" ? 32 : 64; break; }
 		}
-		std::vector<std::string> headers, seqs;
-		for (const auto& f : files) read_fasta(f, headers, seqs, single_file);
-		const size_t n = seqs.size();
-		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		uint64_t total_bases = 0, longest = 0;
 		for (const auto& sq : seqs) { total_bases += sq.size(); longest = std::max<uint64_t>(longest, sq.size()); }
 		msc::PointSet points(ctx, k, dtype, n, sparse ? total_bases + 1024 : 0);

@@ -761,3 +761,25 @@ def test_multi_query_pass_without_emd(ctx, dtype, k, nq):
         raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), mask)
         assert np.array_equal(multi["raw"][i], raw), i
         assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"]), i
+
+
+def test_cluster_driver_trains_its_own_model(tmp_path, ctx):
+    """Without --recover the driver picks k by the reference's find_k rule and the narrowest histogram type, trains a model
+    (own pair generator + msc_train_class), leaves it in weights.txt like the reference does, and clusters with it: every
+    input sequence appears in exactly one cluster, and the weights file loads."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, headers = synth.families(4242, 1200, 1000)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, headers)
+    out = str(tmp_path / "o.clstr")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--id", "0.9", "--output", out], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    log = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, log[-2000:]
+    assert "Recommended K: 4" in log and "Using 8 bit histograms" in log          # ceil(log4(999)) - 1; no count above 255 at k = 4 / 1 kb
+    members = [ln for ln in open(out) if not ln.startswith(">Cluster")]
+    assert len(members) == len(seqs) and len({ln.split(">")[1].split("...")[0] for ln in members}) == len(seqs)
+    feat = api.Feature.from_text(ctx, open(str(tmp_path / "weights.txt")).read(), 0)
+    assert feat is not None
