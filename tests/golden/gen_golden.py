@@ -207,6 +207,21 @@ def make_mixed_clstr():
     print("wrote mixed.clstr")
 
 
+def make_mixed_slow_clstr():
+    """BASELINE cfg5 in small: mixed lengths, --feat slow (all 11 statistics incl. the two divergences), --id 0.6 (min_id stays
+    0.35 at exactly 0.6, cluster/CRunner.cpp:571). Reference CLI end to end, 1 thread: its weights.txt and its .clstr"""
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = mixed_length_set()
+    seqs, hdrs = seqs[::3], hdrs[::3]
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    run_reference_cli(fa, ["--id", "0.6", "--kmer", "6", "--datatype", "16", "--feat", "slow", "--threads", "1", "--output", "out.clstr"], tmp)
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_mixed_slow_k6_u16.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "mixed_slow.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote mixed_slow.clstr")
+
+
 def single_file_set():
     """48 FASTA files of 3 records each (members of one family); with --single-file every file is one sequence"""
     files = []
@@ -307,6 +322,7 @@ if __name__ == "__main__":
     make_training("train_k7_u8_slow.json", 32, 7, 8, SLOW_FLAGS, 2, 3, 0.8, n_templates=30, per_template=10, length=600)
     make_training("train_k9_u32.json", 33, 9, 32, FAST_FLAGS, 3, 4, 0.9, n_templates=24, per_template=10)
     make_mixed_clstr()
+    make_mixed_slow_clstr()
     make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])

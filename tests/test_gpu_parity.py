@@ -783,3 +783,26 @@ def test_cluster_driver_trains_its_own_model(tmp_path, ctx):
     assert len(members) == len(seqs) and len({ln.split(">")[1].split("...")[0] for ln in members}) == len(seqs)
     feat = api.Feature.from_text(ctx, open(str(tmp_path / "weights.txt")).read(), 0)
     assert feat is not None
+
+
+def test_cluster_driver_mixed_lengths_slow_features(tmp_path):
+    """BASELINE cfg5 in small: mixed lengths, a `--feat slow` model that uses jensen_shannon, --id 0.6. The driver reproduces the
+    reference CLI's .clstr byte for byte (the divergence statistics run through the per-centre path of the batched update)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, hdrs = [], []
+    for gi, (n, length, seed) in enumerate(((800, 600, 31), (800, 1000, 32), (800, 1500, 33))):
+        s_, h_ = synth.families(seed, n, length, length_jitter=120)
+        seqs += s_
+        hdrs += [">m%d_%s" % (gi, x[1:]) for x in h_]
+    seqs, hdrs = seqs[::3], hdrs[::3]
+    fa = str(tmp_path / "mixed.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_mixed_slow_k6_u16.txt"),
+                        "--id", "0.6", "--kmer", "6", "--datatype", "16", "--output", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "mixed_slow.clstr"), "rb").read()
+    assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
