@@ -270,6 +270,24 @@ def make_k8_clstr():
     print("wrote k8.clstr")
 
 
+def k9_set():
+    """BASELINE cfg3 in small: 320 sequences of 1 kb, k = 9, histogram type left to the CLI (no count exceeds 255 -> uint8_t)"""
+    return synth.families(61, 320, 1000, family=16)
+
+
+def make_k9_auto_clstr():
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = k9_set()
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    log = run_reference_cli(fa, ["--id", "0.9", "--kmer", "9", "--threads", "1", "--output", "out.clstr"], tmp)
+    assert "Using 8 bit histograms" in log, log[-500:]
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_k9_u8.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "k9_u8.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote k9_u8.clstr")
+
+
 def fastcar_sets():
     db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
     q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
@@ -323,6 +341,7 @@ if __name__ == "__main__":
     make_training("train_k9_u32.json", 33, 9, 32, FAST_FLAGS, 3, 4, 0.9, n_templates=24, per_template=10)
     make_mixed_clstr()
     make_mixed_slow_clstr()
+    make_k9_auto_clstr()
     make_weights("weights_k5_u16.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5, clstr_name="cfg1.clstr")
     make_weights("weights_k9_u32.txt", 20260002, 300, 1000, 9, 32, REG_BLOCK_K9)
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])

@@ -806,3 +806,22 @@ def test_cluster_driver_mixed_lengths_slow_features(tmp_path):
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "mixed_slow.clstr"), "rb").read()
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
+
+
+@pytest.mark.parametrize("extra", [[], ["--sparse"]])
+def test_cluster_driver_k9_uint8(tmp_path, extra):
+    """BASELINE cfg3 in small: k = 9 with the histogram type the reference CLI chose by itself (uint8_t, 256 KiB histograms); the
+    driver, fed the model that run trained, writes the same .clstr bytes from the dense and from the sparse layout."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, hdrs = synth.families(61, 320, 1000, family=16)
+    fa = str(tmp_path / "k9.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9",
+                        "--output", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "k9_u8.clstr"), "rb").read()
+    assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
