@@ -23,25 +23,13 @@
 #include <algorithm>
 
 #include "msc_internal.h"
+#include "msc_wave.h"
 
 namespace {
 
 constexpr int kBlockC = 1024;                 // 16 waves = the 16 index sub-ranges of one sequence
 constexpr int kSub = MSC_SPARSE_SUB;
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
-	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-	v = dpp_add<0x111, 0xf>(v);
-	v = dpp_add<0x112, 0xf>(v);
-	v = dpp_add<0x114, 0xf>(v);
-	v = dpp_add<0x118, 0xf>(v);
-	v = dpp_add<0x142, 0xa>(v);
-	v = dpp_add<0x143, 0xc>(v);
-	return v;
-}
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -825,3 +825,36 @@ def test_cluster_driver_k9_uint8(tmp_path, extra):
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "k9_u8.clstr"), "rb").read()
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
+
+
+def test_degenerate_inputs(ctx, oracle):
+    """Empty candidate lists, a single candidate, no queries, sequences shorter than k, sequences of N only: the operators return
+    what the reference's loops would (nothing scored, is_min true, best (-1, -1) / merge 0) instead of faulting."""
+    k, dtype = 6, 32
+    seqs, _ = synth.families(808, 12, 400, family=4)
+    seqs = list(seqs) + [b"ACG", b"N" * 300, b"ACGTAC"]          # shorter than k, all N, exactly k
+    hs = api.HistogramSet(ctx, k, dtype, len(seqs))
+    hs.build(seqs)
+    for i in (12, 13, 14):
+        oh = oracle.hist(seqs[i], k, dtype)
+        assert np.array_equal(hs.download(i), oh.array()) and hs.info(i)["length"] == oh.length
+    feat = api.Feature.from_text(ctx, weights_text("weights_k9_u32.txt"), 0)
+    trn = api.Trainer(ctx, feat, 0.9)
+    none = np.zeros(0, dtype=np.uint32)
+    flags, bp, bs, im = trn.get_close(hs, none, hs, 0)
+    assert flags.size == 0 and bp == -1 and bs == -1.0 and im
+    flags, bp, bs, im = trn.get_close(hs, np.array([3], dtype=np.uint32), hs, 3)
+    of, obp, obs, oim = oracle.get_close(oracle.predictor(weights_text("weights_k9_u32.txt")), 0.9, oracle.hist(seqs[3], k, dtype), [oracle.hist(seqs[3], k, dtype)])
+    assert np.array_equal(flags, of) and bp == obp and im == oim
+    multi = api.score_multi(ctx, feat, hs, none, hs, np.arange(5, dtype=np.uint32))
+    assert multi["sum"].shape == (5, 0)
+    multi = api.score_multi(ctx, feat, hs, np.arange(12, dtype=np.uint32), hs, none)
+    assert multi["sum"].shape == (0, 12)
+    nearest, kept = trn.update_centres(hs, np.zeros(0, dtype=np.uint32), hs, [])
+    assert nearest.size == 0
+    nearest, kept = trn.update_centres(hs, np.array([0, 1], dtype=np.uint32), hs, [none, none])
+    assert list(nearest) == [-1, -1] and list(kept) == [0, 0]
+    assert list(trn.merge_all(hs, np.array([2], dtype=np.uint32), 5)) == [0]
+    # a zero-length candidate never reaches length_difference in get_close: the length window drops it first (cluster/Trainer.cpp:39-48)
+    flags, bp, bs, im = trn.get_close(hs, np.array([13], dtype=np.uint32), hs, 0)
+    assert list(flags) == [0] and bp == -1 and im
