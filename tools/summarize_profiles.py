@@ -33,7 +33,7 @@ def main():
     with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
         f.write("kernel,calls,total_ns,average_ns,percentage,min_ns,max_ns\n")
         for r in rows:
-            f.write("%s,%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
+            f.write("\"%s\",%s,%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
     pmc = {}
     for ctr, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
         agg = collections.defaultdict(list)
