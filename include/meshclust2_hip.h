@@ -172,6 +172,9 @@ int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc
 /* DivergencePoint::set (clutil/DivergencePoint.cpp:182-190; caller cluster/ClusterFactory.cpp:328,331):
  * bins, length and id are copied, `mag` is NOT. */
 int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
+/* center->set(*next) for many centres in one launch (the tail of every mean_shift_update of a round, cluster/ClusterFactory.cpp:328,331):
+ * msc_hist_assign(dst, dst_slots[i], src, src_slots[i]) for i < n; the destination slots must be distinct. */
+int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n);
 
 /* Exact slot copy: bins and EVERY scalar (incl. a stale mag). What a host container of Center objects needs when it
  * relocates them without going through clone() (std::vector growth of the device-side centre store). */

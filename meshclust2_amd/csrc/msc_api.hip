@@ -810,6 +810,41 @@ extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, con
 	return refresh_bounds(ctx, dst, ds, 1);
 }
 
+// center->set(*next) for many centres at once (the tail of every mean_shift_update of a round): same field semantics as
+// msc_hist_assign; destination slots must be distinct.
+extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n) {
+	if (!ctx || !dst || !src || dst->ctx != ctx || src->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (n == 0) return MSC_OK;
+	if (!dst_slots || !src_slots) return MSC_ERR_INVALID_ARG;
+	if (dst->k != src->k || dst->dtype != src->dtype || dst->sparse != src->sparse) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k, dtype or layout");
+	uint32_t lo = ~0u, hi = 0;
+	for (uint64_t i = 0; i < n; i++) {
+		if (dst_slots[i] >= dst->capacity || src_slots[i] >= src->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "slot out of range");
+		lo = std::min(lo, dst_slots[i]);
+		hi = std::max(hi, dst_slots[i]);
+	}
+	if (dst->sparse || n > 0x7fffffffull) {          // entry lists live in an append-only arena with host bookkeeping: one at a time
+		for (uint64_t i = 0; i < n; i++) { const int r = msc_hist_assign(ctx, dst, dst_slots[i], src, src_slots[i]); if (r) return r; }
+		return MSC_OK;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int r;
+	if ((r = ensure(ctx, ctx->slots, n * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, n * sizeof(uint32_t)))) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, dst_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, src_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_assign_batch(ctx->stream, dst->L, dst->bins, dst->scalars, src->bins, src->scalars, (const uint32_t*)ctx->slots.p,
+	                                     (const uint32_t*)ctx->pair_seg.p, (uint32_t)n));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the caller's slot arrays may go away
+	// host-side bounds: nothing copied can exceed the source set's own maxima
+	dst->max_count = std::max(dst->max_count, src->max_count);
+	dst->max_sum = std::max(dst->max_sum, src->max_sum);
+	if (dst->digest) {
+		if (dst->dg_lo >= dst->dg_hi) { dst->dg_lo = lo; dst->dg_hi = (uint64_t)hi + 1; }
+		else { dst->dg_lo = std::min<uint64_t>(dst->dg_lo, lo); dst->dg_hi = std::max<uint64_t>(dst->dg_hi, (uint64_t)hi + 1); }
+	}
+	return MSC_OK;
+}
+
 extern "C" int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slot_bytes, void** scalars, uint64_t* scalar_bytes) {
 	if (!set || set->sparse) return MSC_ERR_INVALID_ARG;
 	if (bins) *bins = set->bins;

@@ -189,3 +189,5 @@ hipError_t msc_launch_colsum_batch(hipStream_t st, const MscLayout& L, int dtype
 hipError_t msc_launch_distance_batch(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t n, const uint8_t* scalars, uint64_t scalar_stride,
                                      const uint32_t* member_slots, const uint32_t* pair_seg, const uint8_t* r_scalars, uint64_t r_stride, const uint64_t* floor_sum,
                                      double* dist_out);
+hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* dst_bins, uint8_t* dst_scalars, const uint8_t* src_bins,
+                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n);

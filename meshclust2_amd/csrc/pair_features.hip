@@ -25,6 +25,9 @@
 // Integer ranges ("narrow" path, checked on the host before launch): largest bin <= MSC_NARROW_MAX_COUNT,
 // bin sum < 2^31. Within that range every 32-bit product of the reference is exact, so results are
 // bit-identical to the reference's integer accumulators.
+#include <algorithm>
+#include <cstddef>
+
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -1509,6 +1512,46 @@ hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uin
                                  const uint64_t* floor_sum, double* dist_out, MscReduceOut* out) {
 	hipLaunchKernelGGL(k_distance_d, dim3(1), dim3(1024), 0, st, partials, S, m, scalars, scalar_stride, member_slots, r_scalars,
 	                   floor_sum, dist_out, out);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- batched center->set(*next)
+namespace {
+// DivergencePoint::set for many (destination, source) slot pairs (clutil/DivergencePoint.cpp:182-190): bins, then length / derived
+// sums / id / tile prefixes of the scalar record -- NOT mag, NOT stddev, NOT the 1-mers (msc_hist_assign, one pair at a time)
+__global__ void __launch_bounds__(kBlock) k_assign_bins(uint4* __restrict__ dst, const uint4* __restrict__ src, const uint32_t* __restrict__ ds,
+                                                       const uint32_t* __restrict__ ss, uint64_t per_slot, uint64_t total) {
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t pair = e / per_slot, off = e % per_slot;
+		dst[(uint64_t)ds[pair] * per_slot + off] = src[(uint64_t)ss[pair] * per_slot + off];
+	}
+}
+__global__ void __launch_bounds__(kBlock) k_assign_scalars(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, const uint32_t* __restrict__ ds,
+                                                          const uint32_t* __restrict__ ss, uint32_t words_per_slot, uint32_t S, uint64_t total) {
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t pair = e / words_per_slot;
+		const uint32_t w = (uint32_t)(e % words_per_slot);
+		// words of MscSlotScalars: 0 mag | 1 length 2 sum 3 sum_sq 4 max_count | 5-8 one_mers | 9 stddev 10 overflow | 11 id | 12.. ; 16.. tile prefixes
+		const bool copied = (w >= 1 && w <= 4) || w == 11 || (w >= 16 && w < 16 + S);
+		if (copied) dst[(uint64_t)ds[pair] * words_per_slot + w] = src[(uint64_t)ss[pair] * words_per_slot + w];
+	}
+}
+}  // namespace
+
+hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* dst_bins, uint8_t* dst_scalars, const uint8_t* src_bins,
+                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n) {
+	if (n == 0) return hipSuccess;
+	static_assert(offsetof(MscSlotScalars, length) == 8 && offsetof(MscSlotScalars, max_count) == 32 && offsetof(MscSlotScalars, id) == 88 && sizeof(MscSlotScalars) == 128,
+	              "k_assign_scalars hard-codes the record's word positions");
+	const uint64_t per = L.slot_bytes / 16, total = per * n;
+	k_assign_bins<<<dim3((unsigned)std::min<uint64_t>((total + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint4*)dst_bins, (const uint4*)src_bins, dst_slots, src_slots,
+	                                                                                                                  per, total);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	const uint32_t words = (uint32_t)(msc_scalar_stride(L.S) / 8);
+	const uint64_t stotal = (uint64_t)words * n;
+	k_assign_scalars<<<dim3((unsigned)std::min<uint64_t>((stotal + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint64_t*)dst_scalars, (const uint64_t*)src_scalars,
+	                                                                                                                      dst_slots, src_slots, words, L.S, stotal);
 	return hipGetLastError();
 }
 

@@ -344,11 +344,18 @@ struct Driver {
 		std::vector<int64_t> nearest(n, -1);
 		ctx.check(msc_update_centres(ctx.get(), trn.feature().get(), cutoff, centres->get(), cslots.data(), n, points.get(), slots.data(), offsets.data(),
 		                             nearest.data(), nullptr));
+		// center->set(*next) of every centre that moves: one launch for the dense layout (the sparse arena is appended to one by one)
+		std::vector<uint32_t> dst, src;
 		for (size_t j = 0; j < n; j++) {
 			Centre& ce = part[j];
-			if (nearest[j] >= 0) centre_set(ce, good[(size_t)(offsets[j] + (uint64_t)nearest[j])]);
-			else if (delta == 0) centre_set(ce, ce.points[0]);
+			Pt* next = nearest[j] >= 0 ? good[(size_t)(offsets[j] + (uint64_t)nearest[j])] : (delta == 0 ? ce.points[0] : nullptr);
+			if (!next) continue;
+			if (centre_arena) { centre_set(ce, next); continue; }
+			dst.push_back(ce.cslot);
+			src.push_back(next->slot);
+			ce.header = next->header; ce.id = next->id; ce.length = next->length;
 		}
+		if (!dst.empty()) ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), dst.data(), points.get(), src.data(), dst.size()));
 	}
 
 	// merge (cluster/ClusterFactory.cpp:383-401)
