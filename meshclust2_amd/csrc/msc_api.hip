@@ -39,6 +39,7 @@ struct msc_ctx {
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
 	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg;
+	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
 	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum;
@@ -113,6 +114,17 @@ static int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 	return MSC_OK;
 }
 
+// page-locked host staging: a pageable hipMemcpyAsync stalls the host on the runtime's own bounce buffer, which the accumulate
+// loop pays once per step in each direction
+static int ensure_pinned(msc_ctx* ctx, DevBuf& b, size_t bytes) {
+	if (bytes <= b.cap) return MSC_OK;
+	if (b.p) { HIP_TRY(ctx, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+	const size_t cap = (std::max<size_t>(bytes, 65536) + 4095) / 4096 * 4096;
+	HIP_TRY(ctx, hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+	b.cap = cap;
+	return MSC_OK;
+}
+
 static void release(DevBuf& b) {
 	if (b.p) (void)hipFree(b.p);
 	b.p = nullptr;
@@ -159,6 +171,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
 	if (ctx->batch_scratch) msc_hist_set_destroy(ctx->batch_scratch);
+	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
+	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
 	release(ctx->pair_seg);
 	release(ctx->dist);
@@ -779,6 +793,19 @@ static int copy_common(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_h
 	return MSC_OK;
 }
 
+// slot-to-slot copies inside the library: nothing copied can exceed the source set's own maxima, so the bounds merge on the
+// host and the stream is not drained (the accumulate loop clones one centre per step)
+static int inherit_bounds(msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
+	dst->max_count = std::max(dst->max_count, src->max_count);
+	dst->max_sum = std::max(dst->max_sum, src->max_sum);
+	if (dst->sparse) dst->max_nnz = std::max(dst->max_nnz, src->hdr_host[ss].nnz);
+	if (dst->digest) {
+		if (dst->dg_lo >= dst->dg_hi) { dst->dg_lo = ds; dst->dg_hi = ds + 1; }
+		else { dst->dg_lo = std::min(dst->dg_lo, ds); dst->dg_hi = std::max(dst->dg_hi, ds + 1); }
+	}
+	return MSC_OK;
+}
+
 extern "C" int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
 	int r = copy_common(ctx, dst, ds, src, ss);
 	if (r) return r;
@@ -787,14 +814,14 @@ extern "C" int msc_hist_clone(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, cons
 	HIP_TRY(ctx, hipMemcpyAsync(d, s, dst->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
 	// the (pts, len) ctor re-sums mag from the bins (clutil/DivergencePoint.cpp:99-110)
 	HIP_TRY(ctx, hipMemcpyAsync(d + offsetof(MscSlotScalars, mag), s + offsetof(MscSlotScalars, sum), 8, hipMemcpyDeviceToDevice, ctx->stream));
-	return refresh_bounds(ctx, dst, ds, 1);
+	return inherit_bounds(dst, ds, src, ss);
 }
 
 extern "C" int msc_hist_copy(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
 	int r = copy_common(ctx, dst, ds, src, ss);
 	if (r) return r;
 	HIP_TRY(ctx, hipMemcpyAsync(dst->scalars + ds * dst->scalar_stride, src->scalars + ss * src->scalar_stride, dst->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
-	return refresh_bounds(ctx, dst, ds, 1);
+	return inherit_bounds(dst, ds, src, ss);
 }
 
 extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_hist_set* src, uint64_t ss) {
@@ -807,7 +834,7 @@ extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, con
 	HIP_TRY(ctx, hipMemcpyAsync(d + a0, s + a0, a1 - a0, hipMemcpyDeviceToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(d + offsetof(MscSlotScalars, id), s + offsetof(MscSlotScalars, id), 8, hipMemcpyDeviceToDevice, ctx->stream));
 	if (!dst->sparse) HIP_TRY(ctx, hipMemcpyAsync(d + sizeof(MscSlotScalars), s + sizeof(MscSlotScalars), 8ull * dst->L.S, hipMemcpyDeviceToDevice, ctx->stream));
-	return refresh_bounds(ctx, dst, ds, 1);
+	return inherit_bounds(dst, ds, src, ss);
 }
 
 // center->set(*next) for many centres at once (the tail of every mean_shift_update of a round): same field semantics as
@@ -1084,7 +1111,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	if ((r = ensure(ctx, ctx->partials, chunk * PS * sizeof(MscPartial))) != MSC_OK) return r;
 	if (rq.cand_slots) {
 		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t))) != MSC_OK) return r;
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, rq.cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		if ((r = ensure_pinned(ctx, ctx->pin_up, m * sizeof(uint32_t))) != MSC_OK) return r;
+		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
 	if (need_div) {
 		if ((r = ensure(ctx, ctx->div_tables, chunk * (sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
@@ -1159,8 +1188,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (rq.reduce_mode >= 0) {
 			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
 			                               (uint8_t*)ctx->flags.p, (MscReduceOut*)ctx->reduce_out.p));
-			HIP_TRY(ctx, hipMemcpyAsync(rq.reduce_host, ctx->reduce_out.p, sizeof(MscReduceOut), hipMemcpyDeviceToHost, ctx->stream));
-			if (rq.flags_out) HIP_TRY(ctx, hipMemcpyAsync(rq.flags_out, ctx->flags.p, mc, hipMemcpyDeviceToHost, ctx->stream));
+			constexpr size_t kRo = (sizeof(MscReduceOut) + 63) / 64 * 64;
+			if ((r = ensure_pinned(ctx, ctx->pin_down, kRo + mc)) != MSC_OK) return r;
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_down.p, ctx->reduce_out.p, sizeof(MscReduceOut), hipMemcpyDeviceToHost, ctx->stream));
+			if (rq.flags_out) HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->pin_down.p + kRo, ctx->flags.p, mc, hipMemcpyDeviceToHost, ctx->stream));
 		}
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1172,6 +1203,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, hipMemcpyAsync(po_host.data(), ctx->pair_out.p, (size_t)mc * sizeof(MscPairOut), hipMemcpyDeviceToHost, ctx->stream));
 		}
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (rq.reduce_mode >= 0) {
+			constexpr size_t kRo = (sizeof(MscReduceOut) + 63) / 64 * 64;
+			memcpy(rq.reduce_host, ctx->pin_down.p, sizeof(MscReduceOut));
+			if (rq.flags_out) memcpy(rq.flags_out, (const uint8_t*)ctx->pin_down.p + kRo, mc);
+		}
 		float t = 0;
 		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
 		if (need_po) {
