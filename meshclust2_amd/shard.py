@@ -129,3 +129,51 @@ class ShardedBlockScorer:
         else:
             total = counts.cpu().numpy()
         return close, total
+
+
+def device_tensors(hist_set, n_slots):
+    """torch uint8 views [n_slots, slot_bytes] / [n_slots, scalar_bytes] over a dense set's device memory
+    (msc_hist_set_device_view), so that RCCL collectives read and write histogram slots in place.
+    torch must have been imported BEFORE the library was loaded (one HIP runtime per process: torch brings its own)."""
+    import torch
+    bins_ptr, slot_bytes, scal_ptr, scal_bytes = hist_set.device_view()
+
+    class _View:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    bins = torch.as_tensor(_View(bins_ptr, slot_bytes * n_slots), device="cuda").view(n_slots, slot_bytes)
+    scal = torch.as_tensor(_View(scal_ptr, scal_bytes * n_slots), device="cuda").view(n_slots, scal_bytes)
+    return bins, scal
+
+
+class ShardedCentres:
+    """The update-round exchange of SURVEY 8(e): centre j (position in `part`, cluster/ClusterFactory.cpp:386) lives on rank
+    plan.owner(j); one ALL-GATHER per payload region replicates every centre histogram on every rank, after which the
+    Trainer::merge scan over neighbouring centres (cluster/ClusterFactory.cpp:386-388) and the filter neighbourhoods of
+    mean_shift_update are local and give every rank the single-process answer.
+
+    backend.centre_payload(n_pad)  -> list of tensors [n_pad, row_bytes]: this rank's centres in local order, rows past its
+                                      own count are padding (never read back)
+    backend.gather_buffers(n_rows) -> list of tensors [n_rows, row_bytes] the gathered rows land in (n_rows = world * n_pad)
+    backend.import_centres(rows)   -> rows[j] = gathered row of global centre j; called once the collectives have completed
+    """
+
+    def __init__(self, dist, plan, backend, rank, device="cpu"):
+        self.dist, self.plan, self.backend, self.rank, self.device = dist, plan, backend, rank, device
+
+    def gather(self):
+        """-> rows (np.int64, one per global centre); plan.n_total is the number of centres of this round"""
+        world = self.plan.world
+        n_pad = max(self.plan.local_count(r) for r in range(world))
+        payload = self.backend.centre_payload(n_pad)
+        out = self.backend.gather_buffers(world * n_pad)
+        if world > 1:
+            pending = [self.dist.all_gather_into_tensor(o, p, async_op=True) for o, p in zip(out, payload)]
+            for w in pending:
+                w.wait()
+        else:
+            for o, p in zip(out, payload):
+                o.copy_(p)
+        rows = np.array([self.plan.owner(j) * n_pad + self.plan.local(j) for j in range(self.plan.n_total)], dtype=np.int64)
+        self.backend.import_centres(rows)
+        return rows

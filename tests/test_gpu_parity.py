@@ -858,3 +858,51 @@ def test_degenerate_inputs(ctx, oracle):
     # a zero-length candidate never reaches length_difference in get_close: the length window drops it first (cluster/Trainer.cpp:39-48)
     flags, bp, bs, im = trn.get_close(hs, np.array([13], dtype=np.uint32), hs, 0)
     assert list(flags) == [0] and bp == -1 and im
+
+
+@pytest.mark.parametrize("dtype,k,wts", [(16, 5, "weights_k5_u16.txt"), (32, 9, "weights_k9_u32.txt")])
+def test_centre_gather_in_place_keeps_the_merge_scan(ctx, dtype, k, wts):
+    """SURVEY 8(e), update round: shard.ShardedCentres moves centre slots through torch views of the set's device memory
+    (msc_hist_set_device_view -> payload rows -> gathered rows -> msc_hist_import_done) exactly as the RCCL all-gather does
+    on N ranks; Trainer::merge over the gathered slots == over the original ones, also after a Q x M pass has built the
+    digest mirror (the gathered slots must be re-digested)."""
+    import torch
+    from meshclust2_amd import shard
+    seqs, _ = synth.families(515 + k, 60, 700, family=6)
+    pts = api.HistogramSet(ctx, k, dtype, len(seqs))
+    pts.build(seqs)
+    feat = api.Feature.from_text(ctx, weights_text(wts), 0)
+    trn = api.Trainer(ctx, feat, 0.9)
+    nc = 23
+    plan = shard.ShardPlan(nc, 1, block=4)
+    n_pad = plan.local_count(0)
+    cen = api.HistogramSet(ctx, k, dtype, 2 * n_pad)          # slots [0, n_pad): own centres; [n_pad, 2 n_pad): gathered
+    for c in range(nc):
+        cen.clone_from(c, pts, c)
+    own = np.arange(nc, dtype=np.uint32)
+    # a Q x M pass over the (still empty) gathered half builds the digest mirror with stale contents for those slots
+    for c in range(nc):
+        cen.clone_from(n_pad + c, pts, len(seqs) - 1 - c)
+    before = api.score_multi(ctx, feat, cen, np.arange(n_pad, n_pad + nc, dtype=np.uint32), cen, np.arange(16, dtype=np.uint32), want=("sum",))["sum"]
+    ctx.synchronize()
+    bins, scal = shard.device_tensors(cen, 2 * n_pad)
+
+    class Backend:
+        def centre_payload(self, n):
+            return [bins[:n], scal[:n]]
+
+        def gather_buffers(self, n_rows):
+            return [bins[n_pad:n_pad + n_rows], scal[n_pad:n_pad + n_rows]]
+
+        def import_centres(self, rows):
+            torch.cuda.synchronize()
+            cen.import_done(n_pad, n_pad)
+
+    rows = shard.ShardedCentres(None, plan, Backend(), 0, device="cuda").gather()
+    assert rows.tolist() == list(range(nc))
+    gathered = (n_pad + rows).astype(np.uint32)
+    for delta in (1, 5):
+        assert list(trn.merge_all(cen, gathered, delta)) == list(trn.merge_all(cen, own, delta))
+    a = api.score_multi(ctx, feat, cen, gathered, cen, np.arange(16, dtype=np.uint32), want=("sum",))["sum"]
+    b = api.score_multi(ctx, feat, cen, own, cen, np.arange(16, dtype=np.uint32), want=("sum",))["sum"]
+    assert np.array_equal(a, b) and not np.array_equal(a, before)

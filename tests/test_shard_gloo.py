@@ -38,6 +38,60 @@ def _seqs():
     return seqs
 
 
+DELTA = 3
+
+
+def _centres():
+    """14 centres, members of the same family next to each other so that the merge scan finds partners within DELTA"""
+    seqs, headers = synth.families(77, N, 1000, family=6)
+    order = sorted(range(N), key=lambda i: len(seqs[i]))          # position in _seqs() -> original index
+    fam = [headers[i].split()[-1] for i in order]
+    pos = sorted(range(N), key=lambda p: (fam[p], p))
+    return pos[:14]
+
+
+CENTRES = _centres()
+
+
+def _centre_round(dist, rank, world, seqs, pred, nb):
+    """update-round exchange: every rank contributes the centres it owns, all-gathers, and scans Trainer::merge locally"""
+    import ctypes as C
+    import torch
+    from oracle import oracle_py
+    plan = shard.ShardPlan(len(CENTRES), world, block=2)
+    own = [oracle_py.hist(seqs[CENTRES[j]], K, DT) for j in plan.local_globals(rank)]
+
+    class Backend:
+        def centre_payload(self, n_pad):
+            bins = torch.zeros(n_pad, nb, dtype=torch.int32)
+            meta = torch.zeros(n_pad, 2, dtype=torch.int64)
+            for i, h in enumerate(own):
+                bins[i] = torch.from_numpy(h.array().astype(np.int32))
+                meta[i] = torch.tensor([h.mag, h.length])
+            return [bins, meta]
+
+        def gather_buffers(self, n_rows):
+            self.bins, self.meta = torch.full((n_rows, nb), -1, dtype=torch.int32), torch.zeros(n_rows, 2, dtype=torch.int64)
+            return [self.bins, self.meta]
+
+        def import_centres(self, rows):
+            self.keep, self.centres = [], []
+            for r in rows:
+                a = np.ascontiguousarray(self.bins[r].numpy().astype(np.uint16))
+                h = oracle_py.Hist()
+                h.dtype, h.k, h.nbins = DT, K, nb
+                h.bins = a.ctypes.data_as(C.c_void_p).value
+                h.mag, h.length = int(self.meta[r, 0]), int(self.meta[r, 1])
+                self.keep.append(a)
+                self.centres.append(h)
+
+    be = Backend()
+    rows = shard.ShardedCentres(dist, plan, be, rank).gather()
+    n = len(CENTRES)
+    assert len(set(rows.tolist())) == n
+    return [oracle_py.merge(pred, CUTOFF, be.centres, i, i + 1, min(n - 1, i + DELTA)) for i in range(n - 1)]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -86,7 +140,7 @@ def _worker(rank, world, port, q):
         for qg in (0, 9, 17, 30, 45):
             flags, g, sim, is_min, n_close = trn.get_close(qg)
             out.append((qg, flags.tolist(), g, sim, is_min, n_close))
-        q.put((rank, mine.tolist(), out))
+        q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb)))
     finally:
         dist.destroy_process_group()
 
@@ -105,8 +159,8 @@ def test_world2_matches_single_process(oracle):
         p.start()
     res = {}
     for _ in range(world):
-        r, mine, out = q.get(timeout=180)
-        res[r] = (mine, out)
+        r, mine, out, merged = q.get(timeout=180)
+        res[r] = (mine, out, merged)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -118,8 +172,14 @@ def test_world2_matches_single_process(oracle):
         f, bp, bs, im = oracle.get_close(pred, CUTOFF, hs[qg], hs)
         glob_flags = np.zeros(len(seqs), dtype=np.uint8)
         for r in range(world):
-            mine, out = res[r]
+            mine, out, _ = res[r]
             _, flags, g, sim, is_min, n_close = out[qi]
             glob_flags[np.array(mine)] = flags
             assert (g, is_min, n_close) == (bp, im, int(f.sum())) and sim == pytest.approx(bs, rel=1e-12)
         assert np.array_equal(glob_flags, f)
+    # every rank holds all centres after the all-gather: its merge scan equals the single-process one
+    cs = [hs[c] for c in CENTRES]
+    want = [oracle.merge(pred, CUTOFF, cs, i, i + 1, min(len(cs) - 1, i + DELTA)) for i in range(len(cs) - 1)]
+    assert any(w > i for i, w in enumerate(want))           # the scan does merge something
+    for r in range(world):
+        assert res[r][2] == want
