@@ -5,14 +5,18 @@
 //   KmerHashTable::hash + wholesaleIncrementNoOverflow   nonltr/KmerHashTable.cpp:134-160,236-256
 //   Loader::fill_table copy, DivergencePoint ctor copy + mag, stddev loop
 //                                             clutil/Loader.cpp:73-77,158-171; clutil/DivergencePoint.cpp:99-110
-// Three launches, all HBM-bound byte/integer work (no MFMA):
-//   k_fill      : coalesced 16-byte stores of the pseudocount (1) over the batch's slots
-//   k_count     : one thread per k-mer; 2k bits pulled from the packed 2-bit stream, bit-reversed into the
-//                 reference's "first base most significant" index, mapped through the tile permutation
-//                 (msc_layout.h) and added with one global atomic (saturating CAS only when a sequence is
-//                 long enough to saturate T)
-//   k_finalize  : one workgroup per slot re-reads it once: sum, sum of squares, max, per-tile sums;
-//   k_prefix    : exclusive scan of the tile sums -> the tile carries the pair kernel's prefix statistic needs.
+// All HBM-bound byte/integer work (no MFMA). Three builders, chosen per batch by msc_hist_build_packed:
+//   k_build_lds  : 4^k <= 16384 -- the whole histogram in LDS, slot written once
+//   k_build_sort : larger k, <= 32768 k-mers per sequence -- the sequence's k-mer indices sorted in LDS, every scalar derived
+//                  from the runs, slot written once as a stream of ones patched per tile
+//   k_fill + k_count + k_finalize + k_prefix : everything else (long sequences, ungrouped segment lists)
+//     k_fill      : coalesced 16-byte stores of the pseudocount (1) over the batch's slots
+//     k_count     : one thread per k-mer; 2k bits pulled from the packed 2-bit stream, bit-reversed into the
+//                   reference's "first base most significant" index, mapped through the tile permutation
+//                   (msc_layout.h) and added with one global atomic (saturating CAS only when a sequence is
+//                   long enough to saturate T)
+//     k_finalize  : one workgroup per slot re-reads it once: sum, sum of squares, max, per-tile sums;
+//     k_prefix    : exclusive scan of the tile sums -> the tile carries the pair kernel's prefix statistic needs.
 #include "msc_internal.h"
 
 namespace {
@@ -282,6 +286,191 @@ __global__ void __launch_bounds__(kBlock) k_build_lds(T* __restrict__ bins, uint
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ large k: sort + one streaming write
+// 4^k bins do not fit LDS, but a sequence's k-mers do: an L-base sequence touches at most L bins and every other bin is the
+// pseudocount. One workgroup per sequence loads its k-mer indices into LDS, bitonic-sorts them, derives every scalar of the
+// record from the runs of equal indices (sum = N + k-mers, sum of squares, max, saturation, tile prefixes by binary search)
+// and then writes the slot ONCE, tile by tile in the tile-permuted layout: a tile without k-mers is four 16-byte stores of
+// ones per lane, a tile with k-mers is patched in a 4 KiB wave-private LDS stage first. No fill pass, no global atomics, no
+// finalize re-read: N*sizeof(T) bytes written + L/4 read per sequence (the fill + count + finalize path moves 3x that).
+constexpr uint32_t kSortMaxKeys = 32768;
+constexpr uint32_t kStageWords = 1024;               // one 4 KiB tile (LPT == 4)
+constexpr uint32_t kMaxSat = 128;                    // runs that saturate T: >= 255 equal k-mers each, so <= 128 of 32768
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_build_sort(T* __restrict__ bins, uint8_t* __restrict__ scalars, uint64_t scalar_stride,
+                                                       uint64_t slot_elems, uint64_t first_slot, int k, uint32_t R, uint32_t S, uint64_t nbins,
+                                                       const uint32_t* __restrict__ packed, const uint64_t* __restrict__ seg_start,
+                                                       const uint64_t* __restrict__ kmer_off, const uint64_t* __restrict__ seq_seg_begin,
+                                                       const uint32_t* __restrict__ seq_ids, uint32_t P, const uint64_t* __restrict__ seq_meta,
+                                                       unsigned long long* __restrict__ bounds) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];       // [4][kStageWords] tile stages, then P keys
+	__shared__ uint64_t s_red[4][kBlock / 64];
+	__shared__ uint2 s_sat[kMaxSat];                  // (bin, occurrences dropped by saturation)
+	__shared__ uint32_t s_nsat;
+	constexpr uint32_t E = 16 / sizeof(T);
+	uint32_t* keys = s_mem + (kBlock / 64) * kStageWords;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t seq = seq_ids[blockIdx.x];
+	const uint64_t slot = first_slot + seq;
+	const uint32_t tile_bins = 64 * R;
+	// 1. k-mer indices of this sequence (first base most significant, nonltr/KmerHashTable.cpp:108-131)
+	const uint64_t sb = seq_seg_begin[seq], se = seq_seg_begin[seq + 1];
+	const uint64_t k0 = kmer_off[sb];
+	const uint32_t n = (uint32_t)(kmer_off[se] - k0);
+	for (uint64_t j = sb; j < se; j++) {
+		const uint64_t nk = kmer_off[j + 1] - kmer_off[j], base = seg_start[j];
+		const uint32_t o = (uint32_t)(kmer_off[j] - k0);
+		for (uint64_t t = tid; t < nk; t += kBlock) {
+			const uint64_t pos = base + t;
+			const uint64_t window = (uint64_t)packed[pos >> 4] | ((uint64_t)packed[(pos >> 4) + 1] << 32);
+			uint32_t bits = (uint32_t)(window >> ((pos & 15) * 2));
+			if (2 * k < 32) bits &= (1u << (2 * k)) - 1u;
+			keys[o + t] = rev2(bits) >> (32 - 2 * k);
+		}
+	}
+	for (uint32_t i = n + tid; i < P; i += kBlock) keys[i] = 0xffffffffu;
+	{	// every stage starts as a tile of ones and is restored to that after each use
+		T ones[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) ones[j] = (T)1;
+		uint4* st = reinterpret_cast<uint4*>(s_mem + wave * kStageWords);
+#pragma unroll
+		for (int i = 0; i < 4; i++) st[i * 64 + lane] = *reinterpret_cast<const uint4*>(ones);
+	}
+	if (tid == 0) s_nsat = 0;
+	__syncthreads();
+	// 2. bitonic sort
+	for (uint32_t size = 2; size <= P; size <<= 1) {
+		for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+			for (uint32_t t = tid; t < P / 2; t += kBlock) {
+				const uint32_t lo = 2 * t - (t & (stride - 1));
+				const uint32_t hi = lo + stride;
+				const bool up = (lo & size) == 0;
+				const uint32_t a = keys[lo], b = keys[hi];
+				if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+			}
+			__syncthreads();
+		}
+	}
+	// 3. runs of equal keys -> the scalar record. `i` is a run head: length = upper_bound(keys[i]) - i
+	const uint64_t tmax = sizeof(T) == 8 ? ~0ull : ((1ull << (8 * sizeof(T))) - 1);
+	auto run_value = [&](uint32_t i, uint64_t* dropped) -> uint64_t {
+		const uint32_t key = keys[i];
+		uint32_t lo = i + 1, hi = n;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
+		uint64_t v = 1ull + (lo - i);                        // pseudocount + occurrences
+		*dropped = 0;
+		if (v > tmax) { *dropped = v - tmax; v = tmax; }     // wholesaleIncrementNoOverflow stops at max(T)
+		return v;
+	};
+	{
+		const uint32_t C = P / kBlock;                       // P >= kBlock
+		const uint32_t c0 = tid * C, c1 = c0 + C < n ? c0 + C : (c0 < n ? n : c0);
+		uint64_t ex = 0, sq = 0, mx = 1, ovf = 0;
+		for (uint32_t i = c0; i < c1; i++) {
+			if (i == 0 || keys[i] != keys[i - 1]) {
+				uint64_t dropped;
+				const uint64_t v = run_value(i, &dropped);
+				if (dropped) {
+					ovf = 1;
+					const uint32_t w = atomicAdd(&s_nsat, 1u);
+					if (w < kMaxSat) s_sat[w] = make_uint2(keys[i], (uint32_t)dropped);
+				}
+				ex += v - 1; sq += v * v - 1; mx = v > mx ? v : mx;
+			}
+		}
+		ex = wave_sum_u64(ex); sq = wave_sum_u64(sq); mx = wave_max_u64(mx); ovf = wave_max_u64(ovf);
+		if (lane == 0) { s_red[0][wave] = ex; s_red[1][wave] = sq; s_red[2][wave] = mx; s_red[3][wave] = ovf; }
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint64_t ex = 0, sq = 0, mx = 1, ovf = 0;
+		for (int i = 0; i < kBlock / 64; i++) { ex += s_red[0][i]; sq += s_red[1][i]; mx = s_red[2][i] > mx ? s_red[2][i] : mx; ovf |= s_red[3][i]; }
+		// the whole record is written here (length, 1-mer table and k-mer count arrive as 6 words per sequence), and the batch's
+		// range bounds are folded on the device: the host neither uploads nor re-reads one record per slot
+		const uint64_t* meta = seq_meta + 6ull * seq;
+		const uint64_t sum = nbins + ex, sum_sq = nbins + sq;
+		MscSlotScalars rec;
+		rec.mag = sum; rec.length = meta[0]; rec.sum = sum; rec.sum_sq = sum_sq; rec.max_count = mx;
+		rec.one_mers[0] = meta[1]; rec.one_mers[1] = meta[2]; rec.one_mers[2] = meta[3]; rec.one_mers[3] = meta[4];
+		const double N = (double)nbins, aq = (double)sum / N;
+		const double var = ((double)sum_sq - 2.0 * aq * (double)sum + N * aq * aq) / N;
+		rec.stddev = sqrt(var > 0 ? var : 0);
+		rec.overflow = ovf; rec.id = 0; rec.n_kmers = meta[5];
+		rec.reserved[0] = rec.reserved[1] = rec.reserved[2] = 0;
+		*reinterpret_cast<MscSlotScalars*>(scalars + slot * scalar_stride) = rec;
+		atomicMax(&bounds[0], (unsigned long long)mx);
+		atomicMax(&bounds[1], (unsigned long long)sum);
+	}
+	// 4. tile prefixes: bins before tile t sum to t * tile_bins + (k-mers with a smaller index) - (occurrences saturation dropped)
+	const uint32_t nsat = s_nsat < kMaxSat ? s_nsat : kMaxSat;
+	auto lower_bound = [&](uint64_t bound) -> uint32_t {
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)keys[mid] < bound) lo = mid + 1; else hi = mid; }
+		return lo;
+	};
+	{
+		uint64_t* prefix = reinterpret_cast<uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
+		for (uint32_t t = tid; t < S; t += kBlock) {
+			const uint64_t bound = (uint64_t)t * tile_bins;
+			uint64_t v = bound + lower_bound(bound);
+			for (uint32_t i = 0; i < nsat; i++) if ((uint64_t)s_sat[i].x < bound) v -= s_sat[i].y;
+			prefix[t] = v;
+		}
+	}
+	// 5. the slot, written once: wave w streams tiles [w * S/4, (w+1) * S/4)
+	T* stage = reinterpret_cast<T*>(s_mem + wave * kStageWords);
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	const v4u* stage4 = reinterpret_cast<const v4u*>(stage);
+	v4u* out = reinterpret_cast<v4u*>(bins + slot * slot_elems);
+	T ones[E];
+#pragma unroll
+	for (uint32_t j = 0; j < E; j++) ones[j] = (T)1;
+	const v4u one_v = *reinterpret_cast<const v4u*>(ones);
+	const uint32_t per_wave = S / (kBlock / 64);          // S is a power of four >= 16 here
+	const uint32_t t0 = wave * per_wave, t1 = t0 + per_wave;
+	uint32_t lo = lower_bound((uint64_t)t0 * tile_bins);
+	for (uint32_t t = t0; t < t1; t++) {
+		const uint64_t bound_hi = (uint64_t)(t + 1) * tile_bins;
+		uint32_t cnt = 0;                                  // k-mers of this tile: keys[lo, lo + cnt)
+		while (true) {
+			const uint32_t i = lo + cnt + lane;
+			const uint32_t key = i < n ? keys[i] : 0xffffffffu;
+			const uint32_t c = (uint32_t)__popcll(__ballot(i < n && (uint64_t)key < bound_hi));
+			cnt += c;
+			if (c < 64) break;
+		}
+		v4u* dst = out + (uint64_t)t * 256 + lane;
+		if (cnt == 0) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) __builtin_nontemporal_store(one_v, dst + i * 64);
+		} else {
+			for (int pass = 0; pass < 2; pass++) {         // 0: patch the run values in, 1: restore the ones
+				for (uint32_t b = 0; b < cnt; b += 64) {
+					const uint32_t i = lo + b + lane;
+					if (b + lane < cnt && (i == 0 || keys[i] != keys[i - 1])) {
+						const uint32_t e = (uint32_t)(keys[i] % tile_bins);
+						const uint32_t ln = e / R, r = e % R;
+						const uint32_t phys = (r / E) * (64 * E) + ln * E + (r % E);
+						uint64_t dropped;
+						stage[phys] = pass == 0 ? (T)run_value(i, &dropped) : (T)1;
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS operations of one wave execute in order; this
+				__builtin_amdgcn_wave_barrier();                             // pins the compiler's order to the program's
+				if (pass == 0) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) __builtin_nontemporal_store(stage4[i * 64 + lane], dst + i * 64);
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+		}
+		lo += cnt;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ permute (upload / download)
 template <typename T>
 __global__ void __launch_bounds__(kBlock) k_permute(const T* __restrict__ src, T* __restrict__ dst, uint64_t nbins, uint64_t padded,
@@ -359,6 +548,31 @@ hipError_t msc_launch_build_lds(hipStream_t st, void* bins, uint8_t* scalars, co
 		                                                                                         seq_seg_begin);
 	});
 	return hipGetLastError();
+}
+
+bool msc_sort_build_supported(const MscLayout& L, int k) { return L.LPT == 4 && L.S >= 16 && L.S % 4 == 0 && k <= 15; }
+uint32_t msc_sort_build_max_kmers() { return kSortMaxKeys; }
+
+// seq_ids: n sequence numbers (relative to first_slot) whose k-mer counts are all <= P; P a power of two in [256, 32768].
+// seq_meta: 6 words per sequence of the batch (effective length, the four 1-mer counts, k-mers); bounds: two words the kernel
+// folds max(max_count) and max(sum) into (zeroed by the caller).
+hipError_t msc_launch_build_sort(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype, uint64_t first_slot,
+                                 const uint32_t* seq_ids, uint64_t n, uint32_t P, const uint32_t* packed_words, const uint64_t* seg_start,
+                                 const uint64_t* kmer_off, const uint64_t* seq_seg_begin, const uint64_t* seq_meta, uint64_t* bounds) {
+	if (n == 0) return hipSuccess;
+	if (!msc_sort_build_supported(L, k) || P < (uint32_t)kBlock || P > kSortMaxKeys || (P & (P - 1))) return hipErrorInvalidValue;
+	const uint64_t stride = msc_scalar_stride(L.S);
+	const size_t lds = ((size_t)(kBlock / 64) * kStageWords + P) * sizeof(uint32_t);
+	hipError_t e = hipSuccess;
+	by_dtype(dtype, [&](auto tag) {
+		using T = decltype(tag);
+		if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)k_build_sort<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return;
+		k_build_sort<T><<<dim3((unsigned)n), dim3(kBlock), lds, st>>>((T*)bins, scalars, stride, L.padded_bins, first_slot, k, L.R, L.S, L.nbins,
+		                                                              packed_words, seg_start, kmer_off, seq_seg_begin, seq_ids, P, seq_meta,
+		                                                              (unsigned long long*)bounds);
+	});
+	return e != hipSuccess ? e : hipGetLastError();
 }
 
 hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,

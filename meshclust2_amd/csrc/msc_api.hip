@@ -38,7 +38,7 @@ struct msc_ctx {
 	char dev_name[128] = {0};
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
-	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg;
+	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg, seq_ids, seq_meta;
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
@@ -106,10 +106,17 @@ static int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
 
 static int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 	if (bytes <= b.cap) return MSC_OK;
-	if (b.p) { HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+	// a buffer that has to grow grows by at least half: callers that come back with slightly larger batches (chunked builds)
+	// would otherwise pay a hipFree + hipMalloc pair -- milliseconds each next to a resident 100 GB set -- on every call
 	size_t cap = std::max<size_t>(bytes, 4096);
+	if (b.p) { cap = std::max(cap, b.cap + b.cap / 2); HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
 	cap = (cap + 4095) / 4096 * 4096;
-	HIP_TRY(ctx, hipMalloc(&b.p, cap));
+	if (hipMalloc(&b.p, cap) != hipSuccess) {            // no room for the slack: exactly what was asked for
+		(void)hipGetLastError();
+		b.p = nullptr;
+		cap = (bytes + 4095) / 4096 * 4096;
+		HIP_TRY(ctx, hipMalloc(&b.p, cap));
+	}
 	b.cap = cap;
 	return MSC_OK;
 }
@@ -184,7 +191,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
-	                  &ctx->err_word, &ctx->seq_seg};
+	                  &ctx->err_word, &ctx->seq_seg, &ctx->seq_ids, &ctx->seq_meta};
 	for (DevBuf* b : bufs) release(*b);
 	(void)hipEventDestroy(ctx->ev_tiles0);
 	(void)hipEventDestroy(ctx->ev_tiles1);
@@ -599,16 +606,29 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 	bool saturating = false;
 	for (uint64_t i = 0; i < n_seqs; i++) if (kmers_per_seq[i] >= tmax) saturating = true;
 
-	// scalar records: length, k=1 table, overflow cleared
-	std::vector<MscSlotScalars> sc(n_seqs);
-	memset(sc.data(), 0, sizeof(MscSlotScalars) * n_seqs);
-	for (uint64_t i = 0; i < n_seqs; i++) {
-		sc[i].length = eff_len[i];
-		for (int b = 0; b < 4; b++) sc[i].one_mers[b] = one_mers ? one_mers[4 * i + b] : 0;
-		sc[i].n_kmers = kmers_per_seq[i];
+	bool grouped = true;          // segments in ascending sequence order, as msc_hist_build emits them
+	for (uint64_t j = 1; j < n_segs; j++) if (seg_seq[j] < seg_seq[j - 1]) grouped = false;
+	// large k, every sequence's k-mers fit one workgroup's LDS: sort + single streaming write per slot (hist_build.hip)
+	static const bool no_sort = getenv("MSC_NO_SORT_DENSE_BUILD") != nullptr;
+	uint64_t longest = 0;
+	for (uint64_t i = 0; i < n_seqs; i++) longest = std::max(longest, kmers_per_seq[i]);
+	static const bool no_lds = getenv("MSC_NO_LDS_BUILD") != nullptr;
+	const bool use_lds = msc_lds_build_supported(L) && grouped && !no_lds;      // small k: the whole histogram in LDS
+	const bool use_sort = !use_lds && msc_sort_build_supported(L, k) && grouped && !no_sort && longest <= msc_sort_build_max_kmers() && n_seqs <= 0xffffffffull;
+
+	std::vector<MscSlotScalars> sc;
+	if (!use_sort) {
+		// scalar records: length, k=1 table, overflow cleared (the sort builder writes whole records itself)
+		sc.resize(n_seqs);
+		memset(sc.data(), 0, sizeof(MscSlotScalars) * n_seqs);
+		for (uint64_t i = 0; i < n_seqs; i++) {
+			sc[i].length = eff_len[i];
+			for (int b = 0; b < 4; b++) sc[i].one_mers[b] = one_mers ? one_mers[4 * i + b] : 0;
+			sc[i].n_kmers = kmers_per_seq[i];
+		}
+		HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + first_slot * set->scalar_stride, set->scalar_stride, sc.data(), sizeof(MscSlotScalars),
+		                              sizeof(MscSlotScalars), n_seqs, hipMemcpyHostToDevice, ctx->stream));
 	}
-	HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + first_slot * set->scalar_stride, set->scalar_stride, sc.data(), sizeof(MscSlotScalars),
-	                              sizeof(MscSlotScalars), n_seqs, hipMemcpyHostToDevice, ctx->stream));
 
 	// packed stream (+8 bytes so the kernel's 64-bit window never reads past the end)
 	const size_t packed_bytes = (size_t)((n_bases + 3) / 4);
@@ -621,15 +641,12 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		if ((r = ensure(ctx, ctx->seg_seq, n_segs * sizeof(uint32_t))) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->seg_start, n_segs * sizeof(uint64_t))) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->kmer_off, (n_segs + 1) * sizeof(uint64_t))) != MSC_OK) return r;
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_seq.p, seg_seq, n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		if (!use_sort) HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_seq.p, seg_seq, n_segs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->seg_start.p, seg_start, n_segs * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->kmer_off.p, koff.data(), (n_segs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	}
-	// small k: one fused LDS pass per sequence (needs the segments grouped by ascending sequence, as msc_hist_build emits them)
-	bool grouped = true;
-	for (uint64_t j = 1; j < n_segs; j++) if (seg_seq[j] < seg_seq[j - 1]) grouped = false;
-	static const bool no_lds = getenv("MSC_NO_LDS_BUILD") != nullptr;
-	if (msc_lds_build_supported(L) && grouped && !no_lds) {
+	// small k: one fused LDS pass per sequence (needs the segments grouped by ascending sequence)
+	if (use_lds) {
 		std::vector<uint64_t> sbeg(n_seqs + 1, 0);
 		for (uint64_t j = 0; j < n_segs; j++) sbeg[seg_seq[j] + 1]++;
 		for (uint64_t i = 0; i < n_seqs; i++) sbeg[i + 1] += sbeg[i];
@@ -643,6 +660,53 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		                                  (const uint64_t*)ctx->seg_start.p, (const uint64_t*)ctx->kmer_off.p, (const uint64_t*)ctx->seq_seg.p));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // sbeg lives on this stack frame
 		return refresh_bounds(ctx, set, first_slot, n_seqs);
+	}
+	// Sequences are launched in classes of LDS footprint so that short ones keep their occupancy next to long ones.
+	if (use_sort) {
+		std::vector<uint64_t> sbeg(n_seqs + 1, 0), meta(6 * n_seqs);
+		for (uint64_t j = 0; j < n_segs; j++) sbeg[seg_seq[j] + 1]++;
+		for (uint64_t i = 0; i < n_seqs; i++) {
+			sbeg[i + 1] += sbeg[i];
+			meta[6 * i] = eff_len[i];
+			for (int b = 0; b < 4; b++) meta[6 * i + 1 + b] = one_mers ? one_mers[4 * i + b] : 0;
+			meta[6 * i + 5] = kmers_per_seq[i];
+		}
+		const uint32_t classes[] = {1024, 4096, 16384, 32768};
+		std::vector<uint32_t> ids;
+		ids.reserve(n_seqs);
+		uint64_t class_begin[5] = {0, 0, 0, 0, 0};
+		for (int c = 0; c < 4; c++) {
+			const uint64_t lo_k = c ? classes[c - 1] : 0;
+			for (uint64_t i = 0; i < n_seqs; i++)
+				if ((c == 0 ? kmers_per_seq[i] <= classes[0] : (kmers_per_seq[i] > lo_k && kmers_per_seq[i] <= classes[c]))) ids.push_back((uint32_t)i);
+			class_begin[c + 1] = ids.size();
+		}
+		if ((r = ensure(ctx, ctx->seq_seg, (n_seqs + 1) * sizeof(uint64_t))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->seq_ids, n_seqs * sizeof(uint32_t))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->seq_meta, meta.size() * sizeof(uint64_t) + 16)) != MSC_OK) return r;
+		if (n_segs == 0) {
+			if ((r = ensure(ctx, ctx->seg_start, 8)) != MSC_OK) return r;
+			if ((r = ensure(ctx, ctx->kmer_off, 8)) != MSC_OK) return r;
+		}
+		uint64_t* d_bounds = (uint64_t*)ctx->seq_meta.p + meta.size();      // two words after the table
+		HIP_TRY(ctx, hipMemsetAsync(d_bounds, 0, 16, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seq_seg.p, sbeg.data(), (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seq_ids.p, ids.data(), n_seqs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->seq_meta.p, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		for (int c = 0; c < 4; c++)
+			HIP_TRY(ctx, msc_launch_build_sort(ctx->stream, set->bins, set->scalars, L, k, set->dtype, first_slot, (const uint32_t*)ctx->seq_ids.p + class_begin[c],
+			                                   class_begin[c + 1] - class_begin[c], classes[c], (const uint32_t*)ctx->packed.p, (const uint64_t*)ctx->seg_start.p,
+			                                   (const uint64_t*)ctx->kmer_off.p, (const uint64_t*)ctx->seq_seg.p, (const uint64_t*)ctx->seq_meta.p, d_bounds));
+		uint64_t b[2] = {0, 0};
+		HIP_TRY(ctx, hipMemcpyAsync(b, d_bounds, 16, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // sbeg, ids, meta and b live on this stack frame
+		set->max_count = std::max(set->max_count, b[0]);
+		set->max_sum = std::max(set->max_sum, b[1]);
+		if (set->digest && n_seqs) {                         // as refresh_bounds: these slots are stale in the digest mirror
+			if (set->dg_lo >= set->dg_hi) { set->dg_lo = first_slot; set->dg_hi = first_slot + n_seqs; }
+			else { set->dg_lo = std::min(set->dg_lo, first_slot); set->dg_hi = std::max(set->dg_hi, first_slot + n_seqs); }
+		}
+		return MSC_OK;
 	}
 	HIP_TRY(ctx, msc_launch_fill(ctx->stream, set->bins, L, first_slot, n_seqs));
 	HIP_TRY(ctx, msc_launch_count(ctx->stream, set->bins, set->scalars, L, k, set->dtype, first_slot, (const uint32_t*)ctx->packed.p,

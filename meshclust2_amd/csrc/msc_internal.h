@@ -116,6 +116,11 @@ hipError_t msc_launch_count(hipStream_t st, void* bins, uint8_t* scalars, const 
 hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,
                                uint64_t first_slot, uint64_t n_slots, bool keep_mag);
 bool msc_lds_build_supported(const MscLayout& L);
+bool msc_sort_build_supported(const MscLayout& L, int k);
+uint32_t msc_sort_build_max_kmers();
+hipError_t msc_launch_build_sort(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype, uint64_t first_slot,
+                                 const uint32_t* seq_ids, uint64_t n, uint32_t P, const uint32_t* packed_words, const uint64_t* seg_start,
+                                 const uint64_t* kmer_off, const uint64_t* seq_seg_begin, const uint64_t* seq_meta, uint64_t* bounds);
 hipError_t msc_launch_build_lds(hipStream_t st, void* bins, uint8_t* scalars, const MscLayout& L, int k, int dtype, uint64_t first_slot,
                                 uint64_t n_seqs, const uint32_t* packed_words, const uint64_t* seg_start, const uint64_t* kmer_off,
                                 const uint64_t* seq_seg_begin);

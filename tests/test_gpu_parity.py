@@ -906,3 +906,35 @@ def test_centre_gather_in_place_keeps_the_merge_scan(ctx, dtype, k, wts):
     a = api.score_multi(ctx, feat, cen, gathered, cen, np.arange(16, dtype=np.uint32), want=("sum",))["sum"]
     b = api.score_multi(ctx, feat, cen, own, cen, np.arange(16, dtype=np.uint32), want=("sum",))["sum"]
     assert np.array_equal(a, b) and not np.array_equal(a, before)
+
+
+@pytest.mark.parametrize("dtype,k", [(8, 8), (16, 8), (32, 9), (64, 8), (8, 10)])
+def test_sort_build_length_classes_saturation_prefixes(ctx, oracle, dtype, k):
+    """The large-k builder (k_build_sort: LDS sort + one streaming write per slot): sequences of all four LDS classes in one
+    batch, empty and N-only records, runs that saturate uint8_t (>= 255 equal k-mers, several per sequence, in different
+    tiles), and the tile prefixes / sums it derives from the sorted runs (checked through emd and the other statistics).
+    A batch holding a sequence with more than 32768 k-mers takes the fill + count + finalize path: same answers."""
+    rng = np.random.default_rng(31 * k + dtype)
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+    seqs = [rnd(900), rnd(3000), rnd(12000), rnd(30000), b"", b"N" * 50, b"ACG", rnd(200) + b"N" * 40 + rnd(300),
+            b"A" * 700 + rnd(400) + b"C" * 600 + rnd(100) + b"GT" * 500,          # saturating runs for u8 in three tiles
+            b"AC" * 10000 + rnd(50), rnd(1020 + k), rnd(4000 + k)]
+    long_batch = seqs[:4] + [b"AC" * 20000 + rnd(100)]
+    for batch in (seqs, long_batch):
+        hs = api.HistogramSet(ctx, k, dtype, len(batch))
+        hs.build(batch)
+        oh = [oracle.hist(s, k, dtype) for s in batch]
+        for i in range(len(batch)):
+            assert np.array_equal(hs.download(i), oh[i].array()), i
+            inf = hs.info(i)
+            assert (inf["mag"], inf["length"], inf["one_mers"], inf["overflow"]) == (oh[i].mag, oh[i].length, list(oh[i].one_mers), oh[i].overflow), i
+        scored = [i for i in range(len(batch)) if oh[i].length > 0]
+        for q in scored[:3] + scored[-2:]:
+            raw = api.pair_features_raw(ctx, hs, np.array(scored, dtype=np.uint32), hs, q, FAST_MASK, api.ORDER_CAND_FIRST)
+            for i, c in enumerate(scored):
+                for col, (name, bit) in zip(raw[i], FAST):
+                    exp = oracle.raw_feature(1 << bit, oh[c], oh[q])
+                    if name in EXACT and name != "kulczynski2":
+                        assert col == exp or (np.isnan(col) and np.isnan(exp)), (name, c, q)
+                    else:
+                        assert col == pytest.approx(exp, rel=RTOL, abs=1e-13, nan_ok=True), (name, c, q)      # an all-ones histogram has no variance
