@@ -11,8 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "msc_internal.h"
@@ -716,18 +718,26 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 	return refresh_bounds(ctx, set, first_slot, n_seqs);
 }
 
-extern "C" int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const char* const* seqs,
-                              const uint64_t* lens, int strip) {
-	if (!ctx || !set || set->ctx != ctx) return MSC_ERR_INVALID_ARG;
-	if (n_seqs && (!seqs || !lens)) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL sequence array");
-	std::vector<uint8_t> packed;
+// Host half of Loader::get_point for a batch: encode (a1) + 2-bit packing + the k=1 table, on several host threads. Every
+// sequence starts on a byte boundary of the packed stream (up to three filler bases that no segment covers), so the threads'
+// byte ranges are disjoint; segments carry global base offsets, which is all the device side looks at.
+namespace {
+struct EncodedRange {
+	std::vector<uint8_t> packed;                     // this range's sequences, each padded to a multiple of four bases
 	std::vector<uint32_t> seg_seq;
-	std::vector<uint64_t> seg_start, seg_end, eff(n_seqs), ones(4 * n_seqs);
-	uint64_t n_bases = 0;
+	std::vector<uint64_t> seg_start, seg_end;       // base offsets relative to the range's first base
+	uint64_t n_bases = 0;                            // padded
+	int64_t bad = -1;                                // first sequence of the range with a character outside the IUPAC map
+};
+
+void encode_range(const char* const* seqs, const uint64_t* lens, int strip, uint64_t i0, uint64_t i1, uint64_t* eff, uint64_t* ones, EncodedRange& out) {
 	std::vector<uint8_t> codes;
 	std::vector<Seg> segs;
 	std::string stripped;
-	for (uint64_t i = 0; i < n_seqs; i++) {
+	uint64_t total = 0;
+	for (uint64_t i = i0; i < i1; i++) total += (lens[i] + 3) / 4;
+	out.packed.assign((size_t)total, 0);
+	for (uint64_t i = i0; i < i1; i++) {
 		const char* s = seqs[i];
 		size_t len = (size_t)lens[i];
 		if (strip) {       // Loader<T>::get_point(std::string...) keeps upper-case A/C/G/T only (clutil/Loader.cpp:115-121)
@@ -737,26 +747,76 @@ extern "C" int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_sl
 			len = stripped.size();
 		}
 		uint64_t e = 0;
-		if (!encode_sequence(s, len, codes, segs, e))
-			return fail(ctx, MSC_ERR_INVALID_INPUT, "sequence %llu holds a character outside the IUPAC nucleotide map", (unsigned long long)i);
+		if (!encode_sequence(s, len, codes, segs, e)) { out.bad = (int64_t)i; return; }
 		eff[i] = e;
 		uint64_t om[4] = {1, 1, 1, 1};   // KmerHashTable<unsigned long,uint64_t> table_k1(1, 1), clutil/Loader.cpp:143
 		for (const Seg& sg : segs) {
 			for (int64_t p = sg.s; p <= sg.e; p++) om[codes[p] & 3]++;
-			seg_seq.push_back((uint32_t)i);
-			seg_start.push_back(n_bases + (uint64_t)sg.s);
-			seg_end.push_back(n_bases + (uint64_t)sg.e);
+			out.seg_seq.push_back((uint32_t)i);
+			out.seg_start.push_back(out.n_bases + (uint64_t)sg.s);
+			out.seg_end.push_back(out.n_bases + (uint64_t)sg.e);
 		}
 		for (int b = 0; b < 4; b++) ones[4 * i + b] = om[b];
-		packed.resize((size_t)((n_bases + len + 3) / 4), 0);
-		for (size_t p = 0; p < len; p++) {
-			const uint64_t g = n_bases + p;
-			packed[g >> 2] |= (uint8_t)((codes[p] & 3) << (2 * (g & 3)));
-		}
-		n_bases += len;
+		uint8_t* dst = out.packed.data() + (out.n_bases >> 2);
+		size_t p = 0;
+		for (; p + 4 <= len; p += 4) dst[p >> 2] = (uint8_t)((codes[p] & 3) | ((codes[p + 1] & 3) << 2) | ((codes[p + 2] & 3) << 4) | ((codes[p + 3] & 3) << 6));
+		for (; p < len; p++) dst[p >> 2] |= (uint8_t)((codes[p] & 3) << (2 * (p & 3)));
+		out.n_bases += (len + 3) / 4 * 4;
 	}
-	return msc_hist_build_packed(ctx, set, first_slot, n_seqs, packed.data(), n_bases, seg_seq.data(), seg_start.data(), seg_end.data(),
-	                             seg_seq.size(), eff.data(), ones.data());
+}
+}  // namespace
+
+extern "C" int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const char* const* seqs,
+                              const uint64_t* lens, int strip) {
+	if (!ctx || !set || set->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (n_seqs && (!seqs || !lens)) return fail(ctx, MSC_ERR_INVALID_ARG, "NULL sequence array");
+	if (n_seqs > 0xffffffffull) return fail(ctx, MSC_ERR_INVALID_ARG, "more than 2^32 sequences in one batch");
+	std::vector<uint64_t> eff(n_seqs), ones(4 * n_seqs);
+	uint64_t chars = 0;
+	for (uint64_t i = 0; i < n_seqs; i++) chars += lens[i];
+	// ranges of about equal character count, one host thread each (MSC_HOST_THREADS overrides; small batches stay on the caller's thread)
+	static const unsigned env_threads = [] { const char* e = getenv("MSC_HOST_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 0u; }();
+	unsigned nt = env_threads ? env_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if (!env_threads) nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, chars >> 18));          // >= 256 K characters per thread
+	nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, n_seqs));
+	std::vector<uint64_t> cut(nt + 1, n_seqs);
+	cut[0] = 0;
+	{
+		uint64_t acc = 0;
+		unsigned t = 1;
+		for (uint64_t i = 0; i < n_seqs && t < nt; i++) {
+			acc += lens[i];
+			if (acc >= chars * t / nt) cut[t++] = i + 1;
+		}
+	}
+	std::vector<EncodedRange> parts(nt);
+	if (nt == 1) {
+		encode_range(seqs, lens, strip, 0, n_seqs, eff.data(), ones.data(), parts[0]);
+	} else {
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < nt; t++) th.emplace_back(encode_range, seqs, lens, strip, cut[t], cut[t + 1], eff.data(), ones.data(), std::ref(parts[t]));
+		for (auto& x : th) x.join();
+	}
+	for (const EncodedRange& pr : parts)
+		if (pr.bad >= 0) return fail(ctx, MSC_ERR_INVALID_INPUT, "sequence %llu holds a character outside the IUPAC nucleotide map", (unsigned long long)pr.bad);
+	uint64_t n_bases = 0, n_segs = 0;
+	for (const EncodedRange& pr : parts) { n_bases += pr.n_bases; n_segs += pr.seg_seq.size(); }
+	std::vector<uint8_t> packed((size_t)(n_bases / 4));
+	std::vector<uint32_t> seg_seq(n_segs);
+	std::vector<uint64_t> seg_start(n_segs), seg_end(n_segs);
+	uint64_t base = 0, so = 0;
+	for (const EncodedRange& pr : parts) {
+		if (pr.n_bases) memcpy(packed.data() + base / 4, pr.packed.data(), (size_t)(pr.n_bases / 4));      // with `strip` the range buffer is larger than what it holds
+		for (size_t q = 0; q < pr.seg_seq.size(); q++) {
+			seg_seq[so + q] = pr.seg_seq[q];
+			seg_start[so + q] = base + pr.seg_start[q];
+			seg_end[so + q] = base + pr.seg_end[q];
+		}
+		so += pr.seg_seq.size();
+		base += pr.n_bases;
+	}
+	return msc_hist_build_packed(ctx, set, first_slot, n_seqs, packed.data(), n_bases, seg_seq.data(), seg_start.data(), seg_end.data(), n_segs, eff.data(),
+	                             ones.data());
 }
 
 static int check_slot(msc_ctx* ctx, const msc_hist_set* s, uint64_t slot) {

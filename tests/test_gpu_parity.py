@@ -938,3 +938,32 @@ def test_sort_build_length_classes_saturation_prefixes(ctx, oracle, dtype, k):
                         assert col == exp or (np.isnan(col) and np.isnan(exp)), (name, c, q)
                     else:
                         assert col == pytest.approx(exp, rel=RTOL, abs=1e-13, nan_ok=True), (name, c, q)      # an all-ones histogram has no variance
+
+
+@pytest.mark.parametrize("strip", [False, True])
+def test_threaded_host_encode_matches_oracle(ctx, oracle, strip):
+    """msc_hist_build encodes on several host threads once a batch holds >= 512 K characters (each sequence then starts on a
+    byte boundary of the packed stream): ragged lengths, N runs that merge or split segments, lower case, empty records and
+    the strip overload must come out exactly as the oracle's one-by-one encoding."""
+    rng = np.random.default_rng(5 + int(strip))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for i in range(900):
+        n = int(rng.integers(0, 1800))
+        s = bytearray(rng.choice(alpha, n).tobytes())
+        if n > 100 and i % 3 == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.integers(0, n - 50))
+                g = int(rng.integers(1, 30))
+                s[a:a + g] = b"N" * g
+        if i % 7 == 0:
+            s = bytearray(bytes(s).lower())
+        seqs.append(bytes(s))
+    assert sum(len(s) for s in seqs) > (1 << 19)
+    hs = api.HistogramSet(ctx, 5, 16, len(seqs))
+    hs.build(seqs, strip=strip)
+    for i, s in enumerate(seqs):
+        o = oracle.hist(s, 5, 16, strip)
+        assert np.array_equal(hs.download(i), o.array()), i
+        inf = hs.info(i)
+        assert (inf["length"], inf["one_mers"], inf["mag"]) == (o.length, list(o.one_mers), o.mag), i
