@@ -1221,11 +1221,16 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		return MSC_OK;
 	}
 	const bool sp = cs->sparse;
-	// LDS-staged merge kernel: lists must fit the LDS budget and the 32-bit arithmetic range; one record per candidate
-	static const bool no_sp_lds = getenv("MSC_SPARSE_NO_LDS") != nullptr;
-	const bool sp_lds = sp && !no_sp_lds && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 && L.nbins >= 64 &&
+	// Whole-list LDS merge kernel (MSC_SPARSE_LDS=1; superseded by the merge-path kernel below, kept for comparison): lists must fit
+	// the LDS budget and the 32-bit arithmetic range; one record per candidate
+	static const bool want_sp_lds = getenv("MSC_SPARSE_LDS") != nullptr;
+	const bool sp_lds = sp && want_sp_lds && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 && L.nbins >= 64 &&
 	                    ((size_t)(rq.qset->hdr_host[rq.q_slot].nnz + 128) + 4ull * (cs->max_nnz + 128)) * 8 <= 96 * 1024;
-	const uint32_t PS = sp ? (sp_lds ? 1 : MSC_SPARSE_SUB) : L.S;          // partial records per candidate
+	// lists of any length in the 32-bit arithmetic range: the merge-path kernel (chunks of the merged order staged per wave), one record per candidate
+	static const bool no_sp_mp = getenv("MSC_SPARSE_NO_MP") != nullptr;
+	const bool sp_mp = sp && !sp_lds && !no_sp_mp && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 &&
+	                   (uint64_t)rq.qset->hdr_host[rq.q_slot].nnz + cs->max_nnz <= msc_sparse_mp_max_entries();
+	const uint32_t PS = sp ? ((sp_lds || sp_mp) ? 1 : MSC_SPARSE_SUB) : L.S;          // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
@@ -1267,6 +1272,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			                                        rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.qset->hdr_host[rq.q_slot].nnz,
 			                                        cs->max_nnz, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p,
 			                                        need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order, ctx->num_cus));
+		} else if (sp_mp) {
+			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
+			                                       rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,
+			                                       (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr,
+			                                       need_div ? ctx->div_partials.p : nullptr, rq.order, ctx->num_cus,
+			                                       (uint32_t)(rq.qset->hdr_host[rq.q_slot].nnz + cs->max_nnz)));
 		} else if (sp) {
 			HIP_TRY(ctx, msc_launch_pair_sparse(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
 			                                    rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,

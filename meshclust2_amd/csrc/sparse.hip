@@ -12,10 +12,12 @@
 //     jefferey / jensen-shannon = sum_U term(p,q) + (N - |U|) * term(1,1)
 // so the dense epilogue (pair_features.hip) is reused unchanged on 16 partial records per candidate.
 //
-// k_pair_sparse: one LANE per (candidate, index sub-range): a branch-light two-pointer merge of the two sorted lists
-// restricted to the sub-range. No cross-lane communication (the prefix difference at a sub-range start comes from the
-// stored cum arrays), so 64 independent merges run per wavefront and the kernel is bound by the candidate lists' bytes
-// (12 B per stored bin instead of 4^k * sizeof(T) per histogram).
+// k_pair_sparse_mp (default): one WAVE per candidate walks the merged order of the two lists in LDS-staged chunks whose
+// boundaries, and the lanes' shares inside a chunk, come from merge-path co-rank searches (see the kernel).
+// k_pair_sparse (wide arithmetic range): one LANE per (candidate, index sub-range): a branch-light two-pointer merge of the two
+// sorted lists restricted to the sub-range, straight from global memory; the prefix difference at a sub-range start comes from the
+// stored cum arrays. k_pair_sparse_lds: the whole-list LDS variant the merge-path kernel replaced (MSC_SPARSE_LDS=1).
+// Bytes per pair: 8 B per stored bin of the candidate list instead of 4^k * sizeof(T) per histogram.
 //
 // Build: the dense builder (hist_build.hip) fills a scratch slot per sequence of the batch, then k_sparse_count /
 // k_sparse_write compact it IN INDEX ORDER: in the tile-permuted layout every lane already holds a logically consecutive
@@ -512,6 +514,147 @@ __global__ void __launch_bounds__(256) k_pair_sparse_lds(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ merge-path kernel (long lists)
+// Lists that do not fit LDS whole (20 kb sequences at k = 13: ~20 000 entries, 160 KB each). A WAVE owns one candidate and
+// walks the MERGED order of the two lists in chunks of kMpT entries: the chunk boundaries are co-ranks on the merge path
+// (how many candidate entries the first t * kMpT merged entries hold; 64 lanes search the next 63 boundaries at once in global memory),
+// each chunk's two pieces are staged into wave-private LDS with coalesced loads, and a second co-rank search in LDS gives
+// every lane an equal share of the chunk -- balanced whatever the index distribution, which equal index sub-ranges are not.
+// A lane enters its share with the prefix difference and the last event position of everything before it (stored cum arrays,
+// the predecessor entries staged with the chunk), so no cross-lane dependency exists; ties (the same bin in both lists) are
+// never split across a boundary. One record per candidate, 32-bit running values as in the LDS kernel (host-checked).
+// kMpT entries of the merged order per chunk; LDS per wave: predecessor + candidate piece, predecessor + query piece (the pieces
+// sum to <= kMpT + 1) = kMpT + 8 entries
+
+// co-rank of diagonal d: how many of the first d merged entries come from list C (C first on equal indices); cx(i) / qx(j) read
+// the bin index of entry i / j. Afterwards a tie that the diagonal would split is pulled into the earlier side.
+template <typename CX, typename QX>
+__device__ __forceinline__ void mp_split(uint32_t d, uint32_t nc, uint32_t nq, CX cx, QX qx, uint32_t& i_out, uint32_t& j_out) {
+	uint32_t lo = d > nq ? d - nq : 0, hi = d < nc ? d : nc;
+	while (lo < hi) {
+		const uint32_t i = (lo + hi) >> 1;
+		if (cx(i) <= qx(d - i - 1)) lo = i + 1; else hi = i;
+	}
+	uint32_t j = d - lo;
+	if (lo > 0 && j < nq && cx(lo - 1) == qx(j)) j++;
+	i_out = lo;
+	j_out = j;
+}
+
+template <bool DIV, uint32_t kMpT>
+__global__ void __launch_bounds__(256) k_pair_sparse_mp(
+    const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
+    const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
+    const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
+    const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
+    MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order) {
+	constexpr uint32_t kMpBuf = kMpT + 8;
+	__shared__ uint2 s_buf[4][kMpBuf];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint2* buf = s_buf[wave];
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint2* Q = q_ent + qh.off;
+	const uint32_t* CQ = q_cum + qh.off;
+	const uint32_t nq_all = qh.nnz;
+	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
+	const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
+	const uint32_t kInf = 0xffffffffu;
+	for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave; c < m; c += total_waves) {
+		const uint32_t slot = cand_slots ? cand_slots[c] : c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const MscSparseHdr ch = c_hdr[slot];
+		const uint2* P = c_ent + ch.off;
+		const uint32_t* CP = c_cum + ch.off;
+		const uint32_t nc_all = ch.nnz;
+		const uint32_t total = nc_all + nq_all;
+		const uint32_t n_chunks = (total + kMpT - 1) / kMpT;
+		uint32_t manh = 0;
+		uint64_t dotx = 0, emd = 0;
+		double jd = 0.0, js = 0.0, cm = 0.0;
+		DivTerm t11{0.0, 0.0};
+		if constexpr (DIV) { cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order); }
+		uint32_t ci = 0, qj = 0, dchunk = 0;
+		for (uint32_t t = 0; t < n_chunks; t++) {
+			if (t % 63 == 0) {                   // boundaries of the next 63 chunks: lane l searches diagonal (t + l) * kMpT in global memory
+				const uint64_t dd = (uint64_t)(t + lane) * kMpT;
+				const uint32_t d = dd < total ? (uint32_t)dd : total;
+				mp_split(d, nc_all, nq_all, [&](uint32_t i) { return P[i].x; }, [&](uint32_t j) { return Q[j].x; }, ci, qj);
+				dchunk = (ci ? CP[ci - 1] : 0u) - (qj ? CQ[qj - 1] : 0u);      // prefix difference entering that chunk (two's complement)
+			}
+			const uint32_t tl = t % 63;
+			const uint32_t c0 = __shfl(ci, tl, 64), c1 = __shfl(ci, tl + 1, 64);
+			const uint32_t q0 = __shfl(qj, tl, 64), q1 = __shfl(qj, tl + 1, 64);
+			const uint32_t nc = c1 - c0, nq = q1 - q0;
+			uint2* cl = buf;                     // cl[0] = predecessor of the piece (or a neutral entry), cl[1 + k] = P[c0 + k]
+			uint2* ql = buf + nc + 2;
+			__builtin_amdgcn_wave_barrier();     // every lane is done with the previous chunk's entries
+			for (uint32_t k = lane; k <= nc; k += 64) cl[k] = (c0 + k) ? P[c0 + k - 1] : make_uint2(0u, 1u);
+			for (uint32_t k = lane; k <= nq; k += 64) ql[k] = (q0 + k) ? Q[q0 + k - 1] : make_uint2(0u, 1u);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order: the reads below see the writes
+			const uint32_t n = nc + nq, seg = (n + 63) >> 6;
+			uint32_t i, j;
+			{
+				const uint32_t d = lane * seg < n ? lane * seg : n;
+				mp_split(d, nc, nq, [&](uint32_t a) { return cl[a + 1].x; }, [&](uint32_t b) { return ql[b + 1].x; }, i, j);
+			}
+			uint32_t i1 = __shfl_down(i, 1, 64), j1 = __shfl_down(j, 1, 64);
+			if (lane == 63) { i1 = nc; j1 = nq; }
+			// prefix difference entering each share = the chunk's + what the earlier lanes' shares add: a pass over the share's values
+			// and one wave scan instead of two scattered reads of the cum arrays per lane
+			uint32_t delta = 0;
+			for (uint32_t a = i; a < i1; a++) delta += cl[a + 1].y - 1u;
+			for (uint32_t b = j; b < j1; b++) delta -= ql[b + 1].y - 1u;
+			const uint32_t d_in = __shfl(dchunk, tl, 64) + wave_incl_scan(delta) - delta;
+			if (i < i1 || j < j1) {
+				// state entering the share: last event before it, prefix difference after it
+				const uint32_t pc = cl[i].x, pq = ql[j].x;                      // predecessors (neutral entries have index 0)
+				uint32_t pos = pc > pq ? pc : pq;
+				int32_t D = (int32_t)d_in;
+				uint2 a = i < i1 ? cl[i + 1] : make_uint2(kInf, 1u);
+				uint2 b = j < j1 ? ql[j + 1] : make_uint2(kInf, 1u);
+				while (i < i1 || j < j1) {
+					const uint32_t e = a.x < b.x ? a.x : b.x;
+					const bool ta = a.x == e, tb = b.x == e;
+					const uint32_t absD = (uint32_t)(D < 0 ? -D : D);
+					emd += (uint64_t)absD * (e - pos);
+					const uint32_t pv = ta ? a.y : 1u, qv = tb ? b.y : 1u;
+					manh += pv > qv ? pv - qv : qv - pv;
+					dotx += (uint64_t)(pv * qv - 1u);
+					D += (int32_t)pv - (int32_t)qv;
+					if constexpr (DIV) {
+						DivTerm tt;
+						if ((pv | qv) < 16u) tt = div_tables[(uint64_t)c * 256 + pv * 16 + qv];
+						else tt = div_term_sp(pv, qv, cm, qm, order);
+						jd += tt.jd - t11.jd;
+						js += tt.js - t11.js;
+					}
+					pos = e;
+					if (ta) { i++; a = i < i1 ? cl[i + 1] : make_uint2(kInf, 1u); }
+					if (tb) { j++; b = j < j1 ? ql[j + 1] : make_uint2(kInf, 1u); }
+				}
+			}
+		}
+		if (lane == 0) {      // the stretch behind the last event of either list
+			const uint32_t lc = nc_all ? P[nc_all - 1].x : 0u, lq = nq_all ? Q[nq_all - 1].x : 0u;
+			const int64_t D = (int64_t)(nc_all ? CP[nc_all - 1] : 0u) - (int64_t)(nq_all ? CQ[nq_all - 1] : 0u);
+			emd += (uint64_t)(D < 0 ? -D : D) * (nbins - (uint64_t)(lc > lq ? lc : lq));
+		}
+		const uint64_t manh_t = wave_sum_u64(manh), dot_t = wave_sum_u64(dotx), emd_t = wave_sum_u64(emd);
+		if constexpr (DIV) {
+#pragma unroll
+			for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+		}
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = manh_t; out.dot = dot_t; out.emd = emd_t;
+			partials[c] = out;
+			if constexpr (DIV) { div_partials[2ull * c] = jd; div_partials[2ull * c + 1] = js; }
+		}
+	}
+}
+
 // ================================================================================================ launchers
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts) {
 	if (n == 0) return hipSuccess;
@@ -635,4 +778,50 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 		                                                                nullptr, order);
 	}
 	return hipGetLastError();
+}
+
+uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
+
+template <uint32_t T>
+static hipError_t launch_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                   uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                   const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
+                                   uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus) {
+	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
+	uint32_t blocks = (uint32_t)num_cus * per_cu;
+	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+	if (div_tables) {
+		k_pair_sparse_mp<true, T><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                              q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials,
+		                                                              (const DivTerm*)div_tables, (double*)div_partials, order);
+	} else {
+		k_pair_sparse_mp<false, T><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                               q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order);
+	}
+	return hipGetLastError();
+}
+
+// lists of any length up to msc_sparse_mp_max_entries() together; same arithmetic range as the LDS kernel (caller checks)
+hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                     uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                     const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
+                                     uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total) {
+	if (m == 0) return hipSuccess;
+	if (max_total > msc_sparse_mp_max_entries()) return hipErrorInvalidValue;
+	if (div_tables) {
+		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+	}
+	static const int t_env = [] { const char* e = getenv("MSC_SPARSE_MP_T"); return e ? atoi(e) : 0; }();
+#define MSC_MP_ARGS st, c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, \
+	div_tables, div_partials, order, num_cus
+	// 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this latency-bound merge wants (r01: k=9/5 kb lists
+	// 43 M pairs/s at 512, 32 M at 1024, 20 M at 2048)
+	const uint32_t T = t_env == 512 || t_env == 1024 || t_env == 2048 ? (uint32_t)t_env : 512u;
+	(void)max_total;
+	if (T == 512) return launch_sparse_mp<512>(MSC_MP_ARGS);
+	if (T == 1024) return launch_sparse_mp<1024>(MSC_MP_ARGS);
+	return launch_sparse_mp<2048>(MSC_MP_ARGS);
+#undef MSC_MP_ARGS
 }

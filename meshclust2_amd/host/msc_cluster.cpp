@@ -615,7 +615,7 @@ int main(int argc, char** argv) {
 		for (Pt* p : pts) { p->id = idx++; bv.insert(p); }
 		bv.insert_finalize();
 		Driver::stamp("read_in_points");
-		Driver drv(ctx, points, trn, k, dtype, sparse ? std::max<uint64_t>(total_bases / 2, 64 * longest) + (1 << 20) : 0);
+		Driver drv(ctx, points, trn, k, dtype, sparse ? total_bases + 64 * longest + (1 << 20) : 0);      // worst case every sequence stays its own centre; the slack absorbs set() appends between compactions
 		drv.cutoff = similarity;
 		drv.batch_update = !serial_update;
 		drv.MS(bv, similarity, output, iterations, delta);
