@@ -1441,6 +1441,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
 	if (!simple) {
 		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
+		float ms = 0.f;
+		int launches = 0;
 		for (uint64_t q = 0; q < n_q; q++) {
 			ScoreRequest rq;
 			rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slots[q]; rq.order = order;
@@ -1448,7 +1450,11 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			rq.sum_out = sum_out ? sum_out + q * m : nullptr; rq.csum_out = csum_out ? csum_out + q * m : nullptr;
 			rq.flags_out = close_out ? close_out + q * m : nullptr;
 			if ((r = run_score(ctx, rq))) return r;
+			ms += ctx->tiles_ms_accum;
+			launches += ctx->tiles_launches;
 		}
+		ctx->tiles_ms_accum = ms;          // msc_last_kernel_ms / _launches cover the whole call
+		ctx->tiles_launches = launches;
 		return MSC_OK;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
