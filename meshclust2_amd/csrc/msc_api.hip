@@ -1439,6 +1439,83 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
+	// Sparse sets: one merge-path pass per query, but queued back to back into one [n_q][m] record array with ONE epilogue and one
+	// copy back -- no host round trip between the passes.
+	static const bool no_sp_multi = getenv("MSC_SPARSE_NO_MULTI") != nullptr;
+	const bool sparse_multi = cands->sparse && qset->sparse && !no_sp_multi && !(want & MSC_FEAT_DIV) && n_q > 1 && !needs_wide(cands, qset) &&
+	                          std::max(cands->max_count, qset->max_count) < 65536 && n_q * m <= 0x7fffffffull &&
+	                          n_q * m * sizeof(MscPartial) <= (4096ull << 20) && !getenv("MSC_SPARSE_NO_MP") && !getenv("MSC_SPARSE_LDS");
+	if (sparse_multi) {
+		HIP_TRY(ctx, hipSetDevice(ctx->device));
+		ctx->tiles_ms_accum = 0.f;
+		ctx->tiles_launches = 0;
+		ctx->have_timing = false;
+		ctx->last_kernel = "k_pair_sparse";
+		ctx->last_query_tile = 1;
+		ctx->last_partial_stride = 1;
+		if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
+		if ((r = ensure(ctx, ctx->qslots, n_q * sizeof(uint32_t)))) return r;
+		if ((r = ensure(ctx, ctx->partials, n_q * m * sizeof(MscPartial)))) return r;
+		if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * m * sizeof(double)))) return r;
+		if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * m * sizeof(double)))) return r;
+		if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * m))) return r;
+		if (raw_out && (r = ensure(ctx, ctx->raw, n_q * m * nf * sizeof(double)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+		if (cand_slots) {
+			if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		}
+		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p : nullptr;
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		for (uint64_t q = 0; q < n_q; q++)
+			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
+			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,
+			                                       (MscPartial*)ctx->partials.p + q * m, nullptr, nullptr, order, ctx->num_cus,
+			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz)));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		MscEpilogueArgs ea;
+		memset(&ea, 0, sizeof ea);
+		ea.partials = (const MscPartial*)ctx->partials.p;
+		ea.S = 1;
+		ea.m = (uint32_t)(n_q * m);
+		ea.cand_scalars = cands->scalars;
+		ea.cand_scalar_stride = cands->scalar_stride;
+		ea.cand_slots = d_slots;
+		ea.n_queries = (uint32_t)n_q;
+		ea.m_per_query = (uint32_t)m;
+		ea.q_slots = (const uint32_t*)ctx->qslots.p;
+		ea.qset_scalars = qset->scalars;
+		ea.q_scalar_stride = qset->scalar_stride;
+		ea.q_scalars = qset->scalars + (uint64_t)q_slots[0] * qset->scalar_stride;
+		ea.nbins = L.nbins;
+		ea.dtype = cands->dtype;
+		ea.order = order;
+		ea.feat_mask = feat_mask;
+		ea.sparse_base = L.nbins;
+		ea.raw_out = raw_out ? (double*)ctx->raw.p : nullptr;
+		ea.model = model ? model->d : nullptr;
+		ea.sum_soa = sum_out ? (double*)ctx->soa_sum.p : nullptr;
+		ea.csum_soa = csum_out ? (double*)ctx->soa_csum.p : nullptr;
+		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
+		ea.error_word = (int32_t*)ctx->err_word.p;
+		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		if (sum_out) HIP_TRY(ctx, hipMemcpyAsync(sum_out, ctx->soa_sum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		if (csum_out) HIP_TRY(ctx, hipMemcpyAsync(csum_out, ctx->soa_csum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		if (close_out) HIP_TRY(ctx, hipMemcpyAsync(close_out, ctx->soa_close.p, n_q * m, hipMemcpyDeviceToHost, ctx->stream));
+		if (raw_out) HIP_TRY(ctx, hipMemcpyAsync(raw_out, ctx->raw.p, n_q * m * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		int32_t first_err = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		float t = 0;
+		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = (int)n_q; ctx->have_timing = true; }
+		if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+		if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+		if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+		return MSC_OK;
+	}
 	if (!simple) {
 		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
 		float ms = 0.f;
