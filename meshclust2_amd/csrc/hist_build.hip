@@ -358,7 +358,8 @@ __global__ void __launch_bounds__(kBlock) k_build_sort(T* __restrict__ bins, uin
 	auto run_value = [&](uint32_t i, uint64_t* dropped) -> uint64_t {
 		const uint32_t key = keys[i];
 		uint32_t lo = i + 1, hi = n;
-		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
+		if (lo < n && keys[lo] == key)                       // most k-mers of a sequence occur once: one read settles those
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
 		uint64_t v = 1ull + (lo - i);                        // pseudocount + occurrences
 		*dropped = 0;
 		if (v > tmax) { *dropped = v - tmax; v = tmax; }     // wholesaleIncrementNoOverflow stops at max(T)
