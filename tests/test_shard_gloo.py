@@ -145,9 +145,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_matches_single_process(oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_passes_match_single_process(oracle, world):
     import torch.multiprocessing as mp
-    world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
