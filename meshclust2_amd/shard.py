@@ -98,29 +98,38 @@ class ShardedTrainer:
 class ShardedBlockScorer:
     """n_q queries x every candidate of every rank in one pass per rank (the all-pairs shape, fastcar work()).
 
-    backend.query_buffers(j) / export_query(local) as above but per query slot j; backend.import_queries(n_q);
-    backend.score_block(n_q) -> close flags [n_q, local_count] (np.uint8). Per block the only exchanges are the n_q query
-    broadcasts and one all-gather of the per-query close counts."""
+    backend.query_buffers(j) / export_query(local) as above but per query buffer j; backend.import_queries(n, base);
+    backend.score_block(n, base) -> close flags [n, local_count] (np.uint8) of the queries in buffers base .. base + n - 1.
+    Per block the only exchanges are the n_q query broadcasts and one all-gather of the per-query close counts.
+
+    The exchange is split so that a caller can double-buffer it: begin() only ISSUES the copies and asynchronous broadcasts of a
+    block into buffers base .., finish() waits for them and registers the slots, score() runs the local pass. bench.py issues
+    block s + 1 before it scores block s, so the collectives run on RCCL's stream underneath the streaming kernel."""
 
     def __init__(self, dist, plan, backend, rank, device="cpu"):
         self.dist, self.plan, self.backend, self.rank, self.device = dist, plan, backend, rank, device
 
-    def score_block(self, query_globals):
-        import torch
+    def begin(self, query_globals, base=0):
         pending = []
         for j, qg in enumerate(query_globals):
             owner = self.plan.owner(qg)
-            bufs = self.backend.query_buffers(j)
+            bufs = self.backend.query_buffers(base + j)
             if self.rank == owner:
                 for dst, src in zip(bufs, self.backend.export_query(self.plan.local(qg))):
                     dst.copy_(src)
             if self.plan.world > 1:
                 # all 2 * n_q broadcasts are issued before any is waited for: the collectives queue back to back
                 pending += [self.dist.broadcast(b, src=owner, async_op=True) for b in bufs]
+        return pending
+
+    def finish(self, pending, n, base=0):
         for w in pending:
             w.wait()
-        self.backend.import_queries(len(query_globals))
-        close = self.backend.score_block(len(query_globals))
+        self.backend.import_queries(n, base)
+
+    def score(self, n, base=0):
+        import torch
+        close = self.backend.score_block(n, base)
         counts = torch.tensor(close.sum(axis=1).astype(np.float64), dtype=torch.float64, device=self.device)
         if self.plan.world > 1:
             out = [torch.zeros_like(counts) for _ in range(self.plan.world)]
@@ -129,6 +138,11 @@ class ShardedBlockScorer:
         else:
             total = counts.cpu().numpy()
         return close, total
+
+    def score_block(self, query_globals):
+        n = len(query_globals)
+        self.finish(self.begin(query_globals), n)
+        return self.score(n)
 
 
 def device_tensors(hist_set, n_slots):

@@ -92,6 +92,67 @@ def _centre_round(dist, rank, world, seqs, pred, nb):
     return [oracle_py.merge(pred, CUTOFF, be.centres, i, i + 1, min(n - 1, i + DELTA)) for i in range(n - 1)]
 
 
+BLOCK_Q, BLOCK_STEPS = 3, 4
+
+
+def _block_queries(step, total):
+    return [((step * BLOCK_Q + j) * 7) % total for j in range(BLOCK_Q)]
+
+
+def _block_steps(dist, rank, plan, hists, pred, nb):
+    """the all-pairs exchange, double-buffered as bench.py drives it: block s + 1 is issued before block s is scored"""
+    import ctypes as C
+    import torch
+    from oracle import oracle_py
+
+    class Backend:
+        def __init__(self):
+            self.bins = [torch.zeros(nb, dtype=torch.int32) for _ in range(2 * BLOCK_Q)]
+            self.meta = [torch.zeros(2, dtype=torch.int64) for _ in range(2 * BLOCK_Q)]
+            self.q = [None] * (2 * BLOCK_Q)
+            self.keep = [None] * (2 * BLOCK_Q)
+
+        def query_buffers(self, j):
+            return [self.bins[j], self.meta[j]]
+
+        def export_query(self, local):
+            h = hists[local]
+            return [torch.from_numpy(h.array().astype(np.int32)), torch.tensor([h.mag, h.length], dtype=torch.int64)]
+
+        def import_queries(self, n, base=0):
+            for j in range(base, base + n):
+                h = oracle_py.Hist()
+                self.keep[j] = self.bins[j].numpy().astype(np.uint16)
+                h.dtype, h.k, h.nbins = DT, K, nb
+                h.bins = self.keep[j].ctypes.data_as(C.c_void_p).value
+                h.mag, h.length = int(self.meta[j][0]), int(self.meta[j][1])
+                self.q[j] = h
+
+        def score_block(self, n, base=0):
+            return np.stack([oracle_py.get_close(pred, CUTOFF, self.q[j], hists)[0] for j in range(base, base + n)])
+
+    blk = shard.ShardedBlockScorer(dist, plan, Backend(), rank)
+    pending = [None, None]
+    totals = []
+    for st in range(BLOCK_STEPS):
+        cur, nxt = st % 2, (st + 1) % 2
+        if pending[cur] is None:
+            pending[cur] = blk.begin(_block_queries(st, plan.n_total), base=cur * BLOCK_Q)
+        blk.finish(pending[cur], BLOCK_Q, base=cur * BLOCK_Q)
+        pending[cur] = None
+        pending[nxt] = blk.begin(_block_queries(st + 1, plan.n_total), base=nxt * BLOCK_Q)
+        close, total = blk.score(BLOCK_Q, base=cur * BLOCK_Q)
+        assert close.shape == (BLOCK_Q, len(hists))
+        totals.append(total.tolist())
+    for half in pending:
+        for w in half or []:
+            w.wait()
+    # the one-shot form gives the same answer
+    _, again = blk.score_block(_block_queries(1, plan.n_total))
+    assert again.tolist() == totals[1]
+    return totals
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -140,7 +201,7 @@ def _worker(rank, world, port, q):
         for qg in (0, 9, 17, 30, 45):
             flags, g, sim, is_min, n_close = trn.get_close(qg)
             out.append((qg, flags.tolist(), g, sim, is_min, n_close))
-        q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb)))
+        q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb), _block_steps(dist, rank, plan, hists, pred, nb)))
     finally:
         dist.destroy_process_group()
 
@@ -159,8 +220,8 @@ def test_sharded_passes_match_single_process(oracle, world):
         p.start()
     res = {}
     for _ in range(world):
-        r, mine, out, merged = q.get(timeout=180)
-        res[r] = (mine, out, merged)
+        r, mine, out, merged, blocks = q.get(timeout=180)
+        res[r] = (mine, out, merged, blocks)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -172,7 +233,7 @@ def test_sharded_passes_match_single_process(oracle, world):
         f, bp, bs, im = oracle.get_close(pred, CUTOFF, hs[qg], hs)
         glob_flags = np.zeros(len(seqs), dtype=np.uint8)
         for r in range(world):
-            mine, out, _ = res[r]
+            mine, out, _, _ = res[r]
             _, flags, g, sim, is_min, n_close = out[qi]
             glob_flags[np.array(mine)] = flags
             assert (g, is_min, n_close) == (bp, im, int(f.sum())) and sim == pytest.approx(bs, rel=1e-12)
@@ -183,3 +244,8 @@ def test_sharded_passes_match_single_process(oracle, world):
     assert any(w > i for i, w in enumerate(want))           # the scan does merge something
     for r in range(world):
         assert res[r][2] == want
+    # double-buffered all-pairs blocks: per-query close counts over every rank == the single-process count
+    for st in range(BLOCK_STEPS):
+        want_counts = [float(oracle.get_close(pred, CUTOFF, hs[g], hs)[0].sum()) for g in _block_queries(st, len(seqs))]
+        for r in range(world):
+            assert res[r][3][st] == want_counts, (st, r)

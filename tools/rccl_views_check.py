@@ -23,10 +23,15 @@ q = np.arange(16, dtype=np.uint32)
 want = api.score_multi(ctx, feat, hs, np.arange(40, dtype=np.uint32), hs, q, want=("sum",))["sum"]
 ctx.synchronize()
 bins, scal = shard.device_tensors(hs, 64)
-for j in range(8):                                    # "query broadcast" into slots 40..47 from slots 0..7
+pending = []
+for j in range(8):                                    # "query broadcast" into slots 40..47 from slots 0..7, asynchronous as bench.py issues them
     for t in (bins, scal):
         t[40 + j].copy_(t[j])
-        dist.broadcast(t[40 + j], src=0)
+        pending.append(dist.broadcast(t[40 + j], src=0, async_op=True))
+busy = api.score_multi(ctx, feat, hs, np.arange(40, dtype=np.uint32), hs, q, want=("sum",))["sum"]      # the library works underneath the collectives
+assert np.array_equal(busy, want)
+for w in pending:
+    w.wait()
 for t in (bins, scal):                                # "centre all-gather" of slots 8..15 into 48..55
     dist.all_gather_into_tensor(t[48:56], t[8:16])
 rec = torch.tensor([1.0, 0.5, 7.0], dtype=torch.float64, device="cuda")
