@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Randomised parity run: libmeshclust2_hip.so against the CPU oracle over random (k, datatype, layout, lengths, alphabets) -- run on
+the GPU box.   python tools/fuzz_parity.py [seconds] [first seed]
+Test infrastructure like tests/: the oracle is the checker. Every round builds a random batch in the dense and (k >= 6) the sparse
+layout and compares bins, scalar records, all 11 raw statistics for random (candidate, query) pairs in both argument orders, and
+get_close / filter / merge / mean_nearest under a fixture model. Integer statistics must be bit-equal, FP64 ones within 1e-9.
+Prints one line per round and stops at the first mismatch (exit 1)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import EXACT, FEATS, weights_text
+from meshclust2_amd import api
+from oracle import oracle_py as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+MASK = sum(1 << b for _, b in FEATS)
+MODELS = ["weights_k5_u16.txt", "weights_k5_u16_slow.txt", "weights_k9_u32.txt", "weights_k8_u16.txt", "weights_mixed_slow_k6_u16.txt"]
+ctx = api.Context(0)
+
+
+def rand_seq(rng):
+    kind = rng.integers(0, 10)
+    n = int(np.exp(rng.uniform(np.log(25), np.log(6000))))
+    if kind == 0:
+        p = [0.7, 0.1, 0.1, 0.1]
+    elif kind == 1:
+        p = [0.45, 0.05, 0.05, 0.45]
+    else:
+        p = None
+    s = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n, p=p).tobytes())
+    if kind == 2:                                   # a long homopolymer / dinucleotide run: saturation for narrow types
+        a = int(rng.integers(0, n))
+        run = (b"A" if rng.integers(0, 2) else b"AC") * int(rng.integers(50, 900))
+        s[a:a] = run
+    if kind in (3, 4):                              # N runs of every length class (merge < 10, split >= 10, short leftovers)
+        for _ in range(int(rng.integers(1, 6))):
+            a = int(rng.integers(0, len(s)))
+            s[a:a + int(rng.integers(1, 40))] = b"N" * int(rng.integers(1, 40))
+    if kind == 5:
+        for _ in range(int(rng.integers(1, 8))):    # IUPAC ambiguity codes
+            s[int(rng.integers(0, len(s)))] = int(rng.choice(np.frombuffer(b"RYMKSWHBVD", dtype=np.uint8)))
+    if kind == 6:
+        s = bytearray(bytes(s).lower())
+    return bytes(s)
+
+
+def check(cond, what):
+    if not cond:
+        print("MISMATCH:", what, flush=True)
+        sys.exit(1)
+
+
+t_end = time.time() + budget
+seed = seed0
+rounds = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(1, 12))
+    dtype = int(rng.choice([8, 16, 32, 64]))
+    if k >= 11 and dtype == 64:
+        dtype = 32
+    n = int(rng.integers(4, 28))
+    seqs = [rand_seq(rng) for _ in range(n)]
+    base = seqs[0]
+    for i in range(1, n, 3):                        # relatives of the first sequence: shared bins, close pairs
+        m = bytearray(base)
+        for _ in range(max(1, len(m) // 30)):
+            m[int(rng.integers(0, len(m)))] = int(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8)))
+        seqs[i] = bytes(m)
+    oh = [orc.hist(s, k, dtype) for s in seqs]
+    layouts = ["dense"] + (["sparse"] if 4 ** k * dtype // 8 >= 65536 else [])      # the sparse layout exists from 64 KiB histograms up
+    model_name = MODELS[int(rng.integers(0, len(MODELS)))]
+    pred = orc.predictor(weights_text(model_name))
+    for layout in layouts:
+        hs = api.HistogramSet(ctx, k, dtype, n + 1, sparse_entries=(sum(len(s) for s in seqs) * 2 + 4096) if layout == "sparse" else 0)
+        hs.build(seqs)
+        for i in range(n):
+            inf = hs.info(i)
+            check((inf["mag"], inf["length"], inf["one_mers"], inf["overflow"]) == (oh[i].mag, oh[i].length, list(oh[i].one_mers), oh[i].overflow), ("info", seed, layout, i))
+            if 4 ** k * dtype // 8 <= (8 << 20):
+                check(np.array_equal(hs.download(i), oh[i].array()), ("bins", seed, layout, i))
+        live = [i for i in range(n) if oh[i].length > 0]
+        if len(live) < 3:
+            continue
+        cands = np.array(live, dtype=np.uint32)
+        for q in rng.choice(live, size=min(3, len(live)), replace=False):
+            for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+                raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), MASK, order)
+                for ci, c in enumerate(live):
+                    a, b = (oh[c], oh[int(q)]) if order == api.ORDER_CAND_FIRST else (oh[int(q)], oh[c])
+                    for col, (name, bit) in zip(raw[ci], FEATS):
+                        exp = orc.raw_feature(1 << bit, a, b)
+                        if name in EXACT and name != "kulczynski2":
+                            check(col == exp or (np.isnan(col) and np.isnan(exp)), ("raw", seed, layout, name, c, int(q), order, col, exp))
+                        else:
+                            check((np.isnan(col) and np.isnan(exp)) or abs(col - exp) <= 1e-9 * max(abs(exp), 1e-4), ("raw", seed, layout, name, c, int(q), order, col, exp))
+        feat = api.Feature.from_text(ctx, weights_text(model_name), 0)
+        for cutoff in (0.9, 0.6):
+            trn = api.Trainer(ctx, feat, cutoff)
+            q = int(rng.choice(live))
+            w = np.array([c for c in live if c != q], dtype=np.uint32)
+            try:
+                f1, bp1, bs1, im1 = trn.get_close(hs, w, hs, q)
+                gpu_err = None
+            except Exception as e:      # noqa: BLE001 -- MscError
+                gpu_err = e
+            try:
+                f2, bp2, bs2, im2 = orc.get_close(pred, cutoff, oh[q], [oh[c] for c in w])
+                cpu_err = None
+            except Exception as e:      # noqa: BLE001
+                cpu_err = e
+            check((gpu_err is None) == (cpu_err is None), ("get_close error parity", seed, layout, gpu_err, cpu_err))
+            if gpu_err is None:
+                check(np.array_equal(f1, f2) and (bp1, im1) == (bp2, im2) and (bp1 < 0 or abs(bs1 - bs2) <= 1e-9 * max(abs(bs2), 1e-6)), ("get_close", seed, layout, q, cutoff))
+                check(np.array_equal(trn.filter(hs, q, hs, w), orc.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), ("filter", seed, layout, q, cutoff))
+                lv = np.array(live, dtype=np.uint32)
+                cur = int(rng.integers(0, len(live)))
+                last = min(len(live) - 1, cur + 5)
+                if cur + 1 <= last:
+                    check(trn.merge(hs, lv, cur, cur + 1, last) == orc.merge(pred, cutoff, [oh[c] for c in live], cur, cur + 1, last), ("merge", seed, layout, cur))
+        mem = np.array(sorted(set(int(x) for x in rng.choice(live, size=min(6, len(live))))), dtype=np.uint32)
+        pos, d, _ = api.mean_nearest(ctx, hs, mem)
+        _, od, onear = orc.mean_nearest([oh[int(i)] for i in mem])
+        check(pos == onear and np.allclose(d, od, rtol=1e-12, atol=0), ("mean_nearest", seed, layout, mem.tolist()))
+        hs.close()
+    for h in oh:
+        orc.lib().orc_hist_free(h)
+    rounds += 1
+    print("seed %d ok: k=%d u%d n=%d layouts=%s model=%s" % (seed, k, dtype, n, "+".join(layouts), model_name), flush=True)
+    seed += 1
+print("fuzz ok: %d rounds, seeds %d..%d" % (rounds, seed0, seed - 1))
