@@ -115,12 +115,32 @@ while time.time() < t_end:
             check((gpu_err is None) == (cpu_err is None), ("get_close error parity", seed, layout, gpu_err, cpu_err))
             if gpu_err is None:
                 check(np.array_equal(f1, f2) and (bp1, im1) == (bp2, im2) and (bp1 < 0 or abs(bs1 - bs2) <= 1e-9 * max(abs(bs2), 1e-6)), ("get_close", seed, layout, q, cutoff))
-                check(np.array_equal(trn.filter(hs, q, hs, w), orc.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), ("filter", seed, layout, q, cutoff))
-                lv = np.array(live, dtype=np.uint32)
-                cur = int(rng.integers(0, len(live)))
-                last = min(len(live) - 1, cur + 5)
-                if cur + 1 <= last:
-                    check(trn.merge(hs, lv, cur, cur + 1, last) == orc.merge(pred, cutoff, [oh[c] for c in live], cur, cur + 1, last), ("merge", seed, layout, cur))
+
+            def throws(a, b):          # the reference throws where compute() meets a zero length or a NaN after normalisation
+                try:
+                    orc.compute(pred.cls, a, b)
+                    return False
+                except ValueError:
+                    return True
+            idc = cutoff / 100.0 if cutoff > 1 else cutoff
+            lo_len, hi_len = int(oh[q].length * idc), int(oh[q].length / idc)
+            window_throws = any(lo_len <= oh[c].length <= hi_len and throws(oh[q], oh[c]) for c in w)
+            try:
+                kept = trn.filter(hs, q, hs, w)
+                check(not window_throws, ("filter should have failed", seed, layout, q, cutoff))
+                check(np.array_equal(kept, orc.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), ("filter", seed, layout, q, cutoff))
+            except Exception as e:      # noqa: BLE001 -- MscError
+                check(window_throws, ("filter error without a throwing pair", seed, layout, q, cutoff, e))
+            lv = np.array(live, dtype=np.uint32)
+            cur = int(rng.integers(0, len(live)))
+            last = min(len(live) - 1, cur + 5)
+            if cur + 1 <= last:
+                want = orc.merge(pred, cutoff, [oh[c] for c in live], cur, cur + 1, last)
+                try:
+                    got = trn.merge(hs, lv, cur, cur + 1, last)
+                    check(want != -2 and got == want, ("merge", seed, layout, cur, got, want))
+                except Exception as e:      # noqa: BLE001 -- MscError
+                    check(want == -2, ("merge error without a throwing pair", seed, layout, cur, e))
         mem = np.array(sorted(set(int(x) for x in rng.choice(live, size=min(6, len(live))))), dtype=np.uint32)
         pos, d, _ = api.mean_nearest(ctx, hs, mem)
         _, od, onear = orc.mean_nearest([oh[int(i)] for i in mem])
