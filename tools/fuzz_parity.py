@@ -14,11 +14,8 @@ from golden_util import EXACT, FEATS, weights_text
 from meshclust2_amd import api
 from oracle import oracle_py as orc
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 MASK = sum(1 << b for _, b in FEATS)
 MODELS = ["weights_k5_u16.txt", "weights_k5_u16_slow.txt", "weights_k9_u32.txt", "weights_k8_u16.txt", "weights_mixed_slow_k6_u16.txt"]
-ctx = api.Context(0)
 
 
 def rand_seq(rng):
@@ -47,16 +44,17 @@ def rand_seq(rng):
     return bytes(s)
 
 
+class Mismatch(AssertionError):
+    pass
+
+
 def check(cond, what):
     if not cond:
-        print("MISMATCH:", what, flush=True)
-        sys.exit(1)
+        raise Mismatch(repr(what))
 
 
-t_end = time.time() + budget
-seed = seed0
-rounds = 0
-while time.time() < t_end:
+def run_round(ctx, seed):
+    """one random configuration through every comparison; raises Mismatch; returns a one-line summary"""
     rng = np.random.default_rng(seed)
     k = int(rng.integers(1, 12))
     dtype = int(rng.choice([8, 16, 32, 64]))
@@ -84,6 +82,7 @@ while time.time() < t_end:
                 check(np.array_equal(hs.download(i), oh[i].array()), ("bins", seed, layout, i))
         live = [i for i in range(n) if oh[i].length > 0]
         if len(live) < 3:
+            hs.close()
             continue
         cands = np.array(live, dtype=np.uint32)
         for q in rng.choice(live, size=min(3, len(live)), replace=False):
@@ -105,7 +104,7 @@ while time.time() < t_end:
             try:
                 f1, bp1, bs1, im1 = trn.get_close(hs, w, hs, q)
                 gpu_err = None
-            except Exception as e:      # noqa: BLE001 -- MscError
+            except api.MscError as e:
                 gpu_err = e
             try:
                 f2, bp2, bs2, im2 = orc.get_close(pred, cutoff, oh[q], [oh[c] for c in w])
@@ -126,21 +125,24 @@ while time.time() < t_end:
             lo_len, hi_len = int(oh[q].length * idc), int(oh[q].length / idc)
             window_throws = any(lo_len <= oh[c].length <= hi_len and throws(oh[q], oh[c]) for c in w)
             try:
-                kept = trn.filter(hs, q, hs, w)
-                check(not window_throws, ("filter should have failed", seed, layout, q, cutoff))
+                kept, ferr = trn.filter(hs, q, hs, w), None
+            except api.MscError as e:
+                kept, ferr = None, e
+            check((ferr is not None) == window_throws, ("filter error parity", seed, layout, q, cutoff, ferr, window_throws))
+            if ferr is None:
                 check(np.array_equal(kept, orc.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), ("filter", seed, layout, q, cutoff))
-            except Exception as e:      # noqa: BLE001 -- MscError
-                check(window_throws, ("filter error without a throwing pair", seed, layout, q, cutoff, e))
             lv = np.array(live, dtype=np.uint32)
             cur = int(rng.integers(0, len(live)))
             last = min(len(live) - 1, cur + 5)
             if cur + 1 <= last:
                 want = orc.merge(pred, cutoff, [oh[c] for c in live], cur, cur + 1, last)
                 try:
-                    got = trn.merge(hs, lv, cur, cur + 1, last)
-                    check(want != -2 and got == want, ("merge", seed, layout, cur, got, want))
-                except Exception as e:      # noqa: BLE001 -- MscError
-                    check(want == -2, ("merge error without a throwing pair", seed, layout, cur, e))
+                    got, merr = trn.merge(hs, lv, cur, cur + 1, last), None
+                except api.MscError as e:
+                    got, merr = None, e
+                check((merr is not None) == (want == -2), ("merge error parity", seed, layout, cur, merr, want))
+                if merr is None:
+                    check(got == want, ("merge", seed, layout, cur, got, want))
         mem = np.array(sorted(set(int(x) for x in rng.choice(live, size=min(6, len(live))))), dtype=np.uint32)
         pos, d, _ = api.mean_nearest(ctx, hs, mem)
         _, od, onear = orc.mean_nearest([oh[int(i)] for i in mem])
@@ -148,7 +150,24 @@ while time.time() < t_end:
         hs.close()
     for h in oh:
         orc.lib().orc_hist_free(h)
-    rounds += 1
-    print("seed %d ok: k=%d u%d n=%d layouts=%s model=%s" % (seed, k, dtype, n, "+".join(layouts), model_name), flush=True)
-    seed += 1
-print("fuzz ok: %d rounds, seeds %d..%d" % (rounds, seed0, seed - 1))
+    return "seed %d ok: k=%d u%d n=%d layouts=%s model=%s" % (seed, k, dtype, n, "+".join(layouts), model_name)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = api.Context(0)
+    t_end = time.time() + budget
+    seed = seed0
+    while time.time() < t_end:
+        try:
+            print(run_round(ctx, seed), flush=True)
+        except Mismatch as e:
+            print("MISMATCH:", e, flush=True)
+            sys.exit(1)
+        seed += 1
+    print("fuzz ok: %d rounds, seeds %d..%d" % (seed - seed0, seed0, seed - 1))
+
+
+if __name__ == "__main__":
+    main()
