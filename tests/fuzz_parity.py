@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity run: libmeshclust2_hip.so against the CPU oracle over random (k, datatype, layout, lengths, alphabets) -- run on
-the GPU box.   python tools/fuzz_parity.py [seconds] [first seed]
+the GPU box.   python tests/fuzz_parity.py [seconds] [first seed]
 Test infrastructure like tests/: the oracle is the checker. Every round builds a random batch in the dense and (k >= 6) the sparse
 layout and compares bins, scalar records, all 11 raw statistics for random (candidate, query) pairs in both argument orders, and
 get_close / filter / merge / mean_nearest under a fixture model. Integer statistics must be bit-equal, FP64 ones within 1e-9.

@@ -971,13 +971,8 @@ def test_threaded_host_encode_matches_oracle(ctx, oracle, strip):
 
 @pytest.mark.parametrize("seed", [3, 11, 42, 77, 1115, 1149])
 def test_randomised_rounds(ctx, seed):
-    """A few fixed seeds of tools/fuzz_parity.py (random k, datatype, layout, alphabets, lengths; builders, the 11 statistics in both
+    """A few fixed seeds of tests/fuzz_parity.py (random k, datatype, layout, alphabets, lengths; builders, the 11 statistics in both
     argument orders, get_close / filter / merge / mean_nearest under a fixture model, error parity where the reference throws).
     Seed 1115 holds a pair whose normalisation is NaN: the library must fail exactly where the reference does."""
-    import importlib.util
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
-    assert "ok" in fz.run_round(ctx, seed)
+    import fuzz_parity
+    assert "ok" in fuzz_parity.run_round(ctx, seed)
