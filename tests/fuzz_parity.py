@@ -153,6 +153,68 @@ def run_round(ctx, seed):
     return "seed %d ok: k=%d u%d n=%d layouts=%s model=%s" % (seed, k, dtype, n, "+".join(layouts), model_name)
 
 
+def run_multi_round(ctx, seed):
+    """Q x M pass (msc_score_multi: digest / ring / register / sparse-queued kernels, whichever the library picks) against one
+    1 x M pass per query (msc_score, msc_pair_features_raw -- the path run_round pins to the oracle): random k, datatype, layout,
+    candidate subset and order, query count, queries from the same or from another set, model with or without the earth
+    mover's distance, either argument order. Sums, classify sums and raw statistics must be equal, close flags identical."""
+    rng = np.random.default_rng(100000 + seed)
+    k = int(rng.integers(3, 11))
+    dtype = int(rng.choice([8, 16, 32, 64]))
+    n = int(rng.integers(8, 200))
+    L = int(np.exp(rng.uniform(np.log(60), np.log(3000))))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fam = max(2, int(rng.integers(2, 12)))
+    seqs = []
+    for i in range(n):
+        if i % fam == 0:
+            tmpl = bytearray(rng.choice(alpha, max(30, L + int(rng.integers(-L // 5, L // 5 + 1)))).tobytes())
+        m = bytearray(tmpl)
+        for _ in range(len(m) // 25):
+            m[int(rng.integers(0, len(m)))] = int(rng.choice(alpha))
+        if rng.integers(0, 20) == 0:
+            m[0:0] = b"A" * int(rng.integers(100, 600))          # a run that lifts the largest count (u16-count digest, ring fallbacks)
+        seqs.append(bytes(m))
+    sparse = bool(rng.integers(0, 4) == 0) and 4 ** k * dtype // 8 >= 65536
+    ent = (sum(len(s) for s in seqs) * 2 + 4096) if sparse else 0
+    hs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+    hs.build(seqs)
+    other = bool(rng.integers(0, 3) == 0)
+    qs = hs
+    if other:
+        qs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+        qs.build(seqs[::-1])
+    model_name = MODELS[int(rng.integers(0, len(MODELS)))]
+    feat = api.Feature.from_text(ctx, weights_text(model_name), 0)
+    n_q = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 40]))
+    q_slots = rng.integers(0, n, size=n_q).astype(np.uint32)
+    cands = rng.permutation(n)[: int(rng.integers(1, n + 1))].astype(np.uint32) if rng.integers(0, 3) else None
+    m = n if cands is None else cands.size
+    order = api.ORDER_CAND_FIRST if rng.integers(0, 2) else api.ORDER_QUERY_FIRST
+    mask = 0
+    if rng.integers(0, 2):
+        for _, b in FEATS:
+            if rng.integers(0, 2):
+                mask |= 1 << b
+    got = api.score_multi(ctx, feat, hs, cands, qs, q_slots, order=order, m=m, feat_mask=mask)
+    kernel = ctx.last_kernel_info()[0]
+    for i, q in enumerate(q_slots):
+        one = feat.compute(hs, cands, qs, int(q), order=order, m=m)
+        check(np.array_equal(got["sum"][i], one["sum"], equal_nan=True) or np.allclose(got["sum"][i], one["sum"], rtol=1e-9, atol=1e-12, equal_nan=True),
+              ("multi sum", seed, kernel, k, dtype, i))
+        check(np.allclose(got["csum"][i], one["csum"], rtol=1e-9, atol=1e-12, equal_nan=True), ("multi csum", seed, kernel, i))
+        # a flag may differ only where the rounding argument sits within 1e-9 of the threshold, which random data does not hit
+        check(np.array_equal(got["close"][i], (np.round(one["csum"]) > 0).astype(np.uint8)), ("multi close", seed, kernel, i))
+        if mask:
+            raw = api.pair_features_raw(ctx, hs, cands, qs, int(q), mask, order, m=m)
+            check(np.allclose(got["raw"][i], raw, rtol=1e-9, atol=1e-13, equal_nan=True), ("multi raw", seed, kernel, i))
+    hs.close()
+    if other:
+        qs.close()
+    return "multi seed %d ok: k=%d u%d n=%d m=%d q=%d %s%s model=%s kernel=%s" % (seed, k, dtype, n, m, n_q, "sparse " if sparse else "", "other-set " if other else "",
+                                                                               model_name, kernel)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -162,6 +224,8 @@ def main():
     while time.time() < t_end:
         try:
             print(run_round(ctx, seed), flush=True)
+            for sub in range(4):
+                print(run_multi_round(ctx, 4 * seed + sub), flush=True)
         except Mismatch as e:
             print("MISMATCH:", e, flush=True)
             sys.exit(1)

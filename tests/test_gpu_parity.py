@@ -976,3 +976,11 @@ def test_randomised_rounds(ctx, seed):
     Seed 1115 holds a pair whose normalisation is NaN: the library must fail exactly where the reference does."""
     import fuzz_parity
     assert "ok" in fuzz_parity.run_round(ctx, seed)
+
+
+@pytest.mark.parametrize("seed", [80000, 80004, 80008, 80010, 80019, 80025, 80027, 80046])      # digest (u8/u16 counts, with/without emd), ring, register, sparse-queued
+def test_randomised_multi_rounds(ctx, seed):
+    """Fixed seeds of tests/fuzz_parity.py's Q x M rounds: msc_score_multi (whichever kernel the library picks for the random
+    k / datatype / layout / query count / model) against one 1 x M pass per query."""
+    import fuzz_parity
+    assert "ok" in fuzz_parity.run_multi_round(ctx, seed)
