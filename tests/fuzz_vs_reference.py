@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end rounds against the REAL reference CLI -- run where oracle/_ref/meshclust2 exists (this container, and the GPU
+box: the prebuilt binary travels).   python tests/fuzz_vs_reference.py [seconds] [first seed]
+Per round: a random FASTA file (families of mutated templates, mixed lengths, shuffled record order) -> the reference's own
+`meshclust2` trains a model and clusters (OMP_NUM_THREADS=1; it leaves weights.txt behind) -> msc_cluster --recover weights.txt
+clusters the same file on the GPU -> the two .clstr files must be the same bytes. Random k (4..9), histogram type, identity
+threshold, `--feat fast|slow`. Test infrastructure: the reference binary is the checker, exactly as for the committed fixtures."""
+import os, subprocess, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "meshclust2")
+EXE = os.path.join(ROOT, "meshclust2_amd", "host", "msc_cluster")
+
+
+def write_random_fasta(rng, path):
+    n = int(rng.integers(60, 420))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fam = int(rng.integers(3, 20))
+    rate = float(rng.choice([0.01, 0.03, 0.06]))
+    lo, hi = (200, 900) if rng.integers(0, 2) else (400, 2500)
+    recs = []
+    for i in range(n):
+        if i % fam == 0:
+            tmpl = rng.choice(alpha, int(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
+        m = tmpl.copy()
+        hits = rng.random(m.size) < rate
+        m[hits] = rng.choice(alpha, int(hits.sum()))
+        s = bytearray(m.tobytes())
+        if rng.integers(0, 8) == 0:
+            a = int(rng.integers(0, len(s)))
+            del s[a:a + int(rng.integers(1, max(2, len(s) // 12)))]
+        recs.append((">r%d fam%d" % (i, i // fam), bytes(s)))
+    with open(path, "wb") as f:
+        for i in rng.permutation(n):
+            h, s = recs[int(i)]
+            f.write(h.encode() + b"\n")
+            for a in range(0, len(s), 60):
+                f.write(s[a:a + 60] + b"\n")
+    return n
+
+
+def run_round(seed, tmp):
+    rng = np.random.default_rng(seed)
+    d = os.path.join(tmp, "r%d" % seed)
+    os.makedirs(d)
+    fa = os.path.join(d, "in.fa")
+    n = write_random_fasta(rng, fa)
+    k = int(rng.integers(4, 10))
+    dtype = int(rng.choice([8, 16, 32]))
+    ident = float(rng.choice([0.6, 0.8, 0.9, 0.95]))
+    feat = "slow" if rng.integers(0, 3) == 0 else "fast"
+    flags = ["--id", str(ident), "--kmer", str(k), "--datatype", str(dtype), "--feat", feat]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    t0 = time.time()
+    r = subprocess.run([REF, fa] + flags + ["--threads", "1", "--output", "ref.clstr"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    t_ref = time.time() - t0
+    if r.returncode != 0 or not os.path.exists(os.path.join(d, "weights.txt")):
+        return "ref seed %d skipped: the reference exited with %d (%s)" % (seed, r.returncode, r.stdout.decode(errors="replace")[-200:].replace("\n", " | "))
+    t0 = time.time()
+    g = subprocess.run([EXE, fa, "--recover", "weights.txt"] + flags + ["--output", "gpu.clstr"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    t_gpu = time.time() - t0
+    if g.returncode != 0:
+        raise AssertionError("seed %d: msc_cluster failed: %s" % (seed, g.stdout.decode(errors="replace")[-1500:]))
+    a, b = open(os.path.join(d, "ref.clstr"), "rb").read(), open(os.path.join(d, "gpu.clstr"), "rb").read()
+    if a != b:
+        keep = os.path.join(ROOT, "gpurun_out", "ref_mismatch_%d" % seed)
+        os.makedirs(keep, exist_ok=True)
+        for name in ("in.fa", "weights.txt", "ref.clstr", "gpu.clstr"):
+            with open(os.path.join(d, name), "rb") as src, open(os.path.join(keep, name), "wb") as dst:
+                dst.write(src.read())
+        raise AssertionError("seed %d: .clstr differs from the reference's (k=%d u%d id=%.2f feat=%s n=%d); files kept in %s" % (seed, k, dtype, ident, feat, n, keep))
+    return "ref seed %d ok: k=%d u%d id=%.2f %s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, ident, feat, n, a.count(b">Cluster"), t_ref, t_gpu)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if not os.path.exists(REF):
+        raise SystemExit("oracle/_ref/meshclust2 is not built (needs /root/reference at build time)")
+    t_end = time.time() + budget
+    n = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        while time.time() < t_end:
+            print(run_round(seed, tmp), flush=True)
+            seed += 1
+            n += 1
+    print("reference fuzz ok: %d rounds" % n)
+
+
+if __name__ == "__main__":
+    main()
