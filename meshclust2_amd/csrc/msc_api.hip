@@ -1253,7 +1253,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (rq.raw_out && (r = ensure(ctx, ctx->raw, chunk * nf * sizeof(double))) != MSC_OK) return r;
 		if (rq.singles_out && (r = ensure(ctx, ctx->singles, chunk * ns * sizeof(double))) != MSC_OK) return r;
 		if (rq.combos_out && (r = ensure(ctx, ctx->combos, chunk * nc * sizeof(double))) != MSC_OK) return r;
-		if ((r = ensure(ctx, ctx->flags, chunk)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->flags, 64 + chunk)) != MSC_OK) return r;      // [reduce record (64 B)][close flags]: one copy back
 		if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut))) != MSC_OK) return r;
 	}
 	const uint8_t* q_bins = sp ? nullptr : rq.qset->bins + rq.q_slot * rq.qset->L.slot_bytes;
@@ -1322,11 +1322,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
 		if (rq.reduce_mode >= 0) {
 			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
-			                               (uint8_t*)ctx->flags.p, (MscReduceOut*)ctx->reduce_out.p));
-			constexpr size_t kRo = (sizeof(MscReduceOut) + 63) / 64 * 64;
+			                               (uint8_t*)ctx->flags.p + 64, (MscReduceOut*)ctx->flags.p));
+			constexpr size_t kRo = 64;
+			static_assert(sizeof(MscReduceOut) <= kRo, "the reduce record shares the head of the flags buffer");
 			if ((r = ensure_pinned(ctx, ctx->pin_down, kRo + mc)) != MSC_OK) return r;
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_down.p, ctx->reduce_out.p, sizeof(MscReduceOut), hipMemcpyDeviceToHost, ctx->stream));
-			if (rq.flags_out) HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->pin_down.p + kRo, ctx->flags.p, mc, hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_down.p, ctx->flags.p, kRo + (rq.flags_out ? mc : 0), hipMemcpyDeviceToHost, ctx->stream));
 		}
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1339,7 +1339,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (rq.reduce_mode >= 0) {
-			constexpr size_t kRo = (sizeof(MscReduceOut) + 63) / 64 * 64;
+			constexpr size_t kRo = 64;
 			memcpy(rq.reduce_host, ctx->pin_down.p, sizeof(MscReduceOut));
 			if (rq.flags_out) memcpy(rq.flags_out, (const uint8_t*)ctx->pin_down.p + kRo, mc);
 		}
