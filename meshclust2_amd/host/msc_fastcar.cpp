@@ -13,6 +13,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -90,7 +91,7 @@ int main(int argc, char** argv) {
 	std::vector<std::string> files, qfiles;
 	std::string weights, output = "output";
 	size_t chunk = 10000, qblock = 16;
-	bool format = true;
+	bool format = true, sparse = false;
 	int device = 0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -102,11 +103,12 @@ int main(int argc, char** argv) {
 		else if (a == "--query-block") qblock = std::max<size_t>(1, (size_t)std::atol(need("--query-block").c_str()));
 		else if (a == "--no-format" || a == "--noformat") format = false;
 		else if (a == "--threads" || a == "-t") need("--threads");
+		else if (a == "--sparse") sparse = true;        // sparse histogram layout (required for k >= 13; also the faster one for --feat slow models)
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
 		else files.push_back(a);
 	}
 	if (files.empty() || qfiles.empty() || weights.empty()) {
-		std::fprintf(stderr, "usage: %s <db.fa> --query <q.fa> --recover weights.txt [--output prefix] [--chunk 10000] [--no-format]\n", argv[0]);
+		std::fprintf(stderr, "usage: %s <db.fa> --query <q.fa> --recover weights.txt [--output prefix] [--chunk 10000] [--no-format] [--sparse]\n", argv[0]);
 		return 1;
 	}
 	try {
@@ -127,16 +129,25 @@ int main(int argc, char** argv) {
 		std::vector<Rec> db, queries;
 		for (const auto& f : files) { auto r = read_fasta(f); db.insert(db.end(), r.begin(), r.end()); }
 		for (const auto& f : qfiles) { auto r = read_fasta(f); queries.insert(queries.end(), r.begin(), r.end()); }
-		msc::PointSet qset(ctx, k, dtype, std::max<size_t>(1, std::min(chunk, queries.size())));
-		msc::PointSet dset(ctx, k, dtype, std::max<size_t>(1, std::min(chunk, db.size())));
+		// dense sets are refilled chunk after chunk; a sparse set's entry arena is append-only, so each chunk gets a fresh one
+		auto bases_of = [](const std::vector<Rec>& recs, size_t off, size_t n) { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += recs[off + i].seq.size(); return t; };
+		auto make_set = [&](const std::vector<Rec>& recs, size_t off, size_t n) {
+			return std::unique_ptr<msc::PointSet>(new msc::PointSet(ctx, k, dtype, std::max<size_t>(1, n), sparse ? bases_of(recs, off, n) + 1024 : 0));
+		};
+		std::unique_ptr<msc::PointSet> qset_p = make_set(queries, 0, std::min(chunk, queries.size()));
+		std::unique_ptr<msc::PointSet> dset_p = make_set(db, 0, std::min(chunk, db.size()));
 		const std::string delim = format ? "\t" : "!";
 		std::ofstream out((output + "0").c_str());
 		uint64_t num_pred_pos = 0;
 		for (size_t qo = 0; qo < queries.size(); qo += chunk) {
 			std::vector<Pt> qp;
+			if (sparse && qo) qset_p = make_set(queries, qo, std::min(chunk, queries.size() - qo));
+			msc::PointSet& qset = *qset_p;
 			load_chunk(qset, queries, qo, std::min(chunk, queries.size() - qo), qp);
 			for (size_t d0 = 0; d0 < db.size(); d0 += chunk) {
 				std::vector<Pt> dp;
+				if (sparse && (d0 || qo)) dset_p = make_set(db, d0, std::min(chunk, db.size() - d0));
+				msc::PointSet& dset = *dset_p;
 				load_chunk(dset, db, d0, std::min(chunk, db.size() - d0), dp);
 				std::vector<Pt*> pts;
 				for (auto& p : dp) pts.push_back(&p);

@@ -59,7 +59,8 @@ def run_round(seed, tmp):
     if r.returncode != 0 or not os.path.exists(os.path.join(d, "ref_0")):
         return "fastcar seed %d skipped: the reference exited with %d (%s)" % (seed, r.returncode, r.stdout.decode(errors="replace")[-160:].replace("\n", " | "))
     qb = int(rng.choice([1, 3, 16, 32]))
-    g = subprocess.run([EXE, "db.fa", "--query", "q.fa", "--recover", wpath, "--output", "gpu_", "--query-block", str(qb)], cwd=d, stdout=subprocess.PIPE,
+    extra = ["--sparse"] if big and rng.integers(0, 2) else []          # the sparse layout exists from 64 KiB histograms up
+    g = subprocess.run([EXE, "db.fa", "--query", "q.fa", "--recover", wpath, "--output", "gpu_", "--query-block", str(qb)] + extra, cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     if g.returncode != 0:
         raise AssertionError("seed %d: msc_fastcar failed: %s" % (seed, g.stdout.decode(errors="replace")[-1500:]))
@@ -71,7 +72,7 @@ def run_round(seed, tmp):
             with open(os.path.join(d, name), "rb") as src, open(os.path.join(keep, name), "wb") as dst:
                 dst.write(src.read())
         raise AssertionError("seed %d: search output differs from the reference's (%s, %d x %d, block %d); files kept in %s" % (seed, model, n_q, n_db, qb, keep))
-    return "fastcar seed %d ok: %s %d queries x %d, block %d -> %d lines (reference %.1f s)" % (seed, model, n_q, n_db, qb, a.count(b"\n"), t_ref)
+    return "fastcar seed %d ok: %s %d queries x %d, block %d%s -> %d lines (reference %.1f s)" % (seed, model, n_q, n_db, qb, " sparse" if extra else "", a.count(b"\n"), t_ref)
 
 
 def main():

@@ -984,3 +984,25 @@ def test_randomised_multi_rounds(ctx, seed):
     k / datatype / layout / query count / model) against one 1 x M pass per query."""
     import fuzz_parity
     assert "ok" in fuzz_parity.run_multi_round(ctx, seed)
+
+
+def test_fastcar_sparse_layout_writes_the_same_file(tmp_path):
+    """msc_fastcar --sparse (sorted (bin, value) lists; the Q x M pass queues one merge-path pass per query) writes the same bytes
+    as the dense layout, also when the database and the queries come in several chunks (a sparse set is rebuilt per chunk)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, headers = synth.families(123, 260, 1000, length_jitter=120)
+    db, q = str(tmp_path / "db.fa"), str(tmp_path / "q.fa")
+    synth.write_fasta(db, seqs, headers)
+    synth.write_fasta(q, seqs[3:120:4], headers[3:120:4])
+    outs = []
+    for extra in ([], ["--sparse"], ["--sparse", "--chunk", "100"]):
+        prefix = str(tmp_path / ("fc%d_" % len(outs)))
+        r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_fastcar"), db, "--query", q, "--recover", os.path.join(root, "tests", "golden", "weights_k9_u32.txt"),
+                            "--output", prefix] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        outs.append(open(prefix + "0", "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") > 100
+    # chunking changes the order of the lines (query chunk, then database chunk), not their set
+    assert sorted(outs[2].splitlines()) == sorted(outs[0].splitlines())
