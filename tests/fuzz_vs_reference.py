@@ -83,7 +83,9 @@ def run_round(seed, tmp):
     dtype = int(rng.choice([8, 16, 32]))
     ident = float(rng.choice([0.6, 0.8, 0.9, 0.95]))
     feat = "slow" if rng.integers(0, 3) == 0 else "fast"
-    flags = ["--id", str(ident), "--kmer", str(k), "--datatype", str(dtype), "--feat", feat]
+    auto = rng.integers(0, 4) == 0                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
+    id_text = str(ident) if rng.integers(0, 6) else ("%g" % (ident * 100))          # the CLI also takes the threshold as a percentage
+    flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)])
     env = dict(os.environ, OMP_NUM_THREADS="1")
     t0 = time.time()
     r = subprocess.run([REF, fa] + flags + ["--threads", "1", "--output", "ref.clstr"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
@@ -112,7 +114,12 @@ def run_round(seed, tmp):
             with open(os.path.join(d, name), "rb") as src, open(os.path.join(keep, name), "wb") as dst:
                 dst.write(src.read())
         raise AssertionError("seed %d: .clstr differs from the reference's (k=%d u%d id=%.2f feat=%s n=%d); files kept in %s" % (seed, k, dtype, ident, feat, n, keep))
-    return "ref seed %d ok: k=%d u%d id=%.2f %s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, ident, feat, n, a.count(b">Cluster"), t_ref, t_gpu)
+    if auto:
+        text = open(os.path.join(d, "weights.txt")).read()
+        k = int(text.split("k:")[1].split()[0])
+        dtype = {"uint8_t": 8, "uint16_t": 16, "uint32_t": 32, "uint64_t": 64}[text.split("Datatype:")[1].split()[0]]
+    return "ref seed %d ok: k=%d u%d%s id=%s %s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, " (chosen by the reference)" if auto else "", id_text, feat, n,
+                                                                                                         a.count(b">Cluster"), t_ref, t_gpu)
 
 
 def main():
