@@ -446,6 +446,37 @@ struct SplitMix {
 	double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
+// Runner::find_k's per-record size (cluster/CRunner.cpp:479-502). It builds each record with ChromListMaker::makeChromList
+// (nonltr/ChromListMaker.cpp:52-95), whose Chromosome(size) pre-fills the sequence with `size` blanks (nonltr/Chromosome.cpp:18-21) and
+// then APPENDS the record's lines (appendToSequence, :88-97), so the effective size it reports is that of blanks + sequence: the
+// leading blanks are one non-N run that continues into the first run of the record. Same run / merge (< 10 apart) / drop (< 20) rules as
+// the encoder (nonltr/Chromosome.cpp:263-353), including the run that starts on the very last character being lost.
+unsigned long long find_k_record_size(const std::string& seq, size_t n_blanks) {
+	const size_t n = n_blanks + seq.size();
+	auto is_n = [&](size_t i) { return i >= n_blanks && std::toupper((unsigned char)seq[i - n_blanks]) == 'N'; };
+	std::vector<std::pair<long long, long long> > runs;
+	long long start = -1;
+	for (size_t i = 0; i < n; i++) {
+		const bool nn = is_n(i);
+		if (!nn && start == -1) start = (long long)i;
+		else if (nn && start != -1) { runs.push_back({start, (long long)i - 1}); start = -1; }
+		else if (i == n - 1 && !nn && start != -1) { runs.push_back({start, (long long)i}); start = -1; }
+	}
+	if (n > 20 && !runs.empty()) {
+		std::vector<std::pair<long long, long long> > merged;
+		long long s0 = runs[0].first, e0 = runs[0].second;
+		for (size_t i = 1; i < runs.size(); i++) {
+			if (runs[i].first - e0 < 10) e0 = runs[i].second;
+			else { if (e0 - s0 + 1 >= 20) merged.push_back({s0, e0}); s0 = runs[i].first; e0 = runs[i].second; }
+		}
+		if (e0 - s0 + 1 >= 20) merged.push_back({s0, e0});
+		runs.swap(merged);
+	}
+	unsigned long long eff = 0;
+	for (const auto& r : runs) eff += (unsigned long long)(r.second - r.first + 1);
+	return eff;
+}
+
 std::string acgt_only(const std::string& s) {
 	std::string o;
 	for (char c : s) { const char u = (char)std::toupper((unsigned char)c); if (u == 'A' || u == 'C' || u == 'G' || u == 'T') o.push_back(u); }
@@ -563,14 +594,24 @@ int main(int argc, char** argv) {
 	try {
 		msc::Context ctx(device);
 		std::vector<std::string> headers, seqs;
-		for (const auto& f : files) read_fasta(f, headers, seqs, single_file);
+		std::vector<size_t> file_first;                // index of every file's first record (find_k averages per file, then over the files)
+		for (const auto& f : files) { file_first.push_back(seqs.size()); read_fasta(f, headers, seqs, single_file); }
+		file_first.push_back(seqs.size());
 		const size_t n = seqs.size();
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		if (weights.empty()) {
-			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average effective length)) - 1
+			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average record size)) - 1, integer averages
 				unsigned long long length = 0;
-				for (const auto& sq : seqs) length += acgt_only(sq).size();
-				length /= n;
+				size_t n_files = 0;
+				for (size_t f = 0; f + 1 < file_first.size(); f++) {
+					if (file_first[f + 1] == file_first[f]) continue;
+					unsigned long long l = 0;
+					// --single-file: one record per file, pre-sized for every joined record + 50 (nonltr/ChromListMaker.cpp:58-65)
+					for (size_t i = file_first[f]; i < file_first[f + 1]; i++) l += find_k_record_size(seqs[i], seqs[i].size() + (single_file ? 50 : 0));
+					length += l / (file_first[f + 1] - file_first[f]);
+					n_files++;
+				}
+				length /= std::max<size_t>(1, n_files);
 				k = (int)std::ceil(std::log((double)length) / std::log(4.0)) - 1;
 				std::cout << "avg length: " << length << std::endl << "Recommended K: " << k << std::endl;
 			}

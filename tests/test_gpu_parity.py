@@ -778,7 +778,9 @@ def test_cluster_driver_trains_its_own_model(tmp_path, ctx):
                        stderr=subprocess.STDOUT, timeout=900)
     log = r.stdout.decode(errors="replace")
     assert r.returncode == 0, log[-2000:]
-    assert "Recommended K: 4" in log and "Using 8 bit histograms" in log          # ceil(log4(999)) - 1; no count above 255 at k = 4 / 1 kb
+    # find_k measures blanks + sequence (test_find_k_reproduces_the_reference_rule): ceil(log4(~2000)) - 1 = 5, as the reference prints
+    # for this kind of input; no count above 255 at k = 5 / 1 kb
+    assert "Recommended K: 5" in log and "Using 8 bit histograms" in log
     members = [ln for ln in open(out) if not ln.startswith(">Cluster")]
     assert len(members) == len(seqs) and len({ln.split(">")[1].split("...")[0] for ln in members}) == len(seqs)
     feat = api.Feature.from_text(ctx, open(str(tmp_path / "weights.txt")).read(), 0)
@@ -1006,3 +1008,32 @@ def test_fastcar_sparse_layout_writes_the_same_file(tmp_path):
     assert outs[0] == outs[1] and outs[0].count(b"\n") > 100
     # chunking changes the order of the lines (query chunk, then database chunk), not their set
     assert sorted(outs[2].splitlines()) == sorted(outs[0].splitlines())
+
+
+def test_find_k_reproduces_the_reference_rule(tmp_path):
+    """Runner::find_k (cluster/CRunner.cpp:479-502) measures every record through ChromListMaker::makeChromList, whose pre-sized
+    Chromosome is APPENDED to: the record size it averages is that of `len` blanks + the sequence (so 2 x len without N runs).
+    Expected (avg length, k) pairs were printed by the reference CLI for inputs of exactly these shapes (lengths and N runs are all
+    that matter): 100 -> 200/3; 100,300 -> 400/4; 5 x 1000 -> 2000/5; 5 x 1000 + 50 -> 1683/5; 100 N30 100 -> 430/4;
+    100 N5 100 -> 410/4; 100 N30 10 -> 240/3; N20 100 N20 -> 240/3; 15 -> 30/2; two files (100 | 100, 300) -> 300/4."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_cluster")
+    b = lambda n: ("ACGTTGCA" * (n // 8 + 1))[:n]
+    cases = [([[b(100)]], 200, 3), ([[b(100), b(300)]], 400, 4), ([[b(1000)] * 5], 2000, 5), ([[b(1000)] * 5 + [b(50)]], 1683, 5),
+             ([[b(100) + "N" * 30 + b(100)]], 430, 4), ([[b(100) + "n" * 5 + b(100)]], 410, 4), ([[b(100) + "N" * 30 + b(10)]], 240, 3),
+             ([["N" * 20 + b(100) + "N" * 20]], 240, 3), ([[b(15)]], 30, 2), ([[b(100)], [b(100), b(300)]], 300, 4)]
+    for ci, (files, avg, k) in enumerate(cases):
+        names = []
+        for fi, recs in enumerate(files):
+            name = str(tmp_path / ("c%d_%d.fa" % (ci, fi)))
+            with open(name, "w") as f:
+                for ri, s in enumerate(recs):
+                    f.write(">r%d_%d\n" % (fi, ri))
+                    for a in range(0, len(s), 70):
+                        f.write(s[a:a + 70] + "\n")
+            names.append(name)
+        r = subprocess.run([exe] + names + ["--id", "0.9", "--output", str(tmp_path / "o.clstr")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = r.stdout.decode(errors="replace")          # too few sequences to train on: the run stops after printing its choice of k
+        assert "avg length: %d\n" % avg in out and "Recommended K: %d\n" % k in out, (ci, out[-400:])
