@@ -567,10 +567,23 @@ int main(int argc, char** argv) {
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
 		auto need = [&](const char* what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
-		if (a == "--id") similarity = std::atof(need("--id").c_str());
+		if (a == "--id") {          // Runner::get_opts, cluster/CRunner.cpp:247-258: anything outside (0, 1) is refused
+			similarity = std::atof(need("--id").c_str());
+			if (!(similarity > 0 && similarity < 1)) { std::cerr << "Similarity must be between 0 and 1" << std::endl; return 1; }
+		}
 		else if (a == "--kmer" || a == "-k") k = std::atoi(need("--kmer").c_str());
 		else if (a == "--datatype") { std::string v = need("--datatype"); dtype = v == "uint8_t" ? 8 : v == "uint16_t" ? 16 : v == "uint32_t" ? 32 : v == "uint64_t" ? 64 : std::atoi(v.c_str()); }
-		else if (a == "--recover" || a == "-r") weights = need("--recover");
+		else if (a == "--recover" || a == "-r") {
+			// cluster/CRunner.cpp:291-297: the model's ID and k become the run's similarity and k on the spot (a later --id / --kmer overrides)
+			weights = need("--recover");
+			std::ifstream win(weights.c_str());
+			std::string tok;
+			while (win >> tok) {
+				if (tok == "k:") win >> k;
+				else if (tok == "ID:") win >> similarity;
+				else if (tok == "n_combos:") break;
+			}
+		}
 		else if (a == "--output" || a == "-o") output = need("--output");
 		else if (a == "--delta" || a == "-d") delta = std::atoi(need("--delta").c_str());
 		else if (a == "--iterations" || a == "-i" || a == "--iter") iterations = std::atoi(need("--iterations").c_str());

@@ -19,6 +19,7 @@ def write_random_fasta(rng, path):
     rate = float(rng.choice([0.01, 0.03, 0.06]))
     lo, hi = (200, 900) if rng.integers(0, 2) else (400, 2500)
     dirty = rng.integers(0, 3) == 0
+    repeats = not dirty and rng.integers(0, 3) == 0
     recs = []
     for i in range(n):
         if i % fam == 0:
@@ -30,6 +31,9 @@ def write_random_fasta(rng, path):
         if rng.integers(0, 8) == 0:
             a = int(rng.integers(0, len(s)))
             del s[a:a + int(rng.integers(1, max(2, len(s) // 12)))]
+        if repeats and rng.integers(0, 12) == 0:    # a homopolymer / dinucleotide run: counts beyond 255, so the type scan must pick 16 bits
+            a = int(rng.integers(0, len(s)))
+            s[a:a] = (b"A" if rng.integers(0, 2) else b"AC") * int(rng.integers(280, 700))
         if dirty:                                   # the encoder's corner: N runs that merge / split / drop segments, IUPAC codes, lower case
             if rng.integers(0, 5) == 0:
                 for _ in range(int(rng.integers(1, 4))):
@@ -83,8 +87,8 @@ def run_round(seed, tmp):
     dtype = int(rng.choice([8, 16, 32]))
     ident = float(rng.choice([0.6, 0.8, 0.9, 0.95]))
     feat = "slow" if rng.integers(0, 3) == 0 else "fast"
-    auto = rng.integers(0, 4) == 0                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
-    id_text = str(ident) if rng.integers(0, 6) else ("%g" % (ident * 100))          # the CLI also takes the threshold as a percentage
+    auto = rng.integers(0, 4) == 0 or os.environ.get("FUZZ_ALWAYS_AUTO") == "1"                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
+    id_text = str(ident)
     flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)])
     env = dict(os.environ, OMP_NUM_THREADS="1")
     t0 = time.time()
@@ -115,6 +119,13 @@ def run_round(seed, tmp):
                 dst.write(src.read())
         raise AssertionError("seed %d: .clstr differs from the reference's (k=%d u%d id=%.2f feat=%s n=%d); files kept in %s" % (seed, k, dtype, ident, feat, n, keep))
     if auto:
+        # the driver's own choice of k and histogram type (no --recover: it trains its own model, so only the two lines are compared)
+        own = subprocess.run([EXE, fa] + flags + ["--output", "own.clstr", "--dump", "own_weights.txt"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        pick = lambda text, key: [ln.strip() for ln in text.replace("\r", "\n").splitlines() if ln.startswith(key)][:1]
+        ref_log, own_log = r.stdout.decode(errors="replace"), own.stdout.decode(errors="replace")
+        for key in ("avg length:", "Recommended K:", "Using "):
+            if pick(ref_log, key) != pick(own_log, key):
+                raise AssertionError("seed %d: the driver chose differently from the reference: %r vs %r" % (seed, pick(own_log, key), pick(ref_log, key)))
         text = open(os.path.join(d, "weights.txt")).read()
         k = int(text.split("k:")[1].split()[0])
         dtype = {"uint8_t": 8, "uint16_t": 16, "uint32_t": 32, "uint64_t": 64}[text.split("Datatype:")[1].split()[0]]
