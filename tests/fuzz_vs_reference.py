@@ -45,9 +45,12 @@ def write_random_fasta(rng, path):
             if rng.integers(0, 10) == 0:
                 s = bytearray(bytes(s).lower())
         recs.append((">r%d fam%d" % (i, i // fam), bytes(s)))
+    order = [int(i) for i in rng.permutation(n)]
+    if path is None:
+        return [recs[i] for i in order]
     with open(path, "wb") as f:
-        for i in rng.permutation(n):
-            h, s = recs[int(i)]
+        for i in order:
+            h, s = recs[i]
             f.write(h.encode() + b"\n")
             for a in range(0, len(s), 60):
                 f.write(s[a:a + 60] + b"\n")
@@ -81,23 +84,41 @@ def run_round(seed, tmp):
     rng = np.random.default_rng(seed)
     d = os.path.join(tmp, "r%d" % seed)
     os.makedirs(d)
-    fa = os.path.join(d, "in.fa")
-    n = write_random_fasta(rng, fa)
+    single = rng.integers(0, 8) == 0 or os.environ.get("FUZZ_SINGLE_FILE") == "1"
+    if single:          # --single-file: every FASTA file is ONE sequence, its records joined by 50 N (clutil/SingleFileLoader.cpp:45-123)
+        recs = write_random_fasta(rng, None)
+        inputs = []
+        i = 0
+        while i < len(recs):
+            per = int(rng.integers(1, 4))
+            name = os.path.join(d, "f%03d.fa" % len(inputs))
+            with open(name, "wb") as f:
+                for h, sq in recs[i:i + per]:
+                    f.write(h.encode() + b"\n")
+                    for a in range(0, len(sq), 60):
+                        f.write(sq[a:a + 60] + b"\n")
+            inputs.append(name)
+            i += per
+        n = len(inputs)
+    else:
+        fa = os.path.join(d, "in.fa")
+        n = write_random_fasta(rng, fa)
+        inputs = [fa]
     k = int(rng.integers(4, 10))
     dtype = int(rng.choice([8, 16, 32]))
     ident = float(rng.choice([0.6, 0.8, 0.9, 0.95]))
     feat = "slow" if rng.integers(0, 3) == 0 else "fast"
     auto = rng.integers(0, 4) == 0 or os.environ.get("FUZZ_ALWAYS_AUTO") == "1"                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
     id_text = str(ident)
-    flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)])
+    flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)]) + (["--single-file"] if single else [])
     env = dict(os.environ, OMP_NUM_THREADS="1")
     t0 = time.time()
-    r = subprocess.run([REF, fa] + flags + ["--threads", "1", "--output", "ref.clstr"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    r = subprocess.run([REF] + inputs + flags + ["--threads", "1", "--output", "ref.clstr"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
     t_ref = time.time() - t0
     if r.returncode != 0 or not os.path.exists(os.path.join(d, "weights.txt")):
         return "ref seed %d skipped: the reference exited with %d (%s)" % (seed, r.returncode, r.stdout.decode(errors="replace")[-200:].replace("\n", " | "))
     t0 = time.time()
-    g = subprocess.run([EXE, fa, "--recover", "weights.txt"] + flags + ["--output", "gpu.clstr"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    g = subprocess.run([EXE] + inputs + ["--recover", "weights.txt"] + flags + ["--output", "gpu.clstr"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     t_gpu = time.time() - t0
     if g.returncode != 0:
         raise AssertionError("seed %d: msc_cluster failed: %s" % (seed, g.stdout.decode(errors="replace")[-1500:]))
@@ -114,13 +135,13 @@ def run_round(seed, tmp):
     if a != b:
         keep = os.path.join(ROOT, "gpurun_out", "ref_mismatch_%d" % seed)
         os.makedirs(keep, exist_ok=True)
-        for name in ("in.fa", "weights.txt", "ref.clstr", "gpu.clstr"):
+        for name in [os.path.basename(x) for x in inputs] + ["weights.txt", "ref.clstr", "gpu.clstr"]:
             with open(os.path.join(d, name), "rb") as src, open(os.path.join(keep, name), "wb") as dst:
                 dst.write(src.read())
         raise AssertionError("seed %d: .clstr differs from the reference's (k=%d u%d id=%.2f feat=%s n=%d); files kept in %s" % (seed, k, dtype, ident, feat, n, keep))
     if auto:
         # the driver's own choice of k and histogram type (no --recover: it trains its own model, so only the two lines are compared)
-        own = subprocess.run([EXE, fa] + flags + ["--output", "own.clstr", "--dump", "own_weights.txt"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        own = subprocess.run([EXE] + inputs + flags + ["--output", "own.clstr", "--dump", "own_weights.txt"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         pick = lambda text, key: [ln.strip() for ln in text.replace("\r", "\n").splitlines() if ln.startswith(key)][:1]
         ref_log, own_log = r.stdout.decode(errors="replace"), own.stdout.decode(errors="replace")
         for key in ("avg length:", "Recommended K:", "Using "):
@@ -129,7 +150,7 @@ def run_round(seed, tmp):
         text = open(os.path.join(d, "weights.txt")).read()
         k = int(text.split("k:")[1].split()[0])
         dtype = {"uint8_t": 8, "uint16_t": 16, "uint32_t": 32, "uint64_t": 64}[text.split("Datatype:")[1].split()[0]]
-    return "ref seed %d ok: k=%d u%d%s id=%s %s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, " (chosen by the reference)" if auto else "", id_text, feat, n,
+    return "ref seed %d ok: k=%d u%d%s id=%s %s%s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, " (chosen by the reference)" if auto else "", id_text, feat, " single-file" if single else "", n,
                                                                                                          a.count(b">Cluster"), t_ref, t_gpu)
 
 
