@@ -111,6 +111,8 @@ def run_round(seed, tmp):
     auto = rng.integers(0, 4) == 0 or os.environ.get("FUZZ_ALWAYS_AUTO") == "1"                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
     id_text = str(ident)
     flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)]) + (["--single-file"] if single else [])
+    if rng.integers(0, 3) == 0:                      # the mean-shift knobs: neighbourhood half-width and iteration cap
+        flags += ["--delta", str(int(rng.integers(1, 9))), "--iterations", str(int(rng.integers(1, 21)))]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     t0 = time.time()
     r = subprocess.run([REF] + inputs + flags + ["--threads", "1", "--output", "ref.clstr"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
@@ -150,7 +152,7 @@ def run_round(seed, tmp):
         text = open(os.path.join(d, "weights.txt")).read()
         k = int(text.split("k:")[1].split()[0])
         dtype = {"uint8_t": 8, "uint16_t": 16, "uint32_t": 32, "uint64_t": 64}[text.split("Datatype:")[1].split()[0]]
-    return "ref seed %d ok: k=%d u%d%s id=%s %s%s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, " (chosen by the reference)" if auto else "", id_text, feat, " single-file" if single else "", n,
+    return "ref seed %d ok: k=%d u%d%s id=%s %s%s n=%d -> %d clusters (reference %.1f s, msc_cluster %.1f s)" % (seed, k, dtype, " (chosen by the reference)" if auto else "", id_text, feat, (" single-file" if single else "") + (" " + " ".join(flags[flags.index("--delta"):flags.index("--delta") + 4]) if "--delta" in flags else ""), n,
                                                                                                          a.count(b">Cluster"), t_ref, t_gpu)
 
 
