@@ -13,7 +13,7 @@ EXE = os.path.join(ROOT, "meshclust2_amd", "host", "msc_cluster")
 
 
 def write_random_fasta(rng, path):
-    n = int(rng.integers(60, 420))
+    n = int(rng.integers(60, 420)) * (5 if os.environ.get("FUZZ_BIG") == "1" else 1)
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
     fam = int(rng.integers(3, 20))
     rate = float(rng.choice([0.01, 0.03, 0.06]))
