@@ -625,6 +625,7 @@ int main(int argc, char** argv) {
 					n_files++;
 				}
 				length /= std::max<size_t>(1, n_files);
+				if (length == 0) { std::fprintf(stderr, "cannot choose k: the input holds no bases\n"); return 1; }
 				k = (int)std::ceil(std::log((double)length) / std::log(4.0)) - 1;
 				std::cout << "avg length: " << length << std::endl << "Recommended K: " << k << std::endl;
 			}
