@@ -108,6 +108,7 @@ def run_round(seed, tmp):
     dtype = int(rng.choice([8, 16, 32]))
     ident = float(rng.choice([0.6, 0.8, 0.9, 0.95]))
     feat = "slow" if rng.integers(0, 3) == 0 else "fast"
+    feat = os.environ.get("FUZZ_FEAT", feat)
     auto = rng.integers(0, 4) == 0 or os.environ.get("FUZZ_ALWAYS_AUTO") == "1"                  # let the reference choose k (find_k) and the histogram type itself; msc_cluster reads them from weights.txt
     id_text = str(ident)
     flags = ["--id", id_text, "--feat", feat] + ([] if auto else ["--kmer", str(k), "--datatype", str(dtype)]) + (["--single-file"] if single else [])
