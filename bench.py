@@ -2,24 +2,29 @@
 """bench.py -- sequence-pairs/s identity-scored on MI355X (BASELINE.json metric), with the pair kernel's HBM roofline
 and the CPU path timed beside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nseq 100000] [--k 9] [--dtype 32] [--queries 8]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nseq 100000] [--k 9] [--dtype 32] [--queries 64] [--scaling strong|weak]
 
-Workload (BASELINE.json configs[1], "cfg2"): `nseq` synthetic 1 kb sequences per GPU (families of 20, 3 % substitutions,
-0.5 % indels, SplitMix64 seed 20260002 + rank), k = 9, --datatype 32 -> 1 MiB per histogram, all resident in HBM before the
-timed region. One STEP = one block of the full pairwise matrix: `queries` query histograms x ALL resident histograms
-(Predictor::close of fastcar's work(), fastcar/FC_Runner.cpp:426-471; the same per-pair work as cluster/Trainer.cpp:49-52):
-9 `fast` statistics, normalise, 4 combos, GLM, close flags copied back to the host. --mode allpairs (default) scores the
-block in ONE streaming pass (msc_score_multi -> k_pair_digest_multi: a workgroup fetches each candidate tile once for 16
-queries, DESIGN.md 4.1b); --mode get_close issues `queries` separate 1 x M Trainer::get_close passes (the step-serial shape
-of the mean-shift accumulate loop, incl. the arg-max reduce). value = scored pairs per second over the whole job (all ranks).
+Workload (BASELINE.json configs[1], "cfg2"): `nseq` synthetic 1 kb sequences IN TOTAL (families of 20, 3 % substitutions,
+0.5 % indels, SplitMix64 seed 20260002; sequence g is the same whatever the number of ranks), k = 9, --datatype 32 -> 1 MiB
+per histogram, all resident in HBM before the timed region. One STEP = one block of the full pairwise matrix: `queries`
+query histograms x ALL histograms (Predictor::close of fastcar's work(), fastcar/FC_Runner.cpp:426-471; the same per-pair
+work as cluster/Trainer.cpp:49-52): 9 `fast` statistics, normalise, 4 combos, GLM, close flags copied back to the host.
+--mode allpairs (default) scores the block in ONE streaming pass (msc_score_multi -> k_pair_digest_multi: a workgroup fetches
+each candidate tile once for 16 queries); --mode get_close issues `queries` separate 1 x M
+Trainer::get_close passes (the step-serial shape of the mean-shift accumulate loop, incl. the arg-max reduce).
+value = scored pairs per second over the whole job (all ranks).
 roofline: algorithmic bytes per launch = (M * ceil(Q / q) + Q) * 4^k * sizeof(T), q = queries served per HBM read of a
 candidate tile as msc_last_kernel_info reports it for the kernel that actually ran, divided by the kernel's own launch time
 (HIP events on the library's stream).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): candidates are sharded by sequence block (weak scaling: nseq
-per GPU is fixed). Per pass the query histogram is broadcast from its owner rank over RCCL directly into every rank's
-query slot, each rank scores its shard, and one 24-byte (n_close, best_sim, best_global_index) record per rank is
-all-gathered -- the exchange SURVEY.md 8(e) describes. No other data-path collective exists.
+Multi-GPU (--gpus N, launched by torch.distributed.run): the histograms are sharded by sequence block (block-cyclic, 1000 per
+block: meshclust2_amd/shard.py). --scaling strong (default; north_star: ">= 6x 1 -> 8 GPUs on 100k x 1kb"): `nseq` is the TOTAL,
+every rank holds nseq / N of them; --scaling weak: `nseq` per GPU. Per step every rank contributes queries / N of its own
+histograms and ONE all-gather per payload region (bins, scalar records: 2 collectives per step, RCCL over xGMI) assembles the
+step's query block in every rank's query slots -- fastcar's chunked outer loop (fastcar/FC_Runner.cpp:585-597) with the
+database shards resident and the query chunk moving; the exchange of step s + 1 runs underneath the kernel of step s. Each
+rank scores the block against its shard and the per-query close counts are all-gathered. --mode get_close broadcasts one
+query per pass from its owner and all-gathers one 24-byte (n_close, best_sim, best_global_index) record per rank.
 """
 import argparse
 import json
@@ -39,60 +44,73 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed steps; the default scores 64 x 16 x 100000 = 1.02e8 pairs (SURVEY 8d: a >= 1e8-pair slice)")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; the default scores 20 x 64 x 100000 = 1.28e8 pairs (SURVEY 8d: a >= 1e8-pair slice)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nseq", type=int, default=100000, help="sequences resident per GPU")
+    ap.add_argument("--nseq", type=int, default=100000, help="sequences in total (--scaling strong) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--k", type=int, default=9)
     ap.add_argument("--dtype", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=16, help="query histograms per step")
+    ap.add_argument("--queries", type=int, default=64, help="query histograms per step (a multiple of the number of ranks)")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
     ap.add_argument("--layout", choices=("dense", "sparse"), default="dense",
                     help="sparse: the same workload on sorted (bin, value) lists (DESIGN 3b; single GPU only) -- algorithmic bytes are then the list bytes")
+    ap.add_argument("--weights", default=None, help="weights file (default: tests/golden/weights_k9_u32.txt, the 9-feature `fast` model of cfg2); e.g. "
+                                                    "tests/golden/weights_cfg5_k9.txt for a `--feat slow` model with jensen_shannon")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
-    ap.add_argument("--cpu-cands", type=int, default=2048)
+    ap.add_argument("--cpu-cands", type=int, default=16384, help="candidates per CPU get_close pass: enough for every host thread of a 256-thread box to get 64")
     return ap.parse_args()
 
 
-def build_resident_set(api, synth, ctx, args, rank):
-    """Histograms resident in HBM before the clock starts. Sequences are packed on the host in chunks."""
-    sparse_entries = (args.nseq + 2 * args.queries) * (args.length + 64) if args.layout == "sparse" else 0
-    hs = api.HistogramSet(ctx, args.k, args.dtype, args.nseq + 2 * args.queries, sparse_entries=sparse_entries)      # tail slots = two blocks of broadcast queries
-    chunk = 20000
-    seed = 20260002 + rank
+BLOCK = 1000          # sequences per shard block = one bvec bin (cluster/CRunner.cpp:585)
+
+
+def build_resident_set(api, synth, ctx, args, plan, rank):
+    """This rank's shard resident in HBM before the clock starts: global sequence g = plan.global_index(rank, local) -- the same
+    sequence whatever the number of ranks. Sequences are generated and packed on the host in chunks of whole shard blocks."""
+    M = plan.local_count(rank)
+    Q = args.queries
+    sparse_entries = (M + 2 * Q) * (args.length + 64) if args.layout == "sparse" else 0
+    hs = api.HistogramSet(ctx, args.k, args.dtype, M + 2 * Q, sparse_entries=sparse_entries)      # tail slots = two blocks of gathered queries
+    seed = 20260002
+    fam = 20
+    assert BLOCK % fam == 0
     t0 = time.time()
     t_dev = []          # (sequences, seconds) per chunk inside msc_hist_build_packed only: H2D of the 2-bit bases + the build kernels, host packing excluded
     done = 0
-    fam = 20
-    while done < args.nseq:
-        n = min(chunk, args.nseq - done)
-        # families are generated by template index, so chunks are independent and reproducible
-        first_t = done // fam
+    last = None
+    while done < M:
+        n = min(20 * BLOCK, M - done)
         codes = []
-        for t in range(first_t, (done + n + fam - 1) // fam):
-            tmpl = synth.template(seed, t, args.length)
-            for j in range(fam):
-                i = t * fam + j
-                if done <= i < done + n:
-                    codes.append(synth.member(seed, t, j, tmpl))
+        for lb in range(done // BLOCK, (done + n + BLOCK - 1) // BLOCK):          # local blocks of this chunk
+            g0 = plan.global_index(rank, lb * BLOCK)
+            g1 = min(g0 + BLOCK, plan.n_total)
+            # families are generated by template index, so blocks are independent and reproducible
+            for t in range(g0 // fam, (g1 + fam - 1) // fam):
+                tmpl = synth.template(seed, t, args.length)
+                for j in range(fam):
+                    if g0 <= t * fam + j < g1:
+                        codes.append(synth.member(seed, t, j, tmpl))
+        assert len(codes) == n
         b = synth.pack_batch(codes)
         t1 = time.perf_counter()
         hs.build_packed(done, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
         ctx.synchronize()
         t_dev.append((n, time.perf_counter() - t1))
+        last = (done, n, b)
         done += n
-        last = (done - n, n, b)
     # Between chunks the host spends ~1 s generating sequences, so every chunk above starts on an idle GPU (and the first ones
     # allocate the library's scratch buffers). Steady state = the last chunk rebuilt in place three times back to back (same
-    # bytes into the same slots).
+    # bytes into the same slots). Dense only: a sparse set's entry arena is append-only, a rebuilt slot reserves its entries again.
     steady = []
-    for _ in range(3):
+    for _ in range(3 if args.layout == "dense" else 0):
         first, n, b = last
         t1 = time.perf_counter()
         hs.build_packed(first, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
         ctx.synchronize()
         steady.append(n / (time.perf_counter() - t1))
-    return hs, time.time() - t0, {"all": sum(n_ for n_, _ in t_dev) / sum(s_ for _, s_ in t_dev), "median_chunk": max(steady)}
+    rate_all = sum(n_ for n_, _ in t_dev) / sum(s_ for _, s_ in t_dev)
+    return hs, time.time() - t0, {"all": rate_all, "median_chunk": max(steady) if steady else rate_all}
 
 
 def cpu_baseline(args, synth, weights_text, weights_path):
@@ -180,36 +198,42 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    from meshclust2_amd import api, synth
+    from meshclust2_amd import api, shard, synth
 
+    n_total = args.nseq if args.scaling == "strong" else args.nseq * world
+    plan = shard.ShardPlan(n_total, world, block=BLOCK)
+    Q = args.queries
+    if world > 1 and args.layout == "sparse":
+        raise SystemExit("--layout sparse is a single-GPU comparison (the exchange of 8(e) moves dense slots)")
+    if Q % world:
+        raise SystemExit("--queries must be a multiple of the number of ranks (every rank contributes queries / N per step)")
     ctx = api.Context(local_rank)
-    hs, build_s, build_dev_s = build_resident_set(api, synth, ctx, args, rank)
-    M = args.nseq
-    q_slot = M
-    wpath = os.path.join(ROOT, "tests", "golden", "weights_k9_u32.txt" if args.k == 9 else "weights_k5_u16.txt")
+    hs, build_s, build_dev_s = build_resident_set(api, synth, ctx, args, plan, rank)
+    M = plan.local_count(rank)                                  # this rank's shard
+    m_min = min(plan.local_count(r) for r in range(world))
+    wpath = args.weights or os.path.join(ROOT, "tests", "golden", "weights_k9_u32.txt" if args.k == 9 else "weights_k5_u16.txt")
     wtext = open(wpath).read()
     feat = api.Feature.from_text(ctx, wtext, 0)
     trn = api.Trainer(ctx, feat, 0.9)
 
-    # N > 1: the exchange of SURVEY 8(e) through meshclust2_amd/shard.py; RCCL broadcasts land directly in slots M..M+2Q-1 (two blocks:
-    # the next step's queries arrive while this step's are scored)
-    Q = args.queries
+    # N > 1: the exchange of SURVEY 8(e) through meshclust2_amd/shard.py; the collectives land directly in slots M .. M + 2Q - 1 (two
+    # blocks: the next step's queries arrive while this step's are scored)
     sharded = block = None
-    if world > 1 and args.layout == "sparse":
-        raise SystemExit("--layout sparse is a single-GPU comparison (the exchange of 8(e) moves dense slots)")
     if world > 1:
-        from meshclust2_amd import shard
         all_bins, all_scal = shard.device_tensors(hs, M + 2 * Q)      # [slot, bytes] views of the set's device memory
-
-        def _slot(i):
-            return [all_bins[i], all_scal[i]]
 
         class GpuBackend:
             def query_buffers(self, j=0):
-                return _slot(M + j)
+                return [all_bins[M + j], all_scal[M + j]]
 
             def export_query(self, local):
-                return _slot(local)
+                return [all_bins[local], all_scal[local]]
+
+            def export_block(self, local_first, n):
+                return [all_bins[local_first:local_first + n], all_scal[local_first:local_first + n]]
+
+            def block_buffers(self, base, n_rows):
+                return [all_bins[M + base:M + base + n_rows], all_scal[M + base:M + base + n_rows]]
 
             def import_query(self):
                 self.import_queries(1)
@@ -225,37 +249,41 @@ def main():
             def score_block(self, n, base=0):
                 return api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close",))["close"]
 
-        plan = shard.ShardPlan(M * world, world, block=1000)
         sharded = shard.ShardedTrainer(dist, plan, GpuBackend(), rank, device="cuda")
         block = shard.ShardedBlockScorer(dist, plan, GpuBackend(), rank, device="cuda")
 
     tiles_ms, launches = [], []
     step_no = [0]
     pending = [None, None]          # RCCL work handles of the query block in flight per buffer half (N > 1, allpairs)
+    qpr = Q // world                # queries every rank contributes per step
+
+    def block_first(st):
+        """first local slot of the queries / N consecutive histograms every rank contributes to the block of step st"""
+        return (st * qpr * 131) % (m_min - qpr + 1)
 
     def one_step():
         """`queries` query histograms against every resident histogram of every rank"""
         st = step_no[0]
         step_no[0] += 1
-        total = M * world
-        qg = [((st * Q + j) * 7919) % total for j in range(Q)]
         if args.mode == "allpairs":
             if block is not None:
                 # double-buffered exchange: this block's queries were issued during the previous step (or are issued now, on the
-                # first one); the NEXT block's broadcasts go out before this block is scored and run underneath it
+                # first one); the NEXT block's all-gathers go out before this block is scored and run underneath it
                 cur, nxt = st % 2, (st + 1) % 2
                 if pending[cur] is None:
-                    pending[cur] = block.begin(qg, base=cur * Q)
+                    pending[cur] = block.begin_packed(block_first(st), qpr, base=cur * Q)
                 block.finish(pending[cur], Q, base=cur * Q)
                 pending[cur] = None
-                pending[nxt] = block.begin([(((st + 1) * Q + j) * 7919) % total for j in range(Q)], base=nxt * Q)
+                pending[nxt] = block.begin_packed(block_first(st + 1), qpr, base=nxt * Q)
                 block.score(Q, base=cur * Q)
             else:
-                api.score_multi(ctx, feat, hs, None, hs, np.array(qg, dtype=np.uint32), m=M, want=("close",))
+                qs = np.array([((st * Q + j) * 7919) % M for j in range(Q)], dtype=np.uint32)
+                api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",))
             tiles_ms.append(ctx.last_kernel_ms()[0])
             launches.append(ctx.last_kernel_launches())
         else:
-            for g in qg:
+            for j in range(Q):
+                g = ((st * Q + j) * 7919) % n_total
                 if sharded is not None:
                     sharded.get_close(g)
                 else:
@@ -287,11 +315,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    pairs = args.steps * args.queries * M * world
+    pairs = args.steps * Q * n_total
     esz = args.dtype // 8
     # 1 x M streaming = 4^k*sizeof(T) bytes per scored pair. Q x M: the library reports which kernel ran and how
     # many queries ONE HBM read of a candidate tile served in it (16 for the digest kernel: one workgroup scores 16 queries
     # per tile it fetches) -> algorithmic bytes of a launch = candidates x histogram bytes x ceil(Q / that) + the query tiles.
+    # Per-rank figures (rank 0's shard: M candidates).
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
     if kernel.endswith("no emd>"):         # count-only form of the digest kernel: the prefix half of each tile is not fetched
@@ -309,28 +338,35 @@ def main():
     # one timed call may be several launches of the streaming kernel (candidate chunks): report per launch
     alg_bytes = per_call * len(tiles_ms) // n_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    config_key = "nseq=%d,k=%d,dtype=%d,queries=%d,mode=%s,kernel=%s" % (M, args.k, args.dtype, Q, args.mode, kernel)
+    config_key = "nseq=%d,len=%d,k=%d,dtype=%d,queries=%d,mode=%s,kernel=%s" % (M, args.length, args.k, args.dtype, Q, args.mode, kernel)
+    if args.weights:
+        config_key += ",weights=" + os.path.basename(args.weights)
     if args.layout == "sparse":
         config_key += ",layout=sparse"
     traffic = pmc_traffic(kernel.split("<")[0], config_key)
+    per_gpu = "%d per GPU" % args.nseq if args.scaling == "weak" else "%d in total (%d on rank 0)" % (n_total, M)
     line = {
         "metric": "sequence-pairs/sec identity-scored (k=%d, 1kb seqs)" % args.k,
         "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u%d" % args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg2: %d x %d bp synthetic sequences per GPU, k=%d, datatype=%d, resident in HBM; step = %d query histograms x all "
-                               "resident histograms (9 fast features + 4-combo GLM + close flag per pair), mode %s" % (M, args.length, args.k, args.dtype, Q, args.mode),
-                   "pairs_per_step": args.queries * M * world, "pairs_timed": args.queries * M * world * args.steps,
-                   "projected_seconds_full_matrix": round(float(M * world) ** 2 / (pairs / dt), 1), "hist_bytes": hist_bytes if args.layout == "sparse" else (4 ** args.k) * esz, "layout": args.layout, "hbm_resident_gib": hs.nbytes() / 2 ** 30,
+        "config": {"workload": "cfg2: %d x %d bp synthetic sequences, %s, k=%d, datatype=%d, resident in HBM; step = %d query histograms x all "
+                               "histograms (9 fast features + 4-combo GLM + close flag per pair), mode %s" % (n_total, args.length, per_gpu, args.k, args.dtype, Q, args.mode),
+                   "pairs_per_step": Q * n_total, "pairs_timed": pairs,
+                   "projected_seconds_full_matrix": round(float(n_total) ** 2 / (pairs / dt), 1), "hist_bytes": hist_bytes if args.layout == "sparse" else (4 ** args.k) * esz,
+                   "layout": args.layout, "hbm_resident_gib": hs.nbytes() / 2 ** 30,
                    "build_seconds": round(build_s, 2),
                    "hist_build": {"seq_per_s": round(build_dev_s["median_chunk"]), "GBps_written": round(build_dev_s["median_chunk"] * (4 ** args.k) * esz / 1e9, 1),
                                   "seq_per_s_all_chunks": round(build_dev_s["all"]),
-                                  "note": "msc_hist_build_packed only (2-bit bases over PCIe + build kernel): a 20000-sequence chunk rebuilt in place back to "
+                                  "note": "msc_hist_build_packed only (2-bit bases over PCIe + build kernel): the last chunk rebuilt in place back to "
                                           "back; all_chunks = the chunks as first built, each after ~1 s of host-side sequence generation on an idle GPU; "
-                                          "untimed setup"}, "sharding": "sequence blocks, query broadcast + per-query count all-gather (RCCL)" if world > 1 else "single GPU",
+                                          "untimed setup"},
+                   "sharding": ("sequence blocks of %d, block-cyclic; per step 2 all-gathers assemble the query block (RCCL), per-query close counts all-gathered" % BLOCK)
+                               if world > 1 else "single GPU",
                    "queries_per_candidate_read": qtile},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch},
+                     "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
+                     "candidates_per_launch": M, "profile_key": config_key},
     }
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:

@@ -252,7 +252,9 @@ int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff,
               int64_t current, int64_t begin, int64_t last, int64_t* best_out);
 
 /* Predictor::close + similarity for one query against m database entries (fastcar/FC_Runner.cpp:426-471 work()):
- * close_out[i] = p_close (classification block), sim_out[i] = p_predict (regression block, clamped to [0,1]). */
+ * close_out[i] = p_close (classification block), sim_out[i] = p_predict (regression block, clamped to [0,1]).
+ * work() follows Predictor::get_mode() (:432,446-458): cls == NULL (a `mode: 2` weights file) makes every entry close,
+ * reg == NULL (a `mode: 1` file, what `meshclust2 --dump` writes) makes every similarity 1. Not both NULL. */
 int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg,
                const msc_hist_set* db, const uint32_t* db_slots, uint64_t m,
                const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_out, double* sim_out);

@@ -361,24 +361,32 @@ def mean_nearest(ctx, points, member_slots, m=None, want_mean=False):
 
 
 class Predictor:
-    """Predictor::close / similarity (predict/Predictor.cpp:255-333) for one query against a database."""
+    """Predictor::close / similarity (predict/Predictor.cpp:255-333) for one query against a database. Like fastcar's work()
+    (fastcar/FC_Runner.cpp:432,446-458) it follows the weights file's mode: no classification block -> every entry is close,
+    no regression block -> every similarity is 1."""
 
     def __init__(self, ctx, cls_feat, reg_feat=None):
         self.ctx, self.cls, self.reg = ctx, cls_feat, reg_feat
 
     @classmethod
-    def from_file(cls, ctx, path):
-        c = Feature.from_file(ctx, path, 0)
-        try:
-            r = Feature.from_file(ctx, path, 1)
-        except MscError:
-            r = None
+    def from_text(cls, ctx, text):
+        mode = 0
+        for ln in text.splitlines():
+            if ln.startswith("mode:"):
+                mode = int(ln.split()[1])
+                break
+        c = Feature.from_text(ctx, text, 0) if mode & 1 else None
+        r = Feature.from_text(ctx, text, 1) if mode & 2 else None
         return cls(ctx, c, r)
+
+    @classmethod
+    def from_file(cls, ctx, path):
+        return cls.from_text(ctx, open(path).read())
 
     def search(self, db, db_slots, qset, q_slot, m=None):
         sl, m = _slots(db_slots, m)
         close = np.zeros(max(m, 1), dtype=np.uint8)
-        sim = np.zeros(max(m, 1)) if self.reg is not None else None
-        self.ctx.check(self.ctx.lib.msc_search(self.ctx.h, self.cls.h, self.reg.h if self.reg else None, db.h, _ptr(sl), m, qset.h, q_slot,
-                                               _ptr(close), _ptr(sim)))
-        return close[:m], (sim[:m] if sim is not None else None)
+        sim = np.zeros(max(m, 1))
+        self.ctx.check(self.ctx.lib.msc_search(self.ctx.h, self.cls.h if self.cls else None, self.reg.h if self.reg else None, db.h, _ptr(sl), m,
+                                               qset.h, q_slot, _ptr(close), _ptr(sim)))
+        return close[:m], sim[:m]

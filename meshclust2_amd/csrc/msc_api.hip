@@ -98,6 +98,10 @@ static int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
 	return code;
 }
 
+// the same for the other host translation units (msc_train.hip)
+int msc_set_error(msc_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
+bool msc_ctx_owns(const msc_ctx* ctx, const msc_hist_set* set) { return ctx && set && set->ctx == ctx; }
+
 #define HIP_TRY(ctx, expr)                                                                                 \
 	do {                                                                                                   \
 		hipError_t e_ = (expr);                                                                            \
@@ -490,9 +494,12 @@ static int build_sparse_sort(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slo
 	}
 	HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + first_slot * set->scalar_stride, set->scalar_stride, sc.data(), sizeof(MscSlotScalars), sizeof(MscSlotScalars), n_seqs,
 	                              hipMemcpyHostToDevice, ctx->stream));
-	const size_t packed_bytes = (size_t)((n_bases + 3) / 4), padded_bytes = (packed_bytes + 3) / 4 * 4 + 8;
+	// + 12 zero bytes behind the last whole word (the kernel's 64-bit window never reads past the end); the memset also clears the
+	// last word itself before the copy fills it. A batch without a single base (n_bases == 0) is just the 12 zero bytes.
+	const size_t packed_bytes = (size_t)((n_bases + 3) / 4), round4 = (packed_bytes + 3) / 4 * 4, padded_bytes = round4 + 12;
+	const size_t tail_off = round4 >= 4 ? round4 - 4 : 0;
 	if ((r = ensure(ctx, ctx->packed, padded_bytes))) return r;
-	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + (padded_bytes - 12), 0, 12, ctx->stream));
+	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + tail_off, 0, padded_bytes - tail_off, ctx->stream));
 	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
 	if ((r = ensure(ctx, ctx->seg_start, std::max<size_t>(n_segs, 1) * sizeof(uint64_t)))) return r;
 	if ((r = ensure(ctx, ctx->kmer_off, (n_segs + 1) * sizeof(uint64_t)))) return r;
@@ -632,12 +639,15 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		                              sizeof(MscSlotScalars), n_seqs, hipMemcpyHostToDevice, ctx->stream));
 	}
 
-	// packed stream (+8 bytes so the kernel's 64-bit window never reads past the end)
+	// packed stream + 12 zero bytes behind its last whole word (the kernel's 64-bit window never reads past the end); the memset
+	// also clears that last word before the copy fills it. n_bases == 0 (every sequence of the batch empty, or nothing left of a
+	// soft-masked chunk after the strip) leaves just the 12 zero bytes.
 	const size_t packed_bytes = (size_t)((n_bases + 3) / 4);
-	const size_t padded_bytes = (packed_bytes + 3) / 4 * 4 + 8;
+	const size_t round4 = (packed_bytes + 3) / 4 * 4, padded_bytes = round4 + 12;
+	const size_t tail_off = round4 >= 4 ? round4 - 4 : 0;
 	int r;
 	if ((r = ensure(ctx, ctx->packed, padded_bytes)) != MSC_OK) return r;
-	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + (padded_bytes - 12), 0, 12, ctx->stream));
+	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + tail_off, 0, padded_bytes - tail_off, ctx->stream));
 	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
 	if (n_segs) {
 		if ((r = ensure(ctx, ctx->seg_seq, n_segs * sizeof(uint32_t))) != MSC_OK) return r;
@@ -1180,7 +1190,10 @@ struct ScoreRequest {
 // integer range of the fast streaming kernels (pair_features.hip header); outside it the 64-bit kernel runs
 bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) {
 	const uint64_t mc = std::max(a->max_count, b->max_count), ms = std::max(a->max_sum, b->max_sum);
-	return mc > kNarrowMaxCount || ms > kNarrowMaxSum;
+	// a lane adds the |prefix difference| of its R bins of a tile in 32 bits; a prefix difference is at most the larger excess
+	// (k-mer) total, so R * excess must stay below 2^32 (only sequences of >= 2^26 k-mers can break it)
+	const uint64_t excess = ms > a->L.nbins ? ms - a->L.nbins : 0;
+	return mc > kNarrowMaxCount || ms > kNarrowMaxSum || (uint64_t)a->L.R * excess >= (1ull << 32);
 }
 
 int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* qset, uint64_t q_slot, const uint32_t* slots, uint64_t m) {
@@ -1230,6 +1243,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	static const bool no_sp_mp = getenv("MSC_SPARSE_NO_MP") != nullptr;
 	const bool sp_mp = sp && !sp_lds && !no_sp_mp && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 &&
 	                   (uint64_t)rq.qset->hdr_host[rq.q_slot].nnz + cs->max_nnz <= msc_sparse_mp_max_entries();
+	if (sp) ctx->last_kernel = sp_lds ? "k_pair_sparse_lds" : sp_mp ? "k_pair_sparse_mp" : "k_pair_sparse";
 	const uint32_t PS = sp ? ((sp_lds || sp_mp) ? 1 : MSC_SPARSE_SUB) : L.S;          // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
@@ -1450,7 +1464,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ctx->tiles_ms_accum = 0.f;
 		ctx->tiles_launches = 0;
 		ctx->have_timing = false;
-		ctx->last_kernel = "k_pair_sparse";
+		ctx->last_kernel = "k_pair_sparse_mp";
 		ctx->last_query_tile = 1;
 		ctx->last_partial_stride = 1;
 		if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
@@ -1739,13 +1753,21 @@ extern "C" int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff, co
 
 extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg, const msc_hist_set* db, const uint32_t* db_slots,
                           uint64_t m, const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_out, double* sim_out) {
-	if (!ctx || !cls || cls->ctx != ctx) return MSC_ERR_INVALID_ARG;
-	// pred->close(pts[i], query) then pred->similarity(pts[i], query): fastcar/FC_Runner.cpp:449-455
-	ScoreRequest a;
-	a.model = cls; a.cands = db; a.cand_slots = db_slots; a.m = m; a.qset = qset; a.q_slot = q_slot; a.order = MSC_ORDER_CAND_FIRST;
-	a.flags_out = close_out;
-	int r = run_score(ctx, a);
-	if (r) return r;
+	if (!ctx || (cls && cls->ctx != ctx) || (reg && reg->ctx != ctx)) return MSC_ERR_INVALID_ARG;
+	if (!cls && !reg) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_search needs a classification or a regression model");
+	// work() follows pred->get_mode() (fastcar/FC_Runner.cpp:432,446-458): without a classification block every pair of the
+	// window counts as close, without a regression block the similarity of a close pair is 1
+	int r;
+	if (cls) {
+		// pred->close(pts[i], query) then pred->similarity(pts[i], query): fastcar/FC_Runner.cpp:449-455
+		ScoreRequest a;
+		a.model = cls; a.cands = db; a.cand_slots = db_slots; a.m = m; a.qset = qset; a.q_slot = q_slot; a.order = MSC_ORDER_CAND_FIRST;
+		a.flags_out = close_out;
+		if ((r = run_score(ctx, a))) return r;
+	} else {
+		if ((r = validate_pair(ctx, db, qset, q_slot, db_slots, m))) return r;
+		if (close_out) memset(close_out, 1, m);
+	}
 	if (reg && sim_out) {
 		ScoreRequest b;
 		b.model = reg; b.cands = db; b.cand_slots = db_slots; b.m = m; b.qset = qset; b.q_slot = q_slot; b.order = MSC_ORDER_CAND_FIRST;
@@ -1754,6 +1776,8 @@ extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* r
 		for (uint64_t i = 0; i < m; i++) {           // p_predict clamps to [0,1], predict/Predictor.cpp:293-298
 			if (sim_out[i] < 0) sim_out[i] = 0; else if (sim_out[i] > 1) sim_out[i] = 1;
 		}
+	} else if (sim_out) {
+		for (uint64_t i = 0; i < m; i++) sim_out[i] = 1.0;
 	}
 	return MSC_OK;
 }

@@ -16,7 +16,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)      // hipcc builds the kernels; plain g++ (host drivers, tests) sees the same structs
 #define MSC_HD __host__ __device__ __forceinline__
 #else
 #define MSC_HD inline

@@ -29,6 +29,8 @@
 #include "msc_internal.h"
 
 int msc_feat_is_sim(uint64_t f);        // msc_api.hip
+int msc_set_error(msc_ctx* ctx, int code, const char* msg);
+bool msc_ctx_owns(const msc_ctx* ctx, const msc_hist_set* set);
 
 namespace {
 
@@ -208,9 +210,15 @@ std::string fmt15(double v) {
 extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint32_t* first_slots, const uint32_t* second_slots, const double* vals,
                                uint64_t n_train, uint64_t n_test, uint64_t feat_flags, int min_feat, int max_feat, double id, char* text_out, size_t cap,
                                double* train_acc, double* test_acc) {
-	if (!ctx || !pts || !first_slots || !second_slots || !vals || !text_out || n_train == 0 || n_test == 0 || min_feat < 1 || max_feat < min_feat)
-		return MSC_ERR_INVALID_ARG;
-	if (feat_flags == 0 || (feat_flags & ~(uint64_t)MSC_FEAT_SLOW)) return MSC_ERR_UNSUPPORTED;
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	if (!pts || !first_slots || !second_slots || !vals || !text_out) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: NULL argument");
+	if (!msc_ctx_owns(ctx, pts)) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: the histogram set belongs to another context");
+	if (n_train == 0 || n_test == 0) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: needs training and testing pairs");
+	if (min_feat < 1 || max_feat < min_feat) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: need 1 <= min_feat <= max_feat");
+	// a model msc_model_create could not load afterwards is refused before any work is done
+	if (max_feat > MSC_MAX_COMBOS) return msc_set_error(ctx, MSC_ERR_UNSUPPORTED, "msc_train_class: max_feat exceeds MSC_MAX_COMBOS (8)");
+	if (feat_flags == 0 || (feat_flags & ~(uint64_t)MSC_FEAT_SLOW))
+		return msc_set_error(ctx, MSC_ERR_UNSUPPORTED, "msc_train_class: feat_flags must be a non-empty subset of MSC_FEAT_SLOW");
 	const size_t n = (size_t)(n_train + n_test);
 	Table t;
 	t.n_train = (size_t)n_train;
@@ -241,14 +249,15 @@ extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint
 			if (raw[i][s] < t.mins[s]) t.mins[s] = raw[i][s];
 			if (raw[i][s] > t.maxs[s]) t.maxs[s] = raw[i][s];
 		}
-		if (fabs(t.maxs[s] - t.mins[s]) <= 0.000000001 || std::isinf(t.maxs[s]) || std::isinf(t.mins[s])) return MSC_ERR_NAN;      // the reference throws
+		if (fabs(t.maxs[s] - t.mins[s]) <= 0.000000001 || std::isinf(t.maxs[s]) || std::isinf(t.mins[s]))      // the reference throws
+			return msc_set_error(ctx, MSC_ERR_NAN, "msc_train_class: a statistic is constant (or infinite) over the training pairs (Feature::normalize throws)");
 	}
 	t.norm.assign(n, std::vector<double>(ns));
 	t.label.resize(n);
 	for (size_t i = 0; i < n; i++) {
 		for (size_t s = 0; s < ns; s++) {
 			const double v = (raw[i][s] - t.mins[s]) / (t.maxs[s] - t.mins[s]);      // normalize_cache, :137-154
-			if (std::isnan(v)) return MSC_ERR_NAN;
+			if (std::isnan(v)) return msc_set_error(ctx, MSC_ERR_NAN, "msc_train_class: NaN after normalisation");
 			t.norm[i][s] = t.is_sim[s] ? v : 1 - v;
 		}
 		t.label[i] = vals[i] >= id ? 1 : -1;      // generate_feat_mat, predict/FeatureSelector.cpp:26-28
@@ -283,7 +292,7 @@ extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint
 		if (acc > best_acc && (long)cur.size() >= min_feat && (long)cur.size() <= max_feat) { best = cur; best_acc = acc; last_best_changed = iteration; }
 		evaluate(t, children_of(cur, all, closed, open), open, heap);
 	}
-	if (best.empty()) return MSC_ERR_INVALID_ARG;
+	if (best.empty()) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: the search found no model with min_feat..max_feat combos");
 	const Mat xtr = feature_matrix(t, best, 0, t.n_train);
 	const std::vector<double> ytr(t.label.begin(), t.label.begin() + (long)t.n_train);
 	const std::vector<double> w = glm_train(xtr, ytr);
@@ -307,7 +316,7 @@ extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint
 		const int i = index_of(t, f);
 		text += std::to_string((unsigned long long)f) + " " + fmt15(t.mins[(size_t)i]) + " " + fmt15(t.maxs[(size_t)i]) + "\n";
 	}
-	if (text.size() + 1 > cap) return MSC_ERR_INVALID_ARG;
+	if (text.size() + 1 > cap) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: text_out is too small for the weights file");
 	memcpy(text_out, text.c_str(), text.size() + 1);
 	return MSC_OK;
 }

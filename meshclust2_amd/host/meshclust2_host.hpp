@@ -11,6 +11,7 @@
 // parameter. Header-only; link against libmeshclust2_hip.so.
 #pragma once
 #include <cstdint>
+#include <fstream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -160,33 +161,48 @@ private:
 	double cutoff_;
 };
 
-// Predictor<T>::close + similarity for one query against a database chunk (fastcar/FC_Runner.cpp:426-471)
+// Predictor<T>::close + similarity for one query against a database chunk (fastcar/FC_Runner.cpp:426-471). Like work(), it
+// follows the file's mode (predict/Predictor.h:20-21): a `mode: 1` file (classification only: what meshclust2 --dump and
+// msc_train_class write) gives similarity 1 for every close pair, a `mode: 2` file (regression only) calls every pair close.
 class Predictor {
 public:
-	Predictor(Context& ctx, const std::string& weights_file) : ctx_(ctx), cls_(ctx, weights_file, 0), reg_(ctx, weights_file, 1) {}
+	Predictor(Context& ctx, const std::string& weights_file) : ctx_(ctx) {
+		std::ifstream in(weights_file.c_str());
+		std::string tok;
+		unsigned mode = 0;
+		while (in >> tok) if (tok == "mode:") { in >> mode; break; }
+		if (!(mode & 3)) throw Error(MSC_ERR_IO, "weights file " + weights_file + ": no `mode:` line with a classification or regression block");
+		if (mode & 1) cls_.reset(new Feature(ctx, weights_file, 0));
+		if (mode & 2) reg_.reset(new Feature(ctx, weights_file, 1));
+	}
+	uint8_t get_mode() const { return (uint8_t)((cls_ ? 1 : 0) | (reg_ ? 2 : 0)); }
 	void search(const PointSet& db, const std::vector<uint32_t>& slots, const PointSet& q, uint64_t q_slot, std::vector<uint8_t>& close,
 	            std::vector<double>& similarity) const {
 		close.resize(slots.size());
 		similarity.resize(slots.size());
-		ctx_.check(msc_search(ctx_.get(), cls_.get(), reg_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slot, close.data(), similarity.data()));
+		ctx_.check(msc_search(ctx_.get(), cls_ ? cls_->get() : nullptr, reg_ ? reg_->get() : nullptr, db.get(), slots.data(), slots.size(), q.get(), q_slot,
+		                      close.data(), similarity.data()));
 	}
 	// the same for a block of queries in ONE pass over the database window (msc_score_multi: each candidate tile fetched from HBM
 	// serves 16 queries): close[q * slots.size() + i], similarity likewise. Values are bit-identical to search() per query.
 	void search_block(const PointSet& db, const std::vector<uint32_t>& slots, const PointSet& q, const std::vector<uint32_t>& q_slots,
 	                  std::vector<uint8_t>& close, std::vector<double>& similarity) const {
 		const size_t n = slots.size() * q_slots.size();
-		close.assign(n, 0);
-		similarity.assign(n, 0.0);
+		close.assign(n, 1);
+		similarity.assign(n, 1.0);
 		if (n == 0) return;
-		ctx_.check(msc_score_multi(ctx_.get(), cls_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
-		                           nullptr, nullptr, close.data(), 0, nullptr));
-		ctx_.check(msc_score_multi(ctx_.get(), reg_.get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
-		                           similarity.data(), nullptr, nullptr, 0, nullptr));
-		for (double& v : similarity) v = v < 0 ? 0 : (v > 1 ? 1 : v);      // p_predict clamps to [0,1], predict/Predictor.cpp:293-298
+		if (cls_)
+			ctx_.check(msc_score_multi(ctx_.get(), cls_->get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
+			                           nullptr, nullptr, close.data(), 0, nullptr));
+		if (reg_) {
+			ctx_.check(msc_score_multi(ctx_.get(), reg_->get(), db.get(), slots.data(), slots.size(), q.get(), q_slots.data(), q_slots.size(), MSC_ORDER_CAND_FIRST,
+			                           similarity.data(), nullptr, nullptr, 0, nullptr));
+			for (double& v : similarity) v = v < 0 ? 0 : (v > 1 ? 1 : v);      // p_predict clamps to [0,1], predict/Predictor.cpp:293-298
+		}
 	}
 private:
 	Context& ctx_;
-	Feature cls_, reg_;
+	std::unique_ptr<Feature> cls_, reg_;
 };
 
 }  // namespace msc

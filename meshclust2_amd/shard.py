@@ -100,7 +100,9 @@ class ShardedBlockScorer:
 
     backend.query_buffers(j) / export_query(local) as above but per query buffer j; backend.import_queries(n, base);
     backend.score_block(n, base) -> close flags [n, local_count] (np.uint8) of the queries in buffers base .. base + n - 1.
-    Per block the only exchanges are the n_q query broadcasts and one all-gather of the per-query close counts.
+    Per block the only exchanges are the query payload (begin_packed: one all-gather per payload region = 2 collectives per
+    block; begin: one broadcast per query and region, for blocks whose queries are not spread evenly) and one all-gather of
+    the per-query close counts.
 
     The exchange is split so that a caller can double-buffer it: begin() only ISSUES the copies and asynchronous broadcasts of a
     block into buffers base .., finish() waits for them and registers the slots, score() runs the local pass. bench.py issues
@@ -121,6 +123,27 @@ class ShardedBlockScorer:
                 # all 2 * n_q broadcasts are issued before any is waited for: the collectives queue back to back
                 pending += [self.dist.broadcast(b, src=owner, async_op=True) for b in bufs]
         return pending
+
+    def begin_packed(self, local_first, n_per_rank, base=0):
+        """The block exchange in TWO collectives whatever the block size: every rank contributes its local slots local_first ..
+        local_first + n_per_rank - 1 (contiguous in its set, so the payload is a view, not a copy) and one all-gather per payload
+        region drops them into the contiguous query buffers base .. base + world * n_per_rank - 1 of every rank: query j of rank r
+        lands in buffer base + r * n_per_rank + j. The shape of fastcar's outer loop (fastcar/FC_Runner.cpp:585-597) turned
+        around: the database shards stay put, each step's query chunk is assembled from all of them.
+
+        backend.export_block(local_first, n) -> list of tensors [n, row_bytes] (this rank's rows)
+        backend.block_buffers(base, n_rows)  -> list of tensors [n_rows, row_bytes] the gathered rows land in"""
+        srcs = self.backend.export_block(local_first, n_per_rank)
+        dsts = self.backend.block_buffers(base, self.plan.world * n_per_rank)
+        if self.plan.world > 1:
+            return [self.dist.all_gather_into_tensor(d, s_, async_op=True) for d, s_ in zip(dsts, srcs)]
+        for d, s_ in zip(dsts, srcs):
+            d.copy_(s_)
+        return []
+
+    def packed_globals(self, local_first, n_per_rank):
+        """global indices of the queries of a packed block, in buffer order"""
+        return [self.plan.global_index(r, local_first + j) for r in range(self.plan.world) for j in range(n_per_rank)]
 
     def finish(self, pending, n, base=0):
         for w in pending:

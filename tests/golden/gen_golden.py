@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from meshclust2_amd import synth  # noqa: E402
 from oracle import ref_py  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from golden_util import training_set  # noqa: E402
+from golden_util import cfg5_set, training_set, weights_with_mode  # noqa: E402
 
 FEATS = [("manhattan", 2), ("euclidean", 3), ("normalized_vectors", 5), ("jefferey_divergence", 7), ("pearson", 9),
          ("intersection", 13), ("emd", 18), ("length_difference", 21), ("kulczynski2", 27), ("simratio", 28), ("jensen_shannon", 29)]
@@ -288,6 +288,27 @@ def make_k9_auto_clstr():
     print("wrote k9_u8.clstr")
 
 
+def make_cfg5_clstr(tag="cfg5", run_cap=900):
+    """BASELINE cfg5 at its stated parameters (k = 9, lengths log-uniform 500 .. 50 000, --feat slow, --id 0.6), scaled to 240
+    sequences: the reference CLI end to end, 1 thread, histogram type left to its own rule -> its weights.txt and its .clstr"""
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = cfg5_set(run_cap=run_cap)
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    log = run_reference_cli(fa, ["--id", "0.6", "--kmer", "9", "--feat", "slow", "--threads", "1", "--output", "out.clstr"], tmp)
+    bits = [ln for ln in log.splitlines() if "bit histograms" in ln]
+    print(tag, bits)
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_%s_k9.txt" % tag))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "%s.clstr" % tag))
+    shutil.rmtree(tmp)
+    print("wrote %s.clstr" % tag)
+
+
+def make_cfg5_u16_clstr():
+    """the same with tandem repeats of up to 3000 bases: counts pass 255 and the reference picks 16-bit histograms"""
+    make_cfg5_clstr("cfg5_u16", 3000)
+
+
 def fastcar_sets():
     db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
     q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
@@ -307,6 +328,26 @@ def make_fastcar_output():
     shutil.copy(os.path.join(tmp, "fc_out0"), os.path.join(HERE, "fastcar_k5_u16.out"))
     shutil.rmtree(tmp)
     print("wrote fastcar_k5_u16.out")
+
+
+def make_fastcar_mode_outputs():
+    """reference fastcar with a classification-only (`mode: 1`, what meshclust2 --dump writes) and a regression-only (`mode: 2`)
+    weights file: work() follows Predictor::get_mode (fastcar/FC_Runner.cpp:432,446-458)"""
+    text = open(os.path.join(HERE, "weights_k5_u16.txt")).read()
+    for mode in (1, 2):
+        tmp = tempfile.mkdtemp()
+        db, h, q, hq = fastcar_sets()
+        if mode == 2:          # every pair of the length window is written: keep the file small
+            db, h, q, hq = db[:60], h[:60], q[:8], hq[:8]
+        synth.write_fasta(os.path.join(tmp, "db.fa"), db, h)
+        synth.write_fasta(os.path.join(tmp, "q.fa"), q, hq)
+        open(os.path.join(tmp, "w.txt"), "w").write(weights_with_mode(text, mode))
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fastcar"), "db.fa", "--query", "q.fa", "--recover", "w.txt", "--output", "fc_out", "--threads", "1"],
+                       cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, check=True)
+        shutil.copy(os.path.join(tmp, "fc_out0"), os.path.join(HERE, "fastcar_k5_u16_mode%d.out" % mode))
+        shutil.rmtree(tmp)
+        print("wrote fastcar_k5_u16_mode%d.out" % mode)
 
 
 def make_training(name, seed, k, dtype, feat_flags, min_feat, max_feat, ident, n_templates=40, per_template=12, length=1000):
@@ -335,6 +376,10 @@ NASTY = [
 if __name__ == "__main__":
     if not ref_py.available():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` (needs /root/reference)")
+    if len(sys.argv) > 1:          # regenerate single fixtures: python gen_golden.py make_cfg5_clstr ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     make_kat()
     make_training("train_k5_u16.json", 31, 5, 16, FAST_FLAGS, 4, 4, 0.9)
     make_training("train_k7_u8_slow.json", 32, 7, 8, SLOW_FLAGS, 2, 3, 0.8, n_templates=30, per_template=10, length=600)
@@ -347,6 +392,9 @@ if __name__ == "__main__":
     make_weights("weights_k5_u16_slow.txt", 20260001, 1000, 1000, 5, 16, REG_BLOCK_K5_SLOW, extra_args=["--feat", "slow"])
     make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
     make_fastcar_output()
+    make_fastcar_mode_outputs()
+    make_cfg5_clstr()
+    make_cfg5_u16_clstr()
     make_k8_clstr()
     make_single_file_clstr()
     make_vectors("vectors_k5_u16.npz", "weights_k5_u16.txt", 11, 18, 1000, 5, 16, extra=NASTY)

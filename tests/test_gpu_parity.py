@@ -424,6 +424,34 @@ def test_fastcar_search_reproduces_reference_output(tmp_path):
     assert got == exp, "fastcar output differs (%d vs %d bytes)" % (len(got), len(exp))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fastcar_follows_the_weights_file_mode(tmp_path, mode):
+    """work() follows Predictor::get_mode (fastcar/FC_Runner.cpp:432,446-458): a classification-only file (`mode: 1`, what
+    `meshclust2 --dump` / msc_train_class write) prints 100 for every close pair, a regression-only one (`mode: 2`) treats every
+    pair of the length window as close. Fixtures: the reference's fastcar --recover on the same files."""
+    import os
+    import subprocess
+    from golden_util import weights_with_mode
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_fastcar")
+    db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
+    q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
+    q = [x[:len(x) - 7] for x in q]
+    hq = [x.replace(">seq", ">qry") for x in hq]
+    if mode == 2:
+        db, h, q, hq = db[:60], h[:60], q[:8], hq[:8]
+    synth.write_fasta(str(tmp_path / "db.fa"), db, h)
+    synth.write_fasta(str(tmp_path / "q.fa"), q, hq)
+    open(str(tmp_path / "w.txt"), "w").write(weights_with_mode(weights_text("weights_k5_u16.txt"), mode))
+    exp = open(os.path.join(root, "tests", "golden", "fastcar_k5_u16_mode%d.out" % mode), "rb").read()
+    for qb in ("16", "1"):
+        r = subprocess.run([exe, "db.fa", "--query", "q.fa", "--recover", "w.txt", "--output", "fc_out", "--query-block", qb],
+                           cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        got = open(str(tmp_path / "fc_out0"), "rb").read()
+        assert got == exp, "fastcar output differs (%d vs %d bytes)" % (len(got), len(exp))
+
+
 def test_cluster_driver_single_file_mode(tmp_path):
     """--single-file (each FASTA file is one sequence, records joined by 50 N): 48 three-record files,
     .clstr byte-identical to the reference CLI's."""
@@ -528,6 +556,130 @@ def test_sparse_k13_against_the_oracle(ctx, oracle):
                 assert col == pytest.approx(exp, rel=1e-7), (name, c)
             else:
                 assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c)
+    for h in oh:
+        oracle.lib().orc_hist_free(h)
+
+
+CFG4_WEIGHTS = """k: 13
+mode: 1
+max_features: 4
+ID: 0.9
+Datatype: uint64_t
+feature_set: 941892268
+
+n_combos: 4
+-0.35
+0 8192 1.9
+1 537133056 -0.8
+3 268435464 0.45
+2 2097156 -0.6
+
+n_singles: 7
+8192 0.9995 1
+536870912 0 0.0002
+262144 0 400000000000
+268435456 0.5 1
+8 0 600
+2097152 0 4000
+4 0 90000
+"""
+
+
+def _cfg4_sequences():
+    """BASELINE cfg4's shape: 20 kb sequences at k = 13: three relatives (3 % substitutions + indels), one stranger, one relative
+    cut to 17 kb (the length window of get_close matters) -- and, for the wide route, a relative carrying a 70 000-base
+    homopolymer run: ONE bin of 69 988 > 2^16, which the 32-bit merge-path kernel cannot hold."""
+    fam, _ = synth.families(4413, 3, 20000, family=3)
+    other, _ = synth.families(4414, 1, 20000, family=1)
+    seqs = list(fam) + list(other) + [fam[1][:17000]]
+    mono = fam[2][:9000] + b"A" * 70000 + fam[2][9000:]
+    return seqs, mono
+
+
+def _divergence_longdouble(name, a, b):
+    """jefferey_divergence / jensen_shannon (predict/Feature.cpp:1231-1263,984-1009) of two oracle histograms in extended
+    precision: the bins where either count differs from the pseudocount one by one, the (1, 1) term times its count"""
+    p, q = a.array(), b.array()
+    ld = np.longdouble
+    mp_, mq_ = ld(int(a.mag)), ld(int(b.mag))
+    idx = np.nonzero((p != 1) | (q != 1))[0]
+
+    def term(pp, pq):
+        if name == "jefferey_divergence":
+            return (pp - pq) * np.log(pp / pq)
+        avg = (pp + pq) / 2
+        return (pp * np.log(pp / avg) + pq * np.log(pq / avg)) / 2
+    total = np.sum(term(p[idx].astype(ld) / mp_, q[idx].astype(ld) / mq_)) + (p.size - idx.size) * term(ld(1) / mp_, ld(1) / mq_)
+    return float(total)
+
+
+@pytest.mark.parametrize("route", ["k_pair_sparse_mp", "k_pair_sparse"])
+def test_cfg4_k13_u64_20kb_against_the_oracle(ctx, oracle, route):
+    """BASELINE.json configs[3] at its stated parameters: k = 13, datatype = 64, 20 kb sequences, sparse layout (a dense k = 13
+    uint64_t histogram is 512 MiB: SURVEY Q11; the oracle holds a handful of them on the host). Builders, all 11 statistics in
+    both argument orders, one Trainer::get_close window, filter and the mean / closest step against oracle.hist(..., 13, 64).
+    route k_pair_sparse_mp: counts < 2^16, the merge-path kernel; route k_pair_sparse: one sequence with a 70 000-base
+    homopolymer run forces the 64-bit lane-per-sub-range kernel (clutil/Loader.cpp:42-86, predict/Feature.cpp:984-1009,1231-1263)."""
+    k, dtype = 13, 64
+    seqs, mono = _cfg4_sequences()
+    if route == "k_pair_sparse":
+        seqs = seqs[:2] + [mono] + seqs[3:4]
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n + 1, sparse_entries=sum(len(s) for s in seqs) + 4096)
+    hs.build(seqs)
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    for i in range(n):
+        inf = hs.info(i)
+        assert (inf["mag"], inf["length"], inf["one_mers"], inf["overflow"]) == (oh[i].mag, oh[i].length, list(oh[i].one_mers), oh[i].overflow), i
+        # clutil/Loader.cpp:158-171 adds 67 M FP64 squares one by one: its own rounding error is ~1e-10 relative at this size; the
+        # GPU value is a closed form over exact integer moments (the k <= 11 tests hold 1e-10)
+        assert inf["stddev"] == pytest.approx(oh[i].stddev, rel=1e-8)
+        assert np.array_equal(hs.download(i), oh[i].array()), i
+    if route == "k_pair_sparse":
+        assert hs.info(2)["max_count"] >= 1 << 16
+    cands = np.arange(n, dtype=np.uint32)
+    for q in ((0, n - 1) if route == "k_pair_sparse_mp" else (2, 0)):
+        for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+            raw = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, order)
+            assert ctx.last_kernel_info()[0] == route
+            for c in range(n):
+                a, b = (oh[c], oh[q]) if order == api.ORDER_CAND_FIRST else (oh[q], oh[c])
+                for col, (name, bit) in zip(raw[c], FEATS):
+                    exp = oracle.raw_feature(1 << bit, a, b)
+                    if name in EXACT and name != "kulczynski2":
+                        assert col == exp, (name, c, q, order)
+                    elif name == "pearson":
+                        # 67 M FP64 terms added one by one: the reference's own value is only good to ~1e-9 here (see the k13/u8 test)
+                        assert col == pytest.approx(exp, rel=1e-7), (name, c, q)
+                    elif name in ("jefferey_divergence", "jensen_shannon"):
+                        # the same for the two divergences: the reference adds 67 M terms (almost all the tiny (1, 1) term) one by
+                        # one and its sum is 1e-9 off the exact value; the GPU adds the few thousand other terms and multiplies the
+                        # (1, 1) term by its count. Held to the reference at 1e-7 (the north-star bar is 1e-5) and to an
+                        # extended-precision evaluation of the same formula at 1e-12.
+                        assert col == pytest.approx(exp, rel=1e-7, abs=1e-13), (name, c, q, order)
+                        assert col == pytest.approx(_divergence_longdouble(name, a, b), rel=1e-12, abs=1e-18), (name, c, q, order)
+                    else:
+                        assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c, q, order)
+    feat = api.Feature.from_text(ctx, CFG4_WEIGHTS, 0)
+    pred = oracle.predictor(CFG4_WEIGHTS)
+    for cutoff in (0.9, 0.6):
+        trn = api.Trainer(ctx, feat, cutoff)
+        for q in range(n):
+            w = np.array([c for c in range(n) if c != q], dtype=np.uint32)
+            flags, bp, bs, im = trn.get_close(hs, w, hs, q)
+            of, obp, obs, oim = oracle.get_close(pred, cutoff, oh[q], [oh[c] for c in w])
+            assert np.array_equal(flags, of) and (bp, im) == (obp, oim), (cutoff, q)
+            assert bs == pytest.approx(obs, rel=1e-9), (cutoff, q)
+            assert np.array_equal(trn.filter(hs, q, hs, w), oracle.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), (cutoff, q)
+    r = feat.compute(hs, cands, hs, 1)
+    for c in range(n):
+        s_, _, wsum = oracle.score(pred.cls, oh[c], oh[1])
+        assert np.allclose(r["singles"][c], s_, rtol=1e-7, atol=1e-10) and r["sum"][c] == pytest.approx(wsum, rel=1e-7, abs=1e-9), c
+    if route == "k_pair_sparse_mp":
+        mem = np.array([0, 1, 2, 4], dtype=np.uint32)
+        pos, d, _ = api.mean_nearest(ctx, hs, mem)
+        _, od, opos = oracle.mean_nearest([oh[i] for i in mem])
+        assert pos == opos and np.allclose(d, od, rtol=1e-12, atol=0)
     for h in oh:
         oracle.lib().orc_hist_free(h)
 
@@ -810,6 +962,49 @@ def test_cluster_driver_mixed_lengths_slow_features(tmp_path):
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
 
 
+def _same_clusters(a, b):
+    """two .clstr texts hold the same clusters (as sets of member headers), whatever the member / cluster order and the star"""
+    def sets(text):
+        out, cur = [], None
+        for ln in text.decode().splitlines():
+            if ln.startswith(">Cluster"):
+                cur = set()
+                out.append(cur)
+            else:
+                cur.add(ln.split(">")[1].split("...")[0])
+        return sorted(sorted(c) for c in out)
+    return sets(a) == sets(b)
+
+
+@pytest.mark.parametrize("tag,run_cap,bits", [("cfg5", 900, 8), ("cfg5_u16", 3000, 16)])
+@pytest.mark.parametrize("extra", [[], ["--sparse"], ["--serial-update"]])
+def test_cfg5_mixed_lengths_slow_features_at_k9(tmp_path, tag, run_cap, bits, extra):
+    """BASELINE.json configs[4] at its stated parameters, scaled to 240 sequences: k = 9, lengths log-uniform 500 .. 50 000
+    (sequences on both sides of the 32 768-k-mer limit of the sort builder; tandem repeats push counts past the 8/16-entry
+    divergence tables, in the second set past 255 so the reference picks 16-bit histograms), `--feat slow` (the model the
+    reference trained uses jensen_shannon), `--id 0.6`. The fixture is the reference CLI's own .clstr; the driver, fed the model
+    that run trained (and the histogram type recorded in it), reproduces it from the dense layout, the sparse layout and the
+    centre-by-centre update order (predict/Feature.cpp:984-1009,1231-1263; clutil/Loader.cpp:42-86)."""
+    import os
+    import subprocess
+    from golden_util import cfg5_set
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    seqs, hdrs = cfg5_set(run_cap=run_cap)
+    assert min(len(s_) for s_ in seqs) < 600 and max(len(s_) for s_ in seqs) > 40000
+    fa = str(tmp_path / "cfg5.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_%s_k9.txt" % tag), "--id", "0.6",
+                        "--kmer", "9", "--output", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    log = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, log[-2000:]
+    assert "Datatype: uint%d_t" % bits in weights_text("weights_%s_k9.txt" % tag)      # the type the reference chose for this set
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "%s.clstr" % tag), "rb").read()
+    assert _same_clusters(got, exp), "clusters differ"
+    assert got == exp, "same clusters, but the CLSTR bytes differ: %d vs %d bytes" % (len(got), len(exp))
+
+
 @pytest.mark.parametrize("extra", [[], ["--sparse"]])
 def test_cluster_driver_k9_uint8(tmp_path, extra):
     """BASELINE cfg3 in small: k = 9 with the histogram type the reference CLI chose by itself (uint8_t, 256 KiB histograms); the
@@ -860,6 +1055,33 @@ def test_degenerate_inputs(ctx, oracle):
     # a zero-length candidate never reaches length_difference in get_close: the length window drops it first (cluster/Trainer.cpp:39-48)
     flags, bp, bs, im = trn.get_close(hs, np.array([13], dtype=np.uint32), hs, 0)
     assert list(flags) == [0] and bp == -1 and im
+
+
+@pytest.mark.parametrize("k,dtype,sparse", [(5, 16, False), (9, 32, False), (9, 32, True), (11, 8, True)])
+def test_batches_without_a_single_base(ctx, oracle, k, dtype, sparse):
+    """A batch in which no sequence contributes a base -- all records empty, or (fastcar's string overload, strip = 1,
+    clutil/Loader.cpp:115-121) a soft-masked lower-case chunk of which the strip leaves nothing: the packed stream is then
+    0 bytes long. The slots must come out as the reference's points do (every bin the pseudocount), dense and sparse; a later
+    ordinary batch into the same set still builds correctly."""
+    hs = api.HistogramSet(ctx, k, dtype, 6, sparse_entries=5000 if sparse else 0)
+    hs.build([b"", b"", b""])
+    lower = [b"acgtacgtacgtnnnnacgtacgatcgatcgatcagctacgatcgactagc" * 4, b"nnnnnnnn", b"acgt"]
+    hs.build(lower, first_slot=3, strip=True)
+    for i, s_ in enumerate([b"", b"", b""] + lower):
+        oh = oracle.hist(s_, k, dtype, strip=i >= 3)
+        inf = hs.info(i)
+        assert (inf["mag"], inf["length"], inf["one_mers"], inf["overflow"]) == (oh.mag, oh.length, list(oh.one_mers), oh.overflow), i
+        if k <= 9:
+            assert np.array_equal(hs.download(i), oh.array()), i
+        if sparse:
+            assert hs.entries(i) == 0
+    seqs, _ = synth.families(5150 + k, 3, 700, family=3)
+    hs.build(seqs, first_slot=1)
+    for i, s_ in enumerate(seqs):
+        oh = oracle.hist(s_, k, dtype)
+        assert hs.info(1 + i)["mag"] == oh.mag
+        if k <= 9:
+            assert np.array_equal(hs.download(1 + i), oh.array())
 
 
 @pytest.mark.parametrize("dtype,k,wts", [(16, 5, "weights_k5_u16.txt"), (32, 9, "weights_k9_u32.txt")])

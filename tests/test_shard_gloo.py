@@ -153,6 +153,83 @@ def _block_steps(dist, rank, plan, hists, pred, nb):
     return totals
 
 
+PACKED_PER_RANK, PACKED_STEPS = 2, 3
+
+
+def _packed_first(step, m_min):
+    return (step * PACKED_PER_RANK * 5) % (m_min - PACKED_PER_RANK + 1)
+
+
+def _packed_steps(dist, rank, plan, hists, pred, nb):
+    """the block exchange as bench.py drives it since r02: every rank contributes PACKED_PER_RANK consecutive local histograms
+    and ONE all-gather per payload region (2 collectives per step) assembles the block in contiguous query buffers;
+    double-buffered, block s + 1 issued before block s is scored"""
+    import ctypes as C
+    import torch
+    from oracle import oracle_py
+    nq = PACKED_PER_RANK * plan.world
+    m_min = min(plan.local_count(r) for r in range(plan.world))
+    calls = {"all_gather_into_tensor": 0, "broadcast": 0}
+
+    class CountingDist:
+        def __getattr__(self, name):
+            fn = getattr(dist, name)
+            if name in calls:
+                def counted(*a, **kw):
+                    calls[name] += 1
+                    return fn(*a, **kw)
+                return counted
+            return fn
+
+    own_bins = torch.stack([torch.from_numpy(h.array().astype(np.int32)) for h in hists])
+    own_meta = torch.tensor([[h.mag, h.length] for h in hists], dtype=torch.int64)
+
+    class Backend:
+        def __init__(self):
+            self.bins = torch.zeros(2 * nq, nb, dtype=torch.int32)
+            self.meta = torch.zeros(2 * nq, 2, dtype=torch.int64)
+            self.q = [None] * (2 * nq)
+            self.keep = [None] * (2 * nq)
+
+        def export_block(self, local_first, n):
+            return [own_bins[local_first:local_first + n], own_meta[local_first:local_first + n]]
+
+        def block_buffers(self, base, n_rows):
+            return [self.bins[base:base + n_rows], self.meta[base:base + n_rows]]
+
+        def import_queries(self, n, base=0):
+            for j in range(base, base + n):
+                h = oracle_py.Hist()
+                self.keep[j] = self.bins[j].numpy().astype(np.uint16)
+                h.dtype, h.k, h.nbins = DT, K, nb
+                h.bins = self.keep[j].ctypes.data_as(C.c_void_p).value
+                h.mag, h.length = int(self.meta[j][0]), int(self.meta[j][1])
+                self.q[j] = h
+
+        def score_block(self, n, base=0):
+            return np.stack([oracle_py.get_close(pred, CUTOFF, self.q[j], hists)[0] for j in range(base, base + n)])
+
+    blk = shard.ShardedBlockScorer(CountingDist(), plan, Backend(), rank)
+    pending = [None, None]
+    out = []
+    for st in range(PACKED_STEPS):
+        cur, nxt = st % 2, (st + 1) % 2
+        if pending[cur] is None:
+            pending[cur] = blk.begin_packed(_packed_first(st, m_min), PACKED_PER_RANK, base=cur * nq)
+        blk.finish(pending[cur], nq, base=cur * nq)
+        pending[cur] = None
+        pending[nxt] = blk.begin_packed(_packed_first(st + 1, m_min), PACKED_PER_RANK, base=nxt * nq)
+        close, total = blk.score(nq, base=cur * nq)
+        assert close.shape == (nq, len(hists))
+        out.append((blk.packed_globals(_packed_first(st, m_min), PACKED_PER_RANK), total.tolist()))
+    for half in pending:
+        for w in half or []:
+            w.wait()
+    # one all-gather per payload region and block (PACKED_STEPS + 1 blocks were issued), no per-query broadcast
+    assert calls["all_gather_into_tensor"] == 2 * (PACKED_STEPS + 1) and calls["broadcast"] == 0, calls
+    return out
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -201,7 +278,8 @@ def _worker(rank, world, port, q):
         for qg in (0, 9, 17, 30, 45):
             flags, g, sim, is_min, n_close = trn.get_close(qg)
             out.append((qg, flags.tolist(), g, sim, is_min, n_close))
-        q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb), _block_steps(dist, rank, plan, hists, pred, nb)))
+        q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb), _block_steps(dist, rank, plan, hists, pred, nb),
+               _packed_steps(dist, rank, plan, hists, pred, nb)))
     finally:
         dist.destroy_process_group()
 
@@ -220,8 +298,8 @@ def test_sharded_passes_match_single_process(oracle, world):
         p.start()
     res = {}
     for _ in range(world):
-        r, mine, out, merged, blocks = q.get(timeout=180)
-        res[r] = (mine, out, merged, blocks)
+        r, mine, out, merged, blocks, packed = q.get(timeout=180)
+        res[r] = (mine, out, merged, blocks, packed)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -233,7 +311,7 @@ def test_sharded_passes_match_single_process(oracle, world):
         f, bp, bs, im = oracle.get_close(pred, CUTOFF, hs[qg], hs)
         glob_flags = np.zeros(len(seqs), dtype=np.uint8)
         for r in range(world):
-            mine, out, _, _ = res[r]
+            mine, out = res[r][0], res[r][1]
             _, flags, g, sim, is_min, n_close = out[qi]
             glob_flags[np.array(mine)] = flags
             assert (g, is_min, n_close) == (bp, im, int(f.sum())) and sim == pytest.approx(bs, rel=1e-12)
@@ -249,3 +327,10 @@ def test_sharded_passes_match_single_process(oracle, world):
         want_counts = [float(oracle.get_close(pred, CUTOFF, hs[g], hs)[0].sum()) for g in _block_queries(st, len(seqs))]
         for r in range(world):
             assert res[r][3][st] == want_counts, (st, r)
+    # packed exchange (2 collectives per block): every rank reports the same block composition and the single-process counts
+    for st in range(PACKED_STEPS):
+        globals_, _ = res[0][4][st]
+        assert len(set(globals_)) == PACKED_PER_RANK * world
+        want_counts = [float(oracle.get_close(pred, CUTOFF, hs[g], hs)[0].sum()) for g in globals_]
+        for r in range(world):
+            assert res[r][4][st] == (globals_, want_counts), (st, r)

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Folds rocprofv3 CSV output (gpurun_out/<dir>) into the small per-round summaries committed under profiles/.
+"""Folds rocprofv3 CSV output into the small per-round summaries committed under profiles/.
 
-  python tools/summarize_profiles.py r01 gpurun_out/prof_r1 gpurun_out/pmc_fetch gpurun_out/pmc_write
+  python tools/summarize_profiles.py <tag> <stats_dir> <fetch_dir> <write_dir> [config key] [out dir] [extra pmc dirs ...]
 
+writes <out dir>/<tag>_kernel_stats.csv and <out dir>/<tag>_pmc_hbm.json (out dir defaults to profiles/).
 PMC correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE (KiB) reports exactly half of the bytes of a wide
 coalesced streaming read, WRITE_SIZE is exact for 16-byte streaming stores -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+Extra pmc dirs (SQ_* passes): every counter found is averaged per kernel into "<kernel>": {"pmc": {name: mean per launch}}.
 """
 import collections
 import csv
@@ -28,7 +30,9 @@ def short(name):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    key = sys.argv[5] if len(sys.argv) > 5 else ""
+    out_dir = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out_dir, exist_ok=True)
     rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "**", "*kernel_stats.csv")))))
     with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
         f.write("kernel,calls,total_ns,average_ns,percentage,min_ns,max_ns\n")
@@ -45,9 +49,19 @@ def main():
     for k, d in pmc.items():
         if isinstance(d, dict) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE"]["mean_kib"] + d["WRITE_SIZE"]["mean_kib"]) * 1024
-    pmc["_config"] = sys.argv[5] if len(sys.argv) > 5 else ""
+    for d in sys.argv[7:]:
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(files[0])):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, ctrs in agg.items():
+            for c, v in ctrs.items():
+                pmc.setdefault(k, {}).setdefault("pmc", {})[c] = sum(v) / len(v)
+    pmc["_config"] = key
     json.dump(pmc, open(os.path.join(out_dir, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
-    print("wrote profiles/%s_kernel_stats.csv and profiles/%s_pmc_hbm.json" % (tag, tag))
+    print("wrote %s/%s_kernel_stats.csv and %s_pmc_hbm.json" % (out_dir, tag, tag))
 
 
 if __name__ == "__main__":
