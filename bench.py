@@ -198,6 +198,23 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+            real = dist
+
+            class _HostStaged:
+                """gloo with device tensors (the 1-GPU smoke test): the all-gather of the packed exchange goes through host memory"""
+                def __getattr__(self, name):
+                    return getattr(real, name)
+
+                def all_gather_into_tensor(self, out, inp, async_op=False):
+                    ho, hi = out.cpu(), inp.cpu().contiguous()
+                    real.all_gather_into_tensor(ho, hi)
+                    out.copy_(ho)
+
+                    class _Done:
+                        def wait(self):
+                            return True
+                    return _Done()
+            dist = _HostStaged()
     from meshclust2_amd import api, shard, synth
 
     n_total = args.nseq if args.scaling == "strong" else args.nseq * world

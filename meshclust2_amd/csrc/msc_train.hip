@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "msc_internal.h"
+#include "../host/msc_hostmath.hpp"
 
 int msc_feat_is_sim(uint64_t f);        // msc_api.hip
 int msc_set_error(msc_ctx* ctx, int code, const char* msg);
@@ -39,73 +40,10 @@ enum Cmb { C_XY = 0, C_X2Y2 = 1, C_XY2 = 2, C_X2Y = 3 };
 typedef std::pair<uint64_t, int> Cand;          // (flags of one or two singles, Cmb)
 typedef std::set<Cand> CandSet;
 
-typedef std::vector<std::vector<double> > Mat;  // row major, [rows][cols]
-
-Mat mat(size_t r, size_t c) { return Mat(r, std::vector<double>(c, 0.0)); }
-
-// Matrix::operator* (predict/Matrix.cpp:76-96): plain triple loop, sum in k order
-Mat mul(const Mat& a, const Mat& b) {
-	const size_t n = a.size(), m = b.empty() ? 0 : b[0].size(), kk = b.size();
-	Mat out = mat(n, m);
-	for (size_t i = 0; i < n; i++)
-		for (size_t j = 0; j < m; j++) {
-			double s = 0;
-			for (size_t k = 0; k < kk; k++) s = s + a[i][k] * b[k][j];
-			out[i][j] = s;
-		}
-	return out;
-}
-
-Mat transpose(const Mat& a) {
-	const size_t n = a.size(), m = a.empty() ? 0 : a[0].size();
-	Mat t = mat(m, n);
-	for (size_t i = 0; i < n; i++) for (size_t j = 0; j < m; j++) t[j][i] = a[i][j];
-	return t;
-}
-
-// Matrix::gaussJordanInverse (predict/Matrix.cpp:109-207): no pivoting beyond "swap in the first non-zero row below a zero
-// pivot"; when that fails, or the reduced matrix is not exactly the identity, the ORIGINAL matrix is returned as the "inverse"
-Mat gauss_jordan_inverse(const Mat& original) {
-	const size_t n = original.size();
-	Mat a = original, inv = mat(n, n);
-	for (size_t i = 0; i < n; i++) inv[i][i] = 1;
-	for (size_t i = 0; i < n; i++) {
-		if (a[i][i] != 1) {
-			if (a[i][i] == 0) {
-				size_t row = i + 1;
-				while (row < n && a[row][i] == 0) row++;
-				if (row >= n) return original;
-				for (size_t j = 0; j < n; j++) { std::swap(a[i][j], a[row][j]); std::swap(inv[i][j], inv[row][j]); }
-			}
-			const double pv = a[i][i];
-			for (size_t j = 0; j < n; j++) { a[i][j] = a[i][j] / pv; inv[i][j] = inv[i][j] / pv; }
-		}
-		for (size_t below = i + 1; below < n; below++) {
-			if (a[below][i] != 0) {
-				const double pv = a[below][i];
-				for (size_t j = 0; j < n; j++) { a[below][j] = a[below][j] - pv * a[i][j]; inv[below][j] = inv[below][j] - pv * inv[i][j]; }
-			}
-		}
-	}
-	for (size_t ii = n; ii-- > 0;) {
-		for (size_t above = 0; above < ii; above++) {
-			if (a[above][ii] != 0) {
-				const double pv = a[above][ii];
-				for (size_t j = 0; j < n; j++) { a[above][j] = a[above][j] - pv * a[ii][j]; inv[above][j] = inv[above][j] - pv * inv[ii][j]; }
-			}
-		}
-	}
-	for (size_t i = 0; i < n; i++)
-		for (size_t j = 0; j < n; j++)
-			if ((i == j && a[i][j] != 1) || (i != j && a[i][j] != 0)) return original;
-	return inv;
-}
-
-// Matrix::pseudoInverse (:209-221) of a square matrix: (A^T A)^-1 A^T
-Mat pseudo_inverse(const Mat& a) {
-	const Mat t = transpose(a);
-	return mul(gauss_jordan_inverse(mul(t, a)), t);
-}
+typedef msc::hostmath::Matrix Mat;      // the reference's matrix::Matrix, restated in host/msc_hostmath.hpp (product, transpose, Gauss-Jordan)
+using msc::hostmath::product;
+using msc::hostmath::pseudo_inverse;
+using msc::hostmath::transposed;
 
 struct Table {
 	std::vector<uint64_t> singles;            // ascending bit order == Feature::lookup after calculate_table
@@ -133,38 +71,36 @@ double combo_value(const Table& t, size_t pair, const Cand& c) {
 
 // generate_feat_mat (predict/FeatureSelector.cpp:10-38): [1, combo 0, combo 1, ...] per pair, combos in set order
 Mat feature_matrix(const Table& t, const CandSet& set, size_t first, size_t count) {
-	Mat x = mat(count, set.size() + 1);
+	Mat x(count, set.size() + 1);
 	for (size_t r = 0; r < count; r++) {
-		x[r][0] = 1;
+		x.at(r, 0) = 1;
 		size_t c = 1;
-		for (const Cand& cd : set) x[r][c++] = combo_value(t, first + r, cd);
+		for (const Cand& cd : set) x.at(r, c++) = combo_value(t, first + r, cd);
 	}
 	return x;
 }
 
 // GLM::train (predict/GLM.cpp:20-23): weights = pinv(X^T X) * X^T * y, products taken left to right
 std::vector<double> glm_train(const Mat& x, const std::vector<double>& y) {
-	const Mat xt = transpose(x);
-	const Mat w0 = mul(xt, x);
-	Mat ycol = mat(y.size(), 1);
-	for (size_t i = 0; i < y.size(); i++) ycol[i][0] = y[i];
-	const Mat w = mul(mul(pseudo_inverse(w0), xt), ycol);
-	std::vector<double> out(w.size());
-	for (size_t i = 0; i < w.size(); i++) out[i] = w[i][0];
-	return out;
+	const Mat xt = transposed(x);
+	const Mat normal = product(xt, x);
+	Mat ycol(y.size(), 1);
+	for (size_t i = 0; i < y.size(); i++) ycol.at(i, 0) = y[i];
+	const Mat w = product(product(pseudo_inverse(normal), xt), ycol);
+	return w.v;
 }
 
 // GLM::predict + accuracy (predict/GLM.cpp:30-66, FeatureSelector::class_test :93-103): round(logistic(Xw)), 0 counted as -1
 double accuracy(const Mat& x, const std::vector<double>& w, const std::vector<double>& label, size_t first) {
 	size_t same = 0;
-	for (size_t r = 0; r < x.size(); r++) {
+	for (size_t r = 0; r < x.rows; r++) {
 		double s = 0;
-		for (size_t k = 0; k < w.size(); k++) s = s + x[r][k] * w[k];
+		for (size_t k = 0; k < w.size(); k++) s = std::fma(x.at(r, k), w[k], s);      // features * weights, Matrix::operator* as built (msc_hostmath.hpp)
 		double p = round(1.0 / (1 + exp(-s)));
 		if (p == 0) p = -1;
 		if (p == label[first + r]) same++;
 	}
-	return ((double)same * 100) / (double)x.size();
+	return ((double)same * 100) / (double)x.rows;
 }
 
 // feature_accuracy (predict/BestFirstSelector.cpp:129-143): fit on the training pairs, score on the testing pairs
@@ -273,24 +209,31 @@ extern "C" int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint
 			if (i != j) { all.push_back(Cand(i | j, C_X2Y)); all.push_back(Cand(i | j, C_XY2)); }
 		}
 	}
-	// ---- BestFirstSelector::train_class (predict/BestFirstSelector.cpp:187-250)
-	CandSet cur, best;
+	// ---- BestFirstSelector::train_class (predict/BestFirstSelector.cpp:187-250): best-first search over candidate sets. A set is
+	// expanded by toggling one candidate at a time; expansion order = highest testing accuracy first (max-heap, ties as
+	// std::priority_queue leaves them). The search ends when the open list holds a set larger than max_feat, or when the best
+	// admissible set (min_feat..max_feat candidates, strictly better accuracy than any before, starting from -100) has not changed
+	// for three expansions while the open list already holds sets larger than min_feat.
+	CandSet best;
 	std::set<CandSet> closed, open;
 	Heap heap;
-	long last_best_changed = 0;
 	double best_acc = -100;
-	evaluate(t, children_of(cur, all, closed, open), open, heap);
-	for (long iteration = 0; !open.empty(); iteration++) {
-		size_t biggest = 0;
-		for (const CandSet& s : open) biggest = std::max(biggest, s.size());
-		if ((long)biggest > max_feat || (iteration - last_best_changed >= 3 && (long)biggest > min_feat)) break;
-		cur = heap.top().first;
+	long expansions = 0, expansion_of_best = 0;
+	evaluate(t, children_of(CandSet(), all, closed, open), open, heap);
+	while (!open.empty()) {
+		size_t largest_open = 0;
+		for (const CandSet& s : open) largest_open = std::max(largest_open, s.size());
+		const bool stalled = expansions - expansion_of_best >= 3 && (long)largest_open > min_feat;
+		if ((long)largest_open > max_feat || stalled) break;
+		const CandSet cur = heap.top().first;
 		const double acc = heap.top().second;
 		heap.pop();
 		open.erase(cur);
 		closed.insert(cur);
-		if (acc > best_acc && (long)cur.size() >= min_feat && (long)cur.size() <= max_feat) { best = cur; best_acc = acc; last_best_changed = iteration; }
+		const long size = (long)cur.size();
+		if (acc > best_acc && size >= min_feat && size <= max_feat) { best = cur; best_acc = acc; expansion_of_best = expansions; }
 		evaluate(t, children_of(cur, all, closed, open), open, heap);
+		expansions++;
 	}
 	if (best.empty()) return msc_set_error(ctx, MSC_ERR_INVALID_ARG, "msc_train_class: the search found no model with min_feat..max_feat combos");
 	const Mat xtr = feature_matrix(t, best, 0, t.n_train);

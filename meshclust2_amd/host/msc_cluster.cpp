@@ -1,17 +1,13 @@
-// msc_cluster.cpp -- mean-shift driver + CD-HIT .clstr writer over the GPU hot path.
+// msc_cluster.cpp -- the mean-shift driver on ONE GPU: FASTA in, CD-HIT .clstr out.
 //
-// The reference's clustering logic (cluster/ClusterFactory.cpp MS / accumulate / mean_shift_update / merge /
-// print_output, cluster/bvec.cpp, cluster/CRunner.cpp do_run) is host control flow AROUND the hot path. It is written
-// here from scratch against meshclust2_host.hpp so that "identical CLSTR output" can be produced and checked on the GPU
-// box, where only this repository exists. Histograms never leave HBM: the driver handles slots, lengths, flags, scalars.
+// The clustering logic itself (cluster/ClusterFactory.cpp MS / accumulate / mean_shift_update / merge / print_output,
+// cluster/bvec.cpp, cluster/CRunner.cpp do_run) lives in msc_driver.hpp, written against an abstract backend of seven
+// operators so that one GPU, one GPU per rank (meshclust2_amd/cluster.py) and the CPU oracle (the gloo test) share it.
+// This file is what surrounds it on one GPU: reading FASTA, choosing k and the histogram type by the reference's rules,
+// optional training, and GpuBackend -- the operators as direct calls into the C ABI (meshclust2_host.hpp). Histograms
+// never leave HBM: the host handles slots, lengths, flags, scalars.
 //
-// Behaviour reproduced on purpose (SURVEY.md findings): the exclusive use of an inclusive end index in the scoring
-// window (Q6), DivergencePoint::set keeping the stale magnitude of a moved centre (Q7), the OMP_NUM_THREADS=1 order of
-// every reduction and of remove_available (Q10), the unstable std::sort orders (same libstdc++, same comparator, same
-// input order => same permutation), bvec::insert's "middle of the least-filled bins" rule and the quirks of
-// index_of / inner_index_of when a bin is empty.
-//
-// Usage (flag names are the reference's, cluster/CRunner.cpp:243-477; training is out of scope, so a model is required):
+// Usage (flag names are the reference's, cluster/CRunner.cpp:243-477):
 //   msc_cluster <input.fa> [--recover weights.txt] [--id 0.9] [--kmer K] [--datatype 8|16|32|64]   (no --recover: trains first)
 //               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--device 0]
 #include <algorithm>
@@ -28,15 +24,9 @@
 #include <vector>
 
 #include "meshclust2_host.hpp"
+#include "msc_driver.hpp"
 
 namespace {
-
-struct Pt {                      // host shadow of one Point<T>: everything the clustering logic reads
-	std::string header;          // full header line including '>'
-	uint64_t length = 0;         // effective length
-	uint64_t id = 0;
-	uint32_t slot = 0;           // slot in the device point set
-};
 
 // ------------------------------------------------------------------ FASTA (nonltr/ChromListMaker.cpp:24-48,117-165)
 bool safe_getline(std::istream& is, std::string& t) {
@@ -73,143 +63,20 @@ void read_fasta(const std::string& path, std::vector<std::string>& headers, std:
 	}
 }
 
-// ------------------------------------------------------------------ bvec (cluster/bvec.{h,cpp})
-struct BIdx { size_t first = 0, second = 0; bool is_empty = false; };
-using Entry = std::pair<Pt*, bool>;
-
-class BVec {
-public:
-	BVec(std::vector<uint64_t> lengths, uint64_t bin_size = 1000) {
-		std::sort(lengths.begin(), lengths.end());
-		for (uint64_t i = 0; i < lengths.size(); i += bin_size) begin_bounds.push_back(lengths[i]);
-		data.resize(begin_bounds.size());
-	}
-	void insert(Pt* p) {                                   // bvec.cpp:150-184
-		size_t front = 0, back = 0;
-		index_of(p->length, &front, &back);
-		std::vector<size_t> mins;
-		size_t minimum = std::numeric_limits<size_t>::max();
-		for (size_t i = front; i <= back; i++) {
-			size_t sz = data[i].size();
-			if (sz < minimum) { minimum = sz; mins.clear(); mins.push_back(i); }
-			else if (sz == minimum) mins.push_back(i);
-		}
-		if (mins.empty()) { std::fprintf(stderr, "error: no bins to insert into\n"); std::exit(1); }
-		data.at(mins[mins.size() / 2]).push_back(std::make_pair(p, false));
-	}
-	void insert_finalize() {                               // bvec.cpp:216-233
-		for (auto& bin : data) std::sort(bin.begin(), bin.end(), [](const Entry a, const Entry b) { return a.first->length < b.first->length; });
-	}
-	Pt* pop() {                                            // bvec.cpp:27-37
-		for (auto& bin : data) if (!bin.empty()) { Pt* p = bin[0].first; bin.erase(bin.begin()); return p; }
-		return nullptr;
-	}
-	bool index_of(uint64_t point, size_t* pfront, size_t* pback) const {      // bvec.cpp:123-147
-		size_t low = begin_bounds.size() - 1, high = 0;
-		for (size_t i = 1; i < begin_bounds.size(); i++) {
-			const uint64_t prev = begin_bounds[i - 1];
-			if (point >= prev && point < begin_bounds[i]) { low = std::min(low, i - 1); high = std::max(high, i - 1); }
-		}
-		if (point >= begin_bounds[begin_bounds.size() - 1]) high = std::max(high, begin_bounds.size() - 1);
-		if (pfront) *pfront = low;
-		if (pback) *pback = high;
-		return true;
-	}
-	bool inner_index_of(uint64_t length, size_t& idx, size_t* pfront, size_t* pback) const {   // bvec.cpp:52-120
-		if (data.at(idx).empty()) {
-			if (pfront) for (size_t i = 0; i < data.size(); i++) if (!data[i].empty()) { idx = i; *pfront = 0; break; }
-			if (pback) for (long i = (long)data.size() - 1; i >= 0; i--) if (!data[i].empty()) { idx = (size_t)i; *pback = 0; break; }
-			return true;
-		}
-		const auto& bin = data[idx];
-		size_t front = 0, back = 0;
-		size_t low = 0, high = bin.size() - 1;
-		if (length < bin[low].first->length && pfront) *pfront = low;
-		if (length > bin[high].first->length && pback) *pback = high;
-		for (; low <= high;) {
-			size_t mid = (low + high) / 2;
-			uint64_t d = bin[mid].first->length;
-			if (d == length) { front = mid; back = mid; break; }
-			else if (length < d) high = mid;
-			else low = mid + 1;
-			if (low == high) { front = low; back = high; break; }
-		}
-		if (pfront) {
-			for (long i = (long)front; i >= 0 && bin[i].first->length == length; i--) front = (size_t)i;
-			*pfront = front;
-		}
-		if (pback) {
-			for (size_t i = back; i < bin.size() && bin[i].first->length == length; i++) back = i;
-			*pback = back;
-		}
-		return true;
-	}
-	std::pair<BIdx, BIdx> get_range(uint64_t begin_len, uint64_t end_len) const {             // bvec.cpp:261-330
-		BIdx front, back;
-		back.first = data.size() - 1;
-		back.second = data[back.first].size() - 1;
-		index_of(begin_len, &front.first, nullptr);
-		index_of(end_len, nullptr, &back.first);
-		inner_index_of(begin_len, front.first, &front.second, nullptr);
-		inner_index_of(end_len, back.first, nullptr, &back.second);
-		if (back.first == (size_t)-1 || back.second == (size_t)-1) back.is_empty = true;
-		return std::make_pair(front, back);
-	}
-	void erase(size_t r, size_t c) { data.at(r).erase(data.at(r).begin() + (long)c); }
-	void remove_available(BIdx begin, BIdx end, std::vector<Pt*>& available) {                // bvec.cpp:342-384, one thread
-		if (begin.is_empty || end.is_empty) return;
-		for (size_t i = begin.first; i <= end.first && i < data.size(); i++) {
-			for (auto& kv : data[i]) if (kv.second) available.push_back(kv.first);
-			data[i].erase(std::remove_if(data[i].begin(), data[i].end(), [](const Entry d) { return d.second; }), data[i].end());
-		}
-	}
-	std::vector<std::vector<Entry>> data;
-	std::vector<uint64_t> begin_bounds;
-};
-
-// bvec_iterator (cluster/bvec_iterator.{h,cpp})
-struct BIter {
-	size_t r, c;
-	std::vector<std::vector<Entry>>* col;
-	void next() {
-		if (r != col->size()) {
-			if (c + 1 < col->at(r).size()) c++;
-			else { r++; c = 0; while (r < col->size() && col->at(r).empty()) r++; }
-		} else { std::fprintf(stderr, "tried incrementing null iterator\n"); std::exit(1); }
-	}
-	bool less(const BIter& o) const { return r < o.r || (r == o.r && c < o.c); }
-	// operator- (bvec_iterator.h:57-76): what the reference's `#pragma omp parallel for` uses as the trip count
-	int64_t minus(const BIter& rhs) const {
-		if (less(rhs)) return -1 * rhs.minus(*this);
-		if (r == rhs.r) return (int64_t)(c - rhs.c);
-		int64_t sum = (int64_t)c;
-		sum += (int64_t)(col->at(rhs.r).size() - rhs.c);
-		for (size_t i = rhs.r + 1; i < r; i++) sum += (int64_t)col->at(i).size();
-		return sum;
-	}
-};
-
-// ------------------------------------------------------------------ centres (cluster/Center.h)
-struct Centre {
-	uint32_t cslot = 0;          // slot in the device centre store (a clone of a point, possibly moved by set())
-	std::string header;
-	uint64_t id = 0, length = 0;
-	std::vector<Pt*> points;
-	bool to_delete = false;
-};
-
-struct Driver {
+// ------------------------------------------------------------------ the hot path of ONE GPU behind msc::ClusterBackend
+// Point handle = slot in the device point set (records are built in input order); centre handle = slot in the centre store.
+struct GpuBackend : msc::ClusterBackend {
 	msc::Context& ctx;
 	msc::PointSet& points;
 	msc::Trainer& trn;
 	int k, dtype;
+	double cutoff;
 	std::unique_ptr<msc::PointSet> centres;
 	uint64_t n_centres = 0;
-
 	uint64_t centre_arena = 0;      // > 0: sparse centre store with that many entries
 
-	Driver(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt, uint64_t sparse_arena) : ctx(c), points(p), trn(t), k(k_), dtype(dt) {
-		centre_arena = sparse_arena;
+	GpuBackend(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt, double cut, uint64_t sparse_arena)
+	    : ctx(c), points(p), trn(t), k(k_), dtype(dt), cutoff(cut), centre_arena(sparse_arena) {
 		centres.reset(new msc::PointSet(ctx, k, dtype, 256, centre_arena));
 	}
 	// relocate every live centre into a fresh store (exact copies: stale mags survive). Used to grow the slot count and,
@@ -219,10 +86,6 @@ struct Driver {
 		for (uint64_t i = 0; i < n_centres; i++) fresh->copy(i, *centres, i);
 		centres.swap(fresh);
 	}
-	uint32_t new_centre_slot() {
-		if (n_centres == centres->capacity()) rebuild_centres(centres->capacity() * 2);
-		return (uint32_t)n_centres++;
-	}
 	template <class F> void with_arena_retry(F&& f) {      // sparse store: compact once when the arena runs out
 		try { f(); }
 		catch (const msc::Error& e) {
@@ -231,204 +94,40 @@ struct Driver {
 			f();
 		}
 	}
-	// Center(Point* c, pts): center(c->clone())
-	Centre make_centre(Pt* c, const std::vector<Pt*>& pts) {
-		Centre ce;
-		ce.cslot = new_centre_slot();
-		with_arena_retry([&] { centres->clone(ce.cslot, points, c->slot); });
-		ce.header = c->header; ce.id = c->id; ce.length = c->length;
-		ce.points = pts;
-		return ce;
-	}
-	// center->set(*next): bins, length, header, id -- not mag
-	void centre_set(Centre& ce, Pt* next) {
-		with_arena_retry([&] { centres->set(ce.cslot, points, next->slot); });
-		ce.header = next->header; ce.id = next->id; ce.length = next->length;
-	}
 
-	static std::vector<uint32_t> slots_of(const std::vector<Pt*>& v) {
-		std::vector<uint32_t> s(v.size());
-		for (size_t i = 0; i < v.size(); i++) s[i] = v[i]->slot;
-		return s;
+	void get_close(uint32_t q, const std::vector<uint32_t>& window, std::vector<uint8_t>& flags, int64_t& pos, bool& is_min) override {
+		auto res = trn.get_close(points, window, points, q, is_min);
+		pos = std::get<0>(res);
+		flags.swap(std::get<2>(res));
 	}
-
-	// get_mean (cluster/ClusterFactory.cpp:338-380): member nearest to the FP64 mean
-	Pt* get_mean(const std::vector<Pt*>& available) {
-		if (available.empty()) { std::fprintf(stderr, "N cannot be 0, bad\n"); std::exit(1); }
-		int64_t pos = trn.closest(points, slots_of(available));
-		return available[(size_t)pos];
+	int64_t closest(const std::vector<uint32_t>& members) override { return trn.closest(points, members); }
+	uint32_t centre_new(uint32_t point) override {
+		if (n_centres == centres->capacity()) rebuild_centres(centres->capacity() * 2);
+		const uint32_t slot = (uint32_t)n_centres++;
+		with_arena_retry([&] { centres->clone(slot, points, point); });
+		return slot;
 	}
-
-	// accumulate (cluster/ClusterFactory.cpp:553-610)
-	size_t accumulate(Pt** last_ptr, BVec& bv, std::vector<Centre>& part, double sim) {
-		Pt* last = *last_ptr;
-		std::vector<Pt*> current = {last};
-		bool is_min = false;
-		while (!is_min) {
-			const uint64_t len = last->length;
-			auto bounds = bv.get_range((uint64_t)(len * sim), (uint64_t)(len / sim));
-			// the window [iter(first), iter(second)) -- `i < iend` with an inclusive end index
-			std::vector<uint32_t> window;
-			std::vector<std::pair<size_t, size_t>> where;
-			BIter it{bounds.first.first, bounds.first.second, &bv.data}, end{bounds.second.first, bounds.second.second, &bv.data};
-			// OpenMP turns `for (i = istart; i < iend; ++i)` into (iend - istart) iterations of istart + n
-			const int64_t trips = end.minus(it);
-			for (int64_t n = 0; n < trips; n++) {
-				window.push_back(bv.data.at(it.r).at(it.c).first->slot);
-				where.emplace_back(it.r, it.c);
-				if (n + 1 < trips) it.next();
-			}
-			auto res = trn.get_close(points, window, points, last->slot, is_min);
-			const auto& flags = std::get<2>(res);
-			for (size_t j = 0; j < flags.size(); j++) if (flags[j]) bv.data[where[j].first][where[j].second].second = true;
-			if (is_min) {
-				const int64_t pos = std::get<0>(res);
-				if (pos < 0) {
-					*last_ptr = bv.pop();
-				} else {
-					*last_ptr = bv.data[where[(size_t)pos].first][where[(size_t)pos].second].first;
-					bv.erase(where[(size_t)pos].first, where[(size_t)pos].second);
-				}
-				std::vector<Pt*> none;
-				bv.remove_available(bounds.first, bounds.second, none);
-			} else {
-				bv.remove_available(bounds.first, bounds.second, current);
-				last = get_mean(current);
-			}
-		}
-		part.push_back(make_centre(last, current));
-		return current.size();
+	void centre_set(uint32_t centre, uint32_t point) override { with_arena_retry([&] { centres->set(centre, points, point); }); }
+	void filter(uint32_t centre, const std::vector<uint32_t>& pts, std::vector<uint8_t>& keep) override {
+		keep.assign(pts.size(), 0);
+		uint64_t n = 0;
+		ctx.check(msc_filter(ctx.get(), trn.feature().get(), cutoff, centres->get(), centre, points.get(), pts.data(), pts.size(), keep.data(), &n));
 	}
-
-	// mean_shift_update (cluster/ClusterFactory.cpp:288-335)
-	void mean_shift_update(std::vector<Centre>& part, int j, int delta) {
-		Centre& ce = part[(size_t)j];
-		const int i_begin = std::max(0, j - delta);
-		const int i_end = std::min(j + delta, (int)part.size() - 1);
-		std::vector<Pt*> good;
-		for (int i = i_begin; i <= i_end; i++) for (Pt* p : part[(size_t)i].points) good.push_back(p);
-		std::vector<uint32_t> slots = slots_of(good);
-		// trn.filter(center, good): keep what classifies close to the centre
-		{
-			std::vector<uint8_t> keep(slots.size());
-			uint64_t n = 0;
-			ctx.check(msc_filter(ctx.get(), trn.feature().get(), cutoff, centres->get(), ce.cslot, points.get(), slots.data(), slots.size(), keep.data(), &n));
-			std::vector<Pt*> g2;
-			for (size_t i = 0; i < good.size(); i++) if (keep[i]) g2.push_back(good[i]);
-			good.swap(g2);
-		}
-		if (!good.empty()) {
-			int64_t pos = trn.closest(points, slots_of(good));
-			centre_set(ce, good[(size_t)pos]);
-		} else if (delta == 0) {
-			centre_set(ce, ce.points[0]);
-		}
-	}
-
-	// the `omp parallel for` over mean_shift_update of one round (cluster/ClusterFactory.cpp:639,648) as ONE call: the centres of a
-	// round are independent (each reads its own histogram and the member lists of its neighbours, none of which change during
-	// the round), so filter + mean + closest of all of them are batched on the device (msc_update_centres)
-	void mean_shift_update_all(std::vector<Centre>& part, int delta) {
-		const size_t n = part.size();
-		if (n == 0) return;
-		std::vector<uint32_t> cslots(n), slots;
-		std::vector<uint64_t> offsets(n + 1, 0);
-		std::vector<Pt*> good;
-		for (size_t j = 0; j < n; j++) {
-			cslots[j] = part[j].cslot;
-			const int i_begin = std::max(0, (int)j - delta);
-			const int i_end = std::min((int)j + delta, (int)n - 1);
-			for (int i = i_begin; i <= i_end; i++) for (Pt* p : part[(size_t)i].points) { good.push_back(p); slots.push_back(p->slot); }
-			offsets[j + 1] = slots.size();
-		}
-		std::vector<int64_t> nearest(n, -1);
-		ctx.check(msc_update_centres(ctx.get(), trn.feature().get(), cutoff, centres->get(), cslots.data(), n, points.get(), slots.data(), offsets.data(),
+	long merge(const std::vector<uint32_t>& cs, long current, long begin, long last) override { return trn.merge(*centres, cs, current, begin, last); }
+	bool update_centres(const std::vector<uint32_t>& cs, const std::vector<uint32_t>& pts, const std::vector<uint64_t>& offsets, std::vector<int64_t>& nearest) override {
+		ctx.check(msc_update_centres(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), points.get(), pts.data(), offsets.data(),
 		                             nearest.data(), nullptr));
-		// center->set(*next) of every centre that moves: one launch for the dense layout (the sparse arena is appended to one by one)
-		std::vector<uint32_t> dst, src;
-		for (size_t j = 0; j < n; j++) {
-			Centre& ce = part[j];
-			Pt* next = nearest[j] >= 0 ? good[(size_t)(offsets[j] + (uint64_t)nearest[j])] : (delta == 0 ? ce.points[0] : nullptr);
-			if (!next) continue;
-			if (centre_arena) { centre_set(ce, next); continue; }
-			dst.push_back(ce.cslot);
-			src.push_back(next->slot);
-			ce.header = next->header; ce.id = next->id; ce.length = next->length;
-		}
-		if (!dst.empty()) ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), dst.data(), points.get(), src.data(), dst.size()));
+		return true;
 	}
-
-	// merge (cluster/ClusterFactory.cpp:383-401)
-	bool merge(std::vector<Centre>& centers, int delta) {
-		int num_merge = 0;
-		std::vector<uint32_t> cs(centers.size());
-		for (size_t c = 0; c < centers.size(); c++) cs[c] = centers[c].cslot;
-		// every trn.merge(centers, i, i + 1, min(n - 1, i + delta)) of the loop at once: none of them changes a centre
-		std::vector<int64_t> best(centers.size(), 0);
-		if (batch_update) ctx.check(msc_merge_all(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, best.data()));
-		for (int i = 0; i < (int)centers.size(); i++) {
-			long ret = batch_update ? (long)best[(size_t)i] : trn.merge(*centres, cs, i, i + 1, std::min((int)centers.size() - 1, i + delta));
-			if (ret > i) {
-				num_merge++;
-				auto& to_add = centers[(size_t)ret].points;
-				auto& to_del = centers[(size_t)i].points;
-				to_add.insert(to_add.end(), to_del.begin(), to_del.end());
-				centers[(size_t)i].to_delete = true;
-			}
-		}
-		centers.erase(std::remove_if(centers.begin(), centers.end(), [](const Centre& c) { return c.to_delete; }), centers.end());
-		return num_merge > 0;
+	bool centre_set_batch(const std::vector<uint32_t>& cs, const std::vector<uint32_t>& pts) override {
+		if (centre_arena) return false;        // the sparse arena is appended to one centre at a time (with the compaction retry)
+		ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), cs.data(), points.get(), pts.data(), cs.size()));
+		return true;
 	}
-
-	// print_output (cluster/ClusterFactory.cpp:404-435)
-	static void print_output(const std::string& output, const std::vector<Centre>& partition) {
-		std::ofstream ofs(output.c_str());
-		int counter = 0;
-		for (const auto& cen : partition) {
-			if (cen.points.empty()) continue;
-			ofs << ">Cluster " << counter << std::endl;
-			int pt = 0;
-			for (Pt* p : cen.points) {
-				ofs << pt << "\t" << p->length << "nt, " << p->header << "... ";
-				if (p->id == cen.id) ofs << "*";
-				ofs << std::endl;
-				pt++;
-			}
-			counter++;
-		}
+	bool merge_all(const std::vector<uint32_t>& cs, int delta, std::vector<int64_t>& best) override {
+		ctx.check(msc_merge_all(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, best.data()));
+		return true;
 	}
-
-	// Clock::stamp (clutil/Clock.cpp:12-19): same stage names as the reference's driver
-	static void stamp(const char* desc) {
-		static const auto t0 = std::chrono::steady_clock::now();
-		std::cout << "timestamp " << desc << " " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
-	}
-
-	// ClusterFactory<T>::MS (cluster/ClusterFactory.cpp:621-656)
-	void MS(BVec& bv, double sim, const std::string& output, int iter, int delta) {
-		std::vector<Centre> part;
-		Pt* last = bv.pop();
-		while (last != nullptr) accumulate(&last, bv, part, sim);
-		stamp("accumulate");
-		std::cout << "Number of clusters before update: " << part.size() << std::endl;
-		std::vector<size_t> num_clusters;
-		for (int i = 0; i < iter; i++) {
-			if (i >= 3 && part.size() == num_clusters[(size_t)i - 3]) break;
-			if (batch_update) mean_shift_update_all(part, delta);
-			else for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, delta);
-			merge(part, delta);
-			num_clusters.push_back(part.size());
-		}
-		if (batch_update) mean_shift_update_all(part, 0);
-		else for (int j = 0; j < (int)part.size(); j++) mean_shift_update(part, j, 0);
-		stamp("update");
-		print_output(output, part);
-		std::cout << "Number of clusters: " << part.size() << std::endl;
-		stamp("done");
-	}
-
-	double cutoff = 0.9;
-	bool batch_update = true;       // --serial-update: one centre at a time (the order the reference would take with one thread)
 };
 
 }  // namespace
@@ -605,6 +304,7 @@ int main(int argc, char** argv) {
 		return 1;
 	}
 	try {
+		const auto t_start = std::chrono::steady_clock::now();
 		msc::Context ctx(device);
 		std::vector<std::string> headers, seqs;
 		std::vector<size_t> file_first;                // index of every file's first record (find_k averages per file, then over the files)
@@ -634,7 +334,7 @@ int main(int argc, char** argv) {
 			const std::string text = train_model(ctx, k, dtype, id, feat_flags, n_templates, min_feat, max_feat, seqs);
 			std::ofstream(dump.c_str()) << text;       // the reference always leaves weights.txt behind (cluster/Trainer.cpp:188-190)
 			weights = dump;
-			Driver::stamp("GLM");
+			std::cout << "timestamp GLM " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
 		}
 		msc::Trainer trn(ctx, weights, similarity);
 		if (k < 0) k = msc_model_k(trn.feature().get());
@@ -651,32 +351,23 @@ int main(int argc, char** argv) {
 			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(n, off + chunk));
 			points.get_points(off, part);
 		}
-		std::vector<Pt> store(n);
-		std::vector<Pt*> pts(n);
+		std::vector<msc::SeqRecord> records(n);
 		for (size_t i = 0; i < n; i++) {
-			store[i].header = headers[i];
-			store[i].slot = (uint32_t)i;
-			store[i].length = points.get_length(i);
-			pts[i] = &store[i];
+			records[i].header = headers[i];
+			records[i].length = points.get_length(i);      // slot i == point handle i
 		}
 		seqs.clear();
-		// get_points: sort by header, then by length, both unstable std::sort (cluster/CRunner.cpp:538-539)
-		std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->header < b->header; });
-		std::sort(pts.begin(), pts.end(), [](Pt* a, Pt* b) { return a->length < b->length; });
-		std::vector<uint64_t> lengths;
-		for (Pt* p : pts) lengths.push_back(p->length);
-		BVec bv(lengths, 1000);
-		uint64_t idx = 0;
-		for (Pt* p : pts) { p->id = idx++; bv.insert(p); }
-		bv.insert_finalize();
-		Driver::stamp("read_in_points");
-		Driver drv(ctx, points, trn, k, dtype, sparse ? total_bases + 64 * longest + (1 << 20) : 0);      // worst case every sequence stays its own centre; the slack absorbs set() appends between compactions
-		drv.cutoff = similarity;
-		drv.batch_update = !serial_update;
-		drv.MS(bv, similarity, output, iterations, delta);
+		// worst case every sequence stays its own centre; the slack absorbs set() appends between compactions
+		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, sparse ? total_bases + 64 * longest + (1 << 20) : 0);
+		msc::MeanShift ms(gpu, std::cout);
+		ms.batch_update = !serial_update;
+		ms.run(records, similarity, iterations, delta, output.c_str());
 	} catch (const msc::Error& e) {
 		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());
 		return 3;
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return 1;
 	}
 	return 0;
 }

@@ -441,6 +441,84 @@ int ref_mean_nearest(int dtype, void** pts, int n, double* mean_out, double* dis
 
 void ref_set_threads(int n) { omp_set_num_threads(n); }
 
+// ---- cluster/bvec.{h,cpp} + cluster/bvec_iterator.h on their own: the same entry points as msc_bins_* of libmsc_driver.so
+// (include/meshclust2_driver.h), each forwarding to the reference's bvec<uint8_t>. Points are 1-bin DivergencePoints that only
+// carry a length and an id.
+struct RefBins {
+	bvec<uint8_t>* bv;
+	std::vector<Point<uint8_t>*> pts;
+};
+void* ref_bins_create(const uint64_t* lengths, uint64_t n, uint64_t per_bin) {
+	RefBins* rb = new RefBins();
+	std::vector<uint64_t> l(lengths, lengths + n);
+	rb->bv = new bvec<uint8_t>(l, per_bin);
+	for (uint64_t i = 0; i < n; i++) {
+		DivergencePoint<uint8_t>* p = new DivergencePoint<uint8_t>(std::vector<uint8_t>(1, 1), lengths[i]);
+		p->set_length(lengths[i]);
+		p->set_id(i);
+		rb->pts.push_back(p);
+		rb->bv->insert(p);
+	}
+	rb->bv->insert_finalize();
+	return rb;
+}
+void ref_bins_destroy(void* h) {
+	RefBins* rb = (RefBins*)h;
+	for (auto p : rb->pts) delete p;
+	delete rb->bv;
+	delete rb;
+}
+uint64_t ref_bins_count(void* h) { return ((RefBins*)h)->bv->data.size(); }
+uint64_t ref_bins_layout(void* h, uint32_t* ids_out, uint64_t* sizes_out) {
+	auto& data = ((RefBins*)h)->bv->data;
+	uint64_t n = 0;
+	for (size_t i = 0; i < data.size(); i++) {
+		sizes_out[i] = data[i].size();
+		for (auto& kv : data[i]) ids_out[n++] = (uint32_t)kv.first->get_id();
+	}
+	return n;
+}
+void ref_bins_range(void* h, uint64_t begin_len, uint64_t end_len, uint64_t out[5]) {
+	auto r = ((RefBins*)h)->bv->get_range(begin_len, end_len);
+	out[0] = r.first.first; out[1] = r.first.second; out[2] = r.second.first; out[3] = r.second.second; out[4] = r.second.is_empty ? 1 : 0;
+}
+// the loop of Trainer::get_close (cluster/Trainer.cpp:41-48) as OpenMP runs it: (iend - istart) iterations of istart + n
+int64_t ref_bins_window(void* h, uint64_t begin_len, uint64_t end_len, uint32_t* ids_out, uint64_t cap) {
+	bvec<uint8_t>* bv = ((RefBins*)h)->bv;
+	auto r = bv->get_range(begin_len, end_len);
+	bvec_iterator<uint8_t> istart = bv->iter(r.first), iend = bv->iter(r.second);
+	const int64_t trips = iend - istart;
+	for (int64_t n = 0; n < trips; n++) {
+		if ((uint64_t)n < cap) ids_out[n] = (uint32_t)(*istart).first->get_id();
+		if (n + 1 < trips) ++istart;
+	}
+	return trips;
+}
+void ref_bins_mark(void* h, uint64_t bin, uint64_t at) { ((RefBins*)h)->bv->data.at(bin).at(at).second = true; }
+uint64_t ref_bins_take_marked(void* h, uint64_t begin_len, uint64_t end_len, uint32_t* ids_out) {
+	bvec<uint8_t>* bv = ((RefBins*)h)->bv;
+	auto r = bv->get_range(begin_len, end_len);
+	std::vector<Point<uint8_t>*> out;
+	bv->remove_available(r.first, r.second, out);
+	for (size_t i = 0; i < out.size(); i++) ids_out[i] = (uint32_t)out[i]->get_id();
+	return out.size();
+}
+int64_t ref_bins_take_first(void* h) {
+	Point<uint8_t>* p = ((RefBins*)h)->bv->pop();
+	return p ? (int64_t)p->get_id() : -1;
+}
+void ref_bins_erase(void* h, uint64_t bin, uint64_t at) { ((RefBins*)h)->bv->erase(bin, at); }
+
+// Matrix::gaussJordanInverse (predict/Matrix.cpp:109-207) on an n x n row-major matrix
+void ref_host_inverse(uint64_t n, const double* a, double* out) {
+	matrix::Matrix m((int)n, (int)n);
+	for (uint64_t i = 0; i < n; i++) for (uint64_t j = 0; j < n; j++) m.set((int)i, (int)j, a[i * n + j]);
+	std::streambuf* keep = std::cout.rdbuf(nullptr);          // "Inverse does not exist" goes to stdout
+	matrix::Matrix r = m.gaussJordanInverse();
+	std::cout.rdbuf(keep);
+	for (uint64_t i = 0; i < n; i++) for (uint64_t j = 0; j < n; j++) out[i * n + j] = r.get((int)i, (int)j);
+}
+
 long ref_train_class(int dtype, void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int min_feat,
                      int max_feat, double id, char* out, long cap, double* acc_out) {
 	try {

@@ -1,0 +1,156 @@
+"""The multi-rank mean-shift driver (meshclust2_amd/cluster.py) on CPU: world-size-2 and -3 gloo processes shard the points,
+every rank runs the clustering logic of libmsc_driver.so on replicated bookkeeping, the operators exchange through
+torch.distributed, and the rank-local scorer is the CPU oracle (test infrastructure). Rank 0's .clstr must be the reference CLI's
+own output byte for byte (cfg1: k = 5 / 16-bit; k9_u8: k = 9 with the 8-bit type the reference chose by itself)."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, weights_text
+from meshclust2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NP_T = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
+CASES = {
+    "cfg1": dict(seed=20260001, n=1000, family=20, k=5, dtype=16, weights="weights_k5_u16.txt", sim=0.9, clstr="cfg1.clstr", block=100),
+    "k9_u8": dict(seed=61, n=320, family=16, k=9, dtype=8, weights="weights_k9_u8.txt", sim=0.9, clstr="k9_u8.clstr", block=40),
+}
+
+
+class OracleEngine:
+    """rank-local work of cluster.DistributedBackend with the CPU oracle as the scorer; payload = the bins as bytes + (mag, length)"""
+
+    def __init__(self, oracle, seqs, k, dtype, pred, cutoff):
+        import torch
+        self.o, self.k, self.dtype, self.pred, self.cutoff, self.torch = oracle, k, dtype, pred, cutoff, torch
+        self.h = [oracle.hist(s_, k, dtype) for s_ in seqs]
+        self.n_local = len(seqs)
+        self.nbytes = 4 ** k * dtype // 8
+        self.q_bins, self.q_meta = torch.zeros(self.nbytes, dtype=torch.uint8), torch.zeros(2, dtype=torch.int64)
+        self.query = None
+        self.centres = []
+        self.keep = {}
+
+    def lengths(self):
+        return np.array([h.length for h in self.h], dtype=np.int64)
+
+    def _payload(self, h):
+        return [self.torch.from_numpy(h.array().view(np.uint8)), self.torch.tensor([h.mag, h.length], dtype=self.torch.int64)]
+
+    def _hist(self, key, bins, meta):
+        h = self.o.Hist()
+        self.keep[key] = np.ascontiguousarray(bins.numpy()).view(NP_T[self.dtype]).copy()
+        h.dtype, h.k, h.nbins = self.dtype, self.k, 4 ** self.k
+        h.bins = self.keep[key].ctypes.data_as(C.c_void_p).value
+        h.mag, h.length = int(meta[0]), int(meta[1])
+        return h
+
+    def point_payload(self, local):
+        return self._payload(self.h[local])
+
+    def query_payload(self):
+        return [self.q_bins, self.q_meta]
+
+    def query_ready(self):
+        self.query = self._hist("q", self.q_bins, self.q_meta)
+
+    def get_close(self, local_slots):
+        f, pos, sim, _ = self.o.get_close(self.pred, self.cutoff, self.query, [self.h[i] for i in local_slots])
+        return f, pos, sim
+
+    def centre_from_query(self, centre, clone):
+        if clone:
+            c = self.o.Hist()
+            self.o.lib().orc_hist_clone(C.byref(self.query), C.byref(c))
+            self.centres.append(c)
+            return len(self.centres) - 1
+        self.o.lib().orc_hist_set(C.byref(self.centres[centre]), C.byref(self.query))
+        return centre
+
+    def filter(self, centre, local_slots):
+        return self.o.filter_(self.pred, self.cutoff, self.centres[centre], [self.h[i] for i in local_slots])
+
+    def merge(self, centres, current, begin, last):
+        return self.o.merge(self.pred, self.cutoff, [self.centres[c] for c in centres], current, begin, last)
+
+    def merge_all(self, centres, delta):
+        n = len(centres)
+        return np.array([self.merge(centres, i, i + 1, min(n - 1, i + delta)) for i in range(n)], dtype=np.int64)
+
+    def member_payload(self, local_slots, n_pad):
+        bins = self.torch.zeros(n_pad, self.nbytes, dtype=self.torch.uint8)
+        meta = self.torch.zeros(n_pad, 2, dtype=self.torch.int64)
+        for j, i in enumerate(local_slots):
+            bins[j], meta[j] = self._payload(self.h[i])
+        return [bins, meta]
+
+    def scratch_payload(self, n_rows):
+        self.s_bins, self.s_meta = self.torch.zeros(n_rows, self.nbytes, dtype=self.torch.uint8), self.torch.zeros(n_rows, 2, dtype=self.torch.int64)
+        return [self.s_bins, self.s_meta]
+
+    def scratch_ready(self, n_rows):
+        self.scratch = [self._hist(("s", r), self.s_bins[r], self.s_meta[r]) for r in range(n_rows)]
+
+    def mean_nearest(self, rows):
+        return self.o.mean_nearest([self.scratch[r] for r in rows])[2]
+
+
+def _worker(rank, world, port, case, out_path, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from meshclust2_amd import cluster, shard
+    from oracle import oracle_py
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = CASES[case]
+        seqs, hdrs = synth.families(c["seed"], c["n"], 1000, family=c["family"])
+        plan = shard.ShardPlan(len(seqs), world, block=c["block"])
+        pred = oracle_py.predictor(weights_text(c["weights"]))
+        oracle_py.lib().orc_set_threads(max(1, (os.cpu_count() or 2) // world))
+        x = cluster.Exchange(dist if world > 1 else None, rank, world)
+        cluster.cluster(lambda: OracleEngine(oracle_py, [seqs[g] for g in plan.local_globals(rank)], c["k"], c["dtype"], pred, c["sim"]), plan, x, rank, hdrs,
+                        c["sim"], output=out_path, log=os.devnull)
+        q.put((rank, dict(x.calls)))
+    except BaseException as e:      # noqa: BLE001 -- the parent must not wait for its timeout
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("cfg1", 2), ("cfg1", 3), ("k9_u8", 2), ("cfg1", 1)])
+def test_sharded_mean_shift_writes_the_reference_clstr(oracle, tmp_path, case, world):
+    import torch.multiprocessing as mp
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    out = str(tmp_path / "out.clstr")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    calls = {}
+    for _ in range(world):
+        r, c = q.get(timeout=600)
+        if isinstance(c, str):
+            for p in procs:
+                p.kill()
+            pytest.fail("rank %d: %s" % (r, c))
+        calls[r] = c
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, CASES[case]["clstr"]), "rb").read()
+    if world > 1:
+        assert calls[0]["broadcast"] > 0 and calls[0]["all_gather"] > 0
+        assert all(calls[r] == calls[0] for r in range(world))          # every rank issued the same collectives

@@ -655,9 +655,10 @@ def test_cfg4_k13_u64_20kb_against_the_oracle(ctx, oracle, route):
                         # the same for the two divergences: the reference adds 67 M terms (almost all the tiny (1, 1) term) one by
                         # one and its sum is 1e-9 off the exact value; the GPU adds the few thousand other terms and multiplies the
                         # (1, 1) term by its count. Held to the reference at 1e-7 (the north-star bar is 1e-5) and to an
-                        # extended-precision evaluation of the same formula at 1e-12.
+                        # extended-precision evaluation of the same formula at 1e-10.
                         assert col == pytest.approx(exp, rel=1e-7, abs=1e-13), (name, c, q, order)
-                        assert col == pytest.approx(_divergence_longdouble(name, a, b), rel=1e-12, abs=1e-18), (name, c, q, order)
+                        # (1e-10: the two logs of a jensen_shannon term cancel to second order, so FP64 terms carry ~1e-12 each)
+                        assert col == pytest.approx(_divergence_longdouble(name, a, b), rel=1e-10, abs=1e-18), (name, c, q, order)
                     else:
                         assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c, q, order)
     feat = api.Feature.from_text(ctx, CFG4_WEIGHTS, 0)
@@ -669,7 +670,7 @@ def test_cfg4_k13_u64_20kb_against_the_oracle(ctx, oracle, route):
             flags, bp, bs, im = trn.get_close(hs, w, hs, q)
             of, obp, obs, oim = oracle.get_close(pred, cutoff, oh[q], [oh[c] for c in w])
             assert np.array_equal(flags, of) and (bp, im) == (obp, oim), (cutoff, q)
-            assert bs == pytest.approx(obs, rel=1e-9), (cutoff, q)
+            assert bs == pytest.approx(obs, rel=1e-7), (cutoff, q)          # jensen_shannon is in the model: see the 1e-9 note above
             assert np.array_equal(trn.filter(hs, q, hs, w), oracle.filter_(pred, cutoff, oh[q], [oh[c] for c in w])), (cutoff, q)
     r = feat.compute(hs, cands, hs, 1)
     for c in range(n):
@@ -1259,3 +1260,54 @@ def test_find_k_reproduces_the_reference_rule(tmp_path):
         r = subprocess.run([exe] + names + ["--id", "0.9", "--output", str(tmp_path / "o.clstr")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode(errors="replace")          # too few sequences to train on: the run stops after printing its choice of k
         assert "avg length: %d\n" % avg in out and "Recommended K: %d\n" % k in out, (ci, out[-400:])
+
+
+def _run_ranks(module_args, n, tmp_path, timeout=900):
+    """n ranks of `python -m torch.distributed.run ...` sharing GPU 0 over gloo (MSC_BENCH_ONE_GPU: this pool has 1-GPU boxes; the
+    real launch is one rank per GPU over RCCL)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, MSC_BENCH_BACKEND="gloo", MSC_BENCH_ONE_GPU="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                           "--master-port", str(port)] + module_args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+
+
+@pytest.mark.parametrize("case,ranks", [("cfg1", 2), ("k9_u8", 2), ("cfg1", 1)])
+def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks):
+    """meshclust2_amd/cluster.py: the points sharded over `ranks` processes (two ranks sharing this box's GPU, exchanges over gloo
+    staged through host memory), every rank running the clustering logic of libmsc_driver.so on replicated bookkeeping and scoring
+    its shard through the C ABI. Rank 0 writes the reference CLI's own .clstr byte for byte (cluster/ClusterFactory.cpp:553-656)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    seed, n, fam, wts, clstr = {"cfg1": (20260001, 1000, 20, "weights_k5_u16.txt", "cfg1.clstr"), "k9_u8": (61, 320, 16, "weights_k9_u8.txt", "k9_u8.clstr")}[case]
+    seqs, hdrs = synth.families(seed, n, 1000, family=fam)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    args = ["-m", "meshclust2_amd.cluster", fa, "--recover", os.path.join(golden, wts), "--id", "0.9", "--output", out]
+    if case == "cfg1":
+        args += ["--kmer", "5", "--datatype", "16"]
+    r = _run_ranks(args, ranks, tmp_path)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    assert open(out, "rb").read() == open(os.path.join(golden, clstr), "rb").read()
+
+
+def test_bench_two_ranks_packed_exchange(tmp_path):
+    """bench.py --gpus 2 (strong scaling: the sequences split over the ranks, 2 all-gathers per step assemble the query block) on
+    two ranks sharing this GPU: the line is well-formed and the sharded run scores the same pairs as one rank would."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2", "--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0"], 2, tmp_path)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["pairs_per_step"] == 16 * 8000
+    assert line["roofline"]["candidates_per_launch"] == 4000 and line["value"] > 0
