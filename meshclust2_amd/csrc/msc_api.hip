@@ -44,7 +44,7 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
 	DevBuf segs, pair_seg, dist;
@@ -65,6 +65,12 @@ struct msc_hist_set {
 	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
 	mutable uint64_t dg_lo = 0, dg_hi = 0;
 	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
+	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
+	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
+	mutable msc_hist_set* sp_mirror = nullptr;
+	mutable uint64_t sm_lo = 0, sm_hi = 0;
+	mutable bool sp_mirror_unavailable = false;
+	std::vector<uint8_t> written;         // dense sets: slot holds a histogram (unwritten slots are never sparsified)
 	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
 	bool sparse = false;
 	uint2* ent = nullptr;
@@ -194,6 +200,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->sp_acc);
 	release(ctx->sp_chunk_off);
 	release(ctx->sp_chunk_cum);
+	release(ctx->sp_partials);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
@@ -422,6 +429,7 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
+	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
 	if (s->hdr) (void)hipFree(s->hdr);
@@ -437,12 +445,29 @@ extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + s->scalar_stride) * s->capacity;
 }
 
-// pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
-static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
-	if (s->digest && n) {         // every writer of slots ends here: the digest of these slots is stale now
+// every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
+static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
+	if (s->sparse || n == 0) return;
+	if (s->digest) {
 		if (s->dg_lo >= s->dg_hi) { s->dg_lo = first; s->dg_hi = first + n; }
 		else { s->dg_lo = std::min(s->dg_lo, first); s->dg_hi = std::max(s->dg_hi, first + n); }
 	}
+	if (s->sp_mirror) {
+		if (s->sm_lo >= s->sm_hi) { s->sm_lo = first; s->sm_hi = first + n; }
+		else { s->sm_lo = std::min(s->sm_lo, first); s->sm_hi = std::max(s->sm_hi, first + n); }
+	}
+}
+
+static void mark_written(msc_hist_set* s, uint64_t first, uint64_t n) {
+	if (s->sparse || n == 0) return;
+	if (s->written.size() < s->capacity) s->written.resize(s->capacity, 0);
+	for (uint64_t i = first; i < first + n && i < s->capacity; i++) s->written[i] = 1;
+	mark_stale(s, first, n);
+}
+
+// pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
+static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
+	mark_written(s, first, n);
 	std::vector<MscSlotScalars> h(n);
 	HIP_TRY(ctx, hipMemcpy2DAsync(h.data(), sizeof(MscSlotScalars), s->scalars + first * s->scalar_stride, s->scalar_stride,
 	                              sizeof(MscSlotScalars), n, hipMemcpyDeviceToHost, ctx->stream));
@@ -456,6 +481,110 @@ static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_
 }
 
 
+
+// Compaction of dense slots into sparse slots (k_sparse_count + k_sparse_write): dense slots [d_first, d_first + n) of `dense`
+// become slots [s_first, s_first + n) of the sparse set `sp`. need_only: just report how many entries they would take.
+static int sparsify_slots(msc_ctx* ctx, const msc_hist_set* dense, uint64_t d_first, msc_hist_set* sp, uint64_t s_first, uint64_t n, uint64_t* need_only) {
+	const MscLayout& L = dense->L;
+	int r;
+	const uint64_t B = std::min<uint64_t>(n, 16384);
+	if ((r = ensure(ctx, ctx->sp_counts, B * MSC_SPARSE_SUB * 2 * sizeof(uint64_t)))) return r;
+	if ((r = ensure(ctx, ctx->sp_cumbase, B * MSC_SPARSE_SUB * sizeof(uint64_t)))) return r;
+	std::vector<uint64_t> counts, cumbase;
+	if (need_only) *need_only = 0;
+	for (uint64_t b0 = 0; b0 < n; b0 += B) {
+		const uint64_t nb = std::min(B, n - b0);
+		const uint8_t* src = dense->bins + (d_first + b0) * L.slot_bytes;
+		HIP_TRY(ctx, msc_launch_sparse_count(ctx->stream, src, L, dense->dtype, (uint32_t)nb, (uint64_t*)ctx->sp_counts.p));
+		counts.resize(nb * MSC_SPARSE_SUB * 2);
+		HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (need_only) {
+			for (uint64_t i = 0; i < nb * MSC_SPARSE_SUB; i++) *need_only += counts[i * 2];
+			continue;
+		}
+		cumbase.assign(nb * MSC_SPARSE_SUB, 0);
+		for (uint64_t i = 0; i < nb; i++) {
+			MscSparseHdr h{};
+			uint64_t cnt = 0, ex = 0;
+			for (int w = 0; w < MSC_SPARSE_SUB; w++) {
+				h.split[w] = (uint32_t)cnt;
+				cumbase[i * MSC_SPARSE_SUB + w] = ex;
+				cnt += counts[(i * MSC_SPARSE_SUB + w) * 2];
+				ex += counts[(i * MSC_SPARSE_SUB + w) * 2 + 1];
+			}
+			h.split[MSC_SPARSE_SUB] = (uint32_t)cnt;
+			h.nnz = (uint32_t)cnt;
+			if (sp->ent_used + cnt > sp->ent_capacity)
+				return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, slot %llu needs %llu)",
+				            (unsigned long long)sp->ent_used, (unsigned long long)sp->ent_capacity, (unsigned long long)(s_first + b0 + i), (unsigned long long)cnt);
+			h.off = sp->ent_used;
+			sp->ent_used += cnt;
+			sp->hdr_host[s_first + b0 + i] = h;
+			sp->max_nnz = std::max(sp->max_nnz, h.nnz);
+		}
+		HIP_TRY(ctx, hipMemcpyAsync(sp->hdr + s_first + b0, sp->hdr_host.data() + s_first + b0, nb * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_cumbase.p, cumbase.data(), cumbase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_sparse_write(ctx->stream, src, L, dense->dtype, (uint32_t)nb, sp->hdr, s_first + b0, (const uint64_t*)ctx->sp_cumbase.p, sp->ent, sp->cum));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // cumbase / counts are reused by the next batch
+	}
+	return MSC_OK;
+}
+
+// The sparse mirror of a dense set: nullptr where the sparse layout does not exist (histograms under 64 KiB) or
+// cannot be allocated. Refreshes the written slots of the stale hull; when the append-only arena runs out, the mirror is rebuilt
+// compactly from every written slot.
+static int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out) {
+	*out = nullptr;
+	static const bool disabled = getenv("MSC_NO_SPARSE_MIRROR") != nullptr;
+	if (set->sparse) { *out = set; return MSC_OK; }
+	if (disabled || set->sp_mirror_unavailable || set->L.S % MSC_SPARSE_SUB != 0 || set->k > 15 || set->written.empty()) return MSC_OK;
+	// runs of written slots inside [lo, hi)
+	auto runs_of = [&](uint64_t lo, uint64_t hi) {
+		std::vector<std::pair<uint64_t, uint64_t> > runs;
+		for (uint64_t i = lo; i < hi;) {
+			if (!set->written[i]) { i++; continue; }
+			uint64_t j = i;
+			while (j < hi && set->written[j]) j++;
+			runs.emplace_back(i, j - i);
+			i = j;
+		}
+		return runs;
+	};
+	int r;
+	for (int attempt = 0; attempt < 2; attempt++) {
+		uint64_t lo = set->sm_lo, hi = set->sm_hi;
+		if (!set->sp_mirror) { lo = 0; hi = set->capacity; }
+		if (lo >= hi) break;
+		const auto runs = runs_of(lo, hi);
+		uint64_t need = 0;
+		for (const auto& run : runs) {
+			uint64_t nr = 0;
+			if ((r = sparsify_slots(ctx, set, run.first, nullptr, 0, run.second, &nr))) return r;
+			need += nr;
+		}
+		if (set->sp_mirror && set->sp_mirror->ent_used + need > set->sp_mirror->ent_capacity) {
+			// arena full (slots rewritten many times leave their old entries behind): start over, compactly
+			msc_hist_set_destroy(set->sp_mirror);
+			set->sp_mirror = nullptr;
+			continue;
+		}
+		if (!set->sp_mirror) {
+			msc_hist_set* m = nullptr;
+			const uint64_t arena = need + need / 2 + (1u << 16);
+			if (msc_hist_set_create_sparse(ctx, set->k, set->dtype, set->capacity, arena, &m) != MSC_OK) { set->sp_mirror_unavailable = true; return MSC_OK; }
+			set->sp_mirror = m;
+		}
+		for (const auto& run : runs)
+			if ((r = sparsify_slots(ctx, set, run.first, set->sp_mirror, run.first, run.second, nullptr))) return r;
+		set->sm_lo = set->sm_hi = 0;
+		break;
+	}
+	set->sp_mirror->max_count = set->max_count;
+	set->sp_mirror->max_sum = set->max_sum;
+	*out = set->sp_mirror;
+	return MSC_OK;
+}
 
 // Direct sparse build (k_sparse_build_sort): returns 1 when the batch does not qualify (a sequence with > 32768 k-mers,
 // segments not grouped by sequence, or MSC_NO_SORT_BUILD set) and the scratch + compaction path must be used instead.
@@ -540,9 +669,6 @@ static int build_sparse(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, ui
 	std::vector<uint64_t> sbeg(n_seqs + 1, 0);
 	for (uint64_t j = 0; j < n_segs; j++) sbeg[seg_seq[j] + 1]++;
 	for (uint64_t i = 0; i < n_seqs; i++) sbeg[i + 1] += sbeg[i];
-	if ((r = ensure(ctx, ctx->sp_counts, B * MSC_SPARSE_SUB * 2 * sizeof(uint64_t)))) return r;
-	if ((r = ensure(ctx, ctx->sp_cumbase, B * MSC_SPARSE_SUB * sizeof(uint64_t)))) return r;
-	std::vector<uint64_t> counts, cumbase;
 	for (uint64_t b0 = 0; b0 < n_seqs; b0 += B) {
 		const uint64_t nb = std::min(B, n_seqs - b0);
 		const uint64_t s0 = sbeg[b0], s1 = sbeg[b0 + nb];
@@ -551,33 +677,7 @@ static int build_sparse(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, ui
 		if ((r = msc_hist_build_packed(ctx, sc, 0, nb, packed, n_bases, sseq.data(), seg_start + s0, seg_end + s0, s1 - s0, eff_len + b0,
 		                               one_mers ? one_mers + 4 * b0 : nullptr)))
 			return r;
-		HIP_TRY(ctx, msc_launch_sparse_count(ctx->stream, sc->bins, L, set->dtype, (uint32_t)nb, (uint64_t*)ctx->sp_counts.p));
-		counts.resize(nb * MSC_SPARSE_SUB * 2);
-		HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		cumbase.assign(nb * MSC_SPARSE_SUB, 0);
-		for (uint64_t i = 0; i < nb; i++) {
-			MscSparseHdr h{};
-			uint64_t n = 0, ex = 0;
-			for (int w = 0; w < MSC_SPARSE_SUB; w++) {
-				h.split[w] = (uint32_t)n;
-				cumbase[i * MSC_SPARSE_SUB + w] = ex;
-				n += counts[(i * MSC_SPARSE_SUB + w) * 2];
-				ex += counts[(i * MSC_SPARSE_SUB + w) * 2 + 1];
-			}
-			h.split[MSC_SPARSE_SUB] = (uint32_t)n;
-			h.nnz = (uint32_t)n;
-			if (set->ent_used + n > set->ent_capacity)
-				return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, slot %llu needs %llu)",
-				            (unsigned long long)set->ent_used, (unsigned long long)set->ent_capacity, (unsigned long long)(first_slot + b0 + i), (unsigned long long)n);
-			h.off = set->ent_used;
-			set->ent_used += n;
-			set->hdr_host[first_slot + b0 + i] = h;
-		}
-		HIP_TRY(ctx, hipMemcpyAsync(set->hdr + first_slot + b0, set->hdr_host.data() + first_slot + b0, nb * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_cumbase.p, cumbase.data(), cumbase.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, msc_launch_sparse_write(ctx->stream, sc->bins, L, set->dtype, (uint32_t)nb, set->hdr, first_slot + b0, (const uint64_t*)ctx->sp_cumbase.p,
-		                                     set->ent, set->cum));
+		if ((r = sparsify_slots(ctx, sc, 0, set, first_slot + b0, nb, nullptr))) return r;
 		// the scalar record (mag, length, sums, max, 1-mers, stddev, overflow) is the dense slot's
 		HIP_TRY(ctx, hipMemcpy2DAsync(set->scalars + (first_slot + b0) * set->scalar_stride, set->scalar_stride, sc->scalars, sc->scalar_stride,
 		                              sizeof(MscSlotScalars), nb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -714,10 +814,7 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // sbeg, ids, meta and b live on this stack frame
 		set->max_count = std::max(set->max_count, b[0]);
 		set->max_sum = std::max(set->max_sum, b[1]);
-		if (set->digest && n_seqs) {                         // as refresh_bounds: these slots are stale in the digest mirror
-			if (set->dg_lo >= set->dg_hi) { set->dg_lo = first_slot; set->dg_hi = first_slot + n_seqs; }
-			else { set->dg_lo = std::min(set->dg_lo, first_slot); set->dg_hi = std::max(set->dg_hi, first_slot + n_seqs); }
-		}
+		mark_written(set, first_slot, n_seqs);               // as refresh_bounds: these slots are stale in the mirrors
 		return MSC_OK;
 	}
 	HIP_TRY(ctx, msc_launch_fill(ctx->stream, set->bins, L, first_slot, n_seqs));
@@ -933,10 +1030,7 @@ static int inherit_bounds(msc_hist_set* dst, uint64_t ds, const msc_hist_set* sr
 	dst->max_count = std::max(dst->max_count, src->max_count);
 	dst->max_sum = std::max(dst->max_sum, src->max_sum);
 	if (dst->sparse) dst->max_nnz = std::max(dst->max_nnz, src->hdr_host[ss].nnz);
-	if (dst->digest) {
-		if (dst->dg_lo >= dst->dg_hi) { dst->dg_lo = ds; dst->dg_hi = ds + 1; }
-		else { dst->dg_lo = std::min(dst->dg_lo, ds); dst->dg_hi = std::max(dst->dg_hi, ds + 1); }
-	}
+	mark_written(dst, ds, 1);
 	return MSC_OK;
 }
 
@@ -999,10 +1093,9 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 	// host-side bounds: nothing copied can exceed the source set's own maxima
 	dst->max_count = std::max(dst->max_count, src->max_count);
 	dst->max_sum = std::max(dst->max_sum, src->max_sum);
-	if (dst->digest) {
-		if (dst->dg_lo >= dst->dg_hi) { dst->dg_lo = lo; dst->dg_hi = (uint64_t)hi + 1; }
-		else { dst->dg_lo = std::min<uint64_t>(dst->dg_lo, lo); dst->dg_hi = std::max<uint64_t>(dst->dg_hi, (uint64_t)hi + 1); }
-	}
+	if (dst->written.size() < dst->capacity) dst->written.resize(dst->capacity, 0);
+	for (uint64_t i = 0; i < n; i++) dst->written[dst_slots[i]] = 1;
+	mark_stale(dst, lo, (uint64_t)hi + 1 - lo);
 	return MSC_OK;
 }
 
@@ -1207,6 +1300,42 @@ int validate_pair(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* q
 	return MSC_OK;
 }
 
+// Which merge kernel scores a query list against candidate lists -- one rule for sparse sets and for the sparse mirrors of dense
+// sets, so a pair gets the same kernel (hence the same evaluation order of the FP64 divergence sums) in every route:
+//   SPK_LDS     whole lists in LDS (MSC_SPARSE_LDS=1; kept for comparison), 32-bit range, one record per candidate
+//   SPK_MP      merge-path chunks, 32-bit range (counts < 2^16, sums < 2^31), one record per candidate
+//   SPK_GENERIC lane per index sub-range straight from global memory, 64-bit running values, 16 records per candidate
+enum SparseKernel { SPK_LDS = 0, SPK_MP = 1, SPK_GENERIC = 2 };
+SparseKernel pick_sparse_kernel(const msc_hist_set* c_sp, const msc_hist_set* q_sp, uint64_t q_slot, uint64_t max_count, bool wide) {
+	static const bool want_lds = getenv("MSC_SPARSE_LDS") != nullptr;
+	static const bool no_mp = getenv("MSC_SPARSE_NO_MP") != nullptr;
+	const uint64_t q_nnz = q_sp->hdr_host[q_slot].nnz;
+	if (want_lds && !wide && max_count < 65536 && c_sp->L.nbins >= 64 && ((size_t)(q_nnz + 128) + 4ull * (c_sp->max_nnz + 128)) * 8 <= 96 * 1024) return SPK_LDS;
+	if (!no_mp && !wide && max_count < 65536 && q_nnz + c_sp->max_nnz <= msc_sparse_mp_max_entries()) return SPK_MP;
+	return SPK_GENERIC;
+}
+uint32_t sparse_records(SparseKernel k) { return k == SPK_GENERIC ? MSC_SPARSE_SUB : 1; }
+const char* sparse_kernel_name(SparseKernel k) { return k == SPK_LDS ? "k_pair_sparse_lds" : k == SPK_MP ? "k_pair_sparse_mp" : "k_pair_sparse"; }
+
+// candidates [off, off + mc) (or the device slot list d_slots) of the sparse set / mirror c_sp against slot q_slot of q_sp; the
+// scalar records are those of the sets the lists belong to (a mirror has none of its own)
+hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* c_sp, const uint8_t* c_scalars, uint64_t c_stride, const uint32_t* d_slots,
+                              uint64_t off, uint32_t mc, const msc_hist_set* q_sp, uint64_t q_slot, const uint8_t* q_scal, uint64_t nbins, int use_window,
+                              uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order) {
+	const MscSparseHdr* c_hdr = c_sp->hdr + (d_slots ? 0 : off);
+	const uint8_t* c_scal = c_scalars + (d_slots ? 0 : off * c_stride);
+	const uint32_t q_nnz = q_sp->hdr_host[q_slot].nnz;
+	if (k == SPK_LDS)
+		return msc_launch_pair_sparse_lds(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
+		                                  q_nnz, c_sp->max_nnz, use_window, min_len, max_len, partials, div_tables, div_partials, order, ctx->num_cus);
+	if (k == SPK_MP)
+		return msc_launch_pair_sparse_mp(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
+		                                 use_window, min_len, max_len, partials, div_tables, div_partials, order, ctx->num_cus,
+		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz));
+	return msc_launch_pair_sparse(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
+	                              use_window, min_len, max_len, partials, div_tables, div_partials, order);
+}
+
 // Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
 int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	int r = validate_pair(ctx, rq.cands, rq.qset, rq.q_slot, rq.cand_slots, rq.m);
@@ -1234,17 +1363,21 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		return MSC_OK;
 	}
 	const bool sp = cs->sparse;
-	// Whole-list LDS merge kernel (MSC_SPARSE_LDS=1; superseded by the merge-path kernel below, kept for comparison): lists must fit
-	// the LDS budget and the 32-bit arithmetic range; one record per candidate
-	static const bool want_sp_lds = getenv("MSC_SPARSE_LDS") != nullptr;
-	const bool sp_lds = sp && want_sp_lds && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 && L.nbins >= 64 &&
-	                    ((size_t)(rq.qset->hdr_host[rq.q_slot].nnz + 128) + 4ull * (cs->max_nnz + 128)) * 8 <= 96 * 1024;
-	// lists of any length in the 32-bit arithmetic range: the merge-path kernel (chunks of the merged order staged per wave), one record per candidate
-	static const bool no_sp_mp = getenv("MSC_SPARSE_NO_MP") != nullptr;
-	const bool sp_mp = sp && !sp_lds && !no_sp_mp && !needs_wide(rq.cands, rq.qset) && std::max(rq.cands->max_count, rq.qset->max_count) < 65536 &&
-	                   (uint64_t)rq.qset->hdr_host[rq.q_slot].nnz + cs->max_nnz <= msc_sparse_mp_max_entries();
-	if (sp) ctx->last_kernel = sp_lds ? "k_pair_sparse_lds" : sp_mp ? "k_pair_sparse_mp" : "k_pair_sparse";
-	const uint32_t PS = sp ? ((sp_lds || sp_mp) ? 1 : MSC_SPARSE_SUB) : L.S;          // partial records per candidate
+	// The divergence statistics of a DENSE set are scored on its sparse mirror by the same merge kernels a sparse set uses (one
+	// evaluation order in every route); the dense streaming kernel then only produces the integer reductions. Histograms too small
+	// for the sparse layout (< 64 KiB) keep the table form inside the streaming kernel.
+	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
+	if (sp) { c_sp = cs; q_sp = rq.qset; }
+	else if (need_div) {
+		if ((r = ensure_sparse_mirror(ctx, cs, &c_sp)) || (r = ensure_sparse_mirror(ctx, rq.qset, &q_sp))) return r;
+		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
+	}
+	const bool mirror_div = !sp && c_sp != nullptr;
+	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
+	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
+	if (sp) ctx->last_kernel = sparse_kernel_name(spk);
+	const uint32_t SPN = sparse_records(spk);                         // records per candidate the merge kernel writes
+	const uint32_t PS = sp ? SPN : L.S;                               // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
@@ -1259,8 +1392,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
 	if (need_div) {
-		if ((r = ensure(ctx, ctx->div_tables, chunk * (sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
-		if ((r = ensure(ctx, ctx->div_partials, chunk * PS * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? SPN : PS) * 16)) != MSC_OK) return r;
+		if (mirror_div && (r = ensure(ctx, ctx->sp_partials, chunk * SPN * sizeof(MscPartial))) != MSC_OK) return r;
 	}
 	if (!rq.only_tiles) {
 		if ((r = ensure(ctx, ctx->pair_out, chunk * sizeof(MscPairOut))) != MSC_OK) return r;
@@ -1281,31 +1415,21 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (sp_lds) {
-			HIP_TRY(ctx, msc_launch_pair_sparse_lds(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
-			                                        rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.qset->hdr_host[rq.q_slot].nnz,
-			                                        cs->max_nnz, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p,
-			                                        need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order, ctx->num_cus));
-		} else if (sp_mp) {
-			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
-			                                       rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,
-			                                       (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr,
-			                                       need_div ? ctx->div_partials.p : nullptr, rq.order, ctx->num_cus,
-			                                       (uint32_t)(rq.qset->hdr_host[rq.q_slot].nnz + cs->max_nnz)));
-		} else if (sp) {
-			HIP_TRY(ctx, msc_launch_pair_sparse(ctx->stream, cs->ent, cs->cum, cs->hdr + (rq.cand_slots ? 0 : off), c_scal, cs->scalar_stride, d_slots, mc,
-			                                    rq.qset->ent, rq.qset->cum, rq.qset->hdr + rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len, rq.max_len,
-			                                    (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr,
-			                                    need_div ? ctx->div_partials.p : nullptr, rq.order));
+		if (sp) {
+			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
+			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order));
 		} else if (wide) {
 			HIP_TRY(ctx, msc_launch_pair_tiles_wide(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
-			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_partials.p : nullptr, rq.order));
+			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, inline_div ? ctx->div_partials.p : nullptr, rq.order));
 		} else {
 			HIP_TRY(ctx, msc_launch_pair_tiles(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
-			                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, need_div ? ctx->div_tables.p : nullptr,
-			                                   need_div ? ctx->div_partials.p : nullptr, rq.order));
+			                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, inline_div ? ctx->div_tables.p : nullptr,
+			                                   inline_div ? ctx->div_partials.p : nullptr, rq.order));
 		}
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (mirror_div)        // the divergence sums of this chunk, from the lists of the same slots (outside the streaming kernel's timing)
+			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
+			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order));
 		if (rq.only_tiles) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 			break;
@@ -1313,7 +1437,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
-		ea.div_partials = need_div ? ctx->div_partials.p : nullptr;
+		ea.div_partials = inline_div ? ctx->div_partials.p : nullptr;
+		if (need_div && c_sp) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = SPN; ea.div_base = L.nbins; }
 		ea.S = PS;
 		ea.sparse_base = sp ? L.nbins : 0;
 		ea.m = mc;
@@ -1452,7 +1577,16 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const int nf = __builtin_popcountll(feat_mask);
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
-	const bool simple = !(want & MSC_FEAT_DIV) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
+	// divergence statistics in the Q x M pass: the integer reductions come from the streaming kernel below, the two FP64 sums from
+	// one merge pass per query over the sparse mirrors, queued behind it -- the same kernel, hence the same values,
+	// as a 1 x M pass per query
+	const bool want_div = (want & MSC_FEAT_DIV) != 0;
+	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
+	if (want_div && !cands->sparse && n_q > 1 && L.nbins == L.padded_bins && !needs_wide(cands, qset)) {
+		if ((r = ensure_sparse_mirror(ctx, cands, &c_sp)) || (r = ensure_sparse_mirror(ctx, qset, &q_sp))) return r;
+		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
+	}
+	const bool simple = (!want_div || c_sp) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
 	// Sparse sets: one merge-path pass per query, but queued back to back into one [n_q][m] record array with ONE epilogue and one
 	// copy back -- no host round trip between the passes.
 	static const bool no_sp_multi = getenv("MSC_SPARSE_NO_MULTI") != nullptr;
@@ -1596,6 +1730,14 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
 	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * n_rec * rec_bytes))) return r;
+	SparseKernel spk = SPK_MP;
+	if (want_div) {          // one kernel for the whole block: merge-path unless some query's lists are out of its range
+		for (uint64_t q = 0; q < n_q; q++) if (pick_sparse_kernel(c_sp, q_sp, q_slots[q], mc_, false) != SPK_MP) spk = SPK_GENERIC;
+		const uint32_t spn = sparse_records(spk);
+		if ((r = ensure(ctx, ctx->div_tables, chunk * 256 * 16))) return r;
+		if ((r = ensure(ctx, ctx->div_partials, n_q * chunk * spn * 16))) return r;
+		if ((r = ensure(ctx, ctx->sp_partials, chunk * spn * sizeof(MscPartial)))) return r;
+	}
 	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
@@ -1625,9 +1767,15 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (want_div)
+			for (uint64_t q = 0; q < n_q; q++)
+				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
+				                                qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->sp_partials.p,
+				                                ctx->div_tables.p, (double*)ctx->div_partials.p + q * mc * sparse_records(spk) * 2, order));
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
+		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = sparse_records(spk); ea.div_base = L.nbins; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
 		ea.S = n_rec;

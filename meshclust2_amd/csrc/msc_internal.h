@@ -105,6 +105,11 @@ struct MscEpilogueArgs {
 	const MscBatchSeg* segs;
 	const uint32_t* pair_seg;
 	uint64_t sparse_base;             // 4^k when the partials come from k_pair_sparse (sums over the union only), else 0
+	// divergence statistics from the sparse merge kernels (sparse sets, and dense sets through their sparse mirror): per pair
+	// div_direct_n records of {jd, js} summed over the union of stored bins, relative to the (1, 1) term; div_base = 4^k adds it back
+	const double* div_direct;         // [pairs][div_direct_n][2], pair index = the virtual candidate index
+	uint32_t div_direct_n;
+	uint64_t div_base;
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip kernel files)

@@ -905,15 +905,18 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
 	const Side& second = a.order == MSC_ORDER_CAND_FIRST ? qry : cand;
-	if (a.sparse_base) {
-		// k_pair_sparse summed over the union of stored bins only; every other bin is (1, 1)
-		t.dot += a.sparse_base;
-		if (a.div_partials) {
-			const double pp = 1.0 / (double)first.mag, pq = 1.0 / (double)second.mag;
-			const double avg = 0.5 * (pp + pq);
-			t.jd += (double)a.sparse_base * ((pp - pq) * log(pp / pq));
-			t.js += (double)a.sparse_base * (pp * log(pp / avg) + pq * log(pq / avg));
-		}
+	// k_pair_sparse summed over the union of stored bins only; every other bin is (1, 1)
+	if (a.sparse_base) t.dot += a.sparse_base;
+	if (a.div_direct) {
+		// The divergence statistics of EVERY route come from the sparse merge kernels (a dense set is scored through its sparse
+		// mirror): one evaluation order whatever the layout or the batching, so equal pairs give bit-equal values.
+		const double* d = a.div_direct + (uint64_t)c * a.div_direct_n * 2;
+		double jd = 0.0, js = 0.0;
+		for (uint32_t r = 0; r < a.div_direct_n; r++) { jd += d[2 * r]; js += d[2 * r + 1]; }
+		const double pp = 1.0 / (double)first.mag, pq = 1.0 / (double)second.mag;
+		const double avg = 0.5 * (pp + pq);
+		t.jd = jd + (double)a.div_base * ((pp - pq) * log(pp / pq));
+		t.js = js + (double)a.div_base * (pp * log(pp / avg) + pq * log(pq / avg));
 	}
 
 	MscPairOut po;

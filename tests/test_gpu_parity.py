@@ -276,6 +276,73 @@ def test_multi_query_pass_equals_single_query_passes(ctx, dtype, k, nq):
         assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))
 
 
+@pytest.mark.parametrize("dtype,k,nq,length", [(32, 9, 16, 1000), (16, 9, 16, 1000), (8, 9, 20, 1000), (16, 8, 5, 3000), (32, 8, 3, 2000), (64, 9, 4, 800)])
+def test_divergence_statistics_are_the_same_in_every_route(ctx, oracle, dtype, k, nq, length):
+    """jefferey_divergence / jensen_shannon are FP64 sums over 4^k bins; every route scores them with the ONE merge kernel over
+    sorted (bin, value) lists (a dense set through its sparse mirror), so the dense 1 x M pass, the dense Q x M
+    pass (which no longer falls back to one k_pair_tiles pass per query), the batched update stage and a sparse set of the same
+    sequences return BIT-IDENTICAL values and decisions -- tied candidates stay tied whatever the route. Against the oracle the
+    values hold 1e-9 (predict/Feature.cpp:984-1009,1231-1263). Includes a tandem repeat whose counts pass the 16 x 16 term table
+    and (8-bit) saturate, and rewritten slots (the mirror refreshes what was written)."""
+    seqs, _ = synth.families(7300 + k + dtype, 44, length, family=11, length_jitter=length // 8)
+    seqs = list(seqs)
+    seqs[5] = seqs[5][:200] + b"ACG" * 130 + seqs[5][200:]          # counts ~130 for three k-mers (past the 16 x 16 term table)
+    seqs[6] = seqs[6][:100] + b"AC" * 300 + seqs[6][100:]           # counts ~300: saturates uint8_t bins
+    n = len(seqs)
+    dense = api.HistogramSet(ctx, k, dtype, n + 2)
+    sparse = api.HistogramSet(ctx, k, dtype, n + 2, sparse_entries=sum(len(s_) for s_ in seqs) * 2 + 4096)
+    dense.build(seqs)
+    sparse.build(seqs)
+    slow = api.Feature.from_text(ctx, weights_text("weights_cfg5_k9.txt"), 0)          # the reference-trained cfg5 model: uses jensen_shannon
+    div_mask = (1 << 7) | (1 << 29)
+    mask = FAST_MASK
+    cands = np.arange(n, dtype=np.uint32)[::-1].copy()
+    qs = (np.arange(nq, dtype=np.uint32) * 3) % n
+    multi = api.score_multi(ctx, slow, dense, cands, dense, qs, feat_mask=mask)
+    if nq >= 8:
+        assert "k_pair_tiles" not in ctx.last_kernel_info()[0], ctx.last_kernel_info()          # the digest kernel, not one 1 x M pass per query
+    oh = {int(q): oracle.hist(seqs[int(q)], k, dtype) for q in qs[:3]}
+    ohc = [oracle.hist(seqs[int(c)], k, dtype) for c in cands]
+    for i, q in enumerate(qs):
+        one = slow.compute(dense, cands, dense, int(q))
+        raw_d = api.pair_features_raw(ctx, dense, cands, dense, int(q), mask)
+        raw_s = api.pair_features_raw(ctx, sparse, cands, sparse, int(q), mask)
+        sp = slow.compute(sparse, cands, sparse, int(q))
+        assert np.array_equal(multi["raw"][i], raw_d), (i, "Q x M vs 1 x M")
+        assert np.array_equal(raw_d, raw_s), (i, "dense vs sparse")
+        assert np.array_equal(multi["sum"][i], one["sum"]) and np.array_equal(one["sum"], sp["sum"]), i
+        assert np.array_equal(multi["close"][i], (np.round(one["csum"]) > 0).astype(np.uint8))
+        if int(q) in oh:
+            for j, c in enumerate(cands):
+                for bit, col in ((7, 3), (29, 10)):
+                    assert raw_d[j][col] == pytest.approx(oracle.raw_feature(1 << bit, ohc[j], oh[int(q)]), rel=1e-9, abs=1e-14), (q, c, bit)
+    # both argument orders
+    a = api.pair_features_raw(ctx, dense, cands, dense, 2, div_mask, api.ORDER_QUERY_FIRST)
+    b = api.pair_features_raw(ctx, sparse, cands, sparse, 2, div_mask, api.ORDER_QUERY_FIRST)
+    assert np.array_equal(a, b)
+    # the operators: window, filter, batched update == per-centre calls == the sparse layout
+    for cutoff in (0.9, 0.6):
+        td, ts = api.Trainer(ctx, slow, cutoff), api.Trainer(ctx, slow, cutoff)
+        w = np.array([c for c in range(n) if c != 4], dtype=np.uint32)
+        f1, bp1, bs1, im1 = td.get_close(dense, w, dense, 4)
+        f2, bp2, bs2, im2 = ts.get_close(sparse, w, sparse, 4)
+        assert np.array_equal(f1, f2) and (bp1, bs1, im1) == (bp2, bs2, im2)
+    # rewritten slots: the mirror follows (clone + assign into the tail slots, then an in-place rebuild of slot 0)
+    for hs in (dense, sparse):
+        hs.clone_from(n, hs, 5)
+        hs.assign_from(n, hs, 6)
+        hs.clone_from(n + 1, hs, 7)
+        hs.build([seqs[9]], first_slot=0)
+    tail = np.array([n, n + 1, 0, 9], dtype=np.uint32)
+    a = api.pair_features_raw(ctx, dense, tail, dense, n, div_mask)
+    b = api.pair_features_raw(ctx, sparse, tail, sparse, n, div_mask)
+    assert np.array_equal(a, b) and a[0][0] == 0.0 and np.array_equal(a[2], a[3])
+    multi = api.score_multi(ctx, slow, dense, tail, dense, np.array([n, 0, n + 1], dtype=np.uint32), feat_mask=div_mask)
+    assert np.array_equal(multi["raw"][0], a)
+    for h in list(oh.values()) + ohc:
+        oracle.lib().orc_hist_free(h)
+
+
 @pytest.mark.parametrize("tq,slots,p16", [(4, 2, 1), (4, 3, 0), (4, 3, 1), (4, 4, 1), (8, 2, 0), (8, 3, 1), (8, 4, 0), (8, 4, 1)])
 def test_multi_ring_variants(tq, slots, p16):
     """The LDS-DMA ring form of the Q x M kernel (query tile 4 or 8, 2-4 ring slots per wave, the deepest one past 64 KiB of
@@ -493,10 +560,7 @@ def test_sparse_sets_equal_dense_sets(ctx, dtype, k, length):
             a = api.pair_features_raw(ctx, sparse, cands, sparse, q, FAST_MASK, order)
             b = api.pair_features_raw(ctx, dense, cands, dense, q, FAST_MASK, order)
             for c, (name, _) in enumerate(FEATS):
-                if name in ("jefferey_divergence", "jensen_shannon"):
-                    assert np.allclose(a[:, c], b[:, c], rtol=1e-9, atol=1e-14), (name, q)
-                else:
-                    assert np.array_equal(a[:, c], b[:, c]), (name, q)
+                assert np.array_equal(a[:, c], b[:, c]), (name, q)          # the divergences too: one merge kernel scores them in both layouts
     wts = "weights_k9_u32.txt" if dtype == 32 else "weights_k5_u16_slow.txt"
     fs, fd = api.Feature.from_text(ctx, weights_text(wts), 0), api.Feature.from_text(ctx, weights_text(wts), 0)
     rs, rd = api.Feature.from_text(ctx, weights_text(wts), 1), api.Feature.from_text(ctx, weights_text(wts), 1)
