@@ -71,6 +71,10 @@ struct msc_hist_set {
 	mutable uint64_t sm_lo = 0, sm_hi = 0;
 	mutable bool sp_mirror_unavailable = false;
 	std::vector<uint8_t> written;         // dense sets: slot holds a histogram (unwritten slots are never sparsified)
+	// effective lengths as the host last learnt them (len_known[i] != 0): Trainer::get_close / filter / merge derive their length
+	// window from the query's length, and reading it back from the device costs a stream round trip per call
+	mutable std::vector<uint64_t> len_host;
+	mutable std::vector<uint8_t> len_known;
 	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
 	bool sparse = false;
 	uint2* ent = nullptr;
@@ -458,7 +462,17 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 	}
 }
 
+static void forget_lengths(const msc_hist_set* s, uint64_t first, uint64_t n) {
+	for (uint64_t i = first; i < first + n && i < s->len_known.size(); i++) s->len_known[i] = 0;
+}
+static void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len) {
+	if (s->len_known.size() < s->capacity) { s->len_known.resize(s->capacity, 0); s->len_host.resize(s->capacity, 0); }
+	s->len_host[slot] = len;
+	s->len_known[slot] = 1;
+}
+
 static void mark_written(msc_hist_set* s, uint64_t first, uint64_t n) {
+	forget_lengths(s, first, n);
 	if (s->sparse || n == 0) return;
 	if (s->written.size() < s->capacity) s->written.resize(s->capacity, 0);
 	for (uint64_t i = first; i < first + n && i < s->capacity; i++) s->written[i] = 1;
@@ -472,9 +486,10 @@ static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_
 	HIP_TRY(ctx, hipMemcpy2DAsync(h.data(), sizeof(MscSlotScalars), s->scalars + first * s->scalar_stride, s->scalar_stride,
 	                              sizeof(MscSlotScalars), n, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	for (const auto& r : h) {
-		s->max_count = std::max(s->max_count, r.max_count);
-		s->max_sum = std::max(s->max_sum, r.sum);
+	for (uint64_t i = 0; i < n; i++) {
+		s->max_count = std::max(s->max_count, h[i].max_count);
+		s->max_sum = std::max(s->max_sum, h[i].sum);
+		learn_length(s, first + i, h[i].length);
 	}
 	if (s->sparse) for (uint64_t i = first; i < first + n; i++) s->max_nnz = std::max(s->max_nnz, s->hdr_host[i].nnz);
 	return MSC_OK;
@@ -815,6 +830,7 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 		set->max_count = std::max(set->max_count, b[0]);
 		set->max_sum = std::max(set->max_sum, b[1]);
 		mark_written(set, first_slot, n_seqs);               // as refresh_bounds: these slots are stale in the mirrors
+		for (uint64_t i = 0; i < n_seqs; i++) learn_length(set, first_slot + i, eff_len[i]);
 		return MSC_OK;
 	}
 	HIP_TRY(ctx, msc_launch_fill(ctx->stream, set->bins, L, first_slot, n_seqs));
@@ -991,6 +1007,18 @@ extern "C" int msc_hist_info_get(msc_ctx* ctx, const msc_hist_set* set, uint64_t
 	return MSC_OK;
 }
 
+// effective length of a slot: from the host-side cache when a writer left it there, else read back once
+static int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len) {
+	int r = check_slot(ctx, set, slot);
+	if (r) return r;
+	if (slot < set->len_known.size() && set->len_known[slot]) { *len = set->len_host[slot]; return MSC_OK; }
+	msc_hist_info hi;
+	if ((r = msc_hist_info_get(ctx, set, slot, &hi))) return r;
+	learn_length(set, slot, hi.length);
+	*len = hi.length;
+	return MSC_OK;
+}
+
 extern "C" int msc_hist_set_id(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, uint64_t id) {
 	int r = check_slot(ctx, set, slot);
 	if (r) return r;
@@ -1031,6 +1059,7 @@ static int inherit_bounds(msc_hist_set* dst, uint64_t ds, const msc_hist_set* sr
 	dst->max_sum = std::max(dst->max_sum, src->max_sum);
 	if (dst->sparse) dst->max_nnz = std::max(dst->max_nnz, src->hdr_host[ss].nnz);
 	mark_written(dst, ds, 1);
+	if (ss < src->len_known.size() && src->len_known[ss]) learn_length(dst, ds, src->len_host[ss]);      // clone, set and copy all carry the length over
 	return MSC_OK;
 }
 
@@ -1094,7 +1123,11 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 	dst->max_count = std::max(dst->max_count, src->max_count);
 	dst->max_sum = std::max(dst->max_sum, src->max_sum);
 	if (dst->written.size() < dst->capacity) dst->written.resize(dst->capacity, 0);
-	for (uint64_t i = 0; i < n; i++) dst->written[dst_slots[i]] = 1;
+	for (uint64_t i = 0; i < n; i++) {
+		dst->written[dst_slots[i]] = 1;
+		if (src_slots[i] < src->len_known.size() && src->len_known[src_slots[i]]) learn_length(dst, dst_slots[i], src->len_host[src_slots[i]]);
+		else forget_lengths(dst, dst_slots[i], 1);
+	}
 	mark_stale(dst, lo, (uint64_t)hi + 1 - lo);
 	return MSC_OK;
 }
@@ -1827,14 +1860,14 @@ extern "C" int msc_get_close(msc_ctx* ctx, const msc_model* model, double cutoff
 	if (m && !close_flags) return fail(ctx, MSC_ERR_INVALID_ARG, "close_flags is NULL");
 	int r = check_slot(ctx, qset, q_slot);
 	if (r) return r;
-	msc_hist_info qi;
-	if ((r = msc_hist_info_get(ctx, qset, q_slot, &qi))) return r;
+	uint64_t q_len = 0;
+	if ((r = slot_length(ctx, qset, q_slot, &q_len))) return r;
 	ScoreRequest rq;
 	rq.model = model; rq.cands = cands; rq.cand_slots = cand_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot;
 	rq.order = MSC_ORDER_CAND_FIRST;                              // feat->compute(*pt, *p), cluster/Trainer.cpp:49
 	rq.use_window = 1;
-	rq.min_len = (uint64_t)((double)qi.length * cutoff);          // uint64_t min_len = p->get_length() * cutoff;  :39
-	rq.max_len = (uint64_t)((double)qi.length / cutoff);          // uint64_t max_len = p->get_length() / cutoff;  :40
+	rq.min_len = (uint64_t)((double)q_len * cutoff);              // uint64_t min_len = p->get_length() * cutoff;  :39
+	rq.max_len = (uint64_t)((double)q_len / cutoff);              // uint64_t max_len = p->get_length() / cutoff;  :40
 	rq.flags_out = close_flags;
 	rq.reduce_mode = MSC_REDUCE_GET_CLOSE;
 	MscReduceOut ro;
@@ -1853,14 +1886,14 @@ extern "C" int msc_filter(msc_ctx* ctx, const msc_model* model, double cutoff, c
 	if (m && !keep) return fail(ctx, MSC_ERR_INVALID_ARG, "keep is NULL");
 	int r = check_slot(ctx, centre_set, centre_slot);
 	if (r) return r;
-	msc_hist_info ci;
-	if ((r = msc_hist_info_get(ctx, centre_set, centre_slot, &ci))) return r;
+	uint64_t c_len = 0;
+	if ((r = slot_length(ctx, centre_set, centre_slot, &c_len))) return r;
 	ScoreRequest rq;
 	rq.model = model; rq.cands = pts; rq.cand_slots = pt_slots; rq.m = m; rq.qset = centre_set; rq.q_slot = centre_slot;
 	rq.order = MSC_ORDER_QUERY_FIRST;                             // classify(p, pt.first), cluster/Trainer.cpp:133
 	rq.use_window = 1;
-	rq.min_len = (uint64_t)((double)ci.length * trainer_get_id(cutoff));      // :126-127
-	rq.max_len = (uint64_t)((double)ci.length / trainer_get_id(cutoff));
+	rq.min_len = (uint64_t)((double)c_len * trainer_get_id(cutoff));          // :126-127
+	rq.max_len = (uint64_t)((double)c_len / trainer_get_id(cutoff));
 	rq.flags_out = keep;                                          // kept  <=>  in window && round(classify) != 0
 	if ((r = run_score(ctx, rq))) return r;
 	if (n_kept) { uint64_t n = 0; for (uint64_t i = 0; i < m; i++) n += keep[i]; *n_kept = n; }
@@ -1877,8 +1910,8 @@ extern "C" int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff, co
 	const uint64_t cur_slot = centre_slots ? centre_slots[current] : (uint64_t)current;
 	int r = check_slot(ctx, centres, cur_slot);
 	if (r) return r;
-	msc_hist_info ci;
-	if ((r = msc_hist_info_get(ctx, centres, cur_slot, &ci))) return r;
+	uint64_t c_len = 0;
+	if ((r = slot_length(ctx, centres, cur_slot, &c_len))) return r;
 	std::vector<uint32_t> slots((size_t)(last - begin + 1));
 	for (int64_t i = begin; i <= last; i++) slots[(size_t)(i - begin)] = centre_slots ? centre_slots[i] : (uint32_t)i;
 	std::vector<uint8_t> flags(slots.size());
@@ -1886,8 +1919,8 @@ extern "C" int msc_merge(msc_ctx* ctx, const msc_model* model, double cutoff, co
 	rq.model = model; rq.cands = centres; rq.cand_slots = slots.data(); rq.m = slots.size(); rq.qset = centres; rq.q_slot = cur_slot;
 	rq.order = MSC_ORDER_CAND_FIRST;                              // feat->compute(*cen, *p), cluster/Trainer.cpp:93
 	rq.use_window = 1;
-	rq.min_len = (uint64_t)((double)ci.length * trainer_get_id(cutoff));
-	rq.max_len = (uint64_t)((double)ci.length / trainer_get_id(cutoff));
+	rq.min_len = (uint64_t)((double)c_len * trainer_get_id(cutoff));
+	rq.max_len = (uint64_t)((double)c_len / trainer_get_id(cutoff));
 	rq.flags_out = flags.data();
 	rq.reduce_mode = MSC_REDUCE_MERGE;
 	rq.reduce_begin = begin;
