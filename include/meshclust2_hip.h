@@ -107,6 +107,9 @@ int         msc_device_name(const msc_ctx* ctx, char* buf, size_t cap);
 int         msc_synchronize(msc_ctx* ctx);
 /* Wall-clock of the dominant kernel (pair_tiles) of the LAST scoring call, from HIP events on the ctx stream (ms). */
 int         msc_last_kernel_ms(const msc_ctx* ctx, float* pair_tiles_ms, float* total_ms);
+/* The events behind msc_last_kernel_ms cost four records per 1 x M call: a step-serial caller (the accumulate loop issues one
+ * Trainer::get_close per step) switches them off; msc_last_kernel_ms then fails with MSC_ERR_INVALID_ARG. Default: on. */
+int         msc_set_kernel_timing(msc_ctx* ctx, int on);
 /* Number of streaming-kernel launches that pair_tiles_ms sums over (large calls are chunked). */
 int         msc_last_kernel_launches(const msc_ctx* ctx);
 /* Which streaming kernel the LAST scoring call ran (its name is copied to buf) and how many queries one HBM read of a

@@ -54,6 +54,10 @@ class Context:
         self.check(self.lib.msc_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_kernel_timing(self, on):
+        """the HIP events behind last_kernel_ms: off for step-serial loops (four event records per call)"""
+        self.check(self.lib.msc_set_kernel_timing(self.h, 1 if on else 0))
+
     def last_kernel_launches(self):
         return self.lib.msc_last_kernel_launches(self.h)
 

@@ -357,6 +357,7 @@ def main(argv=None):
     headers, seqs = read_fasta(args.fasta)
     plan = shard.ShardPlan(len(seqs), world, block=1000)
     ctx = api.Context(local_rank)
+    ctx.set_kernel_timing(False)          # one get_close per step: no per-call event records
     feat = api.Feature.from_text(ctx, text, 0)
     x = Exchange(dist, rank, world, device="cuda", stage_cpu=world > 1 and backend_name != "nccl")
     cluster(lambda: GpuEngine(api, ctx, k, dtype, [seqs[g] for g in plan.local_globals(rank)], feat, sim), plan, x, rank, headers, sim, args.delta,

@@ -31,6 +31,7 @@ struct msc_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
 	bool have_timing = false;
+	bool timing = true;                      // record the HIP events behind msc_last_kernel_ms (msc_set_kernel_timing)
 	uint32_t last_partial_stride = 0;        // partial records per candidate written by the last run_score
 	float tiles_ms_accum = 0.f;
 	int tiles_launches = 0;
@@ -229,6 +230,13 @@ extern "C" int msc_device_name(const msc_ctx* ctx, char* buf, size_t cap) {
 extern "C" int msc_synchronize(msc_ctx* ctx) {
 	if (!ctx) return MSC_ERR_INVALID_ARG;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_set_kernel_timing(msc_ctx* ctx, int on) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	ctx->timing = on != 0;
+	if (!ctx->timing) ctx->have_timing = false;
 	return MSC_OK;
 }
 
@@ -1441,13 +1449,13 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const uint8_t* q_scal = rq.qset->scalars + rq.q_slot * rq.qset->scalar_stride;
 	std::vector<MscPairOut> po_host;
 	int first_err = 0;
-	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
 		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
 		const uint32_t* d_slots = rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (sp) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order));
@@ -1459,12 +1467,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			                                   rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, inline_div ? ctx->div_tables.p : nullptr,
 			                                   inline_div ? ctx->div_partials.p : nullptr, rq.order));
 		}
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (mirror_div)        // the divergence sums of this chunk, from the lists of the same slots (outside the streaming kernel's timing)
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order));
 		if (rq.only_tiles) {
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+			if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 			break;
 		}
 		MscEpilogueArgs ea;
@@ -1493,14 +1501,17 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		ea.pair_out = (MscPairOut*)ctx->pair_out.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
 		if (rq.reduce_mode >= 0) {
-			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
-			                               (uint8_t*)ctx->flags.p + 64, (MscReduceOut*)ctx->flags.p));
+			// the reduce kernel writes its record and the close flags straight into page-locked host memory the device can address
+			// (no copy command behind the kernel): [reduce record (64 B)][close flags]
 			constexpr size_t kRo = 64;
-			static_assert(sizeof(MscReduceOut) <= kRo, "the reduce record shares the head of the flags buffer");
+			static_assert(sizeof(MscReduceOut) <= kRo, "the reduce record sits in front of the flags");
 			if ((r = ensure_pinned(ctx, ctx->pin_down, kRo + mc)) != MSC_OK) return r;
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_down.p, ctx->flags.p, kRo + (rq.flags_out ? mc : 0), hipMemcpyDeviceToHost, ctx->stream));
+			uint8_t* down = nullptr;
+			HIP_TRY(ctx, hipHostGetDevicePointer((void**)&down, ctx->pin_down.p, 0));
+			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
+			                               rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down));
 		}
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (rq.singles_out) HIP_TRY(ctx, hipMemcpyAsync(rq.singles_out + off * ns, ctx->singles.p, (size_t)mc * ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (rq.combos_out) HIP_TRY(ctx, hipMemcpyAsync(rq.combos_out + off * nc, ctx->combos.p, (size_t)mc * nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1516,7 +1527,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			if (rq.flags_out) memcpy(rq.flags_out, (const uint8_t*)ctx->pin_down.p + kRo, mc);
 		}
 		float t = 0;
-		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
+		if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
 		if (need_po) {
 			for (uint32_t i = 0; i < mc; i++) {
 				const MscPairOut& p = po_host[i];

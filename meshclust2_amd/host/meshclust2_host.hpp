@@ -38,6 +38,7 @@ public:
 	Context(const Context&) = delete;
 	Context& operator=(const Context&) = delete;
 	msc_ctx* get() const { return h_; }
+	void set_kernel_timing(bool on) { check(msc_set_kernel_timing(h_, on ? 1 : 0)); }
 	void check(int rc) const { if (rc != MSC_OK) throw Error(rc, msc_last_error(h_)); }
 private:
 	msc_ctx* h_ = nullptr;

@@ -306,6 +306,7 @@ int main(int argc, char** argv) {
 	try {
 		const auto t_start = std::chrono::steady_clock::now();
 		msc::Context ctx(device);
+		ctx.set_kernel_timing(false);          // the accumulate loop is one get_close per step: no per-call event records
 		std::vector<std::string> headers, seqs;
 		std::vector<size_t> file_first;                // index of every file's first record (find_k averages per file, then over the files)
 		for (const auto& f : files) { file_first.push_back(seqs.size()); read_fasta(f, headers, seqs, single_file); }
