@@ -45,7 +45,7 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
 	DevBuf segs, pair_seg, dist;
@@ -206,6 +206,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->sp_chunk_off);
 	release(ctx->sp_chunk_cum);
 	release(ctx->sp_partials);
+	release(ctx->grp_pairs);
+	release(ctx->grp_self);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
@@ -1159,9 +1161,10 @@ extern "C" int msc_hist_import_done(msc_ctx* ctx, msc_hist_set* set, uint64_t fi
 int msc_feat_is_sim(uint64_t f) {      // Feature<T>::feat_is_sim, predict/Feature.cpp:549-663
 	switch (f) {
 	case MSC_FEAT_NORMALIZED_VECTORS: case MSC_FEAT_PEARSON_COEFF: case MSC_FEAT_INTERSECTION: case MSC_FEAT_KULCZYNSKI2: case MSC_FEAT_SIMRATIO:
+	case MSC_FEAT_SIM_MM:
 		return 1;
 	case MSC_FEAT_MANHATTAN: case MSC_FEAT_EUCLIDEAN: case MSC_FEAT_EMD: case MSC_FEAT_LENGTHD: case MSC_FEAT_JEFFEREY_DIV:
-	case MSC_FEAT_JENSEN_SHANNON:
+	case MSC_FEAT_JENSEN_SHANNON: case MSC_FEAT_RRE_K_R:
 		return 0;
 	default:
 		return -1;     // the other 23 statistics of predict/Feature.h are `extraslow` only: out of scope
@@ -1391,6 +1394,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	uint64_t want = rq.feat_mask;
 	if (rq.model) for (int i = 0; i < ns; i++) want |= rq.model->h.single_flag[i];
 	const bool need_div = (want & MSC_FEAT_DIV) != 0 && !rq.only_tiles;
+	const bool need_grp = (want & MSC_FEAT_GROUPS) != 0 && !rq.only_tiles;      // sim_mm / rre_k_r: 4-bin group statistics, list form only
 	const int tb = msc_div_table_dim(L);
 	const bool wide = needs_wide(rq.cands, rq.qset);
 	ctx->tiles_ms_accum = 0.f;
@@ -1409,10 +1413,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// for the sparse layout (< 64 KiB) keep the table form inside the streaming kernel.
 	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
 	if (sp) { c_sp = cs; q_sp = rq.qset; }
-	else if (need_div) {
+	else if (need_div || need_grp) {
 		if ((r = ensure_sparse_mirror(ctx, cs, &c_sp)) || (r = ensure_sparse_mirror(ctx, rq.qset, &q_sp))) return r;
 		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
 	}
+	if (need_grp && !c_sp)
+		return fail(ctx, MSC_ERR_UNSUPPORTED, "sim_mm / rre_k_r are scored on sorted (bin, value) lists: they need histograms of at least 64 KiB (k=%d, dtype=%d)", cs->k, cs->dtype);
 	const bool mirror_div = !sp && c_sp != nullptr;
 	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
@@ -1436,6 +1442,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if ((r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? SPN : PS) * 16)) != MSC_OK) return r;
 		if (mirror_div && (r = ensure(ctx, ctx->sp_partials, chunk * SPN * sizeof(MscPartial))) != MSC_OK) return r;
+	}
+	if (need_grp) {
+		if ((r = ensure(ctx, ctx->grp_pairs, chunk * 32 * sizeof(double))) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->grp_self, (chunk + 1) * 16 * sizeof(double))) != MSC_OK) return r;      // [candidates][16] then the query's 16
 	}
 	if (!rq.only_tiles) {
 		if ((r = ensure(ctx, ctx->pair_out, chunk * sizeof(MscPairOut))) != MSC_OK) return r;
@@ -1471,6 +1481,13 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (mirror_div)        // the divergence sums of this chunk, from the lists of the same slots (outside the streaming kernel's timing)
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order));
+		if (need_grp) {
+			HIP_TRY(ctx, msc_launch_pair_sparse_groups(ctx->stream, c_sp->ent, c_sp->hdr + (d_slots ? 0 : off), cs->scalars + (d_slots ? 0 : off * cs->scalar_stride),
+			                                           cs->scalar_stride, d_slots, mc, q_sp->ent, q_sp->hdr + rq.q_slot, rq.use_window, rq.min_len, rq.max_len,
+			                                           (double*)ctx->grp_pairs.p));
+			HIP_TRY(ctx, msc_launch_sparse_self_markov(ctx->stream, c_sp->ent, c_sp->hdr, d_slots, off, mc, (double*)ctx->grp_self.p));
+			HIP_TRY(ctx, msc_launch_sparse_self_markov(ctx->stream, q_sp->ent, q_sp->hdr, nullptr, rq.q_slot, 1, (double*)ctx->grp_self.p + (uint64_t)chunk * 16));
+		}
 		if (rq.only_tiles) {
 			if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 			break;
@@ -1480,6 +1497,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		ea.partials = (const MscPartial*)ctx->partials.p;
 		ea.div_partials = inline_div ? ctx->div_partials.p : nullptr;
 		if (need_div && c_sp) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = SPN; ea.div_base = L.nbins; }
+		if (need_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + (uint64_t)chunk * 16; }
 		ea.S = PS;
 		ea.sparse_base = sp ? L.nbins : 0;
 		ea.m = mc;
@@ -1548,7 +1566,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	return MSC_OK;
 }
 
-const uint64_t kSupportedFeats = MSC_FEAT_SLOW;
+const uint64_t kSupportedFeats = MSC_FEAT_SLOW | MSC_FEAT_GROUPS;
 
 
 double trainer_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }      // cluster/Trainer.h:35
@@ -1630,11 +1648,12 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure_sparse_mirror(ctx, cands, &c_sp)) || (r = ensure_sparse_mirror(ctx, qset, &q_sp))) return r;
 		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
 	}
-	const bool simple = (!want_div || c_sp) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
+	const bool want_grp = (want & MSC_FEAT_GROUPS) != 0;      // sim_mm / rre_k_r: one 1 x M pass per query (run_score)
+	const bool simple = !want_grp && (!want_div || c_sp) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
 	// Sparse sets: one merge-path pass per query, but queued back to back into one [n_q][m] record array with ONE epilogue and one
 	// copy back -- no host round trip between the passes.
 	static const bool no_sp_multi = getenv("MSC_SPARSE_NO_MULTI") != nullptr;
-	const bool sparse_multi = cands->sparse && qset->sparse && !no_sp_multi && !(want & MSC_FEAT_DIV) && n_q > 1 && !needs_wide(cands, qset) &&
+	const bool sparse_multi = cands->sparse && qset->sparse && !no_sp_multi && !(want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) && n_q > 1 && !needs_wide(cands, qset) &&
 	                          std::max(cands->max_count, qset->max_count) < 65536 && n_q * m <= 0x7fffffffull &&
 	                          n_q * m * sizeof(MscPartial) <= (4096ull << 20) && !getenv("MSC_SPARSE_NO_MP") && !getenv("MSC_SPARSE_LDS");
 	if (sparse_multi) {
@@ -1659,14 +1678,14 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 		}
 		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p : nullptr;
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		for (uint64_t q = 0; q < n_q; q++)
 			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
 			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,
 			                                       (MscPartial*)ctx->partials.p + q * m, nullptr, nullptr, order, ctx->num_cus,
 			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz)));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
@@ -1693,7 +1712,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (sum_out) HIP_TRY(ctx, hipMemcpyAsync(sum_out, ctx->soa_sum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (csum_out) HIP_TRY(ctx, hipMemcpyAsync(csum_out, ctx->soa_csum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (close_out) HIP_TRY(ctx, hipMemcpyAsync(close_out, ctx->soa_close.p, n_q * m, hipMemcpyDeviceToHost, ctx->stream));
@@ -1702,7 +1721,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		HIP_TRY(ctx, hipMemcpyAsync(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;
-		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = (int)n_q; ctx->have_timing = true; }
+		if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = (int)n_q; ctx->have_timing = true; }
 		if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
 		if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
 		if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
@@ -1794,13 +1813,13 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
 	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 16) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
 	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
-	HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
 		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
 		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
 		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, need_emd, ctx->partials.p, ctx->num_cus));
@@ -1810,7 +1829,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		else
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (want_div)
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
@@ -1844,7 +1863,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
 		const size_t rows = (size_t)n_q;
 		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
@@ -1853,7 +1872,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;
-		if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
+		if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
 		(void)whole;
 	}
 	int32_t first_err = 0;
@@ -2107,7 +2126,7 @@ extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uin
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	float t = 0;
-	if (hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = 1; ctx->have_timing = true; }
+	if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = 1; ctx->have_timing = true; }
 	*nearest_pos = ro.best_pos;
 	return MSC_OK;
 }
@@ -2160,7 +2179,7 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	uint64_t want = 0;
 	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
-	if (no_batch || pts->sparse || centres->sparse || (want & MSC_FEAT_DIV) || needs_wide(pts, centres))
+	if (no_batch || pts->sparse || centres->sparse || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(pts, centres))
 		return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
 
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2312,7 +2331,7 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	uint64_t want = 0;
 	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
-	if (no_batch || centres->sparse || (want & MSC_FEAT_DIV) || needs_wide(centres, centres) || n > 0x7fffffffull) {
+	if (no_batch || centres->sparse || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(centres, centres) || n > 0x7fffffffull) {
 		for (uint64_t i = 0; i < n; i++) {
 			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[i]);
 			if (r) return r;

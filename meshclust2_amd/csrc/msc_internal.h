@@ -110,6 +110,11 @@ struct MscEpilogueArgs {
 	const double* div_direct;         // [pairs][div_direct_n][2], pair index = the virtual candidate index
 	uint32_t div_direct_n;
 	uint64_t div_base;
+	// statistics over 4-bin groups (sim_mm through markov, rre_k_r; k_pair_sparse_groups / k_sparse_self_markov): 16 partial
+	// records per pair / per histogram, summed in sub-range order by the epilogue
+	const double* grp_pairs;          // [pairs][16][2] = {markov, rre}
+	const double* grp_self_c;         // [m_per_query or m][16]: markov(c, c) of every candidate of the launch (index = candidate position)
+	const double* grp_self_q;         // [n_queries or 1][16]: markov(q, q)
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip kernel files)
@@ -187,6 +192,10 @@ hipError_t msc_launch_sparse_scatter(hipStream_t st, const void* ent, const MscS
 hipError_t msc_launch_sparse_mean_count(hipStream_t st, int dtype, const uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m, uint64_t* counts);
 hipError_t msc_launch_sparse_mean_write(hipStream_t st, int dtype, uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m,
                                         const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum);
+hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars, uint64_t scalar_stride,
+                                         const uint32_t* cand_slots, uint32_t m, const void* q_ent, const MscSparseHdr* q_hdr, int use_window, uint64_t min_len,
+                                         uint64_t max_len, double* out);
+hipError_t msc_launch_sparse_self_markov(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, uint64_t first_slot, uint32_t m, double* out);
 hipError_t msc_launch_colsum(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins,
                              const uint32_t* member_slots, uint32_t m, void* rounded_out /*T, physical*/,
                              double* mean_out /*physical, nullable*/, uint64_t* floor_sum_out, uint64_t* scratch);

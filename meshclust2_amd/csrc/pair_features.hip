@@ -817,6 +817,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_tiles_multi32_ring(
 struct PairTotals {
 	uint64_t manh, dot, emd;
 	double jd, js;
+	double markov_ab, markov_aa, markov_bb, rre;      // 4-bin group statistics (a = first argument of the reference call, b = second)
 };
 
 struct Side {
@@ -868,6 +869,13 @@ __device__ double raw_stat(uint64_t flag, const PairTotals& t, const Side& a, co
 		}
 		return (double)t.dot / ((double)t.dot + sqrt((double)norm2));
 	}
+	case MSC_FEAT_RRE_K_R:             // :1029-1062, `0.5 * (op + oq)`
+		return 0.5 * t.rre;
+	case MSC_FEAT_SIM_MM: {            // :1429-1455: d_markov(a, b) = log(markov(b, a) / markov(b, b)) / b.getRealMagnitude()
+		const double d_ab = log(t.markov_ab / t.markov_bb) / (double)(b.mag - nbins);
+		const double d_ba = log(t.markov_ab / t.markov_aa) / (double)(a.mag - nbins);
+		return 1 - exp(0.5 * (d_ab + d_ba));
+	}
 	case MSC_FEAT_JEFFEREY_DIV:        // :1235-1262
 		return t.jd;
 	case MSC_FEAT_JENSEN_SHANNON:      // :988-1008, `return sum / 2`
@@ -917,6 +925,19 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 		const double avg = 0.5 * (pp + pq);
 		t.jd = jd + (double)a.div_base * ((pp - pq) * log(pp / pq));
 		t.js = js + (double)a.div_base * (pp * log(pp / avg) + pq * log(pq / avg));
+	}
+
+	if (a.grp_pairs) {
+		// 16 sub-range records per pair / per histogram, summed in sub-range order; markov(x, y) = total / 2 (predict/Feature.cpp:1392)
+		const double* g = a.grp_pairs + (uint64_t)c * 32;
+		const double* sc = a.grp_self_c + (uint64_t)ci * 16;
+		const double* sq = a.grp_self_q + (uint64_t)qi * 16;
+		double mk = 0.0, rre = 0.0, mc = 0.0, mq = 0.0;
+		for (int r = 0; r < 16; r++) { mk += g[2 * r]; rre += g[2 * r + 1]; mc += sc[r]; mq += sq[r]; }
+		t.markov_ab = mk / 2;
+		t.rre = rre;
+		t.markov_aa = a.order == MSC_ORDER_CAND_FIRST ? mc : mq;
+		t.markov_bb = a.order == MSC_ORDER_CAND_FIRST ? mq : mc;
 	}
 
 	MscPairOut po;
@@ -985,7 +1006,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogue
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
 	if (c >= a.m) return;
-	PairTotals t{0, 0, 0, 0.0, 0.0};
+	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 	for (uint32_t s = lane; s < a.S; s += 64) {
 		if (a.partials16) {
 			const u32x4 p = reinterpret_cast<const u32x4*>(a.partials16)[(uint64_t)c * a.S + s];
@@ -1015,7 +1036,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 	if (w >= a.m_per_query * nqg) return;
 	const uint32_t ci = w / nqg, qg = w % nqg;
 	const u32x4* rec = reinterpret_cast<const u32x4*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 16;
-	PairTotals t{0, 0, 0, 0.0, 0.0};
+	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 	for (uint32_t i = lane; i < a.S * 16; i += 64) {
 		const u32x4 p = rec[i];
 		t.manh += p.x; t.dot += p.y; t.emd += p.z;
@@ -1033,7 +1054,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= a.m) return;
-	PairTotals t{0, 0, 0, 0.0, 0.0};
+	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 	for (uint32_t s = 0; s < a.S; s++) {
 		if (a.partials16) {
 			const u32x4 p = reinterpret_cast<const u32x4*>(a.partials16)[(uint64_t)c * a.S + s];

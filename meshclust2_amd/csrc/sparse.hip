@@ -341,6 +341,118 @@ __global__ void __launch_bounds__(256) k_pair_sparse(
 	if constexpr (DIV) { div_partials[((uint64_t)c * kSub + r) * 2] = jd; div_partials[((uint64_t)c * kSub + r) * 2 + 1] = js; }
 }
 
+// ------------------------------------------------------------------------------------------------ statistics over 4-bin groups
+// Feature<T>::markov (-> sim_mm) and rre_k_r (predict/Feature.cpp:1367-1393,1429-1455,1029-1062) are sums over the groups of four
+// neighbouring bins that share a (k-1)-mer prefix. A group in which both histograms hold only pseudocounts contributes exactly 0
+// to either (every factor (count - 1) vanishes; the conditional distributions are both uniform, log 1 = 0), so the sums run over
+// the groups that hold a stored bin of either list: one lane per (candidate, index sub-range) merges the two lists as
+// k_pair_sparse does -- a group never straddles a sub-range -- and closes a group when the merged order leaves it.
+struct GroupState {
+	uint32_t g;            // group (bin >> 2) being assembled, 0xffffffff = none
+	uint32_t p[4], q[4];
+	double markov, rre;
+};
+__device__ __forceinline__ void group_close(GroupState& st) {
+	if (st.g == 0xffffffffu) return;
+	const double sp = (double)((uint64_t)st.p[0] + st.p[1] + st.p[2] + st.p[3]);
+	const double sq = (double)((uint64_t)st.q[0] + st.q[1] + st.q[2] + st.q[3]);
+	const double lsp = log(sp), lsq = log(sq);
+	double ip = 0.0, iq = 0.0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const double pj = (double)st.p[j], qj = (double)st.q[j];
+		// markov: (q - 1) (log p - log psum) + (p - 1) (log q - log qsum)
+		st.markov += (double)(st.q[j] - 1u) * (log(pj) - lsp);
+		st.markov += (double)(st.p[j] - 1u) * (log(qj) - lsq);
+		// rre_k_r: p log(cp / avg) / psum + q log(cq / avg) / qsum with the conditional probabilities cp = p / psum, cq = q / qsum
+		const double cp = pj / sp, cq = qj / sq;
+		const double avg = 0.5 * (cp + cq);
+		ip += pj * log(cp / avg) / sp;
+		iq += qj * log(cq / avg) / sq;
+	}
+	st.rre += ip;
+	st.rre += iq;
+	st.g = 0xffffffffu;
+}
+__device__ __forceinline__ void group_put(GroupState& st, uint32_t bin, uint32_t pv, uint32_t qv) {
+	const uint32_t g = bin >> 2;
+	if (g != st.g) {
+		group_close(st);
+		st.g = g;
+#pragma unroll
+		for (int j = 0; j < 4; j++) { st.p[j] = 1u; st.q[j] = 1u; }
+	}
+	const uint32_t j = bin & 3u;
+	// (no dynamic register indexing)
+	st.p[0] = j == 0 ? pv : st.p[0]; st.p[1] = j == 1 ? pv : st.p[1]; st.p[2] = j == 2 ? pv : st.p[2]; st.p[3] = j == 3 ? pv : st.p[3];
+	st.q[0] = j == 0 ? qv : st.q[0]; st.q[1] = j == 1 ? qv : st.q[1]; st.q[2] = j == 2 ? qv : st.q[2]; st.q[3] = j == 3 ? qv : st.q[3];
+}
+
+// out[(c * 16 + r) * 2 + {0, 1}] = {markov total (before the reference's / 2), rre op + oq} of sub-range r of candidate c against the query
+__global__ void __launch_bounds__(256) k_pair_sparse_groups(
+    const uint2* __restrict__ c_ent, const MscSparseHdr* __restrict__ c_hdr, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+    const uint32_t* __restrict__ cand_slots, uint32_t m, const uint2* __restrict__ q_ent, const MscSparseHdr* __restrict__ q_hdr_p, int use_window,
+    uint64_t min_len, uint64_t max_len, double* __restrict__ out) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = (uint32_t)(t / kSub), r = (uint32_t)(t % kSub);
+	if (c >= m) return;
+	const uint32_t slot = cand_slots ? cand_slots[c] : c;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+	if (use_window && (cs->length < min_len || cs->length > max_len)) return;
+	const MscSparseHdr ch = c_hdr[slot];
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint2* P = c_ent + ch.off;
+	const uint2* Q = q_ent + qh.off;
+	uint32_t i = ch.split[r], iend = ch.split[r + 1];
+	uint32_t j = qh.split[r], jend = qh.split[r + 1];
+	GroupState st;
+	st.g = 0xffffffffu; st.markov = 0.0; st.rre = 0.0;
+	const uint32_t kInf = 0xffffffffu;
+	uint2 a = i < iend ? P[i] : make_uint2(kInf, 1u);
+	uint2 b = j < jend ? Q[j] : make_uint2(kInf, 1u);
+	while (i < iend || j < jend) {
+		const uint32_t e = a.x < b.x ? a.x : b.x;
+		const bool ta = a.x == e, tb = b.x == e;
+		group_put(st, e, ta ? a.y : 1u, tb ? b.y : 1u);
+		if (ta) { i++; a = i < iend ? P[i] : make_uint2(kInf, 1u); }
+		if (tb) { j++; b = j < jend ? Q[j] : make_uint2(kInf, 1u); }
+	}
+	group_close(st);
+	out[((uint64_t)c * kSub + r) * 2] = st.markov;
+	out[((uint64_t)c * kSub + r) * 2 + 1] = st.rre;
+}
+
+// markov(a, a) of single histograms (the denominators of d_markov): out[c * 16 + r] = sum over the groups of sub-range r of
+// sum_j (a_j - 1) (log a_j - log group sum)  (= Feature<T>::markov(a, a), whose two equal terms per bin are halved at the end)
+__global__ void __launch_bounds__(256) k_sparse_self_markov(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
+                                                            const uint32_t* __restrict__ slots, uint64_t first_slot, uint32_t m, double* __restrict__ out) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = (uint32_t)(t / kSub), r = (uint32_t)(t % kSub);
+	if (c >= m) return;
+	const MscSparseHdr h = hdr[slots ? slots[c] : first_slot + c];
+	const uint2* P = ent + h.off;
+	double total = 0.0;
+	uint32_t g = 0xffffffffu, v[4] = {1u, 1u, 1u, 1u};
+	auto close = [&]() {
+		if (g == 0xffffffffu) return;
+		const double ls = log((double)((uint64_t)v[0] + v[1] + v[2] + v[3]));
+#pragma unroll
+		for (int j = 0; j < 4; j++) total += (double)(v[j] - 1u) * (log((double)v[j]) - ls);
+	};
+	for (uint32_t i = h.split[r]; i < h.split[r + 1]; i++) {
+		const uint2 e = P[i];
+		if ((e.x >> 2) != g) {
+			close();
+			g = e.x >> 2;
+			v[0] = v[1] = v[2] = v[3] = 1u;
+		}
+		const uint32_t j = e.x & 3u;
+		v[0] = j == 0 ? e.y : v[0]; v[1] = j == 1 ? e.y : v[1]; v[2] = j == 2 ? e.y : v[2]; v[3] = j == 3 ? e.y : v[3];
+	}
+	close();
+	out[(uint64_t)c * kSub + r] = total;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ mean of sparse members
@@ -824,4 +936,22 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 	if (T == 1024) return launch_sparse_mp<1024>(MSC_MP_ARGS);
 	return launch_sparse_mp<2048>(MSC_MP_ARGS);
 #undef MSC_MP_ARGS
+}
+
+// candidates (slot list or the first m slots behind c_hdr) against one query list: 16 x {markov, rre} partials per candidate
+hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars, uint64_t scalar_stride,
+                                         const uint32_t* cand_slots, uint32_t m, const void* q_ent, const MscSparseHdr* q_hdr, int use_window, uint64_t min_len,
+                                         uint64_t max_len, double* out) {
+	if (m == 0) return hipSuccess;
+	const uint64_t threads = (uint64_t)m * kSub;
+	k_pair_sparse_groups<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>((const uint2*)c_ent, c_hdr, cand_scalars, scalar_stride, cand_slots, m,
+	                                                                                    (const uint2*)q_ent, q_hdr, use_window, min_len, max_len, out);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_self_markov(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, uint64_t first_slot, uint32_t m, double* out) {
+	if (m == 0) return hipSuccess;
+	const uint64_t threads = (uint64_t)m * kSub;
+	k_sparse_self_markov<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, first_slot, m, out);
+	return hipGetLastError();
 }

@@ -329,6 +329,19 @@ double orc_raw_feature(uint64_t flag, const orc_hist* a, const orc_hist* b, int*
 		return BY_TYPE(dt, simratio_u8(p, q, N), simratio_u16(p, q, N), simratio_u32(p, q, N), simratio_u64(p, q, N));
 	case ORC_FEAT_JENSEN_SHANNON:
 		return BY_TYPE(dt, jensen_shannon_u8(p, q, N, a->mag, b->mag), jensen_shannon_u16(p, q, N, a->mag, b->mag), jensen_shannon_u32(p, q, N, a->mag, b->mag), jensen_shannon_u64(p, q, N, a->mag, b->mag));
+	case ORC_FEAT_RRE_K_R:
+		return BY_TYPE(dt, rre_k_r_u8(p, q, N), rre_k_r_u16(p, q, N), rre_k_r_u32(p, q, N), rre_k_r_u64(p, q, N));
+	case ORC_FEAT_SIM_MM: {
+		/* Feature<T>::sim_mm + d_markov, predict/Feature.cpp:1429-1455: d_markov(a, b) = log(markov(b, a) / markov(b, b)) /
+		 * b.getRealMagnitude() (= mag - N, clutil/DivergencePoint.cpp:272-275); sim_mm = 1 - exp((d(a, b) + d(b, a)) / 2) */
+		double m_ba = BY_TYPE(dt, markov_u8(q, p, N), markov_u16(q, p, N), markov_u32(q, p, N), markov_u64(q, p, N));
+		double m_bb = BY_TYPE(dt, markov_u8(q, q, N), markov_u16(q, q, N), markov_u32(q, q, N), markov_u64(q, q, N));
+		double m_ab = BY_TYPE(dt, markov_u8(p, q, N), markov_u16(p, q, N), markov_u32(p, q, N), markov_u64(p, q, N));
+		double m_aa = BY_TYPE(dt, markov_u8(p, p, N), markov_u16(p, p, N), markov_u32(p, p, N), markov_u64(p, p, N));
+		double d_ab = log(m_ba / m_bb) / (double)(b->mag - N);
+		double d_ba = log(m_ab / m_aa) / (double)(a->mag - N);
+		return 1 - exp(0.5 * (d_ab + d_ba));
+	}
 	default:
 		return NAN;
 	}
@@ -338,10 +351,10 @@ double orc_raw_feature(uint64_t flag, const orc_hist* a, const orc_hist* b, int*
 int orc_feat_is_sim(uint64_t f) {
 	switch (f) {
 	case ORC_FEAT_NORMALIZED_VECTORS: case ORC_FEAT_PEARSON_COEFF: case ORC_FEAT_INTERSECTION:
-	case ORC_FEAT_KULCZYNSKI2: case ORC_FEAT_SIMRATIO:
+	case ORC_FEAT_KULCZYNSKI2: case ORC_FEAT_SIMRATIO: case ORC_FEAT_SIM_MM:
 		return 1;
 	case ORC_FEAT_MANHATTAN: case ORC_FEAT_EUCLIDEAN: case ORC_FEAT_JEFFEREY_DIV: case ORC_FEAT_EMD:
-	case ORC_FEAT_LENGTHD: case ORC_FEAT_JENSEN_SHANNON:
+	case ORC_FEAT_LENGTHD: case ORC_FEAT_JENSEN_SHANNON: case ORC_FEAT_RRE_K_R:
 		return 0;
 	default:
 		return -1;

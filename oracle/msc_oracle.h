@@ -34,6 +34,9 @@ extern "C" {
 #define ORC_FEAT_KULCZYNSKI2        (1ULL << 27)
 #define ORC_FEAT_SIMRATIO           (1ULL << 28)
 #define ORC_FEAT_JENSEN_SHANNON     (1ULL << 29)
+/* two of the reference's `extraslow` statistics (PRED_FEAT_ALL, predict/Predictor.h:25) that BASELINE's north_star names */
+#define ORC_FEAT_RRE_K_R            (1ULL << 14)
+#define ORC_FEAT_SIM_MM             (1ULL << 16)
 /* predict/Predictor.h:23-24 */
 #define ORC_FEAT_FAST (ORC_FEAT_EUCLIDEAN | ORC_FEAT_MANHATTAN | ORC_FEAT_INTERSECTION | ORC_FEAT_KULCZYNSKI2 | \
                        ORC_FEAT_SIMRATIO | ORC_FEAT_NORMALIZED_VECTORS | ORC_FEAT_PEARSON_COEFF | ORC_FEAT_EMD | ORC_FEAT_LENGTHD)

@@ -112,6 +112,9 @@ template <class T> double raw_feature(uint64_t flag, void* a, void* b, int k) {
 		Feature<T> f(k);
 		return f.jensen_shannon(p, q);
 	}
+	case FEAT_RRE_K_R: return Feature<T>::rre_k_r(p, q);        // predict/Feature.cpp:1029-1062
+	case FEAT_SIM_MM: return Feature<T>::sim_mm(p, q);          // :1451-1455
+	case FEAT_MARKOV: return Feature<T>::markov(p, q);          // :1367-1393
 	default: return std::nan("");
 	}
 }

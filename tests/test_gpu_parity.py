@@ -1,6 +1,8 @@
 """GPU parity proper: libmeshclust2_hip.so (through the C ABI) against the CPU oracle on the same seeded inputs and
 against the committed golden fixtures (reference outputs). Integer work is compared bit-exact; FP64 scores to 1e-9
 relative (the north-star bar is 1e-5)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ from golden_util import EXACT, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors
 from meshclust2_amd import api, synth
 
 pytestmark = pytest.mark.gpu
+C_byref = ctypes.byref
 
 # all 11 in-scope statistics (`--feat slow`); the names FAST_* are kept for the column bookkeeping below
 FAST = FEATS
@@ -184,6 +187,85 @@ def test_unsupported_inputs_fail_loudly(ctx):
         api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 1)          # hellinger: out of scope (extraslow only)
     with pytest.raises(api.MscError):
         api.Feature.create(ctx, 3, [(0, 1 << 12)], [0.0, 1.0], [(1 << 12, 0.0, 1.0)])    # markov
+
+
+G1_WEIGHTS = """k: 9
+mode: 1
+max_features: 4
+ID: 0.9
+Datatype: uint32_t
+feature_set: 81920
+
+n_combos: 3
+-0.4
+0 65536 1.7
+1 81920 -0.9
+3 16384 0.35
+
+n_singles: 2
+65536 0 0.02
+16384 0 0.5
+"""
+
+
+@pytest.mark.parametrize("dtype,k,length,layout", [(32, 9, 1000, "dense"), (32, 9, 1000, "sparse"), (8, 9, 700, "dense"), (16, 8, 3000, "dense"),
+                                                     (64, 10, 2500, "sparse"), (16, 11, 9000, "sparse")])
+def test_sim_mm_and_rre_k_r_against_the_oracle(ctx, oracle, dtype, k, length, layout):
+    """The two `extraslow` statistics BASELINE's north_star names: sim_mm (through Feature<T>::markov / d_markov) and rre_k_r
+    (predict/Feature.cpp:1367-1393,1429-1455,1029-1062), sums over the groups of four bins that share a (k-1)-mer prefix. Scored by
+    the merge kernels' group pass (a dense set through its sparse mirror): raw values, both argument orders, a model built on
+    them, get_close / filter decisions -- against the oracle, which tests/test_oracle_vs_ref.py pins to the reference's own
+    static functions. The stale magnitude of a moved centre enters through getRealMagnitude."""
+    seqs, _ = synth.families(9100 + k + dtype, 18, length, family=6, length_jitter=length // 10)
+    seqs = list(seqs) + [seqs[0], b"ACGGT" * 60 + seqs[1][:400]]
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n + 1, sparse_entries=(sum(len(s_) for s_ in seqs) * 2 + 4096) if layout == "sparse" else 0)
+    hs.build(seqs)
+    oh = [oracle.hist(s_, k, dtype) for s_ in seqs]
+    mask = (1 << 14) | (1 << 16) | (1 << 2) | (1 << 29)          # with a fast statistic and a divergence in the same call
+    cands = np.arange(n, dtype=np.uint32)[::-1].copy()
+    for q in (0, 7, n - 1):
+        for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+            raw = api.pair_features_raw(ctx, hs, cands, hs, q, mask, order)
+            for i, c in enumerate(cands):
+                a, b = (oh[c], oh[q]) if order == api.ORDER_CAND_FIRST else (oh[q], oh[c])
+                assert raw[i][0] == oracle.raw_feature(1 << 2, a, b)
+                for col, bit in ((1, 14), (2, 16), (3, 29)):
+                    exp = oracle.raw_feature(1 << bit, a, b)
+                    assert raw[i][col] == pytest.approx(exp, rel=1e-9, abs=1e-13), (q, c, bit, order)
+    assert api.pair_features_raw(ctx, hs, [n - 2], hs, 0, 1 << 16)[0][0] == 0.0          # identical sequences: sim_mm = 1 - exp(0)
+    feat = api.Feature.from_text(ctx, G1_WEIGHTS, 0)
+    pred = oracle.predictor(G1_WEIGHTS)
+    r = feat.compute(hs, cands, hs, 3)
+    for i, c in enumerate(cands):
+        s_, _, wsum = oracle.score(pred.cls, oh[c], oh[3])
+        assert np.allclose(r["singles"][i], s_, rtol=1e-8, atol=1e-11) and r["sum"][i] == pytest.approx(wsum, rel=1e-8, abs=1e-10)
+    trn = api.Trainer(ctx, feat, 0.9)
+    w = np.array([c for c in range(n) if c != 2], dtype=np.uint32)
+    flags, bp, bs, im = trn.get_close(hs, w, hs, 2)
+    of, obp, obs, oim = oracle.get_close(pred, 0.9, oh[2], [oh[c] for c in w])
+    assert np.array_equal(flags, of) and (bp, im) == (obp, oim) and bs == pytest.approx(obs, rel=1e-8)
+    assert np.array_equal(trn.filter(hs, 2, hs, w), oracle.filter_(pred, 0.9, oh[2], [oh[c] for c in w]))
+    multi = api.score_multi(ctx, feat, hs, cands, hs, [3, 5], feat_mask=(1 << 14) | (1 << 16))          # per-query passes underneath
+    assert np.array_equal(multi["sum"][0], r["sum"])
+    # a moved centre keeps its stale magnitude: clone of 4, then set(9)
+    hs.clone_from(n, hs, 4)
+    hs.assign_from(n, hs, 9)
+    oc = oracle.Hist()
+    oracle.lib().orc_hist_clone(C_byref(oh[4]), C_byref(oc))
+    oracle.lib().orc_hist_set(C_byref(oc), C_byref(oh[9]))
+    got = api.pair_features_raw(ctx, hs, [n], hs, 5, (1 << 14) | (1 << 16))[0]
+    assert got[0] == pytest.approx(oracle.raw_feature(1 << 14, oc, oh[5]), rel=1e-9) and got[1] == pytest.approx(oracle.raw_feature(1 << 16, oc, oh[5]), rel=1e-9)
+    for h in oh:
+        oracle.lib().orc_hist_free(h)
+
+
+def test_group_statistics_need_the_list_form(ctx):
+    """histograms under 64 KiB have no sparse form: sim_mm / rre_k_r are refused there, loudly"""
+    hs = api.HistogramSet(ctx, 5, 16, 2)
+    hs.build([b"ACGTTGCA" * 30, b"ACGTAGCA" * 30])
+    with pytest.raises(api.MscError, match="64 KiB"):
+        api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 16)
 
 
 def test_upload_round_trip_and_properties(ctx):
@@ -1324,6 +1406,31 @@ def test_find_k_reproduces_the_reference_rule(tmp_path):
         r = subprocess.run([exe] + names + ["--id", "0.9", "--output", str(tmp_path / "o.clstr")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         out = r.stdout.decode(errors="replace")          # too few sequences to train on: the run stops after printing its choice of k
         assert "avg length: %d\n" % avg in out and "Recommended K: %d\n" % k in out, (ci, out[-400:])
+
+
+def test_operators_without_kernel_timing(oracle):
+    """msc_set_kernel_timing(0) (what the step-serial drivers do: four event records per 1 x M call cost 18 us): every operator
+    gives the same answers, msc_last_kernel_ms reports that nothing was timed, and switching back on works."""
+    ctx = api.Context(0)
+    seqs, _ = synth.families(4242, 40, 900, family=8)
+    hs = api.HistogramSet(ctx, 8, 16, len(seqs))
+    hs.build(seqs)
+    feat = api.Feature.from_text(ctx, weights_text("weights_k8_u16.txt"), 0)
+    trn = api.Trainer(ctx, feat, 0.9)
+    w = np.arange(1, len(seqs), dtype=np.uint32)
+    want = (trn.get_close(hs, w, hs, 0), trn.filter(hs, 3, hs, w), trn.closest(hs, w[:9])[0], api.score_multi(ctx, feat, hs, w, hs, [0, 5, 9, 11])["sum"])
+    assert ctx.last_kernel_ms()[0] > 0
+    ctx.set_kernel_timing(False)
+    got = (trn.get_close(hs, w, hs, 0), trn.filter(hs, 3, hs, w), trn.closest(hs, w[:9])[0], api.score_multi(ctx, feat, hs, w, hs, [0, 5, 9, 11])["sum"])
+    with pytest.raises(api.MscError):
+        ctx.last_kernel_ms()
+    assert np.array_equal(want[0][0], got[0][0]) and want[0][1:] == got[0][1:]
+    assert np.array_equal(want[1], got[1]) and want[2] == got[2] and np.array_equal(want[3], got[3])
+    assert trn.merge(hs, w, 2, 3, 8) == trn.merge(hs, w, 2, 3, 8)
+    ctx.set_kernel_timing(True)
+    trn.get_close(hs, w, hs, 0)
+    assert ctx.last_kernel_ms()[0] > 0
+    ctx.close()
 
 
 def _run_ranks(module_args, n, tmp_path, timeout=900):

@@ -163,3 +163,24 @@ def test_training_fixture_is_what_the_reference_writes(ref):
     text, atr, ate = ref.train_class(fx["dtype"], fx["k"], [pts[a] for a, b, v in pairs], [pts[b] for a, b, v in pairs], [v for a, b, v in pairs], fx["n_train"],
                                      fx["feat_flags"], fx["min_feat"], fx["max_feat"], fx["id"])
     assert text == fx["block"] and atr == fx["train_acc"] and ate == fx["test_acc"]
+
+
+@pytest.mark.parametrize("dtype", [8, 16, 32, 64])
+@pytest.mark.parametrize("k", [2, 4, 6, 8])
+def test_extraslow_statistics_named_by_the_north_star(oracle, ref, dtype, k):
+    """sim_mm (via markov / d_markov) and rre_k_r (predict/Feature.cpp:1367-1393,1429-1455,1029-1062): `extraslow`-only in the
+    reference but named by BASELINE's north_star; the oracle's restatement equals the reference's own static
+    functions on related, unrelated, repetitive and identical pairs, in both argument orders."""
+    rng = np.random.default_rng(31 * dtype + k)
+    base = _rand_seq(rng, 1500)
+    seqs = [base, synth.to_ascii(synth.member(5, 0, 1, np.frombuffer(base, dtype=np.uint8).copy() % 4)), _rand_seq(rng, 1500), _rand_seq(rng, 700),
+            b"ACG" * 200 + _rand_seq(rng, 300), base]
+    hs = [oracle.hist(s_, k, dtype) for s_ in seqs]
+    ps = [ref.Point(dtype, s_, k) for s_ in seqs]
+    for i in range(len(seqs)):
+        for j in range(len(seqs)):
+            for name in ("rre_k_r", "sim_mm"):
+                flag = oracle.FEAT[name]
+                want = ref.raw_feature(flag, ps[i], ps[j])
+                got = oracle.raw_feature(flag, hs[i], hs[j])
+                assert got == want or (np.isnan(got) and np.isnan(want)) or got == pytest.approx(want, rel=1e-13, abs=1e-300), (name, i, j, got, want)
