@@ -45,8 +45,9 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
+	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
 	DevBuf segs, pair_seg, dist;
 	uint64_t sp_acc_bins = 0;
@@ -194,6 +195,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
+	if (ctx->sparse_mean_batch) msc_hist_set_destroy(ctx->sparse_mean_batch);
 	if (ctx->batch_scratch) msc_hist_set_destroy(ctx->batch_scratch);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
@@ -208,6 +210,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->sp_partials);
 	release(ctx->grp_pairs);
 	release(ctx->grp_self);
+	release(ctx->sp_acc_batch);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
@@ -2162,6 +2165,97 @@ static int update_centres_one_by_one(msc_ctx* ctx, const msc_model* model, doubl
 	return MSC_OK;
 }
 
+// Step 3 of the batched update stage on SPARSE sets: the rounded mean of every centre's survivors as a sparse slot of a scratch set
+// (scatter-add of the members' excesses into one 32-bit column accumulator per centre, swept in index order: the kernels of
+// mean_nearest_sparse with a centre dimension), then distance_d of every survivor to the mean of its centre -> ctx->dist[pair].
+// segs[c] = {q_slot = c, first, m} over `members` (device copies are made here), pair_seg[j] = centre of member j.
+static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, const std::vector<MscBatchSeg>& segs, const std::vector<uint32_t>& pair_seg,
+                                      const std::vector<uint32_t>& members, uint32_t nc) {
+	const MscLayout& L = pts->L;
+	const uint64_t P2 = members.size();
+	int r;
+	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	const uint64_t chunk_bins = L.nbins / n_chunks;
+	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
+	// accumulators: zero on allocation, left zero by the write kernel
+	const size_t acc_bytes = (size_t)nc * L.nbins * sizeof(uint32_t);
+	if (acc_bytes > ctx->sp_acc_batch.cap) {
+		if ((r = ensure(ctx, ctx->sp_acc_batch, acc_bytes))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->sp_acc_batch.p, 0, ctx->sp_acc_batch.cap, ctx->stream));
+	}
+	std::vector<uint32_t> m_of(nc);
+	for (uint32_t c = 0; c < nc; c++) m_of[c] = segs[c].m;
+	if ((r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) ||
+	    (r = ensure(ctx, ctx->qslots, nc * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_counts, (size_t)nc * n_chunks * 3 * sizeof(uint64_t))) ||
+	    (r = ensure(ctx, ctx->sp_chunk_off, (size_t)nc * n_chunks * sizeof(uint64_t))) || (r = ensure(ctx, ctx->sp_chunk_cum, (size_t)nc * n_chunks * sizeof(uint64_t))) ||
+	    (r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->partials, P2 * sizeof(MscPartial))) || (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
+		return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, m_of.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, pts->ent, pts->hdr, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)P2, L.nbins,
+	                                             (uint32_t*)ctx->sp_acc_batch.p));
+	HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, pts->dtype, (const uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc,
+	                                                (const uint32_t*)ctx->qslots.p, (uint64_t*)ctx->sp_counts.p));
+	std::vector<uint64_t> counts((size_t)nc * n_chunks * 3);
+	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	// headers, scalar records, floor sums and the chunks' write offsets of every mean
+	std::vector<MscSparseHdr> hdr(nc);
+	std::vector<MscSlotScalars> sc(nc);
+	std::vector<uint64_t> floor_sum(nc), off((size_t)nc * n_chunks), cb((size_t)nc * n_chunks);
+	memset(sc.data(), 0, sizeof(MscSlotScalars) * nc);
+	uint64_t used = 0;
+	uint32_t max_nnz = 0;
+	for (uint32_t c = 0; c < nc; c++) {
+		MscSparseHdr h{};
+		uint64_t n = 0, ex = 0, fl = 0;
+		for (uint32_t ch = 0; ch < n_chunks; ch++) {
+			if (ch % per_sub == 0) h.split[ch / per_sub] = (uint32_t)n;
+			const uint64_t* cnt = &counts[((size_t)c * n_chunks + ch) * 3];
+			off[(size_t)c * n_chunks + ch] = used + n;
+			cb[(size_t)c * n_chunks + ch] = ex;
+			n += cnt[0]; ex += cnt[1]; fl += cnt[2];
+		}
+		h.split[MSC_SPARSE_SUB] = (uint32_t)n;
+		h.nnz = (uint32_t)n;
+		h.off = used;
+		used += n;
+		max_nnz = std::max(max_nnz, h.nnz);
+		hdr[c] = h;
+		sc[c].sum = L.nbins + ex;          // sum of the rounded mean's bins
+		sc[c].mag = sc[c].sum;
+		sc[c].length = 1;
+		floor_sum[c] = L.nbins + fl;
+	}
+	msc_hist_set*& ms = ctx->sparse_mean_batch;
+	if (!ms || ms->k != pts->k || ms->dtype != pts->dtype || ms->capacity < nc || ms->ent_capacity < used + 1) {
+		const uint64_t cap = ms && ms->k == pts->k && ms->dtype == pts->dtype ? std::max<uint64_t>(ms->capacity, nc) : std::max<uint64_t>(nc, 256);
+		const uint64_t arena = std::max<uint64_t>(used + used / 2 + 1, ms ? ms->ent_capacity : (1u << 20));
+		if (ms) { msc_hist_set_destroy(ms); ms = nullptr; }
+		if ((r = msc_hist_set_create_sparse(ctx, pts->k, pts->dtype, cap, arena, &ms))) return r;
+	}
+	ms->ent_used = used;
+	ms->max_nnz = std::max(ms->max_nnz, max_nnz);
+	for (uint32_t c = 0; c < nc; c++) ms->hdr_host[c] = hdr[c];
+	HIP_TRY(ctx, hipMemcpyAsync(ms->hdr, hdr.data(), nc * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ms->scalars, sc.data(), nc * sizeof(MscSlotScalars), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->floor_sum.p, floor_sum.data(), nc * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), cb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, pts->dtype, (uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc, (const uint32_t*)ctx->qslots.p,
+	                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, ms->ent, ms->cum));
+	// survivors against the rounded mean of their own centre: only the |p - r| reduction of the merge kernel is used
+	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P2,
+	                                             ms->ent, ms->cum, ms->hdr, L.nbins, 0, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p,
+	                                             (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST, ctx->num_cus));
+	HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, 1, (uint32_t)P2, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p,
+	                                       (const uint32_t*)ctx->pair_seg.p, ms->scalars, ms->scalar_stride, (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // hdr, sc, floor_sum, off, cb live on this frame
+	return MSC_OK;
+}
+
 extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
                                   uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
                                   uint64_t* n_kept) {
@@ -2179,7 +2273,11 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	uint64_t want = 0;
 	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
-	if (no_batch || pts->sparse || centres->sparse || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(pts, centres))
+	// sparse sets (both): the pair-list form of the merge-path kernel takes the place of k_pair_tiles_batch, and the rounded means of a
+	// chunk of centres are built as sparse slots by the scatter / count / write kernels with a centre dimension (32-bit range)
+	const bool sp = pts->sparse && centres->sparse;
+	if (no_batch || (pts->sparse != centres->sparse) || (sp && std::max(pts->max_count, centres->max_count) >= 65536) || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) ||
+	    needs_wide(pts, centres))
 		return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
 
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2191,9 +2289,12 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	                              hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	const double id = trainer_get_id(cutoff);
-	// chunks of centres: their rounded means share one scratch set (<= 4 GiB) and their pair counts stay 32-bit
-	const uint64_t max_chunk_centres = std::max<uint64_t>(1, (4096ull << 20) / L.slot_bytes);
-	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)L.S * sizeof(MscPartial)));
+	// chunks of centres: their rounded means share one scratch set (<= 4 GiB; sparse: <= 1 GiB of 32-bit column accumulators) and
+	// their pair counts stay 32-bit
+	const uint32_t PS = sp ? 1 : L.S;          // partial records per pair
+	const uint64_t max_chunk_centres = sp ? std::max<uint64_t>(1, std::min<uint64_t>(4096, (1024ull << 20) / (L.nbins * 4)))
+	                                      : std::max<uint64_t>(1, (4096ull << 20) / L.slot_bytes);
+	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial)));
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, members, where;
 	std::vector<uint8_t> keep;
@@ -2221,20 +2322,26 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 		keep.assign(P, 0);
 		if (P) {
 			if ((r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) || (r = ensure(ctx, ctx->pair_seg, P * sizeof(uint32_t))) ||
-			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * L.S * sizeof(MscPartial))) ||
+			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * PS * sizeof(MscPartial))) ||
 			    (r = ensure(ctx, ctx->soa_close, P)) || (r = ensure(ctx, ctx->err_word, sizeof(int32_t))))
 				return r;
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, pt_slots + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
-			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
-			                                         (uint32_t)nc, max_m, centres->bins, centres->L.slot_bytes, centres->scalars, centres->scalar_stride, 1,
-			                                         (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST));
+			if (sp)
+				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p,
+				                                             (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1, (const MscBatchSeg*)ctx->segs.p,
+				                                             (const uint32_t*)ctx->pair_seg.p, (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST, ctx->num_cus));
+			else
+				HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
+				                                         (uint32_t)nc, max_m, centres->bins, centres->L.slot_bytes, centres->scalars, centres->scalar_stride, 1,
+				                                         (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST));
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
-			ea.S = L.S;
+			ea.S = PS;
+			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;
 			ea.cand_scalars = pts->scalars;
 			ea.cand_scalar_stride = pts->scalar_stride;
@@ -2282,28 +2389,32 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 		const uint64_t P2 = members.size();
 		if (P2 == 0) { c0 = c1; continue; }
 		// ---- 3. means of the survivors (exact integer column sums), rounded means as slots of a scratch set, distance_d of every survivor
-		if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc) {
-			if (ctx->batch_scratch) { msc_hist_set_destroy(ctx->batch_scratch); ctx->batch_scratch = nullptr; }
-			if ((r = msc_hist_set_create(ctx, pts->k, pts->dtype, std::min<uint64_t>(max_chunk_centres, std::max<uint64_t>(nc, 256)), &ctx->batch_scratch))) return r;
+		if (sp) {
+			if ((r = sparse_means_and_distances(ctx, pts, segs, pair_seg, members, (uint32_t)nc))) return r;
+		} else {
+			if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc) {
+				if (ctx->batch_scratch) { msc_hist_set_destroy(ctx->batch_scratch); ctx->batch_scratch = nullptr; }
+				if ((r = msc_hist_set_create(ctx, pts->k, pts->dtype, std::min<uint64_t>(max_chunk_centres, std::max<uint64_t>(nc, 256)), &ctx->batch_scratch))) return r;
+			}
+			msc_hist_set* rs = ctx->batch_scratch;
+			if ((r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) ||
+			    (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P2 * L.S * sizeof(MscPartial))) ||
+			    (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
+				return r;
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, msc_launch_colsum_batch(ctx->stream, L, pts->dtype, pts->bins, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc,
+			                                     rs->bins, (uint64_t*)ctx->floor_sum.p));
+			HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, rs->scalar_stride * nc, ctx->stream));
+			HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, pts->dtype, 0, nc, false));
+			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
+			                                         (uint32_t)nc, max_m2, rs->bins, rs->L.slot_bytes, rs->scalars, rs->scalar_stride, 0, (MscPartial*)ctx->partials.p,
+			                                         MSC_ORDER_CAND_FIRST));
+			HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)P2, pts->scalars, pts->scalar_stride,
+			                                       (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, rs->scalars, rs->scalar_stride,
+			                                       (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
 		}
-		msc_hist_set* rs = ctx->batch_scratch;
-		if ((r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) ||
-		    (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P2 * L.S * sizeof(MscPartial))) ||
-		    (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
-			return r;
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, msc_launch_colsum_batch(ctx->stream, L, pts->dtype, pts->bins, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc,
-		                                     rs->bins, (uint64_t*)ctx->floor_sum.p));
-		HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, rs->scalar_stride * nc, ctx->stream));
-		HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, pts->dtype, 0, nc, false));
-		HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
-		                                         (uint32_t)nc, max_m2, rs->bins, rs->L.slot_bytes, rs->scalars, rs->scalar_stride, 0, (MscPartial*)ctx->partials.p,
-		                                         MSC_ORDER_CAND_FIRST));
-		HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)P2, pts->scalars, pts->scalar_stride,
-		                                       (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, rs->scalars, rs->scalar_stride,
-		                                       (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
 		dist.resize(P2);
 		HIP_TRY(ctx, hipMemcpyAsync(dist.data(), ctx->dist.p, P2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2331,7 +2442,9 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	uint64_t want = 0;
 	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
-	if (no_batch || centres->sparse || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(centres, centres) || n > 0x7fffffffull) {
+	// sparse centres: the pair-list form of the merge-path kernel (32-bit range) takes the place of k_pair_tiles_batch
+	const bool sp = centres->sparse;
+	if (no_batch || (sp && centres->max_count >= 65536) || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(centres, centres) || n > 0x7fffffffull) {
 		for (uint64_t i = 0; i < n; i++) {
 			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[i]);
 			if (r) return r;
@@ -2346,7 +2459,8 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	                              hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	const double id = trainer_get_id(cutoff);
-	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)L.S * sizeof(MscPartial)));
+	const uint32_t PS = sp ? 1 : L.S;          // partial records per pair
+	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial)));
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, cand;
 	std::vector<MscPairOut> po;
@@ -2373,20 +2487,27 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 		for (uint64_t i = c0; i < c1; i++) best_out[i] = 0;
 		if (P) {
 			if ((r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) || (r = ensure(ctx, ctx->pair_seg, P * sizeof(uint32_t))) ||
-			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * L.S * sizeof(MscPartial))) ||
+			    (r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P * PS * sizeof(MscPartial))) ||
 			    (r = ensure(ctx, ctx->pair_out, P * sizeof(MscPairOut))) || (r = ensure(ctx, ctx->err_word, sizeof(int32_t))))
 				return r;
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
-			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, centres->dtype, centres->bins, centres->scalars, (const uint32_t*)ctx->slots.p,
-			                                         (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc, max_m, centres->bins, L.slot_bytes, centres->scalars,
-			                                         centres->scalar_stride, 1, (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST));
+			if (sp)
+				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, centres->ent, centres->cum, centres->hdr, centres->scalars, centres->scalar_stride,
+				                                             (const uint32_t*)ctx->slots.p, (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1,
+				                                             (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p, (MscPartial*)ctx->partials.p,
+				                                             MSC_ORDER_CAND_FIRST, ctx->num_cus));
+			else
+				HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, centres->dtype, centres->bins, centres->scalars, (const uint32_t*)ctx->slots.p,
+				                                         (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc, max_m, centres->bins, L.slot_bytes, centres->scalars,
+				                                         centres->scalar_stride, 1, (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST));
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
-			ea.S = L.S;
+			ea.S = PS;
+			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;
 			ea.cand_scalars = centres->scalars;
 			ea.cand_scalar_stride = centres->scalar_stride;

@@ -192,6 +192,16 @@ hipError_t msc_launch_sparse_scatter(hipStream_t st, const void* ent, const MscS
 hipError_t msc_launch_sparse_mean_count(hipStream_t st, int dtype, const uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m, uint64_t* counts);
 hipError_t msc_launch_sparse_mean_write(hipStream_t st, int dtype, uint32_t* acc, uint32_t n_chunks, uint64_t chunk_bins, uint32_t m,
                                         const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum);
+hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                           uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                           const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
+                                           MscPartial* partials, int order, int num_cus);
+hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
+                                           uint64_t nbins, uint32_t* acc);
+hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
+                                              const uint32_t* m_of, uint64_t* counts);
+hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
+                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum);
 hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                          const uint32_t* cand_slots, uint32_t m, const void* q_ent, const MscSparseHdr* q_hdr, int use_window, uint64_t min_len,
                                          uint64_t max_len, double* out);

@@ -527,6 +527,76 @@ __global__ void __launch_bounds__(64) k_sparse_mean_write(uint32_t* __restrict__
 	}
 }
 
+// ---- the same three steps for MANY centres at once (the update stage of a mean-shift round on sparse sets): member j belongs to
+// centre seg[j] of the chunk; accumulator, counts and offsets carry a centre dimension (acc[centre][bin]); m differs per centre.
+__global__ void __launch_bounds__(256) k_sparse_scatter_batch(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
+                                                              const uint32_t* __restrict__ slots, const uint32_t* __restrict__ seg, uint32_t n_members,
+                                                              uint64_t nbins, uint32_t* __restrict__ acc) {
+	const uint32_t j = blockIdx.x;
+	if (j >= n_members) return;
+	const MscSparseHdr h = hdr[slots[j]];
+	uint32_t* a = acc + (uint64_t)seg[j] * nbins;
+	for (uint32_t t = threadIdx.x; t < h.nnz; t += blockDim.x) {
+		const uint2 e = ent[h.off + t];
+		atomicAdd(&a[e.x], e.y - 1u);
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_count_batch(const uint32_t* __restrict__ acc, uint64_t nbins, uint64_t chunk_bins,
+                                                                const uint32_t* __restrict__ m_of, uint64_t* __restrict__ counts) {
+	const uint32_t ci = blockIdx.y, n_chunks = gridDim.x;
+	const uint32_t m = m_of[ci];
+	const uint64_t base = (uint64_t)ci * nbins + (uint64_t)blockIdx.x * chunk_bins;
+	uint64_t n = 0, ex = 0, fl = 0;
+	if (m) {
+		for (uint64_t i = threadIdx.x; i < chunk_bins; i += 64) {
+			const uint32_t E = acc[base + i];
+			if (E) {
+				const MeanBin b = mean_bin<T>(E, m);
+				if (b.r >= 2) { n++; ex += b.r - 1; }
+				fl += b.fl - 1;
+			}
+		}
+	}
+	n = wave_sum_u64(n); ex = wave_sum_u64(ex); fl = wave_sum_u64(fl);
+	if (threadIdx.x == 0) {
+		uint64_t* o = counts + ((uint64_t)ci * n_chunks + blockIdx.x) * 3;
+		o[0] = n; o[1] = ex; o[2] = fl;
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_write_batch(uint32_t* __restrict__ acc, uint64_t nbins, uint64_t chunk_bins, const uint32_t* __restrict__ m_of,
+                                                                const uint64_t* __restrict__ chunk_off, const uint64_t* __restrict__ chunk_cum,
+                                                                uint2* __restrict__ ent, uint32_t* __restrict__ cum) {
+	const uint32_t ci = blockIdx.y, n_chunks = gridDim.x;
+	const uint32_t m = m_of[ci];
+	if (m == 0) return;
+	const uint64_t bin0 = (uint64_t)blockIdx.x * chunk_bins, base = (uint64_t)ci * nbins + bin0;
+	uint64_t o = chunk_off[(uint64_t)ci * n_chunks + blockIdx.x];
+	uint32_t run = (uint32_t)chunk_cum[(uint64_t)ci * n_chunks + blockIdx.x];
+	const uint32_t lane = threadIdx.x;
+	for (uint64_t i0 = 0; i0 < chunk_bins; i0 += 64) {
+		const uint64_t i = i0 + lane;
+		uint32_t E = 0;
+		if (i < chunk_bins) { E = acc[base + i]; if (E) acc[base + i] = 0; }       // leave the accumulator clean for the next chunk of centres
+		uint32_t r = 1;
+		if (E) r = mean_bin<T>(E, m).r;
+		const bool emit = r >= 2;
+		const unsigned long long mask = __ballot(emit);
+		const uint32_t ex = emit ? r - 1 : 0;
+		const uint32_t ex_incl = wave_incl_scan(ex);
+		if (emit) {
+			const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+			ent[o + rank] = make_uint2((uint32_t)(bin0 + i), r);
+			cum[o + rank] = run + ex_incl;
+		}
+		o += (uint64_t)__popcll(mask);
+		run += (uint32_t)__builtin_amdgcn_readlane((int)ex_incl, 63);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ LDS-staged merge kernel
 // k_pair_sparse is bound by the texture-address unit: 64 lanes chase 64 private pointers, ~30 cache lines per wave load.
 // Here a WAVE owns one candidate: its entry list is staged into LDS with coalesced loads (the query list once per
@@ -653,28 +723,41 @@ __device__ __forceinline__ void mp_split(uint32_t d, uint32_t nc, uint32_t nq, C
 	j_out = j;
 }
 
-template <bool DIV, uint32_t kMpT>
+// PAIRS (the batched update stage on sparse sets, msc_update_centres / msc_merge_all): every candidate has its OWN query -- slot
+// segs[pair_seg[c]].q_slot behind q_hdr_p, with that segment's length window -- instead of the one query of a 1 x M pass.
+template <bool DIV, uint32_t kMpT, bool PAIRS = false>
 __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
     const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
-    MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order) {
+    MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
+    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr) {
+	static_assert(!(DIV && PAIRS), "the pair-list form scores the integer statistics only");
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint2* buf = s_buf[wave];
-	const MscSparseHdr qh = *q_hdr_p;
+	MscSparseHdr qh = PAIRS ? MscSparseHdr{} : *q_hdr_p;
 	const uint2* Q = q_ent + qh.off;
 	const uint32_t* CQ = q_cum + qh.off;
-	const uint32_t nq_all = qh.nnz;
+	uint32_t nq_all = qh.nnz;
 	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
 	const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t kInf = 0xffffffffu;
 	for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave; c < m; c += total_waves) {
 		const uint32_t slot = cand_slots ? cand_slots[c] : c;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
-		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		if constexpr (PAIRS) {
+			const MscBatchSeg sg = segs[pair_seg[c]];
+			if (use_window && (cs->length < sg.min_len || cs->length > sg.max_len)) continue;
+			qh = q_hdr_p[sg.q_slot];
+			Q = q_ent + qh.off;
+			CQ = q_cum + qh.off;
+			nq_all = qh.nnz;
+		} else {
+			if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		}
 		const MscSparseHdr ch = c_hdr[slot];
 		const uint2* P = c_ent + ch.off;
 		const uint32_t* CP = c_cum + ch.off;
@@ -953,5 +1036,54 @@ hipError_t msc_launch_sparse_self_markov(hipStream_t st, const void* ent, const 
 	if (m == 0) return hipSuccess;
 	const uint64_t threads = (uint64_t)m * kSub;
 	k_sparse_self_markov<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, first_slot, m, out);
+	return hipGetLastError();
+}
+
+// the pair-list form of the merge-path kernel: candidate c is scored against slot segs[pair_seg[c]].q_slot of the query set, inside
+// that segment's length window (use_window); integer statistics only, one record per candidate
+hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
+                                           uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
+                                           const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
+                                           MscPartial* partials, int order, int num_cus) {
+	if (m == 0) return hipSuccess;
+	constexpr uint32_t T = 512;
+	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));
+	uint32_t blocks = (uint32_t)num_cus * per_cu;
+	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
+	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
+                                           uint64_t nbins, uint32_t* acc) {
+	if (n_members == 0) return hipSuccess;
+	k_sparse_scatter_batch<<<dim3(n_members), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, seg, n_members, nbins, acc);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
+                                              const uint32_t* m_of, uint64_t* counts) {
+	if (n_centres == 0) return hipSuccess;
+	const dim3 grid(n_chunks, n_centres);
+	switch (dtype) {
+	case 8: k_sparse_mean_count_batch<uint8_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
+	case 16: k_sparse_mean_count_batch<uint16_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
+	case 32: k_sparse_mean_count_batch<uint32_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
+	default: k_sparse_mean_count_batch<uint64_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
+                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum) {
+	if (n_centres == 0) return hipSuccess;
+	const dim3 grid(n_chunks, n_centres);
+	switch (dtype) {
+	case 8: k_sparse_mean_write_batch<uint8_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	case 16: k_sparse_mean_write_batch<uint16_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	case 32: k_sparse_mean_write_batch<uint32_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	default: k_sparse_mean_write_batch<uint64_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+	}
 	return hipGetLastError();
 }

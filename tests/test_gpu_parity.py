@@ -906,21 +906,25 @@ def test_full_size_cfg2_properties(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("dtype,k,wts", [(16, 5, "weights_k5_u16.txt"), (32, 9, "weights_k9_u32.txt"), (16, 5, "weights_k5_u16_slow.txt"), (8, 3, "weights_k5_u16.txt")])
-def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts):
+@pytest.mark.parametrize("dtype,k,wts,sparse", [(16, 5, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", False), (16, 5, "weights_k5_u16_slow.txt", False),
+                                                 (8, 3, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", True), (16, 8, "weights_k8_u16.txt", True),
+                                                 (8, 9, "weights_k9_u8.txt", True), (64, 10, "weights_k5_u16.txt", True)])
+def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts, sparse):
     """msc_update_centres / msc_merge_all (one launch per stage for all centres of a round) == msc_filter + msc_mean_nearest /
     msc_merge centre by centre: ragged and empty lists, lists nothing survives, the divergence-statistics fallback, padded tiny
-    histograms."""
+    histograms; on sparse sets too (r02: pair-list merge-path kernel + the scatter / sweep of the rounded means with a centre
+    dimension), where the per-centre calls are the single-query kernels."""
     rng = np.random.default_rng(11 * k + dtype)
     seqs, _ = synth.families(4100 + k, 120, 600 if k > 3 else 80, family=6)
     seqs = [s[: len(s) - int(rng.integers(0, len(s) // 3))] for s in seqs]      # mixed lengths: the length window matters
     n = len(seqs)
-    pts = api.HistogramSet(ctx, k, dtype, n)
+    arena = (sum(len(s_) for s_ in seqs) * 3 + 4096) if sparse else 0
+    pts = api.HistogramSet(ctx, k, dtype, n, sparse_entries=arena)
     pts.build(seqs)
     feat = api.Feature.from_text(ctx, weights_text(wts), 0)
     trn = api.Trainer(ctx, feat, 0.9)
     nc = 37
-    cen = api.HistogramSet(ctx, k, dtype, nc)
+    cen = api.HistogramSet(ctx, k, dtype, nc, sparse_entries=arena)
     owners = rng.permutation(n)[:nc]
     for c, o in enumerate(owners):
         cen.clone_from(c, pts, int(o))
