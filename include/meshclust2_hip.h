@@ -145,7 +145,7 @@ uint64_t msc_hist_set_bytes(const msc_hist_set* set);              /* HBM footpr
  * msc_hist_info_get, clone / assign / copy, msc_pair_features_raw, msc_score(_multi), msc_get_close, msc_filter, msc_merge and
  * msc_search; it is what makes k = 11..15 possible (a dense k = 13 histogram is 64-512 MiB) and it reads 12 bytes per
  * stored bin instead of 4^k * dtype/8 per histogram. max_entries = total stored bins the set can hold (sum over slots, <= the
- * total number of k-mers). Needs 4^k * dtype/8 >= 64 KiB. msc_mean_nearest / msc_hist_upload are not available on sparse sets. */
+ * total number of k-mers). Needs 4^k * dtype/8 >= 64 KiB. msc_hist_upload and the mean_out of msc_mean_nearest are not available on sparse sets. */
 int      msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64_t capacity, uint64_t max_entries, msc_hist_set** out);
 int      msc_hist_set_is_sparse(const msc_hist_set* set);
 uint64_t msc_hist_set_entries(const msc_hist_set* set, uint64_t slot);     /* stored bins of one slot */
@@ -283,7 +283,8 @@ int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* memb
  * the survivor nearest that mean -- mean_shift_update, cluster/ClusterFactory.cpp:288-335, which the reference runs for all
  * centres of a round under `omp parallel for` (:639). nearest_pos[c] = position INSIDE centre c's list of the new centre
  * point, or -1 when nothing survives the filter; n_kept[c] (nullable) = survivors. Same results as msc_filter followed by
- * msc_mean_nearest per centre (which is also what runs for sparse sets, divergence statistics and the wide range). */
+ * msc_mean_nearest per centre (which is also what runs for divergence / group statistics, the wide range, and sparse sets with
+ * counts >= 2^16; sparse sets in the 32-bit range are batched too since r02). */
 int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
                        uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
                        uint64_t* n_kept);

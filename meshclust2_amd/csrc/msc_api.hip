@@ -1120,12 +1120,43 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 		lo = std::min(lo, dst_slots[i]);
 		hi = std::max(hi, dst_slots[i]);
 	}
-	if (dst->sparse || n > 0x7fffffffull) {          // entry lists live in an append-only arena with host bookkeeping: one at a time
+	if (n > 0x7fffffffull || (dst->sparse && src->scalar_stride != dst->scalar_stride)) {
 		for (uint64_t i = 0; i < n; i++) { const int r = msc_hist_assign(ctx, dst, dst_slots[i], src, src_slots[i]); if (r) return r; }
 		return MSC_OK;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int r;
+	if (dst->sparse) {
+		// every list is appended to the destination arena in one launch; all or nothing, so that a caller can compact and retry
+		uint64_t need = 0;
+		for (uint64_t i = 0; i < n; i++) need += src->hdr_host[src_slots[i]].nnz;
+		if (dst->ent_used + need > dst->ent_capacity)
+			return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, %llu needed)", (unsigned long long)dst->ent_used,
+			            (unsigned long long)dst->ent_capacity, (unsigned long long)need);
+		std::vector<uint64_t> off(n);
+		uint64_t o = dst->ent_used;
+		for (uint64_t i = 0; i < n; i++) { off[i] = o; o += src->hdr_host[src_slots[i]].nnz; }
+		if ((r = ensure(ctx, ctx->slots, n * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, n * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_chunk_off, n * sizeof(uint64_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, dst_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, src_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_sparse_assign_batch(ctx->stream, dst->ent, dst->cum, dst->hdr, src->ent, src->cum, src->hdr, (const uint32_t*)ctx->slots.p,
+		                                            (const uint32_t*)ctx->pair_seg.p, (const uint64_t*)ctx->sp_chunk_off.p, (uint32_t)n));
+		HIP_TRY(ctx, msc_launch_assign_scalars(ctx->stream, dst->scalars, src->scalars, dst->scalar_stride, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)n));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // off and the caller's slot arrays may go away
+		for (uint64_t i = 0; i < n; i++) {
+			MscSparseHdr h = src->hdr_host[src_slots[i]];
+			h.off = off[i];
+			dst->hdr_host[dst_slots[i]] = h;
+			dst->max_nnz = std::max(dst->max_nnz, h.nnz);
+			if (src_slots[i] < src->len_known.size() && src->len_known[src_slots[i]]) learn_length(dst, dst_slots[i], src->len_host[src_slots[i]]);
+			else forget_lengths(dst, dst_slots[i], 1);
+		}
+		dst->ent_used = o;
+		dst->max_count = std::max(dst->max_count, src->max_count);
+		dst->max_sum = std::max(dst->max_sum, src->max_sum);
+		return MSC_OK;
+	}
 	if ((r = ensure(ctx, ctx->slots, n * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, n * sizeof(uint32_t)))) return r;
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, dst_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, src_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));

@@ -1579,6 +1579,17 @@ hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* 
 	return hipGetLastError();
 }
 
+// the scalar half of msc_launch_assign_batch on its own (sparse stores: 128-byte records, no tile prefixes)
+hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const uint8_t* src_scalars, uint64_t stride_bytes, const uint32_t* dst_slots,
+                                     const uint32_t* src_slots, uint32_t n) {
+	if (n == 0) return hipSuccess;
+	const uint32_t words = (uint32_t)(stride_bytes / 8);
+	const uint64_t stotal = (uint64_t)words * n;
+	k_assign_scalars<<<dim3((unsigned)std::min<uint64_t>((stotal + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint64_t*)dst_scalars, (const uint64_t*)src_scalars,
+	                                                                                                                      dst_slots, src_slots, words, 0, stotal);
+	return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------- batched launchers (msc_update_centres)
 bool msc_batch_tiles_supported(const MscLayout& L, int dtype) { (void)L; return dtype == 8 || dtype == 16 || dtype == 32 || dtype == 64; }
 

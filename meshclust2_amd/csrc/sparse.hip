@@ -453,6 +453,26 @@ __global__ void __launch_bounds__(256) k_sparse_self_markov(const uint2* __restr
 	out[(uint64_t)c * kSub + r] = total;
 }
 
+// center->set(*next) for many centres of a sparse store at once: pair i appends a copy of src slot ss[i]'s entry list at
+// dst_off[i] of the destination arena and points dst slot ds[i]'s header at it (same sub-range offsets, same length)
+__global__ void __launch_bounds__(256) k_sparse_assign_batch(uint2* __restrict__ d_ent, uint32_t* __restrict__ d_cum, MscSparseHdr* __restrict__ d_hdr,
+                                                             const uint2* __restrict__ s_ent, const uint32_t* __restrict__ s_cum, const MscSparseHdr* __restrict__ s_hdr,
+                                                             const uint32_t* __restrict__ ds, const uint32_t* __restrict__ ss, const uint64_t* __restrict__ dst_off, uint32_t n) {
+	const uint32_t i = blockIdx.x;
+	if (i >= n) return;
+	const MscSparseHdr h = s_hdr[ss[i]];
+	const uint64_t o = dst_off[i];
+	for (uint32_t t = threadIdx.x; t < h.nnz; t += blockDim.x) {
+		d_ent[o + t] = s_ent[h.off + t];
+		d_cum[o + t] = s_cum[h.off + t];
+	}
+	if (threadIdx.x == 0) {
+		MscSparseHdr nh = h;
+		nh.off = o;
+		d_hdr[ds[i]] = nh;
+	}
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ mean of sparse members
@@ -1085,5 +1105,12 @@ hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_
 	case 32: k_sparse_mean_write_batch<uint32_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	default: k_sparse_mean_write_batch<uint64_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_assign_batch(hipStream_t st, void* d_ent, uint32_t* d_cum, MscSparseHdr* d_hdr, const void* s_ent, const uint32_t* s_cum, const MscSparseHdr* s_hdr,
+                                          const uint32_t* ds, const uint32_t* ss, const uint64_t* dst_off, uint32_t n) {
+	if (n == 0) return hipSuccess;
+	k_sparse_assign_batch<<<dim3(n), dim3(256), 0, st>>>((uint2*)d_ent, d_cum, d_hdr, (const uint2*)s_ent, s_cum, s_hdr, ds, ss, dst_off, n);
 	return hipGetLastError();
 }

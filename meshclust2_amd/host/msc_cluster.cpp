@@ -77,7 +77,9 @@ struct GpuBackend : msc::ClusterBackend {
 
 	GpuBackend(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt, double cut, uint64_t sparse_arena)
 	    : ctx(c), points(p), trn(t), k(k_), dtype(dt), cutoff(cut), centre_arena(sparse_arena) {
-		centres.reset(new msc::PointSet(ctx, k, dtype, 256, centre_arena));
+		// a sparse slot is a header and a scalar record: room for every point as its own centre costs nothing; dense slots are whole
+		// histograms, so that store starts small and doubles
+		centres.reset(new msc::PointSet(ctx, k, dtype, centre_arena ? std::max<uint64_t>(256, points.capacity()) : 256, centre_arena));
 	}
 	// relocate every live centre into a fresh store (exact copies: stale mags survive). Used to grow the slot count and,
 	// for the sparse layout, to compact the append-only entry arena.
@@ -120,8 +122,14 @@ struct GpuBackend : msc::ClusterBackend {
 		return true;
 	}
 	bool centre_set_batch(const std::vector<uint32_t>& cs, const std::vector<uint32_t>& pts) override {
-		if (centre_arena) return false;        // the sparse arena is appended to one centre at a time (with the compaction retry)
-		ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), cs.data(), points.get(), pts.data(), cs.size()));
+		// (a sparse store appends every moved centre's list to its arena in one launch, all or nothing: compact once when it runs
+		// out; if even the compacted arena cannot take the whole round, go centre by centre -- each set() frees the list it replaces)
+		try {
+			with_arena_retry([&] { ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), cs.data(), points.get(), pts.data(), cs.size())); });
+		} catch (const msc::Error& e) {
+			if (e.code != MSC_ERR_OOM || centre_arena == 0) throw;
+			return false;
+		}
 		return true;
 	}
 	bool merge_all(const std::vector<uint32_t>& cs, int delta, std::vector<int64_t>& best) override {
@@ -358,8 +366,9 @@ int main(int argc, char** argv) {
 			records[i].length = points.get_length(i);      // slot i == point handle i
 		}
 		seqs.clear();
-		// worst case every sequence stays its own centre; the slack absorbs set() appends between compactions
-		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, sparse ? total_bases + 64 * longest + (1 << 20) : 0);
+		// (sparse centre store: room for every sequence as its own centre TWICE -- a round of the update stage appends the new list of
+		// every moved centre before the old ones are compacted away)
+		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, sparse ? 2 * total_bases + 64 * longest + (1 << 20) : 0);
 		msc::MeanShift ms(gpu, std::cout);
 		ms.batch_update = !serial_update;
 		ms.run(records, similarity, iterations, delta, output.c_str());
