@@ -194,27 +194,54 @@ def main():
         if os.environ.get("MSC_BENCH_ONE_GPU") == "1":
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        real = dist
+
+        class _HostStaged:
+            """every collective of the exchange through host memory over a gloo group: the 1-GPU smoke test (two ranks share a device),
+            and the fallback if RCCL cannot move the library's device views on this node (preflight below)"""
+            def __init__(self, group):
+                self.group = group
+
+            def __getattr__(self, name):
+                return getattr(real, name)
+
+            class _Done:
+                def wait(self):
+                    return True
+
+            def all_gather_into_tensor(self, out, inp, async_op=False):
+                ho, hi = out.cpu(), inp.cpu().contiguous()
+                real.all_gather_into_tensor(ho, hi, group=self.group)
+                out.copy_(ho)
+                return self._Done()
+
+            def broadcast(self, t, src, async_op=False):
+                h = t.cpu()
+                real.broadcast(h, src=src, group=self.group)
+                t.copy_(h)
+                return self._Done()
+
+            def all_gather(self, outs, t):
+                hs_ = [o.cpu() for o in outs]
+                real.all_gather(hs_, t.cpu(), group=self.group)
+                for o, h in zip(outs, hs_):
+                    o.copy_(h)
+
+            def all_reduce(self, t, op=None):
+                h = t.cpu()
+                real.all_reduce(h, op=op if op is not None else real.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+
+            def barrier(self):
+                real.barrier(group=self.group)
+
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            real.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            gloo_group = real.new_group(backend="gloo")
         else:
-            dist.init_process_group(backend)
-            real = dist
-
-            class _HostStaged:
-                """gloo with device tensors (the 1-GPU smoke test): the all-gather of the packed exchange goes through host memory"""
-                def __getattr__(self, name):
-                    return getattr(real, name)
-
-                def all_gather_into_tensor(self, out, inp, async_op=False):
-                    ho, hi = out.cpu(), inp.cpu().contiguous()
-                    real.all_gather_into_tensor(ho, hi)
-                    out.copy_(ho)
-
-                    class _Done:
-                        def wait(self):
-                            return True
-                    return _Done()
-            dist = _HostStaged()
+            real.init_process_group(backend)
+            gloo_group = None
+            dist = _HostStaged(None)
     from meshclust2_amd import api, shard, synth
 
     n_total = args.nseq if args.scaling == "strong" else args.nseq * world
@@ -266,6 +293,21 @@ def main():
             def score_block(self, n, base=0):
                 return api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close",))["close"]
 
+        if gloo_group is not None:
+            # preflight: one all-gather and one broadcast over RCCL on the library's own device views (they are not torch allocations).
+            # If any rank fails, every rank stages the exchange through host memory instead of aborting the run.
+            ok = 1
+            try:
+                real.all_gather_into_tensor(all_scal[M:M + world], all_scal[0:1])
+                real.broadcast(all_scal[M], src=0)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("rank %d: RCCL preflight on device views failed (%r): staging the exchange through host memory\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            real.all_reduce(flag, op=real.ReduceOp.MIN, group=gloo_group)
+            if int(flag.item()) == 0:
+                dist = _HostStaged(gloo_group)
         sharded = shard.ShardedTrainer(dist, plan, GpuBackend(), rank, device="cuda")
         block = shard.ShardedBlockScorer(dist, plan, GpuBackend(), rank, device="cuda")
 

@@ -64,9 +64,9 @@ typedef enum {
 #define MSC_FEAT_SLOW (MSC_FEAT_FAST | MSC_FEAT_DIV)
 /* Two of the reference's `extraslow` statistics (PRED_FEAT_ALL, predict/Predictor.h:25): sums over the groups of four neighbouring
  * bins that share a (k-1)-mer prefix. rre_k_r: predict/Feature.cpp:1029-1062; sim_mm = 1 - exp((d_markov(a,b) + d_markov(b,a)) / 2)
- * with Feature<T>::markov, :1367-1393,1429-1455. Scored on sorted (bin, value) lists: sparse sets, and dense sets of histograms
- * >= 64 KiB through their sparse mirror (MSC_ERR_UNSUPPORTED below that); usable in msc_pair_features_raw, msc_score, the
- * Trainer operators and models, not in msc_train_class. */
+ * with Feature<T>::markov, :1367-1393,1429-1455. Scored on sorted (bin, value) lists (sparse sets, and dense sets of histograms
+ * >= 64 KiB through their sparse mirror) or, for smaller histograms, straight from the dense slots -- same terms, same order;
+ * usable in msc_pair_features_raw, msc_score, the Trainer operators and models, not in msc_train_class. */
 #define MSC_FEAT_RRE_K_R            (1ULL << 14)
 #define MSC_FEAT_SIM_MM             (1ULL << 16)
 #define MSC_FEAT_GROUPS (MSC_FEAT_RRE_K_R | MSC_FEAT_SIM_MM)

@@ -17,7 +17,7 @@ FEAT = {
     "manhattan": 1 << 2, "euclidean": 1 << 3, "normalized_vectors": 1 << 5, "jefferey_divergence": 1 << 7,
     "pearson": 1 << 9, "intersection": 1 << 13, "emd": 1 << 18, "length_difference": 1 << 21,
     "kulczynski2": 1 << 27, "simratio": 1 << 28, "jensen_shannon": 1 << 29,
-    "rre_k_r": 1 << 14, "sim_mm": 1 << 16,          # two `extraslow` statistics (MSC_FEAT_GROUPS): list form only
+    "rre_k_r": 1 << 14, "sim_mm": 1 << 16,          # two `extraslow` statistics (MSC_FEAT_GROUPS)
 }
 FEAT_FAST = sum(FEAT[n] for n in ("euclidean", "manhattan", "intersection", "kulczynski2", "simratio",
                                   "normalized_vectors", "pearson", "emd", "length_difference"))

@@ -1428,7 +1428,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	uint64_t want = rq.feat_mask;
 	if (rq.model) for (int i = 0; i < ns; i++) want |= rq.model->h.single_flag[i];
 	const bool need_div = (want & MSC_FEAT_DIV) != 0 && !rq.only_tiles;
-	const bool need_grp = (want & MSC_FEAT_GROUPS) != 0 && !rq.only_tiles;      // sim_mm / rre_k_r: 4-bin group statistics, list form only
+	const bool need_grp = (want & MSC_FEAT_GROUPS) != 0 && !rq.only_tiles;      // sim_mm / rre_k_r: 4-bin group statistics
 	const int tb = msc_div_table_dim(L);
 	const bool wide = needs_wide(rq.cands, rq.qset);
 	ctx->tiles_ms_accum = 0.f;
@@ -1451,8 +1451,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if ((r = ensure_sparse_mirror(ctx, cs, &c_sp)) || (r = ensure_sparse_mirror(ctx, rq.qset, &q_sp))) return r;
 		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
 	}
-	if (need_grp && !c_sp)
-		return fail(ctx, MSC_ERR_UNSUPPORTED, "sim_mm / rre_k_r are scored on sorted (bin, value) lists: they need histograms of at least 64 KiB (k=%d, dtype=%d)", cs->k, cs->dtype);
+	// sim_mm / rre_k_r: from the lists where they exist, else (histograms under 64 KiB) by the dense group kernels -- a given (k, dtype)
+	// always takes the same one of the two, so a pair has one evaluation order in every route
+	const bool grp_dense = need_grp && !c_sp;
+	if (grp_dense && std::max(rq.cands->max_count, rq.qset->max_count) > 0xffffffffull)
+		return fail(ctx, MSC_ERR_UNSUPPORTED, "sim_mm / rre_k_r: counts above 2^32 - 1 are not supported");
 	const bool mirror_div = !sp && c_sp != nullptr;
 	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
@@ -1515,7 +1518,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (mirror_div)        // the divergence sums of this chunk, from the lists of the same slots (outside the streaming kernel's timing)
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order));
-		if (need_grp) {
+		if (grp_dense) {
+			HIP_TRY(ctx, msc_launch_pair_groups_dense(ctx->stream, L, cs->dtype, c_bins, c_scal, cs->scalar_stride, d_slots, mc, q_bins, rq.use_window, rq.min_len, rq.max_len,
+			                                          (double*)ctx->grp_pairs.p));
+			HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, L, cs->dtype, cs->bins, d_slots, off, mc, (double*)ctx->grp_self.p));
+			HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, rq.qset->L, rq.qset->dtype, rq.qset->bins, nullptr, rq.q_slot, 1, (double*)ctx->grp_self.p + (uint64_t)chunk * 16));
+		} else if (need_grp) {
 			HIP_TRY(ctx, msc_launch_pair_sparse_groups(ctx->stream, c_sp->ent, c_sp->hdr + (d_slots ? 0 : off), cs->scalars + (d_slots ? 0 : off * cs->scalar_stride),
 			                                           cs->scalar_stride, d_slots, mc, q_sp->ent, q_sp->hdr + rq.q_slot, rq.use_window, rq.min_len, rq.max_len,
 			                                           (double*)ctx->grp_pairs.p));
@@ -1678,12 +1686,16 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// as a 1 x M pass per query
 	const bool want_div = (want & MSC_FEAT_DIV) != 0;
 	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
-	if (want_div && !cands->sparse && n_q > 1 && L.nbins == L.padded_bins && !needs_wide(cands, qset)) {
+	// sim_mm / rre_k_r likewise: one group pass per query behind the streaming kernel, over the mirrors' lists or (histograms under
+	// 64 KiB) the dense slots -- the kernels and records of the 1 x M pass
+	const bool want_grp = (want & MSC_FEAT_GROUPS) != 0;
+	if ((want_div || want_grp) && !cands->sparse && n_q > 1 && L.nbins == L.padded_bins && !needs_wide(cands, qset)) {
 		if ((r = ensure_sparse_mirror(ctx, cands, &c_sp)) || (r = ensure_sparse_mirror(ctx, qset, &q_sp))) return r;
 		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
 	}
-	const bool want_grp = (want & MSC_FEAT_GROUPS) != 0;      // sim_mm / rre_k_r: one 1 x M pass per query (run_score)
-	const bool simple = !want_grp && (!want_div || c_sp) && L.nbins == L.padded_bins && n_q > 1 && !needs_wide(cands, qset) && !cands->sparse;
+	const bool grp_dense = want_grp && !c_sp;
+	const bool simple = (!grp_dense || std::max(cands->max_count, qset->max_count) <= 0xffffffffull) && (!want_div || c_sp) && L.nbins == L.padded_bins && n_q > 1 &&
+	                    !needs_wide(cands, qset) && !cands->sparse;
 	// Sparse sets: one merge-path pass per query, but queued back to back into one [n_q][m] record array with ONE epilogue and one
 	// copy back -- no host round trip between the passes.
 	static const bool no_sp_multi = getenv("MSC_SPARSE_NO_MULTI") != nullptr;
@@ -1824,9 +1836,14 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
 	const uint64_t q_rows = digest ? (n_q + 15) / 16 * 16 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
+	if (want_grp) chunk = std::min<uint64_t>(chunk, (1024ull << 20) / (n_q * 32 * sizeof(double)));      // [n_q][chunk][16][2] group records: 1 GiB
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
 	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * n_rec * rec_bytes))) return r;
+	if (want_grp) {
+		if ((r = ensure(ctx, ctx->grp_pairs, n_q * chunk * 32 * sizeof(double)))) return r;
+		if ((r = ensure(ctx, ctx->grp_self, (chunk + n_q) * 16 * sizeof(double)))) return r;      // [candidates][16] then [queries][16]
+	}
 	SparseKernel spk = SPK_MP;
 	if (want_div) {          // one kernel for the whole block: merge-path unless some query's lists are out of its range
 		for (uint64_t q = 0; q < n_q; q++) if (pick_sparse_kernel(c_sp, q_sp, q_slots[q], mc_, false) != SPK_MP) spk = SPK_GENERIC;
@@ -1869,10 +1886,30 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
 				                                qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->sp_partials.p,
 				                                ctx->div_tables.p, (double*)ctx->div_partials.p + q * mc * sparse_records(spk) * 2, order));
+		if (want_grp) {
+			double* gp = (double*)ctx->grp_pairs.p;
+			double* gs_c = (double*)ctx->grp_self.p;
+			double* gs_q = gs_c + chunk * 16;
+			const uint32_t* d_q = (const uint32_t*)ctx->qslots.p;
+			if (grp_dense) {
+				HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, L, cands->dtype, cands->bins, d_slots, off, mc, gs_c));
+				HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, qset->L, qset->dtype, qset->bins, d_q, 0, (uint32_t)n_q, gs_q));
+				for (uint64_t q = 0; q < n_q; q++)
+					HIP_TRY(ctx, msc_launch_pair_groups_dense(ctx->stream, L, cands->dtype, c_bins, c_scal, cands->scalar_stride, d_slots, mc,
+					                                          qset->bins + (uint64_t)q_slots[q] * qset->L.slot_bytes, 0, 0, ~0ull, gp + q * mc * 32));
+			} else {
+				HIP_TRY(ctx, msc_launch_sparse_self_markov(ctx->stream, c_sp->ent, c_sp->hdr, d_slots, off, mc, gs_c));
+				HIP_TRY(ctx, msc_launch_sparse_self_markov(ctx->stream, q_sp->ent, q_sp->hdr, d_q, 0, (uint32_t)n_q, gs_q));
+				for (uint64_t q = 0; q < n_q; q++)
+					HIP_TRY(ctx, msc_launch_pair_sparse_groups(ctx->stream, c_sp->ent, c_sp->hdr + (d_slots ? 0 : off), c_scal, cands->scalar_stride, d_slots, mc, q_sp->ent,
+					                                           q_sp->hdr + q_slots[q], 0, 0, ~0ull, gp + q * mc * 32));
+			}
+		}
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
 		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = sparse_records(spk); ea.div_base = L.nbins; }
+		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
 		ea.S = n_rec;

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstddef>
 
+#include "msc_groups.h"
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -1191,7 +1192,25 @@ __global__ void __launch_bounds__(kBlock) k_colsum(const T* __restrict__ bins, u
 		uint64_t acc[E];
 #pragma unroll
 		for (uint32_t j = 0; j < E; j++) acc[j] = 0;
-		for (uint32_t i = 0; i < m; i++) {
+		// eight members' loads in flight per thread: with one 16-byte column per thread a 1 MiB histogram is only 1 024 waves, so the
+		// walk over the members is latency-bound unless every wave keeps several loads outstanding (r02 profile: 2.15 TB/s with one)
+		constexpr uint32_t U = 8;
+		uint32_t i = 0;
+		for (; i + U <= m; i += U) {
+			u32x4 v[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++) {
+				const uint32_t slot = member_slots ? member_slots[i + u] : i + u;
+				v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bins + (uint64_t)slot * slot_elems + chunk * E));
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++) {
+				const T* e = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+				for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+			}
+		}
+		for (; i < m; i++) {
 			const uint32_t slot = member_slots ? member_slots[i] : i;
 			const uint4 v = *reinterpret_cast<const uint4*>(bins + (uint64_t)slot * slot_elems + chunk * E);
 			const T* e = reinterpret_cast<const T*>(&v);
@@ -1234,7 +1253,21 @@ __global__ void __launch_bounds__(kBlock) k_colsum_batch(const T* __restrict__ b
 		uint64_t acc[E];
 #pragma unroll
 		for (uint32_t j = 0; j < E; j++) acc[j] = 0;
-		for (uint32_t i = 0; i < seg.m; i++) {
+		constexpr uint32_t U = 8;          // eight members' loads in flight per thread (see k_colsum)
+		uint32_t i = 0;
+		for (; i + U <= seg.m; i += U) {
+			u32x4 v[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++)
+				v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bins + (uint64_t)member_slots[seg.first + i + u] * slot_elems + chunk * E));
+#pragma unroll
+			for (uint32_t u = 0; u < U; u++) {
+				const T* e = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+				for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+			}
+		}
+		for (; i < seg.m; i++) {
 			const uint32_t slot = member_slots[seg.first + i];
 			const uint4 v = *reinterpret_cast<const uint4*>(bins + (uint64_t)slot * slot_elems + chunk * E);
 			const T* e = reinterpret_cast<const T*>(&v);
@@ -1587,6 +1620,97 @@ hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const
 	const uint64_t stotal = (uint64_t)words * n;
 	k_assign_scalars<<<dim3((unsigned)std::min<uint64_t>((stotal + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint64_t*)dst_scalars, (const uint64_t*)src_scalars,
 	                                                                                                                      dst_slots, src_slots, words, 0, stotal);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ 4-bin group statistics of small dense sets
+// sim_mm (through markov) and rre_k_r on histograms too small for the sparse layout (4^k * sizeof(T) < 64 KiB, where the list
+// form of sparse.hip does not exist): the same per-group terms (msc_groups.h), the same 16 index sub-ranges per candidate and the
+// same records as k_pair_sparse_groups / k_sparse_self_markov, read straight from the tile-permuted dense slots. One lane per
+// (candidate, sub-range) walks its groups in index order; the slots are a few KiB and stay in L2.
+template <typename T>
+__device__ __forceinline__ void load_group(const T* __restrict__ h, uint64_t g, uint32_t E, uint32_t R, uint32_t (&v)[4]) {
+#pragma unroll
+	for (int j = 0; j < 4; j++) v[j] = (uint32_t)h[msc_phys_index(4 * g + j, E, R)];
+}
+__device__ __forceinline__ void group_span(uint64_t nbins, uint32_t r, uint64_t& g0, uint64_t& g1) {
+	const uint64_t G = nbins / 4, per = (G + 15) / 16;
+	g0 = per * r < G ? per * r : G;
+	g1 = g0 + per < G ? g0 + per : G;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_pair_groups_dense(const uint8_t* __restrict__ c_bins, uint64_t slot_bytes, const uint8_t* __restrict__ cand_scalars,
+                                                           uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
+                                                           const uint8_t* __restrict__ q_bins, uint32_t E, uint32_t R, uint64_t nbins, int use_window,
+                                                           uint64_t min_len, uint64_t max_len, double* __restrict__ out) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = (uint32_t)(t / 16), r = (uint32_t)(t % 16);
+	if (c >= m) return;
+	const uint32_t slot = cand_slots ? cand_slots[c] : c;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+	if (use_window && (cs->length < min_len || cs->length > max_len)) return;
+	const T* P = reinterpret_cast<const T*>(c_bins + (uint64_t)slot * slot_bytes);
+	const T* Q = reinterpret_cast<const T*>(q_bins);
+	uint64_t g0, g1;
+	group_span(nbins, r, g0, g1);
+	double markov = 0.0, rre = 0.0;
+	for (uint64_t g = g0; g < g1; g++) {
+		uint32_t p[4], q[4];
+		load_group(P, g, E, R, p);
+		load_group(Q, g, E, R, q);
+		if ((p[0] & p[1] & p[2] & p[3] & q[0] & q[1] & q[2] & q[3]) == 1u && (p[0] | p[1] | p[2] | p[3] | q[0] | q[1] | q[2] | q[3]) == 1u) continue;
+		msc_group_terms(p, q, markov, rre);
+	}
+	out[((uint64_t)c * 16 + r) * 2] = markov;
+	out[((uint64_t)c * 16 + r) * 2 + 1] = rre;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_self_markov_dense(const uint8_t* __restrict__ bins, uint64_t slot_bytes, const uint32_t* __restrict__ slots,
+                                                           uint64_t first_slot, uint32_t m, uint32_t E, uint32_t R, uint64_t nbins, double* __restrict__ out) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = (uint32_t)(t / 16), r = (uint32_t)(t % 16);
+	if (c >= m) return;
+	const T* P = reinterpret_cast<const T*>(bins + (slots ? (uint64_t)slots[c] : first_slot + c) * slot_bytes);
+	uint64_t g0, g1;
+	group_span(nbins, r, g0, g1);
+	double total = 0.0;
+	for (uint64_t g = g0; g < g1; g++) {
+		uint32_t v[4];
+		load_group(P, g, E, R, v);
+		if ((v[0] | v[1] | v[2] | v[3]) == 1u && (v[0] & v[1] & v[2] & v[3]) == 1u) continue;
+		msc_group_self(v, total);
+	}
+	out[(uint64_t)c * 16 + r] = total;
+}
+
+// c_bins / cand_scalars: base of the set when cand_slots != nullptr, else of the first candidate of the chunk
+hipError_t msc_launch_pair_groups_dense(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* c_bins, const uint8_t* cand_scalars, uint64_t scalar_stride,
+                                        const uint32_t* cand_slots, uint32_t m, const uint8_t* q_bins, int use_window, uint64_t min_len, uint64_t max_len, double* out) {
+	if (m == 0) return hipSuccess;
+	const dim3 grid((unsigned)(((uint64_t)m * 16 + 255) / 256));
+#define MSC_GD(TT) k_pair_groups_dense<TT><<<grid, dim3(256), 0, st>>>(c_bins, L.slot_bytes, cand_scalars, scalar_stride, cand_slots, m, q_bins, L.E, L.R, L.nbins, use_window, min_len, max_len, out)
+	switch (dtype) {
+	case 8: MSC_GD(uint8_t); break;
+	case 16: MSC_GD(uint16_t); break;
+	case 32: MSC_GD(uint32_t); break;
+	default: MSC_GD(uint64_t); break;
+	}
+#undef MSC_GD
+	return hipGetLastError();
+}
+// bins: base of the set; the slots are slots[c] or first_slot + c
+hipError_t msc_launch_self_markov_dense(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* slots, uint64_t first_slot, uint32_t m,
+                                        double* out) {
+	if (m == 0) return hipSuccess;
+	const dim3 grid((unsigned)(((uint64_t)m * 16 + 255) / 256));
+#define MSC_SD(TT) k_self_markov_dense<TT><<<grid, dim3(256), 0, st>>>(bins, L.slot_bytes, slots, first_slot, m, L.E, L.R, L.nbins, out)
+	switch (dtype) {
+	case 8: MSC_SD(uint8_t); break;
+	case 16: MSC_SD(uint16_t); break;
+	case 32: MSC_SD(uint32_t); break;
+	default: MSC_SD(uint64_t); break;
+	}
+#undef MSC_SD
 	return hipGetLastError();
 }
 

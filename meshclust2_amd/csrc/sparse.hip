@@ -24,6 +24,7 @@
 // run, so one wave scan per tile yields ordered output with coalesced reads.
 #include <algorithm>
 
+#include "msc_groups.h"
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -354,24 +355,7 @@ struct GroupState {
 };
 __device__ __forceinline__ void group_close(GroupState& st) {
 	if (st.g == 0xffffffffu) return;
-	const double sp = (double)((uint64_t)st.p[0] + st.p[1] + st.p[2] + st.p[3]);
-	const double sq = (double)((uint64_t)st.q[0] + st.q[1] + st.q[2] + st.q[3]);
-	const double lsp = log(sp), lsq = log(sq);
-	double ip = 0.0, iq = 0.0;
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		const double pj = (double)st.p[j], qj = (double)st.q[j];
-		// markov: (q - 1) (log p - log psum) + (p - 1) (log q - log qsum)
-		st.markov += (double)(st.q[j] - 1u) * (log(pj) - lsp);
-		st.markov += (double)(st.p[j] - 1u) * (log(qj) - lsq);
-		// rre_k_r: p log(cp / avg) / psum + q log(cq / avg) / qsum with the conditional probabilities cp = p / psum, cq = q / qsum
-		const double cp = pj / sp, cq = qj / sq;
-		const double avg = 0.5 * (cp + cq);
-		ip += pj * log(cp / avg) / sp;
-		iq += qj * log(cq / avg) / sq;
-	}
-	st.rre += ip;
-	st.rre += iq;
+	msc_group_terms(st.p, st.q, st.markov, st.rre);
 	st.g = 0xffffffffu;
 }
 __device__ __forceinline__ void group_put(GroupState& st, uint32_t bin, uint32_t pv, uint32_t qv) {
@@ -435,9 +419,7 @@ __global__ void __launch_bounds__(256) k_sparse_self_markov(const uint2* __restr
 	uint32_t g = 0xffffffffu, v[4] = {1u, 1u, 1u, 1u};
 	auto close = [&]() {
 		if (g == 0xffffffffu) return;
-		const double ls = log((double)((uint64_t)v[0] + v[1] + v[2] + v[3]));
-#pragma unroll
-		for (int j = 0; j < 4; j++) total += (double)(v[j] - 1u) * (log((double)v[j]) - ls);
+		msc_group_self(v, total);
 	};
 	for (uint32_t i = h.split[r]; i < h.split[r + 1]; i++) {
 		const uint2 e = P[i];

@@ -209,11 +209,14 @@ n_singles: 2
 
 
 @pytest.mark.parametrize("dtype,k,length,layout", [(32, 9, 1000, "dense"), (32, 9, 1000, "sparse"), (8, 9, 700, "dense"), (16, 8, 3000, "dense"),
-                                                     (64, 10, 2500, "sparse"), (16, 11, 9000, "sparse")])
+                                                     (64, 10, 2500, "sparse"), (16, 11, 9000, "sparse"),
+                                                     # histograms under 64 KiB: no list form, the dense group kernels
+                                                     (16, 5, 300, "dense"), (8, 7, 900, "dense"), (32, 6, 600, "dense"), (64, 3, 120, "dense"),
+                                                     (64, 4, 200, "dense"), (8, 2, 90, "dense")])
 def test_sim_mm_and_rre_k_r_against_the_oracle(ctx, oracle, dtype, k, length, layout):
     """The two `extraslow` statistics BASELINE's north_star names: sim_mm (through Feature<T>::markov / d_markov) and rre_k_r
     (predict/Feature.cpp:1367-1393,1429-1455,1029-1062), sums over the groups of four bins that share a (k-1)-mer prefix. Scored by
-    the merge kernels' group pass (a dense set through its sparse mirror): raw values, both argument orders, a model built on
+    the merge kernels' group pass (a dense set through its sparse mirror; histograms under 64 KiB from the dense slots): raw values, both argument orders, a model built on
     them, get_close / filter decisions -- against the oracle, which tests/test_oracle_vs_ref.py pins to the reference's own
     static functions. The stale magnitude of a moved centre enters through getRealMagnitude."""
     seqs, _ = synth.families(9100 + k + dtype, 18, length, family=6, length_jitter=length // 10)
@@ -246,8 +249,14 @@ def test_sim_mm_and_rre_k_r_against_the_oracle(ctx, oracle, dtype, k, length, la
     of, obp, obs, oim = oracle.get_close(pred, 0.9, oh[2], [oh[c] for c in w])
     assert np.array_equal(flags, of) and (bp, im) == (obp, oim) and bs == pytest.approx(obs, rel=1e-8)
     assert np.array_equal(trn.filter(hs, 2, hs, w), oracle.filter_(pred, 0.9, oh[2], [oh[c] for c in w]))
-    multi = api.score_multi(ctx, feat, hs, cands, hs, [3, 5], feat_mask=(1 << 14) | (1 << 16))          # per-query passes underneath
+    # Q x M: the group passes queued behind the streaming kernel (dense sets) / one 1 x M pass per query (sparse sets) -- same records
+    qs = [3, 5, 0, n - 1, 7, 2, 9, 11]
+    multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=(1 << 14) | (1 << 16))
     assert np.array_equal(multi["sum"][0], r["sum"])
+    for qi, q in enumerate(qs):
+        one = api.pair_features_raw(ctx, hs, cands, hs, q, (1 << 14) | (1 << 16))
+        assert np.array_equal(np.asarray(multi["raw"][qi]).reshape(len(cands), 2), np.asarray(one).reshape(len(cands), 2)), q
+        assert np.array_equal(multi["sum"][qi], feat.compute(hs, cands, hs, q)["sum"]), q
     # a moved centre keeps its stale magnitude: clone of 4, then set(9)
     hs.clone_from(n, hs, 4)
     hs.assign_from(n, hs, 9)
@@ -260,12 +269,30 @@ def test_sim_mm_and_rre_k_r_against_the_oracle(ctx, oracle, dtype, k, length, la
         oracle.lib().orc_hist_free(h)
 
 
-def test_group_statistics_need_the_list_form(ctx):
-    """histograms under 64 KiB have no sparse form: sim_mm / rre_k_r are refused there, loudly"""
-    hs = api.HistogramSet(ctx, 5, 16, 2)
-    hs.build([b"ACGTTGCA" * 30, b"ACGTAGCA" * 30])
-    with pytest.raises(api.MscError, match="64 KiB"):
-        api.pair_features_raw(ctx, hs, [0], hs, 1, 1 << 16)
+def test_group_statistics_dense_and_list_forms_agree(ctx):
+    """the dense group kernels and the list form use the same per-group terms over the same 16 index sub-ranges: the same histograms
+    held as a 64 KiB dense set (list form through the mirror) and scored with the mirror refused (dense form, in a child process:
+    the switch is read once) give the same bits"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys\n"
+        "from meshclust2_amd import api, synth\n"
+        "ctx = api.Context(0)\n"
+        "seqs, _ = synth.families(515, 12, 2000, family=4, length_jitter=100)\n"
+        "hs = api.HistogramSet(ctx, 8, 16, len(seqs)); hs.build(list(seqs))\n"
+        "r = api.pair_features_raw(ctx, hs, np.arange(len(seqs), dtype=np.uint32), hs, 3, (1 << 14) | (1 << 16))\n"
+        "sys.stdout.write(np.asarray(r, dtype=np.float64).tobytes().hex())\n")
+    outs = []
+    for env_extra in ({}, {"MSC_NO_SPARSE_MIRROR": "1"}):
+        env = dict(os.environ, **env_extra)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr
+        outs.append(p.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 12 * 2 * 16
 
 
 def test_upload_round_trip_and_properties(ctx):
