@@ -114,9 +114,14 @@ static int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
 int msc_set_error(msc_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
 bool msc_ctx_owns(const msc_ctx* ctx, const msc_hist_set* set) { return ctx && set && set->ctx == ctx; }
 
+// MSC_TRACE_CALLS (debugging a device fault): every runtime call / kernel launch is named on stderr before it is issued and the
+// device is drained behind it, so the last line printed names the operation that faulted
+static const bool g_trace_calls = getenv("MSC_TRACE_CALLS") != nullptr;
 #define HIP_TRY(ctx, expr)                                                                                 \
 	do {                                                                                                   \
+		if (g_trace_calls) { fprintf(stderr, "[msc] %s:%d %.160s\n", __FILE__, __LINE__, #expr); fflush(stderr); } \
 		hipError_t e_ = (expr);                                                                            \
+		if (g_trace_calls && e_ == hipSuccess) e_ = hipDeviceSynchronize();                                \
 		if (e_ != hipSuccess)                                                                              \
 			return fail(ctx, e_ == hipErrorOutOfMemory ? MSC_ERR_OOM : MSC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
 			            hipGetErrorString(e_), __FILE__, __LINE__);                                        \
@@ -1456,7 +1461,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool grp_dense = need_grp && !c_sp;
 	if (grp_dense && std::max(rq.cands->max_count, rq.qset->max_count) > 0xffffffffull)
 		return fail(ctx, MSC_ERR_UNSUPPORTED, "sim_mm / rre_k_r: counts above 2^32 - 1 are not supported");
-	const bool mirror_div = !sp && c_sp != nullptr;
+	const bool mirror_div = need_div && !sp && c_sp != nullptr;      // (the mirror may be here for the group statistics alone)
 	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
 	if (sp) ctx->last_kernel = sparse_kernel_name(spk);
