@@ -773,24 +773,32 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 		if constexpr (DIV) { cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order); }
 		uint32_t ci = 0, qj = 0, dchunk = 0;
 		for (uint32_t t = 0; t < n_chunks; t++) {
-			if (t % 63 == 0) {                   // boundaries of the next 63 chunks: lane l searches diagonal (t + l) * kMpT in global memory
+			const uint32_t tl = t % 63;
+			if (tl == 0) {                       // boundaries of the next 63 chunks: lane l searches diagonal (t + l) * kMpT in global memory
 				const uint64_t dd = (uint64_t)(t + lane) * kMpT;
 				const uint32_t d = dd < total ? (uint32_t)dd : total;
 				mp_split(d, nc_all, nq_all, [&](uint32_t i) { return P[i].x; }, [&](uint32_t j) { return Q[j].x; }, ci, qj);
 				dchunk = (ci ? CP[ci - 1] : 0u) - (qj ? CQ[qj - 1] : 0u);      // prefix difference entering that chunk (two's complement)
 			}
-			const uint32_t tl = t % 63;
-			const uint32_t c0 = __shfl(ci, tl, 64), c1 = __shfl(ci, tl + 1, 64);
-			const uint32_t q0 = __shfl(qj, tl, 64), q1 = __shfl(qj, tl + 1, 64);
+			// the chunk's boundaries are wave-uniform: scalar registers
+			const uint32_t c0 = __builtin_amdgcn_readlane(ci, tl), c1 = __builtin_amdgcn_readlane(ci, tl + 1);
+			const uint32_t q0 = __builtin_amdgcn_readlane(qj, tl), q1 = __builtin_amdgcn_readlane(qj, tl + 1);
 			const uint32_t nc = c1 - c0, nq = q1 - q0;
 			uint2* cl = buf;                     // cl[0] = predecessor of the piece (or a neutral entry), cl[1 + k] = P[c0 + k]
 			uint2* ql = buf + nc + 2;
 			__builtin_amdgcn_wave_barrier();     // every lane is done with the previous chunk's entries
+			// (a plain load / store loop per piece: the kernel is bound by vector-instruction issue at 8 waves per SIMD, which hide the
+			// latency of these loads; staging through registers with every load of the chunk in flight, a chunk ahead, shortens a lone
+			// wave's chunk by 20 % but costs more instructions and two waves per SIMD -- 12 % slower once the chip is full)
 			for (uint32_t k = lane; k <= nc; k += 64) cl[k] = (c0 + k) ? P[c0 + k - 1] : make_uint2(0u, 1u);
 			for (uint32_t k = lane; k <= nq; k += 64) ql[k] = (q0 + k) ? Q[q0 + k - 1] : make_uint2(0u, 1u);
+			// one entry past either piece: a bin index no share reaches, so a lane that runs off the end of a piece stops by itself
+			if (lane == 0) { cl[nc + 1] = make_uint2(kInf, 1u); ql[nq + 1] = make_uint2(kInf, 1u); }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();     // LDS operations of one wave complete in order: the reads below see the writes
-			const uint32_t n = nc + nq, seg = (n + 63) >> 6;
+			// equal shares of `seg` merged entries; seg is kept ODD: lane l starts near byte 8 * seg * l / 2 of either piece, and an even
+			// seg (8 for a full chunk) lines the 64 lanes up on a quarter of the LDS banks (bank-conflict cycles were 2.4x the active ones)
+			const uint32_t n = nc + nq, seg = ((n + 63) >> 6) | 1u;
 			uint32_t i, j;
 			{
 				const uint32_t d = lane * seg < n ? lane * seg : n;
@@ -800,25 +808,40 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 			if (lane == 63) { i1 = nc; j1 = nq; }
 			// prefix difference entering each share = the chunk's + what the earlier lanes' shares add: a pass over the share's values
 			// and one wave scan instead of two scattered reads of the cum arrays per lane
-			uint32_t delta = 0;
-			for (uint32_t a = i; a < i1; a++) delta += cl[a + 1].y - 1u;
-			for (uint32_t b = j; b < j1; b++) delta -= ql[b + 1].y - 1u;
-			const uint32_t d_in = __shfl(dchunk, tl, 64) + wave_incl_scan(delta) - delta;
-			if (i < i1 || j < j1) {
-				// state entering the share: last event before it, prefix difference after it
+			uint32_t delta = (j1 - j) - (i1 - i);                              // sum of (value - 1) = sum of values - count
+			for (uint32_t a = i; a < i1; a++) delta += cl[a + 1].y;
+			for (uint32_t b = j; b < j1; b++) delta -= ql[b + 1].y;
+			const uint32_t d_in = __builtin_amdgcn_readlane(dchunk, tl) + wave_incl_scan(delta) - delta;
+			// The share: every bin of it lies below the first bin of the next lane's share (the merged order is split between bins,
+			// ties kept together), so the walk needs no per-list bound -- it reloads both heads every step (an entry of the next share,
+			// or the end marker, simply never becomes the minimum) and stops at that bin.
+			// both heads with one ds_read_b64 each (the compiler reads .x and .y separately, and the LDS pipe is the busiest unit here):
+			// pa / pb = LDS byte addresses of the heads; the wait ties the two results so nothing uses them early
+			auto heads = [](uint32_t pa, uint32_t pb, uint2& a, uint2& b) {
+				uint64_t wa, wb;
+				asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(wa), "=&v"(wb) : "v"(pa), "v"(pb) : "memory");
+				a = make_uint2((uint32_t)wa, (uint32_t)(wa >> 32));
+				b = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+			};
+			uint32_t pa = (uint32_t)(uintptr_t)(cl + i + 1), pb = (uint32_t)(uintptr_t)(ql + j + 1);
+			uint2 a, b;
+			heads(pa, pb, a, b);
+			uint32_t e = a.x < b.x ? a.x : b.x;
+			uint32_t e_end = __shfl_down(e, 1, 64);
+			if (lane == 63) e_end = kInf;                                      // (a lane behind the last share reads the end markers: its e is kInf)
+			{
 				const uint32_t pc = cl[i].x, pq = ql[j].x;                      // predecessors (neutral entries have index 0)
 				uint32_t pos = pc > pq ? pc : pq;
 				int32_t D = (int32_t)d_in;
-				uint2 a = i < i1 ? cl[i + 1] : make_uint2(kInf, 1u);
-				uint2 b = j < j1 ? ql[j + 1] : make_uint2(kInf, 1u);
-				while (i < i1 || j < j1) {
-					const uint32_t e = a.x < b.x ? a.x : b.x;
+				uint32_t events = 0;
+				while (e < e_end) {
 					const bool ta = a.x == e, tb = b.x == e;
 					const uint32_t absD = (uint32_t)(D < 0 ? -D : D);
 					emd += (uint64_t)absD * (e - pos);
 					const uint32_t pv = ta ? a.y : 1u, qv = tb ? b.y : 1u;
 					manh += pv > qv ? pv - qv : qv - pv;
-					dotx += (uint64_t)(pv * qv - 1u);
+					dotx += (uint64_t)pv * qv;
+					events++;
 					D += (int32_t)pv - (int32_t)qv;
 					if constexpr (DIV) {
 						DivTerm tt;
@@ -828,9 +851,12 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 						js += tt.js - t11.js;
 					}
 					pos = e;
-					if (ta) { i++; a = i < i1 ? cl[i + 1] : make_uint2(kInf, 1u); }
-					if (tb) { j++; b = j < j1 ? ql[j + 1] : make_uint2(kInf, 1u); }
+					pa += ta ? 8u : 0u;
+					pb += tb ? 8u : 0u;
+					heads(pa, pb, a, b);
+					e = a.x < b.x ? a.x : b.x;
 				}
+				dotx -= events;                                                 // sum of (p q - 1) over the events
 			}
 		}
 		if (lane == 0) {      // the stretch behind the last event of either list
