@@ -1397,14 +1397,14 @@ SparseKernel pick_sparse_kernel(const msc_hist_set* c_sp, const msc_hist_set* q_
 	if (!no_mp && !wide && max_count < 65536 && q_nnz + c_sp->max_nnz <= msc_sparse_mp_max_entries()) return SPK_MP;
 	return SPK_GENERIC;
 }
-uint32_t sparse_records(SparseKernel k) { return k == SPK_GENERIC ? MSC_SPARSE_SUB : 1; }
+uint32_t sparse_records(SparseKernel k, uint32_t mp_parts = 1) { return k == SPK_GENERIC ? MSC_SPARSE_SUB : k == SPK_MP ? mp_parts : 1; }
 const char* sparse_kernel_name(SparseKernel k) { return k == SPK_LDS ? "k_pair_sparse_lds" : k == SPK_MP ? "k_pair_sparse_mp" : "k_pair_sparse"; }
 
 // candidates [off, off + mc) (or the device slot list d_slots) of the sparse set / mirror c_sp against slot q_slot of q_sp; the
 // scalar records are those of the sets the lists belong to (a mirror has none of its own)
 hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* c_sp, const uint8_t* c_scalars, uint64_t c_stride, const uint32_t* d_slots,
                               uint64_t off, uint32_t mc, const msc_hist_set* q_sp, uint64_t q_slot, const uint8_t* q_scal, uint64_t nbins, int use_window,
-                              uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order) {
+                              uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, uint32_t parts = 1) {
 	const MscSparseHdr* c_hdr = c_sp->hdr + (d_slots ? 0 : off);
 	const uint8_t* c_scal = c_scalars + (d_slots ? 0 : off * c_stride);
 	const uint32_t q_nnz = q_sp->hdr_host[q_slot].nnz;
@@ -1414,7 +1414,7 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 	if (k == SPK_MP)
 		return msc_launch_pair_sparse_mp(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 		                                 use_window, min_len, max_len, partials, div_tables, div_partials, order, ctx->num_cus,
-		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz));
+		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz), parts);
 	return msc_launch_pair_sparse(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 	                              use_window, min_len, max_len, partials, div_tables, div_partials, order);
 }
@@ -1465,7 +1465,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
 	if (sp) ctx->last_kernel = sparse_kernel_name(spk);
-	const uint32_t SPN = sparse_records(spk);                         // records per candidate the merge kernel writes
+	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
+	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
+	const uint32_t mp_parts = sp && spk == SPK_MP && !need_div
+	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz, ctx->num_cus) : 1;
+	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
 	const uint32_t PS = sp ? SPN : L.S;                               // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
@@ -1510,7 +1514,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (sp) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
-			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order));
+			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
+			                                mp_parts));
 		} else if (wide) {
 			HIP_TRY(ctx, msc_launch_pair_tiles_wide(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
 			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, inline_div ? ctx->div_partials.p : nullptr, rq.order));
@@ -1735,7 +1740,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
 			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,
 			                                       (MscPartial*)ctx->partials.p + q * m, nullptr, nullptr, order, ctx->num_cus,
-			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz)));
+			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz), 1));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);

@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
-    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr) {
+    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1) {
 	static_assert(!(DIV && PAIRS), "the pair-list form scores the integer statistics only");
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
@@ -747,7 +747,10 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
 	const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t kInf = 0xffffffffu;
-	for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + wave; c < m; c += total_waves) {
+	// `parts` waves share a candidate (a short window would leave most of the chip idle, and a get_close step is as slow as its
+	// slowest wave): part p walks chunks [p n / parts, (p + 1) n / parts) of the merged order and writes record c * parts + p
+	for (uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave; w < m * parts; w += total_waves) {
+		const uint32_t c = w / parts, part = w - c * parts;
 		const uint32_t slot = cand_slots ? cand_slots[c] : c;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
 		if constexpr (PAIRS) {
@@ -772,8 +775,9 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 		DivTerm t11{0.0, 0.0};
 		if constexpr (DIV) { cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order); }
 		uint32_t ci = 0, qj = 0, dchunk = 0;
-		for (uint32_t t = 0; t < n_chunks; t++) {
-			const uint32_t tl = t % 63;
+		const uint32_t t_begin = (uint32_t)((uint64_t)n_chunks * part / parts), t_end = (uint32_t)((uint64_t)n_chunks * (part + 1) / parts);
+		for (uint32_t t = t_begin; t < t_end; t++) {
+			const uint32_t tl = (t - t_begin) % 63;
 			if (tl == 0) {                       // boundaries of the next 63 chunks: lane l searches diagonal (t + l) * kMpT in global memory
 				const uint64_t dd = (uint64_t)(t + lane) * kMpT;
 				const uint32_t d = dd < total ? (uint32_t)dd : total;
@@ -859,7 +863,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 				dotx -= events;                                                 // sum of (p q - 1) over the events
 			}
 		}
-		if (lane == 0) {      // the stretch behind the last event of either list
+		if (lane == 0 && part + 1 == parts) {      // the stretch behind the last event of either list
 			const uint32_t lc = nc_all ? P[nc_all - 1].x : 0u, lq = nq_all ? Q[nq_all - 1].x : 0u;
 			const int64_t D = (int64_t)(nc_all ? CP[nc_all - 1] : 0u) - (int64_t)(nq_all ? CQ[nq_all - 1] : 0u);
 			emd += (uint64_t)(D < 0 ? -D : D) * (nbins - (uint64_t)(lc > lq ? lc : lq));
@@ -872,8 +876,8 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 		if (lane == 0) {
 			MscPartial out;
 			out.manh = manh_t; out.dot = dot_t; out.emd = emd_t;
-			partials[c] = out;
-			if constexpr (DIV) { div_partials[2ull * c] = jd; div_partials[2ull * c + 1] = js; }
+			partials[w] = out;
+			if constexpr (DIV) { div_partials[2ull * w] = jd; div_partials[2ull * w + 1] = js; }
 		}
 	}
 }
@@ -1005,48 +1009,50 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 
 uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
 
-template <uint32_t T>
-static hipError_t launch_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
-                                   uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
-                                   const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
-                                   uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus) {
-	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
-	uint32_t blocks = (uint32_t)num_cus * per_cu;
-	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
-	if (div_tables) {
-		k_pair_sparse_mp<true, T><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
-		                                                              q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials,
-		                                                              (const DivTerm*)div_tables, (double*)div_partials, order);
-	} else {
-		k_pair_sparse_mp<false, T><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
-		                                                               q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order);
-	}
-	return hipGetLastError();
-}
+// 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this merge wants (r01: k=9/5 kb lists 43 M pairs/s at 512,
+// 32 M at 1024, 20 M at 2048)
+constexpr uint32_t kMpChunk = 512;
 
-// lists of any length up to msc_sparse_mp_max_entries() together; same arithmetic range as the LDS kernel (caller checks)
+// lists of any length up to msc_sparse_mp_max_entries() together; same arithmetic range as the LDS kernel (caller checks).
+// parts (1 .. 16): waves per candidate, each writing its own record -- partials[c * parts + p]; the divergence form takes parts = 1
+// (its FP64 sums keep one evaluation order whatever the size of the window).
 hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
                                      uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                      const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
-                                     uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total) {
+                                     uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total,
+                                     uint32_t parts) {
 	if (m == 0) return hipSuccess;
-	if (max_total > msc_sparse_mp_max_entries()) return hipErrorInvalidValue;
+	if (max_total > msc_sparse_mp_max_entries() || parts < 1 || parts > 16 || (div_tables && parts != 1) || (uint64_t)m * parts > 0xffffffffull) return hipErrorInvalidValue;
 	if (div_tables) {
 		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 	}
-	static const int t_env = [] { const char* e = getenv("MSC_SPARSE_MP_T"); return e ? atoi(e) : 0; }();
-#define MSC_MP_ARGS st, c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, \
-	div_tables, div_partials, order, num_cus
-	// 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this latency-bound merge wants (r01: k=9/5 kb lists
-	// 43 M pairs/s at 512, 32 M at 1024, 20 M at 2048)
-	const uint32_t T = t_env == 512 || t_env == 1024 || t_env == 2048 ? (uint32_t)t_env : 512u;
-	(void)max_total;
-	if (T == 512) return launch_sparse_mp<512>(MSC_MP_ARGS);
-	if (T == 1024) return launch_sparse_mp<1024>(MSC_MP_ARGS);
-	return launch_sparse_mp<2048>(MSC_MP_ARGS);
-#undef MSC_MP_ARGS
+	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
+	const uint64_t waves = (uint64_t)m * parts;
+	uint32_t blocks = (uint32_t)num_cus * per_cu;
+	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
+	if (div_tables) {
+		k_pair_sparse_mp<true, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                                     q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials,
+		                                                                     (const DivTerm*)div_tables, (double*)div_partials, order);
+	} else {
+		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
+		                                                                      nullptr, nullptr, parts);
+	}
+	return hipGetLastError();
+}
+
+// how many waves should share a candidate of a window of m (about `entries` merged entries each): fill the resident wave slots, keep
+// at least two chunks per part
+uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus) {
+	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
+	if (off || m == 0) return 1;
+	const uint64_t slots = (uint64_t)num_cus * 32, chunks = entries / kMpChunk;
+	uint32_t parts = 1;
+	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * 2 <= chunks) parts *= 2;
+	return parts;
 }
 
 // candidates (slot list or the first m slots behind c_hdr) against one query list: 16 x {markov, rre} partials per candidate
