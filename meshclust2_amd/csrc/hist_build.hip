@@ -205,6 +205,70 @@ __global__ void __launch_bounds__(64) k_prefix(uint8_t* __restrict__ scalars, ui
 	}
 }
 
+// k_finalize for a FEW large slots (the rounded mean of msc_mean_nearest is one slot: a single workgroup re-reading 1 MiB took
+// 107 us): one WAVE per tile writes the tile's sum into the record's tile array and its sum of squares / maximum into a scratch
+// pair; k_prefix_record (one wave per slot) scans the tile sums and folds the record.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_finalize_tiles(const T* __restrict__ bins, uint8_t* __restrict__ scalars, uint64_t scalar_stride, uint64_t slot_elems,
+                                                           uint64_t first_slot, uint64_t n_slots, uint32_t S, uint32_t tile_bins, uint64_t* __restrict__ sq_max) {
+	constexpr uint32_t E = 16 / sizeof(T);
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t W = (uint64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (W >= n_slots * S) return;
+	const uint64_t rel = W / S, slot = first_slot + rel;
+	const uint32_t t = (uint32_t)(W % S);
+	const T* h = bins + slot * slot_elems + (uint64_t)t * tile_bins;
+	uint64_t ts = 0, sq = 0, mx = 0;
+	for (uint32_t l = 0; l < tile_bins / (64 * E); l++) {
+		const uint4 v = *reinterpret_cast<const uint4*>(h + (uint64_t)l * 64 * E + lane * E);
+		const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) { const uint64_t p = e[j]; ts += p; sq += p * p; mx = p > mx ? p : mx; }
+	}
+	ts = wave_sum_u64(ts);
+	sq = wave_sum_u64(sq);
+	mx = wave_max_u64(mx);
+	if (lane == 0) {
+		reinterpret_cast<uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars))[t] = ts;
+		sq_max[(rel * S + t) * 2] = sq;
+		sq_max[(rel * S + t) * 2 + 1] = mx;
+	}
+}
+__global__ void __launch_bounds__(64) k_prefix_record(uint8_t* __restrict__ scalars, uint64_t scalar_stride, uint64_t first_slot, uint32_t S, uint64_t nbins,
+                                                      int keep_mag, const uint64_t* __restrict__ sq_max) {
+	const uint64_t slot = first_slot + blockIdx.x;
+	MscSlotScalars* sc = reinterpret_cast<MscSlotScalars*>(scalars + slot * scalar_stride);
+	uint64_t* p = reinterpret_cast<uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
+	const uint32_t lane = threadIdx.x;
+	uint64_t carry = 0, sq = 0, mx = 0;
+	for (uint32_t base = 0; base < S; base += 64) {
+		const uint32_t i = base + lane;
+		const uint64_t v = i < S ? p[i] : 0;
+		if (i < S) { sq += sq_max[((uint64_t)blockIdx.x * S + i) * 2]; const uint64_t m_ = sq_max[((uint64_t)blockIdx.x * S + i) * 2 + 1]; mx = m_ > mx ? m_ : mx; }
+		uint64_t inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint64_t o = __shfl_up(inc, off, 64);
+			if ((int)lane >= off) inc += o;
+		}
+		if (i < S) p[i] = carry + inc - v;
+		carry += __shfl(inc, 63, 64);
+	}
+	sq = wave_sum_u64(sq);
+	mx = wave_max_u64(mx);
+	if (lane == 0) {
+		const uint64_t a = carry;
+		sc->sum = a;
+		sc->sum_sq = sq;
+		sc->max_count = mx;
+		if (!keep_mag) sc->mag = a;
+		const double N = (double)nbins;                      // (the same expressions as k_finalize)
+		const double aq = (double)a / N;
+		double var = ((double)sq - 2.0 * aq * (double)a + N * aq * aq) / N;
+		sc->stddev = sqrt(var > 0 ? var : 0);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ small k: one fused LDS pass
 // 4^k <= 16384 bins (k <= 7): the whole histogram lives in LDS as 32-bit counters. One workgroup per sequence streams
 // its packed 2-bit k-mers, counts them with LDS atomics, then writes the slot ONCE in the tile-permuted layout
@@ -576,10 +640,23 @@ hipError_t msc_launch_build_sort(hipStream_t st, void* bins, uint8_t* scalars, c
 	return e != hipSuccess ? e : hipGetLastError();
 }
 
+// tile_scratch (optional, 16 * n_slots * S bytes): the wave-per-tile form, for a few large slots
 hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,
-                               uint64_t first_slot, uint64_t n_slots, bool keep_mag) {
+                               uint64_t first_slot, uint64_t n_slots, bool keep_mag, uint64_t* tile_scratch) {
 	if (n_slots == 0) return hipSuccess;
 	const uint64_t stride = msc_scalar_stride(L.S);
+	if (tile_scratch) {
+		const uint64_t waves = n_slots * L.S;
+		by_dtype(dtype, [&](auto tag) {
+			using T = decltype(tag);
+			k_finalize_tiles<T><<<dim3((unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st>>>((const T*)bins, scalars, stride, L.padded_bins, first_slot,
+			                                                                                                          n_slots, L.S, L.tile_bins, tile_scratch);
+		});
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		k_prefix_record<<<dim3((unsigned)n_slots), dim3(64), 0, st>>>(scalars, stride, first_slot, L.S, L.nbins, keep_mag ? 1 : 0, tile_scratch);
+		return hipGetLastError();
+	}
 	by_dtype(dtype, [&](auto tag) {
 		using T = decltype(tag);
 		k_finalize<T><<<dim3((unsigned)n_slots), dim3(kBlock), 0, st>>>((const T*)bins, scalars, stride, L.padded_bins, first_slot, L.S,

@@ -45,7 +45,7 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
 	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
@@ -215,6 +215,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->sp_partials);
 	release(ctx->grp_pairs);
 	release(ctx->grp_self);
+	release(ctx->tile_scratch);
 	release(ctx->sp_acc_batch);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
@@ -2147,10 +2148,9 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	// members vs the rounded mean: only the |p - r| reduction of the merge kernel is used
 	if ((r = run_score_fwd(ctx, set, member_slots, m, rs))) return r;
 	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
-	if (dist_out && (r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
+	if ((r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
 	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, ctx->last_partial_stride, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
-	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, dist_out ? (double*)ctx->raw.p : nullptr,
-	                                   (MscReduceOut*)ctx->reduce_out.p));
+	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, (double*)ctx->raw.p, (MscReduceOut*)ctx->reduce_out.p));
 	MscReduceOut ro;
 	HIP_TRY(ctx, hipMemcpyAsync(&ro, ctx->reduce_out.p, sizeof ro, hipMemcpyDeviceToHost, ctx->stream));
 	if (dist_out) HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->raw.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2185,17 +2185,17 @@ extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uin
 	HIP_TRY(ctx, msc_launch_colsum(ctx->stream, L, set->dtype, set->bins, d_slots, (uint32_t)m, rs->bins, mean_out ? (double*)ctx->mean.p : nullptr,
 	                               (uint64_t*)ctx->floor_sum.p, nullptr));
 	HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, sizeof(MscSlotScalars), ctx->stream));
-	HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, set->dtype, 0, 1, false));
+	if ((r = ensure(ctx, ctx->tile_scratch, (size_t)L.S * 2 * sizeof(uint64_t)))) return r;
+	HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, set->dtype, 0, 1, false, (uint64_t*)ctx->tile_scratch.p));      // one wave per tile
 	if ((r = refresh_bounds(ctx, rs, 0, 1))) return r;
 	// members vs the rounded mean through the streaming kernel (only the |p - r| reduction is used)
 	ScoreRequest rq;
 	rq.cands = set; rq.cand_slots = member_slots; rq.m = m; rq.qset = rs; rq.q_slot = 0; rq.only_tiles = true;
 	if ((r = run_score(ctx, rq))) return r;
 	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
-	if (dist_out && (r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
+	if ((r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
 	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
-	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, dist_out ? (double*)ctx->raw.p : nullptr,
-	                                   (MscReduceOut*)ctx->reduce_out.p));
+	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, (double*)ctx->raw.p, (MscReduceOut*)ctx->reduce_out.p));
 	MscReduceOut ro;
 	HIP_TRY(ctx, hipMemcpyAsync(&ro, ctx->reduce_out.p, sizeof ro, hipMemcpyDeviceToHost, ctx->stream));
 	if (dist_out) HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->raw.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

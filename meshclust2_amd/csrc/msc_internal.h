@@ -124,7 +124,7 @@ hipError_t msc_launch_count(hipStream_t st, void* bins, uint8_t* scalars, const 
                             const uint64_t* seg_start, const uint64_t* kmer_off, uint64_t n_segs,
                             uint64_t total_kmers, bool saturating);
 hipError_t msc_launch_finalize(hipStream_t st, const void* bins, uint8_t* scalars, const MscLayout& L, int dtype,
-                               uint64_t first_slot, uint64_t n_slots, bool keep_mag);
+                               uint64_t first_slot, uint64_t n_slots, bool keep_mag, uint64_t* tile_scratch = nullptr);
 bool msc_lds_build_supported(const MscLayout& L);
 bool msc_sort_build_supported(const MscLayout& L, int k);
 uint32_t msc_sort_build_max_kmers();

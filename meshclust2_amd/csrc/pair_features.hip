@@ -1176,6 +1176,53 @@ __global__ void __launch_bounds__(1024) k_distance_d(const MscPartial* __restric
 	}
 }
 
+// the same, shared out: one wave per member (its S records are consecutive), then the first minimum over the distances
+__global__ void __launch_bounds__(kBlock) k_distance_members(const MscPartial* __restrict__ partials, uint32_t S, uint32_t m, const uint8_t* __restrict__ scalars,
+                                                             uint64_t scalar_stride, const uint32_t* __restrict__ member_slots, const uint8_t* __restrict__ r_scalars,
+                                                             const uint64_t* __restrict__ floor_sum, double* __restrict__ dist_out) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (i >= m) return;
+	uint64_t manh = 0;
+	for (uint32_t s = lane; s < S; s += 64) manh += partials[(uint64_t)i * S + s].manh;
+	manh = shfl_sum_u64(manh);
+	if (lane == 0) {
+		const MscSlotScalars* rs = reinterpret_cast<const MscSlotScalars*>(r_scalars);
+		const uint32_t slot = member_slots ? member_slots[i] : i;
+		const MscSlotScalars* ps = reinterpret_cast<const MscSlotScalars*>(scalars + (uint64_t)slot * scalar_stride);
+		const uint64_t dist = ps->sum + rs->sum - manh;
+		const uint64_t mag = ps->sum + *floor_sum;
+		const double frac = (double)dist / (double)mag;
+		dist_out[i] = 10000.0 * (1.0 - frac * frac);
+	}
+}
+__global__ void __launch_bounds__(1024) k_first_minimum(const double* __restrict__ dist, uint32_t m, MscReduceOut* __restrict__ out) {
+	__shared__ Best s_best[1024];
+	Best b{0.0, -1};
+	for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+		const double d = dist[i];
+		if (b.pos < 0 || d < b.sim) b = Best{d, (int64_t)i};          // first minimum wins (cluster/Trainer.cpp:150-153)
+	}
+	s_best[threadIdx.x] = b;
+	__syncthreads();
+	for (int stride = 512; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) {
+			Best x = s_best[threadIdx.x], y = s_best[threadIdx.x + stride];
+			if (y.pos >= 0 && (x.pos < 0 || y.sim < x.sim || (y.sim == x.sim && y.pos < x.pos))) s_best[threadIdx.x] = y;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		MscReduceOut r;
+		r.best_sim = s_best[0].sim;
+		r.best_pos = s_best[0].pos;
+		r.any_close = 0;
+		r.n_close = 0;
+		r.first_error = 0;
+		*out = r;
+	}
+}
+
 // ---------------------------------------------------------------------------------------- column sums (mean)
 // get_mean / mean_shift_update mean (cluster/ClusterFactory.cpp:338-357,297-326): mean_i = (sum_members p_i) / m in FP64.
 // Sums of integers are exact below 2^53, so integer column sums + one division reproduce the reference's
@@ -1564,9 +1611,19 @@ hipError_t msc_launch_colsum(hipStream_t st, const MscLayout& L, int dtype, cons
 	return hipGetLastError();
 }
 
+// dist_out != nullptr and more than a handful of records: one wave per member folds its S records (coalesced) and writes the
+// distance, a single workgroup then takes the first minimum; otherwise the one-workgroup kernel does both (a thread per member
+// walking its records took 150 us for 1 000 members of 256 tiles)
 hipError_t msc_launch_distance_d(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t m, const uint8_t* scalars,
                                  uint64_t scalar_stride, const uint32_t* member_slots, const uint8_t* r_scalars,
                                  const uint64_t* floor_sum, double* dist_out, MscReduceOut* out) {
+	if (dist_out && (uint64_t)m * S >= 4096) {
+		k_distance_members<<<dim3((m + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st>>>(partials, S, m, scalars, scalar_stride, member_slots, r_scalars, floor_sum, dist_out);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		k_first_minimum<<<dim3(1), dim3(1024), 0, st>>>(dist_out, m, out);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_distance_d, dim3(1), dim3(1024), 0, st, partials, S, m, scalars, scalar_stride, member_slots, r_scalars,
 	                   floor_sum, dist_out, out);
 	return hipGetLastError();
