@@ -190,6 +190,14 @@ int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_s
 /* Exact slot copy: bins and EVERY scalar (incl. a stale mag). What a host container of Center objects needs when it
  * relocates them without going through clone() (std::vector growth of the device-side centre store). */
 int msc_hist_copy(msc_ctx* ctx, msc_hist_set* dst, uint64_t dst_slot, const msc_hist_set* src, uint64_t src_slot);
+/* The same for n slots in one launch per region (relocating or compacting a whole centre store: the vector<Center*> of
+ * cluster/ClusterFactory.cpp:560-575 as it grows); the destination slots must be distinct. A sparse destination appends all the
+ * lists or none (MSC_ERR_OOM). */
+int msc_hist_copy_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n);
+/* msc_hist_clone for n slots in one launch per region: the Center(c->clone()) of every cluster the accumulate stage opened
+ * (cluster/ClusterFactory.cpp:560-575, cluster/Center.h:13-40) -- a centre is not read before the update stage, so a driver may
+ * queue its clones and issue them together. */
+int msc_hist_clone_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n);
 
 /* ------------------------------------------------------------------ a5/a7: model (Feature<T> + GLM weights) */
 /* Mirrors the state Predictor::read_from builds (predict/Predictor.cpp:125-185): combos are replayed through

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "msc_hist_copy": (_int, [_vp, _vp, _u64, _vp, _u64]),
     "msc_hist_assign": (_int, [_vp, _vp, _u64, _vp, _u64]),
     "msc_hist_assign_batch": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64]),
+    "msc_hist_copy_batch": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64]),
+    "msc_hist_clone_batch": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64]),
     "msc_model_create": (_int, [_vp, _int, _int, C.POINTER(_int), _pu64, _pdbl, _int, _pu64, _pdbl, _pdbl, _dbl, C.POINTER(_vp)]),
     "msc_model_load": (_int, [_vp, C.c_char_p, _int, C.POINTER(_vp)]),
     "msc_model_parse": (_int, [_vp, C.c_char_p, _int, C.POINTER(_vp)]),

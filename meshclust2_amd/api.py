@@ -167,6 +167,24 @@ class HistogramSet:
         """DivergencePoint::set (mag is NOT copied)"""
         self.ctx.check(self.ctx.lib.msc_hist_assign(self.ctx.h, self.h, dst_slot, src.h, src_slot))
 
+    def copy_from(self, dst_slot, src, src_slot):
+        """exact copy of a slot (stale magnitude included)"""
+        self.ctx.check(self.ctx.lib.msc_hist_copy(self.ctx.h, self.h, dst_slot, src.h, src_slot))
+
+    def clone_batch(self, dst_slots, src, src_slots):
+        """DivergencePoint::clone of many slots in one launch per region"""
+        d = np.ascontiguousarray(dst_slots, dtype=np.uint32)
+        s_ = np.ascontiguousarray(src_slots, dtype=np.uint32)
+        assert d.size == s_.size
+        self.ctx.check(self.ctx.lib.msc_hist_clone_batch(self.ctx.h, self.h, _ptr(d), src.h, _ptr(s_), d.size))
+
+    def copy_batch(self, dst_slots, src, src_slots):
+        """exact copies of many slots in one launch per region"""
+        d = np.ascontiguousarray(dst_slots, dtype=np.uint32)
+        s_ = np.ascontiguousarray(src_slots, dtype=np.uint32)
+        assert d.size == s_.size
+        self.ctx.check(self.ctx.lib.msc_hist_copy_batch(self.ctx.h, self.h, _ptr(d), src.h, _ptr(s_), d.size))
+
     def device_view(self):
         b, s = C.c_void_p(), C.c_void_p()
         sb, ss = C.c_uint64(), C.c_uint64()

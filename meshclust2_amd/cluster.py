@@ -238,8 +238,8 @@ class GpuEngine:
         if clone:
             if self.n_centres == self.centres.capacity:          # relocate into a store twice the size (exact copies: stale mags survive)
                 bigger = self.api.HistogramSet(self.ctx, self.k, self.dtype, 2 * self.centres.capacity)
-                for i in range(self.n_centres):
-                    self.ctx.check(self.ctx.lib.msc_hist_copy(self.ctx.h, bigger.h, i, self.centres.h, i))
+                every = np.arange(self.n_centres, dtype=np.uint32)
+                bigger.copy_batch(every, self.centres, every)
                 self.centres.close()
                 self.centres = bigger
             centre = self.n_centres

@@ -1115,7 +1115,9 @@ extern "C" int msc_hist_assign(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, con
 
 // center->set(*next) for many centres at once (the tail of every mean_shift_update of a round): same field semantics as
 // msc_hist_assign; destination slots must be distinct.
-extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n) {
+// center->set(*next) (exact = 0), an exact copy (1: every word of the record, the stale magnitude included) or a clone (2: an exact
+// copy with the magnitude re-summed) of n slots in one launch per region
+static int assign_or_copy_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n, int exact) {
 	if (!ctx || !dst || !src || dst->ctx != ctx || src->ctx != ctx) return MSC_ERR_INVALID_ARG;
 	if (n == 0) return MSC_OK;
 	if (!dst_slots || !src_slots) return MSC_ERR_INVALID_ARG;
@@ -1127,7 +1129,11 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 		hi = std::max(hi, dst_slots[i]);
 	}
 	if (n > 0x7fffffffull || (dst->sparse && src->scalar_stride != dst->scalar_stride)) {
-		for (uint64_t i = 0; i < n; i++) { const int r = msc_hist_assign(ctx, dst, dst_slots[i], src, src_slots[i]); if (r) return r; }
+		for (uint64_t i = 0; i < n; i++) {
+			const int r = exact == 2 ? msc_hist_clone(ctx, dst, dst_slots[i], src, src_slots[i]) : exact ? msc_hist_copy(ctx, dst, dst_slots[i], src, src_slots[i])
+			                                                                                             : msc_hist_assign(ctx, dst, dst_slots[i], src, src_slots[i]);
+			if (r) return r;
+		}
 		return MSC_OK;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1148,7 +1154,8 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, msc_launch_sparse_assign_batch(ctx->stream, dst->ent, dst->cum, dst->hdr, src->ent, src->cum, src->hdr, (const uint32_t*)ctx->slots.p,
 		                                            (const uint32_t*)ctx->pair_seg.p, (const uint64_t*)ctx->sp_chunk_off.p, (uint32_t)n));
-		HIP_TRY(ctx, msc_launch_assign_scalars(ctx->stream, dst->scalars, src->scalars, dst->scalar_stride, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)n));
+		HIP_TRY(ctx, msc_launch_assign_scalars(ctx->stream, dst->scalars, src->scalars, dst->scalar_stride, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)n,
+		                                       exact));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // off and the caller's slot arrays may go away
 		for (uint64_t i = 0; i < n; i++) {
 			MscSparseHdr h = src->hdr_host[src_slots[i]];
@@ -1167,7 +1174,7 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, dst_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, src_slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, msc_launch_assign_batch(ctx->stream, dst->L, dst->bins, dst->scalars, src->bins, src->scalars, (const uint32_t*)ctx->slots.p,
-	                                     (const uint32_t*)ctx->pair_seg.p, (uint32_t)n));
+	                                     (const uint32_t*)ctx->pair_seg.p, (uint32_t)n, exact));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the caller's slot arrays may go away
 	// host-side bounds: nothing copied can exceed the source set's own maxima
 	dst->max_count = std::max(dst->max_count, src->max_count);
@@ -1180,6 +1187,16 @@ extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint
 	}
 	mark_stale(dst, lo, (uint64_t)hi + 1 - lo);
 	return MSC_OK;
+}
+
+extern "C" int msc_hist_assign_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n) {
+	return assign_or_copy_batch(ctx, dst, dst_slots, src, src_slots, n, 0);
+}
+extern "C" int msc_hist_copy_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n) {
+	return assign_or_copy_batch(ctx, dst, dst_slots, src, src_slots, n, 1);
+}
+extern "C" int msc_hist_clone_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t* dst_slots, const msc_hist_set* src, const uint32_t* src_slots, uint64_t n) {
+	return assign_or_copy_batch(ctx, dst, dst_slots, src, src_slots, n, 2);
 }
 
 extern "C" int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slot_bytes, void** scalars, uint64_t* scalar_bytes) {

@@ -206,7 +206,7 @@ hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_
 hipError_t msc_launch_sparse_assign_batch(hipStream_t st, void* d_ent, uint32_t* d_cum, MscSparseHdr* d_hdr, const void* s_ent, const uint32_t* s_cum, const MscSparseHdr* s_hdr,
                                           const uint32_t* ds, const uint32_t* ss, const uint64_t* dst_off, uint32_t n);
 hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const uint8_t* src_scalars, uint64_t stride_bytes, const uint32_t* dst_slots,
-                                     const uint32_t* src_slots, uint32_t n);
+                                     const uint32_t* src_slots, uint32_t n, int exact = 0);
 hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                          const uint32_t* cand_slots, uint32_t m, const void* q_ent, const MscSparseHdr* q_hdr, int use_window, uint64_t min_len,
                                          uint64_t max_len, double* out);
@@ -234,4 +234,4 @@ hipError_t msc_launch_distance_batch(hipStream_t st, const MscPartial* partials,
                                      const uint32_t* member_slots, const uint32_t* pair_seg, const uint8_t* r_scalars, uint64_t r_stride, const uint64_t* floor_sum,
                                      double* dist_out);
 hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* dst_bins, uint8_t* dst_scalars, const uint8_t* src_bins,
-                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n);
+                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n, int exact = 0);

@@ -1641,19 +1641,21 @@ __global__ void __launch_bounds__(kBlock) k_assign_bins(uint4* __restrict__ dst,
 	}
 }
 __global__ void __launch_bounds__(kBlock) k_assign_scalars(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, const uint32_t* __restrict__ ds,
-                                                          const uint32_t* __restrict__ ss, uint32_t words_per_slot, uint32_t S, uint64_t total) {
+                                                          const uint32_t* __restrict__ ss, uint32_t words_per_slot, uint32_t S, uint64_t total, int every_word) {
 	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t pair = e / words_per_slot;
 		const uint32_t w = (uint32_t)(e % words_per_slot);
 		// words of MscSlotScalars: 0 mag | 1 length 2 sum 3 sum_sq 4 max_count | 5-8 one_mers | 9 stddev 10 overflow | 11 id | 12.. ; 16.. tile prefixes
-		const bool copied = (w >= 1 && w <= 4) || w == 11 || (w >= 16 && w < 16 + S);
-		if (copied) dst[(uint64_t)ds[pair] * words_per_slot + w] = src[(uint64_t)ss[pair] * words_per_slot + w];
+		// (every_word 1: an exact copy of the record, msc_hist_copy_batch; 2: DivergencePoint::clone, msc_hist_clone_batch -- an exact
+		// copy whose magnitude is re-summed from the bins, i.e. word 0 <- word 2)
+		const bool copied = every_word || (w >= 1 && w <= 4) || w == 11 || (w >= 16 && w < 16 + S);
+		if (copied) dst[(uint64_t)ds[pair] * words_per_slot + w] = src[(uint64_t)ss[pair] * words_per_slot + (every_word == 2 && w == 0 ? 2u : w)];
 	}
 }
 }  // namespace
 
 hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* dst_bins, uint8_t* dst_scalars, const uint8_t* src_bins,
-                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n) {
+                                   const uint8_t* src_scalars, const uint32_t* dst_slots, const uint32_t* src_slots, uint32_t n, int exact) {
 	if (n == 0) return hipSuccess;
 	static_assert(offsetof(MscSlotScalars, length) == 8 && offsetof(MscSlotScalars, max_count) == 32 && offsetof(MscSlotScalars, id) == 88 && sizeof(MscSlotScalars) == 128,
 	              "k_assign_scalars hard-codes the record's word positions");
@@ -1665,18 +1667,18 @@ hipError_t msc_launch_assign_batch(hipStream_t st, const MscLayout& L, uint8_t* 
 	const uint32_t words = (uint32_t)(msc_scalar_stride(L.S) / 8);
 	const uint64_t stotal = (uint64_t)words * n;
 	k_assign_scalars<<<dim3((unsigned)std::min<uint64_t>((stotal + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint64_t*)dst_scalars, (const uint64_t*)src_scalars,
-	                                                                                                                      dst_slots, src_slots, words, L.S, stotal);
+	                                                                                                                      dst_slots, src_slots, words, L.S, stotal, exact);
 	return hipGetLastError();
 }
 
 // the scalar half of msc_launch_assign_batch on its own (sparse stores: 128-byte records, no tile prefixes)
 hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const uint8_t* src_scalars, uint64_t stride_bytes, const uint32_t* dst_slots,
-                                     const uint32_t* src_slots, uint32_t n) {
+                                     const uint32_t* src_slots, uint32_t n, int exact) {
 	if (n == 0) return hipSuccess;
 	const uint32_t words = (uint32_t)(stride_bytes / 8);
 	const uint64_t stotal = (uint64_t)words * n;
 	k_assign_scalars<<<dim3((unsigned)std::min<uint64_t>((stotal + kBlock - 1) / kBlock, 1u << 20)), dim3(kBlock), 0, st>>>((uint64_t*)dst_scalars, (const uint64_t*)src_scalars,
-	                                                                                                                      dst_slots, src_slots, words, 0, stotal);
+	                                                                                                                      dst_slots, src_slots, words, 0, stotal, exact);
 	return hipGetLastError();
 }
 

@@ -81,6 +81,12 @@ public:
 	void clone(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_clone(ctx_.get(), h_, dst, src.h_, src_slot)); }
 	void set(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_assign(ctx_.get(), h_, dst, src.h_, src_slot)); }
 	void copy(uint64_t dst, const PointSet& src, uint64_t src_slot) { ctx_.check(msc_hist_copy(ctx_.get(), h_, dst, src.h_, src_slot)); }
+	void clone_batch(const std::vector<uint32_t>& dst, const PointSet& src, const std::vector<uint32_t>& src_slots) {
+		ctx_.check(msc_hist_clone_batch(ctx_.get(), h_, dst.data(), src.h_, src_slots.data(), dst.size()));
+	}
+	void copy_batch(const std::vector<uint32_t>& dst, const PointSet& src, const std::vector<uint32_t>& src_slots) {
+		ctx_.check(msc_hist_copy_batch(ctx_.get(), h_, dst.data(), src.h_, src_slots.data(), dst.size()));
+	}
 private:
 	Context& ctx_;
 	msc_hist_set* h_ = nullptr;

@@ -72,7 +72,8 @@ struct GpuBackend : msc::ClusterBackend {
 	int k, dtype;
 	double cutoff;
 	std::unique_ptr<msc::PointSet> centres;
-	uint64_t n_centres = 0;
+	uint64_t n_centres = 0;         // centre slots handed out
+	uint64_t n_stored = 0;          // ... of which the first n_stored exist in the store (the rest are queued clones)
 	uint64_t centre_arena = 0;      // > 0: sparse centre store with that many entries
 
 	GpuBackend(msc::Context& c, msc::PointSet& p, msc::Trainer& t, int k_, int dt, double cut, uint64_t sparse_arena)
@@ -85,8 +86,21 @@ struct GpuBackend : msc::ClusterBackend {
 	// for the sparse layout, to compact the append-only entry arena.
 	void rebuild_centres(uint64_t capacity) {
 		std::unique_ptr<msc::PointSet> fresh(new msc::PointSet(ctx, k, dtype, capacity, centre_arena));
-		for (uint64_t i = 0; i < n_centres; i++) fresh->copy(i, *centres, i);
+		std::vector<uint32_t> all(n_stored);                          // (queued clones are the last slots and are not in the old store yet)
+		for (uint64_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
+		fresh->copy_batch(all, *centres, all);          // one launch per region (slot by slot: 4 copy commands and a sync per centre)
 		centres.swap(fresh);
+	}
+	// Center(c->clone()) of the accumulate stage, queued: nothing reads a centre before the update stage, so the clones of many
+	// clusters go out as one msc_hist_clone_batch (one by one each is four copy commands and a stream sync on a sparse store)
+	std::vector<uint32_t> pend_slot, pend_point;
+	void flush_clones() {
+		if (pend_slot.empty()) return;
+		std::vector<uint32_t> s_, p_;
+		s_.swap(pend_slot);
+		p_.swap(pend_point);
+		with_arena_retry([&] { centres->clone_batch(s_, points, p_); });
+		n_stored = n_centres;
 	}
 	template <class F> void with_arena_retry(F&& f) {      // sparse store: compact once when the arena runs out
 		try { f(); }
@@ -104,19 +118,23 @@ struct GpuBackend : msc::ClusterBackend {
 	}
 	int64_t closest(const std::vector<uint32_t>& members) override { return trn.closest(points, members); }
 	uint32_t centre_new(uint32_t point) override {
-		if (n_centres == centres->capacity()) rebuild_centres(centres->capacity() * 2);
+		if (n_centres == centres->capacity()) { flush_clones(); rebuild_centres(centres->capacity() * 2); }
 		const uint32_t slot = (uint32_t)n_centres++;
-		with_arena_retry([&] { centres->clone(slot, points, point); });
+		pend_slot.push_back(slot);
+		pend_point.push_back(point);
+		if (pend_slot.size() >= 8192) flush_clones();
 		return slot;
 	}
-	void centre_set(uint32_t centre, uint32_t point) override { with_arena_retry([&] { centres->set(centre, points, point); }); }
+	void centre_set(uint32_t centre, uint32_t point) override { flush_clones(); with_arena_retry([&] { centres->set(centre, points, point); }); }
 	void filter(uint32_t centre, const std::vector<uint32_t>& pts, std::vector<uint8_t>& keep) override {
+		flush_clones();
 		keep.assign(pts.size(), 0);
 		uint64_t n = 0;
 		ctx.check(msc_filter(ctx.get(), trn.feature().get(), cutoff, centres->get(), centre, points.get(), pts.data(), pts.size(), keep.data(), &n));
 	}
-	long merge(const std::vector<uint32_t>& cs, long current, long begin, long last) override { return trn.merge(*centres, cs, current, begin, last); }
+	long merge(const std::vector<uint32_t>& cs, long current, long begin, long last) override { flush_clones(); return trn.merge(*centres, cs, current, begin, last); }
 	bool update_centres(const std::vector<uint32_t>& cs, const std::vector<uint32_t>& pts, const std::vector<uint64_t>& offsets, std::vector<int64_t>& nearest) override {
+		flush_clones();
 		ctx.check(msc_update_centres(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), points.get(), pts.data(), offsets.data(),
 		                             nearest.data(), nullptr));
 		return true;
@@ -124,6 +142,7 @@ struct GpuBackend : msc::ClusterBackend {
 	bool centre_set_batch(const std::vector<uint32_t>& cs, const std::vector<uint32_t>& pts) override {
 		// (a sparse store appends every moved centre's list to its arena in one launch, all or nothing: compact once when it runs
 		// out; if even the compacted arena cannot take the whole round, go centre by centre -- each set() frees the list it replaces)
+		flush_clones();
 		try {
 			with_arena_retry([&] { ctx.check(msc_hist_assign_batch(ctx.get(), centres->get(), cs.data(), points.get(), pts.data(), cs.size())); });
 		} catch (const msc::Error& e) {
@@ -133,6 +152,7 @@ struct GpuBackend : msc::ClusterBackend {
 		return true;
 	}
 	bool merge_all(const std::vector<uint32_t>& cs, int delta, std::vector<int64_t>& best) override {
+		flush_clones();
 		ctx.check(msc_merge_all(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, best.data()));
 		return true;
 	}

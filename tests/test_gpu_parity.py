@@ -295,6 +295,50 @@ def test_group_statistics_dense_and_list_forms_agree(ctx):
     assert outs[0] == outs[1] and len(outs[0]) == 12 * 2 * 16
 
 
+@pytest.mark.parametrize("layout", ["dense", "sparse"])
+def test_copy_batch_is_an_exact_copy(ctx, layout):
+    """msc_hist_copy_batch (relocating / compacting a centre store in one launch): bins, list and every word of the record -- a moved
+    centre's stale magnitude included -- equal the slot-by-slot msc_hist_copy, and scores against the copies are the same bits"""
+    seqs, _ = synth.families(4242, 12, 1500, family=4, length_jitter=200)
+    n = len(seqs)
+    k, dtype = 8, 16
+    ent = (sum(len(s_) for s_ in seqs) * 3 + 4096) if layout == "sparse" else 0
+    pts = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+    pts.build(list(seqs))
+    centres = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+    for i in range(n):
+        centres.clone_from(i, pts, i)
+    for i in range(0, n, 2):                       # moved centres: set() keeps the magnitude of the histogram they were cloned from
+        centres.assign_from(i, pts, (i + 5) % n)
+    one = api.HistogramSet(ctx, k, dtype, n + 3, sparse_entries=ent)
+    for i in range(n):
+        one.copy_from(i, centres, i)
+    order = np.array([7, 0, 3, 11, 1, 2, 9, 4, 10, 5, 8, 6], dtype=np.uint32)      # any distinct destinations
+    many = api.HistogramSet(ctx, k, dtype, n + 3, sparse_entries=ent)
+    many.copy_batch(order, centres, np.arange(n, dtype=np.uint32))
+    for i in range(n):
+        a, b, c = centres.info(i), one.info(i), many.info(int(order[i]))
+        assert a == b == c
+        assert np.array_equal(one.download(i), many.download(int(order[i]))) and np.array_equal(one.download(i), centres.download(i))
+    assert any(centres.info(i)["mag"] != centres.info(i)["sum"] for i in range(0, n, 2))          # the stale magnitudes are really there
+    mask = FAST_MASK
+    r1 = api.pair_features_raw(ctx, one, np.arange(n, dtype=np.uint32), pts, 3, mask)
+    r2 = api.pair_features_raw(ctx, many, order, pts, 3, mask)
+    assert np.array_equal(np.asarray(r1), np.asarray(r2))
+    # msc_hist_clone_batch == msc_hist_clone slot by slot (magnitude re-summed from the bins)
+    c1 = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+    c2 = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
+    for i in range(n):
+        c1.clone_from(int(order[i]), centres, i)
+    c2.clone_batch(order, centres, np.arange(n, dtype=np.uint32))
+    for i in range(n):
+        assert c1.info(i) == c2.info(i) and c1.info(i)["mag"] == c1.info(i)["sum"] and np.array_equal(c1.download(i), c2.download(i))
+    if layout == "sparse":                          # all or nothing against the entry arena
+        tiny = api.HistogramSet(ctx, k, dtype, n, sparse_entries=64)
+        with pytest.raises(api.MscError, match="arena"):
+            tiny.copy_batch(np.arange(n, dtype=np.uint32), centres, np.arange(n, dtype=np.uint32))
+
+
 def test_upload_round_trip_and_properties(ctx):
     """Size-independent properties: symmetric statistics, self-pair identities, checksum of checksums."""
     rng = np.random.default_rng(3)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where the mean-shift driver's time goes on the GPU box: writes the synthetic FASTA, runs msc_cluster plain (its own
 # "timestamp" lines) and under rocprofv3 --kernel-trace --stats (calls and mean duration per kernel).
-#   tools/cluster_profile.sh <tag> <n_seqs> <k> <dtype> <weights> [extra msc_cluster flags]
+#   tools/cluster_profile.sh <tag> <n_seqs> <k> <dtype> <weights> [extra msc_cluster flags]      (CLUSTER_TIME_JITTER=j: lengths 1000 +- j)
 set -e
 TAG=$1; N=$2; K=$3; DT=$4; W=$5; shift 5
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -12,7 +12,9 @@ python3 - <<PY
 import sys
 sys.path.insert(0, "$R")
 from meshclust2_amd import synth
-seqs, headers = synth.families(777, $N, 1000)
+import os
+j = int(os.environ.get("CLUSTER_TIME_JITTER", "0"))
+seqs, headers = synth.families(777, $N, 1000, length_jitter=j) if j else synth.families(777, $N, 1000)
 synth.write_fasta("/tmp/cp_$N.fa", seqs, headers)
 PY
 $R/meshclust2_amd/host/msc_cluster /tmp/cp_$N.fa --recover $R/$W --id 0.9 --kmer $K --datatype $DT --output /tmp/cp.clstr "$@" > $O/plain.log 2>&1
