@@ -116,6 +116,19 @@ class DistributedBackend:
     def __init__(self, engine, plan, exchange, rank):
         self.e, self.plan, self.x, self.rank = engine, plan, exchange, rank
         self.resident = -1          # point whose histogram sits in every rank's query slot
+        # MSC_CLUSTER_TRACE=path: rank 0 writes one line per operator call (arguments and result, hashed where long), so that runs with
+        # different numbers of ranks can be compared call by call -- the driver's logic is the same, the first differing line is the bug
+        self.trace = open(os.environ["MSC_CLUSTER_TRACE"], "w") if rank == 0 and os.environ.get("MSC_CLUSTER_TRACE") else None
+
+    def _t(self, what, *vals):
+        if self.trace is not None:
+            import zlib
+            out = []
+            for v in vals:
+                a = np.asarray(v)
+                out.append(str(v) if a.ndim == 0 else "%d:%08x" % (a.size, zlib.crc32(np.ascontiguousarray(a).tobytes())))
+            self.trace.write(what + " " + " ".join(out) + "\n")
+            self.trace.flush()
 
     def _owners(self, points):
         return (points.astype(np.int64) // self.plan.block) % self.plan.world
@@ -153,6 +166,7 @@ class DistributedBackend:
         flags = np.zeros(window.size, dtype=np.uint8)
         if n_close.sum():
             flags[self.x.gather_lists(close_pos, n_close)] = 1
+        self._t("get_close", q, window.astype(np.int64), flags, best_pos, best_sim)
         return flags, best_pos, int(n_close.sum()) == 0
 
     def closest(self, members):
@@ -170,14 +184,18 @@ class DistributedBackend:
         for i, r in enumerate(owners):
             rows[i] = r * n_pad + seen[r]
             seen[r] += 1
-        return self.e.mean_nearest(rows)
+        res = self.e.mean_nearest(rows)
+        self._t("closest", members.astype(np.int64), res)
+        return res
 
     def centre_new(self, point):
         self._make_resident(point)
+        self._t("centre_new", point)
         return self.e.centre_from_query(None, clone=True)
 
     def centre_set(self, centre, point):
         self._make_resident(point)
+        self._t("centre_set", centre, point)
         self.e.centre_from_query(centre, clone=False)
 
     def filter(self, centre, points):
@@ -185,13 +203,18 @@ class DistributedBackend:
         keep_l = self.e.filter(centre, self._locals(points[mine]))
         keep = np.zeros(points.size, dtype=np.uint8)
         keep[self.x.gather_lists(mine[np.flatnonzero(keep_l)])] = 1
+        self._t("filter", centre, points.astype(np.int64), keep)
         return keep
 
     def merge(self, centres, current, begin, last):
-        return self.e.merge(centres, current, begin, last)
+        res = self.e.merge(centres, current, begin, last)
+        self._t("merge", np.asarray(centres, dtype=np.int64), current, begin, last, res)
+        return res
 
     def merge_all(self, centres, delta):
-        return self.e.merge_all(centres, delta)
+        res = self.e.merge_all(centres, delta)
+        self._t("merge_all", np.asarray(centres, dtype=np.int64), delta, np.asarray(res, dtype=np.int64))
+        return res
 
 
 # ------------------------------------------------------------------ rank-local work on the GPU
@@ -247,6 +270,9 @@ class GpuEngine:
             self.centres.clone_from(centre, self.points, self.n_local)
         else:
             self.centres.assign_from(centre, self.points, self.n_local)
+        # clone / set queue their copies on the library's stream and return; the next broadcast overwrites the query slot on torch's
+        # stream, which knows nothing of that queue -- without this the centre could receive the NEXT query's histogram
+        self.ctx.synchronize()
         return centre
 
     def filter(self, centre, local_slots):

@@ -1546,6 +1546,30 @@ def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks):
     assert open(out, "rb").read() == open(os.path.join(golden, clstr), "rb").read()
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks):
+    """The fixtures above hold equal-length sequences, which the reference's length bins turn into (almost) empty windows; here the
+    lengths spread over 900-1100 bases, so every step scores a real window, clusters are opened and moved thousands of times, and
+    the exchanges of every operator carry data. The one-GPU C++ driver (`msc_cluster`, itself held to the reference CLI by the
+    fixtures and the fuzz) is the yardstick: same bytes. (r02: this case exposed a missing stream order between the library's
+    queued centre copy and torch's next write of the query slot -- invisible with equal lengths.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    seqs, hdrs = synth.families(777, 3000, 1000, length_jitter=100)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    common = [fa, "--recover", os.path.join(golden, "weights_k5_u16.txt"), "--id", "0.9", "--kmer", "5", "--datatype", "16", "--output"]
+    one = str(tmp_path / "one.clstr")
+    subprocess.check_call([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + common + [one], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = str(tmp_path / "ranks.clstr")
+    r = _run_ranks(["-m", "meshclust2_amd.cluster"] + common + [out], ranks, tmp_path)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    a, b = open(one, "rb").read(), open(out, "rb").read()
+    assert a.count(b">Cluster") > 500 and a == b
+
+
 def test_bench_two_ranks_packed_exchange(tmp_path):
     """bench.py --gpus 2 (strong scaling: the sequences split over the ranks, 2 all-gathers per step assemble the query block) on
     two ranks sharing this GPU: the line is well-formed and the sharded run scores the same pairs as one rank would."""
