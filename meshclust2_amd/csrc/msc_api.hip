@@ -1432,7 +1432,7 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 	if (k == SPK_MP)
 		return msc_launch_pair_sparse_mp(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 		                                 use_window, min_len, max_len, partials, div_tables, div_partials, order, ctx->num_cus,
-		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz), parts);
+		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz), parts, q_nnz, c_sp->max_nnz);
 	return msc_launch_pair_sparse(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 	                              use_window, min_len, max_len, partials, div_tables, div_partials, order);
 }
@@ -1482,10 +1482,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool mirror_div = need_div && !sp && c_sp != nullptr;      // (the mirror may be here for the group statistics alone)
 	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
-	if (sp) ctx->last_kernel = sparse_kernel_name(spk);
+	if (sp) ctx->last_kernel = spk == SPK_MP && !need_div && msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz) ? "k_pair_sparse_wl" : sparse_kernel_name(spk);
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
 	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
 	const uint32_t mp_parts = sp && spk == SPK_MP && !need_div
+	                                  && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz)      // (short lists: the whole-list kernel, one wave each)
 	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz, ctx->num_cus) : 1;
 	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
 	const uint32_t PS = sp ? SPN : L.S;                               // partial records per candidate
@@ -1758,7 +1759,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
 			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,
 			                                       (MscPartial*)ctx->partials.p + q * m, nullptr, nullptr, order, ctx->num_cus,
-			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz), 1));
+			                                       (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)qset->hdr_host[q_slots[q]].nnz + cands->max_nnz), 1,
+			                                       qset->hdr_host[q_slots[q]].nnz, cands->max_nnz));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);

@@ -882,6 +882,110 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ whole-list kernel (short lists)
+// 1 x M over lists short enough to sit in LDS whole (1 kb sequences: ~1 000 entries, 8 KB): the QUERY list is staged once per
+// workgroup and shared by its four waves for every candidate they walk; a wave stages its candidate's list, takes ONE merge-path
+// split of the two whole lists (k_pair_sparse_mp repeats staging of both pieces, the split and the entry sums per chunk of 512,
+// behind a co-rank search in global memory) and every lane walks an equal share of the merged order with the end-marker walk of
+// the chunked kernel. The prefix difference entering a share is two reads of the stored cum arrays. Integer statistics only: the
+// divergence form stays with the chunked kernel, so its FP64 sums keep one evaluation order whatever the list lengths of a set.
+// LDS: [query: nq + 2][wave 0: c_cap + 2] ... [wave 3: c_cap + 2] entries; entry 0 of a list = the neutral predecessor (bin 0, value
+// 1), entry n + 1 = the end marker.
+__global__ void __launch_bounds__(256) k_pair_sparse_wl(
+    const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
+    const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
+    const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, uint32_t c_cap,
+    uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) uint2 s_wl[];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t kInf = 0xffffffffu;
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint32_t nq = qh.nnz;
+	const uint2* Q = q_ent + qh.off;
+	const uint32_t* CQ = q_cum + qh.off;
+	uint2* ql = s_wl;                                      // ql[0] predecessor, ql[1 + j] = Q[j], ql[nq + 1] marker
+	uint2* cl = s_wl + (nq + 2) + wave * (c_cap + 2);
+	for (uint32_t j = threadIdx.x; j < nq; j += 256) ql[1 + j] = Q[j];
+	if (threadIdx.x == 0) { ql[0] = make_uint2(0u, 1u); ql[nq + 1] = make_uint2(kInf, 1u); }
+	__syncthreads();
+	auto heads = [](uint32_t pa, uint32_t pb, uint2& a, uint2& b) {       // one ds_read_b64 per head (see k_pair_sparse_mp)
+		uint64_t wa, wb;
+		asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(wa), "=&v"(wb) : "v"(pa), "v"(pb) : "memory");
+		a = make_uint2((uint32_t)wa, (uint32_t)(wa >> 32));
+		b = make_uint2((uint32_t)wb, (uint32_t)(wb >> 32));
+	};
+	const uint32_t total_waves = gridDim.x * 4;
+	for (uint32_t c = blockIdx.x * 4 + wave; c < m; c += total_waves) {
+		const uint32_t slot = cand_slots ? cand_slots[c] : c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const MscSparseHdr ch = c_hdr[slot];
+		const uint2* P = c_ent + ch.off;
+		const uint32_t* CP = c_cum + ch.off;
+		const uint32_t nc = ch.nnz;
+		__builtin_amdgcn_wave_barrier();                       // every lane is done with the previous candidate's entries
+		for (uint32_t k0 = lane; k0 < nc; k0 += 256) {         // four loads in flight per lane
+			uint2 v[4];
+#pragma unroll
+			for (uint32_t u = 0; u < 4; u++) v[u] = k0 + 64 * u < nc ? P[k0 + 64 * u] : make_uint2(kInf, 1u);
+#pragma unroll
+			for (uint32_t u = 0; u < 4; u++) if (k0 + 64 * u < nc) cl[1 + k0 + 64 * u] = v[u];
+		}
+		if (lane == 0) { cl[0] = make_uint2(0u, 1u); cl[nc + 1] = make_uint2(kInf, 1u); }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t n = nc + nq, seg = ((n + 63) >> 6) | 1u;             // odd share length: the lanes' heads spread over the LDS banks
+		uint32_t i, j;
+		{
+			const uint32_t d = lane * seg < n ? lane * seg : n;
+			mp_split(d, nc, nq, [&](uint32_t a) { return cl[a + 1].x; }, [&](uint32_t b) { return ql[b + 1].x; }, i, j);
+		}
+		// prefix difference entering the share: the stored inclusive sums of the excess counts before it
+		const uint32_t d_in = (i ? CP[i - 1] : 0u) - (j ? CQ[j - 1] : 0u);
+		uint32_t pa = (uint32_t)(uintptr_t)(cl + i + 1), pb = (uint32_t)(uintptr_t)(ql + j + 1);
+		uint2 a, b;
+		heads(pa, pb, a, b);
+		uint32_t e = a.x < b.x ? a.x : b.x;
+		uint32_t e_end = __shfl_down(e, 1, 64);
+		if (lane == 63) e_end = kInf;
+		uint32_t manh = 0;
+		uint64_t dotx = 0, emd = 0;
+		{
+			const uint32_t pc = cl[i].x, pq = ql[j].x;                         // predecessors (the neutral entries have bin 0)
+			uint32_t pos = pc > pq ? pc : pq;
+			int32_t D = (int32_t)d_in;
+			uint32_t events = 0;
+			while (e < e_end) {
+				const bool ta = a.x == e, tb = b.x == e;
+				const uint32_t absD = (uint32_t)(D < 0 ? -D : D);
+				emd += (uint64_t)absD * (e - pos);
+				const uint32_t pv = ta ? a.y : 1u, qv = tb ? b.y : 1u;
+				manh += pv > qv ? pv - qv : qv - pv;
+				dotx += (uint64_t)pv * qv;
+				events++;
+				D += (int32_t)pv - (int32_t)qv;
+				pos = e;
+				pa += ta ? 8u : 0u;
+				pb += tb ? 8u : 0u;
+				heads(pa, pb, a, b);
+				e = a.x < b.x ? a.x : b.x;
+			}
+			dotx -= events;
+		}
+		if (lane == 0) {      // the stretch behind the last event of either list
+			const uint32_t lc = cl[nc].x, lq = ql[nq].x;                       // (bin 0 of the neutral entry when a list is empty)
+			const int64_t D = (int64_t)(nc ? CP[nc - 1] : 0u) - (int64_t)(nq ? CQ[nq - 1] : 0u);
+			emd += (uint64_t)(D < 0 ? -D : D) * (nbins - (uint64_t)(lc > lq ? lc : lq));
+		}
+		const uint64_t manh_t = wave_sum_u64(manh), dot_t = wave_sum_u64(dotx), emd_t = wave_sum_u64(emd);
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = manh_t; out.dot = dot_t; out.emd = emd_t;
+			partials[c] = out;
+		}
+	}
+}
+
 // ================================================================================================ launchers
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts) {
 	if (n == 0) return hipSuccess;
@@ -1020,13 +1124,23 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
                                      uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                      const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
                                      uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total,
-                                     uint32_t parts) {
+                                     uint32_t parts, uint32_t q_nnz, uint32_t c_max_nnz) {
 	if (m == 0) return hipSuccess;
 	if (max_total > msc_sparse_mp_max_entries() || parts < 1 || parts > 16 || (div_tables && parts != 1) || (uint64_t)m * parts > 0xffffffffull) return hipErrorInvalidValue;
 	if (div_tables) {
 		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
+	}
+	// short lists, integer statistics: the whole-list kernel (the caller passes q_nnz / c_max_nnz; 0 = unknown)
+	if (!div_tables && parts == 1 && msc_sparse_wl_fits(q_nnz, c_max_nnz)) {
+		const size_t lds = ((size_t)q_nnz + 2 + 4 * ((size_t)c_max_nnz + 2)) * sizeof(uint2);
+		const uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 256)));
+		uint32_t blocks = (uint32_t)num_cus * blocks_per_cu;
+		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+		k_pair_sparse_wl<<<dim3(blocks), dim3(256), lds, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum, q_hdr,
+		                                                     c_max_nnz, nbins, use_window, min_len, max_len, partials);
+		return hipGetLastError();
 	}
 	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
 	const uint64_t waves = (uint64_t)m * parts;
@@ -1046,6 +1160,10 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 
 // how many waves should share a candidate of a window of m (about `entries` merged entries each): fill the resident wave slots, keep
 // at least two chunks per part
+bool msc_sparse_wl_fits(uint32_t q_nnz, uint32_t c_max_nnz) {
+	static const bool no_wl = getenv("MSC_SPARSE_NO_WL") != nullptr;
+	return !no_wl && c_max_nnz && (uint64_t)q_nnz + 4ull * c_max_nnz + 10 <= 8192;
+}
 uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus) {
 	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
 	if (off || m == 0) return 1;
