@@ -2353,6 +2353,30 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 	return MSC_OK;
 }
 
+// The two divergence sums of a pair list inside the batched entry points: which lists to merge (the sets themselves, or the sparse
+// mirrors of dense sets) -- or nothing (*ok = false: the caller goes centre by centre) when a 1 x M call on these sets would NOT take
+// the chunked merge kernel, because a pair must get the same kernel, hence the same evaluation order, in every route.
+static int batch_div_lists(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* queries, uint64_t any_q_slot, const msc_hist_set** c_sp,
+                           const msc_hist_set** q_sp, bool* ok) {
+	*ok = false;
+	int r;
+	if ((r = ensure_sparse_mirror(ctx, cands, c_sp)) || (r = ensure_sparse_mirror(ctx, queries, q_sp))) return r;
+	if (!*c_sp || !*q_sp) return MSC_OK;
+	*ok = pick_sparse_kernel(*c_sp, *q_sp, any_q_slot, std::max(cands->max_count, queries->max_count), false) == SPK_MP;
+	return MSC_OK;
+}
+// ... and the pass itself, for P pairs already described by ctx->slots / ctx->segs / ctx->pair_seg: sums -> ctx->div_partials[2 * pair].
+// A sparse pair of sets gets its integer records from the same launch (partials); dense sets have theirs from k_pair_tiles_batch.
+static int batch_div_pass(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* queries, const msc_hist_set* c_sp, const msc_hist_set* q_sp, uint64_t P,
+                          int order, MscPartial* partials) {
+	int r;
+	if ((r = ensure(ctx, ctx->div_tables, P * 256 * 16)) || (r = ensure(ctx, ctx->div_partials, P * 16))) return r;
+	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, c_sp->ent, c_sp->cum, c_sp->hdr, cands->scalars, cands->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P,
+	                                             q_sp->ent, q_sp->cum, q_sp->hdr, cands->L.nbins, 1, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p, partials,
+	                                             order, ctx->num_cus, queries->scalars, queries->scalar_stride, ctx->div_tables.p, ctx->div_partials.p));
+	return MSC_OK;
+}
+
 extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
                                   uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
                                   uint64_t* n_kept) {
@@ -2373,13 +2397,20 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	// sparse sets (both): the pair-list form of the merge-path kernel takes the place of k_pair_tiles_batch, and the rounded means of a
 	// chunk of centres are built as sparse slots by the scatter / count / write kernels with a centre dimension (32-bit range)
 	const bool sp = pts->sparse && centres->sparse;
-	if (no_batch || (pts->sparse != centres->sparse) || (sp && std::max(pts->max_count, centres->max_count) >= 65536) || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) ||
+	if (no_batch || (pts->sparse != centres->sparse) || (sp && std::max(pts->max_count, centres->max_count) >= 65536) || (want & MSC_FEAT_GROUPS) ||
 	    needs_wide(pts, centres))
 		return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
-
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const MscLayout& L = pts->L;
 	int r;
+	// a `--feat slow` model: the filter's two divergence sums from a pair-list pass of the chunked merge kernel over the lists
+	const bool want_div = (want & MSC_FEAT_DIV) != 0;
+	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
+	if (want_div) {
+		bool ok = false;
+		if ((r = batch_div_lists(ctx, pts, centres, centre_slots[0], &c_sp, &q_sp, &ok))) return r;
+		if (!ok) return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
+	}
 	// lengths of every centre slot in one strided copy (Trainer::filter's window is relative to the centre's length)
 	std::vector<uint64_t> clen(centres->capacity);
 	HIP_TRY(ctx, hipMemcpy2DAsync(clen.data(), 8, centres->scalars + offsetof(MscSlotScalars, length), centres->scalar_stride, 8, centres->capacity,
@@ -2391,7 +2422,8 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	const uint32_t PS = sp ? 1 : L.S;          // partial records per pair
 	const uint64_t max_chunk_centres = sp ? std::max<uint64_t>(1, std::min<uint64_t>(4096, (1024ull << 20) / (L.nbins * 4)))
 	                                      : std::max<uint64_t>(1, (4096ull << 20) / L.slot_bytes);
-	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial)));
+	const uint64_t max_chunk_pairs = std::min<uint64_t>(std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial))),
+	                                                    want_div ? (1024ull << 20) / 4096 : ~0ull);      // (a 4 KiB table of divergence terms per pair)
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, members, where;
 	std::vector<uint8_t> keep;
@@ -2426,17 +2458,25 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, pt_slots + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
-			if (sp)
+			if (sp && want_div) {
+				if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->partials.p))) return r;
+			} else if (sp)
 				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p,
 				                                             (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1, (const MscBatchSeg*)ctx->segs.p,
 				                                             (const uint32_t*)ctx->pair_seg.p, (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST, ctx->num_cus));
-			else
+			else {
 				HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
 				                                         (uint32_t)nc, max_m, centres->bins, centres->L.slot_bytes, centres->scalars, centres->scalar_stride, 1,
 				                                         (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST));
+				if (want_div) {          // the mirrors' lists, the dense sets' scalar records (a mirror has none of its own)
+					if ((r = ensure(ctx, ctx->sp_partials, P * sizeof(MscPartial)))) return r;
+					if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->sp_partials.p))) return r;
+				}
+			}
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
+			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = 1; ea.div_base = L.nbins; }
 			ea.S = PS;
 			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;
@@ -2541,7 +2581,16 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
 	// sparse centres: the pair-list form of the merge-path kernel (32-bit range) takes the place of k_pair_tiles_batch
 	const bool sp = centres->sparse;
-	if (no_batch || (sp && centres->max_count >= 65536) || (want & (MSC_FEAT_DIV | MSC_FEAT_GROUPS)) || needs_wide(centres, centres) || n > 0x7fffffffull) {
+	const bool want_div = (want & MSC_FEAT_DIV) != 0;
+	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
+	bool one_by_one = no_batch || (sp && centres->max_count >= 65536) || (want & MSC_FEAT_GROUPS) || needs_wide(centres, centres) || n > 0x7fffffffull;
+	if (!one_by_one && want_div) {
+		bool ok = false;
+		int r0 = hipSetDevice(ctx->device) == hipSuccess ? batch_div_lists(ctx, centres, centres, centre_slots[0], &c_sp, &q_sp, &ok) : MSC_ERR_HIP;
+		if (r0) return r0;
+		one_by_one = !ok;
+	}
+	if (one_by_one) {
 		for (uint64_t i = 0; i < n; i++) {
 			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[i]);
 			if (r) return r;
@@ -2557,7 +2606,8 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	const double id = trainer_get_id(cutoff);
 	const uint32_t PS = sp ? 1 : L.S;          // partial records per pair
-	const uint64_t max_chunk_pairs = std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial)));
+	const uint64_t max_chunk_pairs = std::min<uint64_t>(std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial))),
+	                                                    want_div ? (1024ull << 20) / 4096 : ~0ull);
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, cand;
 	std::vector<MscPairOut> po;
@@ -2591,18 +2641,26 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
-			if (sp)
+			if (sp && want_div) {
+				if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->partials.p))) return r;
+			} else if (sp)
 				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, centres->ent, centres->cum, centres->hdr, centres->scalars, centres->scalar_stride,
 				                                             (const uint32_t*)ctx->slots.p, (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1,
 				                                             (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p, (MscPartial*)ctx->partials.p,
 				                                             MSC_ORDER_CAND_FIRST, ctx->num_cus));
-			else
+			else {
 				HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, centres->dtype, centres->bins, centres->scalars, (const uint32_t*)ctx->slots.p,
 				                                         (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc, max_m, centres->bins, L.slot_bytes, centres->scalars,
 				                                         centres->scalar_stride, 1, (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST));
+				if (want_div) {
+					if ((r = ensure(ctx, ctx->sp_partials, P * sizeof(MscPartial)))) return r;
+					if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->sp_partials.p))) return r;
+				}
+			}
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
+			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = 1; ea.div_base = L.nbins; }
 			ea.S = PS;
 			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;

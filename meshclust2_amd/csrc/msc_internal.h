@@ -197,7 +197,8 @@ hipError_t msc_launch_sparse_mean_write(hipStream_t st, int dtype, uint32_t* acc
 hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
                                            uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                            const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
-                                           MscPartial* partials, int order, int num_cus);
+                                           MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars = nullptr, uint64_t q_scalar_stride = 0,
+                                           void* div_tables = nullptr, void* div_partials = nullptr);
 hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
                                            uint64_t nbins, uint32_t* acc);
 hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,

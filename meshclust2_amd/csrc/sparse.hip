@@ -261,14 +261,17 @@ __device__ __forceinline__ DivTerm div_term_sp(uint32_t cand_count, uint32_t q_c
 }
 
 // per-candidate 16 x 16 table of the exact per-bin divergence terms (same idea as k_div_tables of the dense path)
+// (segs != nullptr: the pair-list form -- the query of pair c is slot segs[pair_seg[c]].q_slot behind q_scalars, stride q_stride)
 __global__ void __launch_bounds__(256) k_sparse_div_tables(const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
                                                            const uint32_t* __restrict__ cand_slots, uint32_t m,
-                                                           const uint8_t* __restrict__ q_scalars, int order, DivTerm* __restrict__ tables) {
+                                                           const uint8_t* __restrict__ q_scalars, int order, DivTerm* __restrict__ tables,
+                                                           const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr,
+                                                           uint64_t q_stride = 0) {
 	const uint32_t c = blockIdx.x;
 	if (c >= m) return;
 	const uint32_t slot = cand_slots ? cand_slots[c] : c;
 	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride)->mag;
-	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars + (segs ? (uint64_t)segs[pair_seg[c]].q_slot * q_stride : 0))->mag;
 	const uint32_t j = threadIdx.x;
 	DivTerm t{0.0, 0.0};
 	if (j / 16 && j % 16) t = div_term_sp(j / 16, j % 16, cm, qm, order);
@@ -734,8 +737,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
-    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1) {
-	static_assert(!(DIV && PAIRS), "the pair-list form scores the integer statistics only");
+    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0) {
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 	const uint2* Q = q_ent + qh.off;
 	const uint32_t* CQ = q_cum + qh.off;
 	uint32_t nq_all = qh.nnz;
-	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
+	double qm = DIV && !PAIRS ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
 	const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t kInf = 0xffffffffu;
 	// `parts` waves share a candidate (a short window would leave most of the chip idle, and a get_close step is as slow as its
@@ -760,6 +762,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 			Q = q_ent + qh.off;
 			CQ = q_cum + qh.off;
 			nq_all = qh.nnz;
+			if constexpr (DIV) qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars + (uint64_t)sg.q_slot * q_scalar_stride)->mag;
 		} else {
 			if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
 		}
@@ -1192,16 +1195,27 @@ hipError_t msc_launch_sparse_self_markov(hipStream_t st, const void* ent, const 
 }
 
 // the pair-list form of the merge-path kernel: candidate c is scored against slot segs[pair_seg[c]].q_slot of the query set, inside
-// that segment's length window (use_window); integer statistics only, one record per candidate
+// that segment's length window (use_window); one record per candidate (and, with div_tables, its two divergence sums)
 hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
                                            uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                            const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
-                                           MscPartial* partials, int order, int num_cus) {
+                                           MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars, uint64_t q_scalar_stride, void* div_tables,
+                                           void* div_partials) {
 	if (m == 0) return hipSuccess;
 	constexpr uint32_t T = 512;
 	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));
 	uint32_t blocks = (uint32_t)num_cus * per_cu;
 	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+	if (div_tables) {      // the divergence sums of every pair as well: the same walk, hence the same bits, as the 1 x M divergence form
+		if (!q_scalars || !div_partials) return hipErrorInvalidValue;
+		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables, segs, pair_seg, q_scalar_stride);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		k_pair_sparse_mp<true, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
+		                                                                   q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials,
+		                                                                   order, segs, pair_seg, 1, q_scalar_stride);
+		return hipGetLastError();
+	}
 	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
 	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg);
 	return hipGetLastError();

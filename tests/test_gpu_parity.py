@@ -979,11 +979,14 @@ def test_full_size_cfg2_properties(oracle):
 
 @pytest.mark.parametrize("dtype,k,wts,sparse", [(16, 5, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", False), (16, 5, "weights_k5_u16_slow.txt", False),
                                                  (8, 3, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", True), (16, 8, "weights_k8_u16.txt", True),
-                                                 (8, 9, "weights_k9_u8.txt", True), (64, 10, "weights_k5_u16.txt", True)])
+                                                 (8, 9, "weights_k9_u8.txt", True), (64, 10, "weights_k5_u16.txt", True),
+                                                 # `--feat slow` models where the list form exists: the pair-list divergence pass (r02)
+                                                 (16, 9, "weights_cfg5_u16_k9.txt", False), (16, 9, "weights_cfg5_u16_k9.txt", True),
+                                                 (8, 9, "weights_cfg5_k9.txt", False), (8, 9, "weights_cfg5_k9.txt", True)])
 def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts, sparse):
     """msc_update_centres / msc_merge_all (one launch per stage for all centres of a round) == msc_filter + msc_mean_nearest /
-    msc_merge centre by centre: ragged and empty lists, lists nothing survives, the divergence-statistics fallback, padded tiny
-    histograms; on sparse sets too (r02: pair-list merge-path kernel + the scatter / sweep of the rounded means with a centre
+    msc_merge centre by centre: ragged and empty lists, lists nothing survives, the divergence statistics (a pair-list pass of the
+    chunked merge kernel over the lists / the mirrors' lists; centre by centre where no list form exists), padded tiny histograms; on sparse sets too (r02: pair-list merge-path kernel + the scatter / sweep of the rounded means with a centre
     dimension), where the per-centre calls are the single-query kernels."""
     rng = np.random.default_rng(11 * k + dtype)
     seqs, _ = synth.families(4100 + k, 120, 600 if k > 3 else 80, family=6)
