@@ -176,6 +176,9 @@ int msc_hist_download(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, void
 int msc_hist_upload(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, const void* bins, uint64_t length,
                     const uint64_t* one_mers /* 4 or NULL */);       /* DivergencePoint(pts, len) ctor: mag recomputed */
 int msc_hist_info_get(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, msc_hist_info* out);
+/* DivergencePoint::get_length() of n consecutive slots at once (the driver's sort by length, cluster/CRunner.cpp:529-560, reads every
+ * point's): served from the lengths the library remembers on the host, or one strided copy. */
+int msc_hist_lengths(msc_ctx* ctx, const msc_hist_set* set, uint64_t first_slot, uint64_t n, uint64_t* lengths_out);
 int msc_hist_set_id(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, uint64_t id);
 
 /* DivergencePoint::clone (clutil/DivergencePoint.h:35-43): full copy, mag re-summed. Used by Center (cluster/Center.h:13-40). */

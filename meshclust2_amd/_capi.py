@@ -62,6 +62,7 @@ PROTOTYPES = {
     "msc_hist_download": (_int, [_vp, _vp, _u64, _vp]),
     "msc_hist_upload": (_int, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "msc_hist_info_get": (_int, [_vp, _vp, _u64, C.POINTER(HistInfo)]),
+    "msc_hist_lengths": (_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp]),
     "msc_hist_set_id": (_int, [_vp, _vp, _u64, _u64]),
     "msc_hist_clone": (_int, [_vp, _vp, _u64, _vp, _u64]),
     "msc_hist_copy": (_int, [_vp, _vp, _u64, _vp, _u64]),

@@ -150,6 +150,13 @@ class HistogramSet:
         om = None if one_mers is None else (C.c_uint64 * 4)(*one_mers)
         self.ctx.check(self.ctx.lib.msc_hist_upload(self.ctx.h, self.h, slot, _ptr(bins), int(length), om))
 
+    def lengths(self, first=0, n=None):
+        """effective lengths of n consecutive slots (one call)"""
+        n = self.capacity - first if n is None else n
+        out = np.zeros(n, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.msc_hist_lengths(self.ctx.h, self.h, first, n, _ptr(out)))
+        return out
+
     def info(self, slot):
         hi = _capi.HistInfo()
         self.ctx.check(self.ctx.lib.msc_hist_info_get(self.ctx.h, self.h, slot, C.byref(hi)))

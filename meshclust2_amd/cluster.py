@@ -237,7 +237,7 @@ class GpuEngine:
         self.s_rows = 0
 
     def lengths(self):
-        return np.array([self.points.info(i)["length"] for i in range(self.n_local)], dtype=np.int64)
+        return self.points.lengths(0, self.n_local).astype(np.int64)
 
     def point_payload(self, local):
         return [self.p_bins[local], self.p_scal[local]]

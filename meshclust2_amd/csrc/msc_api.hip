@@ -1038,6 +1038,22 @@ static int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uin
 	return MSC_OK;
 }
 
+extern "C" int msc_hist_lengths(msc_ctx* ctx, const msc_hist_set* set, uint64_t first_slot, uint64_t n, uint64_t* lengths_out) {
+	if (!ctx || !set || set->ctx != ctx || first_slot + n > set->capacity || (n && !lengths_out)) return MSC_ERR_INVALID_ARG;
+	bool all_known = true;
+	for (uint64_t i = first_slot; i < first_slot + n && all_known; i++) all_known = i < set->len_known.size() && set->len_known[i];
+	if (!all_known && n) {          // one strided copy of the length words, remembered for the operators' window arithmetic
+		HIP_TRY(ctx, hipSetDevice(ctx->device));
+		HIP_TRY(ctx, hipMemcpy2DAsync(lengths_out, 8, set->scalars + first_slot * set->scalar_stride + offsetof(MscSlotScalars, length), set->scalar_stride, 8, n,
+		                              hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		for (uint64_t i = 0; i < n; i++) learn_length(set, first_slot + i, lengths_out[i]);
+		return MSC_OK;
+	}
+	for (uint64_t i = 0; i < n; i++) lengths_out[i] = set->len_host[first_slot + i];
+	return MSC_OK;
+}
+
 extern "C" int msc_hist_set_id(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, uint64_t id) {
 	int r = check_slot(ctx, set, slot);
 	if (r) return r;

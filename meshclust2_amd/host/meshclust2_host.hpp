@@ -72,6 +72,11 @@ public:
 		return i;
 	}
 	uint64_t get_length(uint64_t slot) const { return info(slot).length; }
+	std::vector<uint64_t> get_lengths(uint64_t first, uint64_t n) const {
+		std::vector<uint64_t> out(n);
+		ctx_.check(msc_hist_lengths(ctx_.get(), h_, first, n, out.data()));
+		return out;
+	}
 	template <class T> std::vector<T> get_data(uint64_t slot) const {     // DivergencePoint::points, natural order
 		std::vector<T> v((size_t)1 << (2 * msc_hist_set_k(h_)));
 		ctx_.check(msc_hist_download(ctx_.get(), h_, slot, v.data()));

@@ -381,9 +381,10 @@ int main(int argc, char** argv) {
 			points.get_points(off, part);
 		}
 		std::vector<msc::SeqRecord> records(n);
+		const std::vector<uint64_t> lens = points.get_lengths(0, n);      // (one call: a read-back per point costs 8 us each)
 		for (size_t i = 0; i < n; i++) {
 			records[i].header = headers[i];
-			records[i].length = points.get_length(i);      // slot i == point handle i
+			records[i].length = lens[i];                    // slot i == point handle i
 		}
 		seqs.clear();
 		// (sparse centre store: room for every sequence as its own centre TWICE -- a round of the update stage appends the new list of

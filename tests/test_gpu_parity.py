@@ -305,6 +305,7 @@ def test_copy_batch_is_an_exact_copy(ctx, layout):
     ent = (sum(len(s_) for s_ in seqs) * 3 + 4096) if layout == "sparse" else 0
     pts = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
     pts.build(list(seqs))
+    assert np.array_equal(pts.lengths(), [pts.info(i)["length"] for i in range(n)]) and np.array_equal(pts.lengths(3, 4), pts.lengths()[3:7])      # msc_hist_lengths
     centres = api.HistogramSet(ctx, k, dtype, n, sparse_entries=ent)
     for i in range(n):
         centres.clone_from(i, pts, i)
