@@ -9,7 +9,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "meshclust2_amd", "host", "msc_cluster")
 CASES = [("weights_k5_u16.txt", 5, 16, 0.9), ("weights_k8_u16.txt", 8, 16, 0.9), ("weights_k9_u32.txt", 9, 32, 0.9), ("weights_k9_u8.txt", 9, 8, 0.9),
-         ("weights_mixed_slow_k6_u16.txt", 6, 16, 0.6), ("weights_k5_u16_slow.txt", 5, 16, 0.8)]
+         ("weights_mixed_slow_k6_u16.txt", 6, 16, 0.6), ("weights_k5_u16_slow.txt", 5, 16, 0.8),
+         # `--feat slow` models where the list form exists: the batched update stage takes its divergence sums from a pair-list pass
+         ("weights_cfg5_u16_k9.txt", 9, 16, 0.6), ("weights_cfg5_k9.txt", 9, 8, 0.6), ("weights_cfg5_u16_k9.txt", 9, 16, 0.8)]
 
 
 def run_round(seed, tmp):
@@ -45,7 +47,7 @@ def run_round(seed, tmp):
                 f.write(s[a:a + 70] + b"\n")
     outs = []
     sparse_ok = 4 ** k * dtype // 8 >= 65536
-    modes = [[], ["--serial-update"]] + ([["--sparse"]] if sparse_ok else [])
+    modes = [[], ["--serial-update"]] + ([["--sparse"], ["--sparse", "--serial-update"]] if sparse_ok else [])
     for extra in modes:
         out = os.path.join(tmp, "o_%d_%d.clstr" % (seed, len(outs)))
         r = subprocess.run([EXE, fa, "--recover", os.path.join(ROOT, "tests", "golden", wts), "--id", str(ident), "--kmer", str(k), "--datatype", str(dtype),
