@@ -2165,6 +2165,7 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	h.off = 0;
 	rs->ent_used = n;
 	rs->hdr_host[0] = h;
+	rs->max_nnz = std::max(rs->max_nnz, h.nnz);          // (every writer of hdr_host keeps max_nnz >= each list: the whole-list kernel sizes its LDS by it)
 	MscSlotScalars sc;
 	memset(&sc, 0, sizeof sc);
 	sc.sum = L.nbins + ex;          // sum of the rounded mean's bins
