@@ -45,7 +45,7 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch, reduce_parts;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
 	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
@@ -216,6 +216,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->grp_pairs);
 	release(ctx->grp_self);
 	release(ctx->tile_scratch);
+	release(ctx->reduce_parts);
 	release(ctx->sp_acc_batch);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
@@ -1613,8 +1614,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			if ((r = ensure_pinned(ctx, ctx->pin_down, kRo + mc)) != MSC_OK) return r;
 			uint8_t* down = nullptr;
 			HIP_TRY(ctx, hipHostGetDevicePointer((void**)&down, ctx->pin_down.p, 0));
+			if ((r = ensure(ctx, ctx->reduce_parts, msc_reduce_scratch_bytes())) != MSC_OK) return r;
 			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
-			                               rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down));
+			                               rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down, ctx->reduce_parts.p));
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

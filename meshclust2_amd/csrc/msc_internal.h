@@ -167,7 +167,8 @@ hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, cons
                                         int tiles_per_step, bool need_emd, void* partials16, int num_cus);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
-                             uint8_t* flags_out, MscReduceOut* out);
+                             uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);
+size_t msc_reduce_scratch_bytes();
 
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts);
 hipError_t msc_launch_sparse_write(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, const MscSparseHdr* hdr,

@@ -1132,6 +1132,78 @@ __global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restri
 	}
 }
 
+// The same in two stages for long windows (one workgroup walking 100 000 records and writing their flags took 50 us behind a 320 us
+// kernel): workgroup b folds records [b * per, (b + 1) * per) into parts[b]; k_pair_reduce_fold folds the parts. `better` breaks
+// ties by position, so the order of folding does not matter.
+struct ReducePart { double sim; int64_t pos; unsigned long long nclose; int err; int pad_; };
+__global__ void __launch_bounds__(1024) k_pair_reduce_part(const MscPairOut* __restrict__ po, uint32_t m, uint32_t per, int mode, int64_t begin,
+                                                           uint8_t* __restrict__ flags_out, ReducePart* __restrict__ parts) {
+	__shared__ Best s_best[1024];
+	__shared__ unsigned long long s_nclose;
+	__shared__ int s_err;
+	if (threadIdx.x == 0) { s_nclose = 0; s_err = 0; }
+	__syncthreads();
+	Best b{mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0, -1};
+	unsigned long long nclose = 0;
+	int err = 0;
+	const uint32_t lo = blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+	for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+		const MscPairOut p = po[i];
+		const bool scored = p.status == 0;
+		if (p.status < 0 && p.status < err) err = p.status;
+		if (flags_out) flags_out[i] = (scored && p.close) ? 1 : 0;
+		if (!scored) continue;
+		nclose += p.close ? 1 : 0;
+		if (mode == MSC_REDUCE_GET_CLOSE) {
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)i}, mode);
+		} else {
+			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)i}, mode);
+		}
+	}
+	s_best[threadIdx.x] = b;
+	if (nclose) atomicAdd(&s_nclose, nclose);
+	if (err) atomicMin(&s_err, err);
+	__syncthreads();
+	for (int stride = 512; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) s_best[threadIdx.x] = better(s_best[threadIdx.x], s_best[threadIdx.x + stride], mode);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		ReducePart r;
+		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err; r.pad_ = 0;
+		parts[blockIdx.x] = r;
+	}
+}
+__global__ void __launch_bounds__(256) k_pair_reduce_fold(const ReducePart* __restrict__ parts, uint32_t n_parts, int mode, MscReduceOut* __restrict__ out) {
+	__shared__ Best s_best[256];
+	__shared__ unsigned long long s_nclose;
+	__shared__ int s_err;
+	if (threadIdx.x == 0) { s_nclose = 0; s_err = 0; }
+	__syncthreads();
+	Best b{mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0, -1};
+	if (threadIdx.x < n_parts) {
+		const ReducePart p = parts[threadIdx.x];
+		b = Best{p.sim, p.pos};
+		if (p.nclose) atomicAdd(&s_nclose, p.nclose);
+		if (p.err) atomicMin(&s_err, p.err);
+	}
+	s_best[threadIdx.x] = b;
+	__syncthreads();
+	for (int stride = 128; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) s_best[threadIdx.x] = better(s_best[threadIdx.x], s_best[threadIdx.x + stride], mode);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		MscReduceOut r;
+		r.best_sim = s_best[0].pos >= 0 ? s_best[0].sim : (mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 2.2250738585072014e-308);
+		r.best_pos = s_best[0].pos >= 0 ? s_best[0].pos : (mode == MSC_REDUCE_GET_CLOSE ? -1 : 0);
+		r.any_close = s_nclose > 0;
+		r.n_close = s_nclose;
+		r.first_error = s_err;
+		*out = r;
+	}
+}
+
 // distance_d for the m members against the rounded mean (clutil/DivergencePoint.cpp:55-66):
 //   dist = sum 2*min(p, (T)round(c))  =  sum p + sum r - manh(p, r)
 //   mag  = sum_i floor-accumulated (p_i + c_i) = sum p + sum floor(c_i)      (uint64 += double truncates every step)
@@ -1589,8 +1661,19 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	return hipGetLastError();
 }
 
+// parts_scratch (optional, msc_reduce_scratch_bytes()): long windows are folded by up to 256 workgroups first
+size_t msc_reduce_scratch_bytes() { return 256 * sizeof(ReducePart); }
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin, uint8_t* flags_out,
-                             MscReduceOut* out) {
+                             MscReduceOut* out, void* parts_scratch) {
+	if (parts_scratch && m > 8192) {
+		const uint32_t n_parts = std::min<uint32_t>(256, (m + 4095) / 4096);
+		const uint32_t per = (m + n_parts - 1) / n_parts;
+		k_pair_reduce_part<<<dim3(n_parts), dim3(1024), 0, st>>>(pair_out, m, per, mode, begin, flags_out, (ReducePart*)parts_scratch);
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		k_pair_reduce_fold<<<dim3(1), dim3(256), 0, st>>>((const ReducePart*)parts_scratch, n_parts, mode, out);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_pair_reduce, dim3(1), dim3(1024), 0, st, pair_out, m, mode, begin, flags_out, out);
 	return hipGetLastError();
 }
