@@ -340,6 +340,26 @@ def test_copy_batch_is_an_exact_copy(ctx, layout):
             tiny.copy_batch(np.arange(n, dtype=np.uint32), centres, np.arange(n, dtype=np.uint32))
 
 
+def test_batch_slot_entry_points_reject_bad_arguments(ctx):
+    """msc_hist_copy_batch / _clone_batch / _lengths: out-of-range slots, mismatched sets and empty batches"""
+    a = api.HistogramSet(ctx, 5, 16, 4)
+    b = api.HistogramSet(ctx, 5, 16, 4)
+    c = api.HistogramSet(ctx, 6, 16, 4)
+    a.build([b"ACGTTGCAAC" * 20, b"TTGACCA" * 30, b"GGGATCCA" * 25, b"ACGT" * 40])
+    b.copy_batch(np.zeros(0, dtype=np.uint32), a, np.zeros(0, dtype=np.uint32))          # nothing to do
+    with pytest.raises(api.MscError, match="slot out of range"):
+        b.copy_batch([0, 4], a, [0, 1])
+    with pytest.raises(api.MscError, match="slot out of range"):
+        b.clone_batch([0, 1], a, [0, 9])
+    with pytest.raises(api.MscError, match="differ"):
+        c.copy_batch([0], a, [0])
+    b.clone_batch([3, 1], a, [0, 2])
+    assert np.array_equal(b.download(3), a.download(0)) and np.array_equal(b.download(1), a.download(2))
+    assert list(a.lengths()) == [200, 210, 200, 160] and list(b.lengths(1, 1)) == [200]
+    with pytest.raises(api.MscError):
+        a.lengths(2, 3)                                                                    # runs past the capacity
+
+
 def test_upload_round_trip_and_properties(ctx):
     """Size-independent properties: symmetric statistics, self-pair identities, checksum of checksums."""
     rng = np.random.default_rng(3)
