@@ -2439,7 +2439,16 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	// chunks of centres: their rounded means share one scratch set (<= 4 GiB; sparse: <= 1 GiB of 32-bit column accumulators) and
 	// their pair counts stay 32-bit
 	const uint32_t PS = sp ? 1 : L.S;          // partial records per pair
-	const uint64_t max_chunk_centres = sp ? std::max<uint64_t>(1, std::min<uint64_t>(4096, (1024ull << 20) / (L.nbins * 4)))
+	// sparse: one 32-bit column accumulator of 4^k bins per centre of a chunk. Every chunk costs a handful of launches and two host
+	// round trips, so at k = 13 (256 MiB per accumulator) a 1 GiB budget -- 4 centres per chunk -- made the update stage launch-bound
+	// (2 000 x 20 kb: 1.6 s); the budget is a quarter of the free device memory, between 1 and 16 GiB
+	uint64_t acc_budget = 1024ull << 20;
+	if (sp) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) acc_budget = std::min<uint64_t>(16384ull << 20, std::max<uint64_t>(acc_budget, (free_b + ctx->sp_acc_batch.cap) / 4));
+		else (void)hipGetLastError();
+	}
+	const uint64_t max_chunk_centres = sp ? std::max<uint64_t>(1, std::min<uint64_t>(4096, acc_budget / (L.nbins * 4)))
 	                                      : std::max<uint64_t>(1, (4096ull << 20) / L.slot_bytes);
 	const uint64_t max_chunk_pairs = std::min<uint64_t>(std::max<uint64_t>(1, (2048ull << 20) / ((uint64_t)PS * sizeof(MscPartial))),
 	                                                    want_div ? (1024ull << 20) / 4096 : ~0ull);      // (a 4 KiB table of divergence terms per pair)

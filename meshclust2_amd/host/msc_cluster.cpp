@@ -225,11 +225,17 @@ std::string mutate(const std::string& tmpl, double rate, SplitMix& rng) {
 }
 
 // cluster/CRunner.cpp:56-126: the narrowest type that holds the largest count (pseudocount included)
-int choose_datatype(msc::Context& ctx, int k, const std::vector<std::string>& seqs) {
+int choose_datatype(msc::Context& ctx, int k, const std::vector<std::string>& seqs, bool sparse) {
 	auto largest = [&](int bits) {
-		msc::PointSet probe(ctx, k, bits, 4096);
+		uint64_t most = 0;          // (sparse layout: the probe's entry arena must hold the longest batch)
+		for (size_t off = 0; off < seqs.size(); off += 4096) {
+			uint64_t b = 0;
+			for (size_t i = off; i < std::min(seqs.size(), off + 4096); i++) b += seqs[i].size();
+			most = std::max(most, b);
+		}
 		uint64_t mx = 0;
 		for (size_t off = 0; off < seqs.size(); off += 4096) {
+			msc::PointSet probe(ctx, k, bits, 4096, sparse ? most + 1024 : 0);      // (a sparse arena is append-only: a fresh probe per batch)
 			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(seqs.size(), off + 4096));
 			probe.get_points(0, part);
 			for (size_t i = 0; i < part.size(); i++) mx = std::max<uint64_t>(mx, probe.info(i).max_count);
@@ -243,7 +249,7 @@ int choose_datatype(msc::Context& ctx, int k, const std::vector<std::string>& se
 }
 
 std::string train_model(msc::Context& ctx, int k, int dtype, double id, uint64_t feat_flags, int n_templates, int min_feat, int max_feat,
-                        const std::vector<std::string>& seqs) {
+                        const std::vector<std::string>& seqs, bool sparse) {
 	SplitMix rng{0xAAull};
 	std::vector<std::string> pts;
 	std::vector<uint32_t> first, second;
@@ -266,7 +272,9 @@ std::string train_model(msc::Context& ctx, int k, int dtype, double id, uint64_t
 		const size_t j = (size_t)(rng.next() % (i + 1));
 		std::swap(first[i], first[j]); std::swap(second[i], second[j]); std::swap(val[i], val[j]);
 	}
-	msc::PointSet set(ctx, k, dtype, pts.size());
+	uint64_t train_bases = 0;
+	for (const std::string& p_ : pts) train_bases += p_.size();
+	msc::PointSet set(ctx, k, dtype, pts.size(), sparse ? train_bases + 1024 : 0);      // (at k >= 13 a dense training set would not fit)
 	for (size_t off = 0; off < pts.size(); off += 4096) {
 		std::vector<std::string> part(pts.begin() + (long)off, pts.begin() + (long)std::min(pts.size(), off + 4096));
 		set.get_points(off, part);
@@ -358,9 +366,9 @@ int main(int argc, char** argv) {
 				k = (int)std::ceil(std::log((double)length) / std::log(4.0)) - 1;
 				std::cout << "avg length: " << length << std::endl << "Recommended K: " << k << std::endl;
 			}
-			if (dtype == 0) { dtype = choose_datatype(ctx, k, seqs); std::cout << "Using " << dtype << " bit histograms" << std::endl; }
+			if (dtype == 0) { dtype = choose_datatype(ctx, k, seqs, sparse); std::cout << "Using " << dtype << " bit histograms" << std::endl; }
 			const double id = similarity > 1 ? similarity / 100.0 : similarity;
-			const std::string text = train_model(ctx, k, dtype, id, feat_flags, n_templates, min_feat, max_feat, seqs);
+			const std::string text = train_model(ctx, k, dtype, id, feat_flags, n_templates, min_feat, max_feat, seqs, sparse);
 			std::ofstream(dump.c_str()) << text;       // the reference always leaves weights.txt behind (cluster/Trainer.cpp:188-190)
 			weights = dump;
 			std::cout << "timestamp GLM " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
