@@ -45,7 +45,7 @@ struct msc_ctx {
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
 	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch, reduce_parts;
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch, reduce_parts, sp_touched;
 	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
 	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
@@ -217,6 +217,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->grp_self);
 	release(ctx->tile_scratch);
 	release(ctx->reduce_parts);
+	release(ctx->sp_touched);
 	release(ctx->sp_acc_batch);
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
@@ -2299,6 +2300,17 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 		if ((r = ensure(ctx, ctx->sp_acc_batch, acc_bytes))) return r;
 		HIP_TRY(ctx, hipMemsetAsync(ctx->sp_acc_batch.p, 0, ctx->sp_acc_batch.cap, ctx->stream));
 	}
+	// large k: the sweeps visit touched 64-byte lines only (a bit per 16 bins and centre, set by the scatter, cleared by the write sweep)
+	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
+	const bool grouped = !no_groups && L.nbins >= (1ull << 22) && chunk_bins % 512 == 0;
+	if (grouped) {
+		const size_t tb = (size_t)nc * (L.nbins >> 9) * sizeof(uint32_t);
+		if (tb > ctx->sp_touched.cap) {
+			if ((r = ensure(ctx, ctx->sp_touched, tb))) return r;
+			HIP_TRY(ctx, hipMemsetAsync(ctx->sp_touched.p, 0, ctx->sp_touched.cap, ctx->stream));
+		}
+	}
+	uint32_t* touched = grouped ? (uint32_t*)ctx->sp_touched.p : nullptr;
 	std::vector<uint32_t> m_of(nc);
 	for (uint32_t c = 0; c < nc; c++) m_of[c] = segs[c].m;
 	if ((r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) ||
@@ -2311,9 +2323,9 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, m_of.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, pts->ent, pts->hdr, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)P2, L.nbins,
-	                                             (uint32_t*)ctx->sp_acc_batch.p));
+	                                             (uint32_t*)ctx->sp_acc_batch.p, touched));
 	HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, pts->dtype, (const uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc,
-	                                                (const uint32_t*)ctx->qslots.p, (uint64_t*)ctx->sp_counts.p));
+	                                                (const uint32_t*)ctx->qslots.p, (uint64_t*)ctx->sp_counts.p, touched));
 	std::vector<uint64_t> counts((size_t)nc * n_chunks * 3);
 	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2361,7 +2373,7 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), cb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, pts->dtype, (uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc, (const uint32_t*)ctx->qslots.p,
-	                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, ms->ent, ms->cum));
+	                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, ms->ent, ms->cum, touched));
 	// survivors against the rounded mean of their own centre: only the |p - r| reduction of the merge kernel is used
 	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P2,
 	                                             ms->ent, ms->cum, ms->hdr, L.nbins, 0, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p,

@@ -201,11 +201,11 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
                                            MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars = nullptr, uint64_t q_scalar_stride = 0,
                                            void* div_tables = nullptr, void* div_partials = nullptr);
 hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
-                                           uint64_t nbins, uint32_t* acc);
+                                           uint64_t nbins, uint32_t* acc, uint32_t* touched = nullptr);
 hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
-                                              const uint32_t* m_of, uint64_t* counts);
+                                              const uint32_t* m_of, uint64_t* counts, const uint32_t* touched = nullptr);
 hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
-                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum);
+                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum, uint32_t* touched = nullptr);
 hipError_t msc_launch_sparse_assign_batch(hipStream_t st, void* d_ent, uint32_t* d_cum, MscSparseHdr* d_hdr, const void* s_ent, const uint32_t* s_cum, const MscSparseHdr* s_hdr,
                                           const uint32_t* ds, const uint32_t* ss, const uint64_t* dst_off, uint32_t n);
 hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const uint8_t* src_scalars, uint64_t stride_bytes, const uint32_t* dst_slots,

@@ -534,16 +534,22 @@ __global__ void __launch_bounds__(64) k_sparse_mean_write(uint32_t* __restrict__
 
 // ---- the same three steps for MANY centres at once (the update stage of a mean-shift round on sparse sets): member j belongs to
 // centre seg[j] of the chunk; accumulator, counts and offsets carry a centre dimension (acc[centre][bin]); m differs per centre.
+// touched (optional): one bit per group of 16 bins and centre, word w of a centre = groups 32 w .. 32 w + 31 (the grouped sweeps below)
 __global__ void __launch_bounds__(256) k_sparse_scatter_batch(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
                                                               const uint32_t* __restrict__ slots, const uint32_t* __restrict__ seg, uint32_t n_members,
-                                                              uint64_t nbins, uint32_t* __restrict__ acc) {
+                                                              uint64_t nbins, uint32_t* __restrict__ acc, uint32_t* __restrict__ touched) {
 	const uint32_t j = blockIdx.x;
 	if (j >= n_members) return;
 	const MscSparseHdr h = hdr[slots[j]];
 	uint32_t* a = acc + (uint64_t)seg[j] * nbins;
+	uint32_t* tw = touched ? touched + (uint64_t)seg[j] * (nbins >> 9) : nullptr;
 	for (uint32_t t = threadIdx.x; t < h.nnz; t += blockDim.x) {
 		const uint2 e = ent[h.off + t];
 		atomicAdd(&a[e.x], e.y - 1u);
+		if (tw) {
+			const uint32_t bit = 1u << ((e.x >> 4) & 31u);
+			if (!(__builtin_nontemporal_load(&tw[e.x >> 9]) & bit)) atomicOr(&tw[e.x >> 9], bit);      // (most groups are hit by several members)
+		}
 	}
 }
 
@@ -599,6 +605,120 @@ __global__ void __launch_bounds__(64) k_sparse_mean_write_batch(uint32_t* __rest
 		}
 		o += (uint64_t)__popcll(mask);
 		run += (uint32_t)__builtin_amdgcn_readlane((int)ex_incl, 63);
+	}
+}
+
+// ---- the two sweeps over TOUCHED groups only (large k). At k = 13 a centre's accumulator is 256 MiB and the ~1 M entries of its
+// neighbourhood touch a few per cent of it; sweeping all of it twice per centre and round made the update stage of 20 kb sequences
+// bandwidth-bound on zeros. The scatter marks every group of 16 bins (one 64-byte line) it touches; a wave expands 64 words of that
+// bitmap into the ascending list of touched groups (LDS) and every lane then owns ONE group: its 16 bins are one line, the order of
+// lanes is the order of bins. A chunk of bins is whole bitmap words (chunk_bins % 512 == 0: host-checked).
+constexpr uint32_t kGroupList = 64 * 32;
+__device__ __forceinline__ uint32_t expand_touched(const uint32_t* __restrict__ words, uint32_t w0, uint32_t nw, uint32_t lane, uint32_t* s_list) {
+	uint32_t word = lane < nw ? words[w0 + lane] : 0u;
+	const uint32_t cnt = (uint32_t)__popc(word);
+	const uint32_t incl = wave_incl_scan(cnt);
+	uint32_t off = incl - cnt;
+	while (word) {
+		const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
+		word &= word - 1u;
+		s_list[off++] = (w0 + lane) * 32u + b;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_count_groups(const uint32_t* __restrict__ acc, const uint32_t* __restrict__ touched, uint64_t nbins,
+                                                                 uint64_t chunk_bins, const uint32_t* __restrict__ m_of, uint64_t* __restrict__ counts) {
+	__shared__ uint32_t s_list[kGroupList];
+	const uint32_t ci = blockIdx.y, n_chunks = gridDim.x, lane = threadIdx.x;
+	const uint32_t m = m_of[ci];
+	const uint32_t* a = acc + (uint64_t)ci * nbins;
+	const uint32_t* words = touched + (uint64_t)ci * (nbins >> 9);
+	const uint32_t w_lo = (uint32_t)(((uint64_t)blockIdx.x * chunk_bins) >> 9), w_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1) * chunk_bins) >> 9);
+	uint64_t n = 0, ex = 0, fl = 0;
+	if (m) {
+		for (uint32_t w0 = w_lo; w0 < w_hi; w0 += 64) {
+			const uint32_t T_ = expand_touched(words, w0, w_hi - w0 < 64 ? w_hi - w0 : 64, lane, s_list);
+			for (uint32_t g0 = 0; g0 < T_; g0 += 64) {
+				if (g0 + lane < T_) {
+					const uint4* p = reinterpret_cast<const uint4*>(a + (uint64_t)s_list[g0 + lane] * 16);
+					uint32_t E[16];
+#pragma unroll
+					for (int q = 0; q < 4; q++) { const uint4 v = p[q]; E[4 * q] = v.x; E[4 * q + 1] = v.y; E[4 * q + 2] = v.z; E[4 * q + 3] = v.w; }
+#pragma unroll
+					for (int q = 0; q < 16; q++)
+						if (E[q]) {
+							const MeanBin b = mean_bin<T>(E[q], m);
+							if (b.r >= 2) { n++; ex += b.r - 1; }
+							fl += b.fl - 1;
+						}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();          // the list is rewritten by the next window
+		}
+	}
+	n = wave_sum_u64(n); ex = wave_sum_u64(ex); fl = wave_sum_u64(fl);
+	if (lane == 0) {
+		uint64_t* o = counts + ((uint64_t)ci * n_chunks + blockIdx.x) * 3;
+		o[0] = n; o[1] = ex; o[2] = fl;
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_sparse_mean_write_groups(uint32_t* __restrict__ acc, uint32_t* __restrict__ touched, uint64_t nbins, uint64_t chunk_bins,
+                                                                 const uint32_t* __restrict__ m_of, const uint64_t* __restrict__ chunk_off,
+                                                                 const uint64_t* __restrict__ chunk_cum, uint2* __restrict__ ent, uint32_t* __restrict__ cum) {
+	__shared__ uint32_t s_list[kGroupList];
+	const uint32_t ci = blockIdx.y, n_chunks = gridDim.x, lane = threadIdx.x;
+	const uint32_t m = m_of[ci];
+	if (m == 0) return;
+	uint32_t* a = acc + (uint64_t)ci * nbins;
+	uint32_t* words = touched + (uint64_t)ci * (nbins >> 9);
+	const uint32_t w_lo = (uint32_t)(((uint64_t)blockIdx.x * chunk_bins) >> 9), w_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1) * chunk_bins) >> 9);
+	uint64_t o = chunk_off[(uint64_t)ci * n_chunks + blockIdx.x];
+	uint32_t run = (uint32_t)chunk_cum[(uint64_t)ci * n_chunks + blockIdx.x];
+	for (uint32_t w0 = w_lo; w0 < w_hi; w0 += 64) {
+		const uint32_t nw = w_hi - w0 < 64 ? w_hi - w0 : 64;
+		const uint32_t T_ = expand_touched(words, w0, nw, lane, s_list);
+		for (uint32_t g0 = 0; g0 < T_; g0 += 64) {
+			uint32_t r[16], n_emit = 0, ex_sum = 0, grp = 0;
+			const bool have = g0 + lane < T_;
+			if (have) {
+				grp = s_list[g0 + lane];
+				uint4* p = reinterpret_cast<uint4*>(a + (uint64_t)grp * 16);
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const uint4 v = p[q];
+					r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+					p[q] = make_uint4(0u, 0u, 0u, 0u);          // leave the accumulator clean for the next chunk of centres
+				}
+#pragma unroll
+				for (int q = 0; q < 16; q++) {
+					r[q] = r[q] ? mean_bin<T>(r[q], m).r : 1u;
+					if (r[q] >= 2) { n_emit++; ex_sum += r[q] - 1u; }
+				}
+			}
+			const uint32_t e_incl = wave_incl_scan(n_emit), x_incl = wave_incl_scan(ex_sum);
+			if (n_emit) {
+				uint64_t at = o + (e_incl - n_emit);
+				uint32_t c_run = run + (x_incl - ex_sum);
+#pragma unroll
+				for (int q = 0; q < 16; q++)
+					if (r[q] >= 2) {
+						c_run += r[q] - 1u;
+						ent[at] = make_uint2(grp * 16u + (uint32_t)q, r[q]);
+						cum[at] = c_run;
+						at++;
+					}
+			}
+			o += (uint64_t)__builtin_amdgcn_readlane((int)e_incl, 63);
+			run += (uint32_t)__builtin_amdgcn_readlane((int)x_incl, 63);
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (lane < nw && words[w0 + lane]) words[w0 + lane] = 0u;          // ... and the bitmap
 	}
 }
 
@@ -1222,16 +1342,26 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 }
 
 hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
-                                           uint64_t nbins, uint32_t* acc) {
+                                           uint64_t nbins, uint32_t* acc, uint32_t* touched) {
 	if (n_members == 0) return hipSuccess;
-	k_sparse_scatter_batch<<<dim3(n_members), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, seg, n_members, nbins, acc);
+	k_sparse_scatter_batch<<<dim3(n_members), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, seg, n_members, nbins, acc, touched);
 	return hipGetLastError();
 }
 
 hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
-                                              const uint32_t* m_of, uint64_t* counts) {
+                                              const uint32_t* m_of, uint64_t* counts, const uint32_t* touched) {
 	if (n_centres == 0) return hipSuccess;
 	const dim3 grid(n_chunks, n_centres);
+	if (touched) {
+		if (chunk_bins % 512) return hipErrorInvalidValue;
+		switch (dtype) {
+		case 8: k_sparse_mean_count_groups<uint8_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, counts); break;
+		case 16: k_sparse_mean_count_groups<uint16_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, counts); break;
+		case 32: k_sparse_mean_count_groups<uint32_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, counts); break;
+		default: k_sparse_mean_count_groups<uint64_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, counts); break;
+		}
+		return hipGetLastError();
+	}
 	switch (dtype) {
 	case 8: k_sparse_mean_count_batch<uint8_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
 	case 16: k_sparse_mean_count_batch<uint16_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, counts); break;
@@ -1242,9 +1372,19 @@ hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const u
 }
 
 hipError_t msc_launch_sparse_mean_write_batch(hipStream_t st, int dtype, uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,
-                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum) {
+                                              const uint32_t* m_of, const uint64_t* chunk_off, const uint64_t* chunk_cum, void* ent, uint32_t* cum, uint32_t* touched) {
 	if (n_centres == 0) return hipSuccess;
 	const dim3 grid(n_chunks, n_centres);
+	if (touched) {
+		if (chunk_bins % 512) return hipErrorInvalidValue;
+		switch (dtype) {
+		case 8: k_sparse_mean_write_groups<uint8_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+		case 16: k_sparse_mean_write_groups<uint16_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+		case 32: k_sparse_mean_write_groups<uint32_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+		default: k_sparse_mean_write_groups<uint64_t><<<grid, dim3(64), 0, st>>>(acc, touched, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
+		}
+		return hipGetLastError();
+	}
 	switch (dtype) {
 	case 8: k_sparse_mean_write_batch<uint8_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;
 	case 16: k_sparse_mean_write_batch<uint16_t><<<grid, dim3(64), 0, st>>>(acc, nbins, chunk_bins, m_of, chunk_off, chunk_cum, (uint2*)ent, cum); break;

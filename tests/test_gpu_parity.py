@@ -1003,7 +1003,9 @@ def test_full_size_cfg2_properties(oracle):
                                                  (8, 9, "weights_k9_u8.txt", True), (64, 10, "weights_k5_u16.txt", True),
                                                  # `--feat slow` models where the list form exists: the pair-list divergence pass (r02)
                                                  (16, 9, "weights_cfg5_u16_k9.txt", False), (16, 9, "weights_cfg5_u16_k9.txt", True),
-                                                 (8, 9, "weights_cfg5_k9.txt", False), (8, 9, "weights_cfg5_k9.txt", True)])
+                                                 (8, 9, "weights_cfg5_k9.txt", False), (8, 9, "weights_cfg5_k9.txt", True),
+                                                 # k >= 11: the sweeps of the batched sparse mean visit touched 64-byte lines only (r02)
+                                                 (8, 11, "weights_k9_u8.txt", True), (64, 13, "weights_k5_u16.txt", True)])
 def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts, sparse):
     """msc_update_centres / msc_merge_all (one launch per stage for all centres of a round) == msc_filter + msc_mean_nearest /
     msc_merge centre by centre: ragged and empty lists, lists nothing survives, the divergence statistics (a pair-list pass of the
