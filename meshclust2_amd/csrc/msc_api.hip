@@ -2149,8 +2149,27 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	if ((r = ensure(ctx, ctx->sp_counts, std::max<size_t>(n_chunks * 3 * sizeof(uint64_t), ctx->sp_counts.cap)))) return r;
 	if ((r = ensure(ctx, ctx->sp_chunk_off, n_chunks * sizeof(uint64_t)))) return r;
 	if ((r = ensure(ctx, ctx->sp_chunk_cum, n_chunks * sizeof(uint64_t)))) return r;
+	// k >= 11: the kernels of the batched form with one centre, whose sweeps visit touched 64-byte lines only
+	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
+	const bool grouped = !no_groups && L.nbins >= (1ull << 22) && chunk_bins % 512 == 0 && member_slots;
+	if (grouped) {
+		const size_t tb = (size_t)(L.nbins >> 9) * sizeof(uint32_t);
+		if (tb > ctx->sp_touched.cap) {
+			if ((r = ensure(ctx, ctx->sp_touched, tb))) return r;
+			HIP_TRY(ctx, hipMemsetAsync(ctx->sp_touched.p, 0, ctx->sp_touched.cap, ctx->stream));
+		}
+		if ((r = ensure(ctx, ctx->pair_seg, m * sizeof(uint32_t))) || (r = ensure(ctx, ctx->qslots, sizeof(uint32_t)))) return r;
+		const uint32_t m32 = (uint32_t)m;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->pair_seg.p, 0, m * sizeof(uint32_t), ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, &m32, sizeof m32, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, set->ent, set->hdr, d_slots, (const uint32_t*)ctx->pair_seg.p, m32, L.nbins, (uint32_t*)ctx->sp_acc.p,
+		                                             (uint32_t*)ctx->sp_touched.p));
+		HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, L.nbins, n_chunks, chunk_bins, 1, (const uint32_t*)ctx->qslots.p,
+		                                                (uint64_t*)ctx->sp_counts.p, (const uint32_t*)ctx->sp_touched.p));
+	} else {
 	HIP_TRY(ctx, msc_launch_sparse_scatter(ctx->stream, set->ent, set->hdr, d_slots, (uint32_t)m, (uint32_t*)ctx->sp_acc.p));
 	HIP_TRY(ctx, msc_launch_sparse_mean_count(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (uint64_t*)ctx->sp_counts.p));
+	}
 	std::vector<uint64_t> counts(n_chunks * 3), off(n_chunks), cb(n_chunks);
 	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2181,6 +2200,10 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->floor_sum.p, &floor_sum, 8, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	if (grouped)
+		HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, L.nbins, n_chunks, chunk_bins, 1, (const uint32_t*)ctx->qslots.p,
+		                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, rs->ent, rs->cum, (uint32_t*)ctx->sp_touched.p));
+	else
 	HIP_TRY(ctx, msc_launch_sparse_mean_write(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (const uint64_t*)ctx->sp_chunk_off.p,
 	                                          (const uint64_t*)ctx->sp_chunk_cum.p, rs->ent, rs->cum));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // h, sc, floor_sum, off, cb live on this frame
