@@ -41,6 +41,14 @@ typedef struct {
 	int (*update_centres)(void* user, const uint32_t* centres, uint64_t n, const uint32_t* points, const uint64_t* offsets, int64_t* nearest);
 	int (*centre_set_batch)(void* user, const uint32_t* centres, const uint32_t* points, uint64_t n);
 	int (*merge_all)(void* user, const uint32_t* centres, uint64_t n, int delta, int64_t* best);
+	/* optional (all three or none): the window of get_close kept on the callee's side (msc_window in meshclust2_hip.h).
+	 *   set_order: order[pos] = point at position pos of the sealed length-binned store; every position starts alive.
+	 *   get_close_range: get_close over the alive positions of [first, end) in position order; close[0..*n_close) (room for
+	 *     end - first) = the positions it marks, ascending -- they leave the store with the call; *best = position of the arg-max or -1.
+	 *   kill: a position that leaves the store otherwise (the next seed: bvec::erase / bvec::pop). */
+	int (*set_order)(void* user, const uint32_t* order, uint64_t n);
+	int (*get_close_range)(void* user, uint32_t q, uint64_t first, uint64_t end, uint32_t* close, uint64_t* n_close, int64_t* best, int* is_min);
+	int (*kill)(void* user, uint64_t pos);
 } msc_cluster_callbacks;
 
 /* do_run's tail + ClusterFactory::MS over n points (headers[i] = full header line incl. '>', lengths[i] = effective length).

@@ -281,6 +281,26 @@ int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* reg,
                const msc_hist_set* db, const uint32_t* db_slots, uint64_t m,
                const msc_hist_set* qset, uint64_t q_slot, uint8_t* close_out, double* sim_out);
 
+/* ------------------------------------------------------------------ a8 over a device-resident window
+ * The accumulate loop (cluster/ClusterFactory.cpp:553-610) hands Trainer::get_close an iterator range of the length-sorted store
+ * (bvec::get_range, cluster/bvec.cpp:261-330; the loop `for (i = istart; i < iend; ++i)` of cluster/Trainer.cpp:41-48). A
+ * msc_window keeps that store's ORDER on the device: position i holds slot slots[i] of `set` and an alive flag, all alive at first.
+ * A step then passes the positions [first, end) instead of a slot list rebuilt on the host: host work per step is O(close).
+ *   msc_get_close_window: get_close over the ALIVE positions of [first, end) in position order; same window rule, arg-max and
+ *     tie order as msc_get_close. *close_pos (valid until the next call on this window) lists the n_close positions the reference
+ *     would mark, ascending; they DIE with the call -- the loop removes marked points next (remove_available,
+ *     cluster/ClusterFactory.cpp:598). best_pos = POSITION of the arg-max, -1 if nothing passed the length filter.
+ *   msc_window_kill: positions that leave the store otherwise (bvec::erase of the next seed :589, bvec::pop :593).
+ *   msc_window_alive: alive positions in [first, end), from the host-side count the library keeps (no device read-back). */
+typedef struct msc_window msc_window;
+int      msc_window_create(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* slots, uint64_t n, msc_window** out);
+void     msc_window_destroy(msc_window* w);
+uint64_t msc_window_alive(const msc_window* w, uint64_t first, uint64_t end);
+int      msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* positions, uint64_t n);
+int      msc_get_close_window(msc_ctx* ctx, const msc_model* model, double cutoff, msc_window* w, uint64_t first, uint64_t end,
+                              const msc_hist_set* qset, uint64_t q_slot, const uint32_t** close_pos, uint64_t* n_close,
+                              int64_t* best_pos, double* best_sim, int* is_min);
+
 /* ------------------------------------------------------------------ a4/a10: mean-shift metric */
 /* get_mean (cluster/ClusterFactory.cpp:338-380), the mean part of mean_shift_update (:297-326) and Trainer::closest
  * (cluster/Trainer.cpp:144-157): FP64 column mean of the m members, DivergencePoint::distance_d

@@ -18,12 +18,15 @@ MERGE = C.CFUNCTYPE(_int, _vp, _pu32, _u64, _i64, _i64, _i64, _pi64)
 UPDATE_CENTRES = C.CFUNCTYPE(_int, _vp, _pu32, _u64, _pu32, _pu64, _pi64)
 CENTRE_SET_BATCH = C.CFUNCTYPE(_int, _vp, _pu32, _pu32, _u64)
 MERGE_ALL = C.CFUNCTYPE(_int, _vp, _pu32, _u64, _int, _pi64)
+SET_ORDER = C.CFUNCTYPE(_int, _vp, _pu32, _u64)
+GET_CLOSE_RANGE = C.CFUNCTYPE(_int, _vp, _u32, _u64, _u64, _pu32, _pu64, _pi64, _pint)
+KILL = C.CFUNCTYPE(_int, _vp, _u64)
 
 
 class Callbacks(C.Structure):
     _fields_ = [("user", _vp), ("get_close", GET_CLOSE), ("closest", CLOSEST), ("centre_new", CENTRE_NEW), ("centre_set", CENTRE_SET),
                 ("filter", FILTER), ("merge", MERGE), ("update_centres", UPDATE_CENTRES), ("centre_set_batch", CENTRE_SET_BATCH),
-                ("merge_all", MERGE_ALL)]
+                ("merge_all", MERGE_ALL), ("set_order", SET_ORDER), ("get_close_range", GET_CLOSE_RANGE), ("kill", KILL)]
 
 
 PROTOTYPES = {
@@ -68,6 +71,7 @@ def run(backend, headers, lengths, similarity, delta=5, iterations=15, output=No
          closest(members) -> pos          centre_new(point) -> centre        centre_set(centre, point)
          filter(centre, points) -> keep np.uint8[m]          merge(centres, current, begin, last) -> best
        optional: update_centres(centres, points, offsets) -> nearest np.int64[n]; centre_set_batch(centres, points); merge_all(centres, delta) -> best[n]
+       optional (all three): set_order(order np.uint32[n]); get_close_range(q, first, end) -> (close positions ascending, best position, is_min); kill(pos)
     An exception raised inside a method aborts the run and is re-raised here."""
     import numpy as np
     lib = load_library()
@@ -133,10 +137,31 @@ def run(backend, headers, lengths, similarity, delta=5, iterations=15, output=No
         if n:
             np.ctypeslib.as_array(best, shape=(int(n),))[:] = res
 
+    @guard
+    def set_order(_u, order, n_):
+        backend.set_order(arr(order, n_, np.uint32))
+
+    @guard
+    def get_close_range(_u, q, first, end, close, n_close, best, is_min):
+        c, b, im = backend.get_close_range(int(q), int(first), int(end))
+        c = np.asarray(c, dtype=np.uint32)
+        if c.size:
+            np.ctypeslib.as_array(close, shape=(int(end - first),))[:c.size] = c
+        n_close[0] = int(c.size)
+        best[0] = int(b)
+        is_min[0] = 1 if im else 0
+
+    @guard
+    def kill(_u, pos):
+        backend.kill(int(pos))
+
+    ranged = all(hasattr(backend, m) for m in ("set_order", "get_close_range", "kill"))
     cb = Callbacks(None, GET_CLOSE(get_close), CLOSEST(closest), CENTRE_NEW(centre_new), CENTRE_SET(centre_set), FILTER(filter_), MERGE(merge),
                    UPDATE_CENTRES(update_centres) if hasattr(backend, "update_centres") else UPDATE_CENTRES(),
                    CENTRE_SET_BATCH(centre_set_batch) if hasattr(backend, "centre_set_batch") else CENTRE_SET_BATCH(),
-                   MERGE_ALL(merge_all) if hasattr(backend, "merge_all") else MERGE_ALL())
+                   MERGE_ALL(merge_all) if hasattr(backend, "merge_all") else MERGE_ALL(),
+                   SET_ORDER(set_order) if ranged else SET_ORDER(), GET_CLOSE_RANGE(get_close_range) if ranged else GET_CLOSE_RANGE(),
+                   KILL(kill) if ranged else KILL())
     n = len(headers)
     hdr = (C.c_char_p * max(n, 1))(*[h if isinstance(h, bytes) else h.encode() for h in headers])
     lens = (C.c_uint64 * max(n, 1))(*[int(x) for x in lengths])

@@ -373,6 +373,46 @@ class Trainer:
         return pos.value, d, mean
 
 
+class Window:
+    """The length-sorted store of the accumulate loop kept on the device (msc_window): position i = slot slots[i] of `points`,
+    alive until a get_close marks it or kill() removes it."""
+
+    def __init__(self, ctx, points, slots):
+        self.ctx, self.points = ctx, points
+        sl = np.ascontiguousarray(slots, dtype=np.uint32)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.msc_window_create(ctx.h, points.h, _ptr(sl), sl.size, C.byref(h)))
+        self.h, self.n = h, sl.size
+        ctx._adopt(self)
+
+    def alive(self, first=0, end=None):
+        return self.ctx.lib.msc_window_alive(self.h, first, self.n if end is None else end)
+
+    def kill(self, positions):
+        p = np.ascontiguousarray(positions, dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.msc_window_kill(self.ctx.h, self.h, _ptr(p), p.size))
+
+    def get_close(self, trainer, first, end, qset, q_slot):
+        """Trainer::get_close over the alive positions of [first, end) -> (close positions (ascending; they die), best position, best_sim, is_min)"""
+        lst = C.POINTER(C.c_uint32)()
+        n, bp, bs, im = C.c_uint64(), C.c_int64(), C.c_double(), C.c_int()
+        self.ctx.check(self.ctx.lib.msc_get_close_window(self.ctx.h, trainer.feat.h, trainer.cutoff, self.h, first, end, qset.h, q_slot, C.byref(lst), C.byref(n),
+                                                         C.byref(bp), C.byref(bs), C.byref(im)))
+        close = np.ctypeslib.as_array(lst, shape=(n.value,)).astype(np.int64) if n.value else np.zeros(0, dtype=np.int64)
+        return close, bp.value, bs.value, bool(im.value)
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.msc_window_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def train_class(ctx, points, first_slots, second_slots, vals, n_train, feat_flags, min_feat, max_feat, ident):
     """Predictor::train's selection + GLM on labelled pairs -> (weights file text, training accuracy, testing accuracy)"""
     fs = np.ascontiguousarray(first_slots, dtype=np.uint32)

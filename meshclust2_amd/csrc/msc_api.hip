@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,80 +20,7 @@
 
 #include "msc_internal.h"
 
-// ================================================================================================ objects
-struct DevBuf {
-	void* p = nullptr;
-	size_t cap = 0;
-};
-
-struct msc_ctx {
-	int device = -1;
-	int num_cus = 256;
-	hipStream_t stream = nullptr;
-	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
-	bool have_timing = false;
-	bool timing = true;                      // record the HIP events behind msc_last_kernel_ms (msc_set_kernel_timing)
-	uint32_t last_partial_stride = 0;        // partial records per candidate written by the last run_score
-	float tiles_ms_accum = 0.f;
-	int tiles_launches = 0;
-	const char* last_kernel = "";            // streaming kernel of the last scoring call
-	int last_query_tile = 1;                 // queries one HBM read of a candidate tile served in it
-	std::string err;
-	char dev_name[128] = {0};
-	// growable device scratch
-	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
-	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg, seq_ids, seq_meta;
-	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
-	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
-	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
-	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch, reduce_parts, sp_touched;
-	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
-	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
-	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
-	DevBuf segs, pair_seg, dist;
-	uint64_t sp_acc_bins = 0;
-};
-
-struct msc_hist_set {
-	msc_ctx* ctx = nullptr;
-	int k = 0, dtype = 0;
-	uint64_t capacity = 0;
-	MscLayout L;
-	uint64_t scalar_stride = 0;
-	uint8_t* bins = nullptr;
-	uint8_t* scalars = nullptr;
-	// host-side bounds over every slot ever written (monotone; used to pick the kernels' integer range)
-	uint64_t max_count = 0, max_sum = 0;
-	// digest mirror (pair_digest.hip), allocated on the first Q x M pass that can use it; slots [dg_lo, dg_hi) are stale
-	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
-	mutable uint64_t dg_lo = 0, dg_hi = 0;
-	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
-	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
-	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
-	mutable msc_hist_set* sp_mirror = nullptr;
-	mutable uint64_t sm_lo = 0, sm_hi = 0;
-	mutable bool sp_mirror_unavailable = false;
-	std::vector<uint8_t> written;         // dense sets: slot holds a histogram (unwritten slots are never sparsified)
-	// effective lengths as the host last learnt them (len_known[i] != 0): Trainer::get_close / filter / merge derive their length
-	// window from the query's length, and reading it back from the device costs a stream round trip per call
-	mutable std::vector<uint64_t> len_host;
-	mutable std::vector<uint8_t> len_known;
-	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
-	bool sparse = false;
-	uint2* ent = nullptr;
-	uint32_t* cum = nullptr;
-	MscSparseHdr* hdr = nullptr;          // device, [capacity]
-	std::vector<MscSparseHdr> hdr_host;   // mirror
-	uint64_t ent_capacity = 0, ent_used = 0;
-	uint32_t max_nnz = 0;                 // longest entry list ever stored (monotone)
-};
-
-struct msc_model {
-	msc_ctx* ctx = nullptr;
-	int k = 0;
-	MscDevModel h;
-	MscDevModel* d = nullptr;
-};
+#include "msc_objects.h"
 
 static thread_local std::string g_create_error;
 
@@ -100,7 +28,7 @@ static thread_local std::string g_create_error;
 static const uint64_t kNarrowMaxCount = 8191;
 static const uint64_t kNarrowMaxSum = (1ull << 31) - 1;
 
-static int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
+int fail(msc_ctx* ctx, int code, const char* fmt, ...) {
 	char buf[512];
 	va_list ap;
 	va_start(ap, fmt);
@@ -116,18 +44,11 @@ bool msc_ctx_owns(const msc_ctx* ctx, const msc_hist_set* set) { return ctx && s
 
 // MSC_TRACE_CALLS (debugging a device fault): every runtime call / kernel launch is named on stderr before it is issued and the
 // device is drained behind it, so the last line printed names the operation that faulted
-static const bool g_trace_calls = getenv("MSC_TRACE_CALLS") != nullptr;
-#define HIP_TRY(ctx, expr)                                                                                 \
-	do {                                                                                                   \
-		if (g_trace_calls) { fprintf(stderr, "[msc] %s:%d %.160s\n", __FILE__, __LINE__, #expr); fflush(stderr); } \
-		hipError_t e_ = (expr);                                                                            \
-		if (g_trace_calls && e_ == hipSuccess) e_ = hipDeviceSynchronize();                                \
-		if (e_ != hipSuccess)                                                                              \
-			return fail(ctx, e_ == hipErrorOutOfMemory ? MSC_ERR_OOM : MSC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
-			            hipGetErrorString(e_), __FILE__, __LINE__);                                        \
-	} while (0)
+const bool g_trace_calls = getenv("MSC_TRACE_CALLS") != nullptr;
+static const bool g_profile_calls = getenv("MSC_PROFILE_CALLS") != nullptr;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
+int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 	if (bytes <= b.cap) return MSC_OK;
 	// a buffer that has to grow grows by at least half: callers that come back with slightly larger batches (chunked builds)
 	// would otherwise pay a hipFree + hipMalloc pair -- milliseconds each next to a resident 100 GB set -- on every call
@@ -146,7 +67,7 @@ static int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 
 // page-locked host staging: a pageable hipMemcpyAsync stalls the host on the runtime's own bounce buffer, which the accumulate
 // loop pays once per step in each direction
-static int ensure_pinned(msc_ctx* ctx, DevBuf& b, size_t bytes) {
+int ensure_pinned(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 	if (bytes <= b.cap) return MSC_OK;
 	if (b.p) { HIP_TRY(ctx, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
 	const size_t cap = (std::max<size_t>(bytes, 65536) + 4095) / 4096 * 4096;
@@ -155,7 +76,7 @@ static int ensure_pinned(msc_ctx* ctx, DevBuf& b, size_t bytes) {
 	return MSC_OK;
 }
 
-static void release(DevBuf& b) {
+void release(DevBuf& b) {
 	if (b.p) (void)hipFree(b.p);
 	b.p = nullptr;
 	b.cap = 0;
@@ -197,6 +118,9 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	if (g_profile_calls && ctx->prof_calls)
+		fprintf(stderr, "[msc] 1 x M scoring calls: %llu (%llu candidates) | slot list %.3f s, launches %.3f s, stream wait %.3f s\n", (unsigned long long)ctx->prof_calls,
+		        (unsigned long long)ctx->prof_cands, ctx->prof_prep, ctx->prof_issue, ctx->prof_wait);
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
@@ -486,13 +410,13 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 static void forget_lengths(const msc_hist_set* s, uint64_t first, uint64_t n) {
 	for (uint64_t i = first; i < first + n && i < s->len_known.size(); i++) s->len_known[i] = 0;
 }
-static void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len) {
+void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len) {
 	if (s->len_known.size() < s->capacity) { s->len_known.resize(s->capacity, 0); s->len_host.resize(s->capacity, 0); }
 	s->len_host[slot] = len;
 	s->len_known[slot] = 1;
 }
 
-static void mark_written(msc_hist_set* s, uint64_t first, uint64_t n) {
+void mark_written(msc_hist_set* s, uint64_t first, uint64_t n) {
 	forget_lengths(s, first, n);
 	if (s->sparse || n == 0) return;
 	if (s->written.size() < s->capacity) s->written.resize(s->capacity, 0);
@@ -501,7 +425,7 @@ static void mark_written(msc_hist_set* s, uint64_t first, uint64_t n) {
 }
 
 // pull the scalar records of [first, first+n) and fold their maxima into the set's host-side bounds
-static int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
+int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n) {
 	mark_written(s, first, n);
 	std::vector<MscSlotScalars> h(n);
 	HIP_TRY(ctx, hipMemcpy2DAsync(h.data(), sizeof(MscSlotScalars), s->scalars + first * s->scalar_stride, s->scalar_stride,
@@ -570,7 +494,7 @@ static int sparsify_slots(msc_ctx* ctx, const msc_hist_set* dense, uint64_t d_fi
 // The sparse mirror of a dense set: nullptr where the sparse layout does not exist (histograms under 64 KiB) or
 // cannot be allocated. Refreshes the written slots of the stale hull; when the append-only arena runs out, the mirror is rebuilt
 // compactly from every written slot.
-static int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out) {
+int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out) {
 	*out = nullptr;
 	static const bool disabled = getenv("MSC_NO_SPARSE_MIRROR") != nullptr;
 	if (set->sparse) { *out = set; return MSC_OK; }
@@ -1029,7 +953,7 @@ extern "C" int msc_hist_info_get(msc_ctx* ctx, const msc_hist_set* set, uint64_t
 }
 
 // effective length of a slot: from the host-side cache when a writer left it there, else read back once
-static int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len) {
+int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len) {
 	int r = check_slot(ctx, set, slot);
 	if (r) return r;
 	if (slot < set->len_known.size() && set->len_known[slot]) { *len = set->len_host[slot]; return MSC_OK; }
@@ -1373,31 +1297,6 @@ extern "C" void msc_model_set_bias(msc_model* m, double bias) {
 // ================================================================================================ scoring driver
 namespace {
 
-struct ScoreRequest {
-	const msc_model* model = nullptr;
-	const msc_hist_set* cands = nullptr;
-	const uint32_t* cand_slots = nullptr;   // host
-	uint64_t m = 0;
-	const msc_hist_set* qset = nullptr;
-	uint64_t q_slot = 0;
-	int order = MSC_ORDER_CAND_FIRST;
-	int use_window = 0;
-	uint64_t min_len = 0, max_len = 0;
-	uint64_t feat_mask = 0;
-	// host outputs (nullable)
-	double* raw_out = nullptr;
-	double* singles_out = nullptr;
-	double* combos_out = nullptr;
-	double* sum_out = nullptr;
-	double* csum_out = nullptr;
-	double* combo0_out = nullptr;
-	int32_t* status_out = nullptr;
-	uint8_t* flags_out = nullptr;
-	int reduce_mode = -1;                   // <0: no reduce kernel
-	int64_t reduce_begin = 0;
-	MscReduceOut* reduce_host = nullptr;
-	bool only_tiles = false;                // msc_mean_nearest reuses the streaming kernel and folds partials itself
-};
 
 // integer range of the fast streaming kernels (pair_features.hip header); outside it the 64-bit kernel runs
 bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) {
@@ -1434,13 +1333,16 @@ SparseKernel pick_sparse_kernel(const msc_hist_set* c_sp, const msc_hist_set* q_
 	return SPK_GENERIC;
 }
 uint32_t sparse_records(SparseKernel k, uint32_t mp_parts = 1) { return k == SPK_GENERIC ? MSC_SPARSE_SUB : k == SPK_MP ? mp_parts : 1; }
+// {jd, js} records per pair: the merge-path kernel leaves one per granule of the merged order (lists of up to `entries` together)
+uint32_t div_records(SparseKernel k, uint64_t entries) { return k == SPK_GENERIC ? MSC_SPARSE_SUB : k == SPK_MP ? msc_sparse_mp_div_records(entries) : 1; }
 const char* sparse_kernel_name(SparseKernel k) { return k == SPK_LDS ? "k_pair_sparse_lds" : k == SPK_MP ? "k_pair_sparse_mp" : "k_pair_sparse"; }
 
 // candidates [off, off + mc) (or the device slot list d_slots) of the sparse set / mirror c_sp against slot q_slot of q_sp; the
 // scalar records are those of the sets the lists belong to (a mirror has none of its own)
 hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* c_sp, const uint8_t* c_scalars, uint64_t c_stride, const uint32_t* d_slots,
                               uint64_t off, uint32_t mc, const msc_hist_set* q_sp, uint64_t q_slot, const uint8_t* q_scal, uint64_t nbins, int use_window,
-                              uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, uint32_t parts = 1) {
+                              uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, uint32_t parts = 1,
+                              uint32_t div_stride = 1) {
 	const MscSparseHdr* c_hdr = c_sp->hdr + (d_slots ? 0 : off);
 	const uint8_t* c_scal = c_scalars + (d_slots ? 0 : off * c_stride);
 	const uint32_t q_nnz = q_sp->hdr_host[q_slot].nnz;
@@ -1450,15 +1352,18 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 	if (k == SPK_MP)
 		return msc_launch_pair_sparse_mp(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 		                                 use_window, min_len, max_len, partials, div_tables, div_partials, order, ctx->num_cus,
-		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz), parts, q_nnz, c_sp->max_nnz);
+		                                 (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)q_nnz + c_sp->max_nnz), parts, q_nnz, c_sp->max_nnz, div_stride);
 	return msc_launch_pair_sparse(ctx->stream, c_sp->ent, c_sp->cum, c_hdr, c_scal, c_stride, d_slots, mc, q_sp->ent, q_sp->cum, q_sp->hdr + q_slot, q_scal, nbins,
 	                              use_window, min_len, max_len, partials, div_tables, div_partials, order);
 }
 
 // Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
+}  // namespace
 int run_score(msc_ctx* ctx, ScoreRequest& rq) {
-	int r = validate_pair(ctx, rq.cands, rq.qset, rq.q_slot, rq.cand_slots, rq.m);
+	const double t_call = g_profile_calls ? now_s() : 0;
+	int r = validate_pair(ctx, rq.cands, rq.qset, rq.q_slot, rq.cand_slots, rq.dev_slots ? 0 : rq.m);
 	if (r) return r;
+	if (rq.dev_slots && (rq.cand_slots || rq.reduce_mode < 0 || rq.m > 0xfffffff0ull)) return fail(ctx, MSC_ERR_INVALID_ARG, "run_score: a device slot list goes with a reduction only");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const msc_hist_set* cs = rq.cands;
 	const MscLayout& L = cs->L;
@@ -1503,10 +1408,13 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	if (sp) ctx->last_kernel = spk == SPK_MP && !need_div && msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz) ? "k_pair_sparse_wl" : sparse_kernel_name(spk);
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
 	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
-	const uint32_t mp_parts = sp && spk == SPK_MP && !need_div
-	                                  && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz)      // (short lists: the whole-list kernel, one wave each)
-	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz, ctx->num_cus) : 1;
+	// ... and so is the divergence form (sparse sets and the mirror pass of dense ones): its FP64 sums leave per granule of the merged
+	// order and are added in granule order by the epilogue, whatever the number of waves that shared a pair
+	const uint64_t mp_entries = c_sp ? (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz : 0;
+	const uint32_t mp_parts = c_sp && spk == SPK_MP && (need_div ? true : sp && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
+	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), mp_entries, ctx->num_cus, need_div) : 1;
 	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
+	const uint32_t DVN = div_records(spk, mp_entries);                // ... and {jd, js} records per candidate
 	const uint32_t PS = sp ? SPN : L.S;                               // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
@@ -1523,7 +1431,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	}
 	if (need_div) {
 		if ((r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
-		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? SPN : PS) * 16)) != MSC_OK) return r;
+		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? DVN : PS) * 16)) != MSC_OK) return r;
 		if (mirror_div && (r = ensure(ctx, ctx->sp_partials, chunk * SPN * sizeof(MscPartial))) != MSC_OK) return r;
 	}
 	if (need_grp) {
@@ -1543,16 +1451,20 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	std::vector<MscPairOut> po_host;
 	int first_err = 0;
 	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
+	if (g_profile_calls) { ctx->prof_calls++; ctx->prof_cands += m; ctx->prof_prep += now_s() - t_call; }
 	for (uint64_t off = 0; off < m; off += chunk) {
+		const double t_issue = g_profile_calls ? now_s() : 0;
 		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
-		const uint32_t* d_slots = rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
-		const uint8_t* c_bins = sp ? nullptr : cs->bins + (rq.cand_slots ? 0 : off * L.slot_bytes);
-		const uint8_t* c_scal = cs->scalars + (rq.cand_slots ? 0 : off * cs->scalar_stride);
+		const uint32_t* d_slots = rq.dev_slots ? rq.dev_slots : rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
+		const uint8_t* c_bins = sp ? nullptr : cs->bins + (d_slots ? 0 : off * L.slot_bytes);
+		const uint8_t* c_scal = cs->scalars + (d_slots ? 0 : off * cs->scalar_stride);
+		if (need_div && c_sp && spk == SPK_MP)      // granule records a pair does not reach stay zero
+			HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)mc * DVN * 16, ctx->stream));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (sp) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
-			                                mp_parts));
+			                                mp_parts, DVN));
 		} else if (wide) {
 			HIP_TRY(ctx, msc_launch_pair_tiles_wide(ctx->stream, L, cs->dtype, c_bins, c_scal, d_slots, mc, q_bins, q_scal, rq.use_window, rq.min_len,
 			                                        rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, inline_div ? ctx->div_partials.p : nullptr, rq.order));
@@ -1564,7 +1476,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (mirror_div)        // the divergence sums of this chunk, from the lists of the same slots (outside the streaming kernel's timing)
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
-			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order));
+			                                rq.max_len, (MscPartial*)ctx->sp_partials.p, ctx->div_tables.p, ctx->div_partials.p, rq.order, mp_parts, DVN));
 		if (grp_dense) {
 			HIP_TRY(ctx, msc_launch_pair_groups_dense(ctx->stream, L, cs->dtype, c_bins, c_scal, cs->scalar_stride, d_slots, mc, q_bins, rq.use_window, rq.min_len, rq.max_len,
 			                                          (double*)ctx->grp_pairs.p));
@@ -1585,7 +1497,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
 		ea.div_partials = inline_div ? ctx->div_partials.p : nullptr;
-		if (need_div && c_sp) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = SPN; ea.div_base = L.nbins; }
+		if (need_div && c_sp) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = DVN; ea.div_base = L.nbins; }
 		if (need_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + (uint64_t)chunk * 16; }
 		ea.S = PS;
 		ea.sparse_base = sp ? L.nbins : 0;
@@ -1617,7 +1529,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, hipHostGetDevicePointer((void**)&down, ctx->pin_down.p, 0));
 			if ((r = ensure(ctx, ctx->reduce_parts, msc_reduce_scratch_bytes())) != MSC_OK) return r;
 			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
-			                               rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down, ctx->reduce_parts.p));
+			                               rq.dev_flags_out ? rq.dev_flags_out : rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down, ctx->reduce_parts.p));
+			if (rq.after_reduce) HIP_TRY(ctx, rq.after_reduce((const MscReduceOut*)down));
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1628,7 +1541,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			po_host.resize(mc);
 			HIP_TRY(ctx, hipMemcpyAsync(po_host.data(), ctx->pair_out.p, (size_t)mc * sizeof(MscPairOut), hipMemcpyDeviceToHost, ctx->stream));
 		}
+		const double t_wait = g_profile_calls ? now_s() : 0;
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (g_profile_calls) { ctx->prof_issue += t_wait - t_issue; ctx->prof_wait += now_s() - t_wait; }
 		if (rq.reduce_mode >= 0) {
 			constexpr size_t kRo = 64;
 			memcpy(rq.reduce_host, ctx->pin_down.p, sizeof(MscReduceOut));
@@ -1656,6 +1571,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	return MSC_OK;
 }
 
+namespace {
 const uint64_t kSupportedFeats = MSC_FEAT_SLOW | MSC_FEAT_GROUPS;
 
 
@@ -1894,11 +1810,15 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure(ctx, ctx->grp_self, (chunk + n_q) * 16 * sizeof(double)))) return r;      // [candidates][16] then [queries][16]
 	}
 	SparseKernel spk = SPK_MP;
+	uint32_t dvn = 1;        // {jd, js} records per pair (one stride for the whole block)
 	if (want_div) {          // one kernel for the whole block: merge-path unless some query's lists are out of its range
 		for (uint64_t q = 0; q < n_q; q++) if (pick_sparse_kernel(c_sp, q_sp, q_slots[q], mc_, false) != SPK_MP) spk = SPK_GENERIC;
 		const uint32_t spn = sparse_records(spk);
+		uint64_t q_nnz_max = 0;
+		for (uint64_t q = 0; q < n_q; q++) q_nnz_max = std::max<uint64_t>(q_nnz_max, q_sp->hdr_host[q_slots[q]].nnz);
+		dvn = div_records(spk, q_nnz_max + c_sp->max_nnz);
 		if ((r = ensure(ctx, ctx->div_tables, chunk * 256 * 16))) return r;
-		if ((r = ensure(ctx, ctx->div_partials, n_q * chunk * spn * 16))) return r;
+		if ((r = ensure(ctx, ctx->div_partials, n_q * chunk * dvn * 16))) return r;
 		if ((r = ensure(ctx, ctx->sp_partials, chunk * spn * sizeof(MscPartial)))) return r;
 	}
 	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
@@ -1930,11 +1850,13 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
-		if (want_div)
+		if (want_div) {
+			if (spk == SPK_MP) HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)n_q * mc * dvn * 16, ctx->stream));
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
 				                                qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->sp_partials.p,
-				                                ctx->div_tables.p, (double*)ctx->div_partials.p + q * mc * sparse_records(spk) * 2, order));
+				                                ctx->div_tables.p, (double*)ctx->div_partials.p + q * mc * dvn * 2, order, 1, dvn));
+		}
 		if (want_grp) {
 			double* gp = (double*)ctx->grp_pairs.p;
 			double* gs_c = (double*)ctx->grp_self.p;
@@ -1957,7 +1879,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		MscEpilogueArgs ea;
 		memset(&ea, 0, sizeof ea);
 		ea.partials = (const MscPartial*)ctx->partials.p;
-		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = sparse_records(spk); ea.div_base = L.nbins; }
+		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = dvn; ea.div_base = L.nbins; }
 		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
@@ -2422,12 +2344,15 @@ static int batch_div_lists(msc_ctx* ctx, const msc_hist_set* cands, const msc_hi
 // ... and the pass itself, for P pairs already described by ctx->slots / ctx->segs / ctx->pair_seg: sums -> ctx->div_partials[2 * pair].
 // A sparse pair of sets gets its integer records from the same launch (partials); dense sets have theirs from k_pair_tiles_batch.
 static int batch_div_pass(msc_ctx* ctx, const msc_hist_set* cands, const msc_hist_set* queries, const msc_hist_set* c_sp, const msc_hist_set* q_sp, uint64_t P,
-                          int order, MscPartial* partials) {
+                          int order, MscPartial* partials, uint32_t* div_n) {
 	int r;
-	if ((r = ensure(ctx, ctx->div_tables, P * 256 * 16)) || (r = ensure(ctx, ctx->div_partials, P * 16))) return r;
+	const uint32_t dvn = msc_sparse_mp_div_records((uint64_t)c_sp->max_nnz + q_sp->max_nnz);      // records per pair (the 1 x M form's granules)
+	*div_n = dvn;
+	if ((r = ensure(ctx, ctx->div_tables, P * 256 * 16)) || (r = ensure(ctx, ctx->div_partials, P * dvn * 16))) return r;
+	HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, P * dvn * 16, ctx->stream));
 	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, c_sp->ent, c_sp->cum, c_sp->hdr, cands->scalars, cands->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P,
 	                                             q_sp->ent, q_sp->cum, q_sp->hdr, cands->L.nbins, 1, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p, partials,
-	                                             order, ctx->num_cus, queries->scalars, queries->scalar_stride, ctx->div_tables.p, ctx->div_partials.p));
+	                                             order, ctx->num_cus, queries->scalars, queries->scalar_stride, ctx->div_tables.p, ctx->div_partials.p, dvn));
 	return MSC_OK;
 }
 
@@ -2521,8 +2446,9 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, pt_slots + base, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+			uint32_t dvn = 1;          // {jd, js} records per pair
 			if (sp && want_div) {
-				if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->partials.p))) return r;
+				if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->partials.p, &dvn))) return r;
 			} else if (sp)
 				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p,
 				                                             (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1, (const MscBatchSeg*)ctx->segs.p,
@@ -2533,13 +2459,13 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 				                                         (MscPartial*)ctx->partials.p, MSC_ORDER_QUERY_FIRST));
 				if (want_div) {          // the mirrors' lists, the dense sets' scalar records (a mirror has none of its own)
 					if ((r = ensure(ctx, ctx->sp_partials, P * sizeof(MscPartial)))) return r;
-					if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->sp_partials.p))) return r;
+					if ((r = batch_div_pass(ctx, pts, centres, c_sp, q_sp, P, MSC_ORDER_QUERY_FIRST, (MscPartial*)ctx->sp_partials.p, &dvn))) return r;
 				}
 			}
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
-			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = 1; ea.div_base = L.nbins; }
+			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = dvn; ea.div_base = L.nbins; }
 			ea.S = PS;
 			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;
@@ -2704,8 +2630,9 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand.data(), P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+			uint32_t dvn = 1;          // {jd, js} records per pair
 			if (sp && want_div) {
-				if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->partials.p))) return r;
+				if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->partials.p, &dvn))) return r;
 			} else if (sp)
 				HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, centres->ent, centres->cum, centres->hdr, centres->scalars, centres->scalar_stride,
 				                                             (const uint32_t*)ctx->slots.p, (uint32_t)P, centres->ent, centres->cum, centres->hdr, L.nbins, 1,
@@ -2717,13 +2644,13 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 				                                         centres->scalar_stride, 1, (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST));
 				if (want_div) {
 					if ((r = ensure(ctx, ctx->sp_partials, P * sizeof(MscPartial)))) return r;
-					if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->sp_partials.p))) return r;
+					if ((r = batch_div_pass(ctx, centres, centres, c_sp, q_sp, P, MSC_ORDER_CAND_FIRST, (MscPartial*)ctx->sp_partials.p, &dvn))) return r;
 				}
 			}
 			MscEpilogueArgs ea;
 			memset(&ea, 0, sizeof ea);
 			ea.partials = (const MscPartial*)ctx->partials.p;
-			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = 1; ea.div_base = L.nbins; }
+			if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = dvn; ea.div_base = L.nbins; }
 			ea.S = PS;
 			ea.sparse_base = sp ? L.nbins : 0;
 			ea.m = (uint32_t)P;

@@ -183,11 +183,13 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
                                       uint64_t min_len, uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus);
 uint32_t msc_sparse_mp_max_entries();
 bool msc_sparse_wl_fits(uint32_t q_nnz, uint32_t c_max_nnz);      // the whole-list kernel takes this 1 x M pass (one record per candidate)
-uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus);      // waves per candidate for a window of m (1 .. 16)
+uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div = false);      // waves per candidate for a window of m (1 .. 16)
+uint32_t msc_sparse_mp_div_records(uint64_t entries);      // {jd, js} records per pair the merge-path kernel's divergence form writes
 hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
                                      uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                      const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
-                                     uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total, uint32_t parts, uint32_t q_nnz = 0, uint32_t c_max_nnz = 0);
+                                     uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total, uint32_t parts, uint32_t q_nnz = 0, uint32_t c_max_nnz = 0,
+                                     uint32_t div_stride = 1);
 hipError_t msc_launch_sparse_build_sort(hipStream_t st, int k, int dtype, uint64_t nbins, uint64_t first_slot, uint32_t n_seqs, const uint32_t* packed,
                                         const uint64_t* seg_start, const uint64_t* kmer_off, const uint64_t* seq_seg_begin, const uint64_t* seq_arena_off,
                                         uint32_t P, uint8_t* scalars, uint64_t scalar_stride, MscSparseHdr* hdr, void* ent, uint32_t* cum);
@@ -199,7 +201,7 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
                                            uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                            const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
                                            MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars = nullptr, uint64_t q_scalar_stride = 0,
-                                           void* div_tables = nullptr, void* div_partials = nullptr);
+                                           void* div_tables = nullptr, void* div_partials = nullptr, uint32_t div_stride = 1);
 hipError_t msc_launch_sparse_scatter_batch(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, const uint32_t* seg, uint32_t n_members,
                                            uint64_t nbins, uint32_t* acc, uint32_t* touched = nullptr);
 hipError_t msc_launch_sparse_mean_count_batch(hipStream_t st, int dtype, const uint32_t* acc, uint64_t nbins, uint32_t n_chunks, uint64_t chunk_bins, uint32_t n_centres,

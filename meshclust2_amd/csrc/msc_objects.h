@@ -1,0 +1,142 @@
+// msc_objects.h -- the objects behind the opaque handles of include/meshclust2_hip.h and the host helpers the C-ABI translation
+// units share (msc_api.hip defines them; msc_window.hip and msc_shard.hip use them). Private to the library.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "msc_internal.h"
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+};
+
+struct msc_ctx {
+	int device = -1;
+	int num_cus = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev_tiles0 = nullptr, ev_tiles1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
+	bool have_timing = false;
+	bool timing = true;                      // record the HIP events behind msc_last_kernel_ms (msc_set_kernel_timing)
+	uint32_t last_partial_stride = 0;        // partial records per candidate written by the last run_score
+	float tiles_ms_accum = 0.f;
+	int tiles_launches = 0;
+	const char* last_kernel = "";            // streaming kernel of the last scoring call
+	int last_query_tile = 1;                 // queries one HBM read of a candidate tile served in it
+	std::string err;
+	char dev_name[128] = {0};
+	// growable device scratch
+	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
+	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg, seq_ids, seq_meta;
+	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
+	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
+	msc_hist_set* sparse_scratch = nullptr; // dense slots the sparse builder compacts from
+	DevBuf sp_counts, sp_cumbase, sp_acc, sp_chunk_off, sp_chunk_cum, sp_partials, grp_pairs, grp_self, sp_acc_batch, tile_scratch, reduce_parts, sp_touched;
+	msc_hist_set* sparse_mean_set = nullptr;   // one sparse slot: the rounded mean of msc_mean_nearest on sparse members
+	msc_hist_set* sparse_mean_batch = nullptr; // the rounded means of one chunk of centres (msc_update_centres on sparse sets)
+	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
+	DevBuf segs, pair_seg, dist;
+	uint64_t sp_acc_bins = 0;
+	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the
+	// launches, and waiting for the stream (printed by msc_destroy)
+	double prof_prep = 0, prof_issue = 0, prof_wait = 0;
+	uint64_t prof_calls = 0, prof_cands = 0;
+};
+
+struct msc_hist_set {
+	msc_ctx* ctx = nullptr;
+	int k = 0, dtype = 0;
+	uint64_t capacity = 0;
+	MscLayout L;
+	uint64_t scalar_stride = 0;
+	uint8_t* bins = nullptr;
+	uint8_t* scalars = nullptr;
+	// host-side bounds over every slot ever written (monotone; used to pick the kernels' integer range)
+	uint64_t max_count = 0, max_sum = 0;
+	// digest mirror (pair_digest.hip), allocated on the first Q x M pass that can use it; slots [dg_lo, dg_hi) are stale
+	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
+	mutable uint64_t dg_lo = 0, dg_hi = 0;
+	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
+	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
+	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
+	mutable msc_hist_set* sp_mirror = nullptr;
+	mutable uint64_t sm_lo = 0, sm_hi = 0;
+	mutable bool sp_mirror_unavailable = false;
+	std::vector<uint8_t> written;         // dense sets: slot holds a histogram (unwritten slots are never sparsified)
+	// effective lengths as the host last learnt them (len_known[i] != 0): Trainer::get_close / filter / merge derive their length
+	// window from the query's length, and reading it back from the device costs a stream round trip per call
+	mutable std::vector<uint64_t> len_host;
+	mutable std::vector<uint8_t> len_known;
+	// sparse layout (sparse.hip): entry arena + per-slot headers instead of `bins`
+	bool sparse = false;
+	uint2* ent = nullptr;
+	uint32_t* cum = nullptr;
+	MscSparseHdr* hdr = nullptr;          // device, [capacity]
+	std::vector<MscSparseHdr> hdr_host;   // mirror
+	uint64_t ent_capacity = 0, ent_used = 0;
+	uint32_t max_nnz = 0;                 // longest entry list ever stored (monotone)
+};
+
+struct msc_model {
+	msc_ctx* ctx = nullptr;
+	int k = 0;
+	MscDevModel h;
+	MscDevModel* d = nullptr;
+};
+
+
+int fail(msc_ctx* ctx, int code, const char* fmt, ...);
+extern const bool g_trace_calls;
+#define HIP_TRY(ctx, expr)                                                                                 \
+	do {                                                                                                   \
+		if (g_trace_calls) { fprintf(stderr, "[msc] %s:%d %.160s\n", __FILE__, __LINE__, #expr); fflush(stderr); } \
+		hipError_t e_ = (expr);                                                                            \
+		if (g_trace_calls && e_ == hipSuccess) e_ = hipDeviceSynchronize();                                \
+		if (e_ != hipSuccess)                                                                              \
+			return fail(ctx, e_ == hipErrorOutOfMemory ? MSC_ERR_OOM : MSC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+			            hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+	} while (0)
+
+int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes);             // growable device scratch
+int ensure_pinned(msc_ctx* ctx, DevBuf& b, size_t bytes);      // growable page-locked host staging
+void release(DevBuf& b);
+void mark_written(msc_hist_set* s, uint64_t first, uint64_t n);
+int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n);
+void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len);
+int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len);
+int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out);
+
+// one 1 x M scoring pass (msc_api.hip): streaming kernel -> epilogue -> optional reduce
+struct ScoreRequest {
+	const msc_model* model = nullptr;
+	const msc_hist_set* cands = nullptr;
+	const uint32_t* cand_slots = nullptr;   // host
+	uint64_t m = 0;
+	const msc_hist_set* qset = nullptr;
+	uint64_t q_slot = 0;
+	int order = MSC_ORDER_CAND_FIRST;
+	int use_window = 0;
+	uint64_t min_len = 0, max_len = 0;
+	uint64_t feat_mask = 0;
+	// host outputs (nullable)
+	double* raw_out = nullptr;
+	double* singles_out = nullptr;
+	double* combos_out = nullptr;
+	double* sum_out = nullptr;
+	double* csum_out = nullptr;
+	double* combo0_out = nullptr;
+	int32_t* status_out = nullptr;
+	uint8_t* flags_out = nullptr;
+	int reduce_mode = -1;                   // <0: no reduce kernel
+	int64_t reduce_begin = 0;
+	MscReduceOut* reduce_host = nullptr;
+	bool only_tiles = false;                // msc_mean_nearest reuses the streaming kernel and folds partials itself
+	// msc_get_close_window: the slot list is already on the device (cand_slots == nullptr), the close flags stay there, and
+	// after_reduce queues its own kernel behind the reduce kernel, before the call's one stream sync (d_rec = the reduce record)
+	const uint32_t* dev_slots = nullptr;
+	uint8_t* dev_flags_out = nullptr;
+	std::function<hipError_t(const MscReduceOut* d_rec)> after_reduce;
+};
+
+int run_score(msc_ctx* ctx, ScoreRequest& rq);

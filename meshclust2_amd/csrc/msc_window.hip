@@ -1,0 +1,249 @@
+// msc_window.hip -- Trainer::get_close over a RANGE of a length-sorted order kept on the device (include/meshclust2_hip.h,
+// "window" section).
+//
+// The accumulate loop (cluster/ClusterFactory.cpp:553-610) calls Trainer::get_close (cluster/Trainer.cpp:23-71) once per step on
+// the iterator range bvec::get_range returned: a contiguous stretch of the length-sorted store minus the points that have already
+// left it. The reference walks that range on the host (`for (i = istart; i < iend; ++i)`), and so did the r02 driver -- it rebuilt
+// the slot list of the window element by element and copied it to the device every step, O(window) host work per step. Here the
+// ORDER (position -> slot) and an ALIVE flag per position live in HBM: a step passes [first, end), a compaction kernel lists the
+// alive slots of the range, the ordinary 1 x M pipeline scores them, and what comes back is the reduce record and the POSITIONS
+// of the close candidates -- which the loop removes from its store next (ClusterFactory.cpp:598-601), so they die here at once.
+// Host work per step is O(close + log n): a Fenwick tree over the alive flags answers "how many candidates" without a read-back.
+#include <algorithm>
+#include <cstring>
+
+#include "msc_objects.h"
+
+struct msc_window {
+	msc_ctx* ctx = nullptr;
+	const msc_hist_set* set = nullptr;
+	uint64_t n = 0;
+	uint32_t* d_order = nullptr;      // [n] slot of position i
+	uint8_t* d_alive = nullptr;       // [n] 1 = still in the store
+	uint32_t* d_slots = nullptr;      // [n] compacted slots of the current range
+	uint32_t* d_pos = nullptr;        // [n] ... and their positions
+	uint32_t* d_counts = nullptr;     // per-block alive counts of the two-pass compaction + [kMaxBlocks] the close counter
+	uint8_t* d_flags = nullptr;       // [n] close flags of the current range (candidate order)
+	uint32_t* h_close = nullptr;      // page-locked, device-visible: [0] best position + 1, [1] n written, [2..] close positions
+	uint64_t h_close_cap = 0;
+	std::vector<uint32_t> fen;        // Fenwick tree over alive
+	std::vector<uint32_t> sorted;     // close positions of the last call, ascending (what the caller reads)
+};
+
+namespace {
+
+constexpr uint32_t kWinBlock = 1024;
+constexpr uint32_t kWinPer = 8;                        // positions per thread of the multi-block form
+constexpr uint32_t kWinTile = kWinBlock * kWinPer;     // positions per block
+constexpr uint32_t kMaxBlocks = 1u << 16;
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if ((int)lane >= off) inc += t; }
+	if (lane == 63) s_wave[wave] = inc;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { const uint32_t c = s_wave[w]; if (w < wave) base += c; tot += c; }
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
+}
+
+// one workgroup lists the alive positions of [first, first + range) in order: thread t takes a contiguous run
+__global__ void __launch_bounds__(kWinBlock) k_window_compact_one(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
+                                                                  uint32_t* __restrict__ slots, uint32_t* __restrict__ pos) {
+	__shared__ uint32_t s_wave[kWinBlock / 64];
+	const uint32_t per = (range + kWinBlock - 1) / kWinBlock;
+	const uint32_t lo = min(range, threadIdx.x * per), hi = min(range, lo + per);
+	uint32_t c = 0;
+	for (uint32_t i = lo; i < hi; i++) c += alive[first + i];
+	uint32_t total;
+	uint32_t o = block_excl_scan(c, s_wave, &total);
+	for (uint32_t i = lo; i < hi; i++)
+		if (alive[first + i]) { slots[o] = order[first + i]; pos[o] = first + i; o++; }
+}
+
+// the same over many workgroups: counts per block, then every block adds up the counts in front of it
+__global__ void __launch_bounds__(kWinBlock) k_window_count(const uint8_t* __restrict__ alive, uint32_t first, uint32_t range, uint32_t* __restrict__ counts) {
+	__shared__ uint32_t s_wave[kWinBlock / 64];
+	const uint32_t base = blockIdx.x * kWinTile + threadIdx.x * kWinPer;
+	uint32_t c = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
+	uint32_t total;
+	(void)block_excl_scan(c, s_wave, &total);
+	if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kWinBlock) k_window_write(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
+                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ pos) {
+	__shared__ uint32_t s_wave[kWinBlock / 64];
+	__shared__ uint32_t s_base;
+	uint32_t before = 0;
+	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kWinBlock) before += counts[b];
+	uint32_t total;
+	(void)block_excl_scan(before, s_wave, &total);
+	if (threadIdx.x == 0) s_base = total;
+	__syncthreads();
+	const uint32_t base = blockIdx.x * kWinTile + threadIdx.x * kWinPer;
+	uint32_t c = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
+	uint32_t o = s_base + block_excl_scan(c, s_wave, &total);
+#pragma unroll
+	for (uint32_t j = 0; j < kWinPer; j++)
+		if (base + j < range && alive[first + base + j]) { slots[o] = order[first + base + j]; pos[o] = first + base + j; o++; }
+}
+
+// behind the reduce kernel: the positions of the close candidates (any order; the host sorts the few there are) go to host
+// memory, their alive flags clear, and the best candidate's index becomes a position
+__global__ void __launch_bounds__(256) k_window_close(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint32_t m, uint8_t* __restrict__ alive,
+                                                      uint32_t* __restrict__ counter, const MscReduceOut* __restrict__ rec, uint32_t* __restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) out[0] = rec->best_pos >= 0 ? pos[rec->best_pos] + 1 : 0;
+	if (i >= m || !flags[i]) return;
+	const uint32_t p = pos[i];
+	alive[p] = 0;
+	out[2 + atomicAdd(counter, 1u)] = p;
+}
+
+__global__ void k_window_kill(uint8_t* __restrict__ alive, const uint32_t* __restrict__ positions, uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) alive[positions[i]] = 0;
+}
+
+void fen_add(std::vector<uint32_t>& f, uint64_t i, int d) { for (i++; i < f.size(); i += i & (~i + 1)) f[i] = (uint32_t)((int64_t)f[i] + d); }
+uint64_t fen_prefix(const std::vector<uint32_t>& f, uint64_t i) { uint64_t s = 0; for (; i > 0; i -= i & (~i + 1)) s += f[i]; return s; }
+
+double win_get_id(double cutoff) { return cutoff > 1 ? cutoff / 100.0 : cutoff; }
+
+}  // namespace
+
+extern "C" void msc_window_destroy(msc_window* w) {
+	if (!w) return;
+	if (w->ctx) (void)hipSetDevice(w->ctx->device);
+	(void)hipFree(w->d_order); (void)hipFree(w->d_alive); (void)hipFree(w->d_slots); (void)hipFree(w->d_pos); (void)hipFree(w->d_counts); (void)hipFree(w->d_flags);
+	if (w->h_close) (void)hipHostFree(w->h_close);
+	delete w;
+}
+
+extern "C" int msc_window_create(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* slots, uint64_t n, msc_window** out) {
+	if (!ctx || !set || set->ctx != ctx || !out || (!slots && n)) return MSC_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (n > 0xfffffff0ull) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_create: too many positions");
+	for (uint64_t i = 0; i < n; i++) if (slots[i] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_create: slot %u out of range", slots[i]);
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	msc_window* w = new msc_window();
+	w->ctx = ctx; w->set = set; w->n = n;
+	const size_t nn = std::max<uint64_t>(n, 1);
+	if (hipMalloc(&w->d_order, nn * 4) != hipSuccess || hipMalloc(&w->d_alive, nn) != hipSuccess || hipMalloc(&w->d_slots, nn * 4) != hipSuccess ||
+	    hipMalloc(&w->d_pos, nn * 4) != hipSuccess || hipMalloc(&w->d_counts, (kMaxBlocks + 1) * 4) != hipSuccess || hipMalloc(&w->d_flags, nn) != hipSuccess) {
+		(void)hipGetLastError();
+		msc_window_destroy(w);
+		return fail(ctx, MSC_ERR_OOM, "msc_window_create: out of device memory");
+	}
+	if (n) {
+		HIP_TRY(ctx, hipMemcpyAsync(w->d_order, slots, n * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(w->d_alive, 1, n, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	w->fen.assign(n + 1, 0);
+	for (uint64_t i = 1; i <= n; i++) {          // all ones, built in O(n)
+		w->fen[i] += 1;
+		const uint64_t j = i + (i & (~i + 1));
+		if (j <= n) w->fen[j] += w->fen[i];
+	}
+	*out = w;
+	return MSC_OK;
+}
+
+extern "C" uint64_t msc_window_alive(const msc_window* w, uint64_t first, uint64_t end) {
+	if (!w || first >= end) return 0;
+	end = std::min(end, w->n);
+	if (first >= end) return 0;
+	return fen_prefix(w->fen, end) - fen_prefix(w->fen, first);
+}
+
+extern "C" int msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* positions, uint64_t n) {
+	if (!ctx || !w || w->ctx != ctx || (!positions && n)) return MSC_ERR_INVALID_ARG;
+	if (n == 0) return MSC_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (uint64_t i = 0; i < n; i++) {
+		if (positions[i] >= w->n) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position out of range");
+		// (a position may die once: the tree holds what the device flags hold)
+		if (fen_prefix(w->fen, (uint64_t)positions[i] + 1) - fen_prefix(w->fen, positions[i]) == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position %u is already dead", positions[i]);
+		fen_add(w->fen, positions[i], -1);
+	}
+	if (n <= 4) {
+		for (uint64_t i = 0; i < n; i++) HIP_TRY(ctx, hipMemsetAsync(w->d_alive + positions[i], 0, 1, ctx->stream));
+		return MSC_OK;
+	}
+	int r;
+	if ((r = ensure(ctx, ctx->qslots, n * 4))) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, positions, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	k_window_kill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_alive, (const uint32_t*)ctx->qslots.p, (uint32_t)n);
+	HIP_TRY(ctx, hipGetLastError());
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // `positions` is the caller's
+	return MSC_OK;
+}
+
+extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double cutoff, msc_window* w, uint64_t first, uint64_t end, const msc_hist_set* qset,
+                                    uint64_t q_slot, const uint32_t** close_pos, uint64_t* n_close, int64_t* best_pos, double* best_sim, int* is_min) {
+	if (!ctx || !model || model->ctx != ctx || !w || w->ctx != ctx || !qset || !n_close || !best_pos || !is_min) return MSC_ERR_INVALID_ARG;
+	end = std::min(end, w->n);
+	*n_close = 0; *best_pos = -1; *is_min = 1;
+	if (best_sim) *best_sim = -1.0;
+	if (close_pos) *close_pos = nullptr;
+	const uint64_t m = msc_window_alive(w, first, end);
+	if (m == 0) return MSC_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int r;
+	uint64_t qlen = 0;
+	if ((r = slot_length(ctx, qset, q_slot, &qlen))) return r;
+	const uint32_t range = (uint32_t)(end - first);
+	if (range <= 128 * kWinBlock) {
+		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos);
+	} else {
+		const uint32_t blocks = (range + kWinTile - 1) / kWinTile;
+		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
+		k_window_count<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts);
+		k_window_write<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos);
+	}
+	HIP_TRY(ctx, hipGetLastError());
+	if (w->h_close_cap < m + 2) {
+		if (w->h_close) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipHostFree(w->h_close)); w->h_close = nullptr; w->h_close_cap = 0; }
+		const uint64_t cap = std::max<uint64_t>(m + 2, std::min<uint64_t>(w->n + 2, 2 * w->h_close_cap + 4096));
+		HIP_TRY(ctx, hipHostMalloc((void**)&w->h_close, cap * 4, hipHostMallocDefault));
+		w->h_close_cap = cap;
+	}
+	uint32_t* d_out = nullptr;
+	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_out, w->h_close, 0));
+	uint32_t* counter = w->d_counts + kMaxBlocks;
+	HIP_TRY(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
+	ScoreRequest rq;
+	MscReduceOut ro;
+	rq.model = model; rq.cands = w->set; rq.dev_slots = w->d_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot;
+	rq.order = MSC_ORDER_CAND_FIRST;
+	rq.use_window = 1;
+	rq.min_len = (uint64_t)((double)qlen * cutoff);          // cluster/Trainer.cpp:39-40: uint64 truncation
+	rq.max_len = (uint64_t)((double)qlen / cutoff);
+	rq.dev_flags_out = w->d_flags;
+	rq.reduce_mode = MSC_REDUCE_GET_CLOSE;
+	rq.reduce_host = &ro;
+	rq.after_reduce = [&](const MscReduceOut* d_rec) -> hipError_t {
+		k_window_close<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_flags, w->d_pos, (uint32_t)m, w->d_alive, counter, d_rec, d_out);
+		return hipGetLastError();
+	};
+	(void)win_get_id;
+	if ((r = run_score(ctx, rq))) return r;
+	*n_close = ro.n_close;
+	*is_min = ro.any_close ? 0 : 1;
+	*best_pos = (int64_t)w->h_close[0] - 1;
+	if (best_sim) *best_sim = ro.best_sim;
+	w->sorted.assign(w->h_close + 2, w->h_close + 2 + ro.n_close);
+	std::sort(w->sorted.begin(), w->sorted.end());
+	for (uint32_t p : w->sorted) fen_add(w->fen, p, -1);
+	if (close_pos) *close_pos = w->sorted.data();
+	return MSC_OK;
+}

@@ -850,6 +850,7 @@ __device__ __forceinline__ void mp_split(uint32_t d, uint32_t nc, uint32_t nq, C
 
 // PAIRS (the batched update stage on sparse sets, msc_update_centres / msc_merge_all): every candidate has its OWN query -- slot
 // segs[pair_seg[c]].q_slot behind q_hdr_p, with that segment's length window -- instead of the one query of a 1 x M pass.
+constexpr uint32_t kMpDivGran = 4;      // chunks per divergence record (see the DIV comment inside the kernel)
 template <bool DIV, uint32_t kMpT, bool PAIRS = false>
 __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
@@ -857,9 +858,14 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
-    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0) {
+    const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0,
+    uint32_t div_stride = 1) {
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
+	// DIV: the candidate's 16 x 16 table of terms, already relative to the (1, 1) term, in wave-private LDS -- the walk looks one
+	// entry up per event, and a lookup in global memory (a dependent L2 round trip per step of a serial walk, 4 waves per SIMD to
+	// hide it) was what bounded this form (r03: 124 G merged entries/s against 415 G for the integer form)
+	__shared__ DivTerm s_tab[DIV ? 4 : 1][DIV ? 256 : 1];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint2* buf = s_buf[wave];
 	MscSparseHdr qh = PAIRS ? MscSparseHdr{} : *q_hdr_p;
@@ -896,9 +902,31 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 		uint64_t dotx = 0, emd = 0;
 		double jd = 0.0, js = 0.0, cm = 0.0;
 		DivTerm t11{0.0, 0.0};
-		if constexpr (DIV) { cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order); }
+		if constexpr (DIV) {
+			cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order);
+			__builtin_amdgcn_wave_barrier();          // the previous candidate's walk is over
+#pragma unroll
+			for (uint32_t e = lane; e < 256; e += 64) {
+				const DivTerm g = div_tables[(uint64_t)c * 256 + e];
+				s_tab[wave][e] = DivTerm{g.jd - t11.jd, g.js - t11.js};
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
 		uint32_t ci = 0, qj = 0, dchunk = 0;
-		const uint32_t t_begin = (uint32_t)((uint64_t)n_chunks * part / parts), t_end = (uint32_t)((uint64_t)n_chunks * (part + 1) / parts);
+		// DIV: the two FP64 sums leave the wave once per GRANULE of kMpDivGran chunks, as record [c][granule] of div_partials, and the
+		// epilogue adds a pair's records in granule order -- so the value of a pair depends on the pair alone, not on how many waves
+		// shared it (parts cut the merged order between granules) nor on the route that scored it
+		uint32_t t_begin, t_end;
+		if constexpr (DIV) {
+			const uint32_t n_gran = (n_chunks + kMpDivGran - 1) / kMpDivGran;
+			t_begin = (uint32_t)((uint64_t)n_gran * part / parts) * kMpDivGran;
+			t_end = (uint32_t)((uint64_t)n_gran * (part + 1) / parts) * kMpDivGran;
+			if (t_end > n_chunks) t_end = n_chunks;
+		} else {
+			t_begin = (uint32_t)((uint64_t)n_chunks * part / parts);
+			t_end = (uint32_t)((uint64_t)n_chunks * (part + 1) / parts);
+		}
 		for (uint32_t t = t_begin; t < t_end; t++) {
 			const uint32_t tl = (t - t_begin) % 63;
 			if (tl == 0) {                       // boundaries of the next 63 chunks: lane l searches diagonal (t + l) * kMpT in global memory
@@ -972,10 +1000,10 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 					D += (int32_t)pv - (int32_t)qv;
 					if constexpr (DIV) {
 						DivTerm tt;
-						if ((pv | qv) < 16u) tt = div_tables[(uint64_t)c * 256 + pv * 16 + qv];
-						else tt = div_term_sp(pv, qv, cm, qm, order);
-						jd += tt.jd - t11.jd;
-						js += tt.js - t11.js;
+						if ((pv | qv) < 16u) tt = s_tab[wave][pv * 16 + qv];
+						else { tt = div_term_sp(pv, qv, cm, qm, order); tt.jd -= t11.jd; tt.js -= t11.js; }
+						jd += tt.jd;
+						js += tt.js;
 					}
 					pos = e;
 					pa += ta ? 8u : 0u;
@@ -985,6 +1013,17 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 				}
 				dotx -= events;                                                 // sum of (p q - 1) over the events
 			}
+			if constexpr (DIV) {
+				if ((t + 1) % kMpDivGran == 0 || t + 1 == t_end) {              // (t_begin is a multiple of the granule)
+#pragma unroll
+					for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+					if (lane == 0) {
+						double* rec = div_partials + 2ull * ((uint64_t)c * div_stride + t / kMpDivGran);
+						rec[0] = jd; rec[1] = js;
+					}
+					jd = 0.0; js = 0.0;
+				}
+			}
 		}
 		if (lane == 0 && part + 1 == parts) {      // the stretch behind the last event of either list
 			const uint32_t lc = nc_all ? P[nc_all - 1].x : 0u, lq = nq_all ? Q[nq_all - 1].x : 0u;
@@ -992,15 +1031,10 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 			emd += (uint64_t)(D < 0 ? -D : D) * (nbins - (uint64_t)(lc > lq ? lc : lq));
 		}
 		const uint64_t manh_t = wave_sum_u64(manh), dot_t = wave_sum_u64(dotx), emd_t = wave_sum_u64(emd);
-		if constexpr (DIV) {
-#pragma unroll
-			for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
-		}
 		if (lane == 0) {
 			MscPartial out;
 			out.manh = manh_t; out.dot = dot_t; out.emd = emd_t;
 			partials[w] = out;
-			if constexpr (DIV) { div_partials[2ull * w] = jd; div_partials[2ull * w + 1] = js; }
 		}
 	}
 }
@@ -1241,15 +1275,17 @@ uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists 
 constexpr uint32_t kMpChunk = 512;
 
 // lists of any length up to msc_sparse_mp_max_entries() together; same arithmetic range as the LDS kernel (caller checks).
-// parts (1 .. 16): waves per candidate, each writing its own record -- partials[c * parts + p]; the divergence form takes parts = 1
-// (its FP64 sums keep one evaluation order whatever the size of the window).
+// parts (1 .. 16): waves per candidate, each writing its own record -- partials[c * parts + p]. The divergence form writes its two
+// FP64 sums once per granule of the merged order (div_partials[c][div_stride][2], zeroed by the caller; the epilogue adds a pair's
+// records in order), so they do not depend on parts either.
 hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const uint32_t* c_cum, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars,
                                      uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                      const MscSparseHdr* q_hdr, const uint8_t* q_scalars, uint64_t nbins, int use_window, uint64_t min_len,
                                      uint64_t max_len, MscPartial* partials, void* div_tables, void* div_partials, int order, int num_cus, uint32_t max_total,
-                                     uint32_t parts, uint32_t q_nnz, uint32_t c_max_nnz) {
+                                     uint32_t parts, uint32_t q_nnz, uint32_t c_max_nnz, uint32_t div_stride) {
 	if (m == 0) return hipSuccess;
-	if (max_total > msc_sparse_mp_max_entries() || parts < 1 || parts > 16 || (div_tables && parts != 1) || (uint64_t)m * parts > 0xffffffffull) return hipErrorInvalidValue;
+	if (max_total > msc_sparse_mp_max_entries() || parts < 1 || parts > 16 || (uint64_t)m * parts > 0xffffffffull) return hipErrorInvalidValue;
+	if (div_tables && div_stride < msc_sparse_mp_div_records(max_total)) return hipErrorInvalidValue;
 	if (div_tables) {
 		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
 		hipError_t e = hipGetLastError();
@@ -1265,14 +1301,14 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 		                                                     c_max_nnz, nbins, use_window, min_len, max_len, partials);
 		return hipGetLastError();
 	}
-	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
+	const uint32_t per_cu = div_tables ? 4 : std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
 	const uint64_t waves = (uint64_t)m * parts;
 	uint32_t blocks = (uint32_t)num_cus * per_cu;
 	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
 	if (div_tables) {
 		k_pair_sparse_mp<true, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                     q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials,
-		                                                                     (const DivTerm*)div_tables, (double*)div_partials, order);
+		                                                                     (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride);
 	} else {
 		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
@@ -1287,13 +1323,19 @@ bool msc_sparse_wl_fits(uint32_t q_nnz, uint32_t c_max_nnz) {
 	static const bool no_wl = getenv("MSC_SPARSE_NO_WL") != nullptr;
 	return !no_wl && c_max_nnz && (uint64_t)q_nnz + 4ull * c_max_nnz + 10 <= 8192;
 }
-uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus) {
+uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div) {
 	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
 	if (off || m == 0) return 1;
-	const uint64_t slots = (uint64_t)num_cus * 32, chunks = entries / kMpChunk;
+	// (the divergence form holds fewer waves per SIMD and cuts between granules: a part keeps at least one granule)
+	const uint64_t slots = (uint64_t)num_cus * (div ? 16 : 32), chunks = entries / kMpChunk, per_part = div ? kMpDivGran : 2;
 	uint32_t parts = 1;
-	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * 2 <= chunks) parts *= 2;
+	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * per_part <= chunks) parts *= 2;
 	return parts;
+}
+// divergence records per pair of the merge-path kernel for lists of up to `entries` entries together
+uint32_t msc_sparse_mp_div_records(uint64_t entries) {
+	const uint64_t chunks = (entries + kMpChunk - 1) / kMpChunk;
+	return (uint32_t)std::max<uint64_t>(1, (chunks + kMpDivGran - 1) / kMpDivGran);
 }
 
 // candidates (slot list or the first m slots behind c_hdr) against one query list: 16 x {markov, rre} partials per candidate
@@ -1320,7 +1362,7 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
                                            uint64_t scalar_stride, const uint32_t* cand_slots, uint32_t m, const void* q_ent, const uint32_t* q_cum,
                                            const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, const MscBatchSeg* segs, const uint32_t* pair_seg,
                                            MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars, uint64_t q_scalar_stride, void* div_tables,
-                                           void* div_partials) {
+                                           void* div_partials, uint32_t div_stride) {
 	if (m == 0) return hipSuccess;
 	constexpr uint32_t T = 512;
 	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));
@@ -1333,7 +1375,7 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 		if (e != hipSuccess) return e;
 		k_pair_sparse_mp<true, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
 		                                                                   q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials,
-		                                                                   order, segs, pair_seg, 1, q_scalar_stride);
+		                                                                   order, segs, pair_seg, 1, q_scalar_stride, div_stride);
 		return hipGetLastError();
 	}
 	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,

@@ -9,7 +9,7 @@
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477):
 //   msc_cluster <input.fa> [--recover weights.txt] [--id 0.9] [--kmer K] [--datatype 8|16|32|64]   (no --recover: trains first)
-//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--device 0]
+//               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--no-ranges] [--device 0]
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -111,6 +111,25 @@ struct GpuBackend : msc::ClusterBackend {
 		}
 	}
 
+	// the sealed store's order on the device (msc_window): a step passes two positions instead of a rebuilt slot list
+	msc_window* window_ = nullptr;
+	~GpuBackend() override { msc_window_destroy(window_); }
+	bool set_order(const std::vector<uint32_t>& order) override {
+		ctx.check(msc_window_create(ctx.get(), points.get(), order.data(), order.size(), &window_));
+		return true;
+	}
+	void get_close_range(uint32_t q, uint64_t first, uint64_t end, std::vector<uint32_t>& close, int64_t& best, bool& is_min) override {
+		const uint32_t* list = nullptr;
+		uint64_t n = 0;
+		int im = 1;
+		ctx.check(msc_get_close_window(ctx.get(), trn.feature().get(), cutoff, window_, first, end, points.get(), q, &list, &n, &best, nullptr, &im));
+		close.assign(list, list + n);
+		is_min = im != 0;
+	}
+	void kill(uint64_t pos) override {
+		const uint32_t p = (uint32_t)pos;
+		ctx.check(msc_window_kill(ctx.get(), window_, &p, 1));
+	}
 	void get_close(uint32_t q, const std::vector<uint32_t>& window, std::vector<uint8_t>& flags, int64_t& pos, bool& is_min) override {
 		auto res = trn.get_close(points, window, points, q, is_min);
 		pos = std::get<0>(res);
@@ -295,7 +314,7 @@ int main(int argc, char** argv) {
 	std::string weights, output = "output.clstr";
 	double similarity = 0.90;
 	int k = -1, dtype = 0, delta = 5, iterations = 15, device = 0;
-	bool single_file = false, sparse = false, serial_update = false;
+	bool single_file = false, sparse = false, serial_update = false, no_ranges = false;
 	int n_templates = 300, min_feat = 4, max_feat = 4;      // cluster/CRunner.h:33-35
 	uint64_t feat_flags = MSC_FEAT_FAST;                    // the CLI default (cluster/CRunner.h:51)
 	std::string dump = "weights.txt";
@@ -331,6 +350,7 @@ int main(int argc, char** argv) {
 		else if (a == "--dump") dump = need("--dump");
 		else if (a == "--single-file") single_file = true;
 		else if (a == "--serial-update") serial_update = true;
+		else if (a == "--no-ranges") no_ranges = true;   // get_close receives a slot list rebuilt on the host every step (the r02 form)
 		else if (a == "--sparse") sparse = true;         // sparse histogram layout (required for k >= 13)
 		else files.push_back(a);
 	}
@@ -400,6 +420,7 @@ int main(int argc, char** argv) {
 		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, sparse ? 2 * total_bases + 64 * longest + (1 << 20) : 0);
 		msc::MeanShift ms(gpu, std::cout);
 		ms.batch_update = !serial_update;
+		ms.use_ranges = !no_ranges;
 		ms.run(records, similarity, iterations, delta, output.c_str());
 	} catch (const msc::Error& e) {
 		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());

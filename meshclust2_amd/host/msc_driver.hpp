@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -63,13 +64,21 @@ struct ClusterBackend {
 	virtual bool update_centres(const std::vector<uint32_t>&, const std::vector<uint32_t>&, const std::vector<uint64_t>&, std::vector<int64_t>&) { return false; }
 	virtual bool centre_set_batch(const std::vector<uint32_t>&, const std::vector<uint32_t>&) { return false; }
 	virtual bool merge_all(const std::vector<uint32_t>&, int, std::vector<int64_t>&) { return false; }
+	// The window of get_close kept on the backend's side. set_order: order[pos] = point at position pos of the sealed length-binned
+	// store (bins concatenated; every position alive); true = the backend takes ranges from now on. get_close_range: get_close
+	// over the ALIVE positions of [first, end) in position order; `close` = the positions it marks, ascending -- they leave the store
+	// next (remove_available, cluster/ClusterFactory.cpp:598), so the backend drops them at once; best = position of the arg-max
+	// or -1. kill: a position that leaves the store otherwise (the next seed: bvec::erase / bvec::pop, :589,593).
+	virtual bool set_order(const std::vector<uint32_t>&) { return false; }
+	virtual void get_close_range(uint32_t, uint64_t, uint64_t, std::vector<uint32_t>&, int64_t&, bool&) {}
+	virtual void kill(uint64_t) {}
 };
 
 // ------------------------------------------------------------------ the length-binned store (cluster/bvec.{h,cpp})
 // Bins hold (record, marked) in ascending length; bin b starts at the length of every per_bin-th record of the sorted input.
 class LengthBins {
 public:
-	struct Item { SeqRecord* rec; bool marked; };
+	struct Item { SeqRecord* rec; bool marked; uint32_t fixed = 0; };      // fixed = position in the sealed store (never changes)
 	struct Pos { size_t bin = 0, at = 0; bool none = false; };          // bvec_idx_t
 	typedef std::vector<Item> Bin;
 
@@ -99,9 +108,40 @@ public:
 	void seal() {                                                         // insert_finalize, bvec.cpp:216-233: unstable sort per bin
 		for (Bin& b : bins) std::sort(b.begin(), b.end(), [](const Item x, const Item y) { return x.rec->length < y.rec->length; });
 	}
-	SeqRecord* take_first() {                                             // pop, bvec.cpp:27-37
-		for (Bin& b : bins) if (!b.empty()) { SeqRecord* r = b.front().rec; b.erase(b.begin()); return r; }
+	SeqRecord* take_first(uint32_t* fixed = nullptr) {                    // pop, bvec.cpp:27-37
+		for (Bin& b : bins) if (!b.empty()) { SeqRecord* r = b.front().rec; if (fixed) *fixed = b.front().fixed; b.erase(b.begin()); return r; }
 		return nullptr;
+	}
+	// positions of the sealed store: bins concatenated in order. order[pos] = point handle; bin_of_[pos] = its bin, for good
+	void number(std::vector<uint32_t>& order) {
+		order.clear();
+		bin_of_.clear();
+		for (size_t b = 0; b < bins.size(); b++)
+			for (Item& it : bins[b]) { it.fixed = (uint32_t)order.size(); order.push_back(it.rec->point); bin_of_.push_back((uint32_t)b); }
+	}
+	// where the record of a position sits now (erasing keeps a bin in position order)
+	std::pair<size_t, size_t> locate(uint32_t fixed) const {
+		const size_t b = bin_of_.at(fixed);
+		const Bin& bin = bins[b];
+		const size_t at = (size_t)(std::lower_bound(bin.begin(), bin.end(), fixed, [](const Item& it, uint32_t f) { return it.fixed < f; }) - bin.begin());
+		if (at >= bin.size() || bin[at].fixed != fixed) throw std::runtime_error("length-binned store: position is no longer there");
+		return std::make_pair(b, at);
+	}
+	// the records at these positions (ascending) leave in bin order, as take_marked would take them
+	void take_positions(const std::vector<uint32_t>& fixed, std::vector<SeqRecord*>& out) {
+		size_t i = 0;
+		while (i < fixed.size()) {
+			const size_t b = bin_of_.at(fixed[i]);
+			Bin& bin = bins[b];
+			size_t j = i;
+			for (; j < fixed.size() && bin_of_[fixed[j]] == b; j++) {
+				const std::pair<size_t, size_t> w = locate(fixed[j]);
+				bin[w.second].marked = true;
+				out.push_back(bin[w.second].rec);
+			}
+			bin.erase(std::remove_if(bin.begin(), bin.end(), [](const Item d) { return d.marked; }), bin.end());
+			i = j;
+		}
 	}
 
 	// bvec::inner_index_of (bvec.cpp:52-120) inside a non-empty bin: its bisection ends on an element equal to `len` if there
@@ -151,6 +191,7 @@ public:
 	std::vector<Bin> bins;
 
 private:
+	std::vector<uint32_t> bin_of_;
 	static std::pair<size_t, size_t> run_of(const Bin& b, uint64_t len) {
 		const auto lt = [](const Item& it, uint64_t v) { return it.rec->length < v; };
 		const auto gt = [](uint64_t v, const Item& it) { return v < it.rec->length; };
@@ -198,6 +239,10 @@ class MeanShift {
 public:
 	MeanShift(ClusterBackend& b, std::ostream& log) : be_(b), log_(log) {}
 	bool batch_update = true;    // false: one centre at a time (the order the reference takes with one thread)
+	bool use_ranges = true;      // false: get_close always receives the window as a slot list rebuilt per step (the r02 form)
+	// MSC_CLUSTER_PROFILE=1: where the step-serial accumulate stage spends its wall clock (seconds), printed behind its timestamp
+	struct StepProfile { double window = 0, get_close = 0, mark = 0, closest = 0; uint64_t steps = 0, candidates = 0, closed = 0; } prof;
+	bool profile = std::getenv("MSC_CLUSTER_PROFILE") != nullptr;
 
 	// Clock::stamp (clutil/Clock.cpp:12-19): same stage names as the reference's driver
 	void stamp(const char* desc) {
@@ -218,12 +263,20 @@ public:
 		uint64_t idx = 0;
 		for (SeqRecord* p : pts) { p->id = idx++; store.add(p); }
 		store.seal();
+		{
+			std::vector<uint32_t> order;
+			store.number(order);
+			ranged_ = use_ranges && be_.set_order(order);
+		}
 		stamp("read_in_points");
 
 		std::vector<Cluster> part;
-		SeqRecord* last = store.take_first();
+		SeqRecord* last = take_first(store);
 		while (last != nullptr) accumulate(&last, store, part, sim);
 		stamp("accumulate");
+		if (profile)
+			log_ << "accumulate profile: steps " << prof.steps << " candidates " << prof.candidates << " closed " << prof.closed << " | window " << prof.window
+			     << " s, get_close " << prof.get_close << " s, mark+take " << prof.mark << " s, closest " << prof.closest << " s" << std::endl;
 		log_ << "Number of clusters before update: " << part.size() << std::endl;
 		std::vector<size_t> history;
 		for (int i = 0; i < iterations; i++) {
@@ -277,8 +330,52 @@ private:
 		while (!is_min) {
 			const uint64_t len = last->length;
 			const std::pair<LengthBins::Pos, LengthBins::Pos> bounds = store.range((uint64_t)(len * sim), (uint64_t)(len / sim));
+			if (ranged_) {
+				// the same window as below -- the (iend - istart) records from istart on, iend exclusive -- named by the
+				// sealed-store positions of its two ends: the backend holds the order and knows which positions are still there
+				const auto tq0 = std::chrono::steady_clock::now();
+				const BinCursor it{bounds.first.bin, bounds.first.at, &store.bins}, end{bounds.second.bin, bounds.second.at, &store.bins};
+				const int64_t trips = end.distance_from(it);
+				int64_t best = -1;
+				close_.clear();
+				is_min = true;
+				const auto tq1 = std::chrono::steady_clock::now();
+				if (trips > 0)
+					be_.get_close_range(last->point, store.bins.at(it.bin).at(it.at).fixed, store.bins.at(end.bin).at(end.at).fixed, close_, best, is_min);
+				const auto tq2 = std::chrono::steady_clock::now();
+				if (profile) {
+					prof.steps++;
+					prof.candidates += (uint64_t)std::max<int64_t>(trips, 0);
+					prof.window += std::chrono::duration<double>(tq1 - tq0).count();
+					prof.get_close += std::chrono::duration<double>(tq2 - tq1).count();
+				}
+				if (is_min) {
+					if (best < 0) {
+						*seed = take_first(store);
+					} else {
+						const std::pair<size_t, size_t> w = store.locate((uint32_t)best);
+						*seed = store.bins[w.first][w.second].rec;
+						store.erase(w.first, w.second);
+						be_.kill((uint64_t)best);
+					}
+					if (profile) prof.mark += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq2).count();
+				} else {
+					const size_t before = current.size();
+					store.take_positions(close_, current);
+					if (current.empty()) throw std::runtime_error("N cannot be 0, bad");
+					const auto tq3 = std::chrono::steady_clock::now();
+					last = current[(size_t)be_.closest(handles(current))];       // get_mean (:338-380)
+					if (profile) {
+						prof.closest += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq3).count();
+						prof.mark += std::chrono::duration<double>(tq3 - tq2).count();
+						prof.closed += current.size() - before;
+					}
+				}
+				continue;
+			}
 			// the window [iter(first), iter(second)): `i < iend` with an INCLUSIVE end position, walked the way OpenMP
 			// walks it: (iend - istart) iterations of istart + n
+			const auto tp0 = std::chrono::steady_clock::now();
 			window.clear();
 			where.clear();
 			BinCursor it{bounds.first.bin, bounds.first.at, &store.bins};
@@ -290,11 +387,13 @@ private:
 				if (n + 1 < trips) it.step();
 			}
 			int64_t pos = -1;
+			const auto tp1 = std::chrono::steady_clock::now();
 			be_.get_close(last->point, window, flags, pos, is_min);
+			const auto tp2 = std::chrono::steady_clock::now();
 			for (size_t j = 0; j < flags.size(); j++) if (flags[j]) store.bins[where[j].first][where[j].second].marked = true;
 			if (is_min) {
 				if (pos < 0) {
-					*seed = store.take_first();
+					*seed = take_first(store);
 				} else {
 					*seed = store.bins[where[(size_t)pos].first][where[(size_t)pos].second].rec;
 					store.erase(where[(size_t)pos].first, where[(size_t)pos].second);
@@ -302,9 +401,23 @@ private:
 				std::vector<SeqRecord*> none;
 				store.take_marked(bounds.first, bounds.second, none);
 			} else {
+				const size_t before = current.size();
 				store.take_marked(bounds.first, bounds.second, current);
 				if (current.empty()) throw std::runtime_error("N cannot be 0, bad");
+				const auto tp3 = std::chrono::steady_clock::now();
 				last = current[(size_t)be_.closest(handles(current))];       // get_mean (:338-380)
+				if (profile) {
+					prof.closest += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp3).count();
+					prof.mark += std::chrono::duration<double>(tp3 - tp2).count();
+					prof.closed += current.size() - before;
+				}
+			}
+			if (profile) {
+				prof.steps++;
+				prof.candidates += window.size();
+				prof.window += std::chrono::duration<double>(tp1 - tp0).count();
+				prof.get_close += std::chrono::duration<double>(tp2 - tp1).count();
+				if (is_min) prof.mark += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count();
 			}
 		}
 		Cluster cl;
@@ -387,8 +500,18 @@ private:
 		part.erase(std::remove_if(part.begin(), part.end(), [](const Cluster& c) { return c.merged_away; }), part.end());
 	}
 
+	// bvec::pop; a backend that keeps the window learns that the position is gone
+	SeqRecord* take_first(LengthBins& store) {
+		uint32_t fixed = 0;
+		SeqRecord* r = store.take_first(&fixed);
+		if (r && ranged_) be_.kill(fixed);
+		return r;
+	}
+
 	ClusterBackend& be_;
 	std::ostream& log_;
+	bool ranged_ = false;
+	std::vector<uint32_t> close_;
 	std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
 };
 

@@ -61,6 +61,22 @@ struct CallbackBackend : msc::ClusterBackend {
 		check(cb.merge_all(cb.user, centres.data(), centres.size(), delta, best.data()));
 		return true;
 	}
+	bool set_order(const std::vector<uint32_t>& order) override {
+		if (!cb.set_order || !cb.get_close_range || !cb.kill) return false;
+		check(cb.set_order(cb.user, order.data(), order.size()));
+		return true;
+	}
+	void get_close_range(uint32_t q, uint64_t first, uint64_t end, std::vector<uint32_t>& close, int64_t& best, bool& is_min) override {
+		close.assign((size_t)(end - first), 0);
+		uint64_t n = 0;
+		int im = 1;
+		best = -1;
+		check(cb.get_close_range(cb.user, q, first, end, close.data(), &n, &best, &im));
+		if (n > close.size()) throw std::runtime_error("get_close_range callback returned more positions than the range holds");
+		close.resize((size_t)n);
+		is_min = im != 0;
+	}
+	void kill(uint64_t pos) override { check(cb.kill(cb.user, pos)); }
 };
 
 void put_error(char* err, size_t cap, const std::string& msg) {

@@ -365,6 +365,67 @@ def make_training(name, seed, k, dtype, feat_flags, min_feat, max_feat, ident, n
     print("wrote", name, "train/test accuracy", atr, ate)
 
 
+def make_vectors_k13():
+    """BASELINE cfg4 at its stated parameters, printed by the reference itself: k = 13, uint64_t histograms (512 MiB each, 1.5 GiB while
+    Loader::get_point copies them: clutil/Loader.cpp:138-179), 20 kb sequences -- the five of tests' _cfg4_sequences() plus the relative
+    with a 70 000-base homopolymer run (one bin of 69 988 >= 2^16). Stored: the sequences, the bins that differ from the pseudocount,
+    mag / length / stddev / 1-mers, the 11 raw statistics of every ordered pair (predict/Feature.cpp:682-1518), Trainer::get_close and
+    filter under weights_cfg4_k13.txt for two cut-offs, mean + distance_d of three members. The model file is hand-written (the
+    reference cannot train at this size here: ~4 800 mutant histograms of 512 MiB); every number below it is the reference's."""
+    from golden_util import cfg4_sequences
+    k, dtype = 13, 64
+    seqs, mono = cfg4_sequences()
+    seqs = list(seqs) + [mono]
+    n = len(seqs)
+    ref_py.lib().ref_set_threads(8)
+    pts = [ref_py.Point(dtype, s, k) for s in seqs]
+    out = {"k": k, "dtype": dtype, "n": n, "seqs": np.array(seqs, dtype=object)}
+    metas = [p.meta() for p in pts]
+    out["mag"] = np.array([m["mag"] for m in metas], dtype=np.uint64)
+    out["length"] = np.array([m["length"] for m in metas], dtype=np.uint64)
+    out["stddev"] = np.array([m["stddev"] for m in metas])
+    out["one_mers"] = np.array([m["one_mers"] for m in metas], dtype=np.uint64)
+    for i, p in enumerate(pts):
+        ix, v = sparse(p.bins())
+        out["bins_idx_%d" % i] = ix
+        out["bins_val_%d" % i] = v
+    raw = np.zeros((n, n, len(FEATS)))
+    for i in range(n):
+        for j in range(n):
+            for f, (_, bit) in enumerate(FEATS):
+                raw[i, j, f] = ref_py.raw_feature(1 << bit, pts[i], pts[j])
+        print("k13 raw statistics of point", i, flush=True)
+    out["raw"] = raw
+    model = ref_py.Model(dtype, os.path.join(HERE, "weights_cfg4_k13.txt"))
+    ref_py.lib().ref_set_threads(1)          # the canonical arg-max order of Trainer::get_close (cluster/Trainer.cpp:41)
+    for ci, cutoff in enumerate((0.9, 0.6)):
+        gc_flags = np.zeros((n, n - 1), dtype=np.uint8)
+        gc_best = np.zeros((n, 3))
+        flt = np.zeros((n, n - 1), dtype=np.uint8)
+        for q in range(n):
+            cands = [pts[c] for c in range(n) if c != q]
+            f, bp, bs, im = model.get_close(cutoff, pts[q], cands)
+            gc_flags[q] = f
+            gc_best[q] = (bp, bs, im)
+            flt[q] = model.filter(cutoff, pts[q], cands)
+        out["get_close_flags_%d" % ci] = gc_flags
+        out["get_close_best_%d" % ci] = gc_best
+        out["filter_%d" % ci] = flt
+        print("k13 operators at cut-off", cutoff, flush=True)
+    out["cutoffs"] = np.array([0.9, 0.6])
+    sums = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            sums[i, j] = model.score(pts[i], pts[j])[2]
+    out["sums"] = sums
+    members = [0, 1, 2]
+    mean, d, near = ref_py.mean_nearest([pts[i] for i in members])
+    ix = np.nonzero(mean != 1.0)[0]
+    out.update(mean_members=np.array(members), mean_idx=ix.astype(np.uint32), mean_val=mean[ix], mean_dist=d, mean_nearest=near)
+    np.savez_compressed(os.path.join(HERE, "vectors_k13_u64.npz"), **out)
+    print("wrote vectors_k13_u64.npz", os.path.getsize(os.path.join(HERE, "vectors_k13_u64.npz")), "bytes")
+
+
 FAST_FLAGS = sum(1 << b for b in (2, 3, 5, 9, 13, 18, 21, 27, 28))
 SLOW_FLAGS = FAST_FLAGS | (1 << 7) | (1 << 29)
 
@@ -401,3 +462,4 @@ if __name__ == "__main__":
     make_vectors("vectors_k9_u32.npz", "weights_k9_u32.txt", 12, 8, 1000, 9, 32)
     make_vectors("vectors_k4_u8.npz", "weights_k5_u16.txt", 13, 10, 150, 4, 8)
     make_vectors("vectors_k6_u64.npz", "weights_k5_u16.txt", 14, 8, 1500, 6, 64)
+    make_vectors_k13()

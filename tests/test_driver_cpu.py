@@ -201,6 +201,30 @@ class OracleBackend:
         return self.o.merge(self.pred, self.cutoff, [self.centres[c] for c in centres], current, begin, last)
 
 
+class RangedOracleBackend(OracleBackend):
+    """the same with the window kept on the backend's side (set_order / get_close_range / kill: what msc_window does on the GPU)"""
+
+    def set_order(self, order):
+        self.order = order.astype(np.int64)
+        self.alive = np.ones(order.size, dtype=bool)
+        self.ranges = 0
+
+    def kill(self, pos):
+        assert self.alive[pos]
+        self.alive[pos] = False
+
+    def get_close_range(self, q, first, end):
+        self.ranges += 1
+        pos = first + np.flatnonzero(self.alive[first:end])
+        f, best, _, im = self.o.get_close(self.pred, self.cutoff, self.h[q], [self.h[i] for i in self.order[pos]])
+        close = pos[np.flatnonzero(f)]
+        self.alive[close] = False
+        return close, (int(pos[best]) if best >= 0 else -1), im
+
+    def get_close(self, q, window):
+        raise AssertionError("a backend that keeps the window is given ranges")
+
+
 def test_driver_logic_with_the_oracle_reproduces_cfg1(oracle, tmp_path):
     """BASELINE cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16) through libmsc_driver.so with the CPU oracle as the backend: the
     reference CLI's own cfg1.clstr byte for byte -- the clustering logic is right independently of any GPU (the GPU suite runs the
@@ -229,3 +253,28 @@ def test_driver_run_reports_a_failing_callback(oracle):
     hists = [oracle.hist(s_, 4, 16) for s_ in seqs]
     with pytest.raises(ValueError, match="backend failure"):
         _driver.run(Broken(oracle, hists, oracle.predictor(weights_text("weights_k5_u16.txt")), 0.9), hdrs, [h.length for h in hists], 0.9, log=os.devnull)
+
+
+@pytest.mark.parametrize("case", ["cfg1", "mixed"])
+def test_ranged_windows_give_the_same_clusters(oracle, tmp_path, case):
+    """The accumulate loop over a backend that keeps the length-sorted order itself (positions of the sealed store instead of a slot
+    list per step: msc_window on the GPU) writes the same bytes as the loop that rebuilds the window on the host -- cfg1 (the reference
+    CLI's own .clstr) and a mixed-length set whose windows are real length neighbourhoods (cluster/ClusterFactory.cpp:553-610)."""
+    if case == "cfg1":
+        seqs, hdrs = synth.families(20260001, 1000, 1000)
+        k, dt, w, sim = 5, 16, "weights_k5_u16.txt", 0.9
+    else:
+        seqs, hdrs = synth.families(777, 900, 1000, length_jitter=150)
+        k, dt, w, sim = 5, 16, "weights_k5_u16.txt", 0.9
+    oracle.lib().orc_set_threads(os.cpu_count() or 1)
+    hists = [oracle.hist(s_, k, dt) for s_ in seqs]
+    pred = oracle.predictor(weights_text(w))
+    lens = [h.length for h in hists]
+    a, b = str(tmp_path / "listed.clstr"), str(tmp_path / "ranged.clstr")
+    _driver.run(OracleBackend(oracle, hists, pred, sim), hdrs, lens, sim, output=a, log=os.devnull, batch_update=False)
+    rb = RangedOracleBackend(oracle, hists, pred, sim)
+    _driver.run(rb, hdrs, lens, sim, output=b, log=os.devnull, batch_update=False)
+    assert rb.ranges > 10 and not rb.alive.any()          # every point left the store through a range or a kill
+    assert open(a, "rb").read() == open(b, "rb").read()
+    if case == "cfg1":
+        assert open(b, "rb").read() == open(os.path.join(GOLDEN, "cfg1.clstr"), "rb").read()

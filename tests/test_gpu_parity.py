@@ -1607,3 +1607,42 @@ def test_bench_two_ranks_packed_exchange(tmp_path):
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["pairs_per_step"] == 16 * 8000
     assert line["roofline"]["candidates_per_launch"] == 4000 and line["value"] > 0
+
+
+@pytest.mark.parametrize("dtype,k,wts,sparse,n", [(16, 5, "weights_k5_u16.txt", False, 3000), (32, 9, "weights_k9_u32.txt", False, 400), (8, 9, "weights_k9_u8.txt", True, 2500),
+                                                  (16, 9, "weights_cfg5_k9.txt", True, 600)])
+def test_get_close_over_a_device_window_equals_get_close_over_a_slot_list(ctx, dtype, k, wts, sparse, n):
+    """msc_get_close_window (the accumulate loop's window kept on the device: cluster/ClusterFactory.cpp:553-610 over
+    cluster/Trainer.cpp:23-71) against msc_get_close on the slot list of the same alive positions: the same close set, arg-max and
+    is_min on random ranges while positions die (close ones by themselves, others through msc_window_kill), single-block and
+    multi-block compaction, a `--feat slow` model, dense and sparse sets."""
+    rng = np.random.default_rng(5 + k)
+    seqs, _ = synth.families(900 + k, n, 1000, family=25, length_jitter=120)
+    hs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=(sum(len(s) for s in seqs) + 4096) if sparse else 0)
+    for off in range(0, n, 1024):
+        hs.build(seqs[off:off + 1024], first_slot=off)
+    feat = api.Feature.from_text(ctx, weights_text(wts), 0)
+    trn = api.Trainer(ctx, feat, 0.9 if "cfg5" not in wts else 0.6)
+    order = rng.permutation(n).astype(np.uint32)
+    win = api.Window(ctx, hs, order)
+    alive = np.ones(n, dtype=bool)
+    assert win.alive() == n
+    for step in range(40):
+        q = int(rng.integers(n))
+        a, b = sorted(int(x) for x in rng.integers(0, n + 1, 2))
+        if step % 7 == 0:
+            a, b = 0, n          # the whole store: the multi-block compaction when n > 128 * 1024 positions... and the longest slot list
+        pos = a + np.flatnonzero(alive[a:b])
+        assert win.alive(a, b) == pos.size
+        flags, bp, bs, im = trn.get_close(hs, order[pos], hs, q) if pos.size else (np.zeros(0, dtype=np.uint8), -1, -1.0, True)
+        close, wbp, wbs, wim = win.get_close(trn, a, b, hs, q)
+        assert np.array_equal(close, pos[np.flatnonzero(flags)]), step
+        assert wbp == (int(pos[bp]) if bp >= 0 else -1) and wim == im and (bp < 0 or wbs == bs), step
+        alive[close] = False
+        extra = np.flatnonzero(alive)
+        if extra.size:
+            kill = rng.choice(extra, size=min(extra.size, int(rng.integers(1, 9))), replace=False)
+            win.kill(kill)
+            alive[kill] = False
+    with pytest.raises(api.MscError):
+        win.kill(np.flatnonzero(~alive)[:1])          # a position dies once
