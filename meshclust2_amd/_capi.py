@@ -92,10 +92,10 @@ PROTOTYPES = {
     "msc_train_class": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _int, _int, C.c_double, C.c_char_p, C.c_size_t, _vp, _vp]),
     "msc_hist_set_device_view": (_int, [_vp, C.POINTER(_vp), _pu64, C.POINTER(_vp), _pu64]),
     "msc_hist_import_done": (_int, [_vp, _vp, _u64, _u64]),
-    "msc_window_create": (_int, [_vp, _vp, _pu32, _u64, C.POINTER(_vp)]),
+    "msc_window_create": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "msc_window_destroy": (None, [_vp]),
     "msc_window_alive": (_u64, [_vp, _u64, _u64]),
-    "msc_window_kill": (_int, [_vp, _vp, _pu32, _u64]),
+    "msc_window_kill": (_int, [_vp, _vp, _vp, _u64]),
     "msc_get_close_window": (_int, [_vp, _vp, _dbl, _vp, _u64, _u64, _vp, _u64, C.POINTER(_pu32), _pu64, _pi64, _pdbl, C.POINTER(_int)]),
 }
 

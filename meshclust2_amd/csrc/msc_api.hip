@@ -126,6 +126,9 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
 	if (ctx->sparse_mean_batch) msc_hist_set_destroy(ctx->sparse_mean_batch);
 	if (ctx->batch_scratch) msc_hist_set_destroy(ctx->batch_scratch);
+	if (ctx->shard_gather) msc_hist_set_destroy(ctx->shard_gather);
+	release(ctx->shard_payload);
+	release(ctx->shard_hdrs);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
@@ -1299,7 +1302,7 @@ namespace {
 
 
 // integer range of the fast streaming kernels (pair_features.hip header); outside it the 64-bit kernel runs
-bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) {
+bool needs_wide_impl(const msc_hist_set* a, const msc_hist_set* b) {
 	const uint64_t mc = std::max(a->max_count, b->max_count), ms = std::max(a->max_sum, b->max_sum);
 	// a lane adds the |prefix difference| of its R bins of a tile in 32 bits; a prefix difference is at most the larger excess
 	// (k-mer) total, so R * excess must stay below 2^32 (only sequences of >= 2^26 k-mers can break it)
@@ -1359,6 +1362,7 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 
 // Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
 }  // namespace
+bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) { return needs_wide_impl(a, b); }
 int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const double t_call = g_profile_calls ? now_s() : 0;
 	int r = validate_pair(ctx, rq.cands, rq.qset, rq.q_slot, rq.cand_slots, rq.dev_slots ? 0 : rq.m);
@@ -2231,21 +2235,17 @@ static int update_centres_one_by_one(msc_ctx* ctx, const msc_model* model, doubl
 // (scatter-add of the members' excesses into one 32-bit column accumulator per centre, swept in index order: the kernels of
 // mean_nearest_sparse with a centre dimension), then distance_d of every survivor to the mean of its centre -> ctx->dist[pair].
 // segs[c] = {q_slot = c, first, m} over `members` (device copies are made here), pair_seg[j] = centre of member j.
-static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, const std::vector<MscBatchSeg>& segs, const std::vector<uint32_t>& pair_seg,
-                                      const std::vector<uint32_t>& members, uint32_t nc) {
-	const MscLayout& L = pts->L;
-	const uint64_t P2 = members.size();
+// (a) the accumulators: one 32-bit column array of 4^k bins per list, zero between calls (the write sweep re-zeroes what it read), and
+// for large k a bit per 16 bins and list that the scatter sets and the sweeps follow
+int sparse_acc_prepare(msc_ctx* ctx, const MscLayout& L, uint32_t nc, uint32_t** touched_out) {
 	int r;
-	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);
 	const uint64_t chunk_bins = L.nbins / n_chunks;
-	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
-	// accumulators: zero on allocation, left zero by the write kernel
 	const size_t acc_bytes = (size_t)nc * L.nbins * sizeof(uint32_t);
 	if (acc_bytes > ctx->sp_acc_batch.cap) {
 		if ((r = ensure(ctx, ctx->sp_acc_batch, acc_bytes))) return r;
 		HIP_TRY(ctx, hipMemsetAsync(ctx->sp_acc_batch.p, 0, ctx->sp_acc_batch.cap, ctx->stream));
 	}
-	// large k: the sweeps visit touched 64-byte lines only (a bit per 16 bins and centre, set by the scatter, cleared by the write sweep)
 	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
 	const bool grouped = !no_groups && L.nbins >= (1ull << 22) && chunk_bins % 512 == 0;
 	if (grouped) {
@@ -2255,21 +2255,38 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 			HIP_TRY(ctx, hipMemsetAsync(ctx->sp_touched.p, 0, ctx->sp_touched.cap, ctx->stream));
 		}
 	}
-	uint32_t* touched = grouped ? (uint32_t*)ctx->sp_touched.p : nullptr;
-	std::vector<uint32_t> m_of(nc);
-	for (uint32_t c = 0; c < nc; c++) m_of[c] = segs[c].m;
-	if ((r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) ||
-	    (r = ensure(ctx, ctx->qslots, nc * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_counts, (size_t)nc * n_chunks * 3 * sizeof(uint64_t))) ||
-	    (r = ensure(ctx, ctx->sp_chunk_off, (size_t)nc * n_chunks * sizeof(uint64_t))) || (r = ensure(ctx, ctx->sp_chunk_cum, (size_t)nc * n_chunks * sizeof(uint64_t))) ||
-	    (r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->partials, P2 * sizeof(MscPartial))) || (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
-		return r;
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, m_of.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, pts->ent, pts->hdr, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)P2, L.nbins,
+	*touched_out = grouped ? (uint32_t*)ctx->sp_touched.p : nullptr;
+	return MSC_OK;
+}
+
+// (b) the excesses of P lists of `src` (slots[j] belongs to accumulator seg[j]) are added in
+int sparse_acc_scatter(msc_ctx* ctx, const msc_hist_set* src, const uint32_t* slots, const uint32_t* seg, uint64_t P, uint32_t* touched) {
+	if (P == 0) return MSC_OK;
+	int r;
+	if ((r = ensure(ctx, ctx->slots, P * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, P * sizeof(uint32_t)))) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, slots, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, seg, P * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, src->ent, src->hdr, (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, (uint32_t)P, src->L.nbins,
 	                                             (uint32_t*)ctx->sp_acc_batch.p, touched));
-	HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, pts->dtype, (const uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc,
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (slots / seg are the caller's, and ctx->slots is reused below)
+	return MSC_OK;
+}
+
+// (c) the accumulators of nc lists are swept into the sparse slots 0 .. nc-1 of ctx->sparse_mean_batch: list c's rounded mean over
+// m_of[c] members (value_bits = the set's bin type), or -- m_of[c] = 1 and value_bits = 32 -- its summed excesses + 1, the column sums
+// a rank sends to the others (msc_colsum_partial). floor_sum_out[c] = sum of floor(mean) (nullable). The accumulators are zero again.
+int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const uint32_t* m_of, int value_bits, uint32_t* touched, uint64_t* floor_sum_out) {
+	const MscLayout& L = pts->L;
+	int r;
+	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	const uint64_t chunk_bins = L.nbins / n_chunks;
+	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
+	if ((r = ensure(ctx, ctx->qslots, nc * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_counts, (size_t)nc * n_chunks * 3 * sizeof(uint64_t))) ||
+	    (r = ensure(ctx, ctx->sp_chunk_off, (size_t)nc * n_chunks * sizeof(uint64_t))) || (r = ensure(ctx, ctx->sp_chunk_cum, (size_t)nc * n_chunks * sizeof(uint64_t))) ||
+	    (r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))))
+		return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, m_of, nc * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, value_bits, (const uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc,
 	                                                (const uint32_t*)ctx->qslots.p, (uint64_t*)ctx->sp_counts.p, touched));
 	std::vector<uint64_t> counts((size_t)nc * n_chunks * 3);
 	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2301,6 +2318,7 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 		sc[c].mag = sc[c].sum;
 		sc[c].length = 1;
 		floor_sum[c] = L.nbins + fl;
+		if (floor_sum_out) floor_sum_out[c] = floor_sum[c];
 	}
 	msc_hist_set*& ms = ctx->sparse_mean_batch;
 	if (!ms || ms->k != pts->k || ms->dtype != pts->dtype || ms->capacity < nc || ms->ent_capacity < used + 1) {
@@ -2317,16 +2335,45 @@ static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, con
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->floor_sum.p, floor_sum.data(), nc * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), cb.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, pts->dtype, (uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc, (const uint32_t*)ctx->qslots.p,
+	HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, value_bits, (uint32_t*)ctx->sp_acc_batch.p, L.nbins, n_chunks, chunk_bins, nc, (const uint32_t*)ctx->qslots.p,
 	                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, ms->ent, ms->cum, touched));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // hdr, sc, floor_sum, off, cb live on this frame
+	return MSC_OK;
+}
+
+// (d) distance_d of every member to the rounded mean of ITS list (slot segs[].q_slot of ctx->sparse_mean_batch) -> ctx->dist[pair]
+int sparse_distances_to_means(msc_ctx* ctx, const msc_hist_set* pts, const std::vector<MscBatchSeg>& segs, const std::vector<uint32_t>& pair_seg,
+                              const std::vector<uint32_t>& members, uint32_t nc) {
+	const MscLayout& L = pts->L;
+	const uint64_t P2 = members.size();
+	msc_hist_set* ms = ctx->sparse_mean_batch;
+	int r;
+	if ((r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->segs, nc * sizeof(MscBatchSeg))) ||
+	    (r = ensure(ctx, ctx->partials, P2 * sizeof(MscPartial))) || (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
+		return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
 	// survivors against the rounded mean of their own centre: only the |p - r| reduction of the merge kernel is used
 	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, pts->ent, pts->cum, pts->hdr, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P2,
 	                                             ms->ent, ms->cum, ms->hdr, L.nbins, 0, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p,
 	                                             (MscPartial*)ctx->partials.p, MSC_ORDER_CAND_FIRST, ctx->num_cus));
 	HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, 1, (uint32_t)P2, pts->scalars, pts->scalar_stride, (const uint32_t*)ctx->slots.p,
 	                                       (const uint32_t*)ctx->pair_seg.p, ms->scalars, ms->scalar_stride, (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // hdr, sc, floor_sum, off, cb live on this frame
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return MSC_OK;
+}
+
+static int sparse_means_and_distances(msc_ctx* ctx, const msc_hist_set* pts, const std::vector<MscBatchSeg>& segs, const std::vector<uint32_t>& pair_seg,
+                                      const std::vector<uint32_t>& members, uint32_t nc) {
+	int r;
+	uint32_t* touched = nullptr;
+	if ((r = sparse_acc_prepare(ctx, pts->L, nc, &touched))) return r;
+	if ((r = sparse_acc_scatter(ctx, pts, members.data(), pair_seg.data(), members.size(), touched))) return r;
+	std::vector<uint32_t> m_of(nc);
+	for (uint32_t c = 0; c < nc; c++) m_of[c] = segs[c].m;
+	if ((r = sparse_acc_sweep(ctx, pts, nc, m_of.data(), pts->dtype, touched, nullptr))) return r;
+	return sparse_distances_to_means(ctx, pts, segs, pair_seg, members, nc);
 }
 
 // The two divergence sums of a pair list inside the batched entry points: which lists to merge (the sets themselves, or the sparse
@@ -2356,12 +2403,14 @@ static int batch_div_pass(msc_ctx* ctx, const msc_hist_set* cands, const msc_his
 	return MSC_OK;
 }
 
-extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
-                                  uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
-                                  uint64_t* n_kept) {
+// keep_only != nullptr: Trainer::filter of every list and nothing else -- keep_only[i] = 1 iff pt_slots[i] survives the filter of its
+// centre (msc_filter_batch: the rank-local half of a sharded update round, whose means need the other ranks' column sums)
+static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                               uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
+                               uint64_t* n_kept, uint8_t* keep_only) {
 	if (!ctx || !model || model->ctx != ctx || !centres || !pts || centres->ctx != ctx || pts->ctx != ctx) return MSC_ERR_INVALID_ARG;
 	if (n_centres == 0) return MSC_OK;
-	if (!centre_slots || !offsets || !nearest_pos) return MSC_ERR_INVALID_ARG;
+	if (!centre_slots || !offsets || (!nearest_pos && !keep_only)) return MSC_ERR_INVALID_ARG;
 	if (centres->k != pts->k || centres->dtype != pts->dtype) return fail(ctx, MSC_ERR_INVALID_ARG, "sets differ in k or dtype");
 	const uint64_t total = offsets[n_centres];
 	if (total && !pt_slots) return MSC_ERR_INVALID_ARG;
@@ -2376,9 +2425,18 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	// sparse sets (both): the pair-list form of the merge-path kernel takes the place of k_pair_tiles_batch, and the rounded means of a
 	// chunk of centres are built as sparse slots by the scatter / count / write kernels with a centre dimension (32-bit range)
 	const bool sp = pts->sparse && centres->sparse;
+	auto one_by_one = [&]() -> int {
+		if (!keep_only) return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
+		for (uint64_t c = 0; c < n_centres; c++) {
+			uint64_t n = 0;
+			const int rr = msc_filter(ctx, model, cutoff, centres, centre_slots[c], pts, pt_slots + offsets[c], offsets[c + 1] - offsets[c], keep_only + offsets[c], &n);
+			if (rr) return rr;
+		}
+		return MSC_OK;
+	};
 	if (no_batch || (pts->sparse != centres->sparse) || (sp && std::max(pts->max_count, centres->max_count) >= 65536) || (want & MSC_FEAT_GROUPS) ||
 	    needs_wide(pts, centres))
-		return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
+		return one_by_one();
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const MscLayout& L = pts->L;
 	int r;
@@ -2388,7 +2446,7 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 	if (want_div) {
 		bool ok = false;
 		if ((r = batch_div_lists(ctx, pts, centres, centre_slots[0], &c_sp, &q_sp, &ok))) return r;
-		if (!ok) return update_centres_one_by_one(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept);
+		if (!ok) return one_by_one();
 	}
 	// lengths of every centre slot in one strided copy (Trainer::filter's window is relative to the centre's length)
 	std::vector<uint64_t> clen(centres->capacity);
@@ -2493,6 +2551,11 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 			if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
 			if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
 		}
+		if (keep_only) {
+			if (P) memcpy(keep_only + base, keep.data(), P);
+			c0 = c1;
+			continue;
+		}
 		// ---- 2. survivors per centre
 		members.clear();
 		where.clear();
@@ -2555,6 +2618,19 @@ extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double c
 		c0 = c1;
 	}
 	return MSC_OK;
+}
+
+extern "C" int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                                  uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, int64_t* nearest_pos,
+                                  uint64_t* n_kept) {
+	if (!nearest_pos && n_centres) return MSC_ERR_INVALID_ARG;
+	return update_centres_impl(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nearest_pos, n_kept, nullptr);
+}
+
+extern "C" int msc_filter_batch(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n_centres,
+                                const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, uint8_t* keep) {
+	if (n_centres && offsets && offsets[n_centres] && !keep) return MSC_ERR_INVALID_ARG;
+	return update_centres_impl(ctx, model, cutoff, centres, centre_slots, n_centres, pts, pt_slots, offsets, nullptr, nullptr, keep);
 }
 
 // Trainer::merge for EVERY centre of the serial merge loop in one launch (cluster/ClusterFactory.cpp:383-401 calls

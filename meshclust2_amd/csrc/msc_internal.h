@@ -235,6 +235,10 @@ hipError_t msc_launch_pair_tiles_batch(hipStream_t st, const MscLayout& L, int d
                                        int order);
 hipError_t msc_launch_colsum_batch(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots, const MscBatchSeg* segs,
                                    uint32_t n_segs, void* rounded_out, uint64_t* floor_sum_out);
+hipError_t msc_launch_colsum_sums(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots, const MscBatchSeg* segs, uint32_t n_segs,
+                                  uint64_t* sums_out);
+hipError_t msc_launch_mean_from_sums(hipStream_t st, const MscLayout& L, int dtype, const uint64_t* sums, const uint64_t* m_total, uint32_t n_segs, void* rounded_out,
+                                     uint64_t* floor_sum_out);
 hipError_t msc_launch_distance_batch(hipStream_t st, const MscPartial* partials, uint32_t S, uint32_t n, const uint8_t* scalars, uint64_t scalar_stride,
                                      const uint32_t* member_slots, const uint32_t* pair_seg, const uint8_t* r_scalars, uint64_t r_stride, const uint64_t* floor_sum,
                                      double* dist_out);

@@ -38,6 +38,9 @@ struct msc_ctx {
 	msc_hist_set* batch_scratch = nullptr;     // rounded means of one chunk of centres (msc_update_centres)
 	DevBuf segs, pair_seg, dist;
 	uint64_t sp_acc_bins = 0;
+	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
+	DevBuf shard_payload, shard_hdrs;
+	msc_hist_set* shard_gather = nullptr;
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the
 	// launches, and waiting for the stream (printed by msc_destroy)
 	double prof_prep = 0, prof_issue = 0, prof_wait = 0;
@@ -106,6 +109,14 @@ int refresh_bounds(msc_ctx* ctx, msc_hist_set* s, uint64_t first, uint64_t n);
 void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len);
 int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len);
 int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out);
+
+// the stages of the batched sparse mean (msc_api.hip; msc_shard.hip puts an exchange between them)
+int sparse_acc_prepare(msc_ctx* ctx, const MscLayout& L, uint32_t nc, uint32_t** touched_out);
+int sparse_acc_scatter(msc_ctx* ctx, const msc_hist_set* src, const uint32_t* slots, const uint32_t* seg, uint64_t P, uint32_t* touched);
+int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const uint32_t* m_of, int value_bits, uint32_t* touched, uint64_t* floor_sum_out);
+int sparse_distances_to_means(msc_ctx* ctx, const msc_hist_set* pts, const std::vector<MscBatchSeg>& segs, const std::vector<uint32_t>& pair_seg,
+                              const std::vector<uint32_t>& members, uint32_t nc);
+bool needs_wide(const msc_hist_set* a, const msc_hist_set* b);
 
 // one 1 x M scoring pass (msc_api.hip): streaming kernel -> epilogue -> optional reduce
 struct ScoreRequest {

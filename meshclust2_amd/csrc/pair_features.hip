@@ -1411,6 +1411,74 @@ __global__ void __launch_bounds__(kBlock) k_colsum_batch(const T* __restrict__ b
 	if ((threadIdx.x & 63) == 0 && fl) atomicAdd(floor_sum + si, fl);
 }
 
+// The two halves of k_colsum_batch for a mean whose members are spread over several GPUs ("all-reduce (sum) of partial
+// column sums"): k_colsum_sums leaves the exact integer column sums of each segment's members in sums[si][padded] (what the ranks
+// add up), k_mean_from_sums turns the added-up sums of m_total[si] members into the rounded mean slot and its floor sum -- the same
+// division, rounding and floor as k_colsum_batch, so a sharded get_mean is the single-GPU one bit for bit.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_colsum_sums(const T* __restrict__ bins, uint64_t slot_elems, const uint32_t* __restrict__ member_slots,
+                                                        const MscBatchSeg* __restrict__ segs, uint32_t cpb, uint64_t padded, unsigned long long* __restrict__ sums) {
+	constexpr uint32_t E = 16 / sizeof(T);
+	const uint32_t si = blockIdx.x / cpb;
+	const MscBatchSeg seg = segs[si];
+	const uint64_t chunk = (uint64_t)(blockIdx.x % cpb) * blockDim.x + threadIdx.x;
+	if (chunk * E >= padded) return;
+	uint64_t acc[E];
+#pragma unroll
+	for (uint32_t j = 0; j < E; j++) acc[j] = 0;
+	constexpr uint32_t U = 8;          // eight members' loads in flight per thread (see k_colsum)
+	uint32_t i = 0;
+	for (; i + U <= seg.m; i += U) {
+		u32x4 v[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++)
+			v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bins + (uint64_t)member_slots[seg.first + i + u] * slot_elems + chunk * E));
+#pragma unroll
+		for (uint32_t u = 0; u < U; u++) {
+			const T* e = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+			for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+		}
+	}
+	for (; i < seg.m; i++) {
+		const uint4 v = *reinterpret_cast<const uint4*>(bins + (uint64_t)member_slots[seg.first + i] * slot_elems + chunk * E);
+		const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) acc[j] += e[j];
+	}
+#pragma unroll
+	for (uint32_t j = 0; j < E; j++) sums[(uint64_t)si * padded + chunk * E + j] = acc[j];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_mean_from_sums(const unsigned long long* __restrict__ sums, const unsigned long long* __restrict__ m_total, uint32_t cpb,
+                                                           uint64_t padded, uint64_t nbins, uint32_t R, uint64_t slot_elems, T* __restrict__ rounded,
+                                                           unsigned long long* __restrict__ floor_sum) {
+	constexpr uint32_t E = 16 / sizeof(T);
+	const uint32_t si = blockIdx.x / cpb;
+	const unsigned long long m = m_total[si];
+	if (m == 0) return;
+	const uint64_t chunk = (uint64_t)(blockIdx.x % cpb) * blockDim.x + threadIdx.x;
+	unsigned long long fl = 0;
+	if (chunk * E < padded) {
+		const uint32_t tile_bins = 64 * R;
+		const uint64_t tile = (chunk * E) / tile_bins;
+		const uint32_t in_tile = (uint32_t)((chunk * E) % tile_bins);
+		const uint32_t t = in_tile / (64 * E), lane = (in_tile % (64 * E)) / E;
+		T rv[E];
+#pragma unroll
+		for (uint32_t j = 0; j < E; j++) {
+			const uint64_t logical = tile * tile_bins + (uint64_t)lane * R + t * E + j;
+			const double mean = (double)sums[(uint64_t)si * padded + chunk * E + j] / (double)m;
+			rv[j] = (T)round(mean);
+			if (logical < nbins) fl += (unsigned long long)floor(mean);
+		}
+		*reinterpret_cast<uint4*>(rounded + (uint64_t)si * slot_elems + chunk * E) = *reinterpret_cast<const uint4*>(rv);
+	}
+	fl = shfl_sum_u64(fl);
+	if ((threadIdx.x & 63) == 0 && fl) atomicAdd(floor_sum + si, fl);
+}
+
 // distance_d of every member to the rounded mean of ITS segment (see k_distance_d); the per-segment arg-min is left to the host
 __global__ void __launch_bounds__(kBlock) k_distance_batch(const MscPartial* __restrict__ partials, uint32_t S, uint32_t n, const uint8_t* __restrict__ scalars,
                                                            uint64_t scalar_stride, const uint32_t* __restrict__ member_slots, const uint32_t* __restrict__ pair_seg,
@@ -1908,6 +1976,41 @@ hipError_t msc_launch_colsum_batch(hipStream_t st, const MscLayout& L, int dtype
 	case 16: k_colsum_batch<uint16_t><<<grid, dim3(kBlock), 0, st>>>((const uint16_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint16_t*)rounded_out, fs); break;
 	case 32: k_colsum_batch<uint32_t><<<grid, dim3(kBlock), 0, st>>>((const uint32_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint32_t*)rounded_out, fs); break;
 	default: k_colsum_batch<uint64_t><<<grid, dim3(kBlock), 0, st>>>((const uint64_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, L.nbins, L.R, (uint64_t*)rounded_out, fs); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_colsum_sums(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint32_t* member_slots, const MscBatchSeg* segs, uint32_t n_segs,
+                                  uint64_t* sums_out) {
+	if (n_segs == 0) return hipSuccess;
+	const uint64_t chunks = L.padded_bins / L.E;
+	const uint32_t cpb = (uint32_t)((chunks + kBlock - 1) / kBlock);
+	const dim3 grid(n_segs * cpb);
+	switch (dtype) {
+	case 8: k_colsum_sums<uint8_t><<<grid, dim3(kBlock), 0, st>>>((const uint8_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, (unsigned long long*)sums_out); break;
+	case 16: k_colsum_sums<uint16_t><<<grid, dim3(kBlock), 0, st>>>((const uint16_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, (unsigned long long*)sums_out); break;
+	case 32: k_colsum_sums<uint32_t><<<grid, dim3(kBlock), 0, st>>>((const uint32_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, (unsigned long long*)sums_out); break;
+	default: k_colsum_sums<uint64_t><<<grid, dim3(kBlock), 0, st>>>((const uint64_t*)bins, L.padded_bins, member_slots, segs, cpb, L.padded_bins, (unsigned long long*)sums_out); break;
+	}
+	return hipGetLastError();
+}
+// sums[n_segs][padded] of m_total[si] members -> rounded mean slots 0 .. n_segs-1 behind rounded_out and floor_sum_out[si] (zeroed here)
+hipError_t msc_launch_mean_from_sums(hipStream_t st, const MscLayout& L, int dtype, const uint64_t* sums, const uint64_t* m_total, uint32_t n_segs, void* rounded_out,
+                                     uint64_t* floor_sum_out) {
+	if (n_segs == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(floor_sum_out, 0, (size_t)n_segs * sizeof(uint64_t), st);
+	if (e != hipSuccess) return e;
+	const uint64_t chunks = L.padded_bins / L.E;
+	const uint32_t cpb = (uint32_t)((chunks + kBlock - 1) / kBlock);
+	const dim3 grid(n_segs * cpb);
+	const unsigned long long* su = (const unsigned long long*)sums;
+	const unsigned long long* mt = (const unsigned long long*)m_total;
+	unsigned long long* fs = (unsigned long long*)floor_sum_out;
+	switch (dtype) {
+	case 8: k_mean_from_sums<uint8_t><<<grid, dim3(kBlock), 0, st>>>(su, mt, cpb, L.padded_bins, L.nbins, L.R, L.padded_bins, (uint8_t*)rounded_out, fs); break;
+	case 16: k_mean_from_sums<uint16_t><<<grid, dim3(kBlock), 0, st>>>(su, mt, cpb, L.padded_bins, L.nbins, L.R, L.padded_bins, (uint16_t*)rounded_out, fs); break;
+	case 32: k_mean_from_sums<uint32_t><<<grid, dim3(kBlock), 0, st>>>(su, mt, cpb, L.padded_bins, L.nbins, L.R, L.padded_bins, (uint32_t*)rounded_out, fs); break;
+	default: k_mean_from_sums<uint64_t><<<grid, dim3(kBlock), 0, st>>>(su, mt, cpb, L.padded_bins, L.nbins, L.R, L.padded_bins, (uint64_t*)rounded_out, fs); break;
 	}
 	return hipGetLastError();
 }

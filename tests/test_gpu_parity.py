@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from golden_util import EXACT, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors, weights_text
+from golden_util import EXACT, FEATS, VECTOR_SETS, cfg4_sequences, dense_bins, kat, load_vectors, weights_text
 from meshclust2_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -798,40 +798,8 @@ def test_sparse_k13_against_the_oracle(ctx, oracle):
         oracle.lib().orc_hist_free(h)
 
 
-CFG4_WEIGHTS = """k: 13
-mode: 1
-max_features: 4
-ID: 0.9
-Datatype: uint64_t
-feature_set: 941892268
-
-n_combos: 4
--0.35
-0 8192 1.9
-1 537133056 -0.8
-3 268435464 0.45
-2 2097156 -0.6
-
-n_singles: 7
-8192 0.9995 1
-536870912 0 0.0002
-262144 0 400000000000
-268435456 0.5 1
-8 0 600
-2097152 0 4000
-4 0 90000
-"""
-
-
-def _cfg4_sequences():
-    """BASELINE cfg4's shape: 20 kb sequences at k = 13: three relatives (3 % substitutions + indels), one stranger, one relative
-    cut to 17 kb (the length window of get_close matters) -- and, for the wide route, a relative carrying a 70 000-base
-    homopolymer run: ONE bin of 69 988 > 2^16, which the 32-bit merge-path kernel cannot hold."""
-    fam, _ = synth.families(4413, 3, 20000, family=3)
-    other, _ = synth.families(4414, 1, 20000, family=1)
-    seqs = list(fam) + list(other) + [fam[1][:17000]]
-    mono = fam[2][:9000] + b"A" * 70000 + fam[2][9000:]
-    return seqs, mono
+CFG4_WEIGHTS = weights_text("weights_cfg4_k13.txt")      # hand-written model (the reference cannot train at this size here)
+_cfg4_sequences = cfg4_sequences
 
 
 def _divergence_longdouble(name, a, b):
@@ -921,6 +889,52 @@ def test_cfg4_k13_u64_20kb_against_the_oracle(ctx, oracle, route):
         assert pos == opos and np.allclose(d, od, rtol=1e-12, atol=0)
     for h in oh:
         oracle.lib().orc_hist_free(h)
+
+
+def test_cfg4_k13_u64_values_printed_by_the_reference(ctx):
+    """BASELINE cfg4's parameters against the REFERENCE's own numbers, not only its restatement: tests/golden/vectors_k13_u64.npz was
+    printed by /root/reference code (gen_golden.make_vectors_k13: Loader::get_point at k = 13 / uint64_t -- 512 MiB tables --, the 11
+    statistics of predict/Feature.cpp:682-1518 for every ordered pair of six 17-90 kb sequences, Trainer::get_close / filter under
+    weights_cfg4_k13.txt, get_mean + distance_d). Counts below 2^16 take the merge-path kernel, the homopolymer sequence (one bin of
+    69 988) the 64-bit lane-per-sub-range kernel. Integer statistics: equal; FP64 sums of 67 M terms: 1e-7 (the reference's own rounding, see
+    test_cfg4_k13_u64_20kb_against_the_oracle), decisions and arg-max: equal."""
+    v = load_vectors("vectors_k13_u64.npz")
+    k, dtype, n = int(v["k"]), int(v["dtype"]), int(v["n"])
+    seqs = [bytes(s_) for s_ in v["seqs"]]
+    hs = api.HistogramSet(ctx, k, dtype, n + 1, sparse_entries=sum(len(s_) for s_ in seqs) + 4096)
+    hs.build(seqs)
+    for i in range(n):
+        inf = hs.info(i)
+        assert (inf["mag"], inf["length"], inf["one_mers"]) == (int(v["mag"][i]), int(v["length"][i]), v["one_mers"][i].tolist()), i
+        assert inf["stddev"] == pytest.approx(float(v["stddev"][i]), rel=1e-8)
+        assert hs.entries(i) == v["bins_idx_%d" % i].size
+    cands = np.arange(n, dtype=np.uint32)
+    for q in range(n):
+        raw = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK | api.FEAT["jefferey_divergence"] | api.FEAT["jensen_shannon"], api.ORDER_CAND_FIRST)
+        for c in range(n):
+            for col, (f, (name, bit)) in zip(raw[c], enumerate(FEATS)):
+                exp = v["raw"][c, q, f]          # f(first = candidate, second = query)
+                if name in EXACT and name != "kulczynski2":
+                    assert col == exp, (name, c, q)
+                elif name in ("pearson", "jefferey_divergence", "jensen_shannon"):
+                    assert col == pytest.approx(exp, rel=1e-7, abs=1e-13), (name, c, q)
+                else:
+                    assert col == pytest.approx(exp, rel=1e-9, abs=1e-13), (name, c, q)
+    feat = api.Feature.from_text(ctx, weights_text("weights_cfg4_k13.txt"), 0)
+    for ci, cutoff in enumerate(v["cutoffs"]):
+        trn = api.Trainer(ctx, feat, float(cutoff))
+        for q in range(n):
+            w = np.array([c for c in range(n) if c != q], dtype=np.uint32)
+            flags, bp, bs, im = trn.get_close(hs, w, hs, q)
+            gbp, gbs, gim = v["get_close_best_%d" % ci][q]
+            assert np.array_equal(flags, v["get_close_flags_%d" % ci][q]) and (bp, im) == (int(gbp), bool(gim)), (cutoff, q)
+            assert bs == pytest.approx(gbs, rel=1e-7), (cutoff, q)
+            assert np.array_equal(trn.filter(hs, q, hs, w), v["filter_%d" % ci][q]), (cutoff, q)
+    r = feat.compute(hs, cands, hs, 1)
+    assert np.allclose(r["sum"], v["sums"][:, 1], rtol=1e-7, atol=1e-9)
+    pos, d, _ = api.mean_nearest(ctx, hs, v["mean_members"].astype(np.uint32))
+    # (distance_d = 10000 (1 - frac^2) with frac = 0.99998: 11 digits survive the subtraction)
+    assert pos == int(v["mean_nearest"]) and np.allclose(d, v["mean_dist"], rtol=1e-9, atol=0)
 
 
 @pytest.mark.parametrize("layout", ["dense", "sparse"])

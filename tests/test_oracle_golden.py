@@ -3,7 +3,7 @@ real reference (tests/golden/gen_golden.py). Runs anywhere (no GPU, no /root/ref
 import numpy as np
 import pytest
 
-from golden_util import EXACT, FEATS, VECTOR_SETS, dense_bins, kat, load_vectors, weights_text
+from golden_util import EXACT, FEATS, VECTOR_SETS, cfg4_sequences, dense_bins, kat, load_vectors, weights_text
 
 
 def test_appendix_d_known_answers(oracle):
@@ -81,3 +81,47 @@ def test_weights_file_round_trip(oracle):
         p = oracle.predictor(text)
         again = oracle.predictor_format(p)
         assert again.split() == text.split()      # same tokens (whitespace-insensitive like `in >> tok`)
+
+
+def test_k13_u64_vectors_printed_by_the_reference(oracle):
+    """BASELINE cfg4's parameters (k = 13, uint64_t, 20 kb): vectors_k13_u64.npz holds what the REFERENCE ITSELF computed for six
+    such sequences (gen_golden.make_vectors_k13: Loader::get_point, the 11 statistics of predict/Feature.cpp:682-1518, Trainer::get_close /
+    filter, get_mean) -- the oracle restatement is held to it here, the GPU in test_cfg4_k13_u64_20kb_against_the_oracle. A subset of the
+    pairs (each statistic walks 67 M bins on one core); tolerances: the reference's own sequential FP64 sums of 67 M terms."""
+    v = load_vectors("vectors_k13_u64.npz")
+    k, dt, n = int(v["k"]), int(v["dtype"]), int(v["n"])
+    assert (k, dt, n) == (13, 64, 6)
+    seqs, mono = cfg4_sequences()
+    assert [bytes(s) for s in v["seqs"]] == [bytes(s) for s in list(seqs) + [mono]]
+    oracle.lib().orc_set_threads(8)
+    hs = [oracle.hist(bytes(s), k, dt) for s in v["seqs"]]
+    for i, h in enumerate(hs):
+        a = h.array()
+        idx = np.flatnonzero(a != 1)
+        assert np.array_equal(idx, v["bins_idx_%d" % i]) and np.array_equal(a[idx], v["bins_val_%d" % i]), i
+        assert (h.mag, h.length) == (int(v["mag"][i]), int(v["length"][i])) and list(h.one_mers) == v["one_mers"][i].tolist()
+        assert h.stddev == pytest.approx(float(v["stddev"][i]), rel=1e-12)
+    assert int(v["bins_val_5"].max()) >= 1 << 16          # the homopolymer run: one count beyond 16 bits
+    for i, j in ((0, 1), (1, 0), (0, 3), (5, 0), (4, 1)):
+        for f, (name, bit) in enumerate(FEATS):
+            val = oracle.raw_feature(1 << bit, hs[i], hs[j])
+            if name in EXACT:
+                assert val == v["raw"][i, j, f], (name, i, j)
+            else:          # same bins, same order of summation, another compiler's contraction of a*b+c: 67 M terms
+                assert val == pytest.approx(v["raw"][i, j, f], rel=1e-9, abs=1e-15), (name, i, j)
+    pred = oracle.predictor(weights_text("weights_cfg4_k13.txt"))
+    for ci, cutoff in enumerate(v["cutoffs"]):
+        q = 0
+        cands = [hs[c] for c in range(n) if c != q]
+        f, bp, bs, im = oracle.get_close(pred, float(cutoff), hs[q], cands)
+        gbp, gbs, gim = v["get_close_best_%d" % ci][q]
+        assert np.array_equal(f, v["get_close_flags_%d" % ci][q]) and (bp, im) == (int(gbp), bool(gim)) and bs == pytest.approx(gbs, rel=1e-9)
+        assert np.array_equal(oracle.filter_(pred, float(cutoff), hs[q], cands), v["filter_%d" % ci][q])
+    mean, d, near = oracle.mean_nearest([hs[i] for i in v["mean_members"]])
+    ix = np.flatnonzero(mean != 1.0)
+    assert np.array_equal(ix, v["mean_idx"]) and np.array_equal(mean[ix], v["mean_val"])
+    # distance_d = 10000 (1 - frac^2) with frac = 0.99998: the subtraction leaves 11 digits of the FP64 ratio (and the reference build
+    # contracts 1 - frac * frac into one FMA)
+    assert np.allclose(d, v["mean_dist"], rtol=1e-9, atol=0) and near == int(v["mean_nearest"])
+    for h in hs:
+        oracle.lib().orc_hist_free(h)
