@@ -348,6 +348,54 @@ int msc_hist_set_device_view(const msc_hist_set* set, void** bins, uint64_t* slo
                              void** scalars, uint64_t* scalar_bytes);
 int msc_hist_import_done(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n);
 
+/* A slot as ONE contiguous byte range in device memory, dense or sparse (scalar record + bins, or scalar record + sub-range table +
+ * (bin, value) list + cum array: ~12 bytes per distinct k-mer instead of 4^k bins): what a sharded driver broadcasts as the query of
+ * a Trainer::get_close step (cluster/ClusterFactory.cpp:566) and all-gathers as the new centres of an update round (:328,331).
+ *   msc_hist_packed_bytes: size of slot's range (a multiple of 16; known on the host).
+ *   msc_hist_pack:   slots[i] -> dev_dst + offsets[i] (offsets: multiples of 16, ranges disjoint).
+ *   msc_hist_unpack: dev_src + offsets[i] -> slots[i] of `set` (same k, bin type and layout), an exact copy -- stale magnitude
+ *                    included; clone / assign semantics come from msc_hist_clone / msc_hist_assign(_batch) out of a staging set. A
+ *                    sparse destination appends the lists to its arena (MSC_ERR_OOM when full).
+ *   msc_hist_set_reset: a sparse set forgets every list (its arena is append-only otherwise): what a one-slot staging set does
+ *                    between two queries. */
+uint64_t msc_hist_packed_bytes(const msc_hist_set* set, uint64_t slot);
+int      msc_hist_pack(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* slots, uint64_t n, void* dev_dst, const uint64_t* offsets);
+int      msc_hist_unpack(msc_ctx* ctx, msc_hist_set* set, const uint32_t* slots, uint64_t n, const void* dev_src, const uint64_t* offsets);
+int      msc_hist_set_reset(msc_ctx* ctx, msc_hist_set* set);
+
+/* get_mean / the mean of mean_shift_update (cluster/ClusterFactory.cpp:338-380,297-326) when the members of a list live on several
+ * GPUs: SURVEY 8(e)'s reduction of partial column sums. n lists at once; list c = member_slots[offsets[c] .. offsets[c+1]) of THIS
+ * rank's set (may be empty).
+ *   msc_colsum_partial: the integer column sums of this rank's members. *dev_payload (library-owned, valid until the next call) is
+ *     dense sets : uint64 [n][padded bins] followed by uint64 [n] member counts -> ALL-REDUCE (sum) it in place, payload_bytes / 8 words;
+ *     sparse sets: a table {n, bytes, (members, offset) x n} and per list a packed sparse slot of the summed excesses -> ALL-GATHER
+ *                  it, every rank padded to the largest payload_bytes.
+ *   msc_colsum_nearest: dev_global = the reduced array (dense; world ignored) or the gathered payloads, bytes_per_rank apart (sparse).
+ *     Every rank derives the same FP64 mean of each list (exact integer sums / total members: the single-GPU mean bit for bit),
+ *     rounds it, and measures ITS members: nearest_pos[c] = position inside this rank's list c of its first member nearest the mean
+ *     (DivergencePoint::distance_d, clutil/DivergencePoint.cpp:55-66), -1 for an empty list; nearest_dist[c] its distance;
+ *     m_total_out[c] (nullable) = members of list c over all ranks. The caller folds the ranks' (distance, position) records.
+ *   msc_colsum_list_bytes: device scratch one list costs (a driver sizes its chunks of centres by it).
+ * msc_filter_batch: Trainer::filter (cluster/Trainer.cpp:123-141) of n centres against their lists in one pass -- the first stage of
+ *   msc_update_centres alone; keep[i] = 1 iff pt_slots[i] survives the filter of its centre. */
+uint64_t msc_colsum_list_bytes(const msc_hist_set* set);
+int      msc_colsum_partial(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, const uint64_t* offsets, uint64_t n,
+                            void** dev_payload, uint64_t* payload_bytes);
+int      msc_colsum_nearest(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, const uint64_t* offsets, uint64_t n,
+                            const void* dev_global, uint64_t bytes_per_rank, int world, int64_t* nearest_pos, double* nearest_dist,
+                            uint64_t* m_total_out);
+int      msc_filter_batch(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots,
+                          uint64_t n_centres, const msc_hist_set* pts, const uint32_t* pt_slots, const uint64_t* offsets, uint8_t* keep);
+
+/* Plain device memory and the ctx's HIP stream for a caller that owns the communicator (rccl.h takes a hipStream_t: collectives
+ * queued on this stream are ordered with the library's kernels without a host round trip). */
+void*    msc_stream_handle(msc_ctx* ctx);
+int      msc_device_malloc(msc_ctx* ctx, uint64_t bytes, void** out);
+int      msc_device_free(msc_ctx* ctx, void* p);
+int      msc_memcpy_to_host(msc_ctx* ctx, void* dst, const void* src_dev, uint64_t bytes);
+int      msc_memcpy_to_device(msc_ctx* ctx, void* dst_dev, const void* src, uint64_t bytes);
+int      msc_memcpy_device(msc_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);      /* queued on the ctx stream, not waited for */
+
 #ifdef __cplusplus
 }
 #endif

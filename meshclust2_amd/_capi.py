@@ -92,6 +92,20 @@ PROTOTYPES = {
     "msc_train_class": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _int, _int, C.c_double, C.c_char_p, C.c_size_t, _vp, _vp]),
     "msc_hist_set_device_view": (_int, [_vp, C.POINTER(_vp), _pu64, C.POINTER(_vp), _pu64]),
     "msc_hist_import_done": (_int, [_vp, _vp, _u64, _u64]),
+    "msc_hist_packed_bytes": (_u64, [_vp, _u64]),
+    "msc_hist_pack": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "msc_hist_unpack": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "msc_hist_set_reset": (_int, [_vp, _vp]),
+    "msc_colsum_list_bytes": (_u64, [_vp]),
+    "msc_colsum_partial": (_int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_vp), _pu64]),
+    "msc_colsum_nearest": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _vp]),
+    "msc_filter_batch": (_int, [_vp, _vp, _dbl, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "msc_stream_handle": (_vp, [_vp]),
+    "msc_device_malloc": (_int, [_vp, _u64, C.POINTER(_vp)]),
+    "msc_device_free": (_int, [_vp, _vp]),
+    "msc_memcpy_to_host": (_int, [_vp, _vp, _vp, _u64]),
+    "msc_memcpy_to_device": (_int, [_vp, _vp, _vp, _u64]),
+    "msc_memcpy_device": (_int, [_vp, _vp, _vp, _u64]),
     "msc_window_create": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "msc_window_destroy": (None, [_vp]),
     "msc_window_alive": (_u64, [_vp, _u64, _u64]),

@@ -106,6 +106,14 @@ extern "C" int msc_memcpy_to_device(msc_ctx* ctx, void* dst_dev, const void* src
 	return MSC_OK;
 }
 
+extern "C" int msc_memcpy_device(msc_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes) {
+	if (!ctx || (bytes && (!dst_dev || !src_dev))) return MSC_ERR_INVALID_ARG;
+	if (!bytes) return MSC_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));      // ordered with whatever follows on the ctx stream
+	return MSC_OK;
+}
+
 // ================================================================================================ pack / unpack
 extern "C" uint64_t msc_hist_packed_bytes(const msc_hist_set* set, uint64_t slot) {
 	if (!set || slot >= set->capacity) return 0;

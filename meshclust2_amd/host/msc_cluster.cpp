@@ -8,6 +8,10 @@
 // never leave HBM: the host handles slots, lengths, flags, scalars.
 //
 // Usage (flag names are the reference's, cluster/CRunner.cpp:243-477):
+// Several GPUs: start one process per GPU with the environment torch.distributed.run sets (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR,
+// MASTER_PORT; `python -m torch.distributed.run --no-python ... msc_cluster ...`, or meshclust2_amd/cluster.py). Every rank then holds
+// 1 / WORLD_SIZE of the points and runs the same clustering logic over msc::ShardedBackend (msc_sharded.hpp): RCCL over xGMI between the
+// ranks (MSC_COMM=tcp: plain sockets + host staging, what the tests use when several ranks share one GPU: MSC_ONE_GPU=1).
 //   msc_cluster <input.fa> [--recover weights.txt] [--id 0.9] [--kmer K] [--datatype 8|16|32|64]   (no --recover: trains first)
 //               [--output output.clstr] [--delta 5] [--iterations 15] [--single-file] [--sparse] [--serial-update] [--no-ranges] [--device 0]
 #include <algorithm>
@@ -25,43 +29,15 @@
 
 #include "meshclust2_host.hpp"
 #include "msc_driver.hpp"
+#include "msc_fasta.hpp"
+#include "msc_gpu_engine.hpp"
+#ifdef MSC_WITH_RCCL
+#include "msc_comm_rccl.hpp"
+#endif
 
 namespace {
 
-// ------------------------------------------------------------------ FASTA (nonltr/ChromListMaker.cpp:24-48,117-165)
-bool safe_getline(std::istream& is, std::string& t) {
-	t.clear();
-	std::streambuf* sb = is.rdbuf();
-	for (;;) {
-		int c = sb->sbumpc();
-		if (c == '\n') return true;
-		if (c == '\r') { if (sb->sgetc() == '\n') sb->sbumpc(); return true; }
-		if (c == std::streambuf::traits_type::eof()) { if (t.empty()) { is.setstate(std::ios::eofbit); return false; } return true; }
-		t += (char)c;
-	}
-}
-
-// single_file (--single-file, nonltr/ChromListMaker.cpp:123-147): the whole file is ONE sequence -- the first header, and
-// the records joined by 50 'N'
-void read_fasta(const std::string& path, std::vector<std::string>& headers, std::vector<std::string>& seqs, bool single_file) {
-	std::ifstream in(path.c_str());
-	if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(1); }
-	std::string line;
-	bool have = false;
-	while (in.good()) {
-		if (!safe_getline(in, line)) break;
-		if (!line.empty() && line[0] == '>') {
-			if (single_file && have) { seqs.back() += std::string(50, 'N'); continue; }
-			headers.push_back(line);
-			seqs.emplace_back();
-			have = true;
-		} else if (!line.empty() && (line[0] == ' ' || line[0] == '\t')) {
-			continue;
-		} else if (have) {
-			seqs.back() += line;
-		}
-	}
-}
+using msc::read_fasta;
 
 // ------------------------------------------------------------------ the hot path of ONE GPU behind msc::ClusterBackend
 // Point handle = slot in the device point set (records are built in input order); centre handle = slot in the centre store.
@@ -359,6 +335,9 @@ int main(int argc, char** argv) {
 		                     "       without --recover a model is trained first (--feat fast|slow, --num-templates 300, --min-feat 4, --max-feat 4) and written to --dump (weights.txt)\n", argv[0]);
 		return 1;
 	}
+	const msc::CommEnv env = msc::CommEnv::from_environment();
+	const bool sharded = env.world > 1;
+	if (sharded && !std::getenv("MSC_ONE_GPU")) device = env.local_rank;
 	try {
 		const auto t_start = std::chrono::steady_clock::now();
 		msc::Context ctx(device);
@@ -369,6 +348,14 @@ int main(int argc, char** argv) {
 		file_first.push_back(seqs.size());
 		const size_t n = seqs.size();
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
+		std::unique_ptr<msc::TcpComm> boot;          // rendezvous of the ranks (and the whole transport under MSC_COMM=tcp)
+		if (sharded) boot.reset(new msc::TcpComm(env));
+		if (weights.empty() && sharded && env.rank != 0) {          // rank 0 chooses k and the histogram type and trains; the others wait for its file
+			int64_t kd[2] = {0, 0};
+			boot->broadcast(kd, sizeof kd, 0, false);
+			k = (int)kd[0]; dtype = (int)kd[1];
+			weights = dump;
+		}
 		if (weights.empty()) {
 			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average record size)) - 1, integer averages
 				unsigned long long length = 0;
@@ -392,6 +379,7 @@ int main(int argc, char** argv) {
 			std::ofstream(dump.c_str()) << text;       // the reference always leaves weights.txt behind (cluster/Trainer.cpp:188-190)
 			weights = dump;
 			std::cout << "timestamp GLM " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
+			if (sharded) { int64_t kd[2] = {k, dtype}; boot->broadcast(kd, sizeof kd, 0, false); }
 		}
 		msc::Trainer trn(ctx, weights, similarity);
 		if (k < 0) k = msc_model_k(trn.feature().get());
@@ -402,6 +390,43 @@ int main(int argc, char** argv) {
 		}
 		uint64_t total_bases = 0, longest = 0;
 		for (const auto& sq : seqs) { total_bases += sq.size(); longest = std::max<uint64_t>(longest, sq.size()); }
+		if (sharded) {
+			// ---- one GPU per rank: this rank's share of the points, the operators over msc::ShardedBackend
+			msc::ShardPlan plan;
+			plan.n = n; plan.block = 1000; plan.world = env.world;
+			if (const char* b = std::getenv("MSC_SHARD_BLOCK")) plan.block = std::max<uint64_t>(1, std::strtoull(b, nullptr, 10));      // (tests: small inputs over several ranks)
+			std::vector<std::string> own((size_t)plan.count(env.rank));
+			for (uint64_t l = 0; l < own.size(); l++) own[(size_t)l] = seqs[(size_t)plan.global(env.rank, l)];
+			seqs.clear();
+			seqs.shrink_to_fit();
+			msc::GpuShardEngine engine(ctx, trn, k, dtype, sparse, similarity, own, longest, total_bases, n);
+			own.clear();
+			std::unique_ptr<msc::Comm> fabric;
+			const char* want = std::getenv("MSC_COMM");
+			msc::Comm* comm = boot.get();
+			engine.attach(*boot);
+			if (!want || std::string(want) != "tcp") {
+#ifdef MSC_WITH_RCCL
+				fabric.reset(new msc::RcclComm(ctx.get(), *boot));
+				engine.attach(*fabric);
+				comm = fabric.get();
+#else
+				throw std::runtime_error("this msc_cluster was built without RCCL: set MSC_COMM=tcp");
+#endif
+			}
+			msc::ShardedBackend be(engine, *comm, n, plan.block);
+			std::vector<msc::SeqRecord> records(n);
+			for (size_t i = 0; i < n; i++) { records[i].header = headers[i]; records[i].length = be.lengths()[i]; }
+			std::ofstream quiet;          // (an unopened stream swallows the log of the ranks that do not report)
+			msc::MeanShift ms(be, env.rank == 0 ? (std::ostream&)std::cout : (std::ostream&)quiet);
+			ms.batch_update = !serial_update;
+			ms.run(records, similarity, iterations, delta, env.rank == 0 ? output.c_str() : nullptr);
+			if (env.rank == 0)
+				std::cout << "collectives: broadcast " << comm->calls.broadcast << " all_gather " << comm->calls.all_gather << " all_reduce " << comm->calls.all_reduce << " bytes "
+				          << comm->calls.bytes << " | get_close steps " << be.ops.get_close << " collectives " << be.ops.get_close_collectives << " overflow " << be.ops.get_close_overflow
+				          << " | closest " << be.ops.closest << " update chunks " << be.ops.update_chunks << " set chunks " << be.ops.set_chunks << std::endl;
+			return 0;
+		}
 		msc::PointSet points(ctx, k, dtype, n, sparse ? total_bases + 1024 : 0);
 		const size_t chunk = 8192;
 		for (size_t off = 0; off < n; off += chunk) {
@@ -424,9 +449,11 @@ int main(int argc, char** argv) {
 		ms.run(records, similarity, iterations, delta, output.c_str());
 	} catch (const msc::Error& e) {
 		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());
+		if (sharded) std::_Exit(3);          // (no destructors: the other ranks must see this one go, not wait in a collective)
 		return 3;
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "error: %s\n", e.what());
+		if (sharded) std::_Exit(1);
 		return 1;
 	}
 	return 0;

@@ -1565,34 +1565,79 @@ def _run_ranks(module_args, n, tmp_path, timeout=900):
                            "--master-port", str(port)] + module_args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
 
 
-@pytest.mark.parametrize("case,ranks", [("cfg1", 2), ("k9_u8", 2), ("cfg1", 1)])
-def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks):
-    """meshclust2_amd/cluster.py: the points sharded over `ranks` processes (two ranks sharing this box's GPU, exchanges over gloo
-    staged through host memory), every rank running the clustering logic of libmsc_driver.so on replicated bookkeeping and scoring
-    its shard through the C ABI. Rank 0 writes the reference CLI's own .clstr byte for byte (cluster/ClusterFactory.cpp:553-656)."""
+def _cluster_ranks(args, ranks, tmp_path, block=100, timeout=900):
+    """`ranks` processes of msc_cluster, each holding 1 / ranks of the points (msc::ShardedBackend over msc::GpuShardEngine), sharing
+    this box's one GPU (MSC_ONE_GPU) and exchanging over plain sockets with host staging (MSC_COMM=tcp) -- the pool has 1-GPU boxes;
+    the production launch is one rank per GPU over RCCL. -> (return codes, rank 0's log)"""
     import os
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    procs = []
+    for r in range(ranks):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(ranks), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSC_COMM="tcp", MSC_ONE_GPU="1",
+                   MSC_SHARD_BLOCK=str(block))
+        procs.append(subprocess.Popen([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    logs = []
+    for p_ in procs:
+        try:
+            logs.append(p_.communicate(timeout=timeout)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    return [p_.returncode for p_ in procs], logs[0], logs
+
+
+def _step_collectives(log):
+    import re
+    m = re.search(r"get_close steps (\d+) collectives (\d+) overflow (\d+)", log)
+    assert m, log[-1500:]
+    return tuple(int(x) for x in m.groups())
+
+
+@pytest.mark.parametrize("case,ranks,extra", [("cfg1", 2, []), ("cfg1", 3, []), ("k9_u8", 2, []), ("k9_u8", 2, ["--sparse"]), ("k9_u8", 3, ["--sparse"]),
+                                              ("cfg5", 2, ["--sparse"]), ("cfg5", 3, ["--sparse"]), ("cfg5", 2, []), ("cfg5_u16", 3, ["--sparse"])])
+def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks, extra):
+    """msc_cluster with the points sharded over `ranks` processes: every rank runs the clustering logic of msc_driver.hpp on replicated
+    bookkeeping and scores its shard through the C ABI, dense or sparse; the query travels as a packed slot, get_mean as column sums.
+    Rank 0 writes the reference CLI's own .clstr byte for byte (cluster/ClusterFactory.cpp:553-656) -- cfg1, the k = 9 / uint8_t set
+    (BASELINE cfg3's shape), and BASELINE cfg5's parameters (k = 9, 500 b - 50 kb, a `--feat slow` model, --id 0.6) -- and a get_close
+    step costs at most one broadcast and one all-gather."""
+    import os
+    from golden_util import cfg5_set
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     golden = os.path.join(root, "tests", "golden")
-    seed, n, fam, wts, clstr = {"cfg1": (20260001, 1000, 20, "weights_k5_u16.txt", "cfg1.clstr"), "k9_u8": (61, 320, 16, "weights_k9_u8.txt", "k9_u8.clstr")}[case]
-    seqs, hdrs = synth.families(seed, n, 1000, family=fam)
+    if case.startswith("cfg5"):
+        seqs, hdrs = cfg5_set(run_cap=900 if case == "cfg5" else 3000)
+        args = ["--recover", os.path.join(golden, "weights_%s_k9.txt" % case), "--id", "0.6", "--kmer", "9"]
+        clstr, block = case + ".clstr", 16
+    else:
+        seed, n, fam, wts, clstr = {"cfg1": (20260001, 1000, 20, "weights_k5_u16.txt", "cfg1.clstr"), "k9_u8": (61, 320, 16, "weights_k9_u8.txt", "k9_u8.clstr")}[case]
+        seqs, hdrs = synth.families(seed, n, 1000, family=fam)
+        args = ["--recover", os.path.join(golden, wts), "--id", "0.9"] + (["--kmer", "5", "--datatype", "16"] if case == "cfg1" else [])
+        block = 100 if case == "cfg1" else 40
     fa = str(tmp_path / "in.fa")
     synth.write_fasta(fa, seqs, hdrs)
     out = str(tmp_path / "out.clstr")
-    args = ["-m", "meshclust2_amd.cluster", fa, "--recover", os.path.join(golden, wts), "--id", "0.9", "--output", out]
-    if case == "cfg1":
-        args += ["--kmer", "5", "--datatype", "16"]
-    r = _run_ranks(args, ranks, tmp_path)
-    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    rcs, log, logs = _cluster_ranks([fa] + args + ["--output", out] + extra, ranks, tmp_path, block=block)
+    assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
     assert open(out, "rb").read() == open(os.path.join(golden, clstr), "rb").read()
+    steps, coll, overflow = _step_collectives(log)
+    assert steps > 0 and coll <= 2 * steps + overflow
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks):
-    """The fixtures above hold equal-length sequences, which the reference's length bins turn into (almost) empty windows; here the
-    lengths spread over 900-1100 bases, so every step scores a real window, clusters are opened and moved thousands of times, and
-    the exchanges of every operator carry data. The one-GPU C++ driver (`msc_cluster`, itself held to the reference CLI by the
-    fixtures and the fuzz) is the yardstick: same bytes. (r02: this case exposed a missing stream order between the library's
-    queued centre copy and torch's next write of the query slot -- invisible with equal lengths.)"""
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, []), (2, ["--sparse"]), (3, ["--sparse"])])
+def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks, extra):
+    """The fixtures above hold few real windows; here the lengths spread over 900-1100 bases, so every step scores a real window,
+    clusters are opened and moved thousands of times, and the exchanges of every operator carry data (k = 8: the smallest histograms
+    the sparse layout takes). The one-GPU run of the same binary (itself held to the reference CLI by the fixtures and the fuzz) is the
+    yardstick: same bytes, dense and sparse, 2 and 3 ranks with uneven shares."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1600,14 +1645,38 @@ def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks):
     seqs, hdrs = synth.families(777, 3000, 1000, length_jitter=100)
     fa = str(tmp_path / "in.fa")
     synth.write_fasta(fa, seqs, hdrs)
-    common = [fa, "--recover", os.path.join(golden, "weights_k5_u16.txt"), "--id", "0.9", "--kmer", "5", "--datatype", "16", "--output"]
+    common = [fa, "--recover", os.path.join(golden, "weights_k8_u16.txt"), "--id", "0.85", "--kmer", "8", "--datatype", "16"] + extra + ["--output"]
     one = str(tmp_path / "one.clstr")
     subprocess.check_call([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + common + [one], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = str(tmp_path / "ranks.clstr")
-    r = _run_ranks(["-m", "meshclust2_amd.cluster"] + common + [out], ranks, tmp_path)
-    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    rcs, log, logs = _cluster_ranks(common + [out], ranks, tmp_path, block=128)
+    assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
     a, b = open(one, "rb").read(), open(out, "rb").read()
-    assert a.count(b">Cluster") > 500 and a == b
+    assert a.count(b">Cluster") > 100 and a == b
+    steps, coll, overflow = _step_collectives(log)
+    assert steps > 500 and coll <= 2 * steps + overflow
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_cluster_driver_k13_u64_sparse(tmp_path, ranks):
+    """BASELINE cfg4's parameters over several ranks: k = 13, 64-bit counts, 20 kb sequences, the sparse layout (no dense form exists:
+    512 MiB per histogram) -- the query travels as a ~240 KB list, get_mean as each rank's summed excess list. 2 and 3 ranks write the
+    bytes of the one-GPU run."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    seqs, hdrs = synth.families(4421, 120, 20000, family=6, length_jitter=2500)
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    common = [fa, "--recover", os.path.join(golden, "weights_cfg4_k13.txt"), "--id", "0.9", "--kmer", "13", "--datatype", "64", "--sparse", "--output"]
+    one = str(tmp_path / "one.clstr")
+    subprocess.check_call([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + common + [one], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = str(tmp_path / "ranks.clstr")
+    rcs, log, logs = _cluster_ranks(common + [out], ranks, tmp_path, block=8)
+    assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
+    a, b = open(one, "rb").read(), open(out, "rb").read()
+    assert a.count(b">Cluster") >= 10 and a == b
 
 
 def test_bench_two_ranks_packed_exchange(tmp_path):
@@ -1624,7 +1693,7 @@ def test_bench_two_ranks_packed_exchange(tmp_path):
 
 
 @pytest.mark.parametrize("dtype,k,wts,sparse,n", [(16, 5, "weights_k5_u16.txt", False, 3000), (32, 9, "weights_k9_u32.txt", False, 400), (8, 9, "weights_k9_u8.txt", True, 2500),
-                                                  (16, 9, "weights_cfg5_k9.txt", True, 600)])
+                                                  (16, 9, "weights_cfg5_k9.txt", True, 600), (16, 5, "weights_k5_u16.txt", False, 140000)])
 def test_get_close_over_a_device_window_equals_get_close_over_a_slot_list(ctx, dtype, k, wts, sparse, n):
     """msc_get_close_window (the accumulate loop's window kept on the device: cluster/ClusterFactory.cpp:553-610 over
     cluster/Trainer.cpp:23-71) against msc_get_close on the slot list of the same alive positions: the same close set, arg-max and
@@ -1641,11 +1710,11 @@ def test_get_close_over_a_device_window_equals_get_close_over_a_slot_list(ctx, d
     win = api.Window(ctx, hs, order)
     alive = np.ones(n, dtype=bool)
     assert win.alive() == n
-    for step in range(40):
+    for step in range(40 if n < 100000 else 8):
         q = int(rng.integers(n))
         a, b = sorted(int(x) for x in rng.integers(0, n + 1, 2))
         if step % 7 == 0:
-            a, b = 0, n          # the whole store: the multi-block compaction when n > 128 * 1024 positions... and the longest slot list
+            a, b = 0, n          # the whole store: more than 128 * 1024 positions take the multi-block compaction (the 140 000-point case)
         pos = a + np.flatnonzero(alive[a:b])
         assert win.alive(a, b) == pos.size
         flags, bp, bs, im = trn.get_close(hs, order[pos], hs, q) if pos.size else (np.zeros(0, dtype=np.uint8), -1, -1.0, True)

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Wall time of the multi-rank driver (meshclust2_amd/cluster.py) next to the one-GPU C++ driver on the same file -- run on the GPU box
-# (ranks share device 0 over gloo staged through host memory: the exchange logic, not xGMI).
-#   tools/cluster_ranks_time.sh <n_seqs> <k> <dtype> <weights> <ranks>      (CLUSTER_TIME_JITTER=j: lengths 1000 +- j)
-N=$1; K=$2; DT=$3; W=$4; RANKS=$5
+# Wall time of the sharded driver (msc_cluster, one process per rank: host/msc_sharded.hpp) next to the one-GPU run of the same binary
+# on the same file -- run on the GPU box. The ranks share device 0 and exchange over sockets + host staging (MSC_COMM=tcp): the
+# exchange logic and its host cost, not xGMI.
+#   tools/cluster_ranks_time.sh <n_seqs> <k> <dtype> <weights> <ranks> [msc_cluster flags ...]      (CLUSTER_TIME_JITTER=j: lengths 1000 +- j)
+N=$1; K=$2; DT=$3; W=$4; RANKS=$5; shift 5
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 python3 - <<PY
@@ -14,11 +15,16 @@ seqs, headers = synth.families(777, $N, 1000, length_jitter=j) if j else synth.f
 synth.write_fasta("/tmp/cr_$N.fa", seqs, headers)
 PY
 s=$(date +%s.%N)
-meshclust2_amd/host/msc_cluster /tmp/cr_$N.fa --recover $W --id 0.9 --kmer $K --datatype $DT --output /tmp/cr_one.clstr > /tmp/cr_one.log 2>&1
-e=$(date +%s.%N); echo "one GPU, C++ driver: $(python3 -c "print(round($e - $s, 2))") s"
+meshclust2_amd/host/msc_cluster /tmp/cr_$N.fa --recover $W --id 0.9 --kmer $K --datatype $DT --output /tmp/cr_one.clstr "$@" > /tmp/cr_one.log 2>&1
+e=$(date +%s.%N); echo "one GPU: $(python3 -c "print(round($e - $s, 2))") s"
+grep -E "timestamp (accumulate|update)" /tmp/cr_one.log | tr '\n' ' '; echo
 s=$(date +%s.%N)
-MSC_BENCH_BACKEND=gloo MSC_BENCH_ONE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $RANKS --master-addr 127.0.0.1 --master-port 29611 -m meshclust2_amd.cluster /tmp/cr_$N.fa --recover $W --id 0.9 --kmer $K --datatype $DT --output /tmp/cr_ranks.clstr > /tmp/cr_ranks.log 2>&1
-e=$(date +%s.%N); echo "$RANKS ranks on one GPU (gloo): $(python3 -c "print(round($e - $s, 2))") s"
-tail -3 /tmp/cr_ranks.log | cut -c1-300
+for r in $(seq 0 $((RANKS - 1))); do
+  RANK=$r WORLD_SIZE=$RANKS LOCAL_RANK=$r MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 MSC_COMM=tcp MSC_ONE_GPU=1 \
+    meshclust2_amd/host/msc_cluster /tmp/cr_$N.fa --recover $W --id 0.9 --kmer $K --datatype $DT --output /tmp/cr_ranks.clstr "$@" > /tmp/cr_ranks_$r.log 2>&1 &
+done
+wait
+e=$(date +%s.%N); echo "$RANKS ranks on one GPU (sockets): $(python3 -c "print(round($e - $s, 2))") s"
+grep -E "timestamp (accumulate|update)|collectives" /tmp/cr_ranks_0.log | cut -c1-300
 cmp /tmp/cr_one.clstr /tmp/cr_ranks.clstr && echo "same .clstr bytes"
-mkdir -p $R/gpurun_out/cr; cp /tmp/cr_one.clstr /tmp/cr_ranks.clstr /tmp/cr_one.log /tmp/cr_ranks.log $R/gpurun_out/cr/ 2>/dev/null
+mkdir -p $R/gpurun_out/cr; cp /tmp/cr_one.clstr /tmp/cr_ranks.clstr /tmp/cr_one.log /tmp/cr_ranks_0.log $R/gpurun_out/cr/ 2>/dev/null
