@@ -59,6 +59,9 @@ def parse():
                                                     "tests/golden/weights_cfg5_k9.txt for a `--feat slow` model with jensen_shannon")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
     ap.add_argument("--cpu-cands", type=int, default=16384, help="candidates per CPU get_close pass: enough for every host thread of a 256-thread box to get 64")
+    ap.add_argument("--check", action="store_true", help="add `check` to the line: per timed step, the number of close candidates of every query of the block (all ranks "
+                                                         "summed) -- what two runs with different numbers of ranks must agree on")
+    ap.add_argument("--check-world", type=int, default=0, help="single-rank run: choose each step's query block as a run over this many ranks would (with --check)")
     return ap.parse_args()
 
 
@@ -160,10 +163,10 @@ def cpu_baseline(args, synth, weights_text, weights_path):
 
 def pmc_traffic(kernel_prefix, config_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/*_pmc_hbm.json, written by tools/summarize_profiles.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction).
-    None when no committed profile matches the running configuration."""
+    (profiles/*_pmc_hbm.json, written by tools/summarize_profiles.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction), and the
+    VALU-busy fraction of the same passes where they were taken. (None, None) when no committed profile matches the running configuration."""
     import glob
-    best = None
+    best, busy = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
         try:
             d = json.load(open(f))
@@ -174,7 +177,8 @@ def pmc_traffic(kernel_prefix, config_key):
         for k, v in d.items():
             if k.startswith(kernel_prefix) and isinstance(v, dict) and "hbm_bytes_per_launch_corrected" in v:
                 best = v["hbm_bytes_per_launch_corrected"]
-    return best
+                busy = v.get("valu_busy")
+    return best, busy
 
 
 def main():
@@ -236,8 +240,9 @@ def main():
                 real.barrier(group=self.group)
 
         if backend == "nccl":
-            real.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            gloo_group = real.new_group(backend="gloo")
+            import datetime
+            real.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
+            gloo_group = real.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
         else:
             real.init_process_group(backend)
             gloo_group = None
@@ -296,22 +301,38 @@ def main():
         if gloo_group is not None:
             # preflight: one all-gather and one broadcast over RCCL on the library's own device views (they are not torch allocations).
             # If any rank fails, every rank stages the exchange through host memory instead of aborting the run.
-            ok = 1
+            # The collectives are issued asynchronously and waited for with a deadline: a rank that throws at once does not leave the
+            # others blocked inside the collective for the process group's whole timeout -- they time out here, everybody meets in
+            # the flag all-reduce below (gloo, its own deadline), and a TIMEOUT ends the run non-zero (the communicator is then in an
+            # unknown state), while a refusal every rank sees immediately falls back to host staging.
+            import datetime
+            ok = 2
             try:
-                real.all_gather_into_tensor(all_scal[M:M + world], all_scal[0:1])
-                real.broadcast(all_scal[M], src=0)
+                w1 = real.all_gather_into_tensor(all_scal[M:M + world], all_scal[0:1], async_op=True)
+                w2 = real.broadcast(all_scal[M], src=0, async_op=True)
+                for w in (w1, w2):
+                    w.wait(timeout=datetime.timedelta(seconds=60))
                 torch.cuda.synchronize()
             except Exception as e:      # noqa: BLE001
-                sys.stderr.write("rank %d: RCCL preflight on device views failed (%r): staging the exchange through host memory\n" % (rank, e))
-                ok = 0
+                timed_out = "imeout" in repr(e) or "imed out" in repr(e)
+                sys.stderr.write("rank %d: RCCL preflight on device views %s (%r)\n" % (rank, "TIMED OUT" if timed_out else "failed: staging the exchange through host memory", e))
+                ok = 0 if timed_out else 1
             flag = torch.tensor([ok], dtype=torch.int32)
             real.all_reduce(flag, op=real.ReduceOp.MIN, group=gloo_group)
             if int(flag.item()) == 0:
+                sys.stderr.write("rank %d: a rank timed out in the RCCL preflight: giving up\n" % rank)
+                os._exit(3)
+            if int(flag.item()) == 1:
                 dist = _HostStaged(gloo_group)
         sharded = shard.ShardedTrainer(dist, plan, GpuBackend(), rank, device="cuda")
         block = shard.ShardedBlockScorer(dist, plan, GpuBackend(), rank, device="cuda")
 
     tiles_ms, launches = [], []
+    checks = []                     # --check: per timed step, close candidates per query of the block (all ranks)
+    cw = args.check_world if world == 1 and args.check_world > 1 else 0
+    if cw:
+        plan_w = shard.ShardPlan(n_total, cw, block=BLOCK)
+        m_min_w = min(plan_w.local_count(r) for r in range(cw))
     step_no = [0]
     pending = [None, None]          # RCCL work handles of the query block in flight per buffer half (N > 1, allpairs)
     qpr = Q // world                # queries every rank contributes per step
@@ -334,10 +355,18 @@ def main():
                 block.finish(pending[cur], Q, base=cur * Q)
                 pending[cur] = None
                 pending[nxt] = block.begin_packed(block_first(st + 1), qpr, base=nxt * Q)
-                block.score(Q, base=cur * Q)
+                _, total = block.score(Q, base=cur * Q)
+                if args.check:
+                    checks.append([int(x) for x in total])
             else:
-                qs = np.array([((st * Q + j) * 7919) % M for j in range(Q)], dtype=np.uint32)
-                api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",))
+                if cw:          # the block a cw-rank run assembles at this step: rank r's local slots first .. first + Q / cw - 1, rank-major
+                    first = (st * (Q // cw) * 131) % (m_min_w - Q // cw + 1)
+                    qs = np.array([plan_w.global_index(r, first + j) for r in range(cw) for j in range(Q // cw)], dtype=np.uint32)
+                else:
+                    qs = np.array([((st * Q + j) * 7919) % M for j in range(Q)], dtype=np.uint32)
+                res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",))
+                if args.check:
+                    checks.append([int(x) for x in res["close"].sum(axis=1)])
             tiles_ms.append(ctx.last_kernel_ms()[0])
             launches.append(ctx.last_kernel_launches())
         else:
@@ -360,6 +389,7 @@ def main():
         one_step()
     tiles_ms.clear()
     launches.clear()
+    checks.clear()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -402,15 +432,20 @@ def main():
         config_key += ",weights=" + os.path.basename(args.weights)
     if args.layout == "sparse":
         config_key += ",layout=sparse"
-    traffic = pmc_traffic(kernel.split("<")[0], config_key)
+    traffic, valu_busy = pmc_traffic(kernel.split("<")[0], config_key)
     per_gpu = "%d per GPU" % args.nseq if args.scaling == "weak" else "%d in total (%d on rank 0)" % (n_total, M)
+    length_name = "%gkb" % (args.length / 1000.0) if args.length % 100 == 0 else "%d bp" % args.length
+    is_cfg2 = (n_total, args.length, args.k, args.dtype, args.layout) == (100000, 1000, 9, 32, "dense")
+    calls_per_launch = len(tiles_ms) / n_launch if tiles_ms else 1.0          # < 1: a call is cut into candidate chunks, one launch each
     line = {
-        "metric": "sequence-pairs/sec identity-scored (k=%d, 1kb seqs)" % args.k,
+        "metric": "sequence-pairs/sec identity-scored (k=%d, %s seqs)" % (args.k, length_name),
         "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u%d" % args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg2: %d x %d bp synthetic sequences, %s, k=%d, datatype=%d, resident in HBM; step = %d query histograms x all "
-                               "histograms (9 fast features + 4-combo GLM + close flag per pair), mode %s" % (n_total, args.length, per_gpu, args.k, args.dtype, Q, args.mode),
+        "config": {"workload": "%s: %d x %d bp synthetic sequences, %s, k=%d, datatype=%d, %s layout, resident in HBM; step = %d query histograms x all "
+                               "histograms (model %s: %d single statistics + %d-combo GLM + close flag per pair), mode %s"
+                               % ("cfg2" if is_cfg2 else "custom (not a BASELINE config)", n_total, args.length, per_gpu, args.k, args.dtype, args.layout, Q, os.path.basename(wpath),
+                                  feat.n_singles, feat.n_combos, args.mode),
                    "pairs_per_step": Q * n_total, "pairs_timed": pairs,
                    "projected_seconds_full_matrix": round(float(n_total) ** 2 / (pairs / dt), 1), "hist_bytes": hist_bytes if args.layout == "sparse" else (4 ** args.k) * esz,
                    "layout": args.layout, "hbm_resident_gib": hs.nbytes() / 2 ** 30,
@@ -425,8 +460,15 @@ def main():
                    "queries_per_candidate_read": qtile},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
-                     "candidates_per_launch": M, "profile_key": config_key},
+                     # what the hardware did, from the committed counter passes of this command (null without a matching profile):
+                     # hbm_frac = PMC HBM bytes per launch / launch time / peak (frac above prices the TILE reads of the kernel as it
+                     # is tiled -- query groups that share a candidate mostly hit in L2); valu_busy = VALU cycles / busy cycles
+                     "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms == avg_ms else None, "valu_busy": valu_busy,
+                     "candidates_per_launch": int(round(M * calls_per_launch)), "query_groups_per_launch": -(-Q // qtile) if args.mode == "allpairs" else 1,
+                     "profile_key": config_key},
     }
+    if args.check:
+        line["check"] = checks
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:
             try:

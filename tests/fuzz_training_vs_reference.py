@@ -107,12 +107,19 @@ def main():
         raise SystemExit("oracle/_ref/libmsc_ref.so is not built (needs /root/reference at build time)")
     ctx = api.Context(0)
     t_end = time.time() + budget
-    n = 0
+    n = ill = 0
     while time.time() < t_end:
-        print(run_round(ctx, seed), flush=True)
+        msg = run_round(ctx, seed)
+        print(msg, flush=True)
+        ill += "ILL-CONDITIONED" in msg
         seed += 1
         n += 1
-    print("training fuzz done: %d rounds" % n)
+    print("training fuzz done: %d rounds, %d ILL-CONDITIONED" % (n, ill))
+    # the ILL-CONDITIONED class is a statement about the FINAL model, not about the expansion where the two searches parted: a selection
+    # bug that happens to end on an ill-conditioned set would hide in it. Its rate is therefore bounded: 2 of 616 rounds so far (r01-r02);
+    # more than 3 % of a run (and more than two rounds) fails the fuzz.
+    if ill > 2 and ill > 0.03 * n:
+        raise SystemExit("too many ILL-CONDITIONED rounds: %d of %d" % (ill, n))
 
 
 if __name__ == "__main__":

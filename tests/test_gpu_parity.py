@@ -1635,8 +1635,8 @@ def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks, extra):
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, []), (2, ["--sparse"]), (3, ["--sparse"])])
 def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks, extra):
     """The fixtures above hold few real windows; here the lengths spread over 900-1100 bases, so every step scores a real window,
-    clusters are opened and moved thousands of times, and the exchanges of every operator carry data (k = 8: the smallest histograms
-    the sparse layout takes). The one-GPU run of the same binary (itself held to the reference CLI by the fixtures and the fuzz) is the
+    clusters are opened and moved thousands of times, and the exchanges of every operator carry data (k = 9, 8-bit bins: BASELINE
+    cfg3's shape). The one-GPU run of the same binary (itself held to the reference CLI by the fixtures and the fuzz) is the
     yardstick: same bytes, dense and sparse, 2 and 3 ranks with uneven shares."""
     import os
     import subprocess
@@ -1645,7 +1645,7 @@ def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks, extra):
     seqs, hdrs = synth.families(777, 3000, 1000, length_jitter=100)
     fa = str(tmp_path / "in.fa")
     synth.write_fasta(fa, seqs, hdrs)
-    common = [fa, "--recover", os.path.join(golden, "weights_k8_u16.txt"), "--id", "0.85", "--kmer", "8", "--datatype", "16"] + extra + ["--output"]
+    common = [fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9", "--kmer", "9", "--datatype", "8"] + extra + ["--output"]
     one = str(tmp_path / "one.clstr")
     subprocess.check_call([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + common + [one], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = str(tmp_path / "ranks.clstr")
@@ -1681,15 +1681,27 @@ def test_multi_rank_cluster_driver_k13_u64_sparse(tmp_path, ranks):
 
 def test_bench_two_ranks_packed_exchange(tmp_path):
     """bench.py --gpus 2 (strong scaling: the sequences split over the ranks, 2 all-gathers per step assemble the query block) on
-    two ranks sharing this GPU: the line is well-formed and the sharded run scores the same pairs as one rank would."""
+    two ranks sharing this GPU, against ONE rank scoring the same blocks (--check-world 2): with --check both lines carry, per timed
+    step, the number of close candidates of every query of the block summed over the ranks -- the sharded run scores the same pairs
+    and reaches the same decisions as one rank does."""
     import json
     import os
+    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2", "--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0"], 2, tmp_path)
+    common = ["--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0", "--check"]
+    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2"] + common, 2, tmp_path)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["pairs_per_step"] == 16 * 8000
     assert line["roofline"]["candidates_per_launch"] == 4000 and line["value"] > 0
+    assert line["config"]["workload"].startswith("custom") and "1kb" in line["metric"]          # 8000 sequences are not cfg2
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--check-world", "2"] + common, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert one.returncode == 0, one.stdout.decode(errors="replace")[-3000:]
+    ref_line = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert len(line["check"]) == 3 and all(len(c) == 16 for c in line["check"])
+    assert line["check"] == ref_line["check"]
+    assert sum(sum(c) for c in line["check"]) >= 3 * 16          # every query is at least close to itself
 
 
 @pytest.mark.parametrize("dtype,k,wts,sparse,n", [(16, 5, "weights_k5_u16.txt", False, 3000), (32, 9, "weights_k9_u32.txt", False, 400), (8, 9, "weights_k9_u8.txt", True, 2500),
