@@ -43,6 +43,8 @@ __global__ void __launch_bounds__(256) k_copy_segments(const CopySeg* __restrict
 	}
 }
 
+__global__ void k_write_words(uint32_t* dst, uint4 w) { *reinterpret_cast<uint4*>(dst) = w; }
+
 int run_copies(msc_ctx* ctx, const std::vector<CopySeg>& segs) {
 	if (segs.empty()) return MSC_OK;
 	std::vector<uint32_t> piece_seg, piece_at;
@@ -128,6 +130,36 @@ extern "C" int msc_hist_pack(msc_ctx* ctx, const msc_hist_set* set, const uint32
 	std::vector<PackHead> heads(n);
 	uint8_t* dst = (uint8_t*)dev_dst;
 	const uint64_t sc = up16(set->scalar_stride);
+	if (n == 1) {
+		// one slot (the query of a get_close step): a head written by value and two to four device copies, all queued on the ctx
+		// stream and not waited for -- a collective queued on the same stream (msc_stream_handle) follows them in order
+		const uint32_t slot = slots[0];
+		if (slot >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_pack: slot out of range");
+		if (offsets[0] & 15) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_pack: offsets must be multiples of 16");
+		uint8_t* o = dst + offsets[0];
+		PackHead ph;
+		ph.bytes = packed_bytes(set, slot);
+		ph.kind = set->sparse ? kPackSparse : kPackDense;
+		ph.nnz = set->sparse ? set->hdr_host[slot].nnz : 0;
+		uint4 w;
+		memcpy(&w, &ph, sizeof w);
+		k_write_words<<<dim3(1), dim3(1), 0, ctx->stream>>>((uint32_t*)o, w);
+		HIP_TRY(ctx, hipGetLastError());
+		HIP_TRY(ctx, hipMemcpyAsync(o + sizeof(PackHead), set->scalars + (uint64_t)slot * set->scalar_stride, set->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
+		if (!set->sparse) {
+			HIP_TRY(ctx, hipMemcpyAsync(o + sizeof(PackHead) + sc, set->bins + (uint64_t)slot * set->L.slot_bytes, set->L.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		} else {
+			const MscSparseHdr& h = set->hdr_host[slot];
+			uint8_t* p = o + sizeof(PackHead) + sc;
+			HIP_TRY(ctx, hipMemcpyAsync(p, (const uint8_t*)(set->hdr + slot) + offsetof(MscSparseHdr, split), sizeof(uint32_t) * (MSC_SPARSE_SUB + 1), hipMemcpyDeviceToDevice, ctx->stream));
+			p += kSplitBytes;
+			if (h.nnz) {
+				HIP_TRY(ctx, hipMemcpyAsync(p, set->ent + h.off, (uint64_t)h.nnz * 8, hipMemcpyDeviceToDevice, ctx->stream));
+				HIP_TRY(ctx, hipMemcpyAsync(p + up16((uint64_t)h.nnz * 8), set->cum + h.off, (uint64_t)h.nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			}
+		}
+		return MSC_OK;
+	}
 	for (uint64_t i = 0; i < n; i++) {
 		const uint32_t slot = slots[i];
 		if (slot >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_pack: slot out of range");
@@ -161,8 +193,7 @@ extern "C" int msc_hist_pack(msc_ctx* ctx, const msc_hist_set* set, const uint32
 extern "C" int msc_hist_set_reset(msc_ctx* ctx, msc_hist_set* set) {
 	if (!ctx || !set || set->ctx != ctx) return MSC_ERR_INVALID_ARG;
 	if (!set->sparse) return MSC_OK;
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // nothing queued may still read the lists
+	// (whatever is queued on the ctx stream still reads the old lists; what overwrites them is queued behind it on the same stream)
 	set->ent_used = 0;
 	for (MscSparseHdr& h : set->hdr_host) { h.nnz = 0; h.off = 0; }
 	return MSC_OK;
@@ -175,6 +206,50 @@ extern "C" int msc_hist_unpack(msc_ctx* ctx, msc_hist_set* set, const uint32_t* 
 	const uint8_t* src = (const uint8_t*)dev_src;
 	const uint64_t sc = up16(set->scalar_stride);
 	int r;
+	if (n == 1) {
+		// one slot: head, scalar record and sub-range table in ONE copy to the host (the only wait), the payload by device copies
+		if (slots[0] >= set->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_unpack: slot out of range");
+		if (offsets[0] & 15) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_unpack: offsets must be multiples of 16");
+		const uint8_t* o = src + offsets[0];
+		const uint64_t front = sizeof(PackHead) + sc + (set->sparse ? kSplitBytes : 0);
+		std::vector<uint8_t> hh(front);
+		HIP_TRY(ctx, hipMemcpyAsync(hh.data(), o, front, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		PackHead ph;
+		memcpy(&ph, hh.data(), sizeof ph);
+		if (ph.kind != (set->sparse ? kPackSparse : kPackDense)) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_unpack: the packed slot is not of this set's layout");
+		const uint32_t slot = slots[0];
+		HIP_TRY(ctx, hipMemcpyAsync(set->scalars + (uint64_t)slot * set->scalar_stride, o + sizeof(PackHead), set->scalar_stride, hipMemcpyDeviceToDevice, ctx->stream));
+		if (!set->sparse) {
+			if (ph.bytes != packed_bytes(set, slot)) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_unpack: packed slot of another k or bin type");
+			HIP_TRY(ctx, hipMemcpyAsync(set->bins + (uint64_t)slot * set->L.slot_bytes, o + sizeof(PackHead) + sc, set->L.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+		} else {
+			if (set->ent_used + ph.nnz > set->ent_capacity) return fail(ctx, MSC_ERR_OOM, "sparse set entry arena exhausted (%llu of %llu entries used, %u more needed)",
+			                                                            (unsigned long long)set->ent_used, (unsigned long long)set->ent_capacity, ph.nnz);
+			MscSparseHdr h{};
+			h.off = set->ent_used;
+			h.nnz = ph.nnz;
+			memcpy(h.split, hh.data() + sizeof(PackHead) + sc, sizeof h.split);
+			if (h.split[MSC_SPARSE_SUB] != ph.nnz) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_hist_unpack: corrupt list header");
+			const uint8_t* p = o + sizeof(PackHead) + sc + kSplitBytes;
+			if (ph.nnz) {
+				HIP_TRY(ctx, hipMemcpyAsync(set->ent + h.off, p, (uint64_t)ph.nnz * 8, hipMemcpyDeviceToDevice, ctx->stream));
+				HIP_TRY(ctx, hipMemcpyAsync(set->cum + h.off, p + up16((uint64_t)ph.nnz * 8), (uint64_t)ph.nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			}
+			set->ent_used += ph.nnz;
+			set->hdr_host[slot] = h;          // (the mirror outlives the copy below: it is the source)
+			HIP_TRY(ctx, hipMemcpyAsync(set->hdr + slot, &set->hdr_host[slot], sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
+			set->max_nnz = std::max(set->max_nnz, h.nnz);
+		}
+		// bounds and length from the scalar record that came with the head: no second read-back
+		MscSlotScalars rec;
+		memcpy(&rec, hh.data() + sizeof(PackHead), sizeof rec);
+		mark_written(set, slot, 1);
+		set->max_count = std::max(set->max_count, rec.max_count);
+		set->max_sum = std::max(set->max_sum, rec.sum);
+		learn_length(set, slot, rec.length);
+		return MSC_OK;
+	}
 	// 1. the heads (and, for lists, the sub-range tables) come to the host: list lengths decide where the entries go
 	const uint64_t hb = sizeof(PackHead) + (set->sparse ? kSplitBytes : 0);
 	std::vector<CopySeg> segs;

@@ -851,8 +851,9 @@ __device__ __forceinline__ void mp_split(uint32_t d, uint32_t nc, uint32_t nq, C
 // PAIRS (the batched update stage on sparse sets, msc_update_centres / msc_merge_all): every candidate has its OWN query -- slot
 // segs[pair_seg[c]].q_slot behind q_hdr_p, with that segment's length window -- instead of the one query of a 1 x M pass.
 constexpr uint32_t kMpDivGran = 4;      // chunks per divergence record (see the DIV comment inside the kernel)
-template <bool DIV, uint32_t kMpT, bool PAIRS = false>
-__global__ void __launch_bounds__(256) k_pair_sparse_mp(
+constexpr uint32_t kMpTab = 8;          // side of the divergence-term table in LDS
+template <bool DIV, uint32_t kMpT, bool PAIRS = false, int WPE = 1>
+__global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
     const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
     const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
@@ -862,10 +863,13 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
     uint32_t div_stride = 1) {
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
-	// DIV: the candidate's 16 x 16 table of terms, already relative to the (1, 1) term, in wave-private LDS -- the walk looks one
-	// entry up per event, and a lookup in global memory (a dependent L2 round trip per step of a serial walk, 4 waves per SIMD to
-	// hide it) was what bounded this form (r03: 124 G merged entries/s against 415 G for the integer form)
-	__shared__ DivTerm s_tab[DIV ? 4 : 1][DIV ? 256 : 1];
+	// DIV: the 8 x 8 corner of the candidate's table of terms (counts below 8: all but the k-mers of repeats), already relative to the
+	// (1, 1) term, in wave-private LDS -- the walk looks one entry up per event, and a lookup in global memory (a dependent L2 round
+	// trip per step of a serial walk) was what bounded this form (r03: 124 G merged entries/s against 415 G for the integer form).
+	// 1 KiB per wave keeps 6-7 workgroups per CU; WPE = the waves per SIMD the register allocator is held to (the direct evaluation
+	// of a large count -- three FP64 logs -- is what inflates the kernel to 106 VGPRs; at 80 it spills a few values around that
+	// cold path instead)
+	__shared__ DivTerm s_tab[DIV ? 4 : 1][DIV ? kMpTab * kMpTab : 1];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint2* buf = s_buf[wave];
 	MscSparseHdr qh = PAIRS ? MscSparseHdr{} : *q_hdr_p;
@@ -905,10 +909,10 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 		if constexpr (DIV) {
 			cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order);
 			__builtin_amdgcn_wave_barrier();          // the previous candidate's walk is over
-#pragma unroll
-			for (uint32_t e = lane; e < 256; e += 64) {
-				const DivTerm g = div_tables[(uint64_t)c * 256 + e];
-				s_tab[wave][e] = DivTerm{g.jd - t11.jd, g.js - t11.js};
+			static_assert(kMpTab * kMpTab == 64, "one table entry per lane");
+			{
+				const DivTerm g = div_tables[(uint64_t)c * 256 + (lane / kMpTab) * 16 + (lane % kMpTab)];
+				s_tab[wave][lane] = DivTerm{g.jd - t11.jd, g.js - t11.js};
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -1000,7 +1004,7 @@ __global__ void __launch_bounds__(256) k_pair_sparse_mp(
 					D += (int32_t)pv - (int32_t)qv;
 					if constexpr (DIV) {
 						DivTerm tt;
-						if ((pv | qv) < 16u) tt = s_tab[wave][pv * 16 + qv];
+						if ((pv | qv) < kMpTab) tt = s_tab[wave][pv * kMpTab + qv];
 						else { tt = div_term_sp(pv, qv, cm, qm, order); tt.jd -= t11.jd; tt.js -= t11.js; }
 						jd += tt.jd;
 						js += tt.js;
@@ -1268,6 +1272,7 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 	return hipGetLastError();
 }
 
+int msc_sparse_div_waves();
 uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
 
 // 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this merge wants (r01: k=9/5 kb lists 43 M pairs/s at 512,
@@ -1301,14 +1306,16 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 		                                                     c_max_nnz, nbins, use_window, min_len, max_len, partials);
 		return hipGetLastError();
 	}
-	const uint32_t per_cu = div_tables ? 4 : std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
+	const int wpe = msc_sparse_div_waves();
+	const uint32_t per_cu = div_tables ? (uint32_t)wpe : std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
 	const uint64_t waves = (uint64_t)m * parts;
 	uint32_t blocks = (uint32_t)num_cus * per_cu;
 	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
 	if (div_tables) {
-		k_pair_sparse_mp<true, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
-		                                                                     q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials,
-		                                                                     (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride);
+#define MSC_MP_DIV(W) k_pair_sparse_mp<true, kMpChunk, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
+		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride)
+		if (wpe == 4) MSC_MP_DIV(4); else if (wpe == 7) MSC_MP_DIV(7); else MSC_MP_DIV(6);
+#undef MSC_MP_DIV
 	} else {
 		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
@@ -1323,11 +1330,16 @@ bool msc_sparse_wl_fits(uint32_t q_nnz, uint32_t c_max_nnz) {
 	static const bool no_wl = getenv("MSC_SPARSE_NO_WL") != nullptr;
 	return !no_wl && c_max_nnz && (uint64_t)q_nnz + 4ull * c_max_nnz + 10 <= 8192;
 }
+// waves per SIMD the divergence form of the merge-path kernel is compiled for and launched at (MSC_SPARSE_DIV_WAVES=4|6|7 for A/B runs)
+int msc_sparse_div_waves() {
+	static const int w = [] { const char* e = getenv("MSC_SPARSE_DIV_WAVES"); const int v = e ? atoi(e) : 6; return v == 4 || v == 7 ? v : 6; }();
+	return w;
+}
 uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div) {
 	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
 	if (off || m == 0) return 1;
 	// (the divergence form holds fewer waves per SIMD and cuts between granules: a part keeps at least one granule)
-	const uint64_t slots = (uint64_t)num_cus * (div ? 16 : 32), chunks = entries / kMpChunk, per_part = div ? kMpDivGran : 2;
+	const uint64_t slots = (uint64_t)num_cus * (div ? 4 * msc_sparse_div_waves() : 32), chunks = entries / kMpChunk, per_part = div ? kMpDivGran : 2;
 	uint32_t parts = 1;
 	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * per_part <= chunks) parts *= 2;
 	return parts;
@@ -1373,9 +1385,13 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 		k_sparse_div_tables<<<dim3(m), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables, segs, pair_seg, q_scalar_stride);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
-		k_pair_sparse_mp<true, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
-		                                                                   q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials,
-		                                                                   order, segs, pair_seg, 1, q_scalar_stride, div_stride);
+		const int wpe = msc_sparse_div_waves();
+		blocks = (uint32_t)num_cus * (uint32_t)wpe;
+		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
+#define MSC_MP_DIVP(W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
+		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride)
+		if (wpe == 4) MSC_MP_DIVP(4); else if (wpe == 7) MSC_MP_DIVP(7); else MSC_MP_DIVP(6);
+#undef MSC_MP_DIVP
 		return hipGetLastError();
 	}
 	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -80,7 +81,7 @@ class LengthBins {
 public:
 	struct Item { SeqRecord* rec; bool marked; uint32_t fixed = 0; };      // fixed = position in the sealed store (never changes)
 	struct Pos { size_t bin = 0, at = 0; bool none = false; };          // bvec_idx_t
-	typedef std::vector<Item> Bin;
+	typedef std::deque<Item> Bin;         // (bvec::pop takes the front record of a bin: equal-length inputs pop a million times from one bin)
 
 	LengthBins(std::vector<uint64_t> lengths, uint64_t per_bin) {         // bvec.cpp:10-24
 		std::sort(lengths.begin(), lengths.end());

@@ -1676,7 +1676,7 @@ def test_multi_rank_cluster_driver_k13_u64_sparse(tmp_path, ranks):
     rcs, log, logs = _cluster_ranks(common + [out], ranks, tmp_path, block=8)
     assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
     a, b = open(one, "rb").read(), open(out, "rb").read()
-    assert a.count(b">Cluster") >= 10 and a == b
+    assert a == b and a.count(b">Cluster") >= 2, a.count(b">Cluster")
 
 
 def test_bench_two_ranks_packed_exchange(tmp_path):
