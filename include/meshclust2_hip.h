@@ -338,6 +338,18 @@ int msc_train_class(msc_ctx* ctx, const msc_hist_set* pts, const uint32_t* first
                     uint64_t n_train, uint64_t n_test, uint64_t feat_flags, int min_feat, int max_feat, double id, char* text_out, size_t cap,
                     double* train_acc, double* test_acc);
 
+/* The regression half of Predictor<T>::train (predict/Predictor.cpp:977-985 train_regr -> GreedySelector<T>::train_regression,
+ * predict/GreedySelector.cpp:11-76): the model fastcar's work() reads identities from (Predictor::similarity -> p_predict, :284-300).
+ * Same inputs as msc_train_class; vals are the identity labels the least-squares fit predicts. Greedy forward selection over the
+ * candidates of Predictor::add_feats: at most max_feat rounds, a round keeps the candidate with the smallest mean absolute error over the
+ * TESTING pairs if that beats every earlier round. text_out: a complete weights file with `mode: 2` (msc_model_parse(text, 1) reads
+ * the block); train_err / test_err: mean |prediction - label| of the final fit. The reference's own function cannot run to its end
+ * (no return statement: `fastcar --dump` dies there); oracle/ref_harness.cpp follows its body on the reference's objects and
+ * tests/golden/train_regr_*.json holds the result. */
+int msc_train_regr(msc_ctx* ctx, const msc_hist_set* pts, const uint32_t* first_slots, const uint32_t* second_slots, const double* vals,
+                   uint64_t n_train, uint64_t n_test, uint64_t feat_flags, int max_feat, double id, char* text_out, size_t cap,
+                   double* train_err, double* test_err);
+
 /* ------------------------------------------------------------------ multi-GPU plumbing
  * Raw device views so that a caller that owns an RCCL communicator (torch.distributed / rccl.h) can broadcast a
  * query or all-gather centroid histograms between the per-GPU processes without a host bounce.

@@ -425,6 +425,18 @@ def train_class(ctx, points, first_slots, second_slots, vals, n_train, feat_flag
     return buf.value.decode(), a.value, b.value
 
 
+def train_regr(ctx, points, first_slots, second_slots, vals, n_train, feat_flags, max_feat, ident):
+    """Predictor::train_regr's greedy selection + GLM on labelled pairs -> (weights file text (mode 2), training error, testing error)"""
+    fs = np.ascontiguousarray(first_slots, dtype=np.uint32)
+    ss = np.ascontiguousarray(second_slots, dtype=np.uint32)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    buf = C.create_string_buffer(1 << 16)
+    a, b = C.c_double(), C.c_double()
+    ctx.check(ctx.lib.msc_train_regr(ctx.h, points.h, _ptr(fs), _ptr(ss), _ptr(va), n_train, fs.size - n_train, feat_flags, max_feat, ident, buf, len(buf),
+                                     C.byref(a), C.byref(b)))
+    return buf.value.decode(), a.value, b.value
+
+
 def mean_nearest(ctx, points, member_slots, m=None, want_mean=False):
     return Trainer(ctx, None, 1.0).closest(points, member_slots, m, want_mean)
 

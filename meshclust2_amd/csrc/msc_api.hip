@@ -352,7 +352,7 @@ extern "C" int msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64
 	s->scalar_stride = sizeof(MscSlotScalars);
 	s->ent_capacity = max_entries;
 	hipError_t e = hipMalloc((void**)&s->scalars, s->scalar_stride * capacity);
-	if (e == hipSuccess) e = hipMalloc((void**)&s->ent, max_entries * sizeof(uint2));
+	if (e == hipSuccess) e = hipMalloc((void**)&s->ent, (max_entries + 2) * sizeof(uint2));      // (+2: the merge kernel stages lists two entries at a time)
 	if (e == hipSuccess) e = hipMalloc((void**)&s->cum, max_entries * sizeof(uint32_t));
 	if (e == hipSuccess) e = hipMalloc((void**)&s->hdr, capacity * sizeof(MscSparseHdr));
 	if (e == hipSuccess) e = hipMemsetAsync(s->scalars, 0, s->scalar_stride * capacity, ctx->stream);
@@ -2278,7 +2278,12 @@ int sparse_acc_scatter(msc_ctx* ctx, const msc_hist_set* src, const uint32_t* sl
 int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const uint32_t* m_of, int value_bits, uint32_t* touched, uint64_t* floor_sum_out) {
 	const MscLayout& L = pts->L;
 	int r;
-	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	// a wave per (list, chunk of bins): many lists bring their own parallelism, and every chunk costs 24 bytes of counts to the host and
+	// 16 bytes of offsets back -- with 1024 chunks each, a round over a million centres (BASELINE cfg3) moved 40 GB over PCIe and spent
+	// its time in the loops below (r03 profile, 200 000 x 1 kb: 24 s of update stage around 2.7 s of kernels). About 65 536 waves in
+	// all; at least 16 chunks (one per index sub-range), a power of two.
+	uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	while (n_chunks > MSC_SPARSE_SUB && (uint64_t)n_chunks * nc > 65536) n_chunks /= 2;
 	const uint64_t chunk_bins = L.nbins / n_chunks;
 	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
 	if ((r = ensure(ctx, ctx->qslots, nc * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_counts, (size_t)nc * n_chunks * 3 * sizeof(uint64_t))) ||

@@ -850,6 +850,32 @@ __device__ __forceinline__ void mp_split(uint32_t d, uint32_t nc, uint32_t nq, C
 
 // PAIRS (the batched update stage on sparse sets, msc_update_centres / msc_merge_all): every candidate has its OWN query -- slot
 // segs[pair_seg[c]].q_slot behind q_hdr_p, with that segment's length window -- instead of the one query of a 1 x M pass.
+// `count` 8-byte entries from global memory (src: wave-uniform, 8-byte aligned) straight into LDS at byte address lds_dst, two per lane
+// and instruction (global_load_lds_dwordx4: no destination registers, no load -> store round trip through the VALU); an odd count
+// copies one entry more. The caller waits (vmcnt) before it reads.
+__device__ __forceinline__ void mp_stage_dma(const uint2* src, uint32_t count, uint32_t lds_dst, uint32_t lane) {
+	// (wave-uniform values the compiler cannot prove uniform: through readfirstlane into scalar registers)
+	const uint64_t sbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)src) |
+	                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)src >> 32)) << 32);
+	const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
+	count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
+	for (uint32_t t = 0; t * 128 < count; t++) {
+		if (t * 128 + lane * 2 < count) {
+			const uint32_t off = t * 2048 + lane * 16, dst = lds0 + t * 2048;
+			uint32_t keep;
+			asm volatile(
+			    "s_mov_b32 %0, m0\n\t"
+			    "s_mov_b32 m0, %3\n\t"
+			    "s_nop 0\n\t"
+			    "global_load_lds_dwordx4 %1, %2\n\t"
+			    "s_mov_b32 m0, %0"
+			    : "=&s"(keep)
+			    : "v"(off), "s"(sbase), "s"(dst)
+			    : "memory");
+		}
+	}
+}
+
 constexpr uint32_t kMpDivGran = 4;      // chunks per divergence record (see the DIV comment inside the kernel)
 constexpr uint32_t kMpTab = 8;          // side of the divergence-term table in LDS
 template <bool DIV, uint32_t kMpT, bool PAIRS = false, int WPE = 1>
@@ -860,7 +886,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
     const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0,
-    uint32_t div_stride = 1) {
+    uint32_t div_stride = 1, bool dma = false) {
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
 	// DIV: the 8 x 8 corner of the candidate's table of terms (counts below 8: all but the k-mers of repeats), already relative to the
@@ -944,13 +970,19 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 			const uint32_t q0 = __builtin_amdgcn_readlane(qj, tl), q1 = __builtin_amdgcn_readlane(qj, tl + 1);
 			const uint32_t nc = c1 - c0, nq = q1 - q0;
 			uint2* cl = buf;                     // cl[0] = predecessor of the piece (or a neutral entry), cl[1 + k] = P[c0 + k]
-			uint2* ql = buf + nc + 2;
+			uint2* ql = buf + ((nc + 3) & ~1u);  // (behind cl[0 .. nc + 1], on a 16-byte boundary like buf: the DMA writes 16 bytes per lane)
 			__builtin_amdgcn_wave_barrier();     // every lane is done with the previous chunk's entries
 			// (a plain load / store loop per piece: the kernel is bound by vector-instruction issue at 8 waves per SIMD, which hide the
 			// latency of these loads; staging through registers with every load of the chunk in flight, a chunk ahead, shortens a lone
 			// wave's chunk by 20 % but costs more instructions and two waves per SIMD -- 12 % slower once the chip is full)
-			for (uint32_t k = lane; k <= nc; k += 64) cl[k] = (c0 + k) ? P[c0 + k - 1] : make_uint2(0u, 1u);
-			for (uint32_t k = lane; k <= nq; k += 64) ql[k] = (q0 + k) ? Q[q0 + k - 1] : make_uint2(0u, 1u);
+			// LDS-DMA: a piece and its predecessor entry go from the list to the stage without passing through registers (r02: the load ->
+			// store loops were 37 % of this kernel at k = 13). A piece that STARTS its list has no predecessor in memory (and its entries
+			// would land 8 bytes off the DMA's 16-byte grid): the first chunk of either list keeps the loop.
+			if (dma && c0) mp_stage_dma(P + c0 - 1, nc + 1, (uint32_t)(uintptr_t)cl, lane);
+			else for (uint32_t k = lane; k <= nc; k += 64) cl[k] = (c0 + k) ? P[c0 + k - 1] : make_uint2(0u, 1u);
+			if (dma && q0) mp_stage_dma(Q + q0 - 1, nq + 1, (uint32_t)(uintptr_t)ql, lane);
+			else for (uint32_t k = lane; k <= nq; k += 64) ql[k] = (q0 + k) ? Q[q0 + k - 1] : make_uint2(0u, 1u);
+			if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			// one entry past either piece: a bin index no share reaches, so a lane that runs off the end of a piece stops by itself
 			if (lane == 0) { cl[nc + 1] = make_uint2(kInf, 1u); ql[nq + 1] = make_uint2(kInf, 1u); }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1273,6 +1305,11 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 }
 
 int msc_sparse_div_waves();
+// the chunks of the merge-path kernel are staged by LDS-DMA (MSC_SPARSE_MP_NO_DMA=1: the load -> store loop of r02, for A/B runs)
+bool msc_sparse_mp_dma() {
+	static const bool on = getenv("MSC_SPARSE_MP_NO_DMA") == nullptr;
+	return on;
+}
 uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
 
 // 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this merge wants (r01: k=9/5 kb lists 43 M pairs/s at 512,
@@ -1313,13 +1350,13 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
 	if (div_tables) {
 #define MSC_MP_DIV(W) k_pair_sparse_mp<true, kMpChunk, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
-		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride)
+		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride, msc_sparse_mp_dma())
 		if (wpe == 4) MSC_MP_DIV(4); else if (wpe == 7) MSC_MP_DIV(7); else MSC_MP_DIV(6);
 #undef MSC_MP_DIV
 	} else {
 		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
-		                                                                      nullptr, nullptr, parts);
+		                                                                      nullptr, nullptr, parts, 0, 1, msc_sparse_mp_dma());
 	}
 	return hipGetLastError();
 }
@@ -1389,13 +1426,13 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 		blocks = (uint32_t)num_cus * (uint32_t)wpe;
 		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
 #define MSC_MP_DIVP(W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
-		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride)
+		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride, msc_sparse_mp_dma())
 		if (wpe == 4) MSC_MP_DIVP(4); else if (wpe == 7) MSC_MP_DIVP(7); else MSC_MP_DIVP(6);
 #undef MSC_MP_DIVP
 		return hipGetLastError();
 	}
 	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
-	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg);
+	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg, 1, 0, 1, msc_sparse_mp_dma());
 	return hipGetLastError();
 }
 

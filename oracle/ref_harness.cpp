@@ -319,6 +319,83 @@ long train_class(void** first, void** second, const double* val, int n_train, in
 	return (long)text.size();
 }
 
+// Predictor<T>::train_regr (predict/Predictor.cpp:977-985) on caller-supplied labelled pairs. It hands the work to
+// GreedySelector<T>::train_regression (predict/GreedySelector.cpp:11-76), which cannot be CALLED: the function falls off its end
+// without a return statement (its caller then destroys a pair<Feature*, GLM> that was never written -- the std::bad_cast /
+// crash of `fastcar --dump`). So its body is followed here step by step on the reference's own objects and primitives --
+// Feature<T>::remove_feature / add_feature / normalize / finalize, FeatureSelector<T>::regression_train / regression_test
+// (predict/FeatureSelector.cpp:41-55,77-89), the candidate list of Predictor<T>::add_feats -- and what its last lines compute
+// (feat_r, r_glm) is printed by Predictor<T>::write_to. Returns the text length, or -1; err_out = {training, testing} mean errors.
+template <class T>
+long train_regr(void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int max_feat, char* out, long cap,
+                double* err_out) {
+	std::vector<pra<T> > training, testing;
+	for (int i = 0; i < n_train + n_test; i++) {
+		pra<T> pr((Point<T>*)first[i], (Point<T>*)second[i], val[i]);
+		(i < n_train ? training : testing).push_back(pr);
+	}
+	std::vector<std::pair<uint64_t, Combo> > possible_feats;
+	Predictor<T>* bare = static_cast<Predictor<T>*>(::operator new(sizeof(Predictor<T>)));      // add_feats touches no member
+	bare->add_feats(possible_feats, feat_flags);
+	::operator delete(bare);
+	Feature<T> feat_obj(k);
+	Feature<T>* feat = &feat_obj;
+	feat->set_save(true);
+	for (uint64_t i = 1; i <= feat_flags; i *= 2) if (i & feat_flags) feat->add_feature(i, Combo::xy);      // Predictor<T>::train, :881-894
+	feat->normalize(training);
+	feat->normalize(testing);
+	feat->finalize();
+	// ---- GreedySelector<T>::train_regression, :14-52
+	const int max_num_feat = max_feat;
+	auto c_size = feat->get_combos().size();
+	for (size_t i = 0; i < c_size; i++) feat->remove_feature();
+	std::vector<uintmax_t> used_list;
+	double abs_best_regr = 1000000;
+	for (auto num_feat = 1; num_feat <= max_num_feat; num_feat++) {
+		double best_regr_err = abs_best_regr;
+		uintmax_t best_idx = -1;
+		auto best_regr_feat = possible_feats.front();
+		for (uint64_t i = 0; i < possible_feats.size(); i++) {
+			if (std::find(used_list.begin(), used_list.end(), i) != used_list.end()) continue;
+			auto rfeat = possible_feats[i];
+			feat->add_feature(rfeat.first, rfeat.second);
+			feat->normalize(training);
+			feat->finalize();
+			auto pr = FeatureSelector<T>::regression_train(training, *feat);
+			double regr_mse = FeatureSelector<T>::regression_test(testing, *feat, pr.second);
+			feat->remove_feature();
+			if (regr_mse < best_regr_err) { best_regr_err = regr_mse; best_regr_feat = rfeat; best_idx = i; }
+		}
+		if (best_regr_err < abs_best_regr) {
+			feat->add_feature(best_regr_feat.first, best_regr_feat.second);
+			feat->normalize(training);
+			feat->finalize();
+			abs_best_regr = best_regr_err;
+			used_list.push_back(best_idx);
+		}
+	}
+	Feature<T>* feat_r = new Feature<T>(*feat);      // :55-58
+	feat_r->set_save(false);
+	auto pr = FeatureSelector<T>::regression_train(training, *feat_r);
+	matrix::GLM r_glm = pr.second;
+	if (err_out) { err_out[0] = pr.first; err_out[1] = FeatureSelector<T>::regression_test(testing, *feat_r, r_glm); }
+	const std::string path = "/tmp/msc_ref_regr_" + std::to_string((long)omp_get_wtime()) + "_" + std::to_string((long)(uintptr_t)out) + ".txt";
+	{
+		std::ofstream ofs(path);
+		Predictor<T>* writer = static_cast<Predictor<T>*>(::operator new(sizeof(Predictor<T>)));
+		writer->write_to(ofs, feat_r, r_glm);
+		::operator delete(writer);
+	}
+	std::ifstream ifs(path);
+	std::stringstream ss;
+	ss << ifs.rdbuf();
+	std::remove(path.c_str());
+	const std::string text = ss.str();
+	if ((long)text.size() + 1 > cap) return -1;
+	memcpy(out, text.c_str(), text.size() + 1);
+	return (long)text.size();
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, expr8, expr16, expr32, expr64) \
@@ -520,6 +597,17 @@ void ref_host_inverse(uint64_t n, const double* a, double* out) {
 	matrix::Matrix r = m.gaussJordanInverse();
 	std::cout.rdbuf(keep);
 	for (uint64_t i = 0; i < n; i++) for (uint64_t j = 0; j < n; j++) out[i * n + j] = r.get((int)i, (int)j);
+}
+
+long ref_train_regr(int dtype, void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int max_feat, char* out, long cap,
+                    double* err_out) {
+	try {
+		DISPATCH(dtype, return train_regr<uint8_t>(first, second, val, n_train, n_test, k, feat_flags, max_feat, out, cap, err_out),
+		         return train_regr<uint16_t>(first, second, val, n_train, n_test, k, feat_flags, max_feat, out, cap, err_out),
+		         return train_regr<uint32_t>(first, second, val, n_train, n_test, k, feat_flags, max_feat, out, cap, err_out),
+		         return train_regr<uint64_t>(first, second, val, n_train, n_test, k, feat_flags, max_feat, out, cap, err_out));
+	} catch (...) { return -2; }
+	return -1;
 }
 
 long ref_train_class(int dtype, void** first, void** second, const double* val, int n_train, int n_test, int k, uint64_t feat_flags, int min_feat,

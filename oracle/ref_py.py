@@ -53,6 +53,9 @@ def lib():
         L.ref_train_class.restype = C.c_long
         L.ref_train_class.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                       C.c_double, C.c_char_p, C.c_long, C.POINTER(C.c_double)]
+        L.ref_train_regr.restype = C.c_long
+        L.ref_train_regr.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.c_long,
+                                     C.POINTER(C.c_double)]
         L.ref_time_pairs.restype = C.c_double
         L.ref_time_pairs.argtypes = [C.c_int, vp, C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_double)]
         _lib = L
@@ -175,3 +178,19 @@ def train_class(dtype, k, first, second, vals, n_train, feat_flags, min_feat, ma
     if r < 0:
         raise RuntimeError("reference training failed (%d)" % r)
     return buf.value.decode(), acc[0], acc[1]
+
+
+def train_regr(dtype, k, first, second, vals, n_train, feat_flags, max_feat):
+    """GreedySelector::train_regression followed on the reference's own objects (oracle/ref_harness.cpp train_regr) on labelled pairs
+    -> (regression block of the weights file as text, training mean error, testing mean error)"""
+    n = len(first)
+    vp = C.c_void_p
+    fa = (vp * n)(*[p.h for p in first])
+    sa = (vp * n)(*[p.h for p in second])
+    va = (C.c_double * n)(*[float(v) for v in vals])
+    buf = C.create_string_buffer(1 << 16)
+    err = (C.c_double * 2)()
+    r = lib().ref_train_regr(dtype, fa, sa, va, n_train, n - n_train, k, feat_flags, max_feat, buf, len(buf), err)
+    if r < 0:
+        raise RuntimeError("reference regression training failed (%d)" % r)
+    return buf.value.decode(), err[0], err[1]

@@ -426,6 +426,43 @@ def make_vectors_k13():
     print("wrote vectors_k13_u64.npz", os.path.getsize(os.path.join(HERE, "vectors_k13_u64.npz")), "bytes")
 
 
+def make_training_regr(name, seed, k, dtype, feat_flags, max_feat, ident, n_templates=40, per_template=12, length=1000):
+    """Predictor<T>::train_regr's selection (GreedySelector::train_regression, followed on the REAL reference's objects: oracle/ref_harness.cpp
+    train_regr -- the function itself has no return statement and cannot be run to its end) on labelled pairs with identity above `ident`
+    (Predictor::train keeps those for the regression, predict/Predictor.cpp:923-927) -> tests/golden/<name> (inputs + the block it printed)"""
+    ref_py.lib().ref_set_threads(1)
+    seqs, pairs = training_set(seed, n_templates, per_template, length)
+    pairs = [p for p in pairs if p[2] > ident]
+    pts = [ref_py.Point(dtype, s_, k) for s_ in seqs]
+    n_train = len(pairs) // 2
+    text, etr, ete = ref_py.train_regr(dtype, k, [pts[a] for a, b, v in pairs], [pts[b] for a, b, v in pairs], [v for a, b, v in pairs], n_train, feat_flags, max_feat)
+    json.dump(dict(seed=seed, k=k, dtype=dtype, feat_flags=feat_flags, max_feat=max_feat, id=ident, n_templates=n_templates, per_template=per_template,
+                   length=length, n_train=n_train, pairs=[[a, b, v] for a, b, v in pairs], block=text, train_err=etr, test_err=ete),
+              open(os.path.join(HERE, name), "w"))
+    print("wrote", name, "train/test mean error", etr, ete)
+    return text
+
+
+def make_regr_weights_and_fastcar():
+    """A `mode: 3` weights file whose BOTH blocks were printed by the reference: the classification block of weights_k5_u16.txt (trained by
+    the reference CLI) + the regression block of train_regr_k5_u16.json (above); and the reference fastcar's output with it on the same
+    database / query files as fastcar_k5_u16.out."""
+    block = json.load(open(os.path.join(HERE, "train_regr_k5_u16.json")))["block"]
+    cls = weights_with_mode(open(os.path.join(HERE, "weights_k5_u16.txt")).read(), 1)
+    text = cls.replace("mode: 1", "mode: 3").rstrip("\n") + "\n" + block
+    open(os.path.join(HERE, "weights_k5_u16_regr.txt"), "w").write(text)
+    tmp = tempfile.mkdtemp()
+    db, h, q, hq = fastcar_sets()
+    synth.write_fasta(os.path.join(tmp, "db.fa"), db, h)
+    synth.write_fasta(os.path.join(tmp, "q.fa"), q, hq)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fastcar"), "db.fa", "--query", "q.fa", "--recover", os.path.join(HERE, "weights_k5_u16_regr.txt"),
+                    "--output", "fc_out", "--threads", "1"], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, check=True)
+    shutil.copy(os.path.join(tmp, "fc_out0"), os.path.join(HERE, "fastcar_k5_u16_regr.out"))
+    shutil.rmtree(tmp)
+    print("wrote weights_k5_u16_regr.txt and fastcar_k5_u16_regr.out")
+
+
 FAST_FLAGS = sum(1 << b for b in (2, 3, 5, 9, 13, 18, 21, 27, 28))
 SLOW_FLAGS = FAST_FLAGS | (1 << 7) | (1 << 29)
 
@@ -445,6 +482,8 @@ if __name__ == "__main__":
     make_training("train_k5_u16.json", 31, 5, 16, FAST_FLAGS, 4, 4, 0.9)
     make_training("train_k7_u8_slow.json", 32, 7, 8, SLOW_FLAGS, 2, 3, 0.8, n_templates=30, per_template=10, length=600)
     make_training("train_k9_u32.json", 33, 9, 32, FAST_FLAGS, 3, 4, 0.9, n_templates=24, per_template=10)
+    make_training_regr("train_regr_k5_u16.json", 41, 5, 16, FAST_FLAGS, 4, 0.7)
+    make_training_regr("train_regr_k7_u8_slow.json", 42, 7, 8, SLOW_FLAGS, 3, 0.75, n_templates=30, per_template=10, length=600)
     make_mixed_clstr()
     make_mixed_slow_clstr()
     make_k9_auto_clstr()
@@ -454,6 +493,7 @@ if __name__ == "__main__":
     make_vectors("vectors_k5_u16_slow.npz", "weights_k5_u16_slow.txt", 15, 12, 1000, 5, 16, extra=NASTY)
     make_fastcar_output()
     make_fastcar_mode_outputs()
+    make_regr_weights_and_fastcar()
     make_cfg5_clstr()
     make_cfg5_u16_clstr()
     make_k8_clstr()

@@ -1108,6 +1108,61 @@ def test_training_selects_the_reference_model(ctx, fixture):
     assert np.all(np.isfinite(r["sum"]))
 
 
+@pytest.mark.parametrize("fixture", ["train_regr_k5_u16.json", "train_regr_k7_u8_slow.json"])
+def test_regression_training_selects_the_reference_model(ctx, fixture):
+    """msc_train_regr (Predictor<T>::train_regr -> GreedySelector<T>::train_regression, predict/Predictor.cpp:977-985, predict/GreedySelector.cpp:11-76)
+    on the labelled pairs of a fixture: the SAME combos in the same order of acceptance, the same single features and bounds, weights
+    within 1e-6 and the same mean errors as the reference's own objects gave (oracle/ref_harness.cpp follows the body of its selector,
+    which cannot be run to its end); the text loads as the regression block of a model and predicts inside [0, 1]."""
+    import json
+    import os
+    from golden_util import GOLDEN, parse_class_block, training_set
+    fx = json.load(open(os.path.join(GOLDEN, fixture)))
+    seqs, pairs = training_set(fx["seed"], fx["n_templates"], fx["per_template"], fx["length"])
+    pairs = [p for p in pairs if p[2] > fx["id"]]
+    assert [[a, b] for a, b, _ in pairs] == [[a, b] for a, b, _ in fx["pairs"]]
+    pts = api.HistogramSet(ctx, fx["k"], fx["dtype"], len(seqs))
+    pts.build(seqs)
+    text, etr, ete = api.train_regr(ctx, pts, [p[0] for p in fx["pairs"]], [p[1] for p in fx["pairs"]], [p[2] for p in fx["pairs"]], fx["n_train"], fx["feat_flags"],
+                                    fx["max_feat"], fx["id"])
+    w0, combos, singles = parse_class_block(text)
+    ew0, ecombos, esingles = parse_class_block(fx["block"])
+    assert [(c, f) for c, f, _ in combos] == [(c, f) for c, f, _ in ecombos]
+    assert [f for f, _, _ in singles] == [f for f, _, _ in esingles]
+    assert w0 == pytest.approx(ew0, rel=1e-6)
+    for (_, _, w), (_, _, ew) in zip(combos, ecombos):
+        assert w == pytest.approx(ew, rel=1e-6)
+    for (_, lo, hi), (_, elo, ehi) in zip(singles, esingles):
+        assert lo == pytest.approx(elo, rel=1e-9, abs=1e-12) and hi == pytest.approx(ehi, rel=1e-9, abs=1e-12)
+    assert etr == pytest.approx(fx["train_err"], rel=1e-8) and ete == pytest.approx(fx["test_err"], rel=1e-8)
+    assert "mode: 2" in text
+    pred = api.Predictor.from_text(ctx, text)          # regression only: every entry close, similarity = clamp(prediction)
+    close, sim = pred.search(pts, np.arange(6, dtype=np.uint32), pts, 0)
+    assert close.all() and np.all((sim >= 0) & (sim <= 1)) and sim[0] > 0.9
+
+
+def test_fastcar_with_a_reference_trained_regression_block(tmp_path):
+    """SURVEY 8(f4) with a `mode: 3` weights file whose two blocks were BOTH printed by the reference (weights_k5_u16_regr.txt: the class
+    block the reference CLI trained + the regression block of train_regr_k5_u16.json; r02's files carry a hand-assembled one):
+    msc_fastcar writes the reference fastcar's own output byte for byte (fastcar/FC_Runner.cpp:426-471)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "meshclust2_amd", "host", "msc_fastcar")
+    db, h = synth.families(41, 300, 1000, family=10, length_jitter=150)
+    q, hq = synth.families(41, 40, 1000, family=10, length_jitter=150)
+    q = [x[:len(x) - 7] for x in q]
+    synth.write_fasta(str(tmp_path / "db.fa"), db, h)
+    synth.write_fasta(str(tmp_path / "q.fa"), q, [x.replace(">seq", ">qry") for x in hq])
+    golden = os.path.join(root, "tests", "golden")
+    r = subprocess.run([exe, "db.fa", "--query", "q.fa", "--recover", os.path.join(golden, "weights_k5_u16_regr.txt"), "--output", "fc_out"],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    got = open(str(tmp_path / "fc_out0"), "rb").read()
+    exp = open(os.path.join(golden, "fastcar_k5_u16_regr.out"), "rb").read()
+    assert got == exp, "fastcar output differs (%d vs %d bytes)" % (len(got), len(exp))
+
+
 def test_fastcar_query_blocks_agree(tmp_path):
     """msc_fastcar scores queries in blocks of 16 length-neighbours through msc_score_multi (one pass over the union of their
     length windows); the output is the same bytes as with one query per pass, and as with an odd block size."""
