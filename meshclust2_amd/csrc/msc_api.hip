@@ -129,6 +129,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->shard_gather) msc_hist_set_destroy(ctx->shard_gather);
 	release(ctx->shard_payload);
 	release(ctx->shard_hdrs);
+	release(ctx->gemm_q8);
+	release(ctx->gemm_out);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
@@ -381,6 +383,7 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
+	if (s->count8 && s->count8 != s->bins) (void)hipFree(s->count8);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
@@ -394,7 +397,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 && s->count8 != s->bins ? s->L.padded_bins : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
@@ -407,6 +410,10 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 	if (s->sp_mirror) {
 		if (s->sm_lo >= s->sm_hi) { s->sm_lo = first; s->sm_hi = first + n; }
 		else { s->sm_lo = std::min(s->sm_lo, first); s->sm_hi = std::max(s->sm_hi, first + n); }
+	}
+	if (s->count8) {
+		if (s->c8_lo >= s->c8_hi) { s->c8_lo = first; s->c8_hi = first + n; }
+		else { s->c8_lo = std::min(s->c8_lo, first); s->c8_hi = std::max(s->c8_hi, first + n); }
 	}
 }
 
@@ -1634,6 +1641,30 @@ static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
+// The count8 mirror of a dense set (msc_dot_gemm.hip): one byte per bin, the B / A operands of the int8 GEMM that takes the products
+// of the Q x M pass. An 8-bit set is its own mirror. MSC_OK with set->count8 == nullptr when it cannot be had: the digest kernel then
+// keeps the products.
+static int ensure_count8(msc_ctx* ctx, const msc_hist_set* set) {
+	if (set->sparse || set->count8_unavailable || set->dtype == 64) return MSC_OK;
+	if (set->dtype == 8) { set->count8 = set->bins; return MSC_OK; }
+	if (!set->count8) {
+		void* p = nullptr;
+		if (hipMalloc(&p, set->L.padded_bins * set->capacity) != hipSuccess) {
+			(void)hipGetLastError();
+			set->count8_unavailable = true;
+			return MSC_OK;
+		}
+		set->count8 = (uint8_t*)p;
+		set->c8_lo = 0;
+		set->c8_hi = set->capacity;
+	}
+	if (set->c8_lo < set->c8_hi) {
+		HIP_TRY(ctx, msc_launch_count8_build(ctx->stream, set->L, set->dtype, set->bins, set->count8, set->c8_lo, set->c8_hi - set->c8_lo));
+		set->c8_lo = set->c8_hi = 0;
+	}
+	return MSC_OK;
+}
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
@@ -1792,6 +1823,16 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
 		digest = cands->digest && qset->digest;
 	}
+	// The products on the matrix cores (msc_dot_gemm.hip): int8 operands, exact int32 sums -- every count <= 127 and count x sum < 2^31
+	// (a product sum is at most max count x sum of the other histogram). Up to 64 queries per call; the form the digest kernel has
+	// without its v_dot4 quarter exists for 8-bit counts and two tiles per step.
+	static const bool no_gemm = getenv("MSC_MULTI_NO_GEMM") != nullptr;
+	bool gemm_dot = digest && !no_gemm && mc_ <= 127 && mc_ * ms_ < (1ull << 31) && n_q <= 64 && msc_digest_tiles_per_step(L, mc_) == 2 && !getenv("MSC_DIGEST_SLOTS") &&
+	                L.nbins == L.padded_bins;
+	if (gemm_dot) {
+		if ((r = ensure_count8(ctx, cands)) || (r = ensure_count8(ctx, qset))) return r;
+		gemm_dot = cands->count8 && qset->count8;
+	}
 	// LDS-DMA ring form over the raw bins: 32/64-bit bins, compact totals, query groups of four or eight
 	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
 	if (!digest && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
@@ -1829,9 +1870,11 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
+	const uint32_t gemm_slices = gemm_dot ? msc_dot_gemm_slices(L.nbins, (uint32_t)chunk, ctx->num_cus) : 0;
+	if (gemm_dot && ((r = ensure(ctx, ctx->gemm_q8, 64 * L.nbins)) || (r = ensure(ctx, ctx->gemm_out, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t))))) return r;
 	const bool count_only = digest && tps == 2 && !need_emd;
-	ctx->last_kernel = digest ? (count_only ? (mc_ < 256 ? "k_pair_digest_multi<u8 counts, no emd>" : "k_pair_digest_multi<u16 counts, no emd>")
-	                                        : (mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>"))
+	ctx->last_kernel = digest ? (count_only ? (gemm_dot ? "k_pair_digest_multi<u8 counts, no emd, dot by mfma>" : mc_ < 256 ? "k_pair_digest_multi<u8 counts, no emd>" : "k_pair_digest_multi<u16 counts, no emd>")
+	                                        : (gemm_dot ? "k_pair_digest_multi<u8 counts, dot by mfma>" : mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>"))
 	                          : ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
 	// the digest kernel's workgroup scores up to 16 queries per candidate tile it fetches; the ring kernel's co-located query
 	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
@@ -1846,7 +1889,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
-			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, need_emd, ctx->partials.p, ctx->num_cus));
+			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, need_emd, ctx->partials.p, ctx->num_cus, !gemm_dot));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
@@ -1854,6 +1897,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+		if (gemm_dot)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
+			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, L.padded_bins, d_slots, off, mc, qset->count8, qset->L.padded_bins,
+			                                 (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p));
 		if (want_div) {
 			if (spk == SPK_MP) HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)n_q * mc * dvn * 16, ctx->stream));
 			for (uint64_t q = 0; q < n_q; q++)
@@ -1887,6 +1933,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
+		if (gemm_dot) { ea.dot_gemm = (const int32_t*)ctx->gemm_out.p; ea.dot_slices = gemm_slices; ea.dot_stride = 64; }
 		ea.S = n_rec;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;

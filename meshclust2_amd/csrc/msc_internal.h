@@ -71,6 +71,8 @@ struct MscEpilogueArgs {
 	const MscPartial* partials;       // [m][S]
 	const void* partials16;           // or: [m][S] records of four u32 {manh, dot, emd, 0} (ring kernel); partials is then unused
 	const void* partials_cq;          // or: [m_per_query][ceil(n_queries/16)][S][16] such records (digest kernel: one 256-byte run per workgroup step)
+	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q])
+	uint32_t dot_slices, dot_stride;
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
 	uint32_t m;
@@ -164,7 +166,12 @@ hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uin
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count);      // 1 or 2 consecutive tiles scored per loop step
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus);
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot = true);
+// the products of the Q x M pass as an int8 GEMM on the matrix cores (msc_dot_gemm.hip)
+hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots);
+uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);
+hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, uint64_t cand_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
+                               const uint8_t* q_count8, uint64_t q_stride, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);

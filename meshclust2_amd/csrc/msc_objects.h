@@ -40,6 +40,7 @@ struct msc_ctx {
 	uint64_t sp_acc_bins = 0;
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
+	DevBuf gemm_q8, gemm_out;              // msc_dot_gemm.hip: the gathered query rows, the products per slice
 	msc_hist_set* shard_gather = nullptr;
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the
 	// launches, and waiting for the stream (printed by msc_destroy)
@@ -61,6 +62,11 @@ struct msc_hist_set {
 	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
 	mutable uint64_t dg_lo = 0, dg_hi = 0;
 	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
+	// count8 mirror (msc_dot_gemm.hip): one byte per bin for the int8 GEMM of the Q x M pass; an 8-bit set is its own mirror.
+	// slots [c8_lo, c8_hi) are stale (kept in step with the digest's range by mark_stale)
+	mutable uint8_t* count8 = nullptr;
+	mutable uint64_t c8_lo = 0, c8_hi = 0;
+	mutable bool count8_unavailable = false;
 	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
 	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
 	mutable msc_hist_set* sp_mirror = nullptr;

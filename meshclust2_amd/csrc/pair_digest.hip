@@ -114,14 +114,17 @@ __device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uin
 // row_half_mirror pairs (l, 7-l), two quad_perms finish the quads. Result: every lane of bank 0 holds the row's manh total,
 // bank 1 dot, bank 2 emd (bank 3: emd again). 9 swaps + 9 adds + 9 DPP operations for the 12 sums.
 // EMD = false: the emd sums are not reduced (banks 2 and 3 then hold manh partials nobody reads).
-template <bool EMD>
+// DOT = false: the dot sums are not reduced either (the products come from the int8 GEMM of msc_dot_gemm.hip; bank 1 then holds a manh
+// partial nobody reads).
+template <bool EMD, bool DOT = true>
 __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint32_t (&dot)[4], const uint32_t (&emd)[4]) {
 	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
 	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
 	auto dpp = [](uint32_t old, uint32_t v, auto ctrl, auto bank) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, decltype(ctrl)::value, 0xf, decltype(bank)::value, false); };
 	using std::integral_constant;
 	const uint32_t A = fold16(fold32(manh[0], manh[2]), fold32(manh[1], manh[3]));
-	const uint32_t C = fold16(fold32(dot[0], dot[2]), fold32(dot[1], dot[3]));
+	uint32_t C = 0;
+	if constexpr (DOT) C = fold16(fold32(dot[0], dot[2]), fold32(dot[1], dot[3]));
 	const integral_constant<int, 0x128> ror8;
 	const integral_constant<int, 0x141> half_mirror;
 	const integral_constant<int, 0xe4> ident;
@@ -129,7 +132,8 @@ __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint
 	const integral_constant<int, 0x4e> swap2;
 	const integral_constant<int, 0xf> all;
 	const uint32_t Xa = A + dpp(0, A, ror8, all);
-	const uint32_t Zc = C + dpp(0, C, ror8, all);
+	uint32_t Zc = 0;
+	if constexpr (DOT) Zc = C + dpp(0, C, ror8, all);
 	uint32_t P = Xa;
 	if constexpr (EMD) {
 		const uint32_t B = fold16(fold32(emd[0], emd[2]), fold32(emd[1], emd[3]));
@@ -137,8 +141,10 @@ __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint
 		P = dpp(Xa, Yb, ident, integral_constant<int, 0xc>());         // lanes 8-15 of every row <- emd
 	}
 	P += dpp(0, P, half_mirror, all);
-	const uint32_t Z2 = Zc + dpp(0, Zc, half_mirror, all);
-	P = dpp(P, Z2, ident, integral_constant<int, 0x2>());                 // lanes 4-7 <- dot
+	if constexpr (DOT) {
+		const uint32_t Z2 = Zc + dpp(0, Zc, half_mirror, all);
+		P = dpp(P, Z2, ident, integral_constant<int, 0x2>());                 // lanes 4-7 <- dot
+	}
 	P += dpp(0, P, swap1, all);
 	P += dpp(0, P, swap2, all);
 	return P;
@@ -150,7 +156,8 @@ __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return _
 // EMD = false (the model and the requested statistics do not include the earth mover's distance -- Feature::compute evaluates
 // only the model's own single features too, predict/Feature.cpp:156-171): the prefix half of every tile is neither fetched nor
 // scored; a step is then two 1 KiB count pieces per tile, one DMA piece per wave, and 16 instead of 32 operations per query.
-template <int NB, bool U8, int TPI, bool EMD>
+// DOT = false: the products are left to the matrix cores (msc_dot_gemm.hip): a quarter of this kernel's arithmetic gone.
+template <int NB, bool U8, int TPI, bool EMD, bool DOT = true>
 __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
@@ -268,10 +275,10 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 					for (int i = 0; i < NC; i++) {
 						if constexpr (U8) {
 							manh[j] = __builtin_amdgcn_sad_u8(cc[i], qc[j][u][i], manh[j]);
-							dot[j] = __builtin_amdgcn_udot4(cc[i], qc[j][u][i], dot[j], false);
+							if constexpr (DOT) dot[j] = __builtin_amdgcn_udot4(cc[i], qc[j][u][i], dot[j], false);
 						} else {
 							manh[j] = __builtin_amdgcn_sad_u16(cc[i], qc[j][u][i], manh[j]);
-							dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][u][i]), dot[j], false);
+							if constexpr (DOT) dot[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, cc[i]), __builtin_bit_cast(u16x2, qc[j][u][i]), dot[j], false);
 						}
 					}
 					if constexpr (EMD) {
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 			// 12 per-lane sums -> 4 records of (manh, dot, emd, -): row r of the wave ends up holding query r, its bank b
 			// (lanes 4b .. 4b+3 of the row) word b of that query's record; the first lane of each quad stores its word, so the
 			// wave writes its 64 bytes of the workgroup's 256-byte run with one dword store
-			const uint32_t word = fold12<EMD>(manh, dot, emd);
+			const uint32_t word = fold12<EMD, DOT>(manh, dot, emd);
 			if (owner) {
 				// byte offset = 16 * row + 4 * bank = lane & 0x3c, recomputed from lane * 16 (live anyway) instead of kept in a
 				// register across the loop: the kernel stays within 128 VGPRs
@@ -298,11 +305,11 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
 }
 
-template <int NB, bool U8, int TPI, bool EMD = true>
+template <int NB, bool U8, int TPI, bool EMD = true, bool DOT = true>
 hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_dg, uint64_t slot_bytes, const uint32_t* cand_slots, uint32_t m,
                                const uint8_t* q_dg, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, void* partials16, int num_cus) {
 	const size_t lds = (size_t)NB * TPI * kTileBytes;
-	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI, EMD>;
+	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI, EMD, DOT>;
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
 	const uint32_t nqg = (n_q + 4 * kWaves - 1) / (4 * kWaves);
@@ -314,7 +321,7 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
 	static const bool no_nt = getenv("MSC_DIGEST_NO_NT") != nullptr;
-	k_pair_digest_multi<NB, U8, TPI, EMD><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
+	k_pair_digest_multi<NB, U8, TPI, EMD, DOT><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
 	                                                                            nqg == 1 && !no_nt, (u32x4*)partials16);
 	return hipGetLastError();
 }
@@ -347,13 +354,16 @@ int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
 
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus) {
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	const uint32_t n_tiles = (uint32_t)(L.nbins / 1024);
 	if (!msc_digest_supported(L) || (tiles_per_step != 1 && tiles_per_step != 2) || n_tiles % tiles_per_step) return hipErrorInvalidValue;
 	const uint64_t db = msc_digest_slot_bytes(L);
 	static const int nb_env = [] { const char* e = getenv("MSC_DIGEST_SLOTS"); return e ? atoi(e) : 0; }();
 #define MSC_DG_ARGS st, n_tiles, cand_digest, db, cand_slots, m, q_digest, db, q_slots, n_q, partials16, num_cus
+	// the products come from the GEMM (the caller checked the ranges): the two forms the bench and the drivers reach, 8-bit counts, two tiles per step
+	if (!need_dot && tiles_per_step == 2 && counts_fit_u8 && (nb_env == 0 || nb_env == 4))
+		return need_emd ? launch_digest_multi<4, true, 2, true, false>(MSC_DG_ARGS) : launch_digest_multi<4, true, 2, false, false>(MSC_DG_ARGS);
 #define MSC_DG_NB(U8, TPI)                                                                                                \
 	(nb_env == 2 ? launch_digest_multi<2, U8, TPI>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8, TPI>(MSC_DG_ARGS) \
 	 : nb_env == 6 ? launch_digest_multi<6, U8, TPI>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8, TPI>(MSC_DG_ARGS) \

@@ -1049,7 +1049,14 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 		t.emd += __shfl_xor(t.emd, off, 64);
 	}
 	const uint32_t q = qg * 16 + lane;
-	if (lane < 16 && q < a.n_queries) epilogue_one(a, q * a.m_per_query + ci, t);
+	if (lane < 16 && q < a.n_queries) {
+		if (a.dot_gemm) {          // the products were computed on the matrix cores: add the slices of the bins
+			uint64_t d = 0;
+			for (uint32_t s_ = 0; s_ < a.dot_slices; s_++) d += (uint64_t)(uint32_t)a.dot_gemm[((uint64_t)s_ * a.m_per_query + ci) * a.dot_stride + q];
+			t.dot = d;
+		}
+		epilogue_one(a, q * a.m_per_query + ci, t);
+	}
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {

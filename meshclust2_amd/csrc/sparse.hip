@@ -1305,9 +1305,11 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 }
 
 int msc_sparse_div_waves();
-// the chunks of the merge-path kernel are staged by LDS-DMA (MSC_SPARSE_MP_NO_DMA=1: the load -> store loop of r02, for A/B runs)
+// MSC_SPARSE_MP_DMA=1: the chunks of the merge-path kernel are staged by LDS-DMA instead of the load -> store loop. OFF by default:
+// measured r03 (k = 13, 20 kb lists, 8 000 candidates) 2.89 ms per launch against 0.78 ms for the loop, and results that differ -- list
+// pieces start on 8-byte, not 16-byte, boundaries of global memory, which global_load_lds_dwordx4 does not take (profiles/r03_notes.md).
 bool msc_sparse_mp_dma() {
-	static const bool on = getenv("MSC_SPARSE_MP_NO_DMA") == nullptr;
+	static const bool on = getenv("MSC_SPARSE_MP_DMA") != nullptr;
 	return on;
 }
 uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
