@@ -383,7 +383,7 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
-	if (s->count8 && s->count8 != s->bins) (void)hipFree(s->count8);
+	if (s->count8) (void)hipFree(s->count8);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
@@ -397,7 +397,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 && s->count8 != s->bins ? s->L.padded_bins : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
@@ -1641,15 +1641,13 @@ static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
-// The count8 mirror of a dense set (msc_dot_gemm.hip): one byte per bin, the B / A operands of the int8 GEMM that takes the products
-// of the Q x M pass. An 8-bit set is its own mirror. MSC_OK with set->count8 == nullptr when it cannot be had: the digest kernel then
-// keeps the products.
+// The count8 mirror of a dense set (msc_dot_gemm.hip): one byte per bin, slots blocked by 16: the operands of the int8 GEMM that takes
+// the products of the Q x M pass. MSC_OK with set->count8 == nullptr when it cannot be had: the digest kernel then keeps the products.
 static int ensure_count8(msc_ctx* ctx, const msc_hist_set* set) {
 	if (set->sparse || set->count8_unavailable || set->dtype == 64) return MSC_OK;
-	if (set->dtype == 8) { set->count8 = set->bins; return MSC_OK; }
 	if (!set->count8) {
 		void* p = nullptr;
-		if (hipMalloc(&p, set->L.padded_bins * set->capacity) != hipSuccess) {
+		if (hipMalloc(&p, msc_count8_bytes(set->L, set->capacity)) != hipSuccess) {
 			(void)hipGetLastError();
 			set->count8_unavailable = true;
 			return MSC_OK;
@@ -1898,7 +1896,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (gemm_dot)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
-			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, L.padded_bins, d_slots, off, mc, qset->count8, qset->L.padded_bins,
+			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8,
 			                                 (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p));
 		if (want_div) {
 			if (spk == SPK_MP) HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)n_q * mc * dvn * 16, ctx->stream));

@@ -8,8 +8,10 @@
 // Here it is an int8 GEMM: v_mfma_i32_16x16x64_i8, exact in int32 (counts <= 127 and count x sum < 2^31: host-checked per set).
 //
 //   count8 mirror  one byte per bin in the set's own (tile-permuted) bin order -- any order serves a dot product as long as both
-//                  operands share it. An 8-bit set IS its mirror; 16/32-bit sets get one built (k_count8_build), 1/2 or 1/4 of
-//                  their size, refreshed with the digest mirror's stale range.
+//                  operands share it --, BLOCKED for the B operand: slots in blocks of 16, a block = [64-bin chunk][slot % 16][64 bytes],
+//                  so that the 16 candidates x 64 bytes a wave loads per MFMA are ONE contiguous KiB and the chunks of a block
+//                  follow each other (the first version read 64 bytes from each of 16 rows 256 KiB apart: 2.1 TB/s). 1 byte per
+//                  bin (1/4 of a 32-bit set), refreshed with the digest mirror's stale range.
 //   k_dot_gemm_i8  workgroup = 64 candidates x 64 queries x one slice of the bins; wave w owns candidates 16 w .. 16 w + 15 and
 //                  all 64 queries: 4 accumulators of 16 x 16. Candidate bytes go from HBM straight into the B operand registers
 //                  (lane l: candidate l % 16, 16 bins of block l / 16: a 64-byte run per candidate and load, the next load takes
@@ -26,6 +28,11 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr uint32_t kStep = 256;          // bins per k-step
 
+// byte offset of bins [at, at + 16) (at a multiple of 16) of `slot` in the blocked mirror
+__device__ __forceinline__ uint64_t c8_offset(uint64_t slot, uint64_t at, uint64_t nbins) {
+	return ((slot >> 4) * (nbins >> 6) + (at >> 6)) * 1024 + (slot & 15) * 64 + (at & 63);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_count8_build(const T* __restrict__ bins, uint64_t slot_elems, uint8_t* __restrict__ count8, uint64_t first_slot, uint64_t n_slots) {
 	const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;          // 16 bins per thread
@@ -35,69 +42,82 @@ __global__ void __launch_bounds__(256) k_count8_build(const T* __restrict__ bins
 	uint32_t w[4];
 #pragma unroll
 	for (int j = 0; j < 4; j++) w[j] = (uint32_t)src[4 * j] | ((uint32_t)src[4 * j + 1] << 8) | ((uint32_t)src[4 * j + 2] << 16) | ((uint32_t)src[4 * j + 3] << 24);
-	*reinterpret_cast<uint4*>(count8 + slot * slot_elems + at) = make_uint4(w[0], w[1], w[2], w[3]);
+	*reinterpret_cast<uint4*>(count8 + c8_offset(slot, at, slot_elems)) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// rows of the query operand: q8[r] = the mirror row of slot q_slots[r] (r < n_q), zeros for the rows up to 64
-__global__ void __launch_bounds__(256) k_gather_rows8(const uint8_t* __restrict__ count8, uint64_t stride, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
+// rows of the query operand: q8[r] = the bins of slot q_slots[r] (r < n_q) as one row, zeros for the rows up to 64
+__global__ void __launch_bounds__(256) k_gather_rows8(const uint8_t* __restrict__ count8, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
                                                       uint8_t* __restrict__ q8) {
 	const uint32_t r = blockIdx.y;
 	const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
 	if (i >= nbins) return;
 	uint4 v = make_uint4(0, 0, 0, 0);
-	if (r < n_q) v = *reinterpret_cast<const uint4*>(count8 + (uint64_t)q_slots[r] * stride + i);
+	if (r < n_q) v = *reinterpret_cast<const uint4*>(count8 + c8_offset(q_slots[r], i, nbins));
 	*reinterpret_cast<uint4*>(q8 + (uint64_t)r * nbins + i) = v;
 }
 
-__global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, uint64_t cand_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
+__global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                      const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out) {
-	__shared__ uint4 sA[2][64][16];          // [buffer][query row][16-byte segment ^ (row & 15)]: 32 KiB
+	__shared__ v4i sA[2][64][16];          // [buffer][query row][16-byte segment ^ (row & 15)]: 32 KiB
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t ks = blockIdx.y;
-	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per, k1 = k0 + per;
+	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
 	const uint32_t ci = blockIdx.x * 64 + wave * 16 + (lane & 15);
 	const bool valid = ci < m;
 	const uint32_t cc = valid ? ci : m - 1;
-	const uint32_t slot = cand_slots ? cand_slots[cc] : cc;
-	const uint8_t* brow = cand8 + (uint64_t)slot * cand_stride + (lane >> 4) * 16;
+	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+	// lane l: candidate l % 16 of the wave, bytes 16 (l / 16) .. + 15 of every 64-bin chunk: consecutive slots of one block make the
+	// wave's load one contiguous KiB
+	const uint8_t* brow = cand8 + (slot >> 4) * (nbins >> 6) * 1024 + (slot & 15) * 64 + (lane >> 4) * 16;
 	const uint32_t arow = tid >> 2, aseg0 = (tid & 3) * 4;
 	const uint8_t* asrc = q8 + (uint64_t)arow * nbins + aseg0 * 16;
 	v4i acc[4];
 #pragma unroll
 	for (int rb = 0; rb < 4; rb++) acc[rb] = v4i{0, 0, 0, 0};
-	uint4 a_reg[4], b_cur[4], b_nxt[4];
+	v4i a_reg[4], b0[4], b1[4];          // plain vectors: HIP's uint4 struct kept these arrays in scratch
+	// The rows of the operands are a power of two apart (4^k bytes) and so are the slices: every workgroup walking its steps in the same
+	// order puts the whole chip on the same HBM channels at the same time (first version: 1.7 TB/s). Each workgroup therefore starts
+	// its walk somewhere else -- a sum does not care in which order its terms arrive.
+	const uint32_t steps = (uint32_t)(per / kStep);
+	const uint32_t rot = (blockIdx.x * 37u + ks * 11u) % steps;
+	// operands of step i (the last step once more past the end: a load nobody uses is cheaper than a branch around it -- with the
+	// loads under `if (more)` the compiler parked them in scratch and so waited for each as soon as it was issued)
+	auto fetch = [&](uint32_t i, v4i (&b)[4]) {
+		const uint32_t j = (i < steps ? i : steps - 1) + rot;
+		const uint64_t k = k0 + (uint64_t)(j >= steps ? j - steps : j) * kStep;
 #pragma unroll
-	for (int j = 0; j < 4; j++) a_reg[j] = *reinterpret_cast<const uint4*>(asrc + k0 + 16 * j);
+		for (int t = 0; t < 4; t++) a_reg[t] = *reinterpret_cast<const v4i*>(asrc + k + 16 * t);
 #pragma unroll
-	for (int kc = 0; kc < 4; kc++) b_cur[kc] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + k0 + 64 * kc)));
+		for (int kc = 0; kc < 4; kc++) b[kc] = *reinterpret_cast<const v4i*>(brow + ((k >> 6) + kc) * 1024);
+	};
+	auto park = [&](uint32_t buf) {
 #pragma unroll
-	for (int j = 0; j < 4; j++) sA[0][arow][(aseg0 + j) ^ (arow & 15)] = a_reg[j];
-	__syncthreads();
-	uint32_t buf = 0;
-	for (uint64_t k = k0; k < k1; k += kStep, buf ^= 1) {
-		const bool more = k + kStep < k1;
-		if (more) {
-#pragma unroll
-			for (int j = 0; j < 4; j++) a_reg[j] = *reinterpret_cast<const uint4*>(asrc + k + kStep + 16 * j);
-#pragma unroll
-			for (int kc = 0; kc < 4; kc++) b_nxt[kc] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + k + kStep + 64 * kc)));
-		}
+		for (int t = 0; t < 4; t++) sA[buf][arow][(aseg0 + t) ^ (arow & 15)] = a_reg[t];
+	};
+	auto multiply = [&](uint32_t buf, const v4i (&b)[4]) {
 #pragma unroll
 		for (int kc = 0; kc < 4; kc++) {
-			const v4i B = __builtin_bit_cast(v4i, b_cur[kc]);
+			const v4i B = b[kc];
 #pragma unroll
 			for (int rb = 0; rb < 4; rb++) {
 				// A operand: lane l = query 16 rb + l % 16, bins of block l / 16 of this 64-bin chunk
-				const v4i A = __builtin_bit_cast(v4i, sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)]);
+				const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
 				acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[rb], 0, 0, 0);
 			}
 		}
-		if (more) {
-#pragma unroll
-			for (int j = 0; j < 4; j++) sA[buf ^ 1][arow][(aseg0 + j) ^ (arow & 15)] = a_reg[j];
-#pragma unroll
-			for (int kc = 0; kc < 4; kc++) b_cur[kc] = b_nxt[kc];
-		}
+	};
+	fetch(0, b0);
+	park(0);
+	__syncthreads();
+	for (uint32_t i = 0; i < steps; i += 2) {          // two steps per turn: the operand registers and LDS halves swap roles by name
+		fetch(i + 1, b1);
+		multiply(0, b0);
+		park(1);
+		__syncthreads();
+		if (i + 1 >= steps) break;
+		fetch(i + 2, b0);
+		multiply(1, b1);
+		park(0);
 		__syncthreads();
 	}
 	// D: lane l holds column l % 16 (its candidate), rows 4 (l / 16) .. + 3 of each 16-query block
@@ -110,11 +130,15 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 
 }  // namespace
 
+// bytes of the blocked mirror of a set of `capacity` slots
+uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 15) / 16 * 16 * L.padded_bins; }
+
 hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots) {
 	if (n_slots == 0) return hipSuccess;
 	const uint64_t threads = n_slots * L.padded_bins / 16;
 	const dim3 grid((unsigned)((threads + 255) / 256));
-	if (dtype == 16) k_count8_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, count8, first_slot, n_slots);
+	if (dtype == 8) k_count8_build<uint8_t><<<grid, dim3(256), 0, st>>>((const uint8_t*)bins, L.padded_bins, count8, first_slot, n_slots);
+	else if (dtype == 16) k_count8_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, count8, first_slot, n_slots);
 	else if (dtype == 32) k_count8_build<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)bins, L.padded_bins, count8, first_slot, n_slots);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
@@ -128,13 +152,13 @@ uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus) {
 }
 
 // dots[slice][candidate][64] of n_q <= 64 queries (rows q_slots of q_count8) against m candidates (slot list, or slots first .. first + m - 1)
-hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, uint64_t cand_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
-                               const uint8_t* q_count8, uint64_t q_stride, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out) {
+hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
+                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > 64 || nbins % (16 * 16) || nbins % ((uint64_t)k_slices * kStep)) return hipErrorInvalidValue;
-	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_stride, q_slots_dev, n_q, nbins, q8_scratch);
+	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_slots_dev, n_q, nbins, q8_scratch);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	k_dot_gemm_i8<<<dim3((m + 63) / 64, k_slices), dim3(256), 0, st>>>(cand_count8 + (cand_slots ? 0 : first * cand_stride), cand_stride, cand_slots, m, q8_scratch, nbins, k_slices, out);
+	k_dot_gemm_i8<<<dim3((m + 63) / 64, k_slices), dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out);
 	return hipGetLastError();
 }

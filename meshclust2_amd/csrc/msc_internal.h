@@ -168,10 +168,11 @@ hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, cons
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
                                         int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot = true);
 // the products of the Q x M pass as an int8 GEMM on the matrix cores (msc_dot_gemm.hip)
+uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity);
 hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots);
 uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);
-hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, uint64_t cand_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
-                               const uint8_t* q_count8, uint64_t q_stride, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out);
+hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
+                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);

@@ -62,8 +62,8 @@ struct msc_hist_set {
 	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
 	mutable uint64_t dg_lo = 0, dg_hi = 0;
 	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
-	// count8 mirror (msc_dot_gemm.hip): one byte per bin for the int8 GEMM of the Q x M pass; an 8-bit set is its own mirror.
-	// slots [c8_lo, c8_hi) are stale (kept in step with the digest's range by mark_stale)
+	// count8 mirror (msc_dot_gemm.hip): one byte per bin for the int8 GEMM of the Q x M pass, slots blocked by 16 so that a wave's
+	// operand load is one contiguous KiB. slots [c8_lo, c8_hi) are stale (kept in step with the digest's range by mark_stale)
 	mutable uint8_t* count8 = nullptr;
 	mutable uint64_t c8_lo = 0, c8_hi = 0;
 	mutable bool count8_unavailable = false;

@@ -878,6 +878,7 @@ __device__ __forceinline__ void mp_stage_dma(const uint2* src, uint32_t count, u
 
 constexpr uint32_t kMpDivGran = 4;      // chunks per divergence record (see the DIV comment inside the kernel)
 constexpr uint32_t kMpTab = 8;          // side of the divergence-term table in LDS
+constexpr uint32_t kMpDivMinGran = 4;   // granules a part of a pair keeps at least (16 chunks, 8 192 merged entries)
 template <bool DIV, uint32_t kMpT, bool PAIRS = false, int WPE = 1>
 __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
     const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
@@ -949,9 +950,18 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 		// shared it (parts cut the merged order between granules) nor on the route that scored it
 		uint32_t t_begin, t_end;
 		if constexpr (DIV) {
+			// `parts` is the most a pair of this launch may be cut into; THIS pair takes as many as it has stretches of kMpDivMinGran
+			// granules (a window of mixed lengths: the long pairs are shared out, the short ones stay whole) -- the other parts of its
+			// record group stay empty
 			const uint32_t n_gran = (n_chunks + kMpDivGran - 1) / kMpDivGran;
-			t_begin = (uint32_t)((uint64_t)n_gran * part / parts) * kMpDivGran;
-			t_end = (uint32_t)((uint64_t)n_gran * (part + 1) / parts) * kMpDivGran;
+			uint32_t parts_c = n_gran / kMpDivMinGran;
+			parts_c = parts_c < 1 ? 1 : parts_c > parts ? parts : parts_c;
+			if (part >= parts_c) {
+				if (lane == 0) partials[w] = MscPartial{0, 0, 0};
+				continue;
+			}
+			t_begin = (uint32_t)((uint64_t)n_gran * part / parts_c) * kMpDivGran;
+			t_end = (uint32_t)((uint64_t)n_gran * (part + 1) / parts_c) * kMpDivGran;
 			if (t_end > n_chunks) t_end = n_chunks;
 		} else {
 			t_begin = (uint32_t)((uint64_t)n_chunks * part / parts);
@@ -1061,7 +1071,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 				}
 			}
 		}
-		if (lane == 0 && part + 1 == parts) {      // the stretch behind the last event of either list
+		if (lane == 0 && t_end == n_chunks && (t_begin < t_end || part == 0)) {       // the stretch behind the last event of either list: the part that walks the last chunk
 			const uint32_t lc = nc_all ? P[nc_all - 1].x : 0u, lq = nq_all ? Q[nq_all - 1].x : 0u;
 			const int64_t D = (int64_t)(nc_all ? CP[nc_all - 1] : 0u) - (int64_t)(nq_all ? CQ[nq_all - 1] : 0u);
 			emd += (uint64_t)(D < 0 ? -D : D) * (nbins - (uint64_t)(lc > lq ? lc : lq));
@@ -1377,10 +1387,18 @@ int msc_sparse_div_waves() {
 uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div) {
 	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
 	if (off || m == 0) return 1;
-	// (the divergence form holds fewer waves per SIMD and cuts between granules: a part keeps at least one granule)
-	const uint64_t slots = (uint64_t)num_cus * (div ? 4 * msc_sparse_div_waves() : 32), chunks = entries / kMpChunk, per_part = div ? kMpDivGran : 2;
+	const uint64_t slots = (uint64_t)num_cus * (div ? 4 * msc_sparse_div_waves() : 32), chunks = entries / kMpChunk;
 	uint32_t parts = 1;
-	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * per_part <= chunks) parts *= 2;
+	if (div) {
+		// the divergence form cuts between granules, each pair by its OWN length (k_pair_sparse_mp): the launch only sets the most a
+		// pair may be cut into -- whatever the longest pair can use, unless the window alone fills the chip several times over
+		static const uint32_t cap = [] { const char* e = getenv("MSC_SPARSE_MP_MAX_PARTS"); const int v = e ? atoi(e) : 16; return (uint32_t)std::min(16, std::max(1, v)); }();
+		static const uint64_t fill = [] { const char* e = getenv("MSC_SPARSE_MP_FILL"); const int v = e ? atoi(e) : 1; return (uint64_t)std::max(1, v); }();
+		if ((uint64_t)m >= fill * slots) return 1;
+		while (parts < cap && (uint64_t)parts * 2 * kMpDivGran * kMpDivMinGran <= chunks && (uint64_t)m * parts * 2 <= 2 * fill * slots) parts *= 2;
+		return parts;
+	}
+	while (parts < 16 && (uint64_t)m * parts * 2 <= slots && (uint64_t)parts * 2 * 2 <= chunks) parts *= 2;
 	return parts;
 }
 // divergence records per pair of the merge-path kernel for lists of up to `entries` entries together
