@@ -131,6 +131,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->shard_hdrs);
 	release(ctx->gemm_q8);
 	release(ctx->gemm_out);
+	release(ctx->emd_out);
+	release(ctx->rk_bad);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
@@ -384,6 +386,8 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
 	if (s->count8) (void)hipFree(s->count8);
+	if (s->ranks) (void)hipFree(s->ranks);
+	if (s->rk_n) (void)hipFree(s->rk_n);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
@@ -397,7 +401,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
@@ -414,6 +418,10 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 	if (s->count8) {
 		if (s->c8_lo >= s->c8_hi) { s->c8_lo = first; s->c8_hi = first + n; }
 		else { s->c8_lo = std::min(s->c8_lo, first); s->c8_hi = std::max(s->c8_hi, first + n); }
+	}
+	if (s->ranks) {
+		if (s->rk_lo >= s->rk_hi) { s->rk_lo = first; s->rk_hi = first + n; }
+		else { s->rk_lo = std::min(s->rk_lo, first); s->rk_hi = std::max(s->rk_hi, first + n); }
 	}
 }
 
@@ -1663,6 +1671,56 @@ static int ensure_count8(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
+// The ranks mirror of a dense set (msc_emd_ranks.hip), from its digest mirror (current when this is called). MSC_OK with
+// set->ranks == nullptr when it cannot be had (no memory, or a slot holds a zero count): the digest kernel then keeps the prefixes.
+static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
+	if (set->sparse || !set->digest || set->ranks_unavailable || set->max_sum < set->L.nbins) return MSC_OK;
+	const uint64_t pitch = msc_ranks_pitch(set->max_sum - set->L.nbins);
+	if (set->ranks && pitch > set->rk_pitch) {          // a longer list than any before: lay the mirror out again
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		(void)hipFree(set->ranks);
+		set->ranks = nullptr;
+	}
+	if (!set->ranks) {
+		void *p = nullptr, *pn = set->rk_n;
+		if (hipMalloc(&p, pitch * 4 * set->capacity) != hipSuccess || (!pn && hipMalloc(&pn, 4 * set->capacity) != hipSuccess)) {
+			(void)hipGetLastError();
+			if (p) (void)hipFree(p);
+			set->ranks_unavailable = true;
+			return MSC_OK;
+		}
+		set->ranks = (uint32_t*)p;
+		set->rk_n = (uint32_t*)pn;
+		set->rk_pitch = pitch;
+		set->rk_lo = 0;
+		set->rk_hi = set->capacity;
+	}
+	if (set->rk_lo < set->rk_hi) {
+		int r;
+		if ((r = ensure(ctx, ctx->rk_bad, sizeof(int32_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, sizeof(int32_t), ctx->stream));
+		// runs of slots that hold a histogram (an unwritten slot's digest is whatever the allocation held)
+		const uint64_t hi = std::min<uint64_t>(set->rk_hi, set->written.size());
+		for (uint64_t i = set->rk_lo; i < hi;) {
+			if (!set->written[i]) { i++; continue; }
+			uint64_t j = i;
+			while (j < hi && set->written[j]) j++;
+			HIP_TRY(ctx, msc_launch_ranks_build(ctx->stream, set->L, set->digest, set->ranks, set->rk_n, set->rk_pitch, i, j - i, (int32_t*)ctx->rk_bad.p));
+			i = j;
+		}
+		int32_t bad = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->rk_bad.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		set->rk_lo = set->rk_hi = 0;
+		if (bad) {
+			(void)hipFree(set->ranks);
+			set->ranks = nullptr;
+			set->ranks_unavailable = true;
+		}
+	}
+	return MSC_OK;
+}
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
@@ -1840,9 +1898,22 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
 	const bool need_emd = ((want | feat_mask) & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
 	const int tps = digest ? msc_digest_tiles_per_step(L, mc_) : 1;          // the digest kernel writes one record per step of tps tiles
+	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
+	// longest list is a quarter of the bins or less, for up to 64 queries and 2^20 bins (32-bit wave sums); the digest kernel then runs
+	// its count-only form (two tiles per step)
+	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
+	bool emd_ranks = digest && need_emd && !no_ranks && tps == 2 && n_q <= 64 && L.nbins <= (1ull << 20) && (ms_ - L.nbins) * 4 <= L.nbins && !getenv("MSC_DIGEST_SLOTS");
+	if (emd_ranks) {
+		if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
+		emd_ranks = cands->ranks && qset->ranks;
+	}
+	const bool digest_emd = need_emd && !emd_ranks;                          // the digest kernel streams and scores the prefix half
 	const uint32_t n_rec = digest ? (uint32_t)(L.nbins / 1024) / tps : L.S;
-	const uint64_t rec_bytes = digest || ring ? 16 : sizeof(MscPartial);
-	const uint64_t q_rows = digest ? (n_q + 15) / 16 * 16 : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
+	// manh is all that is left to the digest kernel: eight queries per wave (32 per candidate tile fetched), 4-byte records
+	static const bool no_tq8 = getenv("MSC_DIGEST_NO_TQ8") != nullptr;
+	const int dg_tq = digest && gemm_dot && !digest_emd && n_q > 16 && !no_tq8 ? 8 : 4;
+	const uint64_t rec_bytes = digest && dg_tq == 8 ? 4 : digest && gemm_dot ? 8 : digest || ring ? 16 : sizeof(MscPartial);
+	const uint64_t q_rows = digest ? (n_q + 4 * dg_tq - 1) / (4 * dg_tq) * (4 * dg_tq) : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
 	if (want_grp) chunk = std::min<uint64_t>(chunk, (1024ull << 20) / (n_q * 32 * sizeof(double)));      // [n_q][chunk][16][2] group records: 1 GiB
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
@@ -1870,13 +1941,16 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
 	const uint32_t gemm_slices = gemm_dot ? msc_dot_gemm_slices(L.nbins, (uint32_t)chunk, ctx->num_cus) : 0;
 	if (gemm_dot && ((r = ensure(ctx, ctx->gemm_q8, 64 * L.nbins)) || (r = ensure(ctx, ctx->gemm_out, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t))))) return r;
-	const bool count_only = digest && tps == 2 && !need_emd;
-	ctx->last_kernel = digest ? (count_only ? (gemm_dot ? "k_pair_digest_multi<u8 counts, no emd, dot by mfma>" : mc_ < 256 ? "k_pair_digest_multi<u8 counts, no emd>" : "k_pair_digest_multi<u16 counts, no emd>")
-	                                        : (gemm_dot ? "k_pair_digest_multi<u8 counts, dot by mfma>" : mc_ < 256 ? "k_pair_digest_multi<u8 counts>" : "k_pair_digest_multi<u16 counts>"))
-	                          : ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
+	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * 64 * sizeof(uint64_t)))) return r;
+	const bool count_only = digest && tps == 2 && !digest_emd;
+	if (digest) {
+		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_digest_multi<%s counts%s%s>", mc_ < 256 ? "u8" : "u16",
+		         emd_ranks ? ", emd by ranks" : count_only ? ", no emd" : "", gemm_dot ? ", dot by mfma" : "");
+		ctx->last_kernel = ctx->last_kernel_buf;
+	} else ctx->last_kernel = ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
 	// the digest kernel's workgroup scores up to 16 queries per candidate tile it fetches; the ring kernel's co-located query
 	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
-	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 16) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
+	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 4 * dg_tq) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
 	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
 	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
@@ -1887,7 +1961,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
-			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, need_emd, ctx->partials.p, ctx->num_cus, !gemm_dot));
+			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
@@ -1898,6 +1972,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (gemm_dot)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
 			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8,
 			                                 (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p));
+		if (emd_ranks)
+			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
+			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p));
 		if (want_div) {
 			if (spk == SPK_MP) HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)n_q * mc * dvn * 16, ctx->stream));
 			for (uint64_t q = 0; q < n_q; q++)
@@ -1931,7 +2008,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
+		ea.cq_group = 4 * dg_tq;
 		if (gemm_dot) { ea.dot_gemm = (const int32_t*)ctx->gemm_out.p; ea.dot_slices = gemm_slices; ea.dot_stride = 64; }
+		if (emd_ranks) ea.emd_ranks = (const uint64_t*)ctx->emd_out.p;
 		ea.S = n_rec;
 		ea.m = (uint32_t)(n_q * mc);
 		ea.cand_scalars = c_scal;

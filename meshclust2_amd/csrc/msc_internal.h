@@ -71,7 +71,10 @@ struct MscEpilogueArgs {
 	const MscPartial* partials;       // [m][S]
 	const void* partials16;           // or: [m][S] records of four u32 {manh, dot, emd, 0} (ring kernel); partials is then unused
 	const void* partials_cq;          // or: [m_per_query][ceil(n_queries/16)][S][16] such records (digest kernel: one 256-byte run per workgroup step)
-	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q])
+	uint32_t cq_group;                // with partials_cq: queries per group -- 16, or 32 with 4-byte records (manh only: dot_gemm set, emd from emd_ranks or not wanted)
+	const uint64_t* emd_ranks;        // with partials_cq: the earth mover's distances from msc_emd_ranks.hip instead, [m_per_query][64] (query q at [q])
+	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q]);
+	                                  // the records of partials_cq are then 8 bytes (manh, emd)
 	uint32_t dot_slices, dot_stride;
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
@@ -166,8 +169,13 @@ hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uin
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count);      // 1 or 2 consecutive tiles scored per loop step
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot = true);
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot = true, int queries_per_wave = 4);
 // the products of the Q x M pass as an int8 GEMM on the matrix cores (msc_dot_gemm.hip)
+uint64_t msc_ranks_pitch(uint64_t max_excess);
+hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, const uint8_t* digest, uint32_t* ranks, uint32_t* n_of, uint64_t pitch, uint64_t first_slot,
+                                  uint64_t n_slots, int32_t* bad);
+hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
+                                uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out);
 uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity);
 hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots);
 uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);

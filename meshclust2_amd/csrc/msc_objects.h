@@ -23,6 +23,7 @@ struct msc_ctx {
 	float tiles_ms_accum = 0.f;
 	int tiles_launches = 0;
 	const char* last_kernel = "";            // streaming kernel of the last scoring call
+	char last_kernel_buf[96] = "";           // (where the Q x M pass composes the name of the form it ran)
 	int last_query_tile = 1;                 // queries one HBM read of a candidate tile served in it
 	std::string err;
 	char dev_name[128] = {0};
@@ -41,6 +42,7 @@ struct msc_ctx {
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
 	DevBuf gemm_q8, gemm_out;              // msc_dot_gemm.hip: the gathered query rows, the products per slice
+	DevBuf emd_out, rk_bad;                // msc_emd_ranks.hip: the distances of a chunk, the build's error word
 	msc_hist_set* shard_gather = nullptr;
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the
 	// launches, and waiting for the stream (printed by msc_destroy)
@@ -67,6 +69,13 @@ struct msc_hist_set {
 	mutable uint8_t* count8 = nullptr;
 	mutable uint64_t c8_lo = 0, c8_hi = 0;
 	mutable bool count8_unavailable = false;
+	// ranks mirror (msc_emd_ranks.hip): per slot the bins of its counted k-mers in bin order (rk_pitch entries, padded with 4^k) and
+	// their number: the earth mover's distance of the Q x M pass in O(k-mers) instead of O(bins). Built from the digest mirror;
+	// slots [rk_lo, rk_hi) are stale
+	mutable uint32_t* ranks = nullptr;
+	mutable uint32_t* rk_n = nullptr;
+	mutable uint64_t rk_pitch = 0, rk_lo = 0, rk_hi = 0;
+	mutable bool ranks_unavailable = false;
 	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
 	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
 	mutable msc_hist_set* sp_mirror = nullptr;

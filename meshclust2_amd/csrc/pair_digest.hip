@@ -113,9 +113,9 @@ __device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uin
 // inside the 16-lane rows with DPP, bank masks merging them into one register on the way: row_ror:8 pairs lanes (l, l^8),
 // row_half_mirror pairs (l, 7-l), two quad_perms finish the quads. Result: every lane of bank 0 holds the row's manh total,
 // bank 1 dot, bank 2 emd (bank 3: emd again). 9 swaps + 9 adds + 9 DPP operations for the 12 sums.
-// EMD = false: the emd sums are not reduced (banks 2 and 3 then hold manh partials nobody reads).
-// DOT = false: the dot sums are not reduced either (the products come from the int8 GEMM of msc_dot_gemm.hip; bank 1 then holds a manh
-// partial nobody reads).
+// EMD = false: the emd sums are not reduced (banks 2 and 3 then hold the manh total too).
+// DOT = false: the dot sums are not reduced either (the products come from the int8 GEMM of msc_dot_gemm.hip): banks 0 and 1 both
+// hold the manh total, banks 2 and 3 the emd total -- the kernel stores 8-byte records from banks 0 and 2.
 template <bool EMD, bool DOT = true>
 __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint32_t (&dot)[4], const uint32_t (&emd)[4]) {
 	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
@@ -150,6 +150,23 @@ __device__ __forceinline__ uint32_t fold12(const uint32_t (&manh)[4], const uint
 	return P;
 }
 
+// Eight queries, manh only (the form that leaves the products to the matrix cores and the earth mover's distance to the ranks): the
+// same swaps take 8 -> 4 -> 2 registers whose row r holds 16 partial sums of query r / query 4 + r; after row_ror:8 the second is
+// merged into lanes 8-15 of the first, and three more DPP adds leave query r's total in lanes 0-7 of row r, query 4 + r's in lanes 8-15.
+__device__ __forceinline__ uint32_t fold8(const uint32_t (&manh)[8]) {
+	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
+	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
+	const uint32_t A = fold16(fold32(manh[0], manh[2]), fold32(manh[1], manh[3]));
+	const uint32_t B = fold16(fold32(manh[4], manh[6]), fold32(manh[5], manh[7]));
+	const uint32_t Xa = A + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, 0x128, 0xf, 0xf, false);
+	const uint32_t Yb = B + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B, 0x128, 0xf, 0xf, false);
+	uint32_t P = (uint32_t)__builtin_amdgcn_update_dpp((int)Xa, (int)Yb, 0xe4, 0xf, 0xc, false);      // lanes 8-15 of every row <- queries 4..7
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x141, 0xf, 0xf, false);
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xb1, 0xf, 0xf, false);
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x4e, 0xf, 0xf, false);
+	return P;
+}
+
 // bytes 0 and 2 of `lo` and of `hi`: four 16-bit counts (< 256) -> four bytes
 __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
@@ -157,14 +174,16 @@ __device__ __forceinline__ uint32_t pack_u8(uint32_t lo, uint32_t hi) { return _
 // only the model's own single features too, predict/Feature.cpp:156-171): the prefix half of every tile is neither fetched nor
 // scored; a step is then two 1 KiB count pieces per tile, one DMA piece per wave, and 16 instead of 32 operations per query.
 // DOT = false: the products are left to the matrix cores (msc_dot_gemm.hip): a quarter of this kernel's arithmetic gone.
-template <int NB, bool U8, int TPI, bool EMD, bool DOT = true>
+// TQ = 8 (manh only: EMD = DOT = false, 8-bit counts): eight queries per wave, 32 per workgroup -- the count-only form at four was bound
+// by the 7.6 TB/s its workgroups pulled from L2 into LDS (each candidate tile once per 16 queries), not by arithmetic; 4-byte records.
+template <int NB, bool U8, int TPI, bool EMD, bool DOT = true, int TQ = 4>
 __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_digest_multi(
     const uint8_t* __restrict__ cand_dg, uint64_t slot_bytes, const uint32_t* __restrict__ cand_slots, uint32_t m,
     const uint8_t* __restrict__ q_dg, uint64_t q_slot_bytes, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t ST, uint32_t G,
     uint32_t nqg, bool stream_once, u32x4* __restrict__ partials16) {
 	static_assert(NB >= 2 && NB <= 8 && (TPI == 1 || TPI == 2) && (EMD || TPI == 2), "ring depth, tiles per step; the count-only form moves 4 pieces per step");
+	static_assert(TQ == 4 || (TQ == 8 && U8 && !EMD && !DOT), "eight queries per wave: manh only");
 	constexpr int PF = EMD ? TPI : 1;         // DMA pieces each wave issues per step
-	constexpr int TQ = 4;
 	constexpr int D = NB - 1;                 // steps in flight ahead of the one being scored
 	constexpr int NC = U8 ? 4 : 8;            // count words per lane per tile
 	constexpr uint32_t kStepBytes = TPI * kTileBytes;      // a step = TPI consecutive tiles of one candidate (ST = S / TPI steps per histogram)
@@ -235,11 +254,15 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 #pragma unroll
 	for (int d = 0; d < D; d++) fetch((uint32_t)d, (uint32_t)d);
 
-	const bool owner = (lane & 3) == 0;       // first lane of every quad: stores one word of a record (see fold12 below)
-	// records: [candidate][query group][step][query in group] -- the four waves of a workgroup write one 256-byte run per step;
-	// wave-uniform base in SGPRs, advanced per step, + the owner lanes' constant offset
-	uint64_t out_base = (uint64_t)partials16 + ((((uint64_t)g * nqg + qg) * ST + s) * 16 + wib * TQ) * sizeof(u32x4);
-	const uint64_t out_step = (uint64_t)G * nqg * ST * 16 * sizeof(u32x4);
+	// records: [candidate][query group][step][query in group] -- the four waves of a workgroup write one run per step; wave-uniform
+	// base in SGPRs, advanced per step, + the owner lanes' constant offset. With the products: 16 bytes (manh, dot, emd, -), the first
+	// lane of every quad stores one word (see fold12 below). Without (DOT = false): 8 bytes (manh, emd), the first lane of every
+	// second quad stores -- half the record traffic of this kernel and of the epilogue that sums them.
+	// Eight queries per wave: 4 bytes (manh), 32 queries per run, lanes 0 and 8 of every row store.
+	constexpr uint32_t kRec = TQ == 8 ? 4 : DOT ? 16 : 8;
+	const bool owner = DOT ? (lane & 3) == 0 : (lane & 7) == 0;
+	uint64_t out_base = (uint64_t)partials16 + ((((uint64_t)g * nqg + qg) * ST + s) * (kWaves * TQ) + wib * TQ) * kRec;
+	const uint64_t out_step = (uint64_t)G * nqg * ST * (kWaves * TQ) * kRec;
 
 	uint32_t rd = 0, wr = D % NB;
 	for (uint32_t it = 0; it < n_iter; it++) {
@@ -290,13 +313,24 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 			// 12 per-lane sums -> 4 records of (manh, dot, emd, -): row r of the wave ends up holding query r, its bank b
 			// (lanes 4b .. 4b+3 of the row) word b of that query's record; the first lane of each quad stores its word, so the
 			// wave writes its 64 bytes of the workgroup's 256-byte run with one dword store
-			const uint32_t word = fold12<EMD, DOT>(manh, dot, emd);
+			uint32_t word;
+			if constexpr (TQ == 8) word = fold8(manh); else word = fold12<EMD, DOT>(manh, dot, emd);
 			if (owner) {
 				// byte offset = 16 * row + 4 * bank = lane & 0x3c, recomputed from lane * 16 (live anyway) instead of kept in a
 				// register across the loop: the kernel stays within 128 VGPRs
+				// (8-byte records: 8 * row + 4 * (bank / 2) = (lane >> 1) & 0x1c)
 				uint32_t off;
-				asm volatile("v_lshrrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x3c, %0\n\tglobal_store_dword %0, %2, %3"
-				             : "=&v"(off) : "v"(lane16), "v"(word), "s"(out_base) : "memory");
+				// (eight queries: query r of row r at 4 r, query 4 + r (lanes 8-15) at 16 + 4 r = ((lane >> 2) & 0xc) + ((lane << 1) & 0x10))
+				if constexpr (TQ == 8) {
+					uint32_t half;
+					asm volatile("v_lshrrev_b32 %0, 6, %2\n\tv_and_b32 %0, 0xc, %0\n\tv_bfe_u32 %1, %2, 7, 1\n\tv_lshl_or_b32 %0, %1, 4, %0\n\tglobal_store_dword %0, %3, %4"
+					             : "=&v"(off), "=&v"(half) : "v"(lane16), "v"(word), "s"(out_base) : "memory");
+				} else if constexpr (DOT)
+					asm volatile("v_lshrrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x3c, %0\n\tglobal_store_dword %0, %2, %3"
+					             : "=&v"(off) : "v"(lane16), "v"(word), "s"(out_base) : "memory");
+				else
+					asm volatile("v_lshrrev_b32 %0, 5, %1\n\tv_and_b32 %0, 0x1c, %0\n\tglobal_store_dword %0, %2, %3"
+					             : "=&v"(off) : "v"(lane16), "v"(word), "s"(out_base) : "memory");
 			}
 			out_base += out_step;
 		}
@@ -305,14 +339,14 @@ __global__ void __launch_bounds__(kBlock, (U8 && TPI == 2) ? 4 : 1) k_pair_diges
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring must not be released with fetches in flight
 }
 
-template <int NB, bool U8, int TPI, bool EMD = true, bool DOT = true>
+template <int NB, bool U8, int TPI, bool EMD = true, bool DOT = true, int TQ = 4>
 hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_dg, uint64_t slot_bytes, const uint32_t* cand_slots, uint32_t m,
                                const uint8_t* q_dg, uint64_t q_slot_bytes, const uint32_t* q_slots, uint32_t n_q, void* partials16, int num_cus) {
 	const size_t lds = (size_t)NB * TPI * kTileBytes;
-	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI, EMD, DOT>;
+	const void* fn = (const void*)k_pair_digest_multi<NB, U8, TPI, EMD, DOT, TQ>;
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, lds) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
-	const uint32_t nqg = (n_q + 4 * kWaves - 1) / (4 * kWaves);
+	const uint32_t nqg = (n_q + TQ * kWaves - 1) / (TQ * kWaves);
 	const uint32_t ST = S / TPI;
 	// one resident round of equal-length workgroups
 	uint64_t G = (uint64_t)num_cus * blocks_per_cu / ((uint64_t)ST * nqg);
@@ -321,7 +355,7 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
 	static const bool no_nt = getenv("MSC_DIGEST_NO_NT") != nullptr;
-	k_pair_digest_multi<NB, U8, TPI, EMD, DOT><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
+	k_pair_digest_multi<NB, U8, TPI, EMD, DOT, TQ><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
 	                                                                            nqg == 1 && !no_nt, (u32x4*)partials16);
 	return hipGetLastError();
 }
@@ -354,16 +388,18 @@ int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
 
 hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, const uint8_t* cand_digest, const uint32_t* cand_slots, uint32_t m,
                                         const uint8_t* q_digest, const uint32_t* q_slots, uint32_t n_q, bool counts_fit_u8,
-                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot) {
+                                        int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot, int queries_per_wave) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	const uint32_t n_tiles = (uint32_t)(L.nbins / 1024);
 	if (!msc_digest_supported(L) || (tiles_per_step != 1 && tiles_per_step != 2) || n_tiles % tiles_per_step) return hipErrorInvalidValue;
 	const uint64_t db = msc_digest_slot_bytes(L);
 	static const int nb_env = [] { const char* e = getenv("MSC_DIGEST_SLOTS"); return e ? atoi(e) : 0; }();
 #define MSC_DG_ARGS st, n_tiles, cand_digest, db, cand_slots, m, q_digest, db, q_slots, n_q, partials16, num_cus
-	// the products come from the GEMM (the caller checked the ranges): the two forms the bench and the drivers reach, 8-bit counts, two tiles per step
+	if (queries_per_wave != 4 && (queries_per_wave != 8 || need_dot || need_emd || tiles_per_step != 2 || !counts_fit_u8 || (nb_env != 0 && nb_env != 4))) return hipErrorInvalidValue;
+	// the products come from the GEMM (the caller checked the ranges): the forms the bench and the drivers reach, 8-bit counts, two tiles per step
 	if (!need_dot && tiles_per_step == 2 && counts_fit_u8 && (nb_env == 0 || nb_env == 4))
-		return need_emd ? launch_digest_multi<4, true, 2, true, false>(MSC_DG_ARGS) : launch_digest_multi<4, true, 2, false, false>(MSC_DG_ARGS);
+		return need_emd ? launch_digest_multi<4, true, 2, true, false>(MSC_DG_ARGS)
+		       : queries_per_wave == 8 ? launch_digest_multi<4, true, 2, false, false, 8>(MSC_DG_ARGS) : launch_digest_multi<4, true, 2, false, false>(MSC_DG_ARGS);
 #define MSC_DG_NB(U8, TPI)                                                                                                \
 	(nb_env == 2 ? launch_digest_multi<2, U8, TPI>(MSC_DG_ARGS) : nb_env == 3 ? launch_digest_multi<3, U8, TPI>(MSC_DG_ARGS) \
 	 : nb_env == 6 ? launch_digest_multi<6, U8, TPI>(MSC_DG_ARGS) : nb_env == 8 ? launch_digest_multi<8, U8, TPI>(MSC_DG_ARGS) \

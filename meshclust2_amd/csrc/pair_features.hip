@@ -1033,28 +1033,44 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogue
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueArgs a) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-	const uint32_t nqg = (a.n_queries + 15) / 16;
+	const uint32_t grp = a.cq_group;
+	const uint32_t nqg = (a.n_queries + grp - 1) / grp;
 	if (w >= a.m_per_query * nqg) return;
 	const uint32_t ci = w / nqg, qg = w % nqg;
-	const u32x4* rec = reinterpret_cast<const u32x4*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 16;
 	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-	for (uint32_t i = lane; i < a.S * 16; i += 64) {
-		const u32x4 p = rec[i];
-		t.manh += p.x; t.dot += p.y; t.emd += p.z;
+	if (grp == 32) {           // 4-byte records (manh), 32 queries per group: lane l always sees query l % 32
+		const uint32_t* rec = reinterpret_cast<const uint32_t*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 32;
+		for (uint32_t i = lane; i < a.S * 32; i += 64) t.manh += rec[i];
+		t.manh += __shfl_xor(t.manh, 32, 64);
+	} else if (a.dot_gemm) {   // 8-byte records (manh, emd): the digest kernel left the products to the matrix cores
+		const u32x2* rec = reinterpret_cast<const u32x2*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 16;
+		for (uint32_t i = lane; i < a.S * 16; i += 64) {
+			const u32x2 p = rec[i];
+			t.manh += p.x; t.emd += p.y;
+		}
+	} else {
+		const u32x4* rec = reinterpret_cast<const u32x4*>(a.partials_cq) + ((uint64_t)ci * nqg + qg) * a.S * 16;
+		for (uint32_t i = lane; i < a.S * 16; i += 64) {
+			const u32x4 p = rec[i];
+			t.manh += p.x; t.dot += p.y; t.emd += p.z;
+		}
 	}
+	if (grp == 16) {
 #pragma unroll
-	for (int off = 16; off <= 32; off <<= 1) {
-		t.manh += __shfl_xor(t.manh, off, 64);
-		t.dot += __shfl_xor(t.dot, off, 64);
-		t.emd += __shfl_xor(t.emd, off, 64);
+		for (int off = 16; off <= 32; off <<= 1) {
+			t.manh += __shfl_xor(t.manh, off, 64);
+			t.dot += __shfl_xor(t.dot, off, 64);
+			t.emd += __shfl_xor(t.emd, off, 64);
+		}
 	}
-	const uint32_t q = qg * 16 + lane;
-	if (lane < 16 && q < a.n_queries) {
+	const uint32_t q = qg * grp + lane;
+	if (lane < grp && q < a.n_queries) {
 		if (a.dot_gemm) {          // the products were computed on the matrix cores: add the slices of the bins
 			uint64_t d = 0;
 			for (uint32_t s_ = 0; s_ < a.dot_slices; s_++) d += (uint64_t)(uint32_t)a.dot_gemm[((uint64_t)s_ * a.m_per_query + ci) * a.dot_stride + q];
 			t.dot = d;
 		}
+		if (a.emd_ranks) t.emd = a.emd_ranks[(uint64_t)ci * 64 + q];
 		epilogue_one(a, q * a.m_per_query + ci, t);
 	}
 }
@@ -1724,7 +1740,8 @@ hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.m == 0) return hipSuccess;
 	if (a.partials_cq) {
-		const unsigned waves = a.m_per_query * ((a.n_queries + 15) / 16);
+		if (a.cq_group != 16 && (a.cq_group != 32 || !a.dot_gemm)) return hipErrorInvalidValue;      // (manh-only records: the products must come from the GEMM)
+		const unsigned waves = a.m_per_query * ((a.n_queries + a.cq_group - 1) / a.cq_group);
 		hipLaunchKernelGGL(k_pair_epilogue_cq, dim3((waves + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, a);
 	} else if (a.S > 4) {
 		const unsigned blocks = (a.m + kWavesPerBlock - 1) / kWavesPerBlock;
