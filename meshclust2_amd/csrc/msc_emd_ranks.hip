@@ -10,13 +10,13 @@
 // kernel spends one per BIN: 1 000 against 262 144 for BASELINE cfg2 (1 kb sequences, k = 9), where the prefix half was two thirds of
 // k_pair_digest_multi's arithmetic and half of its bytes.
 //
-//   ranks mirror   per slot `pitch` uint32 (pitch = the set's longest list rounded up to 64) and its length n: a_1 .. a_n, then nbins repeated -- with
+//   ranks mirror   per slot `pitch` uint32 (pitch = the set's longest list rounded up to 256) and its length n: a_1 .. a_n, then nbins repeated -- with
 //                  that padding | a_t - b_t | IS the tail term when one list has ended and 0 when both have, so the kernel has no cases.
 //                  Built from the digest mirror (whose prefix words say where each bin's copies go), refreshed with its stale range.
 //                  Needs every count >= 1 (the reference's histograms start at 1, KmerHashTable's initial value; a mean of such too):
 //                  a zero bin would make the prefix non-monotone -- the build reports it and the caller keeps the digest's prefix form.
-//   k_emd_ranks    one wave per candidate: 1 024 ranks of it in registers per round, every query's list streamed past them (L2-resident:
-//                  64 lists of 4 KiB), v_sad_u32 per rank, one wave sum per (pair, round), the pair's total kept in lane q.
+//   k_emd_ranks    a workgroup stages 1 024 ranks of 16 queries in LDS; each wave holds 1 024 ranks of a candidate in registers and
+//                  walks them past the 16 lists (v_sad_u32 per rank), one transposed fold per candidate for its 16 totals.
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -55,57 +55,103 @@ __global__ void __launch_bounds__(256) k_ranks_build(const uint8_t* __restrict__
 	}
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+
+// 16 per-lane sums (one per query of a group) -> one register: lane (row r, bank b) holds the wave total of query {0, 2, 1, 3}[b] + 4 r
+// in all four lanes of the bank. permlane32/16 swaps take 16 -> 8 -> 4 registers (row r of register i then holds 16 partial sums of
+// query i + 4 r), DPP adds and bank-masked merges the rest: 35 operations for 16 totals.
+__device__ __forceinline__ uint32_t fold16q(const uint32_t (&s)[16]) {
+	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
+	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
+	uint32_t r2[4];
 #pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
+	for (int i = 0; i < 4; i++) r2[i] = fold16(fold32(s[i], s[i + 8]), fold32(s[i + 4], s[i + 12]));
+	uint32_t X[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) X[i] = r2[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r2[i], 0x128, 0xf, 0xf, false);      // row_ror:8
+	uint32_t P = (uint32_t)__builtin_amdgcn_update_dpp((int)X[0], (int)X[1], 0xe4, 0xf, 0xc, false);      // lanes 8-15 <- register 1
+	uint32_t Q = (uint32_t)__builtin_amdgcn_update_dpp((int)X[2], (int)X[3], 0xe4, 0xf, 0xc, false);      // lanes 8-15 <- register 3
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x141, 0xf, 0xf, false);                        // row_half_mirror
+	Q += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Q, 0x141, 0xf, 0xf, false);
+	uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp((int)P, (int)Q, 0xe4, 0xf, 0xa, false);            // banks 1 and 3 <- registers 2 and 3
+	R += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R, 0xb1, 0xf, 0xf, false);
+	R += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R, 0x4e, 0xf, 0xf, false);
+	return R;
 }
 
+// One workgroup = one group of 16 queries x kCandPerWave candidates per wave. The queries' ranks of the current round (1 024 each) are
+// staged in LDS once and every candidate walks past them: 4 ds_read_b128 + 16 v_sad_u32 per pair and a 16-query fold per candidate
+// (the first version streamed every query list from L2 per candidate: 3.9 ms per 100 000 x 64 on cfg2, bound by those 26 GB of L2 reads).
+// Lists longer than a round (1 kb sequences: one round) add their rounds up in `out`.
+constexpr uint32_t kRound = 1024, kQGroup = 16, kCandPerWave = 16;
 __global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
                                                    uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
                                                    const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out) {
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t ci = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (ci >= m) return;
-	const uint64_t slot = cand_slots ? cand_slots[ci] : first + ci;
-	const uint32_t nc = c_n[slot];
-	const uint32_t* A = c_rk + slot * c_pitch;
-	const uint32_t my_q = lane < n_q ? q_slots[lane] : 0;
-	const uint32_t nq_l = lane < n_q ? q_n[my_q] : 0;
-	uint32_t n_all = nq_l;
+	__shared__ v4i_ sQ[kQGroup][kRound / 4];          // 64 KiB
+	__shared__ uint32_t s_nq[kQGroup];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t qg = blockIdx.y, q0 = qg * kQGroup;
+	const uint32_t c0 = (blockIdx.x * 4 + wave) * kCandPerWave;
+	if (threadIdx.x < kQGroup) s_nq[threadIdx.x] = q0 + threadIdx.x < n_q ? q_n[q_slots[q0 + threadIdx.x]] : 0;
+	__syncthreads();
+	uint32_t nq_max = 0;
 #pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(n_all, off, 64); n_all = o > n_all ? o : n_all; }
-	n_all = n_all > nc ? n_all : nc;
-	uint64_t tot = 0;          // lane q: the total of (candidate, query q)
-	for (uint32_t base = 0; base < n_all; base += 1024) {
-		uint32_t a[16];
-#pragma unroll
-		for (int j = 0; j < 16; j++) a[j] = base + 64 * j < c_pitch ? A[base + 64 * j + lane] : nbins;
-		for (uint32_t q = 0; q < n_q; q++) {
-			const uint32_t nq = __builtin_amdgcn_readlane(nq_l, q);
-			const uint32_t lim = nc > nq ? nc : nq;          // past both lists every term is | nbins - nbins |
-			if (base >= lim) continue;
-			const uint32_t* B = q_rk + (uint64_t)__builtin_amdgcn_readlane(my_q, q) * q_pitch;
-			uint32_t sum = 0;
-#pragma unroll
-			for (int j = 0; j < 16; j++) {
-				const uint32_t t0 = base + 64 * j;
-				if (t0 < lim) {
-					const uint32_t b = t0 < q_pitch ? B[t0 + lane] : nbins;
-					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(sum) : "v"(a[j]), "v"(b));      // nbins <= 2^20: 16 terms fit, and so do the 64 lanes' below
-				}
+	for (uint32_t q = 0; q < kQGroup; q++) nq_max = s_nq[q] > nq_max ? s_nq[q] : nq_max;
+	const uint64_t rounds_end = c_pitch > q_pitch ? c_pitch : q_pitch;      // workgroup-uniform (the barriers below); a wave skips what its lists do not reach
+	// which query's total a lane ends up with (fold16q), and whether this lane stores it
+	const uint32_t my_q = q0 + ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
+	const bool owner = (lane & 3) == 0 && my_q < n_q;
+	for (uint64_t base = 0; base < rounds_end; base += kRound) {
+		if (base) __syncthreads();          // everybody is done with the previous round's ranks
+		for (uint32_t i = threadIdx.x; i < kQGroup * (kRound / 4); i += 256) {
+			const uint32_t q = i / (kRound / 4), t4 = i % (kRound / 4);
+			v4i_ v = {(int)nbins, (int)nbins, (int)nbins, (int)nbins};          // (queries past n_q: never stored)
+			if (q0 + q < n_q && base + 4 * t4 < q_pitch) v = *reinterpret_cast<const v4i_*>(q_rk + (uint64_t)q_slots[q0 + q] * q_pitch + base + 4 * t4);
+			sQ[q][t4] = v;
+		}
+		__syncthreads();
+		for (uint32_t k = 0; k < kCandPerWave; k++) {
+			const uint32_t ci = c0 + k;
+			if (ci >= m) break;
+			const uint64_t slot = cand_slots ? cand_slots[ci] : first + ci;
+			const uint32_t nc = c_n[slot];
+			if (base >= (nc > nq_max ? nc : nq_max)) {          // past every list of this candidate and group: all terms | nbins - nbins |
+				if (base == 0 && owner) out[(uint64_t)ci * 64 + my_q] = 0;
+				continue;
 			}
-			sum = wave_sum_u32(sum);
-			if (lane == q) tot += sum;
+			v4i_ a[4];          // lane l: ranks 256 j + 4 l .. + 3 of the round
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				a[j] = v4i_{(int)nbins, (int)nbins, (int)nbins, (int)nbins};
+				if (base + 256 * j < c_pitch) a[j] = *reinterpret_cast<const v4i_*>(c_rk + slot * c_pitch + base + 256 * j + 4 * lane);
+			}
+			uint32_t sum[kQGroup];
+#pragma unroll
+			for (uint32_t q = 0; q < kQGroup; q++) {
+				uint32_t t = 0;          // nbins <= 2^20: 16 terms fit 32 bits, and so do the 64 lanes' in the fold
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const v4i_ b = sQ[q][64 * j + lane];
+					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].x), "v"(b.x));
+					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].y), "v"(b.y));
+					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].z), "v"(b.z));
+					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].w), "v"(b.w));
+				}
+				sum[q] = t;
+			}
+			const uint32_t tot = fold16q(sum);
+			if (owner) {
+				uint64_t* o = out + (uint64_t)ci * 64 + my_q;
+				*o = base ? *o + tot : (uint64_t)tot;
+			}
 		}
 	}
-	if (lane < n_q) out[(uint64_t)ci * 64 + lane] = tot;
 }
 
 }  // namespace
 
 // ranks per slot of a set whose longest list holds `max_excess` k-mers
-uint64_t msc_ranks_pitch(uint64_t max_excess) { return std::max<uint64_t>(64, (max_excess + 63) / 64 * 64); }
+uint64_t msc_ranks_pitch(uint64_t max_excess) { return std::max<uint64_t>(256, (max_excess + 255) / 256 * 256); }      // (k_emd_ranks loads 256 ranks per wave instruction)
 
 // *bad (device int32, zeroed by the caller) is set when a slot holds a zero count: the ranks of that set are then not usable
 hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, const uint8_t* digest, uint32_t* ranks, uint32_t* n_of, uint64_t pitch, uint64_t first_slot,
@@ -121,7 +167,7 @@ hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, const uint
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
                                 uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out) {
 	if (m == 0 || n_q == 0) return hipSuccess;
-	if (n_q > 64 || nbins > (1u << 20) || c_pitch % 64 || q_pitch % 64) return hipErrorInvalidValue;
-	k_emd_ranks<<<dim3((m + 3) / 4), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out);
+	if (n_q > 64 || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
+	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave), (n_q + kQGroup - 1) / kQGroup), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out);
 	return hipGetLastError();
 }

@@ -1210,6 +1210,44 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
         qs_set.clone_from(9, db, 30)
 
 
+@pytest.mark.parametrize("dtype,k,nq", [(32, 8, 24), (32, 8, 7), (16, 9, 40), (8, 8, 64)])
+def test_multi_query_emd_by_ranks_mixed_lengths(ctx, dtype, k, nq):
+    """The earth mover's distance of the Q x M pass from sorted k-mer ranks (msc_emd_ranks.hip): lists of very different lengths,
+    several rounds of 1 024 ranks, repeats (counts > 2), queries from a set with another pitch -- the same integers, hence the same
+    statistics and scores, as the per-bin prefix walk of the 1 x M pass."""
+    rng = np.random.default_rng(900 + k + nq)
+    seqs = []
+    for i in range(90):
+        n = int(rng.integers(200, 5200))
+        s = "".join("ACGT"[b] for b in rng.integers(0, 4, n))
+        if i % 5 == 0:
+            s = s[: n // 2] + "ACGTTGCA" * (n // 40) + s[n // 2:]          # a repeat: some bins counted many times
+        seqs.append(s)
+    db = api.HistogramSet(ctx, k, dtype, 70)
+    db.build(seqs[:70])
+    qset = api.HistogramSet(ctx, k, dtype, 64)
+    short = [s[:700] for s in seqs]
+    qset.build((seqs[70:] + short)[:64])          # the first 20 long, the rest short
+    feat = api.Feature.from_text(ctx, weights_text("weights_k9_u32.txt").replace("k: 9", "k: %d" % k).replace("uint32_t", "uint%d_t" % dtype), 0)
+    mask = FAST_MASK & ~((1 << 7) | (1 << 29))
+    qs = np.arange(nq, dtype=np.uint32)[::-1].copy()
+    multi = api.score_multi(ctx, feat, db, None, qset, qs, m=70, feat_mask=mask)
+    name = ctx.last_kernel_info()[0]
+    assert "emd by ranks" in name, name
+    for i, q in enumerate(qs):
+        raw = api.pair_features_raw(ctx, db, None, qset, int(q), mask, m=70)
+        single = feat.compute(db, None, qset, int(q), m=70)
+        assert np.array_equal(multi["raw"][i], raw), (i, name)
+        assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"]), i
+    # a longer histogram arrives in the candidate set: the mirror is laid out again with the new pitch
+    long_seq = "".join("ACGT"[b] for b in rng.integers(0, 4, 9000))
+    db.build([long_seq], first_slot=5)
+    multi = api.score_multi(ctx, feat, db, None, qset, qs, m=70, feat_mask=mask)
+    for i, q in enumerate(qs[:6]):
+        raw = api.pair_features_raw(ctx, db, None, qset, int(q), mask, m=70)
+        assert np.array_equal(multi["raw"][i], raw), i
+
+
 @pytest.mark.parametrize("dtype,k,nq", [(32, 9, 16), (8, 7, 9), (16, 8, 21), (32, 6, 5)])
 def test_multi_query_pass_without_emd(ctx, dtype, k, nq):
     """When neither the model nor the requested statistics include the earth mover's distance, the Q x M pass runs its count-only
