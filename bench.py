@@ -412,7 +412,9 @@ def main():
     # Per-rank figures (rank 0's shard: M candidates).
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
-    if "no emd" in kernel or "emd by ranks" in kernel:   # count-only form of the digest kernel: the prefix half of each tile is not fetched
+    if kernel.startswith("k_dot_gemm_i8"):   # everything from the matrix cores: the pass reads the count8 mirror, one byte per bin, once per 64 queries
+        hist_bytes = 4 ** args.k
+    elif "no emd" in kernel or "emd by ranks" in kernel:   # count-only form of the digest kernel: the prefix half of each tile is not fetched
         hist_bytes //= 2
     if args.layout == "sparse":            # a pair reads the candidate's entry list: 8 bytes per stored bin (mean over a sample of slots)
         hist_bytes = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))

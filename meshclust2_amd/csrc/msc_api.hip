@@ -132,6 +132,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->gemm_q8);
 	release(ctx->gemm_out);
 	release(ctx->emd_out);
+	release(ctx->gemm_min);
 	release(ctx->rk_bad);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
@@ -1908,6 +1909,17 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		emd_ranks = cands->ranks && qset->ranks;
 	}
 	const bool digest_emd = need_emd && !emd_ranks;                          // the digest kernel streams and scores the prefix half
+	// Every count of both sets below 5 / 9 (excess counts of 2 / 3 bits -- 1 kb sequences at k = 9 qualify): the Manhattan distance
+	// comes from the GEMM as well, as products of thermometer level bytes (msc_dot_gemm.hip) -- the digest kernel does not run at
+	// all, the pass is one read of a byte per bin per 64 queries. Needs the ranks mirrors (their build checks that no count is 0).
+	static const bool no_manh_gemm = getenv("MSC_MULTI_NO_MANH_GEMM") != nullptr;
+	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? atoi(e) : 3; }();
+	int level_bits = 0;
+	if (gemm_dot && !digest_emd && !no_manh_gemm && n_q >= 2 && mc_ <= (1u << max_level_bits)) {
+		if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
+		if (cands->ranks && qset->ranks) level_bits = mc_ <= 4 ? 2 : 3;
+	}
+	const bool manh_gemm = level_bits != 0;
 	const uint32_t n_rec = digest ? (uint32_t)(L.nbins / 1024) / tps : L.S;
 	// manh is all that is left to the digest kernel: eight queries per wave (32 per candidate tile fetched), 4-byte records
 	static const bool no_tq8 = getenv("MSC_DIGEST_NO_TQ8") != nullptr;
@@ -1915,10 +1927,12 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const uint64_t rec_bytes = digest && dg_tq == 8 ? 4 : digest && gemm_dot ? 8 : digest || ring ? 16 : sizeof(MscPartial);
 	const uint64_t q_rows = digest ? (n_q + 4 * dg_tq - 1) / (4 * dg_tq) * (4 * dg_tq) : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
+	// (no records without the digest kernel: the two product arrays of the GEMM, [slices][chunk][64] int32 each, kept to 2 GiB)
+	if (manh_gemm) chunk = (2048ull << 20) / ((uint64_t)msc_dot_gemm_slices(L.nbins, (uint32_t)std::min<uint64_t>(m, 1u << 30), ctx->num_cus) * 64 * sizeof(int32_t) * 2);
 	if (want_grp) chunk = std::min<uint64_t>(chunk, (1024ull << 20) / (n_q * 32 * sizeof(double)));      // [n_q][chunk][16][2] group records: 1 GiB
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
-	if ((r = ensure(ctx, ctx->partials, q_rows * chunk * n_rec * rec_bytes))) return r;
+	if (!manh_gemm && (r = ensure(ctx, ctx->partials, q_rows * chunk * n_rec * rec_bytes))) return r;
 	if (want_grp) {
 		if ((r = ensure(ctx, ctx->grp_pairs, n_q * chunk * 32 * sizeof(double)))) return r;
 		if ((r = ensure(ctx, ctx->grp_self, (chunk + n_q) * 16 * sizeof(double)))) return r;      // [candidates][16] then [queries][16]
@@ -1941,16 +1955,20 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
 	const uint32_t gemm_slices = gemm_dot ? msc_dot_gemm_slices(L.nbins, (uint32_t)chunk, ctx->num_cus) : 0;
 	if (gemm_dot && ((r = ensure(ctx, ctx->gemm_q8, 64 * L.nbins)) || (r = ensure(ctx, ctx->gemm_out, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t))))) return r;
+	if (manh_gemm && (r = ensure(ctx, ctx->gemm_min, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t)))) return r;
 	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * 64 * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
-	if (digest) {
+	if (manh_gemm) {
+		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_dot_gemm_i8<manh by %d levels + dot by mfma%s>", (1 << level_bits) - 1, emd_ranks ? ", emd by ranks" : ", no emd");
+		ctx->last_kernel = ctx->last_kernel_buf;
+	} else if (digest) {
 		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_digest_multi<%s counts%s%s>", mc_ < 256 ? "u8" : "u16",
 		         emd_ranks ? ", emd by ranks" : count_only ? ", no emd" : "", gemm_dot ? ", dot by mfma" : "");
 		ctx->last_kernel = ctx->last_kernel_buf;
 	} else ctx->last_kernel = ring ? "k_pair_tiles_multi32_ring" : "k_pair_tiles_multi";
 	// the digest kernel's workgroup scores up to 16 queries per candidate tile it fetches; the ring kernel's co-located query
 	// blocks fetch the tile once per group of tq queries (the followers usually hit in L2, which is not counted on)
-	ctx->last_query_tile = digest ? (int)std::min<uint64_t>(n_q, 4 * dg_tq) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
+	ctx->last_query_tile = manh_gemm ? (int)n_q : digest ? (int)std::min<uint64_t>(n_q, 4 * dg_tq) : (int)std::min<uint64_t>(n_q, (uint64_t)tq);
 	const bool whole = chunk == m;                 // one chunk: results land in the caller's arrays with plain copies
 	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	for (uint64_t off = 0; off < m; off += chunk) {
@@ -1959,7 +1977,10 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (digest)
+		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
+			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q,
+			                                 (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p, level_bits, (int32_t*)ctx->gemm_min.p));
+		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
 		else if (ring)
@@ -1969,7 +1990,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
-		if (gemm_dot)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
+		if (gemm_dot && !manh_gemm)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
 			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8,
 			                                 (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p));
 		if (emd_ranks)
@@ -2007,7 +2028,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = dvn; ea.div_base = L.nbins; }
 		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
-		ea.partials_cq = digest ? ctx->partials.p : nullptr;
+		ea.partials_cq = digest && !manh_gemm ? ctx->partials.p : nullptr;
+		if (manh_gemm) ea.min_gemm = (const int32_t*)ctx->gemm_min.p;
 		ea.cq_group = 4 * dg_tq;
 		if (gemm_dot) { ea.dot_gemm = (const int32_t*)ctx->gemm_out.p; ea.dot_slices = gemm_slices; ea.dot_stride = 64; }
 		if (emd_ranks) ea.emd_ranks = (const uint64_t*)ctx->emd_out.p;

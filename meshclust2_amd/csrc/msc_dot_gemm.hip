@@ -56,8 +56,32 @@ __global__ void __launch_bounds__(256) k_gather_rows8(const uint8_t* __restrict_
 	*reinterpret_cast<uint4*>(q8 + (uint64_t)r * nbins + i) = v;
 }
 
+// The thermometer levels of four bins' excess counts e = count - 1 (one byte each): byte b of lv[t - 1] = [e_b >= t], t = 1 .. 2^LB - 1, for
+// e < 2^LB (host-checked: the sets' largest count). min(e, e') = sum over t of [e >= t][e' >= t], so the products of the level bytes of two
+// histograms, added over levels and bins, are sum min(e_i, e'_i) -- and sum |e_i - e'_i| = sum e + sum e' - 2 sum min: the Manhattan
+// distance, the one statistic of the Q x M pass that is not bilinear in the counts, IS bilinear in their levels.
+template <int LB>
+__device__ __forceinline__ void levels(const v4i counts, v4i (&lv)[(1 << LB) - 1]) {
+	const v4i one = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+	const v4i e = counts - one;          // every count >= 1 (the ranks mirror's build checked): no borrow between bytes
+	if constexpr (LB == 2) {
+		const v4i b0 = e & one, b1 = (e >> 1) & one;
+		lv[0] = b0 | b1; lv[1] = b1; lv[2] = b0 & b1;
+	} else {
+		static_assert(LB == 3, "levels of 2- or 3-bit excess counts");
+		const v4i b0 = e & one, b1 = (e >> 1) & one, b2 = (e >> 2) & one;
+		const v4i lo = b0 | b1;
+		lv[3] = b2; lv[1] = b2 | b1; lv[5] = b2 & b1; lv[0] = b2 | lo; lv[2] = b2 | (b0 & b1); lv[4] = b2 & lo; lv[6] = lv[5] & b0;
+	}
+}
+
+// LB > 0: besides the products of the counts, sum min(e, e') from the level bytes (out_min, same layout): 2^LB - 1 more MFMAs per tile,
+// operands derived in registers from the same bytes -- the candidates are still read once.
+template <int LB>
 __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
-                                                     const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out) {
+                                                     const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out,
+                                                     int32_t* __restrict__ out_min) {
+	constexpr int NL = LB ? (1 << LB) - 1 : 0;
 	__shared__ v4i sA[2][64][16];          // [buffer][query row][16-byte segment ^ (row & 15)]: 32 KiB
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t ks = blockIdx.y;
@@ -71,9 +95,11 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 	const uint8_t* brow = cand8 + (slot >> 4) * (nbins >> 6) * 1024 + (slot & 15) * 64 + (lane >> 4) * 16;
 	const uint32_t arow = tid >> 2, aseg0 = (tid & 3) * 4;
 	const uint8_t* asrc = q8 + (uint64_t)arow * nbins + aseg0 * 16;
-	v4i acc[4];
+	v4i acc[4], acc_min[LB ? 4 : 1];
 #pragma unroll
 	for (int rb = 0; rb < 4; rb++) acc[rb] = v4i{0, 0, 0, 0};
+#pragma unroll
+	for (int rb = 0; rb < (LB ? 4 : 1); rb++) acc_min[rb] = v4i{0, 0, 0, 0};
 	v4i a_reg[4], b0[4], b1[4];          // plain vectors: HIP's uint4 struct kept these arrays in scratch
 	// The rows of the operands are a power of two apart (4^k bytes) and so are the slices: every workgroup walking its steps in the same
 	// order puts the whole chip on the same HBM channels at the same time (first version: 1.7 TB/s). Each workgroup therefore starts
@@ -81,7 +107,9 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 	const uint32_t steps = (uint32_t)(per / kStep);
 	const uint32_t rot = (blockIdx.x * 37u + ks * 11u) % steps;
 	// operands of step i (the last step once more past the end: a load nobody uses is cheaper than a branch around it -- with the
-	// loads under `if (more)` the compiler parked them in scratch and so waited for each as soon as it was issued)
+	// loads under `if (more)` the compiler parked them in scratch and so waited for each as soon as it was issued). One step ahead is
+	// enough: a third register set, two steps ahead, changed nothing (6.58 -> 6.51 ms) -- what held this kernel at 4 TB/s was the queries'
+	// side falling out of L2 (msc_dot_gemm_slices).
 	auto fetch = [&](uint32_t i, v4i (&b)[4]) {
 		const uint32_t j = (i < steps ? i : steps - 1) + rot;
 		const uint64_t k = k0 + (uint64_t)(j >= steps ? j - steps : j) * kStep;
@@ -98,11 +126,19 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 #pragma unroll
 		for (int kc = 0; kc < 4; kc++) {
 			const v4i B = b[kc];
+			v4i BL[NL ? NL : 1];
+			if constexpr (LB > 0) levels<LB>(B, BL);
 #pragma unroll
 			for (int rb = 0; rb < 4; rb++) {
 				// A operand: lane l = query 16 rb + l % 16, bins of block l / 16 of this 64-bin chunk
 				const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
 				acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[rb], 0, 0, 0);
+				if constexpr (LB > 0) {
+					v4i AL[NL];
+					levels<LB>(A, AL);
+#pragma unroll
+					for (int t = 0; t < NL; t++) acc_min[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AL[t], BL[t], acc_min[rb], 0, 0, 0);
+				}
 			}
 		}
 	};
@@ -125,6 +161,11 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 		int32_t* o = out + ((uint64_t)ks * m + ci) * 64 + 4 * (lane >> 4);
 #pragma unroll
 		for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o + 16 * rb) = acc[rb];
+		if constexpr (LB > 0) {
+			int32_t* o2 = out_min + ((uint64_t)ks * m + ci) * 64 + 4 * (lane >> 4);
+#pragma unroll
+			for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o2 + 16 * rb) = acc_min[rb];
+		}
 	}
 }
 
@@ -148,17 +189,28 @@ uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus) {
 	// enough workgroups for a few rounds of the chip; a slice is a whole number of 256-bin steps
 	uint32_t s = 1;
 	while (s < 64 && (uint64_t)((m + 63) / 64) * s < (uint64_t)num_cus * 10 && nbins / (2 * s) >= kStep && nbins % (2 * s * kStep) == 0) s *= 2;
+	// and slices short enough that the queries' side of ONE slice (64 rows) stays in an XCD's 4 MiB L2 while the workgroups of that
+	// slice -- dispatched together -- walk it in their different orders: with two slices of 8 MiB every step re-read its 16 KiB of queries
+	// from beyond L2, as many bytes again as the candidates' (4.0 TB/s of candidate bytes; 1 MiB slices: 5.5 TB/s, the epilogue adds 16 slices)
+	static const uint64_t a_bytes = [] { const char* e = getenv("MSC_GEMM_A_KIB"); return (uint64_t)(e ? std::max(64, atoi(e)) : 1024) << 10; }();
+	while (s < 64 && 64 * (nbins / s) > a_bytes && nbins / (2 * s) >= kStep && nbins % (2 * s * kStep) == 0) s *= 2;
 	return s;
 }
 
 // dots[slice][candidate][64] of n_q <= 64 queries (rows q_slots of q_count8) against m candidates (slot list, or slots first .. first + m - 1)
+// level_bits 2 / 3 (every excess count below 4 / 8): out_min[slice][candidate][64] = sum min(e, e') as well
 hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
-                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out) {
+                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,
+                               int level_bits, int32_t* out_min) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > 64 || nbins % (16 * 16) || nbins % ((uint64_t)k_slices * kStep)) return hipErrorInvalidValue;
+	if (level_bits != 0 && ((level_bits != 2 && level_bits != 3) || !out_min)) return hipErrorInvalidValue;
 	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_slots_dev, n_q, nbins, q8_scratch);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	k_dot_gemm_i8<<<dim3((m + 63) / 64, k_slices), dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out);
+	const dim3 grid((m + 63) / 64, k_slices);
+	if (level_bits == 2) k_dot_gemm_i8<2><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min);
+	else if (level_bits == 3) k_dot_gemm_i8<3><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min);
+	else k_dot_gemm_i8<0><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, nullptr);
 	return hipGetLastError();
 }

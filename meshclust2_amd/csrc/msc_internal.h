@@ -73,6 +73,7 @@ struct MscEpilogueArgs {
 	const void* partials_cq;          // or: [m_per_query][ceil(n_queries/16)][S][16] such records (digest kernel: one 256-byte run per workgroup step)
 	uint32_t cq_group;                // with partials_cq: queries per group -- 16, or 32 with 4-byte records (manh only: dot_gemm set, emd from emd_ranks or not wanted)
 	const uint64_t* emd_ranks;        // with partials_cq: the earth mover's distances from msc_emd_ranks.hip instead, [m_per_query][64] (query q at [q])
+	const int32_t* min_gemm;          // with dot_gemm, same layout: sum min(e, e') from the level bytes -- manh without any records (partials_cq unused)
 	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q]);
 	                                  // the records of partials_cq are then 8 bytes (manh, emd)
 	uint32_t dot_slices, dot_stride;
@@ -180,7 +181,8 @@ uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity);
 hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots);
 uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);
 hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
-                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out);
+                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,
+                               int level_bits = 0, int32_t* out_min = nullptr);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);

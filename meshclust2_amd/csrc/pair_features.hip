@@ -1075,6 +1075,29 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 	}
 }
 
+// No records at all (msc_dot_gemm.hip with level bytes): the products and sum min(e, e') per slice of the bins from the matrix cores,
+// the earth mover's distance from the ranks. One wave per candidate, lane q = query q -- every lane evaluates a pair.
+//     manh = sum |e - e'| = sum e + sum e' - 2 sum min(e, e'),     sum e = (sum of the bins) - 4^k
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_gemm(const MscEpilogueArgs a) {
+	const uint32_t q = threadIdx.x & 63;
+	const uint32_t ci = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+	if (ci >= a.m_per_query || q >= a.n_queries) return;
+	uint64_t dot = 0, common = 0;
+	for (uint32_t s_ = 0; s_ < a.dot_slices; s_++) {
+		const uint64_t at = ((uint64_t)s_ * a.m_per_query + ci) * a.dot_stride + q;
+		dot += (uint64_t)(uint32_t)a.dot_gemm[at];
+		common += (uint64_t)(uint32_t)a.min_gemm[at];
+	}
+	const uint32_t slot = a.cand_slots ? a.cand_slots[ci] : ci;
+	const uint64_t sum_c = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride)->sum;
+	const uint64_t sum_q = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)a.q_slots[q] * a.q_scalar_stride)->sum;
+	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+	t.manh = (sum_c - a.nbins) + (sum_q - a.nbins) - 2 * common;
+	t.dot = dot;
+	if (a.emd_ranks) t.emd = a.emd_ranks[(uint64_t)ci * 64 + q];
+	epilogue_one(a, q * a.m_per_query + ci, t);
+}
+
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= a.m) return;
@@ -1739,7 +1762,10 @@ hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, 
 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.m == 0) return hipSuccess;
-	if (a.partials_cq) {
+	if (a.min_gemm) {
+		if (!a.dot_gemm || a.n_queries > 64 || a.n_queries < 2) return hipErrorInvalidValue;      // (epilogue_one's query-major index needs n_queries > 1)
+		hipLaunchKernelGGL(k_pair_epilogue_gemm, dim3((a.m_per_query + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, a);
+	} else if (a.partials_cq) {
 		if (a.cq_group != 16 && (a.cq_group != 32 || !a.dot_gemm)) return hipErrorInvalidValue;      // (manh-only records: the products must come from the GEMM)
 		const unsigned waves = a.m_per_query * ((a.n_queries + a.cq_group - 1) / a.cq_group);
 		hipLaunchKernelGGL(k_pair_epilogue_cq, dim3((waves + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, a);

@@ -24,7 +24,8 @@ def main():
         feat = api.Feature.from_text(ctx, open(os.path.join(golden, "weights_k9_u32.txt")).read(), 0)
         mask = FAST_MASK
         for nq, cands in ((4, np.arange(n, dtype=np.uint32)), (9, np.arange(5, n, dtype=np.uint32)), (16, np.arange(n - 1, -1, -1, dtype=np.uint32)),
-                          (8, np.array([7], dtype=np.uint32)), (5, np.array([3, 9, 4], dtype=np.uint32))):
+                          (8, np.array([7], dtype=np.uint32)), (5, np.array([3, 9, 4], dtype=np.uint32)),
+                          (40, np.arange(n, dtype=np.uint32)), (64, np.arange(3, n, dtype=np.uint32)), (33, np.arange(n - 1, 100, -1, dtype=np.uint32))):
             qs = (np.arange(nq, dtype=np.uint32) * 3) % n
             multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
             for i, q in enumerate(qs):

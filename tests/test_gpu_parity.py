@@ -551,6 +551,28 @@ def test_multi_digest_variants(slots):
     assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
 
 
+@pytest.mark.parametrize("switches", ["", "MSC_MULTI_NO_MANH_GEMM", "MSC_MULTI_NO_MANH_GEMM MSC_DIGEST_NO_TQ8", "MSC_MULTI_NO_MANH_GEMM MSC_MULTI_NO_RANKS",
+                                      "MSC_MULTI_NO_GEMM", "MSC_MULTI_NO_GEMM MSC_MULTI_NO_RANKS", "MSC_GEMM_LEVEL_BITS=2"])
+def test_multi_route_variants(switches):
+    """Every route of the Q x M pass over a dense set == independent 1 x M passes, bit for bit (the library reads its switches once
+    per process): everything on the matrix cores (manh from thermometer levels, msc_dot_gemm.hip) with the earth mover's distance
+    from ranks (msc_emd_ranks.hip); the manh-only digest kernel with 8 and with 4 queries per wave + GEMM + ranks; digest with its
+    prefix half + GEMM; digest with its own products + ranks; the r02 digest kernel alone; level products for counts up to 4 only."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    for k in ("MSC_MULTI_TQ", "MSC_MULTI_NO_DIGEST", "MSC_MULTI_NO_RING", "MSC_RING_NO_P16", "MSC_RING_SLOTS", "MSC_DIGEST_SLOTS", "MSC_MULTI_NO_MANH_GEMM",
+              "MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_GEMM", "MSC_DIGEST_NO_TQ8", "MSC_GEMM_LEVEL_BITS"):
+        env.pop(k, None)
+    for sw in switches.split():
+        name, _, val = sw.partition("=")
+        env[name] = val or "1"
+    out = subprocess.run([sys.executable, os.path.join(here, "ring_variant_check.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
+
+
 def test_cluster_driver_reproduces_reference_clstr(tmp_path):
     """the from-scratch mean-shift driver over the GPU path, fed the model the reference trained, writes
     the SAME .clstr bytes as the reference CLI did for cfg1 (1000 x 1 kb, --id 0.9 --kmer 5 --datatype 16, 1 thread)."""
@@ -988,7 +1010,7 @@ def test_full_size_cfg2_properties(oracle):
     qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
     fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
     multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
-    assert ctx.last_kernel_info()[0].startswith("k_pair_digest_multi")
+    assert ctx.last_kernel_info()[0].startswith(("k_dot_gemm_i8", "k_pair_digest_multi"))
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
@@ -1201,7 +1223,7 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
     mask = FAST_MASK & ~((1 << 7) | (1 << 29))
     for rnd in range(2):
         multi = api.score_multi(ctx, feat, db, None, qs_set, q_slots, m=70, feat_mask=mask)
-        assert ctx.last_kernel_info()[0].startswith("k_pair_digest_multi")
+        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_dot_gemm_i8"))
         for i, q in enumerate(q_slots):
             raw = api.pair_features_raw(ctx, db, None, qs_set, int(q), mask, m=70)
             single = feat.compute(db, None, qs_set, int(q), m=70)
