@@ -60,25 +60,35 @@ __global__ void __launch_bounds__(256) k_gather_rows8(const uint8_t* __restrict_
 // e < 2^LB (host-checked: the sets' largest count). min(e, e') = sum over t of [e >= t][e' >= t], so the products of the level bytes of two
 // histograms, added over levels and bins, are sum min(e_i, e'_i) -- and sum |e_i - e'_i| = sum e + sum e' - 2 sum min: the Manhattan
 // distance, the one statistic of the Q x M pass that is not bilinear in the counts, IS bilinear in their levels.
-template <int LB>
-__device__ __forceinline__ void levels(const v4i counts, v4i (&lv)[(1 << LB) - 1]) {
-	const v4i one = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
-	const v4i e = counts - one;          // every count >= 1 (the ranks mirror's build checked): no borrow between bytes
-	if constexpr (LB == 2) {
-		const v4i b0 = e & one, b1 = (e >> 1) & one;
-		lv[0] = b0 | b1; lv[1] = b1; lv[2] = b0 & b1;
-	} else {
-		static_assert(LB == 3, "levels of 2- or 3-bit excess counts");
-		const v4i b0 = e & one, b1 = (e >> 1) & one, b2 = (e >> 2) & one;
-		const v4i lo = b0 | b1;
-		lv[3] = b2; lv[1] = b2 | b1; lv[5] = b2 & b1; lv[0] = b2 | lo; lv[2] = b2 | (b0 & b1); lv[4] = b2 & lo; lv[6] = lv[5] & b0;
-	}
+// byte b of the result = [e_b >= T] for the four excess counts e_b < 8 of a word. v_perm_b32 is a byte-wise table lookup: selector bytes
+// 0..7 pick from an 8-byte table -- with the excess counts as selectors and the table [j >= T] (j = 0..7), one instruction per level and
+// word (bit logic on the three bits of e took 12 per word for 7 levels).
+template <int T>
+__device__ __forceinline__ v4i level_of(const v4i e) {
+	uint32_t lo = 0, hi = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) { lo |= (uint32_t)(j >= T) << (8 * j); hi |= (uint32_t)(j + 4 >= T) << (8 * j); }
+	v4i r;
+#pragma unroll
+	for (int c = 0; c < 4; c++) r[c] = (int)__builtin_amdgcn_perm(hi, lo, (uint32_t)e[c]);
+	return r;
+}
+// the same with the level in a register (the path for tiles that hold repeats: a loop, not seven copies of its body)
+__device__ __forceinline__ v4i level_at(const v4i e, uint32_t T) {
+	const uint64_t tab = 0x0101010101010101ull << (8 * T);          // byte j = [j >= T]
+	v4i r;
+#pragma unroll
+	for (int c = 0; c < 4; c++) r[c] = (int)__builtin_amdgcn_perm((uint32_t)(tab >> 32), (uint32_t)tab, (uint32_t)e[c]);
+	return r;
 }
 
 // LB > 0: besides the products of the counts, sum min(e, e') from the level bytes (out_min, same layout): 2^LB - 1 more MFMAs per tile,
 // operands derived in registers from the same bytes -- the candidates are still read once.
-template <int LB>
-__global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+// NCB: blocks of 16 candidates per wave. The level bytes of a query operand serve every candidate block of the wave (and a candidate
+// operand's all four query blocks): with one block a step derived 20 operands for 16 MFMA tiles and the kernel was bound by those
+// v_perm_b32, with two it derives 24 for 32.
+template <int LB, int NCB>
+__global__ void __launch_bounds__(256) k_dot_gemm_i8(          // (held to 128 registers -- 4 waves per SIMD -- the compiler spills the operand loads: 12.4 ms against 5.2)const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                      const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out,
                                                      int32_t* __restrict__ out_min) {
 	constexpr int NL = LB ? (1 << LB) - 1 : 0;
@@ -86,21 +96,31 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t ks = blockIdx.y;
 	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
-	const uint32_t ci = blockIdx.x * 64 + wave * 16 + (lane & 15);
-	const bool valid = ci < m;
-	const uint32_t cc = valid ? ci : m - 1;
-	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
-	// lane l: candidate l % 16 of the wave, bytes 16 (l / 16) .. + 15 of every 64-bin chunk: consecutive slots of one block make the
-	// wave's load one contiguous KiB
-	const uint8_t* brow = cand8 + (slot >> 4) * (nbins >> 6) * 1024 + (slot & 15) * 64 + (lane >> 4) * 16;
+	uint32_t ci[NCB];
+	bool valid[NCB];
+	const uint8_t* brow[NCB];
+#pragma unroll
+	for (int cb = 0; cb < NCB; cb++) {
+		ci[cb] = (blockIdx.x * 4 + wave) * (16 * NCB) + 16 * cb + (lane & 15);
+		valid[cb] = ci[cb] < m;
+		const uint32_t cc = valid[cb] ? ci[cb] : m - 1;
+		const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+		// lane l: candidate l % 16 of the block, bytes 16 (l / 16) .. + 15 of every 64-bin chunk: consecutive slots of one block make the
+		// wave's load one contiguous KiB
+		brow[cb] = cand8 + (slot >> 4) * (nbins >> 6) * 1024 + (slot & 15) * 64 + (lane >> 4) * 16;
+	}
 	const uint32_t arow = tid >> 2, aseg0 = (tid & 3) * 4;
 	const uint8_t* asrc = q8 + (uint64_t)arow * nbins + aseg0 * 16;
-	v4i acc[4], acc_min[LB ? 4 : 1];
+	v4i acc[NCB][4], acc_min[LB ? NCB : 1][4];
 #pragma unroll
-	for (int rb = 0; rb < 4; rb++) acc[rb] = v4i{0, 0, 0, 0};
+	for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-	for (int rb = 0; rb < (LB ? 4 : 1); rb++) acc_min[rb] = v4i{0, 0, 0, 0};
-	v4i a_reg[4], b0[4], b1[4];          // plain vectors: HIP's uint4 struct kept these arrays in scratch
+		for (int rb = 0; rb < 4; rb++) acc[cb][rb] = v4i{0, 0, 0, 0};
+#pragma unroll
+	for (int cb = 0; cb < (LB ? NCB : 1); cb++)
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++) acc_min[cb][rb] = v4i{0, 0, 0, 0};
+	v4i a_reg[4], b0[NCB][4], b1[NCB][4];          // plain vectors: HIP's uint4 struct kept these arrays in scratch
 	// The rows of the operands are a power of two apart (4^k bytes) and so are the slices: every workgroup walking its steps in the same
 	// order puts the whole chip on the same HBM channels at the same time (first version: 1.7 TB/s). Each workgroup therefore starts
 	// its walk somewhere else -- a sum does not care in which order its terms arrive.
@@ -110,34 +130,79 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 	// loads under `if (more)` the compiler parked them in scratch and so waited for each as soon as it was issued). One step ahead is
 	// enough: a third register set, two steps ahead, changed nothing (6.58 -> 6.51 ms) -- what held this kernel at 4 TB/s was the queries'
 	// side falling out of L2 (msc_dot_gemm_slices).
-	auto fetch = [&](uint32_t i, v4i (&b)[4]) {
+	auto fetch = [&](uint32_t i, v4i (&b)[NCB][4]) {
 		const uint32_t j = (i < steps ? i : steps - 1) + rot;
 		const uint64_t k = k0 + (uint64_t)(j >= steps ? j - steps : j) * kStep;
 #pragma unroll
 		for (int t = 0; t < 4; t++) a_reg[t] = *reinterpret_cast<const v4i*>(asrc + k + 16 * t);
 #pragma unroll
-		for (int kc = 0; kc < 4; kc++) b[kc] = *reinterpret_cast<const v4i*>(brow + ((k >> 6) + kc) * 1024);
+		for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+			for (int kc = 0; kc < 4; kc++) b[cb][kc] = *reinterpret_cast<const v4i*>(brow[cb] + ((k >> 6) + kc) * 1024);
 	};
 	auto park = [&](uint32_t buf) {
 #pragma unroll
 		for (int t = 0; t < 4; t++) sA[buf][arow][(aseg0 + t) ^ (arow & 15)] = a_reg[t];
 	};
-	auto multiply = [&](uint32_t buf, const v4i (&b)[4]) {
+	// The levels a tile of candidates does not reach cost nothing: their products are zero whatever the queries hold (min(e, e') <= e), so
+	// a wave looks at its candidates' bytes first. No excess count above 1 in the tile (1 kb sequences at k = 9: 99 % of the tiles) --
+	// the candidates' level-1 bytes are the excess counts themselves and only the queries' level 1 is derived: 2 MFMAs per tile instead
+	// of 2^LB. Otherwise the levels present are taken one by one until one is absent from every candidate of the tile (they nest).
+	auto multiply = [&](uint32_t buf, const v4i (&b)[NCB][4]) {
+		const v4i one = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 #pragma unroll
 		for (int kc = 0; kc < 4; kc++) {
-			const v4i B = b[kc];
-			v4i BL[NL ? NL : 1];
-			if constexpr (LB > 0) levels<LB>(B, BL);
+			if constexpr (LB == 0) {
 #pragma unroll
-			for (int rb = 0; rb < 4; rb++) {
-				// A operand: lane l = query 16 rb + l % 16, bins of block l / 16 of this 64-bin chunk
-				const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
-				acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B, acc[rb], 0, 0, 0);
-				if constexpr (LB > 0) {
-					v4i AL[NL];
-					levels<LB>(A, AL);
+				for (int rb = 0; rb < 4; rb++) {
+					// A operand: lane l = query 16 rb + l % 16, bins of block l / 16 of this 64-bin chunk
+					const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
 #pragma unroll
-					for (int t = 0; t < NL; t++) acc_min[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(AL[t], BL[t], acc_min[rb], 0, 0, 0);
+					for (int cb = 0; cb < NCB; cb++) acc[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, b[cb][kc], acc[cb][rb], 0, 0, 0);
+				}
+			} else {
+				v4i E[NCB];          // excess counts of the candidates (every count >= 1, the ranks mirror's build checked: no borrow between bytes)
+				uint32_t above = 0;
+#pragma unroll
+				for (int cb = 0; cb < NCB; cb++) {
+					E[cb] = b[cb][kc] - one;
+					above |= (uint32_t)(E[cb].x | E[cb].y | E[cb].z | E[cb].w);
+				}
+				if (__builtin_amdgcn_ballot_w64((above & 0xfefefefeu) != 0) == 0) {
+#pragma unroll
+					for (int rb = 0; rb < 4; rb++) {
+						const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
+						const v4i A1 = level_of<1>(A - one);
+#pragma unroll
+						for (int cb = 0; cb < NCB; cb++) {
+							acc[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, b[cb][kc], acc[cb][rb], 0, 0, 0);
+							acc_min[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, E[cb], acc_min[cb][rb], 0, 0, 0);
+						}
+					}
+				} else {
+					// how many levels the tile reaches (they nest: the first one no candidate byte reaches ends the walk)
+					uint32_t reach = 1;
+#pragma unroll 1
+					for (uint32_t T = 2; T <= (uint32_t)NL; T++) {
+						uint32_t any = 0;
+#pragma unroll
+						for (int cb = 0; cb < NCB; cb++) { const v4i l = level_at(E[cb], T); any |= (uint32_t)(l.x | l.y | l.z | l.w); }
+						if (__builtin_amdgcn_ballot_w64(any != 0) == 0) break;
+						reach = T;
+					}
+#pragma unroll
+					for (int rb = 0; rb < 4; rb++) {
+						const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
+						const v4i AE = A - one;
+#pragma unroll
+						for (int cb = 0; cb < NCB; cb++) acc[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, b[cb][kc], acc[cb][rb], 0, 0, 0);
+#pragma unroll 1
+						for (uint32_t T = 1; T <= reach; T++) {
+							const v4i al = level_at(AE, T);
+#pragma unroll
+							for (int cb = 0; cb < NCB; cb++) acc_min[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, level_at(E[cb], T), acc_min[cb][rb], 0, 0, 0);
+						}
+					}
 				}
 			}
 		}
@@ -157,14 +222,16 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 		__syncthreads();
 	}
 	// D: lane l holds column l % 16 (its candidate), rows 4 (l / 16) .. + 3 of each 16-query block
-	if (valid) {
-		int32_t* o = out + ((uint64_t)ks * m + ci) * 64 + 4 * (lane >> 4);
 #pragma unroll
-		for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o + 16 * rb) = acc[rb];
+	for (int cb = 0; cb < NCB; cb++) {
+		if (!valid[cb]) continue;
+		int32_t* o = out + ((uint64_t)ks * m + ci[cb]) * 64 + 4 * (lane >> 4);
+#pragma unroll
+		for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o + 16 * rb) = acc[cb][rb];
 		if constexpr (LB > 0) {
-			int32_t* o2 = out_min + ((uint64_t)ks * m + ci) * 64 + 4 * (lane >> 4);
+			int32_t* o2 = out_min + ((uint64_t)ks * m + ci[cb]) * 64 + 4 * (lane >> 4);
 #pragma unroll
-			for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o2 + 16 * rb) = acc_min[rb];
+			for (int rb = 0; rb < 4; rb++) *reinterpret_cast<v4i*>(o2 + 16 * rb) = acc_min[cb][rb];
 		}
 	}
 }
@@ -208,9 +275,13 @@ hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* ca
 	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_slots_dev, n_q, nbins, q8_scratch);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
-	const dim3 grid((m + 63) / 64, k_slices);
-	if (level_bits == 2) k_dot_gemm_i8<2><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min);
-	else if (level_bits == 3) k_dot_gemm_i8<3><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min);
-	else k_dot_gemm_i8<0><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, nullptr);
+	static const int ncb_env = [] { const char* e = getenv("MSC_GEMM_NCB"); return e ? atoi(e) : 0; }();
+	const int ncb = ncb_env == 2 ? 2 : 1;          // (two blocks paid while every level was multiplied out; with the levels a tile does not reach skipped, one is faster: 5.25 against 5.44 ms)
+	const dim3 grid((m + 64 * ncb - 1) / (64 * ncb), k_slices);
+#define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min)
+	if (level_bits == 2) { if (ncb == 2) MSC_GEMM_GO(2, 2); else MSC_GEMM_GO(2, 1); }
+	else if (level_bits == 3) { if (ncb == 2) MSC_GEMM_GO(3, 2); else MSC_GEMM_GO(3, 1); }
+	else { if (ncb == 2) MSC_GEMM_GO(0, 2); else MSC_GEMM_GO(0, 1); }
+#undef MSC_GEMM_GO
 	return hipGetLastError();
 }
