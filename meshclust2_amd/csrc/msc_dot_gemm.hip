@@ -87,8 +87,9 @@ __device__ __forceinline__ v4i level_at(const v4i e, uint32_t T) {
 // NCB: blocks of 16 candidates per wave. The level bytes of a query operand serve every candidate block of the wave (and a candidate
 // operand's all four query blocks): with one block a step derived 20 operands for 16 MFMA tiles and the kernel was bound by those
 // v_perm_b32, with two it derives 24 for 32.
+// (Held to 128 registers -- 4 waves per SIMD instead of 3 -- the compiler spills the operand loads: 12.4 ms against 5.2.)
 template <int LB, int NCB>
-__global__ void __launch_bounds__(256) k_dot_gemm_i8(          // (held to 128 registers -- 4 waves per SIMD -- the compiler spills the operand loads: 12.4 ms against 5.2)const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+__global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                      const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out,
                                                      int32_t* __restrict__ out_min) {
 	constexpr int NL = LB ? (1 << LB) - 1 : 0;
