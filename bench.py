@@ -271,6 +271,8 @@ def main():
     if world > 1:
         all_bins, all_scal = shard.device_tensors(hs, M + 2 * Q)      # [slot, bytes] views of the set's device memory
 
+        block_out = {}
+
         class GpuBackend:
             def query_buffers(self, j=0):
                 return [all_bins[M + j], all_scal[M + j]]
@@ -296,7 +298,9 @@ def main():
                 return flags, bp, bs
 
             def score_block(self, n, base=0):
-                return api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close",))["close"]
+                if n not in block_out:          # the block's product (one close flag per pair) lands in page-locked memory allocated once
+                    block_out[n] = {"close": api.pinned_array(ctx, (n, M), np.uint8)}
+                return api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close",), out=block_out[n])["close"]
 
         if gloo_group is not None:
             # preflight: one all-gather and one broadcast over RCCL on the library's own device views (they are not torch allocations).
@@ -333,6 +337,8 @@ def main():
     if cw:
         plan_w = shard.ShardPlan(n_total, cw, block=BLOCK)
         m_min_w = min(plan_w.local_count(r) for r in range(cw))
+    # the step's product -- one close flag per pair, Q x M bytes -- lands in page-locked host memory allocated once
+    out_close = {"close": api.pinned_array(ctx, (Q, M), np.uint8)} if args.mode == "allpairs" and world == 1 else None
     step_no = [0]
     pending = [None, None]          # RCCL work handles of the query block in flight per buffer half (N > 1, allpairs)
     qpr = Q // world                # queries every rank contributes per step
@@ -364,7 +370,7 @@ def main():
                     qs = np.array([plan_w.global_index(r, first + j) for r in range(cw) for j in range(Q // cw)], dtype=np.uint32)
                 else:
                     qs = np.array([((st * Q + j) * 7919) % M for j in range(Q)], dtype=np.uint32)
-                res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",))
+                res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",), out=out_close)
                 if args.check:
                     checks.append([int(x) for x in res["close"].sum(axis=1)])
             tiles_ms.append(ctx.last_kernel_ms()[0])

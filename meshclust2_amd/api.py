@@ -297,17 +297,36 @@ def pair_features_raw(ctx, cands, cand_slots, qset, q_slot, feat_mask=FEAT_FAST,
     return out
 
 
-def score_multi(ctx, feat, cands, cand_slots, qset, q_slots, order=ORDER_CAND_FIRST, m=None, feat_mask=0, want=("sum", "csum", "close")):
+def pinned_array(ctx, shape, dtype):
+    """a numpy array over page-locked host memory (msc_host_alloc; lives as long as the context): device-to-host copies into it are
+    not staged by the runtime. For result arrays that are filled call after call (score_multi's `out`)."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    ctx.check(ctx.lib.msc_host_alloc(ctx.h, n, C.byref(p)))
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def score_multi(ctx, feat, cands, cand_slots, qset, q_slots, order=ORDER_CAND_FIRST, m=None, feat_mask=0, want=("sum", "csum", "close"), out=None):
     """n_q queries x m candidates in one pass over the candidates (all-pairs shape).
-    -> dict(sum [n_q,m], csum [n_q,m], close [n_q,m], raw [n_q,m,nf] or None); `want` limits what is copied back"""
+    -> dict(sum [n_q,m], csum [n_q,m], close [n_q,m], raw [n_q,m,nf] or None); `want` limits what is copied back;
+    out: dict of arrays of those shapes to fill instead of new ones (pinned_array: no allocation, no staged copy per call)"""
     sl, m = _slots(cand_slots, m)
     qs = np.ascontiguousarray(q_slots, dtype=np.uint32)
     nq = qs.size
     nf = bin(feat_mask).count("1")
-    s = np.zeros((nq, m)) if feat is not None and "sum" in want else None
-    cs = np.zeros((nq, m)) if feat is not None and "csum" in want else None
-    close = np.zeros((nq, m), dtype=np.uint8) if feat is not None and "close" in want else None
-    raw = np.zeros((nq, m, nf)) if nf else None
+
+    def arr(name, shape, dtype):
+        a = (out or {}).get(name)
+        if a is not None:
+            if a.shape != shape or a.dtype != np.dtype(dtype) or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("out[%r] must be a C-contiguous %s array of shape %r" % (name, np.dtype(dtype), shape))
+            return a
+        return np.zeros(shape, dtype=dtype)
+    s = arr("sum", (nq, m), np.float64) if feat is not None and "sum" in want else None
+    cs = arr("csum", (nq, m), np.float64) if feat is not None and "csum" in want else None
+    close = arr("close", (nq, m), np.uint8) if feat is not None and "close" in want else None
+    raw = arr("raw", (nq, m, nf), np.float64) if nf else None
     ctx.check(ctx.lib.msc_score_multi(ctx.h, feat.h if feat is not None else None, cands.h, _ptr(sl), m, qset.h, _ptr(qs), nq, order,
                                       _ptr(s), _ptr(cs), _ptr(close), feat_mask, _ptr(raw)))
     return dict(sum=s, csum=cs, close=close, raw=raw)

@@ -1666,16 +1666,32 @@ static int ensure_count8(msc_ctx* ctx, const msc_hist_set* set) {
 		set->c8_hi = set->capacity;
 	}
 	if (set->c8_lo < set->c8_hi) {
-		HIP_TRY(ctx, msc_launch_count8_build(ctx->stream, set->L, set->dtype, set->bins, set->count8, set->c8_lo, set->c8_hi - set->c8_lo));
+		// runs of slots that hold a histogram; the build says whether it met a zero count (sticky: the level products of
+		// msc_dot_gemm.hip take count - 1 of every byte)
+		int r;
+		if ((r = ensure(ctx, ctx->rk_bad, sizeof(int32_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, sizeof(int32_t), ctx->stream));
+		const uint64_t hi = std::min<uint64_t>(set->c8_hi, set->written.size());
+		for (uint64_t i = set->c8_lo; i < hi;) {
+			if (!set->written[i]) { i++; continue; }
+			uint64_t j = i;
+			while (j < hi && set->written[j]) j++;
+			HIP_TRY(ctx, msc_launch_count8_build(ctx->stream, set->L, set->dtype, set->bins, set->count8, i, j - i, (int32_t*)ctx->rk_bad.p));
+			i = j;
+		}
+		int32_t bad = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->rk_bad.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (bad) set->c8_has_zero = true;
 		set->c8_lo = set->c8_hi = 0;
 	}
 	return MSC_OK;
 }
 
-// The ranks mirror of a dense set (msc_emd_ranks.hip), from its digest mirror (current when this is called). MSC_OK with
-// set->ranks == nullptr when it cannot be had (no memory, or a slot holds a zero count): the digest kernel then keeps the prefixes.
+// The ranks mirror of a dense set (msc_emd_ranks.hip), from its bins. MSC_OK with set->ranks == nullptr when it cannot be had (no
+// memory, or a slot holds a zero count): the digest kernel then keeps the prefixes.
 static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
-	if (set->sparse || !set->digest || set->ranks_unavailable || set->max_sum < set->L.nbins) return MSC_OK;
+	if (set->sparse || set->dtype == 64 || !msc_digest_supported(set->L) || set->ranks_unavailable || set->max_sum < set->L.nbins) return MSC_OK;
 	const uint64_t pitch = msc_ranks_pitch(set->max_sum - set->L.nbins);
 	if (set->ranks && pitch > set->rk_pitch) {          // a longer list than any before: lay the mirror out again
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1706,7 +1722,7 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 			if (!set->written[i]) { i++; continue; }
 			uint64_t j = i;
 			while (j < hi && set->written[j]) j++;
-			HIP_TRY(ctx, msc_launch_ranks_build(ctx->stream, set->L, set->digest, set->ranks, set->rk_n, set->rk_pitch, i, j - i, (int32_t*)ctx->rk_bad.p));
+			HIP_TRY(ctx, msc_launch_ranks_build(ctx->stream, set->L, set->dtype, set->bins, set->scalars, set->ranks, set->rk_n, set->rk_pitch, i, j - i, (int32_t*)ctx->rk_bad.p));
 			i = j;
 		}
 		int32_t bad = 0;
@@ -1868,58 +1884,64 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const bool compact = 64ull * L.R * mc_ * mc_ < (1ull << 32) && 64ull * L.R * ms_ < (1ull << 32);
 	// every prefix of excess counts (count - 1) is at most the histogram's k-mer total = sum - 4^k: 16-bit prefix form when that fits
 	const bool excess16 = ms_ >= L.nbins && ms_ - L.nbins < 65536;
-	// Digest form (pair_digest.hip): 32-bit sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen
-	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
+	const bool need_emd = ((want | feat_mask) & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
 	static const bool no_digest = getenv("MSC_MULTI_NO_DIGEST") != nullptr;
+	static const bool no_gemm = getenv("MSC_MULTI_NO_GEMM") != nullptr;
+	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
+	static const bool no_manh_gemm = getenv("MSC_MULTI_NO_MANH_GEMM") != nullptr;
+	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? atoi(e) : 3; }();
+	const bool tuned_by_hand = getenv("MSC_MULTI_TQ") || getenv("MSC_DIGEST_SLOTS");          // A/B switches of the older kernels: keep to them
+	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
+	// longest list is a quarter of the bins or less, for up to 64 queries and 2^20 bins (32-bit wave sums)
+	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 64 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
+	// The products on the matrix cores (msc_dot_gemm.hip): int8 operands, exact int32 sums -- every count <= 127 and count x sum < 2^31
+	// (a product sum is at most max count x sum of the other histogram). Up to 64 queries per call.
+	const bool gemm_fit = !no_gemm && !tuned_by_hand && cands->dtype != 64 && mc_ <= 127 && mc_ * ms_ < (1ull << 31) && n_q <= 64 && L.nbins == L.padded_bins && L.nbins % 1024 == 0;
+	// EVERYTHING on the matrix cores. Every count of both sets below 9 (1 kb sequences at k = 9 qualify; every count >= 1, which the
+	// build of the count8 mirror checks): the Manhattan distance is a sum of products of thermometer level bytes and comes out of the
+	// same GEMM as the products of the counts -- one read of a byte per bin per 64 queries, no digest mirror, no partial records.
+	int level_bits = 0;
+	bool emd_ranks = false;
+	if (gemm_fit && !no_digest && !no_manh_gemm && n_q >= 2 && mc_ <= (1u << max_level_bits) && ms_ >= L.nbins && msc_digest_supported(L) && (!need_emd || ranks_fit)) {
+		if ((r = ensure_count8(ctx, cands)) || (r = ensure_count8(ctx, qset))) return r;
+		bool ok = cands->count8 && qset->count8 && !cands->c8_has_zero && !qset->c8_has_zero;
+		if (ok && need_emd) {
+			if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
+			ok = cands->ranks && qset->ranks;
+		}
+		if (ok) { level_bits = mc_ <= 4 ? 2 : 3; emd_ranks = need_emd; }
+	}
+	const bool manh_gemm = level_bits != 0;
+	// Digest form (pair_digest.hip): sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen (or 32)
+	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
 	// (one digest tile per lane-run of 16 bins: wave totals of 1024 * max^2 must fit 32 bits)
 	// The mirror streams 4 bytes per bin: against 8/16-bit raw bins it pays once enough queries share each candidate read
 	// (measured crossovers at k = 9: 7 queries for uint8_t, 5-6 for uint16_t, 4 for uint32_t)
 	const uint64_t dg_min_q = cands->dtype == 8 ? 8 : cands->dtype == 16 ? 6 : 4;
-	bool digest = !no_digest && excess16 && msc_digest_supported(L) && mc_ < 2048 && n_q >= dg_min_q && !getenv("MSC_MULTI_TQ");
+	bool digest = !manh_gemm && !no_digest && excess16 && msc_digest_supported(L) && mc_ < 2048 && n_q >= dg_min_q && !getenv("MSC_MULTI_TQ");
 	if (digest) {
 		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
 		digest = cands->digest && qset->digest;
 	}
-	// The products on the matrix cores (msc_dot_gemm.hip): int8 operands, exact int32 sums -- every count <= 127 and count x sum < 2^31
-	// (a product sum is at most max count x sum of the other histogram). Up to 64 queries per call; the form the digest kernel has
-	// without its v_dot4 quarter exists for 8-bit counts and two tiles per step.
-	static const bool no_gemm = getenv("MSC_MULTI_NO_GEMM") != nullptr;
-	bool gemm_dot = digest && !no_gemm && mc_ <= 127 && mc_ * ms_ < (1ull << 31) && n_q <= 64 && msc_digest_tiles_per_step(L, mc_) == 2 && !getenv("MSC_DIGEST_SLOTS") &&
-	                L.nbins == L.padded_bins;
-	if (gemm_dot) {
+	// the form the digest kernel has without its v_dot4 quarter exists for 8-bit counts and two tiles per step
+	bool gemm_dot = manh_gemm || (digest && gemm_fit && msc_digest_tiles_per_step(L, mc_) == 2);
+	if (gemm_dot && !manh_gemm) {
 		if ((r = ensure_count8(ctx, cands)) || (r = ensure_count8(ctx, qset))) return r;
 		gemm_dot = cands->count8 && qset->count8;
 	}
 	// LDS-DMA ring form over the raw bins: 32/64-bit bins, compact totals, query groups of four or eight
 	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
-	if (!digest && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
-	const bool ring = !digest && !no_ring && compact && L.LPT == 4 && (cands->dtype == 32 || cands->dtype == 64) && (tq == 4 || tq == 8) && n_q >= 4;
+	if (!digest && !manh_gemm && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
+	const bool ring = !digest && !manh_gemm && !no_ring && compact && L.LPT == 4 && (cands->dtype == 32 || cands->dtype == 64) && (tq == 4 || tq == 8) && n_q >= 4;
 	static const bool no_p16 = getenv("MSC_RING_NO_P16") != nullptr;
 	const bool prefix16 = ring && !no_p16 && excess16;
 	// partial records of one launch are capped at 4 GiB: equal candidate chunks
-	const bool need_emd = ((want | feat_mask) & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
 	const int tps = digest ? msc_digest_tiles_per_step(L, mc_) : 1;          // the digest kernel writes one record per step of tps tiles
-	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
-	// longest list is a quarter of the bins or less, for up to 64 queries and 2^20 bins (32-bit wave sums); the digest kernel then runs
-	// its count-only form (two tiles per step)
-	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
-	bool emd_ranks = digest && need_emd && !no_ranks && tps == 2 && n_q <= 64 && L.nbins <= (1ull << 20) && (ms_ - L.nbins) * 4 <= L.nbins && !getenv("MSC_DIGEST_SLOTS");
-	if (emd_ranks) {
+	if (digest && need_emd && ranks_fit && tps == 2) {          // the digest kernel then runs its count-only form (two tiles per step)
 		if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
 		emd_ranks = cands->ranks && qset->ranks;
 	}
 	const bool digest_emd = need_emd && !emd_ranks;                          // the digest kernel streams and scores the prefix half
-	// Every count of both sets below 5 / 9 (excess counts of 2 / 3 bits -- 1 kb sequences at k = 9 qualify): the Manhattan distance
-	// comes from the GEMM as well, as products of thermometer level bytes (msc_dot_gemm.hip) -- the digest kernel does not run at
-	// all, the pass is one read of a byte per bin per 64 queries. Needs the ranks mirrors (their build checks that no count is 0).
-	static const bool no_manh_gemm = getenv("MSC_MULTI_NO_MANH_GEMM") != nullptr;
-	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? atoi(e) : 3; }();
-	int level_bits = 0;
-	if (gemm_dot && !digest_emd && !no_manh_gemm && n_q >= 2 && mc_ <= (1u << max_level_bits)) {
-		if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
-		if (cands->ranks && qset->ranks) level_bits = mc_ <= 4 ? 2 : 3;
-	}
-	const bool manh_gemm = level_bits != 0;
 	const uint32_t n_rec = digest ? (uint32_t)(L.nbins / 1024) / tps : L.S;
 	// manh is all that is left to the digest kernel: eight queries per wave (32 per candidate tile fetched), 4-byte records
 	static const bool no_tq8 = getenv("MSC_DIGEST_NO_TQ8") != nullptr;

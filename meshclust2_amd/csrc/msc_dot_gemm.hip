@@ -34,7 +34,8 @@ __device__ __forceinline__ uint64_t c8_offset(uint64_t slot, uint64_t at, uint64
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_count8_build(const T* __restrict__ bins, uint64_t slot_elems, uint8_t* __restrict__ count8, uint64_t first_slot, uint64_t n_slots) {
+__global__ void __launch_bounds__(256) k_count8_build(const T* __restrict__ bins, uint64_t slot_elems, uint8_t* __restrict__ count8, uint64_t first_slot, uint64_t n_slots,
+                                                      int32_t* __restrict__ has_zero) {
 	const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;          // 16 bins per thread
 	if (i >= n_slots * slot_elems) return;
 	const uint64_t slot = first_slot + i / slot_elems, at = i % slot_elems;
@@ -43,6 +44,10 @@ __global__ void __launch_bounds__(256) k_count8_build(const T* __restrict__ bins
 #pragma unroll
 	for (int j = 0; j < 4; j++) w[j] = (uint32_t)src[4 * j] | ((uint32_t)src[4 * j + 1] << 8) | ((uint32_t)src[4 * j + 2] << 16) | ((uint32_t)src[4 * j + 3] << 24);
 	*reinterpret_cast<uint4*>(count8 + c8_offset(slot, at, slot_elems)) = make_uint4(w[0], w[1], w[2], w[3]);
+	bool zero = false;
+#pragma unroll
+	for (int j = 0; j < 16; j++) zero |= src[j] == 0;
+	if (zero) atomicOr(has_zero, 1);
 }
 
 // rows of the query operand: q8[r] = the bins of slot q_slots[r] (r < n_q) as one row, zeros for the rows up to 64
@@ -242,13 +247,13 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 // bytes of the blocked mirror of a set of `capacity` slots
 uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 15) / 16 * 16 * L.padded_bins; }
 
-hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots) {
+hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots, int32_t* has_zero) {
 	if (n_slots == 0) return hipSuccess;
 	const uint64_t threads = n_slots * L.padded_bins / 16;
 	const dim3 grid((unsigned)((threads + 255) / 256));
-	if (dtype == 8) k_count8_build<uint8_t><<<grid, dim3(256), 0, st>>>((const uint8_t*)bins, L.padded_bins, count8, first_slot, n_slots);
-	else if (dtype == 16) k_count8_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, count8, first_slot, n_slots);
-	else if (dtype == 32) k_count8_build<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)bins, L.padded_bins, count8, first_slot, n_slots);
+	if (dtype == 8) k_count8_build<uint8_t><<<grid, dim3(256), 0, st>>>((const uint8_t*)bins, L.padded_bins, count8, first_slot, n_slots, has_zero);
+	else if (dtype == 16) k_count8_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, count8, first_slot, n_slots, has_zero);
+	else if (dtype == 32) k_count8_build<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)bins, L.padded_bins, count8, first_slot, n_slots, has_zero);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }

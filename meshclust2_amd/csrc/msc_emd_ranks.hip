@@ -12,7 +12,8 @@
 //
 //   ranks mirror   per slot `pitch` uint32 (pitch = the set's longest list rounded up to 256) and its length n: a_1 .. a_n, then nbins repeated -- with
 //                  that padding | a_t - b_t | IS the tail term when one list has ended and 0 when both have, so the kernel has no cases.
-//                  Built from the digest mirror (whose prefix words say where each bin's copies go), refreshed with its stale range.
+//                  Built from the slots' bins (the tile prefixes of the scalar record say where each bin's copies go), refreshed with the
+//                  other mirrors' stale range.
 //                  Needs every count >= 1 (the reference's histograms start at 1, KmerHashTable's initial value; a mean of such too):
 //                  a zero bin would make the prefix non-monotone -- the build reports it and the caller keeps the digest's prefix form.
 //   k_emd_ranks    a workgroup stages 1 024 ranks of 16 queries in LDS; each wave holds 1 024 ranks of a candidate in registers and
@@ -22,36 +23,45 @@
 
 namespace {
 
-constexpr uint32_t kTileBytes = 4096;      // a digest tile: 1024 bins = 64 lanes x 16 words (pair_digest.hip)
+constexpr uint32_t kTileBytes = 4096;      // a raw tile: 64 lanes x 4 loads of 16 bytes (msc_layout.h, LPT = 4)
 
-// one wave per digest tile: lane l holds 16 consecutive bins (words 0..7: two counts each) and their inclusive excess prefixes (words 8..15)
-__global__ void __launch_bounds__(256) k_ranks_build(const uint8_t* __restrict__ digest, uint64_t dg_slot_bytes, uint32_t* __restrict__ ranks, uint32_t* __restrict__ n_of,
-                                                     uint64_t pitch, uint64_t nbins, uint64_t first_slot, uint64_t n_slots, uint32_t S, int32_t* __restrict__ bad) {
+// One wave per RAW tile of a dense slot (64 lanes x R = 64 / 32 / 16 bins of uint8 / uint16 / uint32, the lane's R bins logically
+// consecutive -- the walk k_digest_build takes): the tile prefix of the scalar record + a wave scan place the lane's run, and every bin
+// is written as many times as it was counted.
+template <typename T>
+__global__ void __launch_bounds__(256) k_ranks_build(const uint8_t* __restrict__ bins, uint64_t slot_bytes, const uint8_t* __restrict__ scalars, uint64_t scalar_stride,
+                                                     uint32_t* __restrict__ ranks, uint32_t* __restrict__ n_of, uint64_t pitch, uint64_t nbins, uint64_t first_slot,
+                                                     uint64_t n_slots, uint32_t S, int32_t* __restrict__ bad) {
+	constexpr int R = 64 / sizeof(T);
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t W = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (W >= n_slots * S) return;
 	const uint64_t slot = first_slot + W / S;
 	const uint32_t s = (uint32_t)(W % S);
-	const u32x4* src = reinterpret_cast<const u32x4*>(digest + slot * dg_slot_bytes + (uint64_t)s * kTileBytes) + lane;
+	const u32x4* src = reinterpret_cast<const u32x4*>(bins + slot * slot_bytes + (uint64_t)s * kTileBytes) + lane;
 	u32x4 v[4];
 #pragma unroll
 	for (int l = 0; l < 4; l++) v[l] = src[64 * l];
-	const uint32_t* w = reinterpret_cast<const uint32_t*>(v);
+	const T* w = reinterpret_cast<const T*>(v);
+	uint32_t t = 0;
+#pragma unroll
+	for (int r = 0; r < R; r++) t += (uint32_t)w[r];
+	const uint64_t* prefix = reinterpret_cast<const uint64_t*>(scalars + slot * scalar_stride + sizeof(MscSlotScalars));
+	const uint32_t first_bin = s * (64u * R) + lane * R;
+	uint32_t run = (uint32_t)prefix[s] + wave_incl_scan(t) - t - first_bin;      // counted k-mers in the bins before this lane's run
 	uint32_t* out = ranks + slot * pitch;
-	const uint32_t bin0 = s * 1024u + lane * 16u;
 	bool zero = false;
 #pragma unroll
-	for (int r = 0; r < 16; r++) {
-		const uint32_t c = (w[r >> 1] >> (16 * (r & 1))) & 0xffffu;
-		const uint32_t E = (w[8 + (r >> 1)] >> (16 * (r & 1))) & 0xffffu;      // excess prefix up to and including this bin
+	for (int r = 0; r < R; r++) {
+		const uint32_t c = (uint32_t)w[r];
 		if (c == 0) { zero = true; continue; }
-		for (uint32_t e = c - 1; e > 0; e--) if (E - e < pitch) out[E - e] = bin0 + r;
+		for (uint32_t e = c - 1; e > 0; e--, run++) if (run < pitch) out[run] = first_bin + r;
 	}
 	if (zero) atomicOr(bad, 1);
-	if (s == S - 1) {          // behind the last counted k-mer (the prefix of the last bin says how many there are): nbins up to the pitch
-		const uint32_t n = __builtin_amdgcn_readlane(w[15] >> 16, 63);
+	if (s == S - 1) {          // behind the last counted k-mer: nbins up to the pitch
+		const uint32_t n = __builtin_amdgcn_readlane(run, 63);
 		if (lane == 0) { n_of[slot] = n; if (n > pitch) atomicOr(bad, 2); }          // (the host sized the pitch from the set's largest sum)
-		for (uint64_t t = n + lane; t < pitch; t += 64) out[t] = (uint32_t)nbins;
+		for (uint64_t i = n + lane; i < pitch; i += 64) out[i] = (uint32_t)nbins;
 	}
 }
 
@@ -154,12 +164,17 @@ __global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ 
 uint64_t msc_ranks_pitch(uint64_t max_excess) { return std::max<uint64_t>(256, (max_excess + 255) / 256 * 256); }      // (k_emd_ranks loads 256 ranks per wave instruction)
 
 // *bad (device int32, zeroed by the caller) is set when a slot holds a zero count: the ranks of that set are then not usable
-hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, const uint8_t* digest, uint32_t* ranks, uint32_t* n_of, uint64_t pitch, uint64_t first_slot,
-                                  uint64_t n_slots, int32_t* bad) {
+hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint8_t* scalars, uint32_t* ranks, uint32_t* n_of, uint64_t pitch,
+                                  uint64_t first_slot, uint64_t n_slots, int32_t* bad) {
 	if (n_slots == 0) return hipSuccess;
-	const uint32_t S = (uint32_t)(L.nbins / 1024);
-	const uint64_t waves = n_slots * S;
-	k_ranks_build<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st>>>(digest, msc_digest_slot_bytes(L), ranks, n_of, pitch, L.nbins, first_slot, n_slots, S, bad);
+	if (L.LPT != 4 || L.nbins != L.padded_bins) return hipErrorInvalidValue;
+	const uint64_t waves = n_slots * L.S;
+	const dim3 grid((unsigned)((waves + 3) / 4));
+	const uint64_t ss = msc_scalar_stride(L.S);
+	if (dtype == 8) k_ranks_build<uint8_t><<<grid, dim3(256), 0, st>>>(bins, L.slot_bytes, scalars, ss, ranks, n_of, pitch, L.nbins, first_slot, n_slots, L.S, bad);
+	else if (dtype == 16) k_ranks_build<uint16_t><<<grid, dim3(256), 0, st>>>(bins, L.slot_bytes, scalars, ss, ranks, n_of, pitch, L.nbins, first_slot, n_slots, L.S, bad);
+	else if (dtype == 32) k_ranks_build<uint32_t><<<grid, dim3(256), 0, st>>>(bins, L.slot_bytes, scalars, ss, ranks, n_of, pitch, L.nbins, first_slot, n_slots, L.S, bad);
+	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 

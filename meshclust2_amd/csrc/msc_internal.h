@@ -173,12 +173,12 @@ hipError_t msc_launch_pair_digest_multi(hipStream_t st, const MscLayout& L, cons
                                         int tiles_per_step, bool need_emd, void* partials16, int num_cus, bool need_dot = true, int queries_per_wave = 4);
 // the products of the Q x M pass as an int8 GEMM on the matrix cores (msc_dot_gemm.hip)
 uint64_t msc_ranks_pitch(uint64_t max_excess);
-hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, const uint8_t* digest, uint32_t* ranks, uint32_t* n_of, uint64_t pitch, uint64_t first_slot,
-                                  uint64_t n_slots, int32_t* bad);
+hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint8_t* scalars, uint32_t* ranks, uint32_t* n_of, uint64_t pitch,
+                                  uint64_t first_slot, uint64_t n_slots, int32_t* bad);
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
                                 uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out);
 uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity);
-hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots);
+hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots, int32_t* has_zero);
 uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);
 hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,

@@ -69,6 +69,7 @@ struct msc_hist_set {
 	mutable uint8_t* count8 = nullptr;
 	mutable uint64_t c8_lo = 0, c8_hi = 0;
 	mutable bool count8_unavailable = false;
+	mutable bool c8_has_zero = false;         // a slot with a zero count went into the mirror (never the case for built histograms and their means)
 	// ranks mirror (msc_emd_ranks.hip): per slot the bins of its counted k-mers in bin order (rk_pitch entries, padded with 4^k) and
 	// their number: the earth mover's distance of the Q x M pass in O(k-mers) instead of O(bins). Built from the digest mirror;
 	// slots [rk_lo, rk_hi) are stale

@@ -91,6 +91,18 @@ extern "C" int msc_device_free(msc_ctx* ctx, void* p) {
 	if (p) { HIP_TRY(ctx, hipSetDevice(ctx->device)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(p)); }
 	return MSC_OK;
 }
+extern "C" int msc_host_alloc(msc_ctx* ctx, uint64_t bytes, void** out) {
+	if (!ctx || !out) return MSC_ERR_INVALID_ARG;
+	*out = nullptr;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipHostMalloc(out, std::max<uint64_t>(bytes, 16), hipHostMallocDefault));
+	return MSC_OK;
+}
+extern "C" int msc_host_free(msc_ctx* ctx, void* p) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	if (p) { HIP_TRY(ctx, hipSetDevice(ctx->device)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipHostFree(p)); }
+	return MSC_OK;
+}
 extern "C" int msc_memcpy_to_host(msc_ctx* ctx, void* dst, const void* src_dev, uint64_t bytes) {
 	if (!ctx || (bytes && (!dst || !src_dev))) return MSC_ERR_INVALID_ARG;
 	if (!bytes) return MSC_OK;
