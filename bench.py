@@ -44,14 +44,16 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed steps; the default scores 20 x 64 x 100000 = 1.28e8 pairs (SURVEY 8d: a >= 1e8-pair slice)")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; the default scores 20 x 512 x 100000 = 1.02e9 pairs (SURVEY 8d: a >= 1e8-pair slice)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nseq", type=int, default=100000, help="sequences in total (--scaling strong) or per GPU (--scaling weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--k", type=int, default=9)
     ap.add_argument("--dtype", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=64, help="query histograms per step (a multiple of the number of ranks)")
+    ap.add_argument("--queries", type=int, default=512, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 64, "
+                                                             "one pass over the candidates each -- a step of 8 blocks keeps the per-step exchange and host work of an 8-rank run "
+                                                             "(12 500 candidates per rank) small next to the scoring")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
     ap.add_argument("--layout", choices=("dense", "sparse"), default="dense",
                     help="sparse: the same workload on sorted (bin, value) lists (DESIGN 3b; single GPU only) -- algorithmic bytes are then the list bytes")
@@ -429,7 +431,7 @@ def main():
     if args.mode == "allpairs" and args.layout == "sparse":
         per_call = Q * (M + 1) * hist_bytes          # one 1 x M merge pass per query
     elif args.mode == "allpairs":
-        per_call = (M * -(-Q // qtile) + Q) * hist_bytes
+        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 64: a call with more queries is that many passes)
     else:
         per_call = (M + 1) * hist_bytes
     # one timed call may be several launches of the streaming kernel (candidate chunks): report per launch
@@ -472,7 +474,9 @@ def main():
                      # hbm_frac = PMC HBM bytes per launch / launch time / peak (frac above prices the TILE reads of the kernel as it
                      # is tiled -- query groups that share a candidate mostly hit in L2); valu_busy = VALU cycles / busy cycles
                      "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms == avg_ms else None, "valu_busy": valu_busy,
-                     "candidates_per_launch": int(round(M * calls_per_launch)), "query_groups_per_launch": -(-Q // qtile) if args.mode == "allpairs" else 1,
+                     # a call scores its queries in blocks of 64 (one pass over the candidates each) and may cut a pass into candidate chunks
+                     "candidates_per_launch": int(round(M * calls_per_launch * (-(-Q // 64) if args.mode == "allpairs" and args.layout == "dense" else 1))),
+                     "query_groups_per_launch": -(-min(Q, 64) // qtile) if args.mode == "allpairs" else 1,
                      "profile_key": config_key},
     }
     if args.check:

@@ -1751,6 +1751,23 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (r) return r;
 	const MscLayout& L = cands->L;
 	const int nf = __builtin_popcountll(feat_mask);
+	if (n_q > 64) {
+		// blocks of 64 queries: the unit of the pass on the matrix cores (a 64-row operand) and of the digest kernel (four groups of 16);
+		// msc_last_kernel_ms / _launches then cover the whole call
+		float ms = 0.f;
+		int launches = 0;
+		for (uint64_t b = 0; b < n_q; b += 64) {
+			const uint64_t nb = std::min<uint64_t>(64, n_q - b);
+			if ((r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
+			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr)))
+				return r;
+			ms += ctx->tiles_ms_accum;
+			launches += ctx->tiles_launches;
+		}
+		ctx->tiles_ms_accum = ms;
+		ctx->tiles_launches = launches;
+		return MSC_OK;
+	}
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	// divergence statistics in the Q x M pass: the integer reductions come from the streaming kernel below, the two FP64 sums from
