@@ -44,15 +44,20 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed steps; the default scores 20 x 512 x 100000 = 1.02e9 pairs (SURVEY 8d: a >= 1e8-pair slice)")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; the default scores 20 x 1024 x 100000 = 2.05e9 pairs (SURVEY 8d: a >= 1e8-pair slice)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nseq", type=int, default=100000, help="sequences in total (--scaling strong) or per GPU (--scaling weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--k", type=int, default=9)
     ap.add_argument("--dtype", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=512, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 64, "
-                                                             "one pass over the candidates each -- a step of 8 blocks keeps the per-step exchange and host work of an 8-rank run "
+    ap.add_argument("--exchange", choices=("sequences", "histograms"), default="sequences",
+                    help="what the ranks of an N > 1 all-pairs run send each other per step: the queries' 2-bit packed SEQUENCES (250 bytes for 1 kb; every "
+                         "rank builds the block's histograms itself, bit-identical to the owner's) or their HISTOGRAMS as they sit in HBM (4^k x sizeof(T) "
+                         "bytes each: SURVEY 8(e)'s exchange -- at 1 MiB per query the ring all-gather takes longer than scoring the block once the pass "
+                         "runs on the matrix cores)")
+    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 64, "
+                                                             "one pass over the candidates each -- a step of 16 blocks keeps the per-step exchange and host work of an 8-rank run "
                                                              "(12 500 candidates per rank) small next to the scoring")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
     ap.add_argument("--layout", choices=("dense", "sparse"), default="dense",
@@ -84,6 +89,12 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
     t_dev = []          # (sequences, seconds) per chunk inside msc_hist_build_packed only: H2D of the 2-bit bases + the build kernels, host packing excluded
     done = 0
     last = None
+    # --exchange sequences: this rank's sequences as they go over the wire, 4 bases per byte, each padded to whole bytes, + their 1-mer counts
+    # (the family members carry indels: lengths vary by a few bases around --length, so a row has room to spare and column 4 of the
+    # second array holds the length)
+    lp4 = (args.length + args.length // 8 + 64 + 3) // 4
+    seq_rows = np.zeros((M, lp4), dtype=np.uint8)
+    one_rows = np.zeros((M, 5), dtype=np.uint64)
     while done < M:
         n = min(20 * BLOCK, M - done)
         codes = []
@@ -98,6 +109,14 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
                         codes.append(synth.member(seed, t, j, tmpl))
         assert len(codes) == n
         b = synth.pack_batch(codes)
+        c4 = np.zeros((n, lp4 * 4), dtype=np.uint8)
+        for i, c in enumerate(codes):
+            assert c.size <= lp4 * 4
+            c4[i, :c.size] = c
+        c4 = c4.reshape(n, lp4, 4)
+        seq_rows[done:done + n] = c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6)
+        one_rows[done:done + n, :4] = b["one_mers"].reshape(n, 4)
+        one_rows[done:done + n, 4] = b["eff_len"]
         t1 = time.perf_counter()
         hs.build_packed(done, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
         ctx.synchronize()
@@ -115,7 +134,7 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
         ctx.synchronize()
         steady.append(n / (time.perf_counter() - t1))
     rate_all = sum(n_ for n_, _ in t_dev) / sum(s_ for _, s_ in t_dev)
-    return hs, time.time() - t0, {"all": rate_all, "median_chunk": max(steady) if steady else rate_all}
+    return hs, time.time() - t0, {"all": rate_all, "median_chunk": max(steady) if steady else rate_all}, (seq_rows, one_rows)
 
 
 def cpu_baseline(args, synth, weights_text, weights_path):
@@ -259,7 +278,7 @@ def main():
     if Q % world:
         raise SystemExit("--queries must be a multiple of the number of ranks (every rank contributes queries / N per step)")
     ctx = api.Context(local_rank)
-    hs, build_s, build_dev_s = build_resident_set(api, synth, ctx, args, plan, rank)
+    hs, build_s, build_dev_s, (seq_rows, one_rows) = build_resident_set(api, synth, ctx, args, plan, rank)
     M = plan.local_count(rank)                                  # this rank's shard
     m_min = min(plan.local_count(r) for r in range(world))
     wpath = args.weights or os.path.join(ROOT, "tests", "golden", "weights_k9_u32.txt" if args.k == 9 else "weights_k5_u16.txt")
@@ -272,6 +291,11 @@ def main():
     sharded = block = None
     if world > 1:
         all_bins, all_scal = shard.device_tensors(hs, M + 2 * Q)      # [slot, bytes] views of the set's device memory
+        ship_seq = args.exchange == "sequences" and args.mode == "allpairs"
+        if ship_seq:
+            seq_dev, one_dev = torch.from_numpy(seq_rows).cuda(), torch.from_numpy(one_rows.view(np.int64)).cuda()
+            qseq_dev = torch.zeros((2 * Q, seq_rows.shape[1]), dtype=torch.uint8, device="cuda")
+            qone_dev = torch.zeros((2 * Q, 5), dtype=torch.int64, device="cuda")
 
         block_out = {}
 
@@ -283,9 +307,13 @@ def main():
                 return [all_bins[local], all_scal[local]]
 
             def export_block(self, local_first, n):
+                if ship_seq:
+                    return [seq_dev[local_first:local_first + n], one_dev[local_first:local_first + n]]
                 return [all_bins[local_first:local_first + n], all_scal[local_first:local_first + n]]
 
             def block_buffers(self, base, n_rows):
+                if ship_seq:
+                    return [qseq_dev[base:base + n_rows], qone_dev[base:base + n_rows]]
                 return [all_bins[M + base:M + base + n_rows], all_scal[M + base:M + base + n_rows]]
 
             def import_query(self):
@@ -293,6 +321,16 @@ def main():
 
             def import_queries(self, n, base=0):
                 torch.cuda.synchronize()
+                if ship_seq and n > 1:
+                    # the block arrived as sequences: its histograms are built here (the packed input of msc_hist_build_packed: one
+                    # segment per sequence, every sequence on its own bytes)
+                    pk = qseq_dev[base:base + n].cpu().numpy().reshape(-1)
+                    meta = qone_dev[base:base + n].cpu().numpy().astype(np.uint64)
+                    starts = np.arange(n, dtype=np.uint64) * np.uint64(seq_rows.shape[1] * 4)
+                    lens = meta[:, 4].copy()
+                    hs.build_packed(M + base, n, pk, n * seq_rows.shape[1] * 4, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
+                                    np.ascontiguousarray(meta[:, :4]).reshape(-1))
+                    return
                 hs.import_done(M + base, n)
 
             def score_local(self):
@@ -465,7 +503,8 @@ def main():
                                   "note": "msc_hist_build_packed only (2-bit bases over PCIe + build kernel): the last chunk rebuilt in place back to "
                                           "back; all_chunks = the chunks as first built, each after ~1 s of host-side sequence generation on an idle GPU; "
                                           "untimed setup"},
-                   "sharding": ("sequence blocks of %d, block-cyclic; per step 2 all-gathers assemble the query block (RCCL), per-query close counts all-gathered" % BLOCK)
+                   "sharding": ("sequence blocks of %d, block-cyclic; per step 2 all-gathers assemble the query block (RCCL) as %s, per-query close counts all-gathered"
+                                % (BLOCK, "2-bit packed sequences + 1-mer counts (every rank builds the block's histograms)" if args.exchange == "sequences" else "histograms"))
                                if world > 1 else "single GPU",
                    "queries_per_candidate_read": qtile},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -1798,17 +1798,19 @@ def test_multi_rank_cluster_driver_k13_u64_sparse(tmp_path, ranks):
     assert a == b and a.count(b">Cluster") >= 2, a.count(b">Cluster")
 
 
-def test_bench_two_ranks_packed_exchange(tmp_path):
-    """bench.py --gpus 2 (strong scaling: the sequences split over the ranks, 2 all-gathers per step assemble the query block) on
-    two ranks sharing this GPU, against ONE rank scoring the same blocks (--check-world 2): with --check both lines carry, per timed
-    step, the number of close candidates of every query of the block summed over the ranks -- the sharded run scores the same pairs
-    and reaches the same decisions as one rank does."""
+@pytest.mark.parametrize("exchange", ["sequences", "histograms"])
+def test_bench_two_ranks_packed_exchange(tmp_path, exchange):
+    """bench.py --gpus 2 (strong scaling: the sequences split over the ranks, 2 all-gathers per step assemble the query block -- as
+    2-bit packed sequences every rank builds the histograms of, or as the histograms themselves) on two ranks sharing this GPU,
+    against ONE rank scoring the same blocks (--check-world 2): with --check both lines carry, per timed step, the number of close
+    candidates of every query of the block summed over the ranks -- the sharded run scores the same pairs and reaches the same
+    decisions as one rank does."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0", "--check"]
+    common = ["--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0", "--check", "--exchange", exchange]
     r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2"] + common, 2, tmp_path)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
