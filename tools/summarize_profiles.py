@@ -59,6 +59,14 @@ def main():
         for k, ctrs in agg.items():
             for c, v in ctrs.items():
                 pmc.setdefault(k, {}).setdefault("pmc", {})[c] = sum(v) / len(v)
+    # VALU-busy fraction as the gfx94x derived metric states it (ROCm 7.2 ships no gfx950 section): cycles with a VALU instruction in
+    # flight x 4 (a wave64 instruction occupies its SIMD for four) / SIMDs / elapsed cycles; elapsed = SQ_BUSY_CYCLES / 32 (the
+    # counter sums the 8 XCDs x 4 shader engines). On the r02 digest kernel this gives 0.84 where instruction counts x measured
+    # cycle costs gave 0.86.
+    for k, d in pmc.items():
+        c = d.get("pmc") if isinstance(d, dict) else None
+        if c and c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
+            d["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["SQ_BUSY_CYCLES"] / 32)
     pmc["_config"] = key
     json.dump(pmc, open(os.path.join(out_dir, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
     print("wrote %s/%s_kernel_stats.csv and %s_pmc_hbm.json" % (out_dir, tag, tag))
