@@ -96,7 +96,7 @@ __device__ __forceinline__ v4i level_at(const v4i e, uint32_t T) {
 template <int LB, int NCB>
 __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                      const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out,
-                                                     int32_t* __restrict__ out_min) {
+                                                     int32_t* __restrict__ out_min, bool nt) {
 	constexpr int NL = LB ? (1 << LB) - 1 : 0;
 	__shared__ v4i sA[2][64][16];          // [buffer][query row][16-byte segment ^ (row & 15)]: 32 KiB
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,7 +144,10 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 #pragma unroll
 		for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-			for (int kc = 0; kc < 4; kc++) b[cb][kc] = *reinterpret_cast<const v4i*>(brow[cb] + ((k >> 6) + kc) * 1024);
+			for (int kc = 0; kc < 4; kc++) {
+				const v4i* src = reinterpret_cast<const v4i*>(brow[cb] + ((k >> 6) + kc) * 1024);
+				b[cb][kc] = nt ? __builtin_nontemporal_load(src) : *src;
+			}
 	};
 	auto park = [&](uint32_t buf) {
 #pragma unroll
@@ -264,8 +267,10 @@ uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus) {
 	while (s < 64 && (uint64_t)((m + 63) / 64) * s < (uint64_t)num_cus * 10 && nbins / (2 * s) >= kStep && nbins % (2 * s * kStep) == 0) s *= 2;
 	// and slices short enough that the queries' side of ONE slice (64 rows) stays in an XCD's 4 MiB L2 while the workgroups of that
 	// slice -- dispatched together -- walk it in their different orders: with two slices of 8 MiB every step re-read its 16 KiB of queries
-	// from beyond L2, as many bytes again as the candidates' (4.0 TB/s of candidate bytes; 1 MiB slices: 5.5 TB/s, the epilogue adds 16 slices)
-	static const uint64_t a_bytes = [] { const char* e = getenv("MSC_GEMM_A_KIB"); return (uint64_t)(e ? std::max(64, atoi(e)) : 1024) << 10; }();
+	// from beyond L2, as many bytes again as the candidates' (4.0 TB/s of candidate bytes against 5.5 with 1 MiB slices for the plain
+	// products; with the level products 8 slices of 2 MiB measure best: 5.21 ms against 5.46 with 16 and 5.84 with 4, and the epilogue
+	// adds half as many)
+	static const uint64_t a_bytes = [] { const char* e = getenv("MSC_GEMM_A_KIB"); return (uint64_t)(e ? std::max(64, atoi(e)) : 2048) << 10; }();
 	while (s < 64 && 64 * (nbins / s) > a_bytes && nbins / (2 * s) >= kStep && nbins % (2 * s * kStep) == 0) s *= 2;
 	return s;
 }
@@ -281,10 +286,11 @@ hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* ca
 	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_slots_dev, n_q, nbins, q8_scratch);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
+	static const bool nt = getenv("MSC_GEMM_NT") != nullptr;
 	static const int ncb_env = [] { const char* e = getenv("MSC_GEMM_NCB"); return e ? atoi(e) : 0; }();
 	const int ncb = ncb_env == 2 ? 2 : 1;          // (two blocks paid while every level was multiplied out; with the levels a tile does not reach skipped, one is faster: 5.25 against 5.44 ms)
 	const dim3 grid((m + 64 * ncb - 1) / (64 * ncb), k_slices);
-#define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min)
+#define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min, nt)
 	if (level_bits == 2) { if (ncb == 2) MSC_GEMM_GO(2, 2); else MSC_GEMM_GO(2, 1); }
 	else if (level_bits == 3) { if (ncb == 2) MSC_GEMM_GO(3, 2); else MSC_GEMM_GO(3, 1); }
 	else { if (ncb == 2) MSC_GEMM_GO(0, 2); else MSC_GEMM_GO(0, 1); }
