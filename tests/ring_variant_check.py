@@ -34,6 +34,23 @@ def main():
                 assert np.array_equal(multi["sum"][i], single["sum"]), (dtype, k, nq, i)
                 assert np.array_equal(multi["raw"][i], raw), (dtype, k, nq, i)
                 assert np.array_equal(multi["close"][i], (np.round(single["csum"]) > 0).astype(np.uint8))
+    # counts of 3 .. 8 in most tiles (3 kb sequences over the 16 384 bins of k = 7): the level products beyond the first, tile by tile;
+    # more queries than one block of 64, windows shorter than a workgroup's 64 candidates, slot lists
+    seqs, _ = synth.families(913, 150, 3000, family=10)
+    for dtype in (16, 8, 32):
+        hs = api.HistogramSet(ctx, 7, dtype, len(seqs))
+        hs.build(seqs)
+        assert 3 <= int(max(hs.download(i).max() for i in (0, 7, 77))) <= 127
+        n = len(seqs)
+        for nq, cands in ((2, np.arange(n, dtype=np.uint32)), (65, np.arange(n - 1, -1, -1, dtype=np.uint32)), (130, np.arange(3, 40, dtype=np.uint32)),
+                          (7, np.array([5, 5, 9], dtype=np.uint32)), (64, np.arange(0, n, 2, dtype=np.uint32))):
+            qs = (np.arange(nq, dtype=np.uint32) * 7) % n
+            multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+            for i in range(0, nq, 1 if nq <= 16 else 9):
+                raw = api.pair_features_raw(ctx, hs, cands, hs, int(qs[i]), mask)
+                single = feat.compute(hs, cands, hs, int(qs[i]))
+                assert np.array_equal(multi["raw"][i], raw), ("levels", dtype, nq, i, ctx.last_kernel_info()[0])
+                assert np.array_equal(multi["sum"][i], single["sum"]), ("levels", dtype, nq, i)
     # one long sequence (70 kb: more k-mers than a 16-bit prefix of excess counts holds) switches the whole pass to 32-bit prefixes
     seqs, _ = synth.families(977, 40, 1000, family=10)
     long_seqs, _ = synth.families(978, 2, 70000, family=2)
