@@ -340,7 +340,8 @@ def main():
             def score_block(self, n, base=0):
                 if n not in block_out:          # the block's product (one close flag per pair) lands in page-locked memory allocated once
                     block_out[n] = {"close": api.pinned_array(ctx, (n, M), np.uint8)}
-                return api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close",), out=block_out[n])["close"]
+                res = api.score_multi(ctx, feat, hs, None, hs, np.arange(M + base, M + base + n, dtype=np.uint32), m=M, want=("close", "counts"), out=block_out[n])
+                return res["close"], res["counts"]
 
         if gloo_group is not None:
             # preflight: one all-gather and one broadcast over RCCL on the library's own device views (they are not torch allocations).
@@ -410,9 +411,9 @@ def main():
                     qs = np.array([plan_w.global_index(r, first + j) for r in range(cw) for j in range(Q // cw)], dtype=np.uint32)
                 else:
                     qs = np.array([((st * Q + j) * 7919) % M for j in range(Q)], dtype=np.uint32)
-                res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close",), out=out_close)
+                res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close", "counts"), out=out_close)
                 if args.check:
-                    checks.append([int(x) for x in res["close"].sum(axis=1)])
+                    checks.append([int(x) for x in res["counts"]])
             tiles_ms.append(ctx.last_kernel_ms()[0])
             launches.append(ctx.last_kernel_launches())
         else:

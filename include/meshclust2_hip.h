@@ -248,6 +248,10 @@ int msc_score(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, c
 int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                     const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order,
                     double* sum_out, double* csum_out, uint8_t* close_out, uint64_t feat_mask, double* raw_out);
+/* counts[q] = number of close candidates of query q in the last msc_score_multi call that asked for close_out (the row sums of
+ * close_out, added up on the device: the per-query result of fastcar's work() loop, fastcar/FC_Runner.cpp:449-455, without a host pass
+ * over n_q x m flags). MSC_ERR_UNSUPPORTED when that call took a route that keeps no counts (one pass per query). */
+int msc_last_close_counts(msc_ctx* ctx, uint64_t* counts, uint64_t n_q);
 
 /* ------------------------------------------------------------------ a8/a9: Trainer operators */
 /* Trainer<T>::get_close (cluster/Trainer.cpp:23-71; caller cluster/ClusterFactory.cpp:566).

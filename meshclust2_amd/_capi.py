@@ -107,6 +107,7 @@ PROTOTYPES = {
     "msc_memcpy_to_host": (_int, [_vp, _vp, _vp, _u64]),
     "msc_memcpy_to_device": (_int, [_vp, _vp, _vp, _u64]),
     "msc_memcpy_device": (_int, [_vp, _vp, _vp, _u64]),
+    "msc_last_close_counts": (_int, [_vp, _vp, _u64]),
     "msc_host_alloc": (_int, [_vp, _u64, C.POINTER(_vp)]),
     "msc_host_free": (_int, [_vp, _vp]),
     "msc_window_create": (_int, [_vp, _vp, _vp, _u64, C.POINTER(_vp)]),

@@ -329,7 +329,12 @@ def score_multi(ctx, feat, cands, cand_slots, qset, q_slots, order=ORDER_CAND_FI
     raw = arr("raw", (nq, m, nf), np.float64) if nf else None
     ctx.check(ctx.lib.msc_score_multi(ctx.h, feat.h if feat is not None else None, cands.h, _ptr(sl), m, qset.h, _ptr(qs), nq, order,
                                       _ptr(s), _ptr(cs), _ptr(close), feat_mask, _ptr(raw)))
-    return dict(sum=s, csum=cs, close=close, raw=raw)
+    counts = None
+    if close is not None and "counts" in want:          # row sums of `close`, from the device where the route keeps them
+        counts = np.zeros(nq, dtype=np.uint64)
+        if ctx.lib.msc_last_close_counts(ctx.h, _ptr(counts), nq) != 0:
+            counts = np.einsum("ij->i", close, dtype=np.uint64)
+    return dict(sum=s, csum=cs, close=close, raw=raw, counts=counts)
 
 
 class Trainer:

@@ -132,6 +132,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->gemm_q8);
 	release(ctx->gemm_out);
 	release(ctx->emd_out);
+	release(ctx->close_counts);
 	release(ctx->gemm_min);
 	release(ctx->rk_bad);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
@@ -191,6 +192,16 @@ extern "C" int msc_last_kernel_info(const msc_ctx* ctx, char* buf, size_t cap, i
 	if (!ctx) return MSC_ERR_INVALID_ARG;
 	if (buf && cap) snprintf(buf, cap, "%s", ctx->last_kernel);
 	if (queries_per_candidate_read) *queries_per_candidate_read = ctx->last_query_tile;
+	return MSC_OK;
+}
+
+extern "C" int msc_last_close_counts(msc_ctx* ctx, uint64_t* counts, uint64_t n_q) {
+	if (!ctx || !counts) return MSC_ERR_INVALID_ARG;
+	if (ctx->close_counts_n == 0 || n_q != ctx->close_counts_n) return fail(ctx, MSC_ERR_UNSUPPORTED, "no close counts of %llu queries on file (the last msc_score_multi call had %llu, or took a route that keeps none)",
+	                                                                        (unsigned long long)n_q, (unsigned long long)ctx->close_counts_n);
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->close_counts.p, n_q * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return MSC_OK;
 }
 
@@ -1751,19 +1762,31 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (r) return r;
 	const MscLayout& L = cands->L;
 	const int nf = __builtin_popcountll(feat_mask);
+	// close candidates per query, kept on the device for msc_last_close_counts (a caller that only needs the counts of a block of the
+	// pairwise matrix does not have to add up n_q x m flags on the host)
+	const bool top_level = ctx->close_counts_base == 0 && !ctx->in_score_multi;
+	if (top_level && close_out) {
+		if ((r = ensure(ctx, ctx->close_counts, n_q * sizeof(uint64_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->close_counts.p, 0, n_q * sizeof(uint64_t), ctx->stream));
+		ctx->close_counts_n = n_q;
+	} else if (top_level) ctx->close_counts_n = 0;
 	if (n_q > 64) {
 		// blocks of 64 queries: the unit of the pass on the matrix cores (a 64-row operand) and of the digest kernel (four groups of 16);
 		// msc_last_kernel_ms / _launches then cover the whole call
 		float ms = 0.f;
 		int launches = 0;
+		ctx->in_score_multi = true;
 		for (uint64_t b = 0; b < n_q; b += 64) {
 			const uint64_t nb = std::min<uint64_t>(64, n_q - b);
+			ctx->close_counts_base = b;
 			if ((r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
 			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr)))
-				return r;
+				{ ctx->in_score_multi = false; ctx->close_counts_base = 0; return r; }
 			ms += ctx->tiles_ms_accum;
 			launches += ctx->tiles_launches;
 		}
+		ctx->in_score_multi = false;
+		ctx->close_counts_base = 0;
 		ctx->tiles_ms_accum = ms;
 		ctx->tiles_launches = launches;
 		return MSC_OK;
@@ -1848,6 +1871,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(ctx->stream, (const uint8_t*)ctx->soa_close.p, (uint32_t)n_q, (uint32_t)m, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (sum_out) HIP_TRY(ctx, hipMemcpyAsync(sum_out, ctx->soa_sum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (csum_out) HIP_TRY(ctx, hipMemcpyAsync(csum_out, ctx->soa_csum.p, n_q * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1864,6 +1888,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		return MSC_OK;
 	}
 	if (!simple) {
+		ctx->close_counts_n = 0;          // (no counts from this route: msc_last_close_counts says so)
 		// divergence statistics / padded tiny histograms: one streaming pass per query through the single-query kernel
 		float ms = 0.f;
 		int launches = 0;
@@ -2094,6 +2119,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(ctx->stream, (const uint8_t*)ctx->soa_close.p, (uint32_t)n_q, mc, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
 		const size_t rows = (size_t)n_q;

@@ -184,6 +184,7 @@ hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* ca
                                const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,
                                int level_bits = 0, int32_t* out_min = nullptr);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
+hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);
 size_t msc_reduce_scratch_bytes();

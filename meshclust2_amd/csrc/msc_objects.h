@@ -42,6 +42,9 @@ struct msc_ctx {
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
 	DevBuf gemm_q8, gemm_out, gemm_min;    // msc_dot_gemm.hip: the gathered query rows, the products per slice, sum min(e, e') per slice
+	DevBuf close_counts;                   // msc_score_multi: close candidates per query of the call in progress / the last call (msc_last_close_counts)
+	uint64_t close_counts_n = 0, close_counts_base = 0;
+	bool in_score_multi = false;
 	DevBuf emd_out, rk_bad;                // msc_emd_ranks.hip: the distances of a chunk, the build's error word
 	msc_hist_set* shard_gather = nullptr;
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the

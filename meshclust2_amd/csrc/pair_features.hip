@@ -1760,6 +1760,22 @@ hipError_t msc_launch_pair_tiles_multi_ring(hipStream_t st, const MscLayout& L, 
 #undef MSC_RING_ARGS
 }
 
+// counts[q] += number of close flags in row q of flags[n_q][m] (one workgroup per 4 096 flags of a row)
+__global__ void __launch_bounds__(256) k_close_counts(const uint8_t* __restrict__ flags, uint32_t m, unsigned long long* __restrict__ counts) {
+	const uint32_t q = blockIdx.y;
+	const uint8_t* row = flags + (uint64_t)q * m;
+	uint32_t n = 0;
+	for (uint32_t i = blockIdx.x * 4096 + threadIdx.x; i < m && i < (blockIdx.x + 1) * 4096; i += 256) n += row[i] != 0;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+	if ((threadIdx.x & 63) == 0 && n) atomicAdd(counts + q, (unsigned long long)n);
+}
+hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts) {
+	if (!n_q || !m) return hipSuccess;
+	k_close_counts<<<dim3((m + 4095) / 4096, n_q), dim3(256), 0, st>>>(flags, m, (unsigned long long*)counts);
+	return hipGetLastError();
+}
+
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.m == 0) return hipSuccess;
 	if (a.min_gemm) {

@@ -153,7 +153,13 @@ class ShardedBlockScorer:
     def score(self, n, base=0):
         import torch
         close = self.backend.score_block(n, base)
-        counts = torch.tensor(close.sum(axis=1).astype(np.float64), dtype=torch.float64, device=self.device)
+        # a backend may hand back (flags, per-query counts): a block of 1 024 queries x 12 500 candidates is 12.8 MB of flags, 6-10 ms of
+        # numpy's uint8 row sums against a step of ~15 ms on an 8-rank run, while the library adds them up on the device
+        if isinstance(close, tuple):
+            close, row_counts = close
+        else:
+            row_counts = np.einsum("ij->i", close, dtype=np.uint64)
+        counts = torch.tensor(np.asarray(row_counts, dtype=np.float64), dtype=torch.float64, device=self.device)
         if self.plan.world > 1:
             out = [torch.zeros_like(counts) for _ in range(self.plan.world)]
             self.dist.all_gather(out, counts)

@@ -45,7 +45,8 @@ def main():
         for nq, cands in ((2, np.arange(n, dtype=np.uint32)), (65, np.arange(n - 1, -1, -1, dtype=np.uint32)), (130, np.arange(3, 40, dtype=np.uint32)),
                           (7, np.array([5, 5, 9], dtype=np.uint32)), (64, np.arange(0, n, 2, dtype=np.uint32))):
             qs = (np.arange(nq, dtype=np.uint32) * 7) % n
-            multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+            multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask, want=("sum", "csum", "close", "counts"))
+            assert np.array_equal(multi["counts"], multi["close"].sum(axis=1, dtype=np.uint64)), ("counts", dtype, nq)      # msc_last_close_counts
             for i in range(0, nq, 1 if nq <= 16 else 9):
                 raw = api.pair_features_raw(ctx, hs, cands, hs, int(qs[i]), mask)
                 single = feat.compute(hs, cands, hs, int(qs[i]))
