@@ -46,6 +46,11 @@ bool msc_ctx_owns(const msc_ctx* ctx, const msc_hist_set* set) { return ctx && s
 // device is drained behind it, so the last line printed names the operation that faulted
 const bool g_trace_calls = getenv("MSC_TRACE_CALLS") != nullptr;
 static const bool g_profile_calls = getenv("MSC_PROFILE_CALLS") != nullptr;
+// from how many bins on the sparse mean sweeps only the 64-byte lines its members touched (MSC_SPARSE_MEAN_GROUPS_MIN_K for A/B runs)
+static uint64_t msc_sparse_groups_min_bins() {
+	static const uint64_t v = [] { const char* e = getenv("MSC_SPARSE_MEAN_GROUPS_MIN_K"); const int k = e ? atoi(e) : 11; return 1ull << (2 * std::max(5, std::min(16, k))); }();
+	return v;
+}
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int ensure(msc_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -2288,7 +2293,7 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	if ((r = ensure(ctx, ctx->sp_chunk_cum, n_chunks * sizeof(uint64_t)))) return r;
 	// k >= 11: the kernels of the batched form with one centre, whose sweeps visit touched 64-byte lines only
 	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
-	const bool grouped = !no_groups && L.nbins >= (1ull << 22) && chunk_bins % 512 == 0 && member_slots;
+	const bool grouped = !no_groups && L.nbins >= msc_sparse_groups_min_bins() && chunk_bins % 512 == 0 && member_slots;
 	if (grouped) {
 		const size_t tb = (size_t)(L.nbins >> 9) * sizeof(uint32_t);
 		if (tb > ctx->sp_touched.cap) {
@@ -2458,7 +2463,7 @@ int sparse_acc_prepare(msc_ctx* ctx, const MscLayout& L, uint32_t nc, uint32_t**
 		HIP_TRY(ctx, hipMemsetAsync(ctx->sp_acc_batch.p, 0, ctx->sp_acc_batch.cap, ctx->stream));
 	}
 	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
-	const bool grouped = !no_groups && L.nbins >= (1ull << 22) && chunk_bins % 512 == 0;
+	const bool grouped = !no_groups && L.nbins >= msc_sparse_groups_min_bins() && chunk_bins % 512 == 0;
 	if (grouped) {
 		const size_t tb = (size_t)nc * (L.nbins >> 9) * sizeof(uint32_t);
 		if (tb > ctx->sp_touched.cap) {
