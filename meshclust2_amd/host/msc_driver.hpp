@@ -244,6 +244,9 @@ public:
 	// MSC_CLUSTER_PROFILE=1: where the step-serial accumulate stage spends its wall clock (seconds), printed behind its timestamp
 	struct StepProfile { double window = 0, get_close = 0, mark = 0, closest = 0; uint64_t steps = 0, candidates = 0, closed = 0; } prof;
 	bool profile = std::getenv("MSC_CLUSTER_PROFILE") != nullptr;
+	// ... and the update stage: building the neighbourhood lists / update_centres / centre_set_batch / merge_all / the host's merge bookkeeping
+	struct UpdateProfile { double lists = 0, update = 0, set = 0, merge = 0, book = 0; int rounds = 0; } uprof;
+	static double seconds_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
 
 	// Clock::stamp (clutil/Clock.cpp:12-19): same stage names as the reference's driver
 	void stamp(const char* desc) {
@@ -288,6 +291,9 @@ public:
 		}
 		update_round(part, 0);
 		stamp("update");
+		if (profile)
+			log_ << "update profile: rounds " << uprof.rounds << " | lists " << uprof.lists << " s, update_centres " << uprof.update << " s, centre_set " << uprof.set
+			     << " s, merge_all " << uprof.merge << " s, merge bookkeeping " << uprof.book << " s" << std::endl;
 		if (output) write_clstr(output, part);
 		log_ << "Number of clusters: " << part.size() << std::endl;
 		stamp("done");
@@ -441,6 +447,7 @@ private:
 		const size_t n = part.size();
 		if (n == 0) return;
 		if (batch_update) {
+			auto t0 = std::chrono::steady_clock::now();
 			std::vector<uint32_t> centres(n), flat;
 			std::vector<uint64_t> offsets(n + 1, 0);
 			std::vector<SeqRecord*> good;
@@ -451,7 +458,13 @@ private:
 			}
 			flat = handles(good);
 			std::vector<int64_t> nearest(n, -1);
-			if (be_.update_centres(centres, flat, offsets, nearest)) {
+			uprof.rounds++;
+			uprof.lists += seconds_since(t0);
+			t0 = std::chrono::steady_clock::now();
+			const bool took = be_.update_centres(centres, flat, offsets, nearest);
+			uprof.update += seconds_since(t0);
+			if (took) {
+				t0 = std::chrono::steady_clock::now();
 				std::vector<uint32_t> dst, src;
 				for (size_t j = 0; j < n; j++) {
 					SeqRecord* next = nearest[j] >= 0 ? good[(size_t)(offsets[j] + (uint64_t)nearest[j])] : (delta == 0 ? part[j].members[0] : nullptr);
@@ -462,6 +475,7 @@ private:
 				}
 				if (!dst.empty() && !be_.centre_set_batch(dst, src))
 					for (size_t i = 0; i < dst.size(); i++) be_.centre_set(dst[i], src[i]);
+				uprof.set += seconds_since(t0);
 				return;
 			}
 		}
@@ -488,7 +502,10 @@ private:
 		for (int c = 0; c < n; c++) centres[(size_t)c] = part[(size_t)c].centre;
 		// no merge call changes a histogram, so all of them may be answered at once
 		std::vector<int64_t> best((size_t)n, 0);
+		auto t0 = std::chrono::steady_clock::now();
 		const bool have = batch_update && be_.merge_all(centres, delta, best);
+		uprof.merge += seconds_since(t0);
+		t0 = std::chrono::steady_clock::now();
 		for (int i = 0; i < n; i++) {
 			const long ret = have ? (long)best[(size_t)i] : be_.merge(centres, i, i + 1, std::min(n - 1, i + delta));
 			if (ret > i) {
@@ -499,6 +516,7 @@ private:
 			}
 		}
 		part.erase(std::remove_if(part.begin(), part.end(), [](const Cluster& c) { return c.merged_away; }), part.end());
+		uprof.book += seconds_since(t0);
 	}
 
 	// bvec::pop; a backend that keeps the window learns that the position is gone
