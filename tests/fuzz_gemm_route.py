@@ -20,7 +20,7 @@ MASK = sum(1 << b for _, b in FAST)
 
 def one_round(ctx, seed):
     rng = np.random.default_rng(seed)
-    k = int(rng.integers(7, 10))
+    k = int(rng.integers(5, 10))
     dtype = int(rng.choice([8, 16, 32]))
     nbins = 4 ** k
     n = int(rng.integers(12, 160))
