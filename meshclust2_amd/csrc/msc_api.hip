@@ -418,7 +418,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins + 64 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)

@@ -29,8 +29,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr uint32_t kStep = 256;          // bins per k-step
 
 // byte offset of bins [at, at + 16) (at a multiple of 16) of `slot` in the blocked mirror
+// (a block takes one KiB more than its chunks: blocks 4^k * 16 bytes apart -- a power of two -- would put the same chunk of every block
+// on the same HBM channels, and the workgroups of a slice walk their blocks nearly in step)
+__host__ __device__ __forceinline__ uint64_t c8_block_bytes(uint64_t nbins) { return ((nbins >> 6) + 1) * 1024; }
 __device__ __forceinline__ uint64_t c8_offset(uint64_t slot, uint64_t at, uint64_t nbins) {
-	return ((slot >> 4) * (nbins >> 6) + (at >> 6)) * 1024 + (slot & 15) * 64 + (at & 63);
+	return (slot >> 4) * c8_block_bytes(nbins) + (at >> 6) * 1024 + (slot & 15) * 64 + (at & 63);
 }
 
 template <typename T>
@@ -96,7 +99,7 @@ __device__ __forceinline__ v4i level_at(const v4i e, uint32_t T) {
 template <int LB, int NCB>
 __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                      const uint8_t* __restrict__ q8, uint64_t nbins, uint32_t k_slices, int32_t* __restrict__ out,
-                                                     int32_t* __restrict__ out_min, bool nt) {
+                                                     int32_t* __restrict__ out_min, bool nt, bool lockstep) {
 	constexpr int NL = LB ? (1 << LB) - 1 : 0;
 	__shared__ v4i sA[2][64][16];          // [buffer][query row][16-byte segment ^ (row & 15)]: 32 KiB
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 		const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
 		// lane l: candidate l % 16 of the block, bytes 16 (l / 16) .. + 15 of every 64-bin chunk: consecutive slots of one block make the
 		// wave's load one contiguous KiB
-		brow[cb] = cand8 + (slot >> 4) * (nbins >> 6) * 1024 + (slot & 15) * 64 + (lane >> 4) * 16;
+		brow[cb] = cand8 + (slot >> 4) * c8_block_bytes(nbins) + (slot & 15) * 64 + (lane >> 4) * 16;
 	}
 	const uint32_t arow = tid >> 2, aseg0 = (tid & 3) * 4;
 	const uint8_t* asrc = q8 + (uint64_t)arow * nbins + aseg0 * 16;
@@ -127,11 +130,12 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 #pragma unroll
 		for (int rb = 0; rb < 4; rb++) acc_min[cb][rb] = v4i{0, 0, 0, 0};
 	v4i a_reg[4], b0[NCB][4], b1[NCB][4];          // plain vectors: HIP's uint4 struct kept these arrays in scratch
-	// The rows of the operands are a power of two apart (4^k bytes) and so are the slices: every workgroup walking its steps in the same
-	// order puts the whole chip on the same HBM channels at the same time (first version: 1.7 TB/s). Each workgroup therefore starts
-	// its walk somewhere else -- a sum does not care in which order its terms arrive.
+	// Rows of the operands a power of two apart (4^k bytes): every workgroup walking its steps in the same order put the whole chip on the
+	// same HBM channels at the same time (first version: 1.7 TB/s), so each workgroup started its walk somewhere else (MSC_GEMM_NO_LOCKSTEP
+	// still does). Since the blocks of the mirror are a KiB more than a power of two apart the workgroups may walk in step again, and
+	// then the queries' tile of a step is hot in L2 for all of them: 4-5 % faster than the scattered walk.
 	const uint32_t steps = (uint32_t)(per / kStep);
-	const uint32_t rot = (blockIdx.x * 37u + ks * 11u) % steps;
+	const uint32_t rot = lockstep ? 0u : (blockIdx.x * 37u + ks * 11u) % steps;
 	// operands of step i (the last step once more past the end: a load nobody uses is cheaper than a branch around it -- with the
 	// loads under `if (more)` the compiler parked them in scratch and so waited for each as soon as it was issued). One step ahead is
 	// enough: a third register set, two steps ahead, changed nothing (6.58 -> 6.51 ms) -- what held this kernel at 4 TB/s was the queries'
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 }  // namespace
 
 // bytes of the blocked mirror of a set of `capacity` slots
-uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 15) / 16 * 16 * L.padded_bins; }
+uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 15) / 16 * c8_block_bytes(L.padded_bins); }
 
 hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots, int32_t* has_zero) {
 	if (n_slots == 0) return hipSuccess;
@@ -287,10 +291,11 @@ hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* ca
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	static const bool nt = getenv("MSC_GEMM_NT") != nullptr;
+	static const bool lockstep = getenv("MSC_GEMM_NO_LOCKSTEP") == nullptr;
 	static const int ncb_env = [] { const char* e = getenv("MSC_GEMM_NCB"); return e ? atoi(e) : 0; }();
 	const int ncb = ncb_env == 2 ? 2 : 1;          // (two blocks paid while every level was multiplied out; with the levels a tile does not reach skipped, one is faster: 5.25 against 5.44 ms)
 	const dim3 grid((m + 64 * ncb - 1) / (64 * ncb), k_slices);
-#define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min, nt)
+#define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min, nt, lockstep)
 	if (level_bits == 2) { if (ncb == 2) MSC_GEMM_GO(2, 2); else MSC_GEMM_GO(2, 1); }
 	else if (level_bits == 3) { if (ncb == 2) MSC_GEMM_GO(3, 2); else MSC_GEMM_GO(3, 1); }
 	else { if (ncb == 2) MSC_GEMM_GO(0, 2); else MSC_GEMM_GO(0, 1); }
