@@ -1936,7 +1936,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	static const bool no_gemm = getenv("MSC_MULTI_NO_GEMM") != nullptr;
 	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
 	static const bool no_manh_gemm = getenv("MSC_MULTI_NO_MANH_GEMM") != nullptr;
-	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? atoi(e) : 3; }();
+	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? std::min(4, atoi(e)) : 4; }();
 	const bool tuned_by_hand = getenv("MSC_MULTI_TQ") || getenv("MSC_DIGEST_SLOTS");          // A/B switches of the older kernels: keep to them
 	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
 	// longest list is a quarter of the bins or less, for up to 64 queries and 2^20 bins (32-bit wave sums)
@@ -1944,7 +1944,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// The products on the matrix cores (msc_dot_gemm.hip): int8 operands, exact int32 sums -- every count <= 127 and count x sum < 2^31
 	// (a product sum is at most max count x sum of the other histogram). Up to 64 queries per call.
 	const bool gemm_fit = !no_gemm && !tuned_by_hand && cands->dtype != 64 && mc_ <= 127 && mc_ * ms_ < (1ull << 31) && n_q <= 64 && L.nbins == L.padded_bins && L.nbins % 1024 == 0;
-	// EVERYTHING on the matrix cores. Every count of both sets below 9 (1 kb sequences at k = 9 qualify; every count >= 1, which the
+	// EVERYTHING on the matrix cores. Every count of both sets below 17 (1 kb sequences at k = 9 qualify; every count >= 1, which the
 	// build of the count8 mirror checks): the Manhattan distance is a sum of products of thermometer level bytes and comes out of the
 	// same GEMM as the products of the counts -- one read of a byte per bin per 64 queries, no digest mirror, no partial records.
 	int level_bits = 0;
@@ -1956,7 +1956,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
 			ok = cands->ranks && qset->ranks;
 		}
-		if (ok) { level_bits = mc_ <= 4 ? 2 : 3; emd_ranks = need_emd; }
+		if (ok) { level_bits = mc_ <= 4 ? 2 : mc_ <= 8 ? 3 : 4; emd_ranks = need_emd; }
 	}
 	const bool manh_gemm = level_bits != 0;
 	// Digest form (pair_digest.hip): sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen (or 32)

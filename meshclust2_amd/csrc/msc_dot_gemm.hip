@@ -90,6 +90,20 @@ __device__ __forceinline__ v4i level_at(const v4i e, uint32_t T) {
 	return r;
 }
 
+// Excess counts of four bits (LB = 4: counts up to 16): the selector of v_perm_b32 only reaches an 8-byte table, so the low three bits are
+// looked up and the fourth decides -- [e >= T] = hi | [lo >= T] below 8, hi at 8, hi & [lo >= T - 8] above.
+template <int LB>
+__device__ __forceinline__ v4i level_any(const v4i e, uint32_t T) {
+	if constexpr (LB < 4) return level_at(e, T);
+	else {
+		const v4i m7 = {0x07070707, 0x07070707, 0x07070707, 0x07070707}, m1 = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+		const v4i lo = e & m7, hi = (e >> 3) & m1;
+		if (T == 8) return hi;
+		const v4i l = level_at(lo, T < 8 ? T : T - 8);
+		return T < 8 ? (hi | l) : (hi & l);
+	}
+}
+
 // LB > 0: besides the products of the counts, sum min(e, e') from the level bytes (out_min, same layout): 2^LB - 1 more MFMAs per tile,
 // operands derived in registers from the same bytes -- the candidates are still read once.
 // NCB: blocks of 16 candidates per wave. The level bytes of a query operand serve every candidate block of the wave (and a candidate
@@ -185,7 +199,7 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 #pragma unroll
 					for (int rb = 0; rb < 4; rb++) {
 						const v4i A = sA[buf][16 * rb + (lane & 15)][(4 * kc + (lane >> 4)) ^ (lane & 15)];
-						const v4i A1 = level_of<1>(A - one);
+						const v4i A1 = LB < 4 ? level_of<1>(A - one) : level_any<LB>(A - one, 1);
 #pragma unroll
 						for (int cb = 0; cb < NCB; cb++) {
 							acc[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, b[cb][kc], acc[cb][rb], 0, 0, 0);
@@ -199,7 +213,7 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 					for (uint32_t T = 2; T <= (uint32_t)NL; T++) {
 						uint32_t any = 0;
 #pragma unroll
-						for (int cb = 0; cb < NCB; cb++) { const v4i l = level_at(E[cb], T); any |= (uint32_t)(l.x | l.y | l.z | l.w); }
+						for (int cb = 0; cb < NCB; cb++) { const v4i l = level_any<LB>(E[cb], T); any |= (uint32_t)(l.x | l.y | l.z | l.w); }
 						if (__builtin_amdgcn_ballot_w64(any != 0) == 0) break;
 						reach = T;
 					}
@@ -211,9 +225,9 @@ __global__ void __launch_bounds__(256) k_dot_gemm_i8(const uint8_t* __restrict__
 						for (int cb = 0; cb < NCB; cb++) acc[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, b[cb][kc], acc[cb][rb], 0, 0, 0);
 #pragma unroll 1
 						for (uint32_t T = 1; T <= reach; T++) {
-							const v4i al = level_at(AE, T);
+							const v4i al = level_any<LB>(AE, T);
 #pragma unroll
-							for (int cb = 0; cb < NCB; cb++) acc_min[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, level_at(E[cb], T), acc_min[cb][rb], 0, 0, 0);
+							for (int cb = 0; cb < NCB; cb++) acc_min[cb][rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, level_any<LB>(E[cb], T), acc_min[cb][rb], 0, 0, 0);
 						}
 					}
 				}
@@ -280,13 +294,13 @@ uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus) {
 }
 
 // dots[slice][candidate][64] of n_q <= 64 queries (rows q_slots of q_count8) against m candidates (slot list, or slots first .. first + m - 1)
-// level_bits 2 / 3 (every excess count below 4 / 8): out_min[slice][candidate][64] = sum min(e, e') as well
+// level_bits 2 / 3 / 4 (every excess count below 4 / 8 / 16): out_min[slice][candidate][64] = sum min(e, e') as well
 hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,
                                int level_bits, int32_t* out_min) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > 64 || nbins % (16 * 16) || nbins % ((uint64_t)k_slices * kStep)) return hipErrorInvalidValue;
-	if (level_bits != 0 && ((level_bits != 2 && level_bits != 3) || !out_min)) return hipErrorInvalidValue;
+	if (level_bits != 0 && (level_bits < 2 || level_bits > 4 || !out_min)) return hipErrorInvalidValue;
 	k_gather_rows8<<<dim3((unsigned)((nbins / 16 + 255) / 256), 64), dim3(256), 0, st>>>(q_count8, q_slots_dev, n_q, nbins, q8_scratch);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
@@ -298,6 +312,7 @@ hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* ca
 #define MSC_GEMM_GO(LB, NCB) k_dot_gemm_i8<LB, NCB><<<grid, dim3(256), 0, st>>>(cand_count8, cand_slots, first, m, q8_scratch, nbins, k_slices, out, out_min, nt, lockstep)
 	if (level_bits == 2) { if (ncb == 2) MSC_GEMM_GO(2, 2); else MSC_GEMM_GO(2, 1); }
 	else if (level_bits == 3) { if (ncb == 2) MSC_GEMM_GO(3, 2); else MSC_GEMM_GO(3, 1); }
+	else if (level_bits == 4) MSC_GEMM_GO(4, 1);
 	else { if (ncb == 2) MSC_GEMM_GO(0, 2); else MSC_GEMM_GO(0, 1); }
 #undef MSC_GEMM_GO
 	return hipGetLastError();

@@ -31,6 +31,9 @@ def one_round(ctx, seed):
         s = list(base[i % len(base)])
         for _ in range(int(rng.integers(0, 1 + len(s) // 20))):
             s[int(rng.integers(0, len(s)))] = "ACGT"[int(rng.integers(0, 4))]
+        if seed % 3 == 0 and i % 4 == 0:          # a short unit repeated: counts up to ~16 (the four-bit levels), sometimes past them (the digest route)
+            at = int(rng.integers(0, len(s)))
+            s[at:at] = list("".join("ACGT"[b] for b in rng.integers(0, 4, int(rng.integers(k, 2 * k)))) * int(rng.integers(2, 18)))
         seqs.append("".join(s))
     hs = api.HistogramSet(ctx, k, dtype, n)
     hs.build(seqs)

@@ -37,10 +37,13 @@ def main():
     # counts of 3 .. 8 in most tiles (3 kb sequences over the 16 384 bins of k = 7): the level products beyond the first, tile by tile;
     # more queries than one block of 64, windows shorter than a workgroup's 64 candidates, slot lists
     seqs, _ = synth.families(913, 150, 3000, family=10)
-    for dtype in (16, 8, 32):
+    # (the second round: a 12-mer repeated 11 times in every third sequence -- counts of 9 .. 16, the four-bit levels)
+    rep = [s if i % 3 else s[:1500] + (b"ACGTTGCAAGTC" if isinstance(s, bytes) else "ACGTTGCAAGTC") * 11 + s[1500:] for i, s in enumerate(seqs)]
+    for dtype, seqs in ((16, seqs), (8, seqs), (32, seqs), (16, rep), (32, rep)):
         hs = api.HistogramSet(ctx, 7, dtype, len(seqs))
         hs.build(seqs)
-        assert 3 <= int(max(hs.download(i).max() for i in (0, 7, 77))) <= 127
+        top = int(max(hs.download(i).max() for i in (0, 3, 7, 77)))
+        assert (9 <= top <= 16) if seqs is rep else (3 <= top <= 8), top
         n = len(seqs)
         for nq, cands in ((2, np.arange(n, dtype=np.uint32)), (65, np.arange(n - 1, -1, -1, dtype=np.uint32)), (130, np.arange(3, 40, dtype=np.uint32)),
                           (7, np.array([5, 5, 9], dtype=np.uint32)), (64, np.arange(0, n, 2, dtype=np.uint32))):
