@@ -1,25 +1,28 @@
-// msc_dot_gemm.hip -- the one GEMM-shaped piece of the Q x M pass on the matrix cores (gfx950 MFMA).
+// msc_dot_gemm.hip -- the Q x M pass on the matrix cores (gfx950 MFMA): the products of the counts and, through their thermometer
+// levels, the Manhattan distance.
 //
-// Of the three integer reductions the all-pairs pass needs per pair (pair_digest.hip), two are not bilinear (sum |p - q|, sum of |prefix
-// differences|: v_sad_* on the VALU, nothing else will do) and one is: dot(q, c) = sum over bins of q_i c_i for every (query, candidate)
-// is the matrix product  D[64 x M] = Q[64 x 4^k] . C[4^k x M]  -- normalized_vectors, pearson, euclidean and simratio
+// Of the three integer reductions the all-pairs pass needs per pair (pair_digest.hip), dot(q, c) = sum over bins of q_i c_i for every
+// (query, candidate) is the matrix product  D[64 x M] = Q[64 x 4^k] . C[4^k x M]  -- normalized_vectors, pearson, euclidean and simratio
 // (predict/Feature.cpp:1171-1184,795-811,1113-1124,829-841) all derive from it. The digest kernel spent a quarter of its arithmetic on it
 // (8 of 32 VALU operations per query and 32 bins: v_dot4_u32_u8) while VALU-bound at 86 % busy (r02 counters), with the matrix cores idle.
 // Here it is an int8 GEMM: v_mfma_i32_16x16x64_i8, exact in int32 (counts <= 127 and count x sum < 2^31: host-checked per set).
+// sum |q_i - c_i| is not bilinear in the counts but is in their levels [count - 1 >= t] (see `level_of` below): with every count of both
+// sets <= 16 it comes out of the same pass over the same bytes as a second accumulator, and the digest kernel does not run at all (the
+// third reduction, the earth mover's distance, comes from msc_emd_ranks.hip).
 //
-//   count8 mirror  one byte per bin in the set's own (tile-permuted) bin order -- any order serves a dot product as long as both
-//                  operands share it --, BLOCKED for the B operand: slots in blocks of 16, a block = [64-bin chunk][slot % 16][64 bytes],
-//                  so that the 16 candidates x 64 bytes a wave loads per MFMA are ONE contiguous KiB and the chunks of a block
-//                  follow each other (the first version read 64 bytes from each of 16 rows 256 KiB apart: 2.1 TB/s). 1 byte per
-//                  bin (1/4 of a 32-bit set), refreshed with the digest mirror's stale range.
+//   count8 mirror  one byte per bin in the set's own (tile-permuted) bin order -- any order serves a product as long as both
+//                  operands share it --, BLOCKED for the B operand: slots in blocks of 16, a block = [64-bin chunk][slot % 16][64 bytes]
+//                  + a KiB of padding, so that the 16 candidates x 64 bytes a wave loads per MFMA are ONE contiguous KiB, the chunks of
+//                  a block follow each other (the first version read 64 bytes from each of 16 rows 256 KiB apart: 2.1 TB/s) and blocks
+//                  are not a power of two apart. 1 byte per bin (1/4 of a 32-bit set), refreshed with the other mirrors' stale range.
 //   k_dot_gemm_i8  workgroup = 64 candidates x 64 queries x one slice of the bins; wave w owns candidates 16 w .. 16 w + 15 and
-//                  all 64 queries: 4 accumulators of 16 x 16. Candidate bytes go from HBM straight into the B operand registers
+//                  all 64 queries: 4 (+ 4) accumulators of 16 x 16. Candidate bytes go from HBM straight into the B operand registers
 //                  (lane l: candidate l % 16, 16 bins of block l / 16: a 64-byte run per candidate and load, the next load takes
 //                  the other half of the line); the query tile of a 256-bin step is staged once per workgroup in LDS, 16-byte
 //                  segments XOR-swizzled by row so that the 16 rows an A operand touches sit in 16 different bank groups.
-//                  Roofline: HBM -- every candidate byte is read once per 64 queries (1 byte per bin: a quarter of the digest
-//                  stream); the MFMA pipe needs 512 of the ~2000 cycles a step's 16 KiB take to arrive.
-//   output         int32 dots[slice][candidate][64]: the epilogue adds the slices (no atomics: deterministic).
+//                  Roofline: HBM -- every candidate byte is read once per 64 queries (1 byte per bin): 5.1 ms per 100 000 x 64 at
+//                  k = 9 = 5.1 TB/s.
+//   output         int32 [slice][candidate][64] per accumulator: the epilogue adds the slices (no atomics: deterministic).
 #include "msc_internal.h"
 #include "msc_wave.h"
 
