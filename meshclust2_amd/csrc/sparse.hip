@@ -932,6 +932,23 @@ __device__ __forceinline__ void mp_stage_dma(const uint2* src, uint32_t count, u
 	}
 }
 
+// A piece and its predecessor (entries first - 1 .. first + n - 1 of a list; a neutral entry when first == 0) into the stage dst[0 .. n].
+// pairs: two entries per lane and instruction -- one 16-byte load (list entries are 8-byte aligned; the hardware asks a multi-dword
+// global load for dword alignment only) and one ds_write_b128 (dst is 16-byte aligned) instead of two of each; the lane that takes the
+// last entry may copy one entry more (the arena keeps two entries of slack; the caller writes its end marker afterwards).
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void stage_pairs(const uint2* __restrict__ list, uint32_t first, uint32_t n, uint2* dst, uint32_t lane, bool pairs) {
+	if (!pairs || first == 0) {
+		for (uint32_t k = lane; k <= n; k += 64) dst[k] = (first + k) ? list[first + k - 1] : make_uint2(0u, 1u);
+		return;
+	}
+	const uint2* src = list + first - 1;
+	for (uint32_t k = 2 * lane; k <= n; k += 128) {
+		const u32x4_a8 v = *reinterpret_cast<const u32x4_a8*>(src + k);
+		*reinterpret_cast<u32x4*>(dst + k) = u32x4{v.x, v.y, v.z, v.w};
+	}
+}
+
 constexpr uint32_t kMpDivGran = 4;      // chunks per divergence record (see the DIV comment inside the kernel)
 constexpr uint32_t kMpTab = 8;          // side of the divergence-term table in LDS
 constexpr uint32_t kMpDivMinGran = 4;   // granules a part of a pair keeps at least (16 chunks, 8 192 merged entries)
@@ -943,7 +960,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
     const uint8_t* __restrict__ q_scalars, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
     const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0,
-    uint32_t div_stride = 1, bool dma = false) {
+    uint32_t div_stride = 1, bool dma = false, bool pairs = false) {
 	constexpr uint32_t kMpBuf = kMpT + 8;
 	__shared__ uint2 s_buf[4][kMpBuf];
 	// DIV: the 8 x 8 corner of the candidate's table of terms (counts below 8: all but the k-mers of repeats), already relative to the
@@ -1045,9 +1062,9 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 			// store loops were 37 % of this kernel at k = 13). A piece that STARTS its list has no predecessor in memory (and its entries
 			// would land 8 bytes off the DMA's 16-byte grid): the first chunk of either list keeps the loop.
 			if (dma && c0) mp_stage_dma(P + c0 - 1, nc + 1, (uint32_t)(uintptr_t)cl, lane);
-			else for (uint32_t k = lane; k <= nc; k += 64) cl[k] = (c0 + k) ? P[c0 + k - 1] : make_uint2(0u, 1u);
+			else stage_pairs(P, c0, nc, cl, lane, pairs);
 			if (dma && q0) mp_stage_dma(Q + q0 - 1, nq + 1, (uint32_t)(uintptr_t)ql, lane);
-			else for (uint32_t k = lane; k <= nq; k += 64) ql[k] = (q0 + k) ? Q[q0 + k - 1] : make_uint2(0u, 1u);
+			else stage_pairs(Q, q0, nq, ql, lane, pairs);
 			if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			// one entry past either piece: a bin index no share reaches, so a lane that runs off the end of a piece stops by itself
 			if (lane == 0) { cl[nc + 1] = make_uint2(kInf, 1u); ql[nq + 1] = make_uint2(kInf, 1u); }
@@ -1371,9 +1388,15 @@ hipError_t msc_launch_pair_sparse_lds(hipStream_t st, const void* c_ent, const u
 }
 
 int msc_sparse_div_waves();
+bool msc_sparse_mp_pairs();
 // MSC_SPARSE_MP_DMA=1: the chunks of the merge-path kernel are staged by LDS-DMA instead of the load -> store loop. OFF by default:
 // measured r03 (k = 13, 20 kb lists, 8 000 candidates) 2.89 ms per launch against 0.78 ms for the loop, and results that differ -- list
 // pieces start on 8-byte, not 16-byte, boundaries of global memory, which global_load_lds_dwordx4 does not take (profiles/r03_notes.md).
+// two list entries per lane and instruction when a chunk is staged (MSC_SPARSE_MP_NO_PAIRS for A/B runs)
+bool msc_sparse_mp_pairs() {
+	static const bool off = getenv("MSC_SPARSE_MP_NO_PAIRS") != nullptr;
+	return !off;
+}
 bool msc_sparse_mp_dma() {
 	static const bool on = getenv("MSC_SPARSE_MP_DMA") != nullptr;
 	return on;
@@ -1418,13 +1441,13 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
 	if (div_tables) {
 #define MSC_MP_DIV(W) k_pair_sparse_mp<true, kMpChunk, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
-		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride, msc_sparse_mp_dma())
+		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
 		if (wpe == 4) MSC_MP_DIV(4); else if (wpe == 7) MSC_MP_DIV(7); else MSC_MP_DIV(6);
 #undef MSC_MP_DIV
 	} else {
 		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
-		                                                                      nullptr, nullptr, parts, 0, 1, msc_sparse_mp_dma());
+		                                                                      nullptr, nullptr, parts, 0, 1, msc_sparse_mp_dma(), msc_sparse_mp_pairs());
 	}
 	return hipGetLastError();
 }
@@ -1502,13 +1525,13 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 		blocks = (uint32_t)num_cus * (uint32_t)wpe;
 		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
 #define MSC_MP_DIVP(W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
-		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride, msc_sparse_mp_dma())
+		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
 		if (wpe == 4) MSC_MP_DIVP(4); else if (wpe == 7) MSC_MP_DIVP(7); else MSC_MP_DIVP(6);
 #undef MSC_MP_DIVP
 		return hipGetLastError();
 	}
 	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
-	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg, 1, 0, 1, msc_sparse_mp_dma());
+	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg, 1, 0, 1, msc_sparse_mp_dma(), msc_sparse_mp_pairs());
 	return hipGetLastError();
 }
 
