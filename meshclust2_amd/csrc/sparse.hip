@@ -278,21 +278,6 @@ __global__ void __launch_bounds__(256) k_sparse_div_tables(const uint8_t* __rest
 	tables[(uint64_t)c * 256 + j] = t;
 }
 
-// the 8 x 8 corner only -- all the merge-path kernel looks up (kMpTab): one wave per candidate, a quarter of the logarithms
-__global__ void __launch_bounds__(256) k_sparse_div_corner(const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint32_t m,
-                                                           const uint8_t* __restrict__ q_scalars, int order, DivTerm* __restrict__ tables,
-                                                           const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint64_t q_stride = 0) {
-	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (c >= m) return;
-	const uint32_t slot = cand_slots ? cand_slots[c] : c;
-	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride)->mag;
-	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars + (segs ? (uint64_t)segs[pair_seg[c]].q_slot * q_stride : 0))->mag;
-	const uint32_t a = (threadIdx.x & 63) >> 3, b = threadIdx.x & 7;
-	DivTerm t{0.0, 0.0};
-	if (a && b) t = div_term_sp(a, b, cm, qm, order);
-	tables[(uint64_t)c * 256 + a * 16 + b] = t;
-}
-
 template <bool DIV>
 __global__ void __launch_bounds__(256) k_pair_sparse(
     const uint2* __restrict__ c_ent, const uint32_t* __restrict__ c_cum, const MscSparseHdr* __restrict__ c_hdr,
@@ -1011,7 +996,10 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 			__builtin_amdgcn_wave_barrier();          // the previous candidate's walk is over
 			static_assert(kMpTab * kMpTab == 64, "one table entry per lane");
 			{
-				const DivTerm g = div_tables[(uint64_t)c * 256 + (lane / kMpTab) * 16 + (lane % kMpTab)];
+				// (computed here, one term per lane: a table kernel of its own ahead of every pass was 10 us of a 500 us step)
+				const uint32_t a = lane / kMpTab, b = lane % kMpTab;
+				DivTerm g{0.0, 0.0};
+				if (a && b) g = div_term_sp(a, b, cm, qm, order);
 				s_tab[wave][lane] = DivTerm{g.jd - t11.jd, g.js - t11.js};
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1419,11 +1407,6 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 	if (m == 0) return hipSuccess;
 	if (max_total > msc_sparse_mp_max_entries() || parts < 1 || parts > 16 || (uint64_t)m * parts > 0xffffffffull) return hipErrorInvalidValue;
 	if (div_tables && div_stride < msc_sparse_mp_div_records(max_total)) return hipErrorInvalidValue;
-	if (div_tables) {
-		k_sparse_div_corner<<<dim3((m + 3) / 4), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables);
-		hipError_t e = hipGetLastError();
-		if (e != hipSuccess) return e;
-	}
 	// short lists, integer statistics: the whole-list kernel (the caller passes q_nnz / c_max_nnz; 0 = unknown)
 	if (!div_tables && parts == 1 && msc_sparse_wl_fits(q_nnz, c_max_nnz)) {
 		const size_t lds = ((size_t)q_nnz + 2 + 4 * ((size_t)c_max_nnz + 2)) * sizeof(uint2);
@@ -1518,9 +1501,6 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
 	if (div_tables) {      // the divergence sums of every pair as well: the same walk, hence the same bits, as the 1 x M divergence form
 		if (!q_scalars || !div_partials) return hipErrorInvalidValue;
-		k_sparse_div_corner<<<dim3((m + 3) / 4), dim3(256), 0, st>>>(cand_scalars, scalar_stride, cand_slots, m, q_scalars, order, (DivTerm*)div_tables, segs, pair_seg, q_scalar_stride);
-		hipError_t e = hipGetLastError();
-		if (e != hipSuccess) return e;
 		const int wpe = msc_sparse_div_waves();
 		blocks = (uint32_t)num_cus * (uint32_t)wpe;
 		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
