@@ -149,6 +149,11 @@ uint64_t msc_hist_set_bytes(const msc_hist_set* set);              /* HBM footpr
 int      msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64_t capacity, uint64_t max_entries, msc_hist_set** out);
 int      msc_hist_set_is_sparse(const msc_hist_set* set);
 uint64_t msc_hist_set_entries(const msc_hist_set* set, uint64_t slot);     /* stored bins of one slot */
+/* Empties a sparse set: every slot back to "never written", the whole entry arena free again. The entry arena is append-only
+ * (a slot that is assigned again leaves its old list behind), so a store of moving centres is compacted by copying its live slots
+ * into a second set (msc_hist_copy_batch) and clearing the first for the next time -- no allocation in the loop. The reference has
+ * no counterpart: its centres are heap objects (Center<T>, cluster/Center.h). Dense sets: MSC_ERR_UNSUPPORTED. */
+int      msc_hist_set_clear(msc_ctx* ctx, msc_hist_set* set);
 
 /* Replaces Loader<T>::get_point (clutil/Loader.cpp:112-179; callers cluster/CRunner.cpp:526,
  * predict/Predictor.cpp:799,858, fastcar/FC_Runner.cpp:501) for n_seqs sequences at once.

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "msc_hist_set_create_sparse": (_int, [_vp, _int, _int, _u64, _u64, C.POINTER(_vp)]),
     "msc_hist_set_is_sparse": (_int, [_vp]),
     "msc_hist_set_entries": (_u64, [_vp, _u64]),
+    "msc_hist_set_clear": (_int, [_vp, _vp]),
     "msc_hist_set_destroy": (None, [_vp]),
     "msc_hist_set_capacity": (_u64, [_vp]),
     "msc_hist_set_k": (_int, [_vp]),

@@ -121,6 +121,10 @@ class HistogramSet:
     def entries(self, slot):
         return self.ctx.lib.msc_hist_set_entries(self.h, slot)
 
+    def clear(self):
+        """msc_hist_set_clear: a sparse set back to empty, its whole entry arena free (compaction target of a centre store)."""
+        self.ctx.check(self.ctx.lib.msc_hist_set_clear(self.ctx.h, self.h))
+
     def build(self, seqs, first_slot=0, strip=False):
         """Loader<T>::get_point for a batch (clutil/Loader.cpp:112-179)."""
         seqs = [s if isinstance(s, bytes) else s.encode() for s in seqs]

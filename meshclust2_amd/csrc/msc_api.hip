@@ -392,6 +392,23 @@ extern "C" int msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64
 	return MSC_OK;
 }
 
+static void forget_lengths(const msc_hist_set* s, uint64_t first, uint64_t n);
+// a sparse set back to the state msc_hist_set_create_sparse left it in: no slot holds a list, the whole arena is free
+extern "C" int msc_hist_set_clear(msc_ctx* ctx, msc_hist_set* s) {
+	if (!ctx || !s || s->ctx != ctx) return MSC_ERR_INVALID_ARG;
+	if (!s->sparse) return fail(ctx, MSC_ERR_UNSUPPORTED, "msc_hist_set_clear: sparse sets only (a dense slot is overwritten in place)");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemsetAsync(s->scalars, 0, s->scalar_stride * s->capacity, ctx->stream));
+	HIP_TRY(ctx, hipMemsetAsync(s->hdr, 0, s->capacity * sizeof(MscSparseHdr), ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	s->hdr_host.assign(s->capacity, MscSparseHdr{});
+	s->ent_used = 0;
+	s->max_nnz = 0;
+	s->max_count = s->max_sum = 0;
+	forget_lengths(s, 0, s->capacity);
+	return MSC_OK;
+}
+
 extern "C" int msc_hist_set_is_sparse(const msc_hist_set* s) { return s && s->sparse ? 1 : 0; }
 extern "C" uint64_t msc_hist_set_entries(const msc_hist_set* s, uint64_t slot) { return s && s->sparse && slot < s->capacity ? s->hdr_host[slot].nnz : 0; }
 
@@ -1494,8 +1511,6 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint32_t* d_slots = rq.dev_slots ? rq.dev_slots : rq.cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (d_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (d_slots ? 0 : off * cs->scalar_stride);
-		if (need_div && c_sp && spk == SPK_MP)      // granule records a pair does not reach stay zero
-			HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)mc * DVN * 16, ctx->stream));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (sp) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
@@ -2066,7 +2081,6 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
 			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p));
 		if (want_div) {
-			if (spk == SPK_MP) HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, (size_t)n_q * mc * dvn * 16, ctx->stream));
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
 				                                qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->sp_partials.p,
@@ -2617,7 +2631,6 @@ static int batch_div_pass(msc_ctx* ctx, const msc_hist_set* cands, const msc_his
 	const uint32_t dvn = msc_sparse_mp_div_records((uint64_t)c_sp->max_nnz + q_sp->max_nnz);      // records per pair (the 1 x M form's granules)
 	*div_n = dvn;
 	if ((r = ensure(ctx, ctx->div_tables, P * 256 * 16)) || (r = ensure(ctx, ctx->div_partials, P * dvn * 16))) return r;
-	HIP_TRY(ctx, hipMemsetAsync(ctx->div_partials.p, 0, P * dvn * 16, ctx->stream));
 	HIP_TRY(ctx, msc_launch_pair_sparse_mp_pairs(ctx->stream, c_sp->ent, c_sp->cum, c_sp->hdr, cands->scalars, cands->scalar_stride, (const uint32_t*)ctx->slots.p, (uint32_t)P,
 	                                             q_sp->ent, q_sp->cum, q_sp->hdr, cands->L.nbins, 1, (const MscBatchSeg*)ctx->segs.p, (const uint32_t*)ctx->pair_seg.p, partials,
 	                                             order, ctx->num_cus, queries->scalars, queries->scalar_stride, ctx->div_tables.p, ctx->div_partials.p, dvn));

@@ -59,8 +59,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 
 // one workgroup lists the alive positions of [first, first + range) in order: thread t takes a contiguous run
 __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
-                                                                  uint32_t* __restrict__ slots, uint32_t* __restrict__ pos) {
+                                                                  uint32_t* __restrict__ slots, uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
+	if (threadIdx.x == 0) *close_counter = 0;      // k_window_close counts from zero (a memset command of its own was 4 us of every step)
 	const uint32_t per = (range + kWinBlock - 1) / kWinBlock;
 	const uint32_t lo = min(range, threadIdx.x * per), hi = min(range, lo + per);
 	uint32_t c = 0;
@@ -83,9 +84,11 @@ __global__ void __launch_bounds__(kWinBlock) k_window_count(const uint8_t* __res
 	if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 __global__ void __launch_bounds__(kWinBlock) k_window_write(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
-                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ pos) {
+                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ pos,
+                                                            uint32_t* __restrict__ close_counter) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
 	__shared__ uint32_t s_base;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *close_counter = 0;
 	uint32_t before = 0;
 	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kWinBlock) before += counts[b];
 	uint32_t total;
@@ -222,12 +225,12 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	if ((r = flush_kills(ctx, w))) return r;
 	const uint32_t range = (uint32_t)(end - first);
 	if (range <= 128 * kWinBlock) {
-		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos);
+		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
 	} else {
 		const uint32_t blocks = (range + kWinTile - 1) / kWinTile;
 		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
 		k_window_count<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts);
-		k_window_write<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos);
+		k_window_write<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	if (w->h_close_cap < m + 2) {
@@ -239,7 +242,6 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	uint32_t* d_out = nullptr;
 	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_out, w->h_close, 0));
 	uint32_t* counter = w->d_counts + kMaxBlocks;
-	HIP_TRY(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
 	ScoreRequest rq;
 	MscReduceOut ro;
 	rq.model = model; rq.cands = w->set; rq.dev_slots = w->d_slots; rq.m = m; rq.qset = qset; rq.q_slot = q_slot;

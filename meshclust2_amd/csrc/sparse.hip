@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
     MscPartial* __restrict__ partials, const DivTerm* __restrict__ div_tables, double* __restrict__ div_partials, int order,
     const MscBatchSeg* __restrict__ segs = nullptr, const uint32_t* __restrict__ pair_seg = nullptr, uint32_t parts = 1, uint64_t q_scalar_stride = 0,
     uint32_t div_stride = 1, bool dma = false, bool pairs = false) {
-	constexpr uint32_t kMpBuf = kMpT + 8;
+	constexpr uint32_t kMpBuf = (kMpT + 9) & ~1u;      // (a wave's stage starts on a 16-byte boundary: the staging writes two entries at a time)
 	__shared__ uint2 s_buf[4][kMpBuf];
 	// DIV: the 8 x 8 corner of the candidate's table of terms (counts below 8: all but the k-mers of repeats), already relative to the
 	// (1, 1) term, in wave-private LDS -- the walk looks one entry up per event, and a lookup in global memory (a dependent L2 round
@@ -966,20 +966,28 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 	const uint32_t kInf = 0xffffffffu;
 	// `parts` waves share a candidate (a short window would leave most of the chip idle, and a get_close step is as slow as its
 	// slowest wave): part p walks chunks [p n / parts, (p + 1) n / parts) of the merged order and writes record c * parts + p
+	// the records of a pair the walk does not reach (and all of them for a candidate outside the length window) read as zero: written
+	// here by the pair's first part -- a memset of the whole array ahead of every pass was one more launch per step
+	auto zero_records = [&](uint32_t c, uint32_t from) {
+		if constexpr (DIV) {
+			double* rec = div_partials + 2ull * (uint64_t)c * div_stride;
+			for (uint32_t g = from + lane; g < div_stride; g += 64) { rec[2 * g] = 0.0; rec[2 * g + 1] = 0.0; }
+		}
+	};
 	for (uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave; w < m * parts; w += total_waves) {
 		const uint32_t c = w / parts, part = w - c * parts;
 		const uint32_t slot = cand_slots ? cand_slots[c] : c;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (uint64_t)slot * scalar_stride);
 		if constexpr (PAIRS) {
 			const MscBatchSeg sg = segs[pair_seg[c]];
-			if (use_window && (cs->length < sg.min_len || cs->length > sg.max_len)) continue;
+			if (use_window && (cs->length < sg.min_len || cs->length > sg.max_len)) { if (part == 0) zero_records(c, 0); continue; }
 			qh = q_hdr_p[sg.q_slot];
 			Q = q_ent + qh.off;
 			CQ = q_cum + qh.off;
 			nq_all = qh.nnz;
 			if constexpr (DIV) qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars + (uint64_t)sg.q_slot * q_scalar_stride)->mag;
 		} else {
-			if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+			if (use_window && (cs->length < min_len || cs->length > max_len)) { if (part == 0) zero_records(c, 0); continue; }
 		}
 		const MscSparseHdr ch = c_hdr[slot];
 		const uint2* P = c_ent + ch.off;
@@ -1015,6 +1023,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 			// granules (a window of mixed lengths: the long pairs are shared out, the short ones stay whole) -- the other parts of its
 			// record group stay empty
 			const uint32_t n_gran = (n_chunks + kMpDivGran - 1) / kMpDivGran;
+			if (part == 0) zero_records(c, n_gran);
 			uint32_t parts_c = n_gran / kMpDivMinGran;
 			parts_c = parts_c < 1 ? 1 : parts_c > parts ? parts : parts_c;
 			if (part >= parts_c) {
@@ -1392,8 +1401,18 @@ bool msc_sparse_mp_dma() {
 uint32_t msc_sparse_mp_max_entries() { return 0x7fffffffu; }      // both lists together (32-bit merged positions)
 
 // 512 merged entries per chunk keep 8 waves per SIMD resident, which is what this merge wants (r01: k=9/5 kb lists 43 M pairs/s at 512,
-// 32 M at 1024, 20 M at 2048)
-constexpr uint32_t kMpChunk = 512;
+// 32 M at 1024, 20 M at 2048). A chunk is walked in 64 shares of an ODD number of entries (see the kernel): 9 for 512, which leaves 7
+// lanes without a share. 575 gives every lane its 9 (575, not 576: a chunk holds one entry more when a tie straddles its end, and 577
+// would make the share 11). r03, same box: cfg5's accumulate stage -5 % at 20 000 sequences and -7 % at full size (get_close 46.1 ->
+// 42.9 s); but a window of 8 000 EQUAL lists (one and a third fills of the grid, k = 9, 11 or 13 alike) takes 0.87 ms instead of
+// 0.67 -- and so does the 512 build as soon as the records are dealt to the waves in any other order, so it is the placement of
+// that window's second helping, not the chunk, that the 0.67 depends on (profiles/r03_notes.md). Until that is understood the wide
+// chunk is for the sets it was measured to help, k <= 11; a set's chunk never changes, so a pair's FP64 sums do not either.
+constexpr uint32_t kMpChunk = 512, kMpChunkWide = 575;
+static bool mp_wide(uint64_t nbins) {
+	static const int force = [] { const char* e = getenv("MSC_SPARSE_MP_CHUNK"); return e ? atoi(e) : 0; }();
+	return force == 575 ? true : force == 512 ? false : nbins <= (1ull << 22);
+}
 
 // lists of any length up to msc_sparse_mp_max_entries() together; same arithmetic range as the LDS kernel (caller checks).
 // parts (1 .. 16): waves per candidate, each writing its own record -- partials[c * parts + p]. The divergence form writes its two
@@ -1418,15 +1437,22 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 		return hipGetLastError();
 	}
 	const int wpe = msc_sparse_div_waves();
-	const uint32_t per_cu = div_tables ? (uint32_t)wpe : std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunk + 8) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
+	const bool wide = mp_wide(nbins);
+	const uint32_t per_cu = div_tables ? (uint32_t)wpe : std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunkWide + 9) * 8 + 512));      // LDS-limited residency; every wave walks several candidates
 	const uint64_t waves = (uint64_t)m * parts;
 	uint32_t blocks = (uint32_t)num_cus * per_cu;
 	if (blocks > (waves + 3) / 4) blocks = (uint32_t)((waves + 3) / 4);
 	if (div_tables) {
-#define MSC_MP_DIV(W) k_pair_sparse_mp<true, kMpChunk, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
+#define MSC_MP_DIV(W) if (wide) MSC_MP_DIV_T(kMpChunkWide, W); else MSC_MP_DIV_T(kMpChunk, W)
+#define MSC_MP_DIV_T(T, W) k_pair_sparse_mp<true, T, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
 		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
-		if (wpe == 4) MSC_MP_DIV(4); else if (wpe == 7) MSC_MP_DIV(7); else MSC_MP_DIV(6);
+		if (wpe == 4) { MSC_MP_DIV(4); } else if (wpe == 7) { MSC_MP_DIV(7); } else { MSC_MP_DIV(6); }
 #undef MSC_MP_DIV
+#undef MSC_MP_DIV_T
+	} else if (wide) {
+		k_pair_sparse_mp<false, kMpChunkWide><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
+		                                                                          q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
+		                                                                          nullptr, nullptr, parts, 0, 1, msc_sparse_mp_dma(), msc_sparse_mp_pairs());
 	} else {
 		k_pair_sparse_mp<false, kMpChunk><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent,
 		                                                                      q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, nullptr, nullptr, order,
@@ -1465,6 +1491,7 @@ uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div
 }
 // divergence records per pair of the merge-path kernel for lists of up to `entries` entries together
 uint32_t msc_sparse_mp_div_records(uint64_t entries) {
+	// (counted in the shorter of the two chunk sizes: enough for either; the kernel zeroes the records a pair does not reach)
 	const uint64_t chunks = (entries + kMpChunk - 1) / kMpChunk;
 	return (uint32_t)std::max<uint64_t>(1, (chunks + kMpDivGran - 1) / kMpDivGran);
 }
@@ -1495,8 +1522,8 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
                                            MscPartial* partials, int order, int num_cus, const uint8_t* q_scalars, uint64_t q_scalar_stride, void* div_tables,
                                            void* div_partials, uint32_t div_stride) {
 	if (m == 0) return hipSuccess;
-	constexpr uint32_t T = 512;
-	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (T + 8) * 8 + 512));
+	const bool wide = mp_wide(nbins);
+	const uint32_t per_cu = std::min<uint32_t>(8, (160 * 1024) / (4 * (kMpChunkWide + 9) * 8 + 512));
 	uint32_t blocks = (uint32_t)num_cus * per_cu;
 	if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
 	if (div_tables) {      // the divergence sums of every pair as well: the same walk, hence the same bits, as the 1 x M divergence form
@@ -1504,13 +1531,20 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 		const int wpe = msc_sparse_div_waves();
 		blocks = (uint32_t)num_cus * (uint32_t)wpe;
 		if (blocks > (m + 3) / 4) blocks = (m + 3) / 4;
-#define MSC_MP_DIVP(W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
+#define MSC_MP_DIVP(W) if (wide) MSC_MP_DIVP_T(kMpChunkWide, W); else MSC_MP_DIVP_T(kMpChunk, W)
+#define MSC_MP_DIVP_T(T, W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
 		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
-		if (wpe == 4) MSC_MP_DIVP(4); else if (wpe == 7) MSC_MP_DIVP(7); else MSC_MP_DIVP(6);
+		if (wpe == 4) { MSC_MP_DIVP(4); } else if (wpe == 7) { MSC_MP_DIVP(7); } else { MSC_MP_DIVP(6); }
 #undef MSC_MP_DIVP
+#undef MSC_MP_DIVP_T
 		return hipGetLastError();
 	}
-	k_pair_sparse_mp<false, T, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
+	if (wide) {
+		k_pair_sparse_mp<false, kMpChunkWide, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
+		                                                                               q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg, 1, 0, 1, msc_sparse_mp_dma(), msc_sparse_mp_pairs());
+		return hipGetLastError();
+	}
+	k_pair_sparse_mp<false, kMpChunk, true><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, q_cum,
 	                                                                    q_hdr, nullptr, nbins, use_window, 0, ~0ull, partials, nullptr, nullptr, order, segs, pair_seg, 1, 0, 1, msc_sparse_mp_dma(), msc_sparse_mp_pairs());
 	return hipGetLastError();
 }

@@ -58,6 +58,7 @@ public:
 	msc_hist_set* get() const { return h_; }
 	Context& ctx() const { return ctx_; }
 	uint64_t capacity() const { return msc_hist_set_capacity(h_); }
+	void clear() { ctx_.check(msc_hist_set_clear(ctx_.get(), h_)); }      // sparse sets: every slot empty, the whole arena free
 
 	// Loader<T>::get_point for a batch. strip = the std::string overload (drops non-ACGT first).
 	void get_points(uint64_t first_slot, const std::vector<std::string>& seqs, bool strip = false) {

@@ -338,6 +338,22 @@ def test_copy_batch_is_an_exact_copy(ctx, layout):
         tiny = api.HistogramSet(ctx, k, dtype, n, sparse_entries=64)
         with pytest.raises(api.MscError, match="arena"):
             tiny.copy_batch(np.arange(n, dtype=np.uint32), centres, np.arange(n, dtype=np.uint32))
+        # msc_hist_set_clear: the arena of a filled store is free again, and what is copied in afterwards is what a fresh store holds
+        exact = sum(centres.entries(i) for i in range(n))
+        snug = api.HistogramSet(ctx, k, dtype, n + 3, sparse_entries=exact + exact // 2)
+        snug.copy_batch(order, centres, np.arange(n, dtype=np.uint32))
+        with pytest.raises(api.MscError, match="arena"):          # (append-only: a second round does not fit ...
+            snug.copy_batch(order, centres, np.arange(n, dtype=np.uint32))
+        snug.clear()                                              # ... until the store is emptied)
+        assert all(snug.entries(i) == 0 for i in range(n + 3))
+        snug.copy_batch(order, centres, np.arange(n, dtype=np.uint32))
+        for i in range(n):
+            assert snug.info(int(order[i])) == many.info(int(order[i])) and np.array_equal(snug.download(int(order[i])), many.download(int(order[i])))
+        r3 = api.pair_features_raw(ctx, snug, order, pts, 3, mask)
+        assert np.array_equal(np.asarray(r1), np.asarray(r3))
+    else:
+        with pytest.raises(api.MscError, match="sparse sets only"):
+            many.clear()
 
 
 def test_batch_slot_entry_points_reject_bad_arguments(ctx):
