@@ -456,7 +456,11 @@ int main(int argc, char** argv) {
 		seqs.clear();
 		// (sparse centre store: room for every sequence as its own centre TWICE -- a round of the update stage appends the new list of
 		// every moved centre before the old ones are compacted away)
-		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, sparse ? 2 * total_bases + 64 * longest + (1 << 20) : 0);
+		uint64_t centre_arena = sparse ? 2 * total_bases + 64 * longest + (1 << 20) : 0;
+		if (const char* e = std::getenv("MSC_CLUSTER_CENTRE_ARENA")) {      // (tests: a snug arena, so that a small run compacts its store)
+			if (sparse && std::atoll(e) > 0) centre_arena = (uint64_t)std::atoll(e);
+		}
+		GpuBackend gpu(ctx, points, trn, k, dtype, similarity, centre_arena);
 		msc::MeanShift ms(gpu, std::cout);
 		ms.batch_update = !serial_update;
 		ms.use_ranges = !no_ranges;

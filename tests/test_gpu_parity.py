@@ -1421,6 +1421,30 @@ def test_cluster_driver_k9_uint8(tmp_path, extra):
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
 
 
+def test_cluster_driver_compacts_its_sparse_centre_store(tmp_path):
+    """The sparse centre store is append-only; when its arena runs out msc_cluster copies the live centres into a second store and
+    clears the first for the next time (msc_hist_copy_batch + msc_hist_set_clear). With an arena that holds the centres little more
+    than twice over, a small run compacts several times and still writes the golden .clstr bytes."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seqs, hdrs = synth.families(61, 320, 1000, family=16)
+    fa = str(tmp_path / "k9.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    golden = os.path.join(root, "tests", "golden")
+    env = dict(os.environ, MSC_CLUSTER_CENTRE_ARENA="60000", MSC_CLUSTER_PROFILE="1")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9",
+                        "--output", out, "--sparse"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
+    log = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, log[-2000:]
+    m = re.search(r"centre store: rebuilt (\d+) times", log)
+    assert m and int(m.group(1)) >= 2, log[-1500:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "k9_u8.clstr"), "rb").read()
+    assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
+
+
 def test_degenerate_inputs(ctx, oracle):
     """Empty candidate lists, a single candidate, no queries, sequences shorter than k, sequences of N only: the operators return
     what the reference's loops would (nothing scored, is_min true, best (-1, -1) / merge 0) instead of faulting."""
