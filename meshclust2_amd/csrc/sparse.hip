@@ -260,6 +260,12 @@ __device__ __forceinline__ DivTerm div_term_sp(uint32_t cand_count, uint32_t q_c
 	return t;
 }
 
+// the same as a call: the merge-path kernel evaluates a term directly only off its hot path (once per pair, and for the counts its
+// table does not hold), and three FP64 logs inlined there cost the walk its registers
+__device__ __noinline__ DivTerm div_term_call(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {
+	return div_term_sp(cand_count, q_count, cand_mag, q_mag, order);
+}
+
 // per-candidate 16 x 16 table of the exact per-bin divergence terms (same idea as k_div_tables of the dense path)
 // (segs != nullptr: the pair-list form -- the query of pair c is slot segs[pair_seg[c]].q_slot behind q_scalars, stride q_stride)
 __global__ void __launch_bounds__(256) k_sparse_div_tables(const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
@@ -1000,14 +1006,14 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 		double jd = 0.0, js = 0.0, cm = 0.0;
 		DivTerm t11{0.0, 0.0};
 		if constexpr (DIV) {
-			cm = (double)cs->mag; t11 = div_term_sp(1, 1, cm, qm, order);
+			cm = (double)cs->mag; t11 = div_term_call(1, 1, cm, qm, order);
 			__builtin_amdgcn_wave_barrier();          // the previous candidate's walk is over
 			static_assert(kMpTab * kMpTab == 64, "one table entry per lane");
 			{
 				// (computed here, one term per lane: a table kernel of its own ahead of every pass was 10 us of a 500 us step)
 				const uint32_t a = lane / kMpTab, b = lane % kMpTab;
 				DivTerm g{0.0, 0.0};
-				if (a && b) g = div_term_sp(a, b, cm, qm, order);
+				if (a && b) g = div_term_call(a, b, cm, qm, order);
 				s_tab[wave][lane] = DivTerm{g.jd - t11.jd, g.js - t11.js};
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1117,7 +1123,7 @@ __global__ void __launch_bounds__(256, WPE) k_pair_sparse_mp(
 					if constexpr (DIV) {
 						DivTerm tt;
 						if ((pv | qv) < kMpTab) tt = s_tab[wave][pv * kMpTab + qv];
-						else { tt = div_term_sp(pv, qv, cm, qm, order); tt.jd -= t11.jd; tt.js -= t11.js; }
+						else { tt = div_term_call(pv, qv, cm, qm, order); tt.jd -= t11.jd; tt.js -= t11.js; }
 						jd += tt.jd;
 						js += tt.js;
 					}
