@@ -6,6 +6,8 @@
 //   window   msc_window over the rank's own points in position order
 // Every buffer a collective touches is device memory of this GPU (msc_device_malloc), so RCCL moves it without a host bounce.
 #pragma once
+#include <cstdlib>
+#include <iostream>
 #include <memory>
 
 #include "meshclust2_host.hpp"
@@ -30,9 +32,13 @@ public:
 		// sparse centre store: a slot is a header and a scalar record, so room for every point as its own centre costs little; its arena
 		// takes every sequence's list twice (a round appends the new list of every moved centre before the old ones are compacted away)
 		centre_arena_ = sparse ? 2 * total_global + 64 * longest + (1 << 20) : 0;
+		if (const char* e = std::getenv("MSC_CLUSTER_CENTRE_ARENA")) {      // (tests: a snug arena, so that a small run compacts its store)
+			if (sparse && std::atoll(e) > 0) centre_arena_ = (uint64_t)std::atoll(e);
+		}
 		centres_.reset(new PointSet(ctx, k, dtype, sparse ? std::max<uint64_t>(256, n_total) : 256, centre_arena_));
 	}
 	~GpuShardEngine() override {
+		if (std::getenv("MSC_CLUSTER_PROFILE")) std::cout << "centre store: rebuilt " << n_rebuilds_ << " times" << std::endl;
 		msc_window_destroy(win_);
 		for (void* p : bufs_) if (p) (void)msc_device_free(ctx_.get(), p);
 	}
@@ -126,12 +132,17 @@ public:
 
 private:
 	// relocate every live centre into a fresh store: grows the slot count; for the sparse layout it compacts the append-only arena
+	// (a compaction goes back and forth between two standing stores, as in msc_cluster.cpp: no arena is allocated or freed for it)
 	void rebuild_centres(uint64_t capacity) {
-		std::unique_ptr<PointSet> fresh(new PointSet(ctx_, k_, dtype_, capacity, centre_arena_));
+		std::unique_ptr<PointSet> fresh;
+		if (centre_arena_ && spare_ && spare_->capacity() == capacity) { fresh.swap(spare_); fresh->clear(); }
+		else { spare_.reset(); fresh.reset(new PointSet(ctx_, k_, dtype_, capacity, centre_arena_)); }
 		std::vector<uint32_t> all((size_t)n_centres_);
 		for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
 		if (!all.empty()) fresh->copy_batch(all, *centres_, all);
 		centres_.swap(fresh);
+		if (centre_arena_ && centres_->capacity() == fresh->capacity()) spare_.swap(fresh);
+		n_rebuilds_++;
 	}
 	template <class F> void with_arena_retry(F&& f) {
 		try { f(); }
@@ -149,7 +160,8 @@ private:
 	double cutoff_;
 	uint64_t n_, longest_;
 	std::unique_ptr<PointSet> points_, qset_, centres_, stage_;
-	uint64_t n_centres_ = 0, centre_arena_ = 0, stage_entries_ = 0;
+	uint64_t n_centres_ = 0, centre_arena_ = 0, stage_entries_ = 0, n_rebuilds_ = 0;
+	std::unique_ptr<PointSet> spare_;
 	msc_window* win_ = nullptr;
 	void* bufs_[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t caps_[4] = {0, 0, 0, 0};

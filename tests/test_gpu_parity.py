@@ -1421,7 +1421,8 @@ def test_cluster_driver_k9_uint8(tmp_path, extra):
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
 
 
-def test_cluster_driver_compacts_its_sparse_centre_store(tmp_path):
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_cluster_driver_compacts_its_sparse_centre_store(tmp_path, monkeypatch, ranks):
     """The sparse centre store is append-only; when its arena runs out msc_cluster copies the live centres into a second store and
     clears the first for the next time (msc_hist_copy_batch + msc_hist_set_clear). With an arena that holds the centres little more
     than twice over, a small run compacts several times and still writes the golden .clstr bytes."""
@@ -1434,11 +1435,17 @@ def test_cluster_driver_compacts_its_sparse_centre_store(tmp_path):
     synth.write_fasta(fa, seqs, hdrs)
     out = str(tmp_path / "out.clstr")
     golden = os.path.join(root, "tests", "golden")
-    env = dict(os.environ, MSC_CLUSTER_CENTRE_ARENA="60000", MSC_CLUSTER_PROFILE="1")
-    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9",
-                        "--output", out, "--sparse"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
-    log = r.stdout.decode(errors="replace")
-    assert r.returncode == 0, log[-2000:]
+    args = [fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9", "--output", out, "--sparse"]
+    if ranks == 1:
+        env = dict(os.environ, MSC_CLUSTER_CENTRE_ARENA="60000", MSC_CLUSTER_PROFILE="1")
+        r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
+        log = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, log[-2000:]
+    else:          # every rank keeps the whole centre store (msc::GpuShardEngine): the same two standing stores there
+        monkeypatch.setenv("MSC_CLUSTER_CENTRE_ARENA", "100000")      # (the engine moves a round's centres in one batch: room for the live lists + one round)
+        monkeypatch.setenv("MSC_CLUSTER_PROFILE", "1")
+        rcs, log, logs = _cluster_ranks(args, ranks, tmp_path, block=40)
+        assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
     m = re.search(r"centre store: rebuilt (\d+) times", log)
     assert m and int(m.group(1)) >= 2, log[-1500:]
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "k9_u8.clstr"), "rb").read()
