@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
 	std::vector<std::string> files, qfiles;
 	std::string weights, output = "output";
 	size_t chunk = 10000, qblock = 16;
-	bool format = true, sparse = false;
+	bool format = true, sparse = false, report_kernels = false;
 	int device = 0;
 	for (int i = 1; i < argc; i++) {
 		std::string a = argv[i];
@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
 		else if (a == "--query-block") qblock = std::max<size_t>(1, (size_t)std::atol(need("--query-block").c_str()));
 		else if (a == "--no-format" || a == "--noformat") format = false;
 		else if (a == "--threads" || a == "-t") need("--threads");
+		else if (a == "--kernels") report_kernels = true;   // after the run: the streaming kernels the library picked for the scoring passes, on stderr
 		else if (a == "--sparse") sparse = true;        // sparse histogram layout (required for k >= 13; also the faster one for --feat slow models)
 		else if (a == "--device") device = std::atoi(need("--device").c_str());
 		else files.push_back(a);
@@ -139,6 +140,13 @@ int main(int argc, char** argv) {
 		const std::string delim = format ? "\t" : "!";
 		std::ofstream out((output + "0").c_str());
 		uint64_t num_pred_pos = 0;
+		std::vector<std::string> kernels;
+		auto note_kernel = [&] {
+			char name[160];
+			int q_per_read = 0;
+			if (!report_kernels || msc_last_kernel_info(ctx.get(), name, sizeof name, &q_per_read) != MSC_OK) return;
+			if (std::find(kernels.begin(), kernels.end(), name) == kernels.end()) kernels.push_back(name);
+		};
 		for (size_t qo = 0; qo < queries.size(); qo += chunk) {
 			std::vector<Pt> qp;
 			if (sparse && qo) qset_p = make_set(queries, qo, std::min(chunk, queries.size() - qo));
@@ -191,6 +199,7 @@ int main(int argc, char** argv) {
 					std::vector<double> sim;
 					if (members.size() == 1) pred.search(dset, window, qset, q_slots[0], close, sim);      // pred->close / similarity, one query
 					else pred.search_block(dset, window, qset, q_slots, close, sim);
+					note_kernel();
 					for (size_t j = 0; j < members.size(); j++) {
 						const size_t qi = members[j];
 						for (size_t i = win_start[qi]; i < win_end[qi]; i++) {
@@ -213,6 +222,7 @@ int main(int argc, char** argv) {
 			}
 		}
 		std::cout << "# of predicted positive: " << num_pred_pos << std::endl;
+		for (const auto& kn : kernels) std::fprintf(stderr, "kernel: %s\n", kn.c_str());
 	} catch (const msc::Error& e) {
 		std::fprintf(stderr, "msc error %d: %s\n", e.code, e.what());
 		return 3;

@@ -463,6 +463,49 @@ def make_regr_weights_and_fastcar():
     print("wrote weights_k5_u16_regr.txt and fastcar_k5_u16_regr.out")
 
 
+def fastcar_k9_sets():
+    """cfg2's shape for the search: 1 kb relatives at k = 9; every ninth database sequence and one query carry a run (a 300-base
+    homopolymer, 150 x `AC`, or a 12-mer x 10) -- counts of 11 .. 290 among counts of 1 .. 3, as real FASTA has them"""
+    db, h = synth.families(43, 220, 1000, family=10, length_jitter=120)
+    q, hq = synth.families(43, 30, 1000, family=10, length_jitter=120)
+    runs = [b"A" * 300, b"AC" * 150, b"ACGTTGCAAGTC" * 10]
+    db = [s[:200 + i] + runs[(i // 9) % 3] + s[200 + i:] if i % 9 == 4 else s for i, s in enumerate(db)]
+    q = [x[:len(x) - 5] for x in q]
+    q[4] = q[4][:333] + runs[0] + q[4][333:]
+    return db, h, q, [x.replace(">seq", ">qry") for x in hq]
+
+
+REG_BLOCK_K9_FC = """
+n_combos: 2
+0.03
+0 8192 0.9
+3 262144 0.06
+
+n_singles: 2
+8192 0 1
+262144 0 90000000
+"""
+
+
+def make_fastcar_k9_output():
+    """reference fastcar at k = 9 / uint32_t (the histogram shape of BASELINE cfg2) on a database with repeat-bearing sequences: the
+    classification block the reference trained (weights_k9_u32.txt) + a regression block over intersection and emd whose values spread
+    over (0, 1), so the third column of the output is not all 100"""
+    cls = weights_with_mode(open(os.path.join(HERE, "weights_k9_u32.txt")).read(), 1)
+    text = cls.replace("mode: 1", "mode: 3").rstrip("\n") + "\n" + REG_BLOCK_K9_FC
+    open(os.path.join(HERE, "weights_k9_u32_fc.txt"), "w").write(text)
+    tmp = tempfile.mkdtemp()
+    db, h, q, hq = fastcar_k9_sets()
+    synth.write_fasta(os.path.join(tmp, "db.fa"), db, h)
+    synth.write_fasta(os.path.join(tmp, "q.fa"), q, hq)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fastcar"), "db.fa", "--query", "q.fa", "--recover", os.path.join(HERE, "weights_k9_u32_fc.txt"),
+                    "--output", "fc_out", "--threads", "1"], cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT, check=True)
+    shutil.copy(os.path.join(tmp, "fc_out0"), os.path.join(HERE, "fastcar_k9_u32.out"))
+    shutil.rmtree(tmp)
+    print("wrote weights_k9_u32_fc.txt and fastcar_k9_u32.out")
+
+
 FAST_FLAGS = sum(1 << b for b in (2, 3, 5, 9, 13, 18, 21, 27, 28))
 SLOW_FLAGS = FAST_FLAGS | (1 << 7) | (1 << 29)
 
@@ -494,6 +537,7 @@ if __name__ == "__main__":
     make_fastcar_output()
     make_fastcar_mode_outputs()
     make_regr_weights_and_fastcar()
+    make_fastcar_k9_output()
     make_cfg5_clstr()
     make_cfg5_u16_clstr()
     make_k8_clstr()

@@ -1026,13 +1026,28 @@ def test_full_size_cfg2_properties(oracle):
     qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
     fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
     multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
-    assert ctx.last_kernel_info()[0].startswith(("k_dot_gemm_i8", "k_pair_digest_multi"))
+    assert ctx.last_kernel_info()[0].startswith(("k_pair_gemm_x8", "k_dot_gemm_i8")), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
         assert ctx.last_kernel_info()[0] == "k_pair_tiles"
         assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
         assert int(multi["close"][i].sum()) == int((np.round(single["csum"]) > 0).sum())
+    # first-hand at full size: the pass's weighted sums, close flags and integer statistics for the kept candidates x all 16 queries
+    # next to the CPU oracle (predict/Feature.cpp:156-171, cluster/Trainer.cpp:49-52) -- 15 x 16 pairs out of the 1.6e6 scored
+    pred = oracle.predictor(weights_text("weights_k9_u32.txt"))
+    q_h = [oracle.hist(synth.to_ascii(synth.member(seed, int(q) // fam, int(q) % fam, synth.template(seed, int(q) // fam, 1000))), k, dtype) for q in qs]
+    for slot, code in keep.items():
+        c_h = oracle.hist(synth.to_ascii(code), k, dtype)
+        for i in range(16):
+            _, _, w = oracle.score(pred.cls, c_h, q_h[i])
+            assert multi["sum"][i][slot] == pytest.approx(w, rel=1e-8, abs=1e-10), (slot, i)
+            assert multi["close"][i][slot] == (1 if round(1.0 / (1.0 + np.exp(-w))) > 0 else 0), (slot, i)
+            assert multi["raw"][i][slot][0] == oracle.raw_feature(1 << 2, c_h, q_h[i]), (slot, i)          # manhattan, bitwise
+            assert multi["raw"][i][slot][1] == oracle.raw_feature(1 << 13, c_h, q_h[i]), (slot, i)         # intersection, bitwise
+        oracle.lib().orc_hist_free(c_h)
+    for h_ in q_h:
+        oracle.lib().orc_hist_free(h_)
     # symmetry of the symmetric statistics: stat(query a, candidate b) == stat(query b, candidate a). (The model score itself is
     # NOT symmetric for uint32_t bins: the reference's simratio wraps `p - q` before widening, SURVEY Q3, reproduced here.)
     for i in range(16):
