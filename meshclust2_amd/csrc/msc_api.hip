@@ -134,11 +134,14 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->shard_gather) msc_hist_set_destroy(ctx->shard_gather);
 	release(ctx->shard_payload);
 	release(ctx->shard_hdrs);
-	release(ctx->gemm_q8);
-	release(ctx->gemm_out);
+	release(ctx->x8_fimg);
+	release(ctx->x8_qT);
+	release(ctx->x8_hot);
+	release(ctx->x8_hot_idx);
+	release(ctx->x8_min);
+	release(ctx->x8_diff);
 	release(ctx->emd_out);
 	release(ctx->close_counts);
-	release(ctx->gemm_min);
 	release(ctx->rk_bad);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
@@ -419,7 +422,10 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
-	if (s->count8) (void)hipFree(s->count8);
+	if (s->x8) (void)hipFree(s->x8);
+	if (s->mb) (void)hipFree(s->mb);
+	if (s->mb_n) (void)hipFree(s->mb_n);
+	if (s->mb_big) (void)hipFree(s->mb_big);
 	if (s->ranks) (void)hipFree(s->ranks);
 	if (s->rk_n) (void)hipFree(s->rk_n);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
@@ -435,7 +441,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->count8 ? s->L.padded_bins + 64 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->x8 ? s->L.padded_bins + 32 + (uint64_t)s->mb_pitch * 8 + 8 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
@@ -449,9 +455,9 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 		if (s->sm_lo >= s->sm_hi) { s->sm_lo = first; s->sm_hi = first + n; }
 		else { s->sm_lo = std::min(s->sm_lo, first); s->sm_hi = std::max(s->sm_hi, first + n); }
 	}
-	if (s->count8) {
-		if (s->c8_lo >= s->c8_hi) { s->c8_lo = first; s->c8_hi = first + n; }
-		else { s->c8_lo = std::min(s->c8_lo, first); s->c8_hi = std::max(s->c8_hi, first + n); }
+	if (s->x8) {
+		if (s->x8_lo >= s->x8_hi) { s->x8_lo = first; s->x8_hi = first + n; }
+		else { s->x8_lo = std::min(s->x8_lo, first); s->x8_hi = std::max(s->x8_hi, first + n); }
 	}
 	if (s->ranks) {
 		if (s->rk_lo >= s->rk_hi) { s->rk_lo = first; s->rk_hi = first + n; }
@@ -1681,40 +1687,68 @@ static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
-// The count8 mirror of a dense set (msc_dot_gemm.hip): one byte per bin, slots blocked by 16: the operands of the int8 GEMM that takes
-// the products of the Q x M pass. MSC_OK with set->count8 == nullptr when it cannot be had: the digest kernel then keeps the products.
-static int ensure_count8(msc_ctx* ctx, const msc_hist_set* set) {
-	if (set->sparse || set->count8_unavailable || set->dtype == 64) return MSC_OK;
-	if (!set->count8) {
-		void* p = nullptr;
-		if (hipMalloc(&p, msc_count8_bytes(set->L, set->capacity)) != hipSuccess) {
-			(void)hipGetLastError();
-			set->count8_unavailable = true;
-			return MSC_OK;
-		}
-		set->count8 = (uint8_t*)p;
-		set->c8_lo = 0;
-		set->c8_hi = set->capacity;
+// The x8 mirror of a dense set and its lists of large bins (msc_pair_gemm.hip): the operands of the int8 product that takes the Q x M
+// pass. MSC_OK with set->x8 == nullptr when it cannot be had (no memory): the older routes then run.
+static int ensure_x8(msc_ctx* ctx, const msc_hist_set* set) {
+	if (set->sparse || set->x8_unavailable || set->dtype == 64) return MSC_OK;
+	auto give_up = [&] {
+		(void)hipGetLastError();
+		if (set->x8) (void)hipFree(set->x8);
+		if (set->mb) (void)hipFree(set->mb);
+		if (set->mb_n) (void)hipFree(set->mb_n);
+		if (set->mb_big) (void)hipFree(set->mb_big);
+		set->x8 = nullptr; set->mb = nullptr; set->mb_n = set->mb_big = nullptr;
+		set->x8_unavailable = true;
+		return MSC_OK;
+	};
+	if (!set->x8) {
+		void *p = nullptr, *pm = nullptr, *pn = nullptr, *pb = nullptr;
+		set->mb_pitch = 16;
+		if (hipMalloc(&p, msc_x8_bytes(set->L, set->capacity)) != hipSuccess) return give_up();
+		set->x8 = (uint8_t*)p;
+		if (hipMalloc(&pm, (size_t)set->capacity * set->mb_pitch * 8) != hipSuccess) return give_up();
+		set->mb = pm;
+		if (hipMalloc(&pn, (size_t)set->capacity * 4) != hipSuccess) return give_up();
+		set->mb_n = (uint32_t*)pn;
+		if (hipMalloc(&pb, (size_t)set->capacity * 4) != hipSuccess) return give_up();
+		set->mb_big = (uint32_t*)pb;
+		HIP_TRY(ctx, hipMemsetAsync(set->mb_n, 0, (size_t)set->capacity * 4, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(set->mb_big, 0, (size_t)set->capacity * 4, ctx->stream));
+		set->mb_n_host.assign(set->capacity, 0);
+		set->x8_lo = 0;
+		set->x8_hi = set->capacity;
 	}
-	if (set->c8_lo < set->c8_hi) {
-		// runs of slots that hold a histogram; the build says whether it met a zero count (sticky: the level products of
-		// msc_dot_gemm.hip take count - 1 of every byte)
+	while (set->x8_lo < set->x8_hi) {
+		// runs of slots that hold a histogram; the build reports a zero count (sticky: the pass's identities take count - 1 of every
+		// bin) and the longest list of large bins it met: past the pitch, the lists are laid out again and every written slot rebuilt
 		int r;
-		if ((r = ensure(ctx, ctx->rk_bad, sizeof(int32_t)))) return r;
-		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, sizeof(int32_t), ctx->stream));
-		const uint64_t hi = std::min<uint64_t>(set->c8_hi, set->written.size());
-		for (uint64_t i = set->c8_lo; i < hi;) {
+		if ((r = ensure(ctx, ctx->rk_bad, 2 * sizeof(int32_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, 2 * sizeof(int32_t), ctx->stream));
+		const uint64_t lo = set->x8_lo, hi = std::min<uint64_t>(set->x8_hi, set->written.size());
+		for (uint64_t i = lo; i < hi;) {
 			if (!set->written[i]) { i++; continue; }
 			uint64_t j = i;
 			while (j < hi && set->written[j]) j++;
-			HIP_TRY(ctx, msc_launch_count8_build(ctx->stream, set->L, set->dtype, set->bins, set->count8, i, j - i, (int32_t*)ctx->rk_bad.p));
+			HIP_TRY(ctx, msc_launch_x8_build(ctx->stream, set->L, set->dtype, set->bins, set->x8, i, j - i, set->mb, set->mb_n, set->mb_big, set->mb_pitch, (int32_t*)ctx->rk_bad.p));
 			i = j;
 		}
-		int32_t bad = 0;
-		HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->rk_bad.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+		int32_t flags[2] = {0, 0};
+		HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->rk_bad.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+		if (hi > lo) HIP_TRY(ctx, hipMemcpyAsync(set->mb_n_host.data() + lo, set->mb_n + lo, (hi - lo) * 4, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (bad) set->c8_has_zero = true;
-		set->c8_lo = set->c8_hi = 0;
+		if (flags[0]) set->x8_has_zero = true;
+		set->x8_lo = set->x8_hi = 0;
+		if ((uint32_t)flags[1] > set->mb_pitch) {
+			const uint32_t pitch = ((uint32_t)flags[1] + 15) / 16 * 16;
+			void* pm = nullptr;
+			(void)hipFree(set->mb);
+			set->mb = nullptr;
+			if (hipMalloc(&pm, (size_t)set->capacity * pitch * 8) != hipSuccess) return give_up();
+			set->mb = pm;
+			set->mb_pitch = pitch;
+			set->x8_lo = 0;
+			set->x8_hi = set->capacity;
+		}
 	}
 	return MSC_OK;
 }
@@ -1769,6 +1803,20 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
+// Whether the pass on the matrix cores (msc_pair_gemm.hip) can take a Q x M call over these sets -- host-side bounds only: dense 8/16/32-bit
+// sets of the narrow range whose histograms are whole 4 KiB tiles, P1 / P2 within int32 (at most 127 x the k-mers of a sequence) and, when
+// the earth mover's distance is wanted, lists short enough for the ranks mirror (msc_emd_ranks.hip).
+static bool x8_route_fits(const msc_hist_set* cands, const msc_hist_set* qset, bool need_emd) {
+	static const bool off = getenv("MSC_MULTI_NO_GEMM") != nullptr;
+	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
+	const MscLayout& L = cands->L;
+	if (off || cands->sparse || qset->sparse || cands->dtype == 64 || L.nbins != L.padded_bins || !msc_digest_supported(L) || needs_wide(cands, qset)) return false;
+	const uint64_t ms_ = std::max(cands->max_sum, qset->max_sum);
+	if (ms_ < L.nbins || (ms_ - L.nbins) * 127 >= (1ull << 31)) return false;
+	if (need_emd && (no_ranks || L.nbins > (1ull << 20) || (ms_ - L.nbins) * 4 > L.nbins)) return false;
+	return true;
+}
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
@@ -1782,37 +1830,48 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (r) return r;
 	const MscLayout& L = cands->L;
 	const int nf = __builtin_popcountll(feat_mask);
+	uint64_t want = feat_mask;
+	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
+	const bool need_emd = (want & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
+	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 128 queries per read of a candidate byte; the older routes 64
+	bool x8_fit = !ctx->no_x8_now && n_q >= 2 && x8_route_fits(cands, qset, need_emd);
+	if (x8_fit) {
+		if ((r = ensure_x8(ctx, cands)) || (r = ensure_x8(ctx, qset))) return r;
+		x8_fit = cands->x8 && qset->x8 && !cands->x8_has_zero && !qset->x8_has_zero;
+	}
 	// close candidates per query, kept on the device for msc_last_close_counts (a caller that only needs the counts of a block of the
 	// pairwise matrix does not have to add up n_q x m flags on the host)
-	const bool top_level = ctx->close_counts_base == 0 && !ctx->in_score_multi;
+	const bool top_level = !ctx->in_score_multi;
 	if (top_level && close_out) {
 		if ((r = ensure(ctx, ctx->close_counts, n_q * sizeof(uint64_t)))) return r;
 		HIP_TRY(ctx, hipMemsetAsync(ctx->close_counts.p, 0, n_q * sizeof(uint64_t), ctx->stream));
 		ctx->close_counts_n = n_q;
-	} else if (top_level) ctx->close_counts_n = 0;
-	if (n_q > 64) {
-		// blocks of 64 queries: the unit of the pass on the matrix cores (a 64-row operand) and of the digest kernel (four groups of 16);
+		ctx->close_counts_base = 0;
+	} else if (top_level) { ctx->close_counts_n = 0; ctx->close_counts_base = 0; }
+	const uint64_t blk = x8_fit ? 128 : 64;
+	if (n_q > blk) {
+		// blocks of queries: the unit of the pass on the matrix cores (a 128-row operand) and of the digest kernel (four groups of 16);
 		// msc_last_kernel_ms / _launches then cover the whole call
 		float ms = 0.f;
 		int launches = 0;
+		const bool was_in = ctx->in_score_multi;
+		const uint64_t base0 = ctx->close_counts_base;
 		ctx->in_score_multi = true;
-		for (uint64_t b = 0; b < n_q; b += 64) {
-			const uint64_t nb = std::min<uint64_t>(64, n_q - b);
-			ctx->close_counts_base = b;
+		for (uint64_t b = 0; b < n_q; b += blk) {
+			const uint64_t nb = std::min<uint64_t>(blk, n_q - b);
+			ctx->close_counts_base = base0 + b;
 			if ((r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
 			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr)))
-				{ ctx->in_score_multi = false; ctx->close_counts_base = 0; return r; }
+				{ ctx->in_score_multi = was_in; ctx->close_counts_base = base0; return r; }
 			ms += ctx->tiles_ms_accum;
 			launches += ctx->tiles_launches;
 		}
-		ctx->in_score_multi = false;
-		ctx->close_counts_base = 0;
+		ctx->in_score_multi = was_in;
+		ctx->close_counts_base = base0;
 		ctx->tiles_ms_accum = ms;
 		ctx->tiles_launches = launches;
 		return MSC_OK;
 	}
-	uint64_t want = feat_mask;
-	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	// divergence statistics in the Q x M pass: the integer reductions come from the streaming kernel below, the two FP64 sums from
 	// one merge pass per query over the sparse mirrors, queued behind it -- the same kernel, hence the same values,
 	// as a 1 x M pass per query
@@ -1946,34 +2005,33 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const bool compact = 64ull * L.R * mc_ * mc_ < (1ull << 32) && 64ull * L.R * ms_ < (1ull << 32);
 	// every prefix of excess counts (count - 1) is at most the histogram's k-mer total = sum - 4^k: 16-bit prefix form when that fits
 	const bool excess16 = ms_ >= L.nbins && ms_ - L.nbins < 65536;
-	const bool need_emd = ((want | feat_mask) & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
 	static const bool no_digest = getenv("MSC_MULTI_NO_DIGEST") != nullptr;
-	static const bool no_gemm = getenv("MSC_MULTI_NO_GEMM") != nullptr;
 	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
-	static const bool no_manh_gemm = getenv("MSC_MULTI_NO_MANH_GEMM") != nullptr;
-	static const int max_level_bits = [] { const char* e = getenv("MSC_GEMM_LEVEL_BITS"); return e ? std::min(4, atoi(e)) : 4; }();
 	const bool tuned_by_hand = getenv("MSC_MULTI_TQ") || getenv("MSC_DIGEST_SLOTS");          // A/B switches of the older kernels: keep to them
 	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
-	// longest list is a quarter of the bins or less, for up to 64 queries and 2^20 bins (32-bit wave sums)
-	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 64 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
-	// The products on the matrix cores (msc_dot_gemm.hip): int8 operands, exact int32 sums -- every count <= 127 and count x sum < 2^31
-	// (a product sum is at most max count x sum of the other histogram). Up to 64 queries per call.
-	const bool gemm_fit = !no_gemm && !tuned_by_hand && cands->dtype != 64 && mc_ <= 127 && mc_ * ms_ < (1ull << 31) && n_q <= 64 && L.nbins == L.padded_bins && L.nbins % 1024 == 0;
-	// EVERYTHING on the matrix cores. Every count of both sets below 17 (1 kb sequences at k = 9 qualify; every count >= 1, which the
-	// build of the count8 mirror checks): the Manhattan distance is a sum of products of thermometer level bytes and comes out of the
-	// same GEMM as the products of the counts -- one read of a byte per bin per 64 queries, no digest mirror, no partial records.
-	int level_bits = 0;
-	bool emd_ranks = false;
-	if (gemm_fit && !no_digest && !no_manh_gemm && n_q >= 2 && mc_ <= (1u << max_level_bits) && ms_ >= L.nbins && msc_digest_supported(L) && (!need_emd || ranks_fit)) {
-		if ((r = ensure_count8(ctx, cands)) || (r = ensure_count8(ctx, qset))) return r;
-		bool ok = cands->count8 && qset->count8 && !cands->c8_has_zero && !qset->c8_has_zero;
-		if (ok && need_emd) {
+	// longest list is a quarter of the bins or less, for up to 128 queries and 2^20 bins (32-bit wave sums)
+	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 128 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
+	// EVERYTHING on the matrix cores (msc_pair_gemm.hip): one int8 product per tile of bins over the x8 mirrors + corrections from the
+	// lists of large bins -- exact for any counts of the narrow range; one read of a candidate byte per 128 queries, no partial records.
+	// The queries' large bins become this block's hot list: its size is known here (the lists' lengths are mirrored on the host), and
+	// a block whose list would average more than 64 entries per 128-bin step (long sequences in few bins: the walk over the list would
+	// then take several times the step's product) is left to the older routes.
+	bool manh_gemm = false, emd_ranks = false;
+	uint64_t n_hot = 0;
+	if (x8_fit && simple && !tuned_by_hand && !no_digest) {
+		for (uint64_t q = 0; q < n_q; q++) n_hot += std::min(qset->mb_n_host[q_slots[q]], qset->mb_pitch);
+		manh_gemm = n_hot <= 64 * (L.nbins / 128);
+		if (manh_gemm && need_emd) {
 			if ((r = ensure_ranks(ctx, cands)) || (r = ensure_ranks(ctx, qset))) return r;
-			ok = cands->ranks && qset->ranks;
+			manh_gemm = emd_ranks = cands->ranks && qset->ranks;
 		}
-		if (ok) { level_bits = mc_ <= 4 ? 2 : mc_ <= 8 ? 3 : 4; emd_ranks = need_emd; }
 	}
-	const bool manh_gemm = level_bits != 0;
+	if (!manh_gemm && n_q > 64) {          // (a block of 128 was cut for the matrix cores: the older routes take it as two of 64)
+		ctx->no_x8_now = true;
+		r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
+		ctx->no_x8_now = false;
+		return r;
+	}
 	// Digest form (pair_digest.hip): sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen (or 32)
 	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
 	// (one digest tile per lane-run of 16 bins: wave totals of 1024 * max^2 must fit 32 bits)
@@ -1985,12 +2043,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
 		digest = cands->digest && qset->digest;
 	}
-	// the form the digest kernel has without its v_dot4 quarter exists for 8-bit counts and two tiles per step
-	bool gemm_dot = manh_gemm || (digest && gemm_fit && msc_digest_tiles_per_step(L, mc_) == 2);
-	if (gemm_dot && !manh_gemm) {
-		if ((r = ensure_count8(ctx, cands)) || (r = ensure_count8(ctx, qset))) return r;
-		gemm_dot = cands->count8 && qset->count8;
-	}
+	const bool gemm_dot = false;          // (r03's digest forms without their products took them from an int8 GEMM over a count mirror: the x8 route replaced both)
 	// LDS-DMA ring form over the raw bins: 32/64-bit bins, compact totals, query groups of four or eight
 	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
 	if (!digest && !manh_gemm && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
@@ -2011,8 +2064,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const uint64_t rec_bytes = digest && dg_tq == 8 ? 4 : digest && gemm_dot ? 8 : digest || ring ? 16 : sizeof(MscPartial);
 	const uint64_t q_rows = digest ? (n_q + 4 * dg_tq - 1) / (4 * dg_tq) * (4 * dg_tq) : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
-	// (no records without the digest kernel: the two product arrays of the GEMM, [slices][chunk][64] int32 each, kept to 2 GiB)
-	if (manh_gemm) chunk = (2048ull << 20) / ((uint64_t)msc_dot_gemm_slices(L.nbins, (uint32_t)std::min<uint64_t>(m, 1u << 30), ctx->num_cus) * 64 * sizeof(int32_t) * 2);
+	// (no records without the digest kernel: the product array of the GEMM, [slices][chunk][rows] int32, kept to 2 GiB)
+	const uint32_t x8_qn = manh_gemm ? msc_pair_gemm_rows((uint32_t)n_q) : 0;
+	if (manh_gemm) chunk = (2048ull << 20) / ((uint64_t)msc_pair_gemm_slices(L.nbins, (uint32_t)std::min<uint64_t>(m, 1u << 30), x8_qn, ctx->num_cus) * x8_qn * sizeof(int32_t));
 	if (want_grp) chunk = std::min<uint64_t>(chunk, (1024ull << 20) / (n_q * 32 * sizeof(double)));      // [n_q][chunk][16][2] group records: 1 GiB
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
@@ -2037,13 +2091,26 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
-	const uint32_t gemm_slices = gemm_dot ? msc_dot_gemm_slices(L.nbins, (uint32_t)chunk, ctx->num_cus) : 0;
-	if (gemm_dot && ((r = ensure(ctx, ctx->gemm_q8, 64 * L.nbins)) || (r = ensure(ctx, ctx->gemm_out, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t))))) return r;
-	if (manh_gemm && (r = ensure(ctx, ctx->gemm_min, (size_t)gemm_slices * chunk * 64 * sizeof(int32_t)))) return r;
-	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * 64 * sizeof(uint64_t)))) return r;
+	const uint32_t gemm_slices = manh_gemm ? msc_pair_gemm_slices(L.nbins, (uint32_t)chunk, x8_qn, ctx->num_cus) : 0;
+	uint32_t *hot_ptr = nullptr, *hot_cursor = nullptr, *hot_cnt = nullptr;
+	if (manh_gemm) {
+		const uint64_t img = msc_pair_gemm_image_bytes(L.nbins, x8_qn), nsteps = L.nbins / 128;
+		if ((r = ensure(ctx, ctx->x8_fimg, img)) || (r = ensure(ctx, ctx->x8_qT, img)) || (r = ensure(ctx, ctx->x8_min, (size_t)gemm_slices * chunk * x8_qn * sizeof(int32_t)))) return r;
+		if (n_hot) {
+			if ((r = ensure(ctx, ctx->x8_hot, n_hot * 8)) || (r = ensure(ctx, ctx->x8_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
+			    (r = ensure(ctx, ctx->x8_diff, chunk * x8_qn * sizeof(int32_t)))) return r;
+			hot_ptr = (uint32_t*)ctx->x8_hot_idx.p;
+			hot_cursor = hot_ptr + (nsteps + 1);
+			hot_cnt = hot_cursor + (nsteps + 1);
+		}
+		// the queries' side of the block, once for all chunks of candidates
+		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->x8, qset->mb, qset->mb_n, qset->mb_pitch, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, x8_qn,
+		                                          (uint8_t*)ctx->x8_fimg.p, (uint8_t*)ctx->x8_qT.p, n_hot, ctx->x8_hot.p, hot_ptr, hot_cursor, hot_cnt));
+	}
+	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? x8_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
 	if (manh_gemm) {
-		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_dot_gemm_i8<manh by %d levels + dot by mfma%s>", (1 << level_bits) - 1, emd_ranks ? ", emd by ranks" : ", no emd");
+		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_gemm_x8<%u query rows, one int8 product per tile%s>", x8_qn, emd_ranks ? ", emd by ranks" : ", no emd");
 		ctx->last_kernel = ctx->last_kernel_buf;
 	} else if (digest) {
 		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_digest_multi<%s counts%s%s>", mc_ < 256 ? "u8" : "u16",
@@ -2062,8 +2129,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
-			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q,
-			                                 (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p, level_bits, (int32_t*)ctx->gemm_min.p));
+			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->x8, d_slots, off, mc, (const uint8_t*)ctx->x8_fimg.p, x8_qn, gemm_slices, hot_ptr, ctx->x8_hot.p,
+			                                  (int32_t*)ctx->x8_min.p, (int32_t*)ctx->x8_diff.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
@@ -2074,12 +2141,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
-		if (gemm_dot && !manh_gemm)          // the products of this chunk: queries x candidates on the matrix cores, behind the streaming kernel
-			HIP_TRY(ctx, msc_launch_dot_gemm(ctx->stream, L.nbins, cands->count8, d_slots, off, mc, qset->count8,
-			                                 (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint8_t*)ctx->gemm_q8.p, gemm_slices, (int32_t*)ctx->gemm_out.p));
 		if (emd_ranks)
 			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
-			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p));
+			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? x8_qn : 64));
 		if (want_div) {
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
@@ -2111,10 +2175,20 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (want_div) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = dvn; ea.div_base = L.nbins; }
 		if (want_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + chunk * 16; }
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
-		ea.partials_cq = digest && !manh_gemm ? ctx->partials.p : nullptr;
-		if (manh_gemm) ea.min_gemm = (const int32_t*)ctx->gemm_min.p;
+		ea.partials_cq = digest ? ctx->partials.p : nullptr;
+		if (manh_gemm) {
+			ea.x8_min = (const int32_t*)ctx->x8_min.p;
+			ea.x8_diff = n_hot ? (const int32_t*)ctx->x8_diff.p : nullptr;
+			ea.x8_slices = gemm_slices;
+			ea.x8_qn = x8_qn;
+			ea.x8_first = cand_slots ? 0 : off;
+			ea.x8_c_mb = cands->mb; ea.x8_c_mb_n = cands->mb_n; ea.x8_c_pitch = cands->mb_pitch;
+			ea.x8_q_mb = qset->mb; ea.x8_q_mb_n = qset->mb_n; ea.x8_q_mb_big = qset->mb_big; ea.x8_q_pitch = qset->mb_pitch;
+			ea.x8_qT = (const uint8_t*)ctx->x8_qT.p;
+			ea.x8_cand = cands->x8;
+			ea.emd_stride = x8_qn;
+		}
 		ea.cq_group = 4 * dg_tq;
-		if (gemm_dot) { ea.dot_gemm = (const int32_t*)ctx->gemm_out.p; ea.dot_slices = gemm_slices; ea.dot_stride = 64; }
 		if (emd_ranks) ea.emd_ranks = (const uint64_t*)ctx->emd_out.p;
 		ea.S = n_rec;
 		ea.m = (uint32_t)(n_q * mc);

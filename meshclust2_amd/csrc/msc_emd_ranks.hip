@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t fold16q(const uint32_t (&s)[16]) {
 constexpr uint32_t kRound = 1024, kQGroup = 16, kCandPerWave = 16;
 __global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
                                                    uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
-                                                   const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out) {
+                                                   const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
 	__shared__ v4i_ sQ[kQGroup][kRound / 4];          // 64 KiB
 	__shared__ uint32_t s_nq[kQGroup];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ 
 			const uint64_t slot = cand_slots ? cand_slots[ci] : first + ci;
 			const uint32_t nc = c_n[slot];
 			if (base >= (nc > nq_max ? nc : nq_max)) {          // past every list of this candidate and group: all terms | nbins - nbins |
-				if (base == 0 && owner) out[(uint64_t)ci * 64 + my_q] = 0;
+				if (base == 0 && owner) out[(uint64_t)ci * out_stride + my_q] = 0;
 				continue;
 			}
 			v4i_ a[4];          // lane l: ranks 256 j + 4 l .. + 3 of the round
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ 
 			}
 			const uint32_t tot = fold16q(sum);
 			if (owner) {
-				uint64_t* o = out + (uint64_t)ci * 64 + my_q;
+				uint64_t* o = out + (uint64_t)ci * out_stride + my_q;
 				*o = base ? *o + tot : (uint64_t)tot;
 			}
 		}
@@ -178,11 +178,12 @@ hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype,
 	return hipGetLastError();
 }
 
-// out[candidate][64]: emd of (candidate, query q) at [q], q < n_q <= 64; nbins <= 2^20
+// out[candidate][out_stride]: emd of (candidate, query q) at [q], q < n_q <= out_stride; nbins <= 2^20
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
-                                uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out) {
+                                uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out,
+                                uint32_t out_stride) {
 	if (m == 0 || n_q == 0) return hipSuccess;
-	if (n_q > 64 || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
-	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave), (n_q + kQGroup - 1) / kQGroup), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out);
+	if (n_q > out_stride || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
+	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave), (n_q + kQGroup - 1) / kQGroup), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
 	return hipGetLastError();
 }

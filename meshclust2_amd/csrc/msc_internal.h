@@ -73,10 +73,25 @@ struct MscEpilogueArgs {
 	const void* partials_cq;          // or: [m_per_query][ceil(n_queries/16)][S][16] such records (digest kernel: one 256-byte run per workgroup step)
 	uint32_t cq_group;                // with partials_cq: queries per group -- 16, or 32 with 4-byte records (manh only: dot_gemm set, emd from emd_ranks or not wanted)
 	const uint64_t* emd_ranks;        // with partials_cq: the earth mover's distances from msc_emd_ranks.hip instead, [m_per_query][64] (query q at [q])
-	const int32_t* min_gemm;          // with dot_gemm, same layout: sum min(e, e') from the level bytes -- manh without any records (partials_cq unused)
 	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q]);
 	                                  // the records of partials_cq are then 8 bytes (manh, emd)
 	uint32_t dot_slices, dot_stride;
+	// the r04 pass on the matrix cores (msc_pair_gemm.hip, k_pair_epilogue_x8): P1 per slice and P2 of the block, the lists of large
+	// bins (e = count - 1 >= 2) of both sets, the queries' clamped bytes [bin][x8_qn], the candidates' mirror (msc_x8.h)
+	const int32_t* x8_min;            // [x8_slices][m_per_query][x8_qn]; non-null selects k_pair_epilogue_x8
+	const int32_t* x8_diff;           // [m_per_query][x8_qn], or null when no query of the block has a large bin
+	uint32_t x8_slices, x8_qn;
+	uint64_t x8_first;                // slot of candidate 0 when cand_slots is null (cand_scalars is then already offset to it)
+	const void* x8_c_mb;              // uint2 (bin, e) [slot][x8_c_pitch]
+	const uint32_t* x8_c_mb_n;
+	uint32_t x8_c_pitch;
+	const void* x8_q_mb;
+	const uint32_t* x8_q_mb_n;
+	const uint32_t* x8_q_mb_big;      // per slot: entries with e >= 127
+	uint32_t x8_q_pitch;
+	const uint8_t* x8_qT;
+	const uint8_t* x8_cand;           // the candidates' x8 mirror
+	uint32_t emd_stride;              // entries per candidate of emd_ranks (0 = 64)
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
 	uint32_t m;
@@ -176,13 +191,20 @@ uint64_t msc_ranks_pitch(uint64_t max_excess);
 hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, const uint8_t* scalars, uint32_t* ranks, uint32_t* n_of, uint64_t pitch,
                                   uint64_t first_slot, uint64_t n_slots, int32_t* bad);
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
-                                uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out);
-uint64_t msc_count8_bytes(const MscLayout& L, uint64_t capacity);
-hipError_t msc_launch_count8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* count8, uint64_t first_slot, uint64_t n_slots, int32_t* has_zero);
-uint32_t msc_dot_gemm_slices(uint64_t nbins, uint32_t m, int num_cus);
-hipError_t msc_launch_dot_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_count8, const uint32_t* cand_slots, uint64_t first, uint32_t m,
-                               const uint8_t* q_count8, const uint32_t* q_slots_dev, uint32_t n_q, uint8_t* q8_scratch, uint32_t k_slices, int32_t* out,
-                               int level_bits = 0, int32_t* out_min = nullptr);
+                                uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out,
+                                uint32_t out_stride = 64);
+// the r04 form of that pass (msc_pair_gemm.hip): x8 mirror + lists of large bins, the queries' side of a block, the product
+uint64_t msc_x8_bytes(const MscLayout& L, uint64_t capacity);
+hipError_t msc_launch_x8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* x8, uint64_t first_slot, uint64_t n_slots, void* mb,
+                               uint32_t* mb_n, uint32_t* mb_big, uint32_t pitch, int32_t* flags);
+uint32_t msc_pair_gemm_rows(uint32_t n_q);
+uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
+uint64_t msc_pair_gemm_image_bytes(uint64_t nbins, uint32_t qn);
+hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_x8, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
+                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* fimg, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
+                                        uint32_t* hot_cursor, uint32_t* hot_cnt);
+hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_x8, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* fimg,
+                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,

@@ -41,7 +41,9 @@ struct msc_ctx {
 	uint64_t sp_acc_bins = 0;
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
-	DevBuf gemm_q8, gemm_out, gemm_min;    // msc_dot_gemm.hip: the gathered query rows, the products per slice, sum min(e, e') per slice
+	// msc_pair_gemm.hip: the queries' side of a block (flag image, transposed bytes, hot list + its three step arrays), P1 per slice, P2
+	DevBuf x8_fimg, x8_qT, x8_hot, x8_hot_idx, x8_min, x8_diff;
+	bool no_x8_now = false;                // msc_score_multi: this block is taken by the older routes (its hot list would be too long)
 	DevBuf close_counts;                   // msc_score_multi: close candidates per query of the call in progress / the last call (msc_last_close_counts)
 	uint64_t close_counts_n = 0, close_counts_base = 0;
 	bool in_score_multi = false;
@@ -67,12 +69,19 @@ struct msc_hist_set {
 	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
 	mutable uint64_t dg_lo = 0, dg_hi = 0;
 	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
-	// count8 mirror (msc_dot_gemm.hip): one byte per bin for the int8 GEMM of the Q x M pass, slots blocked by 16 so that a wave's
-	// operand load is one contiguous KiB. slots [c8_lo, c8_hi) are stale (kept in step with the digest's range by mark_stale)
-	mutable uint8_t* count8 = nullptr;
-	mutable uint64_t c8_lo = 0, c8_hi = 0;
-	mutable bool count8_unavailable = false;
-	mutable bool c8_has_zero = false;         // a slot with a zero count went into the mirror (never the case for built histograms and their means)
+	// x8 mirror (msc_pair_gemm.hip, msc_x8.h): one byte per bin = min(count - 1, 127), slots blocked by 32 -- the B operand of the int8
+	// product of the Q x M pass -- and beside it the lists of large bins (count - 1 >= 2) that make the pass exact for any counts:
+	// mb[slot][mb_pitch] = (bin, count - 1), unordered; mb_n / mb_big = entries / entries with count - 1 >= 127 per slot (mb_n also on
+	// the host: the size of a query block's hot list is known without a read-back). slots [x8_lo, x8_hi) are stale (mark_stale)
+	mutable uint8_t* x8 = nullptr;
+	mutable uint64_t x8_lo = 0, x8_hi = 0;
+	mutable bool x8_unavailable = false;
+	mutable bool x8_has_zero = false;         // a slot with a zero count went into the mirror (never the case for built histograms and their means)
+	mutable void* mb = nullptr;
+	mutable uint32_t* mb_n = nullptr;
+	mutable uint32_t* mb_big = nullptr;
+	mutable uint32_t mb_pitch = 0;
+	mutable std::vector<uint32_t> mb_n_host;
 	// ranks mirror (msc_emd_ranks.hip): per slot the bins of its counted k-mers in bin order (rk_pitch entries, padded with 4^k) and
 	// their number: the earth mover's distance of the Q x M pass in O(k-mers) instead of O(bins). Built from the digest mirror;
 	// slots [rk_lo, rk_hi) are stale

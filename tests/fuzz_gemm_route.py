@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised rounds aimed at the matrix-core route of the Q x M pass (msc_dot_gemm.hip + msc_emd_ranks.hip): sets whose counts stay
+"""Randomised rounds aimed at the matrix-core route of the Q x M pass (msc_pair_gemm.hip + msc_emd_ranks.hip): sets whose counts stay
 small (sequences much shorter than 4^k), random k / bin type / window / slot lists with repeats / query blocks of 2 .. 200 from the same
 or another set / both argument orders -- msc_score_multi against one 1 x M pass per query (independent raw-bin kernels): integer
 statistics and decisions bit-equal, sums equal.   python tests/fuzz_gemm_route.py [seconds] [first seed]     (run on the GPU box)"""
@@ -73,11 +73,11 @@ def main():
     t0, n, gemm = time.time(), 0, 0
     while time.time() - t0 < budget:
         line = one_round(ctx, seed)
-        gemm += "k_dot_gemm" in line
+        gemm += "k_pair_gemm_x8" in line
         print(line, flush=True)
         seed += 1
         n += 1
-    print("fuzz ok: %d rounds, %d of them through k_dot_gemm_i8" % (n, gemm))
+    print("fuzz ok: %d rounds, %d of them through k_pair_gemm_x8" % (n, gemm))
 
 
 if __name__ == "__main__":

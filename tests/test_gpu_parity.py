@@ -567,20 +567,20 @@ def test_multi_digest_variants(slots):
     assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
 
 
-@pytest.mark.parametrize("switches", ["", "MSC_MULTI_NO_MANH_GEMM", "MSC_MULTI_NO_MANH_GEMM MSC_DIGEST_NO_TQ8", "MSC_MULTI_NO_MANH_GEMM MSC_MULTI_NO_RANKS",
-                                      "MSC_MULTI_NO_GEMM", "MSC_MULTI_NO_GEMM MSC_MULTI_NO_RANKS", "MSC_GEMM_LEVEL_BITS=2"])
+@pytest.mark.parametrize("switches", ["", "MSC_MULTI_NO_GEMM", "MSC_MULTI_NO_GEMM MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_RANKS", "MSC_GEMM_A_KIB=256"])
 def test_multi_route_variants(switches):
     """Every route of the Q x M pass over a dense set == independent 1 x M passes, bit for bit (the library reads its switches once
-    per process): everything on the matrix cores (manh from thermometer levels, msc_dot_gemm.hip) with the earth mover's distance
-    from ranks (msc_emd_ranks.hip); the manh-only digest kernel with 8 and with 4 queries per wave + GEMM + ranks; digest with its
-    prefix half + GEMM; digest with its own products + ranks; the r02 digest kernel alone; level products for counts up to 4 only."""
+    per process): everything on the matrix cores (one int8 product per tile + corrections from the lists of large bins,
+    msc_pair_gemm.hip) with the earth mover's distance from ranks (msc_emd_ranks.hip); the digest kernel with its own products + ranks;
+    the r02 digest kernel alone; without the ranks mirror (the matrix-core pass then only serves models without emd); the matrix-core
+    pass cut into many thin slices of the bins."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
-    for k in ("MSC_MULTI_TQ", "MSC_MULTI_NO_DIGEST", "MSC_MULTI_NO_RING", "MSC_RING_NO_P16", "MSC_RING_SLOTS", "MSC_DIGEST_SLOTS", "MSC_MULTI_NO_MANH_GEMM",
-              "MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_GEMM", "MSC_DIGEST_NO_TQ8", "MSC_GEMM_LEVEL_BITS"):
+    for k in ("MSC_MULTI_TQ", "MSC_MULTI_NO_DIGEST", "MSC_MULTI_NO_RING", "MSC_RING_NO_P16", "MSC_RING_SLOTS", "MSC_DIGEST_SLOTS",
+              "MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_GEMM", "MSC_DIGEST_NO_TQ8", "MSC_GEMM_A_KIB"):
         env.pop(k, None)
     for sw in switches.split():
         name, _, val = sw.partition("=")
@@ -1026,7 +1026,7 @@ def test_full_size_cfg2_properties(oracle):
     qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
     fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
     multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
-    assert ctx.last_kernel_info()[0].startswith(("k_pair_gemm_x8", "k_dot_gemm_i8")), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
+    assert ctx.last_kernel_info()[0].startswith("k_pair_gemm_x8"), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
@@ -1254,7 +1254,7 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
     mask = FAST_MASK & ~((1 << 7) | (1 << 29))
     for rnd in range(2):
         multi = api.score_multi(ctx, feat, db, None, qs_set, q_slots, m=70, feat_mask=mask)
-        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_dot_gemm_i8"))
+        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_pair_gemm_x8"))
         for i, q in enumerate(q_slots):
             raw = api.pair_features_raw(ctx, db, None, qs_set, int(q), mask, m=70)
             single = feat.compute(db, None, qs_set, int(q), m=70)
