@@ -56,7 +56,7 @@ def parse():
                          "rank builds the block's histograms itself, bit-identical to the owner's) or their HISTOGRAMS as they sit in HBM (4^k x sizeof(T) "
                          "bytes each: SURVEY 8(e)'s exchange -- at 1 MiB per query the ring all-gather takes longer than scoring the block once the pass "
                          "runs on the matrix cores)")
-    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 128 (64 off the matrix cores), "
+    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 256 (64 off the matrix cores), "
                                                              "one pass over the candidates each -- a step of 16 blocks keeps the per-step exchange and host work of an 8-rank run "
                                                              "(12 500 candidates per rank) small next to the scoring")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
@@ -460,7 +460,9 @@ def main():
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
     on_mfma = kernel.startswith("k_pair_gemm_x8")
-    if on_mfma:   # everything from the matrix cores: the pass reads the x8 mirror, one byte per bin, once per block of up to 128 queries
+    qblk = int(os.environ.get("MSC_GEMM_BLOCK", "256"))          # queries per pass over the candidates on the matrix cores (the library's block)
+    qblk = qblk if qblk in (64, 128) else 256
+    if on_mfma:   # everything from the matrix cores: the pass reads the x8 mirror, one byte per bin, once per block of up to 256 queries
         hist_bytes = 4 ** args.k
     elif "no emd" in kernel or "emd by ranks" in kernel:   # count-only form of the digest kernel: the prefix half of each tile is not fetched
         hist_bytes //= 2
@@ -471,7 +473,7 @@ def main():
     if args.mode == "allpairs" and args.layout == "sparse":
         per_call = Q * (M + 1) * hist_bytes          # one 1 x M merge pass per query
     elif args.mode == "allpairs":
-        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 128: a call with more queries is that many passes)
+        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 256: a call with more queries is that many passes)
     else:
         per_call = (M + 1) * hist_bytes
     # one timed call may be several launches of the streaming kernel (candidate chunks): report per launch
@@ -516,9 +518,9 @@ def main():
                      # hbm_frac = PMC HBM bytes per launch / launch time / peak (frac above prices the TILE reads of the kernel as it
                      # is tiled -- query groups that share a candidate mostly hit in L2); valu_busy = VALU cycles / busy cycles
                      "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms == avg_ms else None, "valu_busy": valu_busy,
-                     # a call scores its queries in blocks of 128 (matrix cores) or 64 (one pass over the candidates each) and may cut a pass into candidate chunks
-                     "candidates_per_launch": int(round(M * calls_per_launch * (-(-Q // (128 if on_mfma else 64)) if args.mode == "allpairs" and args.layout == "dense" else 1))),
-                     "query_groups_per_launch": -(-min(Q, 128 if on_mfma else 64) // qtile) if args.mode == "allpairs" else 1,
+                     # a call scores its queries in blocks of 256 (matrix cores) or 64 (one pass over the candidates each) and may cut a pass into candidate chunks
+                     "candidates_per_launch": int(round(M * calls_per_launch * (-(-Q // (qblk if on_mfma else 64)) if args.mode == "allpairs" and args.layout == "dense" else 1))),
+                     "query_groups_per_launch": -(-min(Q, qblk if on_mfma else 64) // qtile) if args.mode == "allpairs" else 1,
                      "profile_key": config_key},
     }
     if args.check:

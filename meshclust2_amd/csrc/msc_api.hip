@@ -1833,7 +1833,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	const bool need_emd = (want & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
-	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 128 queries per read of a candidate byte; the older routes 64
+	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 256 queries per read of a candidate byte; the older routes 64
 	bool x8_fit = !ctx->no_x8_now && n_q >= 2 && x8_route_fits(cands, qset, need_emd);
 	if (x8_fit) {
 		if ((r = ensure_x8(ctx, cands)) || (r = ensure_x8(ctx, qset))) return r;
@@ -1848,7 +1848,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ctx->close_counts_n = n_q;
 		ctx->close_counts_base = 0;
 	} else if (top_level) { ctx->close_counts_n = 0; ctx->close_counts_base = 0; }
-	const uint64_t blk = x8_fit ? 128 : 64;
+	static const uint64_t x8_blk = [] { const char* e = getenv("MSC_GEMM_BLOCK"); const int v = e ? atoi(e) : 256; return (uint64_t)(v == 64 || v == 128 ? v : 256); }();
+	const uint64_t blk = x8_fit ? x8_blk : 64;
 	if (n_q > blk) {
 		// blocks of queries: the unit of the pass on the matrix cores (a 128-row operand) and of the digest kernel (four groups of 16);
 		// msc_last_kernel_ms / _launches then cover the whole call
@@ -2009,10 +2010,10 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
 	const bool tuned_by_hand = getenv("MSC_MULTI_TQ") || getenv("MSC_DIGEST_SLOTS");          // A/B switches of the older kernels: keep to them
 	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
-	// longest list is a quarter of the bins or less, for up to 128 queries and 2^20 bins (32-bit wave sums)
-	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 128 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
+	// longest list is a quarter of the bins or less, for up to 256 queries and 2^20 bins (32-bit wave sums)
+	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 256 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
 	// EVERYTHING on the matrix cores (msc_pair_gemm.hip): one int8 product per tile of bins over the x8 mirrors + corrections from the
-	// lists of large bins -- exact for any counts of the narrow range; one read of a candidate byte per 128 queries, no partial records.
+	// lists of large bins -- exact for any counts of the narrow range; one read of a candidate byte per 256 queries, no partial records.
 	// The queries' large bins become this block's hot list: its size is known here (the lists' lengths are mirrored on the host), and
 	// a block whose list would average more than 64 entries per 128-bin step (long sequences in few bins: the walk over the list would
 	// then take several times the step's product) is left to the older routes.
@@ -2026,7 +2027,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 			manh_gemm = emd_ranks = cands->ranks && qset->ranks;
 		}
 	}
-	if (!manh_gemm && n_q > 64) {          // (a block of 128 was cut for the matrix cores: the older routes take it as two of 64)
+	if (!manh_gemm && n_q > 64) {          // (a block of up to 256 was cut for the matrix cores: the older routes take it in blocks of 64)
 		ctx->no_x8_now = true;
 		r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
 		ctx->no_x8_now = false;

@@ -16,8 +16,9 @@
 //                  other mirrors' stale range.
 //                  Needs every count >= 1 (the reference's histograms start at 1, KmerHashTable's initial value; a mean of such too):
 //                  a zero bin would make the prefix non-monotone -- the build reports it and the caller keeps the digest's prefix form.
-//   k_emd_ranks    a workgroup stages 1 024 ranks of 16 queries in LDS; each wave holds 1 024 ranks of a candidate in registers and
-//                  walks them past the 16 lists (v_sad_u32 per rank), one transposed fold per candidate for its 16 totals.
+//   k_emd_ranks    a wave holds 1 024 ranks of each of four candidates in registers; the workgroup stages 1 024 ranks of 16 queries in LDS
+//                  at a time and every wave walks its candidates past them (v_sad_u32 per rank), one transposed fold per candidate and
+//                  group for the 16 totals.
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -89,70 +90,83 @@ __device__ __forceinline__ uint32_t fold16q(const uint32_t (&s)[16]) {
 	return R;
 }
 
-// One workgroup = one group of 16 queries x kCandPerWave candidates per wave. The queries' ranks of the current round (1 024 each) are
-// staged in LDS once and every candidate walks past them: 4 ds_read_b128 + 16 v_sad_u32 per pair and a 16-query fold per candidate
-// (the first version streamed every query list from L2 per candidate: 3.9 ms per 100 000 x 64 on cfg2, bound by those 26 GB of L2 reads).
+// One workgroup = 16 candidates (4 per wave, their ranks of the current round held in registers: 64 VGPRs) x ALL queries of the block,
+// taken 16 at a time through LDS (64 KiB). Per query a wave reads its 1 024 ranks once (4 ds_read_b128) and walks them past its four
+// candidates (64 v_sad_u32); one transposed fold per candidate and group for the 16 totals.
+// (r03 held ONE candidate per wave and gave every group of 16 queries its own workgroups: every candidate list was fetched once per
+// 16 queries -- 3.3 GB per 128-query block of cfg2, more than the kernel's arithmetic took -- and every LDS word served one pair.)
 // Lists longer than a round (1 kb sequences: one round) add their rounds up in `out`.
-constexpr uint32_t kRound = 1024, kQGroup = 16, kCandPerWave = 16;
-__global__ void __launch_bounds__(256) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
-                                                   uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
-                                                   const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
+constexpr uint32_t kRound = 1024, kQGroup = 16, kCandPerWave = 4;
+__global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
+                                                      uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
+                                                      const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
 	__shared__ v4i_ sQ[kQGroup][kRound / 4];          // 64 KiB
 	__shared__ uint32_t s_nq[kQGroup];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t qg = blockIdx.y, q0 = qg * kQGroup;
 	const uint32_t c0 = (blockIdx.x * 4 + wave) * kCandPerWave;
-	if (threadIdx.x < kQGroup) s_nq[threadIdx.x] = q0 + threadIdx.x < n_q ? q_n[q_slots[q0 + threadIdx.x]] : 0;
-	__syncthreads();
-	uint32_t nq_max = 0;
+	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup;
+	uint64_t slot[kCandPerWave];
+	uint32_t nc[kCandPerWave];
 #pragma unroll
-	for (uint32_t q = 0; q < kQGroup; q++) nq_max = s_nq[q] > nq_max ? s_nq[q] : nq_max;
-	const uint64_t rounds_end = c_pitch > q_pitch ? c_pitch : q_pitch;      // workgroup-uniform (the barriers below); a wave skips what its lists do not reach
+	for (uint32_t c = 0; c < kCandPerWave; c++) {
+		const uint32_t ci = c0 + c < m ? c0 + c : m - 1;
+		slot[c] = cand_slots ? cand_slots[ci] : first + ci;
+		nc[c] = c_n[slot[c]];
+	}
+	const uint64_t rounds_end = c_pitch > q_pitch ? c_pitch : q_pitch;      // workgroup-uniform (the barriers below)
 	// which query's total a lane ends up with (fold16q), and whether this lane stores it
-	const uint32_t my_q = q0 + ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
-	const bool owner = (lane & 3) == 0 && my_q < n_q;
+	const uint32_t my_q = ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
 	for (uint64_t base = 0; base < rounds_end; base += kRound) {
-		if (base) __syncthreads();          // everybody is done with the previous round's ranks
-		for (uint32_t i = threadIdx.x; i < kQGroup * (kRound / 4); i += 256) {
-			const uint32_t q = i / (kRound / 4), t4 = i % (kRound / 4);
-			v4i_ v = {(int)nbins, (int)nbins, (int)nbins, (int)nbins};          // (queries past n_q: never stored)
-			if (q0 + q < n_q && base + 4 * t4 < q_pitch) v = *reinterpret_cast<const v4i_*>(q_rk + (uint64_t)q_slots[q0 + q] * q_pitch + base + 4 * t4);
-			sQ[q][t4] = v;
-		}
-		__syncthreads();
-		for (uint32_t k = 0; k < kCandPerWave; k++) {
-			const uint32_t ci = c0 + k;
-			if (ci >= m) break;
-			const uint64_t slot = cand_slots ? cand_slots[ci] : first + ci;
-			const uint32_t nc = c_n[slot];
-			if (base >= (nc > nq_max ? nc : nq_max)) {          // past every list of this candidate and group: all terms | nbins - nbins |
-				if (base == 0 && owner) out[(uint64_t)ci * out_stride + my_q] = 0;
-				continue;
-			}
-			v4i_ a[4];          // lane l: ranks 256 j + 4 l .. + 3 of the round
+		v4i_ a[kCandPerWave][4];          // lane l: ranks 256 j + 4 l .. + 3 of the round
+#pragma unroll
+		for (uint32_t c = 0; c < kCandPerWave; c++)
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				a[j] = v4i_{(int)nbins, (int)nbins, (int)nbins, (int)nbins};
-				if (base + 256 * j < c_pitch) a[j] = *reinterpret_cast<const v4i_*>(c_rk + slot * c_pitch + base + 256 * j + 4 * lane);
+				a[c][j] = v4i_{(int)nbins, (int)nbins, (int)nbins, (int)nbins};
+				if (base + 256 * j < c_pitch) a[c][j] = *reinterpret_cast<const v4i_*>(c_rk + slot[c] * c_pitch + base + 256 * j + 4 * lane);
 			}
-			uint32_t sum[kQGroup];
+		for (uint32_t qg = 0; qg < n_groups; qg++) {
+			const uint32_t q0 = qg * kQGroup;
+			__syncthreads();          // everybody is done with the previous group's ranks
+			if (threadIdx.x < kQGroup) s_nq[threadIdx.x] = q0 + threadIdx.x < n_q ? q_n[q_slots[q0 + threadIdx.x]] : 0;
+			for (uint32_t i = threadIdx.x; i < kQGroup * (kRound / 4); i += 256) {
+				const uint32_t q = i / (kRound / 4), t4 = i % (kRound / 4);
+				v4i_ v = {(int)nbins, (int)nbins, (int)nbins, (int)nbins};          // (queries past n_q: never stored)
+				if (q0 + q < n_q && base + 4 * t4 < q_pitch) v = *reinterpret_cast<const v4i_*>(q_rk + (uint64_t)q_slots[q0 + q] * q_pitch + base + 4 * t4);
+				sQ[q][t4] = v;
+			}
+			__syncthreads();
+			uint32_t nq_max = 0;
+#pragma unroll
+			for (uint32_t q = 0; q < kQGroup; q++) nq_max = s_nq[q] > nq_max ? s_nq[q] : nq_max;
+			uint32_t sum[kCandPerWave][kQGroup];
 #pragma unroll
 			for (uint32_t q = 0; q < kQGroup; q++) {
-				uint32_t t = 0;          // nbins <= 2^20: 16 terms fit 32 bits, and so do the 64 lanes' in the fold
+				v4i_ b[4];
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
-					const v4i_ b = sQ[q][64 * j + lane];
-					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].x), "v"(b.x));
-					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].y), "v"(b.y));
-					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].z), "v"(b.z));
-					asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[j].w), "v"(b.w));
+				for (int j = 0; j < 4; j++) b[j] = sQ[q][64 * j + lane];
+#pragma unroll
+				for (uint32_t c = 0; c < kCandPerWave; c++) {
+					uint32_t t = 0;          // nbins <= 2^20: 16 terms fit 32 bits, and so do the 64 lanes' in the fold
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].x), "v"(b[j].x));
+						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].y), "v"(b[j].y));
+						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
+						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
+					}
+					sum[c][q] = t;
 				}
-				sum[q] = t;
 			}
-			const uint32_t tot = fold16q(sum);
-			if (owner) {
-				uint64_t* o = out + (uint64_t)ci * out_stride + my_q;
-				*o = base ? *o + tot : (uint64_t)tot;
+			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
+#pragma unroll
+			for (uint32_t c = 0; c < kCandPerWave; c++) {
+				const uint32_t tot = fold16q(sum[c]);
+				// past every list of this candidate and group all terms are | nbins - nbins |: nothing to add
+				if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
+					uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
+					*o = base ? *o + tot : (uint64_t)tot;
+				}
 			}
 		}
 	}
@@ -184,6 +198,6 @@ hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* 
                                 uint32_t out_stride) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > out_stride || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
-	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave), (n_q + kQGroup - 1) / kQGroup), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
+	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave)), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
 	return hipGetLastError();
 }

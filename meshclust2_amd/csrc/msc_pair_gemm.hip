@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_hot_fill(const uint2* __restrict__ mb, 
 // NRB = QN / 32 row blocks of queries. Registers: 16 NRB accumulators + two operand sets of 4 x 4 + NRB x 4 of staging: 3 waves per
 // SIMD up to QN = 128, 2 at 256.
 template <int NRB>
-__global__ void __launch_bounds__(256) k_pair_gemm_x8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+__global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_x8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                       const uint8_t* __restrict__ fimg, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
                                                       const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
 	constexpr int QN = 32 * NRB;
@@ -255,8 +255,8 @@ hipError_t msc_launch_x8_build(hipStream_t st, const MscLayout& L, int dtype, co
 	return hipGetLastError();
 }
 
-// rows of queries one pass serves for a block of n_q: 32, 64 or 128
-uint32_t msc_pair_gemm_rows(uint32_t n_q) { return n_q <= 32 ? 32 : n_q <= 64 ? 64 : 128; }
+// rows of queries one pass serves for a block of n_q: 32, 64, 128 or 256
+uint32_t msc_pair_gemm_rows(uint32_t n_q) { return n_q <= 32 ? 32 : n_q <= 64 ? 64 : n_q <= 128 ? 128 : 256; }
 
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus) {
 	// enough workgroups for a few rounds of the chip (3 workgroups of 128 candidates per CU); a slice is an even number of 128-bin steps
@@ -283,6 +283,7 @@ hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const ui
 	if (qn == 32) k_x8_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
 	else if (qn == 64) k_x8_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
 	else if (qn == 128) k_x8_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
+	else if (qn == 256) k_x8_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
 	else return hipErrorInvalidValue;
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || n_hot == 0) return e;
@@ -308,6 +309,7 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 	if (qn == 32) MSC_PG_GO(1);
 	else if (qn == 64) MSC_PG_GO(2);
 	else if (qn == 128) MSC_PG_GO(4);
+	else if (qn == 256) MSC_PG_GO(8);
 	else return hipErrorInvalidValue;
 #undef MSC_PG_GO
 	return hipGetLastError();
