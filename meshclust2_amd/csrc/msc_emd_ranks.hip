@@ -16,9 +16,9 @@
 //                  other mirrors' stale range.
 //                  Needs every count >= 1 (the reference's histograms start at 1, KmerHashTable's initial value; a mean of such too):
 //                  a zero bin would make the prefix non-monotone -- the build reports it and the caller keeps the digest's prefix form.
-//   k_emd_ranks    a wave holds 1 024 ranks of each of four candidates in registers; the workgroup stages 1 024 ranks of 16 queries in LDS
-//                  at a time and every wave walks its candidates past them (v_sad_u32 per rank), one transposed fold per candidate and
-//                  group for the 16 totals.
+//   k_emd_ranks    a wave holds 1 024 ranks of each of four candidates in registers; the workgroup moves 1 024 ranks of 8 queries at a
+//                  time into LDS (LDS-DMA, a two-slot ring) and every wave walks its candidates past them (v_sad_u32 per rank), one
+//                  transposed fold per candidate and 16 queries.
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -90,21 +90,37 @@ __device__ __forceinline__ uint32_t fold16q(const uint32_t (&s)[16]) {
 	return R;
 }
 
+// one wave-instruction of LDS-DMA: 64 lanes x 16 bytes from global memory (wave-uniform base in SGPRs + per-lane byte offset) straight
+// into LDS at lds_dst + 16 lane (no destination VGPRs); m0 is the compiler's: saved and restored
+__device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uint32_t lds_dst) {
+	uint32_t keep;
+	asm volatile(
+	    "s_mov_b32 %0, m0\n\t"
+	    "s_mov_b32 m0, %3\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dwordx4 %1, %2\n\t"
+	    "s_mov_b32 m0, %0"
+	    : "=&s"(keep)
+	    : "v"(lane_off), "s"(sbase), "s"(lds_dst)
+	    : "memory");
+}
+
 // One workgroup = 16 candidates (4 per wave, their ranks of the current round held in registers: 64 VGPRs) x ALL queries of the block,
-// taken 16 at a time through LDS (64 KiB). Per query a wave reads its 1 024 ranks once (4 ds_read_b128) and walks them past its four
-// candidates (64 v_sad_u32); one transposed fold per candidate and group for the 16 totals.
+// taken 8 at a time through a two-slot LDS ring (2 x 32 KiB) filled by LDS-DMA one half-group ahead: while a wave walks the 8 lists of
+// one slot past its four candidates (per query 4 ds_read_b128 + 64 v_sad_u32), the next 8 lists land in the other. One barrier per
+// half-group; one transposed fold per candidate and 16 queries.
 // (r03 held ONE candidate per wave and gave every group of 16 queries its own workgroups: every candidate list was fetched once per
-// 16 queries -- 3.3 GB per 128-query block of cfg2, more than the kernel's arithmetic took -- and every LDS word served one pair.)
+// 16 queries -- 3.3 GB per 128-query block of cfg2 -- and every LDS word served one pair; the first r04 form staged 16 lists through
+// registers between two barriers, the loads' latency in the open: 85 ps per pair against 92.)
 // Lists longer than a round (1 kb sequences: one round) add their rounds up in `out`.
-constexpr uint32_t kRound = 1024, kQGroup = 16, kCandPerWave = 4;
+constexpr uint32_t kRound = 1024, kQGroup = 16, kQHalf = 8, kCandPerWave = 4;
 __global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
                                                       uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
                                                       const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
-	__shared__ v4i_ sQ[kQGroup][kRound / 4];          // 64 KiB
-	__shared__ uint32_t s_nq[kQGroup];
-	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__shared__ v4i_ sQ[2][kQHalf][kRound / 4];          // 2 x 32 KiB
+	const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t c0 = (blockIdx.x * 4 + wave) * kCandPerWave;
-	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup;
+	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup, n_halves = 2 * n_groups;
 	uint64_t slot[kCandPerWave];
 	uint32_t nc[kCandPerWave];
 #pragma unroll
@@ -116,35 +132,56 @@ __global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict
 	const uint64_t rounds_end = c_pitch > q_pitch ? c_pitch : q_pitch;      // workgroup-uniform (the barriers below)
 	// which query's total a lane ends up with (fold16q), and whether this lane stores it
 	const uint32_t my_q = ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
+	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sQ[0][0][0]);
+	const v4i_ pad = {(int)nbins, (int)nbins, (int)nbins, (int)nbins};
 	for (uint64_t base = 0; base < rounds_end; base += kRound) {
 		v4i_ a[kCandPerWave][4];          // lane l: ranks 256 j + 4 l .. + 3 of the round
 #pragma unroll
 		for (uint32_t c = 0; c < kCandPerWave; c++)
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				a[c][j] = v4i_{(int)nbins, (int)nbins, (int)nbins, (int)nbins};
+				a[c][j] = pad;
 				if (base + 256 * j < c_pitch) a[c][j] = *reinterpret_cast<const v4i_*>(c_rk + slot[c] * c_pitch + base + 256 * j + 4 * lane);
 			}
-		for (uint32_t qg = 0; qg < n_groups; qg++) {
-			const uint32_t q0 = qg * kQGroup;
-			__syncthreads();          // everybody is done with the previous group's ranks
-			if (threadIdx.x < kQGroup) s_nq[threadIdx.x] = q0 + threadIdx.x < n_q ? q_n[q_slots[q0 + threadIdx.x]] : 0;
-			for (uint32_t i = threadIdx.x; i < kQGroup * (kRound / 4); i += 256) {
-				const uint32_t q = i / (kRound / 4), t4 = i % (kRound / 4);
-				v4i_ v = {(int)nbins, (int)nbins, (int)nbins, (int)nbins};          // (queries past n_q: never stored)
-				if (q0 + q < n_q && base + 4 * t4 < q_pitch) v = *reinterpret_cast<const v4i_*>(q_rk + (uint64_t)q_slots[q0 + q] * q_pitch + base + 4 * t4);
-				sQ[q][t4] = v;
+		// the compiler must see these loads complete HERE: its scoreboard knows nothing of the DMA pieces issued from inline asm, and a
+		// wait of its own inside the loop would drain them
+#pragma unroll
+		for (uint32_t c = 0; c < kCandPerWave; c++)
+#pragma unroll
+			for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a[c][j]));
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		// half-group h = queries 8 h .. 8 h + 7 -> ring slot h % 2: each wave moves 8 of its 32 pieces of 1 KiB (a quarter of a list's round)
+		auto stage = [&](uint32_t h) {
+#pragma unroll
+			for (uint32_t i = 0; i < 8; i++) {
+				const uint32_t id = wave * 8 + i, q = id >> 2, part = id & 3;
+				const uint32_t qi = h * kQHalf + q;
+				if (qi < n_q && base + 256 * part < q_pitch)
+					dma_piece((uint64_t)(q_rk + (uint64_t)q_slots[qi] * q_pitch + base + 256 * part), lane * 16u, lds0 + (((h & 1) * kQHalf + q) * (kRound / 4) + 64 * part) * 16);
+				else
+					sQ[h & 1][q][64 * part + lane] = pad;          // (queries past n_q: never stored; parts past the pitch: | x - nbins | is the tail term)
 			}
-			__syncthreads();
-			uint32_t nq_max = 0;
+		};
+		stage(0);
+		uint32_t sum[kCandPerWave][kQGroup];
+		uint32_t nq_max = 0;
+		for (uint32_t h = 0; h < n_halves; h++) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of half-group h have landed (and its stores have left)
+			__syncthreads();                                           // everybody's have, and everybody is done with half-group h - 1
+			if (h + 1 < n_halves) stage(h + 1);
+			if ((h & 1) == 0) {
+				nq_max = 0;
+				for (uint32_t q = 0; q < kQGroup; q++) {
+					const uint32_t qi = (h >> 1) * kQGroup + q;
+					const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
+					nq_max = v > nq_max ? v : nq_max;
+				}
+			}
 #pragma unroll
-			for (uint32_t q = 0; q < kQGroup; q++) nq_max = s_nq[q] > nq_max ? s_nq[q] : nq_max;
-			uint32_t sum[kCandPerWave][kQGroup];
-#pragma unroll
-			for (uint32_t q = 0; q < kQGroup; q++) {
+			for (uint32_t q = 0; q < kQHalf; q++) {
 				v4i_ b[4];
 #pragma unroll
-				for (int j = 0; j < 4; j++) b[j] = sQ[q][64 * j + lane];
+				for (int j = 0; j < 4; j++) b[j] = sQ[h & 1][q][64 * j + lane];
 #pragma unroll
 				for (uint32_t c = 0; c < kCandPerWave; c++) {
 					uint32_t t = 0;          // nbins <= 2^20: 16 terms fit 32 bits, and so do the 64 lanes' in the fold
@@ -155,20 +192,25 @@ __global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict
 						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
 						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
 					}
-					sum[c][q] = t;
+					if (h & 1) sum[c][kQHalf + q] = t; else sum[c][q] = t;
 				}
 			}
-			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
+			if (h & 1) {
+				const uint32_t q0 = (h >> 1) * kQGroup;
+				const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
 #pragma unroll
-			for (uint32_t c = 0; c < kCandPerWave; c++) {
-				const uint32_t tot = fold16q(sum[c]);
-				// past every list of this candidate and group all terms are | nbins - nbins |: nothing to add
-				if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
-					uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
-					*o = base ? *o + tot : (uint64_t)tot;
+				for (uint32_t c = 0; c < kCandPerWave; c++) {
+					const uint32_t tot = fold16q(sum[c]);
+					// past every list of this candidate and group all terms are | nbins - nbins |: nothing to add
+					if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
+						uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
+						*o = base ? *o + tot : (uint64_t)tot;
+					}
 				}
 			}
 		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();          // the ring is free for the next round's first half-group
 	}
 }
 
