@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 matrix rate: 2 x the bf16 rate per clock (same guide, Matrix cores: bf16 ~2.5 PF dense)
 
 
 def parse():
@@ -56,7 +57,7 @@ def parse():
                          "rank builds the block's histograms itself, bit-identical to the owner's) or their HISTOGRAMS as they sit in HBM (4^k x sizeof(T) "
                          "bytes each: SURVEY 8(e)'s exchange -- at 1 MiB per query the ring all-gather takes longer than scoring the block once the pass "
                          "runs on the matrix cores)")
-    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 256 (64 off the matrix cores), "
+    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 128 (64 off the matrix cores), "
                                                              "one pass over the candidates each -- a step of 16 blocks keeps the per-step exchange and host work of an 8-rank run "
                                                              "(12 500 candidates per rank) small next to the scoring")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
@@ -459,11 +460,11 @@ def main():
     # Per-rank figures (rank 0's shard: M candidates).
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
-    on_mfma = kernel.startswith("k_pair_gemm_x8")
-    qblk = int(os.environ.get("MSC_GEMM_BLOCK", "256"))          # queries per pass over the candidates on the matrix cores (the library's block)
-    qblk = qblk if qblk in (64, 128) else 256
-    if on_mfma:   # everything from the matrix cores: the pass reads the x8 mirror, one byte per bin, once per block of up to 256 queries
-        hist_bytes = 4 ** args.k
+    on_mfma = kernel.startswith("k_pair_gemm_bits")
+    qblk = int(os.environ.get("MSC_GEMM_BLOCK", "128"))          # queries per pass over the candidates on the matrix cores (the library's block)
+    qblk = qblk if qblk in (64, 256) else 128
+    if on_mfma:   # everything from the matrix cores: the pass reads the presence-bit mirror, one BIT per bin, once per block of up to 128 queries
+        hist_bytes = 4 ** args.k // 8
     elif "no emd" in kernel or "emd by ranks" in kernel:   # count-only form of the digest kernel: the prefix half of each tile is not fetched
         hist_bytes //= 2
     if args.layout == "sparse":            # a pair reads the candidate's entry list: 8 bytes per stored bin (mean over a sample of slots)
@@ -473,7 +474,7 @@ def main():
     if args.mode == "allpairs" and args.layout == "sparse":
         per_call = Q * (M + 1) * hist_bytes          # one 1 x M merge pass per query
     elif args.mode == "allpairs":
-        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 256: a call with more queries is that many passes)
+        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 128: a call with more queries is that many passes)
     else:
         per_call = (M + 1) * hist_bytes
     # one timed call may be several launches of the streaming kernel (candidate chunks): report per launch
@@ -514,15 +515,26 @@ def main():
                    "queries_per_candidate_read": qtile},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
+                     "algorithmic_GBps": achieved,
                      # what the hardware did, from the committed counter passes of this command (null without a matching profile):
                      # hbm_frac = PMC HBM bytes per launch / launch time / peak (frac above prices the TILE reads of the kernel as it
                      # is tiled -- query groups that share a candidate mostly hit in L2); valu_busy = VALU cycles / busy cycles
                      "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms == avg_ms else None, "valu_busy": valu_busy,
-                     # a call scores its queries in blocks of 256 (matrix cores) or 64 (one pass over the candidates each) and may cut a pass into candidate chunks
+                     # a call scores its queries in blocks of 128 (matrix cores) or 64 (one pass over the candidates each) and may cut a pass into candidate chunks
                      "candidates_per_launch": int(round(M * calls_per_launch * (-(-Q // (qblk if on_mfma else 64)) if args.mode == "allpairs" and args.layout == "dense" else 1))),
                      "query_groups_per_launch": -(-min(Q, qblk if on_mfma else 64) // qtile) if args.mode == "allpairs" else 1,
                      "profile_key": config_key},
     }
+    if on_mfma and args.mode == "allpairs" and avg_ms == avg_ms:
+        # The pass on the matrix cores is bound by the int8 matrix pipe, not by HBM (it streams one bit per bin): 4^k multiply-adds per
+        # pair = 2 * 4^k integer operations; a launch scores (candidates of the launch) x (rows of its query block, padded rows included
+        # in the work the pipe does but NOT in the operations counted here).
+        pairs_per_launch = float(M) * Q * len(tiles_ms) / n_launch
+        ops = 2.0 * pairs_per_launch * (4 ** args.k)
+        tops = ops / (avg_ms * 1e-3) / 1e12
+        line["roofline"].update({"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_I8_PEAK_TOPS,
+                                 "ops": "int8 multiply-adds counted as 2 operations each (v_mfma_i32_32x32x32_i8), exact int32 sums",
+                                 "algorithmic_ops_per_launch": ops})
     if args.check:
         line["check"] = checks
     if rank == 0:

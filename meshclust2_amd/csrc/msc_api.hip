@@ -134,12 +134,12 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->shard_gather) msc_hist_set_destroy(ctx->shard_gather);
 	release(ctx->shard_payload);
 	release(ctx->shard_hdrs);
-	release(ctx->x8_fimg);
-	release(ctx->x8_qT);
-	release(ctx->x8_hot);
-	release(ctx->x8_hot_idx);
-	release(ctx->x8_min);
-	release(ctx->x8_diff);
+	release(ctx->kb_abits);
+	release(ctx->kb_qT);
+	release(ctx->kb_hot);
+	release(ctx->kb_hot_idx);
+	release(ctx->kb_min);
+	release(ctx->kb_diff);
 	release(ctx->emd_out);
 	release(ctx->close_counts);
 	release(ctx->rk_bad);
@@ -422,10 +422,9 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->bins) (void)hipFree(s->bins);
 	if (s->scalars) (void)hipFree(s->scalars);
 	if (s->digest) (void)hipFree(s->digest);
-	if (s->x8) (void)hipFree(s->x8);
+	if (s->kb) (void)hipFree(s->kb);
 	if (s->mb) (void)hipFree(s->mb);
 	if (s->mb_n) (void)hipFree(s->mb_n);
-	if (s->mb_big) (void)hipFree(s->mb_big);
 	if (s->ranks) (void)hipFree(s->ranks);
 	if (s->rk_n) (void)hipFree(s->rk_n);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
@@ -441,7 +440,7 @@ extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype :
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
 	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
-	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->x8 ? s->L.padded_bins + 32 + (uint64_t)s->mb_pitch * 8 + 8 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
+	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->kb ? s->L.padded_bins / 8 + 32 + (uint64_t)s->mb_pitch * 8 + 4 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
 // every writer of slots ends here: both mirrors of a dense set (digest, sparse lists) are stale for [first, first + n)
@@ -455,9 +454,9 @@ static void mark_stale(msc_hist_set* s, uint64_t first, uint64_t n) {
 		if (s->sm_lo >= s->sm_hi) { s->sm_lo = first; s->sm_hi = first + n; }
 		else { s->sm_lo = std::min(s->sm_lo, first); s->sm_hi = std::max(s->sm_hi, first + n); }
 	}
-	if (s->x8) {
-		if (s->x8_lo >= s->x8_hi) { s->x8_lo = first; s->x8_hi = first + n; }
-		else { s->x8_lo = std::min(s->x8_lo, first); s->x8_hi = std::max(s->x8_hi, first + n); }
+	if (s->kb) {
+		if (s->kb_lo >= s->kb_hi) { s->kb_lo = first; s->kb_hi = first + n; }
+		else { s->kb_lo = std::min(s->kb_lo, first); s->kb_hi = std::max(s->kb_hi, first + n); }
 	}
 	if (s->ranks) {
 		if (s->rk_lo >= s->rk_hi) { s->rk_lo = first; s->rk_hi = first + n; }
@@ -1687,57 +1686,53 @@ static int ensure_digest(msc_ctx* ctx, const msc_hist_set* set) {
 	return MSC_OK;
 }
 
-// The x8 mirror of a dense set and its lists of large bins (msc_pair_gemm.hip): the operands of the int8 product that takes the Q x M
-// pass. MSC_OK with set->x8 == nullptr when it cannot be had (no memory): the older routes then run.
-static int ensure_x8(msc_ctx* ctx, const msc_hist_set* set) {
-	if (set->sparse || set->x8_unavailable || set->dtype == 64) return MSC_OK;
+// The presence-bit mirror of a dense set and its lists of large bins (msc_pair_gemm.hip): the operands of the int8 product that takes the
+// Q x M pass. MSC_OK with set->kb == nullptr when it cannot be had (no memory): the older routes then run.
+static int ensure_kb(msc_ctx* ctx, const msc_hist_set* set) {
+	if (set->sparse || set->kb_unavailable || set->dtype == 64) return MSC_OK;
 	auto give_up = [&] {
 		(void)hipGetLastError();
-		if (set->x8) (void)hipFree(set->x8);
+		if (set->kb) (void)hipFree(set->kb);
 		if (set->mb) (void)hipFree(set->mb);
 		if (set->mb_n) (void)hipFree(set->mb_n);
-		if (set->mb_big) (void)hipFree(set->mb_big);
-		set->x8 = nullptr; set->mb = nullptr; set->mb_n = set->mb_big = nullptr;
-		set->x8_unavailable = true;
+		set->kb = nullptr; set->mb = nullptr; set->mb_n = nullptr;
+		set->kb_unavailable = true;
 		return MSC_OK;
 	};
-	if (!set->x8) {
-		void *p = nullptr, *pm = nullptr, *pn = nullptr, *pb = nullptr;
+	if (!set->kb) {
+		void *p = nullptr, *pm = nullptr, *pn = nullptr;
 		set->mb_pitch = 16;
-		if (hipMalloc(&p, msc_x8_bytes(set->L, set->capacity)) != hipSuccess) return give_up();
-		set->x8 = (uint8_t*)p;
+		if (hipMalloc(&p, msc_kb_bytes(set->L, set->capacity)) != hipSuccess) return give_up();
+		set->kb = (uint8_t*)p;
 		if (hipMalloc(&pm, (size_t)set->capacity * set->mb_pitch * 8) != hipSuccess) return give_up();
 		set->mb = pm;
 		if (hipMalloc(&pn, (size_t)set->capacity * 4) != hipSuccess) return give_up();
 		set->mb_n = (uint32_t*)pn;
-		if (hipMalloc(&pb, (size_t)set->capacity * 4) != hipSuccess) return give_up();
-		set->mb_big = (uint32_t*)pb;
 		HIP_TRY(ctx, hipMemsetAsync(set->mb_n, 0, (size_t)set->capacity * 4, ctx->stream));
-		HIP_TRY(ctx, hipMemsetAsync(set->mb_big, 0, (size_t)set->capacity * 4, ctx->stream));
 		set->mb_n_host.assign(set->capacity, 0);
-		set->x8_lo = 0;
-		set->x8_hi = set->capacity;
+		set->kb_lo = 0;
+		set->kb_hi = set->capacity;
 	}
-	while (set->x8_lo < set->x8_hi) {
+	while (set->kb_lo < set->kb_hi) {
 		// runs of slots that hold a histogram; the build reports a zero count (sticky: the pass's identities take count - 1 of every
 		// bin) and the longest list of large bins it met: past the pitch, the lists are laid out again and every written slot rebuilt
 		int r;
 		if ((r = ensure(ctx, ctx->rk_bad, 2 * sizeof(int32_t)))) return r;
 		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, 2 * sizeof(int32_t), ctx->stream));
-		const uint64_t lo = set->x8_lo, hi = std::min<uint64_t>(set->x8_hi, set->written.size());
+		const uint64_t lo = set->kb_lo, hi = std::min<uint64_t>(set->kb_hi, set->written.size());
 		for (uint64_t i = lo; i < hi;) {
 			if (!set->written[i]) { i++; continue; }
 			uint64_t j = i;
 			while (j < hi && set->written[j]) j++;
-			HIP_TRY(ctx, msc_launch_x8_build(ctx->stream, set->L, set->dtype, set->bins, set->x8, i, j - i, set->mb, set->mb_n, set->mb_big, set->mb_pitch, (int32_t*)ctx->rk_bad.p));
+			HIP_TRY(ctx, msc_launch_kb_build(ctx->stream, set->L, set->dtype, set->bins, set->kb, i, j - i, set->mb, set->mb_n, set->mb_pitch, (int32_t*)ctx->rk_bad.p));
 			i = j;
 		}
 		int32_t flags[2] = {0, 0};
 		HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->rk_bad.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
 		if (hi > lo) HIP_TRY(ctx, hipMemcpyAsync(set->mb_n_host.data() + lo, set->mb_n + lo, (hi - lo) * 4, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (flags[0]) set->x8_has_zero = true;
-		set->x8_lo = set->x8_hi = 0;
+		if (flags[0]) set->kb_has_zero = true;
+		set->kb_lo = set->kb_hi = 0;
 		if ((uint32_t)flags[1] > set->mb_pitch) {
 			const uint32_t pitch = ((uint32_t)flags[1] + 15) / 16 * 16;
 			void* pm = nullptr;
@@ -1746,8 +1741,8 @@ static int ensure_x8(msc_ctx* ctx, const msc_hist_set* set) {
 			if (hipMalloc(&pm, (size_t)set->capacity * pitch * 8) != hipSuccess) return give_up();
 			set->mb = pm;
 			set->mb_pitch = pitch;
-			set->x8_lo = 0;
-			set->x8_hi = set->capacity;
+			set->kb_lo = 0;
+			set->kb_hi = set->capacity;
 		}
 	}
 	return MSC_OK;
@@ -1804,15 +1799,15 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 }
 
 // Whether the pass on the matrix cores (msc_pair_gemm.hip) can take a Q x M call over these sets -- host-side bounds only: dense 8/16/32-bit
-// sets of the narrow range whose histograms are whole 4 KiB tiles, P1 / P2 within int32 (at most 127 x the k-mers of a sequence) and, when
+// sets of the narrow range whose histograms are whole 4 KiB tiles, P1 / P2 within int32 and, when
 // the earth mover's distance is wanted, lists short enough for the ranks mirror (msc_emd_ranks.hip).
-static bool x8_route_fits(const msc_hist_set* cands, const msc_hist_set* qset, bool need_emd) {
+static bool kb_route_fits(const msc_hist_set* cands, const msc_hist_set* qset, bool need_emd) {
 	static const bool off = getenv("MSC_MULTI_NO_GEMM") != nullptr;
 	static const bool no_ranks = getenv("MSC_MULTI_NO_RANKS") != nullptr;
 	const MscLayout& L = cands->L;
 	if (off || cands->sparse || qset->sparse || cands->dtype == 64 || L.nbins != L.padded_bins || !msc_digest_supported(L) || needs_wide(cands, qset)) return false;
 	const uint64_t ms_ = std::max(cands->max_sum, qset->max_sum);
-	if (ms_ < L.nbins || (ms_ - L.nbins) * 127 >= (1ull << 31)) return false;
+	if (ms_ < L.nbins || ms_ - L.nbins >= (1ull << 31)) return false;
 	if (need_emd && (no_ranks || L.nbins > (1ull << 20) || (ms_ - L.nbins) * 4 > L.nbins)) return false;
 	return true;
 }
@@ -1833,11 +1828,11 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	const bool need_emd = (want & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
-	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 256 queries per read of a candidate byte; the older routes 64
-	bool x8_fit = !ctx->no_x8_now && n_q >= 2 && x8_route_fits(cands, qset, need_emd);
-	if (x8_fit) {
-		if ((r = ensure_x8(ctx, cands)) || (r = ensure_x8(ctx, qset))) return r;
-		x8_fit = cands->x8 && qset->x8 && !cands->x8_has_zero && !qset->x8_has_zero;
+	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 128 queries per pass over the candidates' bits (256 with MSC_GEMM_BLOCK: two waves per SIMD instead of four, measured slower); the older routes 64
+	bool kb_fit = !ctx->no_kb_now && n_q >= 2 && kb_route_fits(cands, qset, need_emd);
+	if (kb_fit) {
+		if ((r = ensure_kb(ctx, cands)) || (r = ensure_kb(ctx, qset))) return r;
+		kb_fit = cands->kb && qset->kb && !cands->kb_has_zero && !qset->kb_has_zero;
 	}
 	// close candidates per query, kept on the device for msc_last_close_counts (a caller that only needs the counts of a block of the
 	// pairwise matrix does not have to add up n_q x m flags on the host)
@@ -1848,8 +1843,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ctx->close_counts_n = n_q;
 		ctx->close_counts_base = 0;
 	} else if (top_level) { ctx->close_counts_n = 0; ctx->close_counts_base = 0; }
-	static const uint64_t x8_blk = [] { const char* e = getenv("MSC_GEMM_BLOCK"); const int v = e ? atoi(e) : 256; return (uint64_t)(v == 64 || v == 128 ? v : 256); }();
-	const uint64_t blk = x8_fit ? x8_blk : 64;
+	static const uint64_t kb_blk = [] { const char* e = getenv("MSC_GEMM_BLOCK"); const int v = e ? atoi(e) : 128; return (uint64_t)(v == 64 || v == 256 ? v : 128); }();
+	const uint64_t blk = kb_fit ? kb_blk : 64;
 	if (n_q > blk) {
 		// blocks of queries: the unit of the pass on the matrix cores (a 128-row operand) and of the digest kernel (four groups of 16);
 		// msc_last_kernel_ms / _launches then cover the whole call
@@ -2012,14 +2007,14 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	// The earth mover's distance from sorted k-mer ranks (msc_emd_ranks.hip) -- O(k-mers) per pair instead of O(bins): while the
 	// longest list is a quarter of the bins or less, for up to 256 queries and 2^20 bins (32-bit wave sums)
 	const bool ranks_fit = !no_ranks && !tuned_by_hand && n_q <= 256 && L.nbins <= (1ull << 20) && ms_ >= L.nbins && (ms_ - L.nbins) * 4 <= L.nbins && msc_digest_supported(L);
-	// EVERYTHING on the matrix cores (msc_pair_gemm.hip): one int8 product per tile of bins over the x8 mirrors + corrections from the
+	// EVERYTHING on the matrix cores (msc_pair_gemm.hip): one int8 product per tile of bins over the presence-bit mirrors + corrections from the
 	// lists of large bins -- exact for any counts of the narrow range; one read of a candidate byte per 256 queries, no partial records.
 	// The queries' large bins become this block's hot list: its size is known here (the lists' lengths are mirrored on the host), and
 	// a block whose list would average more than 64 entries per 128-bin step (long sequences in few bins: the walk over the list would
 	// then take several times the step's product) is left to the older routes.
 	bool manh_gemm = false, emd_ranks = false;
 	uint64_t n_hot = 0;
-	if (x8_fit && simple && !tuned_by_hand && !no_digest) {
+	if (kb_fit && simple && !tuned_by_hand && !no_digest) {
 		for (uint64_t q = 0; q < n_q; q++) n_hot += std::min(qset->mb_n_host[q_slots[q]], qset->mb_pitch);
 		manh_gemm = n_hot <= 64 * (L.nbins / 128);
 		if (manh_gemm && need_emd) {
@@ -2028,9 +2023,9 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		}
 	}
 	if (!manh_gemm && n_q > 64) {          // (a block of up to 256 was cut for the matrix cores: the older routes take it in blocks of 64)
-		ctx->no_x8_now = true;
+		ctx->no_kb_now = true;
 		r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
-		ctx->no_x8_now = false;
+		ctx->no_kb_now = false;
 		return r;
 	}
 	// Digest form (pair_digest.hip): sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen (or 32)
@@ -2044,7 +2039,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if ((r = ensure_digest(ctx, cands)) || (r = ensure_digest(ctx, qset))) return r;
 		digest = cands->digest && qset->digest;
 	}
-	const bool gemm_dot = false;          // (r03's digest forms without their products took them from an int8 GEMM over a count mirror: the x8 route replaced both)
+	const bool gemm_dot = false;          // (r03's digest forms without their products took them from an int8 GEMM over a count mirror: the presence-bit route replaced both)
 	// LDS-DMA ring form over the raw bins: 32/64-bit bins, compact totals, query groups of four or eight
 	static const bool no_ring = getenv("MSC_MULTI_NO_RING") != nullptr;
 	if (!digest && !manh_gemm && n_q >= 16 && !getenv("MSC_MULTI_TQ") && (cands->dtype == 32 || cands->dtype == 64)) tq = 8;      // measured best from 16 queries up
@@ -2066,8 +2061,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	const uint64_t q_rows = digest ? (n_q + 4 * dg_tq - 1) / (4 * dg_tq) * (4 * dg_tq) : ring ? (n_q + tq - 1) / tq * tq : n_q;       // records cover the padded query count
 	uint64_t chunk = (4096ull << 20) / ((uint64_t)n_rec * rec_bytes * q_rows);
 	// (no records without the digest kernel: the product array of the GEMM, [slices][chunk][rows] int32, kept to 2 GiB)
-	const uint32_t x8_qn = manh_gemm ? msc_pair_gemm_rows((uint32_t)n_q) : 0;
-	if (manh_gemm) chunk = (2048ull << 20) / ((uint64_t)msc_pair_gemm_slices(L.nbins, (uint32_t)std::min<uint64_t>(m, 1u << 30), x8_qn, ctx->num_cus) * x8_qn * sizeof(int32_t));
+	const uint32_t kb_qn = manh_gemm ? msc_pair_gemm_rows((uint32_t)n_q) : 0;
+	if (manh_gemm) chunk = (2048ull << 20) / ((uint64_t)msc_pair_gemm_slices(L.nbins, (uint32_t)std::min<uint64_t>(m, 1u << 30), kb_qn, ctx->num_cus) * kb_qn * sizeof(int32_t));
 	if (want_grp) chunk = std::min<uint64_t>(chunk, (1024ull << 20) / (n_q * 32 * sizeof(double)));      // [n_q][chunk][16][2] group records: 1 GiB
 	chunk = std::min(std::max<uint64_t>(chunk, 256), m);
 	chunk = (m + (m + chunk - 1) / chunk - 1) / ((m + chunk - 1) / chunk);
@@ -2092,26 +2087,26 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
 	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
-	const uint32_t gemm_slices = manh_gemm ? msc_pair_gemm_slices(L.nbins, (uint32_t)chunk, x8_qn, ctx->num_cus) : 0;
+	const uint32_t gemm_slices = manh_gemm ? msc_pair_gemm_slices(L.nbins, (uint32_t)chunk, kb_qn, ctx->num_cus) : 0;
 	uint32_t *hot_ptr = nullptr, *hot_cursor = nullptr, *hot_cnt = nullptr;
 	if (manh_gemm) {
-		const uint64_t img = msc_pair_gemm_image_bytes(L.nbins, x8_qn), nsteps = L.nbins / 128;
-		if ((r = ensure(ctx, ctx->x8_fimg, img)) || (r = ensure(ctx, ctx->x8_qT, img)) || (r = ensure(ctx, ctx->x8_min, (size_t)gemm_slices * chunk * x8_qn * sizeof(int32_t)))) return r;
+		const uint64_t nsteps = L.nbins / 128;
+		if ((r = ensure(ctx, ctx->kb_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, ctx->kb_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, ctx->kb_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
 		if (n_hot) {
-			if ((r = ensure(ctx, ctx->x8_hot, n_hot * 8)) || (r = ensure(ctx, ctx->x8_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
-			    (r = ensure(ctx, ctx->x8_diff, chunk * x8_qn * sizeof(int32_t)))) return r;
-			hot_ptr = (uint32_t*)ctx->x8_hot_idx.p;
+			if ((r = ensure(ctx, ctx->kb_hot, n_hot * 8)) || (r = ensure(ctx, ctx->kb_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
+			    (r = ensure(ctx, ctx->kb_diff, chunk * kb_qn * sizeof(int32_t)))) return r;
+			hot_ptr = (uint32_t*)ctx->kb_hot_idx.p;
 			hot_cursor = hot_ptr + (nsteps + 1);
 			hot_cnt = hot_cursor + (nsteps + 1);
 		}
 		// the queries' side of the block, once for all chunks of candidates
-		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->x8, qset->mb, qset->mb_n, qset->mb_pitch, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, x8_qn,
-		                                          (uint8_t*)ctx->x8_fimg.p, (uint8_t*)ctx->x8_qT.p, n_hot, ctx->x8_hot.p, hot_ptr, hot_cursor, hot_cnt));
+		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, kb_qn,
+		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)ctx->kb_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt));
 	}
-	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? x8_qn : 64) * sizeof(uint64_t)))) return r;
+	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? kb_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
 	if (manh_gemm) {
-		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_gemm_x8<%u query rows, one int8 product per tile%s>", x8_qn, emd_ranks ? ", emd by ranks" : ", no emd");
+		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_gemm_bits<%u query rows, one int8 product per tile of presence bits%s>", kb_qn, emd_ranks ? ", emd by ranks" : ", no emd");
 		ctx->last_kernel = ctx->last_kernel_buf;
 	} else if (digest) {
 		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_digest_multi<%s counts%s%s>", mc_ < 256 ? "u8" : "u16",
@@ -2130,8 +2125,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
-			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->x8, d_slots, off, mc, (const uint8_t*)ctx->x8_fimg.p, x8_qn, gemm_slices, hot_ptr, ctx->x8_hot.p,
-			                                  (int32_t*)ctx->x8_min.p, (int32_t*)ctx->x8_diff.p));
+			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)ctx->kb_abits.p, kb_qn, gemm_slices, hot_ptr, ctx->kb_hot.p,
+			                                  (int32_t*)ctx->kb_min.p, (int32_t*)ctx->kb_diff.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
@@ -2144,7 +2139,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
 		if (emd_ranks)
 			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
-			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? x8_qn : 64));
+			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
 		if (want_div) {
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
@@ -2178,16 +2173,15 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
 		if (manh_gemm) {
-			ea.x8_min = (const int32_t*)ctx->x8_min.p;
-			ea.x8_diff = n_hot ? (const int32_t*)ctx->x8_diff.p : nullptr;
-			ea.x8_slices = gemm_slices;
-			ea.x8_qn = x8_qn;
-			ea.x8_first = cand_slots ? 0 : off;
-			ea.x8_c_mb = cands->mb; ea.x8_c_mb_n = cands->mb_n; ea.x8_c_pitch = cands->mb_pitch;
-			ea.x8_q_mb = qset->mb; ea.x8_q_mb_n = qset->mb_n; ea.x8_q_mb_big = qset->mb_big; ea.x8_q_pitch = qset->mb_pitch;
-			ea.x8_qT = (const uint8_t*)ctx->x8_qT.p;
-			ea.x8_cand = cands->x8;
-			ea.emd_stride = x8_qn;
+			ea.kb_min = (const int32_t*)ctx->kb_min.p;
+			ea.kb_diff = n_hot ? (const int32_t*)ctx->kb_diff.p : nullptr;
+			ea.kb_slices = gemm_slices;
+			ea.kb_qn = kb_qn;
+			ea.kb_first = cand_slots ? 0 : off;
+			ea.kb_c_mb = cands->mb; ea.kb_c_mb_n = cands->mb_n; ea.kb_c_pitch = cands->mb_pitch;
+			ea.kb_q_mb = qset->mb; ea.kb_q_mb_n = qset->mb_n; ea.kb_q_pitch = qset->mb_pitch;
+			ea.kb_qT = (const uint8_t*)ctx->kb_qT.p;
+			ea.emd_stride = kb_qn;
 		}
 		ea.cq_group = 4 * dg_tq;
 		if (emd_ranks) ea.emd_ranks = (const uint64_t*)ctx->emd_out.p;

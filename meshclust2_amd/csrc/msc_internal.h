@@ -76,21 +76,19 @@ struct MscEpilogueArgs {
 	const int32_t* dot_gemm;          // with partials_cq: the products from msc_dot_gemm.hip instead, [dot_slices][m_per_query][dot_stride] (query q at [q]);
 	                                  // the records of partials_cq are then 8 bytes (manh, emd)
 	uint32_t dot_slices, dot_stride;
-	// the r04 pass on the matrix cores (msc_pair_gemm.hip, k_pair_epilogue_x8): P1 per slice and P2 of the block, the lists of large
-	// bins (e = count - 1 >= 2) of both sets, the queries' clamped bytes [bin][x8_qn], the candidates' mirror (msc_x8.h)
-	const int32_t* x8_min;            // [x8_slices][m_per_query][x8_qn]; non-null selects k_pair_epilogue_x8
-	const int32_t* x8_diff;           // [m_per_query][x8_qn], or null when no query of the block has a large bin
-	uint32_t x8_slices, x8_qn;
-	uint64_t x8_first;                // slot of candidate 0 when cand_slots is null (cand_scalars is then already offset to it)
-	const void* x8_c_mb;              // uint2 (bin, e) [slot][x8_c_pitch]
-	const uint32_t* x8_c_mb_n;
-	uint32_t x8_c_pitch;
-	const void* x8_q_mb;
-	const uint32_t* x8_q_mb_n;
-	const uint32_t* x8_q_mb_big;      // per slot: entries with e >= 127
-	uint32_t x8_q_pitch;
-	const uint8_t* x8_qT;
-	const uint8_t* x8_cand;           // the candidates' x8 mirror
+	// the r04 pass on the matrix cores (msc_pair_gemm.hip, k_pair_epilogue_bits): P1 per slice and P2 of the block, the lists of large
+	// bins (e = count - 1 >= 2) of both sets, the queries' counts [bin][kb_qn] (bytes, clamped at 127)
+	const int32_t* kb_min;            // [kb_slices][m_per_query][kb_qn]; non-null selects k_pair_epilogue_bits
+	const int32_t* kb_diff;           // [m_per_query][kb_qn], or null when no query of the block has a large bin
+	uint32_t kb_slices, kb_qn;
+	uint64_t kb_first;                // slot of candidate 0 when cand_slots is null (cand_scalars is then already offset to it)
+	const void* kb_c_mb;              // uint2 (bin, e) [slot][kb_c_pitch]
+	const uint32_t* kb_c_mb_n;
+	uint32_t kb_c_pitch;
+	const void* kb_q_mb;
+	const uint32_t* kb_q_mb_n;
+	uint32_t kb_q_pitch;
+	const uint8_t* kb_qT;
 	uint32_t emd_stride;              // entries per candidate of emd_ranks (0 = 64)
 	const void* div_partials;         // [m][S] {jd, js} doubles, or null when no divergence statistic is requested
 	uint32_t S;
@@ -193,17 +191,18 @@ hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype,
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
                                 uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out,
                                 uint32_t out_stride = 64);
-// the r04 form of that pass (msc_pair_gemm.hip): x8 mirror + lists of large bins, the queries' side of a block, the product
-uint64_t msc_x8_bytes(const MscLayout& L, uint64_t capacity);
-hipError_t msc_launch_x8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* x8, uint64_t first_slot, uint64_t n_slots, void* mb,
-                               uint32_t* mb_n, uint32_t* mb_big, uint32_t pitch, int32_t* flags);
+// the r04 form of that pass (msc_pair_gemm.hip): presence-bit mirror + lists of large bins, the queries' side of a block, the product
+uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity);
+hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* kb, uint64_t first_slot, uint64_t n_slots, void* mb,
+                               uint32_t* mb_n, uint32_t pitch, int32_t* flags);
 uint32_t msc_pair_gemm_rows(uint32_t n_q);
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
-uint64_t msc_pair_gemm_image_bytes(uint64_t nbins, uint32_t qn);
-hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_x8, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
-                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* fimg, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
+uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn);
+uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn);
+hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_kb, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
+                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* abits, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
                                         uint32_t* hot_cursor, uint32_t* hot_cnt);
-hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_x8, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* fimg,
+hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* abits,
                                 uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);

@@ -41,9 +41,9 @@ struct msc_ctx {
 	uint64_t sp_acc_bins = 0;
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
-	// msc_pair_gemm.hip: the queries' side of a block (flag image, transposed bytes, hot list + its three step arrays), P1 per slice, P2
-	DevBuf x8_fimg, x8_qT, x8_hot, x8_hot_idx, x8_min, x8_diff;
-	bool no_x8_now = false;                // msc_score_multi: this block is taken by the older routes (its hot list would be too long)
+	// msc_pair_gemm.hip: the queries' side of a block (bit image, transposed counts, hot list + its three step arrays), P1 per slice, P2
+	DevBuf kb_abits, kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff;
+	bool no_kb_now = false;                // msc_score_multi: this block is taken by the older routes (its hot list would be too long)
 	DevBuf close_counts;                   // msc_score_multi: close candidates per query of the call in progress / the last call (msc_last_close_counts)
 	uint64_t close_counts_n = 0, close_counts_base = 0;
 	bool in_score_multi = false;
@@ -69,17 +69,16 @@ struct msc_hist_set {
 	mutable uint8_t* digest = nullptr;    // a cache: maintained through const handles
 	mutable uint64_t dg_lo = 0, dg_hi = 0;
 	mutable bool digest_unavailable = false;      // allocation failed once: do not retry every pass
-	// x8 mirror (msc_pair_gemm.hip, msc_x8.h): one byte per bin = min(count - 1, 127), slots blocked by 32 -- the B operand of the int8
-	// product of the Q x M pass -- and beside it the lists of large bins (count - 1 >= 2) that make the pass exact for any counts:
-	// mb[slot][mb_pitch] = (bin, count - 1), unordered; mb_n / mb_big = entries / entries with count - 1 >= 127 per slot (mb_n also on
-	// the host: the size of a query block's hot list is known without a read-back). slots [x8_lo, x8_hi) are stale (mark_stale)
-	mutable uint8_t* x8 = nullptr;
-	mutable uint64_t x8_lo = 0, x8_hi = 0;
-	mutable bool x8_unavailable = false;
-	mutable bool x8_has_zero = false;         // a slot with a zero count went into the mirror (never the case for built histograms and their means)
+	// presence-bit mirror (msc_pair_gemm.hip, msc_kbits.h): one BIT per bin = [count >= 2], slots blocked by 32 -- the B operand of the
+	// int8 product of the Q x M pass -- and beside it the lists of large bins (count - 1 >= 2) that make the pass exact for any counts:
+	// mb[slot][mb_pitch] = (bin, count - 1), unordered; mb_n = entries per slot (also on the host: the size of a query block's hot list is
+	// known without a read-back). slots [kb_lo, kb_hi) are stale (mark_stale)
+	mutable uint8_t* kb = nullptr;
+	mutable uint64_t kb_lo = 0, kb_hi = 0;
+	mutable bool kb_unavailable = false;
+	mutable bool kb_has_zero = false;         // a slot with a zero count went into the mirror (never the case for built histograms and their means)
 	mutable void* mb = nullptr;
 	mutable uint32_t* mb_n = nullptr;
-	mutable uint32_t* mb_big = nullptr;
 	mutable uint32_t mb_pitch = 0;
 	mutable std::vector<uint32_t> mb_n_host;
 	// ranks mirror (msc_emd_ranks.hip): per slot the bins of its counted k-mers in bin order (rk_pitch entries, padded with 4^k) and

@@ -1,51 +1,66 @@
-// msc_pair_gemm.hip -- the Q x M pass on the matrix cores (gfx950 MFMA), r04 form: ONE int8 matrix product per tile of bins, exact
-// for ANY counts.
+// msc_pair_gemm.hip -- the Q x M pass on the matrix cores (gfx950 MFMA), r04 form: ONE int8 matrix product per tile of bins over ONE
+// BIT per bin, exact for ANY counts.
 //
 // The pass needs three integer reductions per (query q, candidate c) (pair_features.hip): sum |q_i - c_i| (manhattan, intersection,
 // kulczynski2: predict/Feature.cpp:859-871,764-777,682-695), sum q_i c_i (euclidean, normalized_vectors, pearson, simratio:
 // :1113-1124,1171-1184,795-811,829-841) and the earth mover's distance (:1505-1518; msc_emd_ranks.hip). With excess counts
 // e = count - 1 (every bin starts at the pseudocount 1, nonltr/KmerHashTable.cpp:69-72):
 //     sum |q_i - c_i| = sum e_q + sum e_c - 2 sum min(e_q, e_c)          sum q_i c_i = 4^k + sum e_q + sum e_c + sum e_q e_c
-// An L-base sequence touches at most L of the 4^k bins, almost all of them ONCE: a 1 kb sequence at k = 9 has ~2 bins with e >= 2.
-// Where the candidate's excess is 0 or 1, min(e_q, e_c) = [e_q >= 1] e_c -- bilinear. So with the clamped bytes x = min(e, 127) and the
-// queries' flag bytes f = [e >= 1]:
-//     P1(q, c) = sum_i f_q(i) x_c(i)                  one v_mfma_i32_32x32x32_i8 per 32 queries x 32 candidates x 32 bins, nothing else
-//     sum min(e_q, e_c) = P1 + sum over the candidate's bins with e_c >= 2 of [ min(e_q, e_c) - f_q min(e_c, 127) ]
-//     sum e_q e_c       = P1 + P2 + sum over bins with e_q > 127 or e_c > 127 of [ e_q e_c - x_q x_c ],   P2 = sum_i (x_q(i) - f_q(i)) x_c(i)
-// The corrections run over SHORT LISTS, not over bins: per slot the (bin, e) pairs with e >= 2 ("large bins": ~2 per 1 kb sequence at
-// k = 9, one more per repeat unit), kept beside the mirror. The candidate's list is walked by the epilogue (k_pair_epilogue_x8 in
-// pair_features.hip: one coalesced read of the queries' bytes at that bin per entry); the queries' lists become a per-step "hot list"
-// this kernel consults while the candidates' bytes of that step sit in its registers (P2: one atomic add per (entry, candidate that
-// holds the k-mer) -- 0.4 % of the candidates at k = 9). Exact in integers for any counts the narrow range admits (<= 8191): the r03
-// form (thermometer levels) ran only while the LARGEST count of both whole sets was <= 16 -- one homopolymer run among 100 000
-// sequences sent every pair to the digest kernel at a fifth of the rate.
+// An L-base sequence touches at most L of the 4^k bins, almost all of them ONCE (a 1 kb sequence at k = 9 has ~2 bins with e >= 2), and
+// where both excesses are 0 or 1, min(e_q, e_c) = e_q e_c = f_q f_c with the presence bits f = [e >= 1]. Write e = f + g (g = e - 1
+// on the "large bins" e >= 2, else 0). Then, exactly:
+//     P1(q, c) = sum_i f_q(i) f_c(i)        the number of shared k-mers: one v_mfma_i32_32x32x32_i8 per 32 queries x 32 candidates x 32 bins
+//     sum min(e_q, e_c) = P1 + sum over bins large in BOTH of [ min(e_q, e_c) - 1 ]
+//     sum e_q e_c       = P1 + sum_i g_q(i) f_c(i)  +  sum over the candidate's large bins of g_c e_q
+//                              ^ P2: the queries' large bins      ^ walked by the epilogue
+// The corrections run over SHORT LISTS, not over bins: per slot the (bin, e) pairs with e >= 2 (~2 per 1 kb sequence at k = 9, one more per
+// repeat unit), kept beside the mirror. The candidate's list is walked by the epilogue (k_pair_epilogue_bits in pair_features.hip: per entry
+// one coalesced read of the queries' counts at that bin); the queries' lists become a per-step "hot list" this kernel consults while the
+// candidates' bits of that step sit in its registers (P2: one atomic add per (entry, candidate that holds the k-mer) -- 0.4 % of the
+// candidates at k = 9). Exact in integers for any counts of the narrow range (<= 8191): the r03 form (thermometer levels over a byte per
+// bin) ran only while the LARGEST count of both whole sets was <= 16 -- one homopolymer run among 100 000 sequences sent every pair to the
+// digest kernel at a fifth of the rate -- and streamed 8 x the bytes.
 //
-//   x8 mirror       msc_x8.h: a byte per bin, slots blocked by 32; + the lists of large bins (mb, pitch entries per slot, unordered)
-//   k_x8_gather     the queries' side of a block of <= QN queries: the flag bytes as the LDS image the GEMM stages (16-byte segments
-//                   XOR-swizzled so that a 32-row A operand read is conflict-free), and the clamped bytes transposed [bin][query] for
-//                   the epilogue's lookups
-//   k_hot_*         the queries' large bins bucketed by 128-bin step: (bin, query row, x - 1)
-//   k_pair_gemm_x8  workgroup = 128 candidates x QN queries x one slice of the bins; wave = 32 candidates x QN queries: QN / 32
-//                   accumulators of 32 x 32. Candidate bytes go from HBM straight into the B operand registers, one step ahead; the
-//                   queries' tile of a step (QN x 128 bytes) is staged once per workgroup in LDS. Per 32 x 32 x 32 tile: one
-//                   ds_read_b128 + one MFMA. Roofline: HBM -- a candidate byte is read once per QN queries.
-//   output          int32 P1 [slice][candidate][QN] (plain stores, the epilogue adds the slices), int32 P2 [candidate][QN] (atomics)
+//   kb mirror         msc_kbits.h: a bit per bin, slots blocked by 32; + the lists of large bins (mb, pitch entries per slot, unordered)
+//   k_kb_gather       the queries' side of a block of <= QN queries: their bits in the order the GEMM stages them (16 bytes per row and
+//                     128-bin step) and their counts transposed [bin][query] (bytes, 0 / 1 here) for the epilogue's lookups
+//   k_hot_*           the queries' large bins bucketed by 128-bin step: (bin, query row, e - 1); the fill also writes the counts of those
+//                     bins into the transposed image
+//   k_pair_gemm_bits  workgroup = 128 candidates x QN queries x one slice of the bins; wave = 32 candidates x QN queries: QN / 32
+//                     accumulators of 32 x 32. A lane loads 16 bytes of its candidate per 256 bins and expands 16 bits to the 16 bytes of
+//                     a B operand with 12 VALU operations (v_bfe, v_mul_u32_u24, v_and per dword), shared by the QN / 32 products of
+//                     that k-chunk; the queries' tile of a 128-bin step is expanded once per workgroup into LDS (16-byte segments
+//                     XOR-swizzled so that a 32-row A operand read is conflict-free). Per 32 x 32 x 32 tile: one ds_read_b128 + one MFMA.
+//                     Roofline: the int8 matrix pipe (5 POPS dense) -- 4^k multiply-adds per pair; HBM sees 4^k / 8 bytes per candidate
+//                     and QN queries.
+//   output            int32 P1 [slice][candidate][QN] (plain stores, the epilogue adds the slices), int32 P2 [candidate][QN] (atomics)
 #include "msc_internal.h"
 #include "msc_wave.h"
-#include "msc_x8.h"
+#include "msc_kbits.h"
 
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr uint32_t kStep = 128;          // bins per step
+constexpr uint32_t kStep = 128;          // bins per step of the queries' tile; the candidates' bits are loaded per 256 (two steps)
+
+// 16 presence bits -> the 16 bytes (0 / 1) of an MFMA operand: per dword one nibble, spread by a multiply (n * 0x204081 puts bit i of
+// the nibble at bit 8 i: the four shifted copies do not overlap) -- v_bfe_u32, v_mul_u32_u24, v_and_b32
+__device__ __forceinline__ v4i expand16(uint32_t hw) {
+	v4i r;
+#pragma unroll
+	for (int d = 0; d < 4; d++) r[d] = (int)(__umul24((hw >> (4 * d)) & 0xfu, 0x00204081u) & 0x01010101u);
+	return r;
+}
 
 // ------------------------------------------------------------------------------------------------ the mirror and its lists
-// 16 bins per thread. flags[0] |= 1 when a zero count is met (the identities above need every count >= 1: KmerHashTable's initial
-// value, and a mean of such histograms too); flags[1] = the longest list seen (the host re-lays the lists out when it passes the pitch).
+// 16 bins per thread = one halfword of the mirror. flags[0] |= 1 when a zero count is met (the identities above need every count >= 1:
+// KmerHashTable's initial value, and a mean of such histograms too); flags[1] = the longest list seen (the host re-lays the lists out
+// when it passes the pitch).
 template <typename T>
-__global__ void __launch_bounds__(256) k_x8_build(const T* __restrict__ bins, uint64_t nbins, uint8_t* __restrict__ x8, uint64_t first_slot, uint64_t n_slots,
-                                                  uint2* __restrict__ mb, uint32_t* __restrict__ mb_n, uint32_t* __restrict__ mb_big, uint32_t pitch, int32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(256) k_kb_build(const T* __restrict__ bins, uint64_t nbins, uint8_t* __restrict__ kb, uint64_t first_slot, uint64_t n_slots,
+                                                  uint2* __restrict__ mb, uint32_t* __restrict__ mb_n, uint32_t pitch, int32_t* __restrict__ flags) {
 	const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
 	if (i >= n_slots * nbins) return;
 	const uint64_t slot = first_slot + i / nbins, at = i % nbins;
@@ -54,7 +69,7 @@ __global__ void __launch_bounds__(256) k_x8_build(const T* __restrict__ bins, ui
 	const uint4* src = reinterpret_cast<const uint4*>(bins + slot * nbins + at);
 #pragma unroll
 	for (int v = 0; v < NV; v++) { const uint4 q = src[v]; raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w; }
-	uint32_t w[4] = {0, 0, 0, 0};
+	uint32_t hw = 0;
 	bool zero = false;
 #pragma unroll
 	for (int j = 0; j < 16; j++) {
@@ -64,37 +79,47 @@ __global__ void __launch_bounds__(256) k_x8_build(const T* __restrict__ bins, ui
 		else c = raw[j];
 		if (c == 0) { zero = true; continue; }
 		const uint32_t e = c - 1;
-		w[j >> 2] |= (e > MSC_X8_CAP ? MSC_X8_CAP : e) << (8 * (j & 3));
+		if (e) hw |= 1u << j;
 		if (e >= 2) {
 			const uint32_t pos = atomicAdd(&mb_n[slot], 1u);
 			if (pos < pitch) mb[slot * pitch + pos] = make_uint2((uint32_t)at + j, e);
 			atomicMax(&flags[1], (int32_t)(pos + 1));
-			if (e >= MSC_X8_CAP) atomicAdd(&mb_big[slot], 1u);
 		}
 	}
-	*reinterpret_cast<uint4*>(x8 + msc_x8_offset(slot, at, nbins)) = make_uint4(w[0], w[1], w[2], w[3]);
+	*reinterpret_cast<uint16_t*>(kb + msc_kb_offset(slot, at, nbins)) = (uint16_t)hw;
 	if (zero) atomicOr(&flags[0], 1);
 }
 
 // ------------------------------------------------------------------------------------------------ the queries' side of a block
-// One workgroup per 128-bin step. fimg[step][row][seg ^ ((row >> 1) & 7)] (16-byte segments; rows past n_q are zero) is the image
-// k_pair_gemm_x8 copies into LDS as it stands; qT[bin][row] the clamped bytes for the epilogue.
+// One workgroup per 128-bin step, one thread per query row. abits[step][row] = 8 halfwords, halfword 2 kc + h = the bits of bins
+// 32 kc + 16 h .. + 15 of the step (what lane half h feeds k-chunk kc); rows past n_q are zero. qT[bin][row] = 0 / 1 (k_hot_fill then
+// writes the counts of the large bins over it).
 template <int QN>
-__global__ void __launch_bounds__(256) k_x8_gather(const uint8_t* __restrict__ x8, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
-                                                   uint8_t* __restrict__ fimg, uint8_t* __restrict__ qT) {
-	__shared__ v4i tile[QN * 8];          // [row][segment]: the clamped bytes of this step
-	const uint32_t step = blockIdx.x;
-	for (uint32_t it = threadIdx.x; it < QN * 8; it += 256) {
-		const uint32_t row = it >> 3, s = it & 7;
-		v4i v = {0, 0, 0, 0};
-		if (row < n_q) v = *reinterpret_cast<const v4i*>(x8 + msc_x8_offset(q_slots[row], (uint64_t)step * kStep + 16 * s, nbins));
-		tile[it] = v;
-		v4i f;          // [x >= 1] per byte: x <= 127, so x + 127 carries into bit 7 of its own byte only
+__global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ kb, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
+                                                   uint8_t* __restrict__ abits, uint8_t* __restrict__ qT) {
+	__shared__ v4i tile[QN * 8];          // [row][16-byte segment 2 kc + h]: the presence bytes of this step
+	const uint32_t step = blockIdx.x, row = threadIdx.x;
+	if (row < QN) {
+		uint32_t hwv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		if (row < n_q) {
+			// the mirror keeps a 256-bin super-step as [h][8 halfwords j]: this step is j = 4 (step & 1) .. + 3 of both halves
+			const uint8_t* src = kb + msc_kb_offset(q_slots[row], (uint64_t)(step >> 1) * 256, nbins) + 8 * (step & 1);
+			const v2i lo = *reinterpret_cast<const v2i*>(src), hi = *reinterpret_cast<const v2i*>(src + 16);
 #pragma unroll
-		for (int c = 0; c < 4; c++) f[c] = (int)((((uint32_t)v[c] + 0x7f7f7f7fu) >> 7) & 0x01010101u);
-		*reinterpret_cast<v4i*>(fimg + ((uint64_t)step * QN + row) * kStep + ((s ^ ((row >> 1) & 7)) * 16)) = f;
+			for (int kc = 0; kc < 4; kc++) {
+				hwv[2 * kc] = ((uint32_t)lo[kc >> 1] >> (16 * (kc & 1))) & 0xffffu;
+				hwv[2 * kc + 1] = ((uint32_t)hi[kc >> 1] >> (16 * (kc & 1))) & 0xffffu;
+			}
+		}
+		v4i packed;
+#pragma unroll
+		for (int d = 0; d < 4; d++) packed[d] = (int)(hwv[2 * d] | (hwv[2 * d + 1] << 16));
+		*reinterpret_cast<v4i*>(abits + ((uint64_t)step * QN + row) * 16) = packed;
+#pragma unroll
+		for (int sg = 0; sg < 8; sg++) tile[row * 8 + sg] = expand16(hwv[sg]);
 	}
 	__syncthreads();
+	// transposed: bin p of the step (k-chunk p / 32, half (p / 16) % 2, bit p % 16) x 16 rows per 16-byte store
 	const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
 	for (uint32_t it = threadIdx.x; it < kStep * (QN / 16); it += 256) {
 		const uint32_t p = it / (QN / 16), r0 = (it % (QN / 16)) * 16;
@@ -105,7 +130,8 @@ __global__ void __launch_bounds__(256) k_x8_gather(const uint8_t* __restrict__ x
 	}
 }
 
-// The queries' large bins, bucketed by step: count, exclusive scan, fill. An entry = (bin, row << 8 | x - 1), x = min(e, 127) >= 2.
+// The queries' large bins, bucketed by step: count, exclusive scan, fill. An entry = (bin, row << 16 | e - 1); the fill also puts
+// min(e, 127) at [bin][row] of the transposed image (behind k_kb_gather on the stream).
 __global__ void __launch_bounds__(256) k_hot_count(const uint2* __restrict__ mb, const uint32_t* __restrict__ mb_n, uint32_t pitch, const uint32_t* __restrict__ q_slots,
                                                    uint32_t n_q, uint32_t* __restrict__ cnt) {
 	const uint32_t row = blockIdx.x;
@@ -132,98 +158,110 @@ __global__ void __launch_bounds__(1024) k_hot_scan(const uint32_t* __restrict__ 
 	if (threadIdx.x == 1023) ptr[nsteps] = part[1023];
 }
 __global__ void __launch_bounds__(256) k_hot_fill(const uint2* __restrict__ mb, const uint32_t* __restrict__ mb_n, uint32_t pitch, const uint32_t* __restrict__ q_slots,
-                                                  uint32_t n_q, uint32_t* __restrict__ cursor, uint2* __restrict__ hot) {
+                                                  uint32_t n_q, uint32_t qn, uint32_t* __restrict__ cursor, uint2* __restrict__ hot, uint8_t* __restrict__ qT) {
 	const uint32_t row = blockIdx.x;
 	if (row >= n_q) return;
 	const uint32_t slot = q_slots[row];
 	const uint32_t n = mb_n[slot] < pitch ? mb_n[slot] : pitch;
 	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
 		const uint2 en = mb[(uint64_t)slot * pitch + i];
-		const uint32_t x = en.y > MSC_X8_CAP ? MSC_X8_CAP : en.y;
-		hot[atomicAdd(&cursor[en.x / kStep], 1u)] = make_uint2(en.x, (row << 8) | (x - 1));
+		const uint32_t g = en.y - 1 > 0xffffu ? 0xffffu : en.y - 1;          // (counts of the narrow range are <= 8191)
+		hot[atomicAdd(&cursor[en.x / kStep], 1u)] = make_uint2(en.x, (row << 16) | g);
+		qT[(uint64_t)en.x * qn + row] = (uint8_t)(en.y > MSC_KB_QCAP ? MSC_KB_QCAP : en.y);
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ the product
-// NRB = QN / 32 row blocks of queries. Registers: 16 NRB accumulators + two operand sets of 4 x 4 + NRB x 4 of staging: 3 waves per
-// SIMD up to QN = 128, 2 at 256.
+// NRB = QN / 32 row blocks of queries. Registers: 16 NRB accumulators + 8 of candidate bits + the operands in flight: 3 waves per SIMD up
+// to QN = 128, 2 at 256.
 template <int NRB>
-__global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_x8(const uint8_t* __restrict__ cand8, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
-                                                      const uint8_t* __restrict__ fimg, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
-                                                      const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
+__global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_bits(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                                          const uint8_t* __restrict__ abits, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
+                                                                          const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
 	constexpr int QN = 32 * NRB;
+	constexpr int TPR = 8 / NRB;             // threads that stage one query row (NRB of its 8 segments each)
 	__shared__ v4i sA[2][QN * 8];          // [buffer][row][16-byte segment ^ ((row >> 1) & 7)]: QN x 128 bytes each
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t ks = blockIdx.y;
 	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
-	const uint32_t steps = (uint32_t)(per / kStep), gstep0 = (uint32_t)(k0 / kStep);
+	const uint32_t steps = (uint32_t)(per / kStep), gstep0 = (uint32_t)(k0 / kStep), n_ss = steps / 2;          // (the host makes `steps` even)
 	const uint32_t ci = (blockIdx.x * 4 + wave) * 32 + (lane & 31);
 	const bool valid = ci < m;
 	const uint32_t cc = valid ? ci : m - 1;
 	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
-	// lane l: candidate l % 32 of the block, bytes 16 (l / 32) .. + 15 of every 32-bin chunk: consecutive slots of one block make the
-	// wave's load one contiguous KiB
-	const uint8_t* brow = cand8 + (slot >> 5) * msc_x8_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16;
-	const uint8_t* asrc = fimg + (uint64_t)tid * 16;
+	// lane l: candidate l % 32 of the block, half l / 32: its 16 bytes of every 256-bin super-step; consecutive slots of one block make
+	// the wave's load one contiguous KiB
+	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	// staging: thread -> (row, NRB segments). Rows are dealt so that the 8 lanes of a ds_write_b128 group write 8 different swizzled
+	// segments (rows 0, 2, .. 14, then 1, 3, .. 15 of each 16)
+	const uint32_t u = tid / TPR, part = tid % TPR;
+	const uint32_t srow = (u & ~15u) | (2 * (u & 7) + ((u >> 3) & 1));
+	const uint8_t* asrc = abits + (uint64_t)srow * 16 + part * (2 * NRB);
 	v16i acc[NRB];
 #pragma unroll
 	for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
 		for (int i = 0; i < 16; i++) acc[rb][i] = 0;
-	v4i a_reg[NRB], b0[4], b1[4];
-	// operands of step i (the last step once more past the end: a load nobody uses is cheaper than a branch around it)
-	auto fetch = [&](uint32_t i, v4i (&b)[4]) {
-		const uint32_t j = i < steps ? i : steps - 1;
-		const uint64_t k = k0 + (uint64_t)j * kStep;
-#pragma unroll
-		for (int t = 0; t < NRB; t++) a_reg[t] = *reinterpret_cast<const v4i*>(asrc + (uint64_t)(gstep0 + j) * (QN * kStep) + 4096 * t);
-#pragma unroll
-		for (int kc = 0; kc < 4; kc++) b[kc] = *reinterpret_cast<const v4i*>(brow + ((k >> 5) + kc) * 1024);
+	uint32_t a_reg[(NRB + 1) / 2];          // NRB halfwords of the row's bits
+	auto fetch_a = [&](uint32_t i) {
+		const uint8_t* p = asrc + (uint64_t)(gstep0 + (i < steps ? i : steps - 1)) * (QN * 16);
+		if constexpr (NRB == 8) { const v4i v = *reinterpret_cast<const v4i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; }
+		else if constexpr (NRB == 4) { const v2i v = *reinterpret_cast<const v2i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; }
+		else if constexpr (NRB == 2) a_reg[0] = *reinterpret_cast<const uint32_t*>(p);
+		else a_reg[0] = *reinterpret_cast<const uint16_t*>(p);
 	};
 	auto park = [&](uint32_t buf) {
 #pragma unroll
-		for (int t = 0; t < NRB; t++) sA[buf][tid + 256 * t] = a_reg[t];
+		for (int t = 0; t < NRB; t++) {
+			const uint32_t sg = part * NRB + t;
+			sA[buf][srow * 8 + (sg ^ ((srow >> 1) & 7))] = expand16((a_reg[t >> 1] >> (16 * (t & 1))) & 0xffffu);
+		}
 	};
-	auto multiply = [&](uint32_t buf, const v4i (&b)[4]) {
+	auto fetch_b = [&](uint32_t ss) { return *reinterpret_cast<const v4i*>(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024); };
+	// one 128-bin step: k-chunks kc = 0 .. 3 = the four halfwords of (w0, w1)
+	auto multiply = [&](uint32_t buf, uint32_t w0, uint32_t w1) {
 		const uint32_t r = lane & 31, sw = (r >> 1) & 7, hh = lane >> 5;
 #pragma unroll
-		for (int kc = 0; kc < 4; kc++)
+		for (int kc = 0; kc < 4; kc++) {
+			const v4i B = expand16(((kc < 2 ? w0 : w1) >> (16 * (kc & 1))) & 0xffffu);
 #pragma unroll
 			for (int rb = 0; rb < NRB; rb++) {
 				// A operand: lane l = query 32 rb + l % 32, the bins of half l / 32 of this 32-bin chunk
 				const v4i A = sA[buf][(32 * rb + r) * 8 + ((2 * kc + hh) ^ sw)];
-				acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, b[kc], acc[rb], 0, 0, 0);
+				acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[rb], 0, 0, 0);
 			}
+		}
 	};
-	// P2: the queries' large bins that fall into this step, while the candidates' bytes of the step are in registers. Wave-uniform
-	// entries; the lane that holds (its candidate, that bin) adds (x_q - 1) x_c for its pair unless x_c is 0 (99.6 % of them at k = 9).
-	auto hotfix = [&](uint32_t i, const v4i (&b)[4]) {
+	// P2: the queries' large bins that fall into this step, while the candidates' bits of the step are in registers. Wave-uniform
+	// entries; the lane that holds (its candidate, that bin) adds e_q - 1 for its pair when the bit is set (0.4 % of them at k = 9).
+	auto hotfix = [&](uint32_t i, const v4i& bq) {
 		const uint32_t h0 = __builtin_amdgcn_readfirstlane(hot_ptr[gstep0 + i]), h1 = __builtin_amdgcn_readfirstlane(hot_ptr[gstep0 + i + 1]);
 		for (uint32_t e = h0; e < h1; e++) {
 			const uint2 en = hot[e];
 			const uint32_t bin = __builtin_amdgcn_readfirstlane(en.x), rg = __builtin_amdgcn_readfirstlane(en.y);
-			const uint32_t kc = (bin >> 5) & 3, byte = bin & 15;
-			const v4i bj = kc == 0 ? b[0] : kc == 1 ? b[1] : kc == 2 ? b[2] : b[3];
-			const uint32_t wsel = byte >> 2;
-			const uint32_t w = (uint32_t)(wsel == 0 ? bj.x : wsel == 1 ? bj.y : wsel == 2 ? bj.z : bj.w);
-			const uint32_t val = (w >> (8 * (byte & 3))) & 0xffu;
-			if (valid && (lane >> 5) == ((bin >> 4) & 1) && val) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 8), (int32_t)((rg & 0xffu) * val));
+			const uint32_t j = (bin >> 5) & 7, wsel = j >> 1;
+			const uint32_t w = (uint32_t)(wsel == 0 ? bq.x : wsel == 1 ? bq.y : wsel == 2 ? bq.z : bq.w);
+			const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
+			if (valid && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
 		}
 	};
-	fetch(0, b0);
+	v4i bcur = fetch_b(0);
+	fetch_a(0);
 	park(0);
 	__syncthreads();
-	for (uint32_t i = 0; i < steps; i += 2) {          // two steps per turn (the host makes `steps` even): the operand registers and LDS halves swap roles by name
-		fetch(i + 1, b1);
-		multiply(0, b0);
-		if (hot_ptr) hotfix(i, b0);
+	for (uint32_t ss = 0; ss < n_ss; ss++) {          // a super-step of 256 bins = two steps of the queries' tile; the LDS halves swap roles by name
+		const v4i bnext = fetch_b(ss + 1);            // (the last one once more past the end: a load nobody uses is cheaper than a branch around it)
+		fetch_a(2 * ss + 1);
+		multiply(0, (uint32_t)bcur.x, (uint32_t)bcur.y);
+		if (hot_ptr) hotfix(2 * ss, bcur);
 		park(1);
 		__syncthreads();
-		fetch(i + 2, b0);
-		multiply(1, b1);
-		if (hot_ptr) hotfix(i + 1, b1);
+		fetch_a(2 * ss + 2);
+		multiply(1, (uint32_t)bcur.z, (uint32_t)bcur.w);
+		if (hot_ptr) hotfix(2 * ss + 1, bcur);
 		park(0);
 		__syncthreads();
+		bcur = bnext;
 	}
 	// D: lane l holds column l % 32 (its candidate); register 4 g + j = row 8 g + 4 (l / 32) + j of each 32-query block
 	if (!valid) return;
@@ -236,21 +274,20 @@ __global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_x8(const ui
 
 }  // namespace
 
-uint64_t msc_x8_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 31) / 32 * msc_x8_block_bytes(L.padded_bins); }
+uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 31) / 32 * msc_kb_block_bytes(L.padded_bins); }
 
 // flags (device, two int32 zeroed by the caller): [0] a zero count was met, [1] the longest list of large bins
-hipError_t msc_launch_x8_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* x8, uint64_t first_slot, uint64_t n_slots, void* mb,
-                               uint32_t* mb_n, uint32_t* mb_big, uint32_t pitch, int32_t* flags) {
+hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* kb, uint64_t first_slot, uint64_t n_slots, void* mb,
+                               uint32_t* mb_n, uint32_t pitch, int32_t* flags) {
 	if (n_slots == 0) return hipSuccess;
-	if (L.padded_bins % 16) return hipErrorInvalidValue;
+	if (L.padded_bins % 256) return hipErrorInvalidValue;
 	hipError_t e = hipMemsetAsync(mb_n + first_slot, 0, n_slots * sizeof(uint32_t), st);
-	if (e == hipSuccess) e = hipMemsetAsync(mb_big + first_slot, 0, n_slots * sizeof(uint32_t), st);
 	if (e != hipSuccess) return e;
 	const uint64_t threads = n_slots * L.padded_bins / 16;
 	const dim3 grid((unsigned)((threads + 255) / 256));
-	if (dtype == 8) k_x8_build<uint8_t><<<grid, dim3(256), 0, st>>>((const uint8_t*)bins, L.padded_bins, x8, first_slot, n_slots, (uint2*)mb, mb_n, mb_big, pitch, flags);
-	else if (dtype == 16) k_x8_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, x8, first_slot, n_slots, (uint2*)mb, mb_n, mb_big, pitch, flags);
-	else if (dtype == 32) k_x8_build<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)bins, L.padded_bins, x8, first_slot, n_slots, (uint2*)mb, mb_n, mb_big, pitch, flags);
+	if (dtype == 8) k_kb_build<uint8_t><<<grid, dim3(256), 0, st>>>((const uint8_t*)bins, L.padded_bins, kb, first_slot, n_slots, (uint2*)mb, mb_n, pitch, flags);
+	else if (dtype == 16) k_kb_build<uint16_t><<<grid, dim3(256), 0, st>>>((const uint16_t*)bins, L.padded_bins, kb, first_slot, n_slots, (uint2*)mb, mb_n, pitch, flags);
+	else if (dtype == 32) k_kb_build<uint32_t><<<grid, dim3(256), 0, st>>>((const uint32_t*)bins, L.padded_bins, kb, first_slot, n_slots, (uint2*)mb, mb_n, pitch, flags);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
@@ -259,44 +296,44 @@ hipError_t msc_launch_x8_build(hipStream_t st, const MscLayout& L, int dtype, co
 uint32_t msc_pair_gemm_rows(uint32_t n_q) { return n_q <= 32 ? 32 : n_q <= 64 ? 64 : n_q <= 128 ? 128 : 256; }
 
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus) {
-	// enough workgroups for a few rounds of the chip (3 workgroups of 128 candidates per CU); a slice is an even number of 128-bin steps
+	// enough workgroups for a few rounds of the chip (2-3 workgroups of 128 candidates per CU); a slice is an even number of 128-bin steps
+	(void)qn;
 	uint32_t s = 1;
 	auto can_split = [&] { return s < 64 && nbins / (2 * s) >= 2 * kStep && nbins % (2 * s * 2 * kStep) == 0; };
 	while (can_split() && (uint64_t)((m + 127) / 128) * s < (uint64_t)num_cus * 12) s *= 2;
-	// and slices short enough that the queries' image of ONE slice stays in an XCD's 4 MiB L2 while the workgroups of that slice --
-	// dispatched together -- walk it in step (msc_dot_gemm.hip measured 8 slices of 2 MiB best with 64 rows)
-	static const uint64_t a_bytes = [] { const char* e = getenv("MSC_GEMM_A_KIB"); return (uint64_t)(e ? std::max(64, atoi(e)) : 4096) << 10; }();
-	while (can_split() && (uint64_t)qn * (nbins / s) > a_bytes) s *= 2;
+	static const uint32_t s_min = [] { const char* e = getenv("MSC_GEMM_SLICES"); return (uint32_t)(e ? std::max(1, atoi(e)) : 1); }();
+	while (can_split() && s < s_min) s *= 2;
 	return s;
 }
 
-// bytes of the queries' side of a block: the flag image and the transposed bytes
-uint64_t msc_pair_gemm_image_bytes(uint64_t nbins, uint32_t qn) { return nbins * qn; }
+// bytes of the queries' side of a block: the bit image (16 bytes per row and step) and the transposed counts (a byte per bin and row)
+uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn) { return nbins / 8 * qn; }
+uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn) { return nbins * qn; }
 
-// The queries' side: fimg and qT (nbins x qn bytes each) of rows q_slots[0 .. n_q) of the mirror q_x8; when n_hot > 0 also the hot list
-// (hot: n_hot entries; hot_ptr, hot_cursor, hot_cnt: nbins / 128 + 1 words each) from the queries' lists of large bins.
-hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_x8, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
-                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* fimg, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
+// The queries' side: abits and qT of rows q_slots[0 .. n_q) of the mirror q_kb; when n_hot > 0 also the hot list (hot: n_hot entries;
+// hot_ptr, hot_cursor, hot_cnt: nbins / 128 + 1 words each) from the queries' lists of large bins.
+hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_kb, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
+                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* abits, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
                                         uint32_t* hot_cursor, uint32_t* hot_cnt) {
-	if (n_q == 0 || n_q > qn || nbins % kStep) return hipErrorInvalidValue;
+	if (n_q == 0 || n_q > qn || nbins % 256) return hipErrorInvalidValue;
 	const uint32_t nsteps = (uint32_t)(nbins / kStep);
-	if (qn == 32) k_x8_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
-	else if (qn == 64) k_x8_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
-	else if (qn == 128) k_x8_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
-	else if (qn == 256) k_x8_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_x8, q_slots_dev, n_q, nbins, fimg, qT);
+	if (qn == 32) k_kb_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
+	else if (qn == 64) k_kb_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
+	else if (qn == 128) k_kb_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
+	else if (qn == 256) k_kb_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
 	else return hipErrorInvalidValue;
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || n_hot == 0) return e;
 	if ((e = hipMemsetAsync(hot_cnt, 0, (nsteps + 1) * sizeof(uint32_t), st)) != hipSuccess) return e;
 	k_hot_count<<<dim3(n_q), dim3(256), 0, st>>>((const uint2*)q_mb, q_mb_n, q_pitch, q_slots_dev, n_q, hot_cnt);
 	k_hot_scan<<<dim3(1), dim3(1024), 0, st>>>(hot_cnt, nsteps, hot_ptr, hot_cursor);
-	k_hot_fill<<<dim3(n_q), dim3(256), 0, st>>>((const uint2*)q_mb, q_mb_n, q_pitch, q_slots_dev, n_q, hot_cursor, (uint2*)hot);
+	k_hot_fill<<<dim3(n_q), dim3(256), 0, st>>>((const uint2*)q_mb, q_mb_n, q_pitch, q_slots_dev, n_q, qn, hot_cursor, (uint2*)hot, qT);
 	return hipGetLastError();
 }
 
 // P1 [k_slices][m][qn] and, with a hot list, P2 [m][qn] (zeroed here) of the block's queries against m candidates (slot list, or slots
-// first .. first + m - 1) of the mirror cand_x8
-hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_x8, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* fimg,
+// first .. first + m - 1) of the mirror cand_kb
+hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* abits,
                                 uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff) {
 	if (m == 0) return hipSuccess;
 	if (k_slices == 0 || nbins % ((uint64_t)k_slices * 2 * kStep)) return hipErrorInvalidValue;
@@ -305,7 +342,7 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 		if (e != hipSuccess) return e;
 	}
 	const dim3 grid((m + 127) / 128, k_slices);
-#define MSC_PG_GO(NRB) k_pair_gemm_x8<NRB><<<grid, dim3(256), 0, st>>>(cand_x8, cand_slots, first, m, fimg, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
+#define MSC_PG_GO(NRB) k_pair_gemm_bits<NRB><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
 	if (qn == 32) MSC_PG_GO(1);
 	else if (qn == 64) MSC_PG_GO(2);
 	else if (qn == 128) MSC_PG_GO(4);

@@ -30,7 +30,7 @@
 
 #include "msc_groups.h"
 #include "msc_internal.h"
-#include "msc_x8.h"
+#include "msc_kbits.h"
 #include "msc_wave.h"
 
 namespace {
@@ -1076,12 +1076,12 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 	}
 }
 
-// The r04 pass on the matrix cores (msc_pair_gemm.hip): P1 = sum [e_q >= 1] min(e_c, 127) per slice, P2 = sum (min(e_q, 127) - [e_q >= 1])
-// min(e_c, 127), and what the clamped / flagged bytes leave out, taken from the lists of large bins (e = count - 1 >= 2) -- see the head
-// of that file. One wave per (candidate, 64 queries), lane = query: the candidate's list is walked by the wave (entries are wave-uniform,
-// the queries' bytes at an entry's bin are one coalesced 64-byte read of the transposed image); a query's own entries with e >= 127 --
-// repeats -- by its lane. Everything in exact 64-bit integers.
-__global__ void __launch_bounds__(kBlock) k_pair_epilogue_x8(const MscEpilogueArgs a) {
+// The r04 pass on the matrix cores (msc_pair_gemm.hip): P1 = the shared k-mers per slice (sum of products of presence bits), P2 = sum of
+// (e_q - 1) over the queries' large bins the candidate holds, and what the bits leave out, taken from the candidate's list of large bins
+// (e = count - 1 >= 2) -- see the head of that file. One wave per (candidate, 64 queries), lane = query: the list is walked by the wave
+// (entries are wave-uniform, the queries' counts at an entry's bin are one coalesced 64-byte read of the transposed image).
+// Everything in exact 64-bit integers.
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits(const MscEpilogueArgs a) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t groups = (a.n_queries + 63) / 64;
 	const uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -1090,36 +1090,27 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_x8(const MscEpilogueAr
 	const bool live = q < a.n_queries;
 	const uint32_t qq = live ? q : 0;
 	const uint32_t slot_rel = a.cand_slots ? a.cand_slots[ci] : ci;
-	const uint64_t slot = a.cand_slots ? (uint64_t)slot_rel : a.x8_first + ci;
+	const uint64_t slot = a.cand_slots ? (uint64_t)slot_rel : a.kb_first + ci;
 	const uint32_t q_slot = a.q_slots[qq];
-	int64_t min_e = 0, dot_e = 0;
-	for (uint32_t s_ = 0; s_ < a.x8_slices; s_++) min_e += a.x8_min[((uint64_t)s_ * a.m_per_query + ci) * a.x8_qn + qq];
-	dot_e = min_e;
-	if (a.x8_diff) dot_e += a.x8_diff[(uint64_t)ci * a.x8_qn + qq];
-	const uint2* qmb = reinterpret_cast<const uint2*>(a.x8_q_mb) + (uint64_t)q_slot * a.x8_q_pitch;
-	const uint32_t q_n = a.x8_q_mb_n[q_slot], q_big = a.x8_q_mb_big[q_slot];
-	// the candidate's large bins: min(e_q, e_c) where the product took [e_q >= 1] min(e_c, 127); e_q e_c where it took the clamped bytes
-	const uint2* cmb = reinterpret_cast<const uint2*>(a.x8_c_mb) + slot * a.x8_c_pitch;
-	const uint32_t c_n = a.x8_c_mb_n[slot];
+	int64_t min_e = 0;
+	for (uint32_t s_ = 0; s_ < a.kb_slices; s_++) min_e += a.kb_min[((uint64_t)s_ * a.m_per_query + ci) * a.kb_qn + qq];
+	int64_t dot_e = min_e;
+	if (a.kb_diff) dot_e += a.kb_diff[(uint64_t)ci * a.kb_qn + qq];
+	// the candidate's large bins: e_q (e_c - 1) for the products; min(e_q, e_c) - 1 where the query's bin is large too
+	const uint2* cmb = reinterpret_cast<const uint2*>(a.kb_c_mb) + slot * a.kb_c_pitch;
+	const uint32_t c_n = a.kb_c_mb_n[slot] < a.kb_c_pitch ? a.kb_c_mb_n[slot] : a.kb_c_pitch;
 	for (uint32_t i = 0; i < c_n; i++) {
 		const uint2 en = cmb[i];
-		const int64_t e_c = en.y, x_c = en.y > MSC_X8_CAP ? MSC_X8_CAP : en.y;
-		const uint32_t x_q = a.x8_qT[(uint64_t)en.x * a.x8_qn + qq];
+		const int64_t e_c = en.y;
+		const uint32_t x_q = a.kb_qT[(uint64_t)en.x * a.kb_qn + qq];
 		int64_t e_q = x_q;
-		if (x_q == MSC_X8_CAP) {          // clamped (or exactly 127): the query's own list has the count
+		if (x_q == MSC_KB_QCAP) {          // clamped (or exactly 127): the query's own list has the count
+			const uint2* qmb = reinterpret_cast<const uint2*>(a.kb_q_mb) + (uint64_t)q_slot * a.kb_q_pitch;
+			const uint32_t q_n = a.kb_q_mb_n[q_slot] < a.kb_q_pitch ? a.kb_q_mb_n[q_slot] : a.kb_q_pitch;
 			for (uint32_t j = 0; j < q_n; j++) if (qmb[j].x == en.x) { e_q = qmb[j].y; break; }
 		}
-		min_e += (e_q < e_c ? e_q : e_c) - (x_q ? x_c : 0);
-		if (en.y >= MSC_X8_CAP) dot_e += e_q * e_c - (int64_t)x_q * x_c;
-	}
-	// the query's bins with e_q >= 127 against a candidate byte below 127 (at 127 the candidate's entry above has taken the pair)
-	if (q_big) {
-		for (uint32_t j = 0; j < q_n; j++) {
-			const uint2 en = qmb[j];
-			if (en.y < MSC_X8_CAP) continue;
-			const uint32_t x_c = a.x8_cand[msc_x8_offset(slot, en.x, a.nbins)];
-			if (x_c < MSC_X8_CAP) dot_e += (int64_t)(en.y - MSC_X8_CAP) * x_c;
-		}
+		dot_e += (e_c - 1) * e_q;
+		if (e_q >= 2) min_e += (e_q < e_c ? e_q : e_c) - 1;
 	}
 	if (!live) return;
 	const uint64_t sum_c = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot_rel * a.cand_scalar_stride)->sum;
@@ -1812,10 +1803,10 @@ hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_
 
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.m == 0) return hipSuccess;
-	if (a.x8_min) {
-		if (a.n_queries < 2 || a.n_queries > a.x8_qn || !a.x8_c_mb || !a.x8_q_mb || !a.x8_qT || !a.x8_cand) return hipErrorInvalidValue;      // (epilogue_one's query-major index needs n_queries > 1)
+	if (a.kb_min) {
+		if (a.n_queries < 2 || a.n_queries > a.kb_qn || !a.kb_c_mb || !a.kb_q_mb || !a.kb_qT) return hipErrorInvalidValue;      // (epilogue_one's query-major index needs n_queries > 1)
 		const uint64_t waves = (uint64_t)a.m_per_query * ((a.n_queries + 63) / 64);
-		hipLaunchKernelGGL(k_pair_epilogue_x8, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
+		hipLaunchKernelGGL(k_pair_epilogue_bits, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
 	} else if (a.partials_cq) {
 		if (a.cq_group != 16 && (a.cq_group != 32 || !a.dot_gemm)) return hipErrorInvalidValue;      // (manh-only records: the products must come from the GEMM)
 		const unsigned waves = a.m_per_query * ((a.n_queries + a.cq_group - 1) / a.cq_group);
