@@ -19,6 +19,8 @@
 //   k_emd_ranks    a wave holds 1 024 ranks of each of four candidates in registers; the workgroup moves 1 024 ranks of 8 queries at a
 //                  time into LDS (LDS-DMA, a two-slot ring) and every wave walks its candidates past them (v_sad_u32 per rank), one
 //                  transposed fold per candidate and 16 queries.
+#include <type_traits>
+
 #include "msc_internal.h"
 #include "msc_wave.h"
 
@@ -105,22 +107,23 @@ __device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uin
 	    : "memory");
 }
 
-// One workgroup = 16 candidates (4 per wave, their ranks of the current round held in registers: 64 VGPRs) x ALL queries of the block,
-// taken 8 at a time through a two-slot LDS ring (2 x 32 KiB) filled by LDS-DMA one half-group ahead: while a wave walks the 8 lists of
-// one slot past its four candidates (per query 4 ds_read_b128 + 64 v_sad_u32), the next 8 lists land in the other. One barrier per
-// half-group; one transposed fold per candidate and 16 queries.
+// One workgroup = 8 waves = 16 candidates (2 per wave, their ranks of the current round held in registers: 32 VGPRs) x ALL queries of the
+// block, taken 8 at a time through a two-slot LDS ring (2 x 32 KiB) filled by LDS-DMA one half-group ahead: while a wave walks the 8
+// lists of one slot past its two candidates (per query 4 ds_read_b128 + 32 v_sad_u32), the next 8 lists land in the other. One barrier
+// per half-group; one transposed fold per candidate and 16 queries. ~100 registers: four waves per SIMD (two workgroups per CU by LDS).
 // (r03 held ONE candidate per wave and gave every group of 16 queries its own workgroups: every candidate list was fetched once per
-// 16 queries -- 3.3 GB per 128-query block of cfg2 -- and every LDS word served one pair; the first r04 form staged 16 lists through
-// registers between two barriers, the loads' latency in the open: 85 ps per pair against 92.)
+// 16 queries -- 3.3 GB per 128-query block of cfg2 -- and every LDS word served one pair. Forms tried on the way here, per pair of cfg2:
+// r03 92 ps; 4 candidates per wave + 16 lists staged through registers between two barriers 85 ps; the same with the DMA ring 83 ps --
+// at two waves per SIMD the waits were never covered; this form: see DESIGN.md.)
 // Lists longer than a round (1 kb sequences: one round) add their rounds up in `out`.
-constexpr uint32_t kRound = 1024, kQGroup = 16, kQHalf = 8, kCandPerWave = 4;
-__global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
+constexpr uint32_t kRound = 1024, kQGroup = 16, kQHalf = 8, kCandPerWave = 2, kWaves = 8;
+__global__ void __launch_bounds__(512, 2) k_emd_ranks(const uint32_t* __restrict__ c_rk, uint64_t c_pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
                                                       uint64_t first, uint32_t m, const uint32_t* __restrict__ q_rk, uint64_t q_pitch, const uint32_t* __restrict__ q_n,
                                                       const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
 	__shared__ v4i_ sQ[2][kQHalf][kRound / 4];          // 2 x 32 KiB
 	const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t c0 = (blockIdx.x * 4 + wave) * kCandPerWave;
-	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup, n_halves = 2 * n_groups;
+	const uint32_t c0 = (blockIdx.x * kWaves + wave) * kCandPerWave;
+	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup;
 	uint64_t slot[kCandPerWave];
 	uint32_t nc[kCandPerWave];
 #pragma unroll
@@ -150,38 +153,26 @@ __global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict
 #pragma unroll
 			for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a[c][j]));
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		// half-group h = queries 8 h .. 8 h + 7 -> ring slot h % 2: each wave moves 8 of its 32 pieces of 1 KiB (a quarter of a list's round)
+		// half-group h = queries 8 h .. 8 h + 7 -> ring slot h % 2: each wave moves 4 of its 32 pieces of 1 KiB = one list's round
 		auto stage = [&](uint32_t h) {
+			const uint32_t q = wave, qi = h * kQHalf + q;
 #pragma unroll
-			for (uint32_t i = 0; i < 8; i++) {
-				const uint32_t id = wave * 8 + i, q = id >> 2, part = id & 3;
-				const uint32_t qi = h * kQHalf + q;
+			for (uint32_t part = 0; part < 4; part++) {
 				if (qi < n_q && base + 256 * part < q_pitch)
 					dma_piece((uint64_t)(q_rk + (uint64_t)q_slots[qi] * q_pitch + base + 256 * part), lane * 16u, lds0 + (((h & 1) * kQHalf + q) * (kRound / 4) + 64 * part) * 16);
 				else
 					sQ[h & 1][q][64 * part + lane] = pad;          // (queries past n_q: never stored; parts past the pitch: | x - nbins | is the tail term)
 			}
 		};
-		stage(0);
+		// the 8 lists of ring slot `buf` past this wave's candidates: sums of queries 8 `half` .. + 7 of the group
 		uint32_t sum[kCandPerWave][kQGroup];
-		uint32_t nq_max = 0;
-		for (uint32_t h = 0; h < n_halves; h++) {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of half-group h have landed (and its stores have left)
-			__syncthreads();                                           // everybody's have, and everybody is done with half-group h - 1
-			if (h + 1 < n_halves) stage(h + 1);
-			if ((h & 1) == 0) {
-				nq_max = 0;
-				for (uint32_t q = 0; q < kQGroup; q++) {
-					const uint32_t qi = (h >> 1) * kQGroup + q;
-					const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
-					nq_max = v > nq_max ? v : nq_max;
-				}
-			}
+		auto walk = [&](uint32_t buf, auto half) {
+			constexpr uint32_t H = decltype(half)::value;
 #pragma unroll
 			for (uint32_t q = 0; q < kQHalf; q++) {
 				v4i_ b[4];
 #pragma unroll
-				for (int j = 0; j < 4; j++) b[j] = sQ[h & 1][q][64 * j + lane];
+				for (int j = 0; j < 4; j++) b[j] = sQ[buf][q][64 * j + lane];
 #pragma unroll
 				for (uint32_t c = 0; c < kCandPerWave; c++) {
 					uint32_t t = 0;          // nbins <= 2^20: 16 terms fit 32 bits, and so do the 64 lanes' in the fold
@@ -192,20 +183,37 @@ __global__ void __launch_bounds__(256, 2) k_emd_ranks(const uint32_t* __restrict
 						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
 						asm("v_sad_u32 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
 					}
-					if (h & 1) sum[c][kQHalf + q] = t; else sum[c][q] = t;
+					sum[c][H * kQHalf + q] = t;
 				}
 			}
-			if (h & 1) {
-				const uint32_t q0 = (h >> 1) * kQGroup;
-				const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
+		};
+		auto landed = [&] {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces have landed (and its stores have left)
+			__syncthreads();                                           // everybody's have, and everybody is done with the slot refilled next
+		};
+		stage(0);
+		for (uint32_t g = 0; g < n_groups; g++) {          // two half-groups per turn: ring slots 0 and 1
+			landed();
+			stage(2 * g + 1);
+			walk(0, std::integral_constant<uint32_t, 0>());
+			landed();
+			if (g + 1 < n_groups) stage(2 * g + 2);
+			walk(1, std::integral_constant<uint32_t, 1>());
+			uint32_t nq_max = 0;
+			for (uint32_t q = 0; q < kQGroup; q++) {
+				const uint32_t qi = g * kQGroup + q;
+				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
+				nq_max = v > nq_max ? v : nq_max;
+			}
+			const uint32_t q0 = g * kQGroup;
+			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
 #pragma unroll
-				for (uint32_t c = 0; c < kCandPerWave; c++) {
-					const uint32_t tot = fold16q(sum[c]);
-					// past every list of this candidate and group all terms are | nbins - nbins |: nothing to add
-					if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
-						uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
-						*o = base ? *o + tot : (uint64_t)tot;
-					}
+			for (uint32_t c = 0; c < kCandPerWave; c++) {
+				const uint32_t tot = fold16q(sum[c]);
+				// past every list of this candidate and group all terms are | nbins - nbins |: nothing to add
+				if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
+					uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
+					*o = base ? *o + tot : (uint64_t)tot;
 				}
 			}
 		}
@@ -240,6 +248,6 @@ hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* 
                                 uint32_t out_stride) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > out_stride || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
-	k_emd_ranks<<<dim3((m + 4 * kCandPerWave - 1) / (4 * kCandPerWave)), dim3(256), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
+	k_emd_ranks<<<dim3((m + kWaves * kCandPerWave - 1) / (kWaves * kCandPerWave)), dim3(64 * kWaves), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
 	return hipGetLastError();
 }

@@ -894,25 +894,12 @@ __device__ __forceinline__ uint64_t shfl_sum_u64(uint64_t v) {
 	return v;
 }
 
-__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t_in) {
+// The evaluation of one pair from its integer reductions and the two histograms' scalars: raw statistics -> normalize_cache ->
+// combos -> weighted sum -> logistic + bias -> close (predict/Feature.cpp:137-171, predict/Feature.h:205-239, cluster/Trainer.cpp:112-120).
+// c = the pair's index in the outputs; ci / qi = its candidate / query position (group and divergence records)
+__device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci, uint32_t qi, const Side& cand, const Side& qry, uint64_t min_len, uint64_t max_len,
+                              const PairTotals& t_in) {
 	PairTotals t = t_in;
-	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
-	uint32_t ci = c, qi = 0;
-	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
-	const uint32_t slot = a.cand_slots ? a.cand_slots[ci] : ci;
-	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride);
-	uint64_t min_len = a.min_len, max_len = a.max_len;
-	const MscSlotScalars* qs = a.n_queries > 1
-	    ? reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)a.q_slots[qi] * a.q_scalar_stride)
-	    : reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
-	if (a.segs) {
-		const MscBatchSeg sg = a.segs[a.pair_seg[c]];
-		qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)sg.q_slot * a.q_scalar_stride);
-		min_len = sg.min_len;
-		max_len = sg.max_len;
-	}
-	Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
-	Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
 	const Side& second = a.order == MSC_ORDER_CAND_FIRST ? qry : cand;
 	// k_pair_sparse summed over the union of stored bins only; every other bin is (1, 1)
@@ -1004,6 +991,27 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	if (err < 0 && a.error_word) atomicMin(a.error_word, err);
 }
 
+__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t) {
+	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
+	uint32_t ci = c, qi = 0;
+	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
+	const uint32_t slot = a.cand_slots ? a.cand_slots[ci] : ci;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot * a.cand_scalar_stride);
+	uint64_t min_len = a.min_len, max_len = a.max_len;
+	const MscSlotScalars* qs = a.n_queries > 1
+	    ? reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)a.q_slots[qi] * a.q_scalar_stride)
+	    : reinterpret_cast<const MscSlotScalars*>(a.q_scalars);
+	if (a.segs) {
+		const MscBatchSeg sg = a.segs[a.pair_seg[c]];
+		qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)sg.q_slot * a.q_scalar_stride);
+		min_len = sg.min_len;
+		max_len = sg.max_len;
+	}
+	const Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
+	const Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
+	epilogue_eval(a, c, ci, qi, cand, qry, min_len, max_len, t);
+}
+
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogueArgs a) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t c = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -1084,43 +1092,63 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits(const MscEpilogueArgs a) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t groups = (a.n_queries + 63) / 64;
-	const uint32_t w = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+	const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));          // wave-uniform: the candidate's record and list go through the scalar cache
 	if (w >= a.m_per_query * groups) return;
 	const uint32_t ci = w / groups, q = (w % groups) * 64 + lane;
 	const bool live = q < a.n_queries;
 	const uint32_t qq = live ? q : 0;
 	const uint32_t slot_rel = a.cand_slots ? a.cand_slots[ci] : ci;
 	const uint64_t slot = a.cand_slots ? (uint64_t)slot_rel : a.kb_first + ci;
+	// every load that depends on nothing else first: a wave has few instructions between its loads, so what is not in flight together
+	// is a round trip each (the first form of this kernel spent two thirds of its time waiting)
 	const uint32_t q_slot = a.q_slots[qq];
-	int64_t min_e = 0;
-	for (uint32_t s_ = 0; s_ < a.kb_slices; s_++) min_e += a.kb_min[((uint64_t)s_ * a.m_per_query + ci) * a.kb_qn + qq];
-	int64_t dot_e = min_e;
-	if (a.kb_diff) dot_e += a.kb_diff[(uint64_t)ci * a.kb_qn + qq];
-	// the candidate's large bins: e_q (e_c - 1) for the products; min(e_q, e_c) - 1 where the query's bin is large too
 	const uint2* cmb = reinterpret_cast<const uint2*>(a.kb_c_mb) + slot * a.kb_c_pitch;
 	const uint32_t c_n = a.kb_c_mb_n[slot] < a.kb_c_pitch ? a.kb_c_mb_n[slot] : a.kb_c_pitch;
-	for (uint32_t i = 0; i < c_n; i++) {
-		const uint2 en = cmb[i];
-		const int64_t e_c = en.y;
-		const uint32_t x_q = a.kb_qT[(uint64_t)en.x * a.kb_qn + qq];
-		int64_t e_q = x_q;
-		if (x_q == MSC_KB_QCAP) {          // clamped (or exactly 127): the query's own list has the count
-			const uint2* qmb = reinterpret_cast<const uint2*>(a.kb_q_mb) + (uint64_t)q_slot * a.kb_q_pitch;
-			const uint32_t q_n = a.kb_q_mb_n[q_slot] < a.kb_q_pitch ? a.kb_q_mb_n[q_slot] : a.kb_q_pitch;
-			for (uint32_t j = 0; j < q_n; j++) if (qmb[j].x == en.x) { e_q = qmb[j].y; break; }
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot_rel * a.cand_scalar_stride);
+	const Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
+	int32_t part[16];
+	const uint32_t ns = a.kb_slices;          // (at most 64; summed 16 at a time)
+	int64_t min_e = 0;
+	for (uint32_t s0 = 0; s0 < ns; s0 += 16) {
+#pragma unroll
+		for (uint32_t j = 0; j < 16; j++) part[j] = s0 + j < ns ? a.kb_min[((uint64_t)(s0 + j) * a.m_per_query + ci) * a.kb_qn + qq] : 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 16; j++) min_e += part[j];
+	}
+	int64_t dot_e = min_e;
+	if (a.kb_diff) dot_e += a.kb_diff[(uint64_t)ci * a.kb_qn + qq];
+	const uint64_t emd = a.emd_ranks ? a.emd_ranks[(uint64_t)ci * (a.emd_stride ? a.emd_stride : 64) + qq] : 0;
+	const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)q_slot * a.q_scalar_stride);
+	const Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
+	// the candidate's large bins, four at a time: e_q (e_c - 1) for the products; min(e_q, e_c) - 1 where the query's bin is large too
+	for (uint32_t i0 = 0; i0 < c_n; i0 += 4) {
+		uint2 en[4];
+		uint32_t x_q[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) en[j] = cmb[i0 + j < c_n ? i0 + j : c_n - 1];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) x_q[j] = a.kb_qT[(uint64_t)en[j].x * a.kb_qn + qq];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			if (i0 + j >= c_n) break;
+			const int64_t e_c = en[j].y;
+			int64_t e_q = x_q[j];
+			if (x_q[j] == MSC_KB_QCAP) {          // clamped (or exactly 127): the query's own list has the count
+				const uint2* qmb = reinterpret_cast<const uint2*>(a.kb_q_mb) + (uint64_t)q_slot * a.kb_q_pitch;
+				const uint32_t q_n = a.kb_q_mb_n[q_slot] < a.kb_q_pitch ? a.kb_q_mb_n[q_slot] : a.kb_q_pitch;
+				for (uint32_t t_ = 0; t_ < q_n; t_++) if (qmb[t_].x == en[j].x) { e_q = qmb[t_].y; break; }
+			}
+			dot_e += (e_c - 1) * e_q;
+			if (e_q >= 2) min_e += (e_q < e_c ? e_q : e_c) - 1;
 		}
-		dot_e += (e_c - 1) * e_q;
-		if (e_q >= 2) min_e += (e_q < e_c ? e_q : e_c) - 1;
 	}
 	if (!live) return;
-	const uint64_t sum_c = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot_rel * a.cand_scalar_stride)->sum;
-	const uint64_t sum_q = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)q_slot * a.q_scalar_stride)->sum;
 	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-	const uint64_t ex_c = sum_c - a.nbins, ex_q = sum_q - a.nbins;          // sum of the excess counts
+	const uint64_t ex_c = cand.sum - a.nbins, ex_q = qry.sum - a.nbins;          // sum of the excess counts
 	t.manh = ex_c + ex_q - 2 * (uint64_t)min_e;
 	t.dot = a.nbins + ex_c + ex_q + (uint64_t)dot_e;
-	if (a.emd_ranks) t.emd = a.emd_ranks[(uint64_t)ci * (a.emd_stride ? a.emd_stride : 64) + q];
-	epilogue_one(a, q * a.m_per_query + ci, t);
+	t.emd = emd;
+	epilogue_eval(a, q * a.m_per_query + ci, ci, q, cand, qry, a.min_len, a.max_len, t);
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
