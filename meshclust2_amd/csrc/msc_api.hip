@@ -111,7 +111,10 @@ extern "C" int msc_create(int device, msc_ctx** out) {
 	ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->num_cus);
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev_tiles0) != hipSuccess ||
-	    hipEventCreate(&ctx->ev_tiles1) != hipSuccess || hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess) {
+	    hipEventCreate(&ctx->ev_tiles1) != hipSuccess || hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess ||
+	    hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_scored[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scored[1], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_copied[1], hipEventDisableTiming) != hipSuccess) {
 		delete ctx;
 		return fail(nullptr, MSC_ERR_HIP, "msc_create: stream/event creation failed");
 	}
@@ -123,6 +126,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	(void)hipStreamSynchronize(ctx->copy_stream);
 	if (g_profile_calls && ctx->prof_calls)
 		fprintf(stderr, "[msc] 1 x M scoring calls: %llu (%llu candidates) | slot list %.3f s, launches %.3f s, stream wait %.3f s\n", (unsigned long long)ctx->prof_calls,
 		        (unsigned long long)ctx->prof_cands, ctx->prof_prep, ctx->prof_issue, ctx->prof_wait);
@@ -169,6 +173,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipEventDestroy(ctx->ev_tiles1);
 	(void)hipEventDestroy(ctx->ev_all0);
 	(void)hipEventDestroy(ctx->ev_all1);
+	for (int i = 0; i < 2; i++) { release(ctx->close_pp[i]); (void)hipEventDestroy(ctx->ev_scored[i]); (void)hipEventDestroy(ctx->ev_copied[i]); }
+	(void)hipStreamDestroy(ctx->copy_stream);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1812,9 +1818,26 @@ static bool kb_route_fits(const msc_hist_set* cands, const msc_hist_set* qset, b
 	return true;
 }
 
+static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                            const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
+                            uint8_t* close_out, uint64_t feat_mask, double* raw_out);
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
+	const int r = score_multi_impl(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
+	if (ctx && ctx->copy_pending) {          // the flag copies of the last blocks (issued beside the kernels that followed them)
+		const hipError_t e = hipStreamSynchronize(ctx->copy_stream);
+		ctx->copy_pending = false;
+		ctx->close_pp_busy[0] = ctx->close_pp_busy[1] = false;
+		if (e != hipSuccess && r == MSC_OK) return fail(ctx, MSC_ERR_HIP, "copy of the close flags failed: %s", hipGetErrorString(e));
+	}
+	return r;
+}
+
+static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
+                            const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
+                            uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
 	if (!ctx || !cands || !qset || !q_slots) return MSC_ERR_INVALID_ARG;
 	if (model && model->ctx != ctx) return MSC_ERR_INVALID_ARG;
 	if (raw_out && (feat_mask == 0 || (feat_mask & ~kSupportedFeats))) return fail(ctx, MSC_ERR_UNSUPPORTED, "feat_mask holds statistics outside the GPU path");
@@ -1856,7 +1879,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		for (uint64_t b = 0; b < n_q; b += blk) {
 			const uint64_t nb = std::min<uint64_t>(blk, n_q - b);
 			ctx->close_counts_base = base0 + b;
-			if ((r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
+			if ((r = score_multi_impl(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
 			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr)))
 				{ ctx->in_score_multi = was_in; ctx->close_counts_base = base0; return r; }
 			ms += ctx->tiles_ms_accum;
@@ -2024,7 +2047,7 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	}
 	if (!manh_gemm && n_q > 64) {          // (a block of up to 256 was cut for the matrix cores: the older routes take it in blocks of 64)
 		ctx->no_kb_now = true;
-		r = msc_score_multi(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
+		r = score_multi_impl(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
 		ctx->no_kb_now = false;
 		return r;
 	}
@@ -2085,7 +2108,8 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 	}
 	if (sum_out && (r = ensure(ctx, ctx->soa_sum, n_q * chunk * sizeof(double)))) return r;
 	if (csum_out && (r = ensure(ctx, ctx->soa_csum, n_q * chunk * sizeof(double)))) return r;
-	if (close_out && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
+	if (close_out && !manh_gemm && (r = ensure(ctx, ctx->soa_close, n_q * chunk))) return r;
+	if (close_out && manh_gemm && ((r = ensure(ctx, ctx->close_pp[0], n_q * chunk)) || (r = ensure(ctx, ctx->close_pp[1], n_q * chunk)))) return r;
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
 	const uint32_t gemm_slices = manh_gemm ? msc_pair_gemm_slices(L.nbins, (uint32_t)chunk, kb_qn, ctx->num_cus) : 0;
 	uint32_t *hot_ptr = nullptr, *hot_cursor = nullptr, *hot_cnt = nullptr;
@@ -2204,16 +2228,30 @@ extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_h
 		ea.model = model ? model->d : nullptr;
 		ea.sum_soa = sum_out ? (double*)ctx->soa_sum.p : nullptr;
 		ea.csum_soa = csum_out ? (double*)ctx->soa_csum.p : nullptr;
-		ea.close_soa = close_out ? (uint8_t*)ctx->soa_close.p : nullptr;
+		// (matrix-core pass: the flags go into one of two buffers and back to the host on the copy stream, under the next block's kernels)
+		const int pp = ctx->close_pp_next;
+		uint8_t* d_close = !close_out ? nullptr : manh_gemm ? (uint8_t*)ctx->close_pp[pp].p : (uint8_t*)ctx->soa_close.p;
+		if (close_out && manh_gemm) {
+			ctx->close_pp_next ^= 1;
+			if (ctx->close_pp_busy[pp]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[pp], 0));
+		}
+		ea.close_soa = d_close;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
-		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(ctx->stream, (const uint8_t*)ctx->soa_close.p, (uint32_t)n_q, mc, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
+		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(ctx->stream, d_close, (uint32_t)n_q, mc, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
 		const size_t rows = (size_t)n_q;
 		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
 		if (csum_out) HIP_TRY(ctx, hipMemcpy2DAsync(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
-		if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, ctx->soa_close.p, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (close_out && manh_gemm) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_scored[pp], ctx->stream));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_scored[pp], 0));
+			HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->copy_stream));
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_copied[pp], ctx->copy_stream));
+			ctx->close_pp_busy[pp] = true;
+			ctx->copy_pending = true;
+		} else if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->stream));
 		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;

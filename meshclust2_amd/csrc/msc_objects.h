@@ -43,6 +43,14 @@ struct msc_ctx {
 	DevBuf shard_payload, shard_hdrs;
 	// msc_pair_gemm.hip: the queries' side of a block (bit image, transposed counts, hot list + its three step arrays), P1 per slice, P2
 	DevBuf kb_abits, kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff;
+	// the close flags of a block of the matrix-core pass go back to the host on a stream of their own, under the next block's kernels:
+	// two device buffers take turns; msc_score_multi waits for the copies before it returns
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_scored[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+	DevBuf close_pp[2];
+	bool close_pp_busy[2] = {false, false};
+	int close_pp_next = 0;
+	bool copy_pending = false;
 	bool no_kb_now = false;                // msc_score_multi: this block is taken by the older routes (its hot list would be too long)
 	DevBuf close_counts;                   // msc_score_multi: close candidates per query of the call in progress / the last call (msc_last_close_counts)
 	uint64_t close_counts_n = 0, close_counts_base = 0;

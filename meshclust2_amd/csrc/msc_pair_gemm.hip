@@ -174,18 +174,21 @@ __global__ void __launch_bounds__(256) k_hot_fill(const uint2* __restrict__ mb, 
 // ------------------------------------------------------------------------------------------------ the product
 // NRB = QN / 32 row blocks of queries. Registers: 16 NRB accumulators + 8 of candidate bits + the operands in flight: 3 waves per SIMD up
 // to QN = 128, 2 at 256.
-template <int NRB>
-__global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_bits(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+template <int NRB, int NW>
+__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : (NW == 8 ? 2 : 3)) k_pair_gemm_bits(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                                           const uint8_t* __restrict__ abits, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
                                                                           const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
 	constexpr int QN = 32 * NRB;
-	constexpr int TPR = 8 / NRB;             // threads that stage one query row (NRB of its 8 segments each)
+	constexpr int NT = 64 * NW;              // NW waves of 32 candidates each share the queries' tile
+	constexpr int SPT = QN * 8 / NT;         // 16-byte segments of the tile a thread expands per step
+	constexpr int TPR = 8 / SPT;             // threads that stage one query row
+	static_assert(SPT >= 1 && SPT <= 8 && TPR * SPT == 8, "tile staging");
 	__shared__ v4i sA[2][QN * 8];          // [buffer][row][16-byte segment ^ ((row >> 1) & 7)]: QN x 128 bytes each
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t ks = blockIdx.y;
 	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
 	const uint32_t steps = (uint32_t)(per / kStep), gstep0 = (uint32_t)(k0 / kStep), n_ss = steps / 2;          // (the host makes `steps` even)
-	const uint32_t ci = (blockIdx.x * 4 + wave) * 32 + (lane & 31);
+	const uint32_t ci = (blockIdx.x * NW + wave) * 32 + (lane & 31);
 	const bool valid = ci < m;
 	const uint32_t cc = valid ? ci : m - 1;
 	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
@@ -196,24 +199,24 @@ __global__ void __launch_bounds__(256, NRB == 8 ? 2 : 3) k_pair_gemm_bits(const 
 	// segments (rows 0, 2, .. 14, then 1, 3, .. 15 of each 16)
 	const uint32_t u = tid / TPR, part = tid % TPR;
 	const uint32_t srow = (u & ~15u) | (2 * (u & 7) + ((u >> 3) & 1));
-	const uint8_t* asrc = abits + (uint64_t)srow * 16 + part * (2 * NRB);
+	const uint8_t* asrc = abits + (uint64_t)srow * 16 + part * (2 * SPT);
 	v16i acc[NRB];
 #pragma unroll
 	for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
 		for (int i = 0; i < 16; i++) acc[rb][i] = 0;
-	uint32_t a_reg[(NRB + 1) / 2];          // NRB halfwords of the row's bits
+	uint32_t a_reg[(SPT + 1) / 2];          // SPT halfwords of the row's bits
 	auto fetch_a = [&](uint32_t i) {
 		const uint8_t* p = asrc + (uint64_t)(gstep0 + (i < steps ? i : steps - 1)) * (QN * 16);
-		if constexpr (NRB == 8) { const v4i v = *reinterpret_cast<const v4i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; }
-		else if constexpr (NRB == 4) { const v2i v = *reinterpret_cast<const v2i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; }
-		else if constexpr (NRB == 2) a_reg[0] = *reinterpret_cast<const uint32_t*>(p);
+		if constexpr (SPT == 8) { const v4i v = *reinterpret_cast<const v4i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; }
+		else if constexpr (SPT == 4) { const v2i v = *reinterpret_cast<const v2i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; }
+		else if constexpr (SPT == 2) a_reg[0] = *reinterpret_cast<const uint32_t*>(p);
 		else a_reg[0] = *reinterpret_cast<const uint16_t*>(p);
 	};
 	auto park = [&](uint32_t buf) {
 #pragma unroll
-		for (int t = 0; t < NRB; t++) {
-			const uint32_t sg = part * NRB + t;
+		for (int t = 0; t < SPT; t++) {
+			const uint32_t sg = part * SPT + t;
 			sA[buf][srow * 8 + (sg ^ ((srow >> 1) & 7))] = expand16((a_reg[t >> 1] >> (16 * (t & 1))) & 0xffffu);
 		}
 	};
@@ -295,12 +298,19 @@ hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, co
 // rows of queries one pass serves for a block of n_q: 32, 64, 128 or 256
 uint32_t msc_pair_gemm_rows(uint32_t n_q) { return n_q <= 32 ? 32 : n_q <= 64 ? 64 : n_q <= 128 ? 128 : 256; }
 
+// 128 candidates per workgroup (4 waves), or 256 (8 waves: the queries' tile is expanded into LDS once for twice the products) where that
+// still leaves every CU a few workgroups
+static bool pair_gemm_wide(uint32_t qn, uint32_t m) {
+	static const int nw_env = [] { const char* e = getenv("MSC_GEMM_WAVES"); return e ? atoi(e) : 0; }();
+	return qn == 128 && (nw_env == 8 || (nw_env != 4 && m >= 16384));
+}
+
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus) {
-	// enough workgroups for a few rounds of the chip (2-3 workgroups of 128 candidates per CU); a slice is an even number of 128-bin steps
-	(void)qn;
+	// enough workgroups for a few rounds of the chip (16 waves per CU); a slice is an even number of 128-bin steps
+	const uint32_t per_wg = pair_gemm_wide(qn, m) ? 256 : 128;
 	uint32_t s = 1;
 	auto can_split = [&] { return s < 64 && nbins / (2 * s) >= 2 * kStep && nbins % (2 * s * 2 * kStep) == 0; };
-	while (can_split() && (uint64_t)((m + 127) / 128) * s < (uint64_t)num_cus * 12) s *= 2;
+	while (can_split() && (uint64_t)((m + per_wg - 1) / per_wg) * s < (uint64_t)num_cus * (per_wg == 256 ? 12 : 24)) s *= 2;
 	static const uint32_t s_min = [] { const char* e = getenv("MSC_GEMM_SLICES"); return (uint32_t)(e ? std::max(1, atoi(e)) : 1); }();
 	while (can_split() && s < s_min) s *= 2;
 	return s;
@@ -341,12 +351,14 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 		const hipError_t e = hipMemsetAsync(out_diff, 0, (size_t)m * qn * sizeof(int32_t), st);
 		if (e != hipSuccess) return e;
 	}
-	const dim3 grid((m + 127) / 128, k_slices);
-#define MSC_PG_GO(NRB) k_pair_gemm_bits<NRB><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
-	if (qn == 32) MSC_PG_GO(1);
-	else if (qn == 64) MSC_PG_GO(2);
-	else if (qn == 128) MSC_PG_GO(4);
-	else if (qn == 256) MSC_PG_GO(8);
+	const bool wide = pair_gemm_wide(qn, m);
+	const dim3 grid((m + (wide ? 255 : 127)) / (wide ? 256 : 128), k_slices);
+#define MSC_PG_GO(NRB, NW) k_pair_gemm_bits<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
+	if (qn == 32) MSC_PG_GO(1, 4);
+	else if (qn == 64) MSC_PG_GO(2, 4);
+	else if (qn == 128 && wide) MSC_PG_GO(4, 8);
+	else if (qn == 128) MSC_PG_GO(4, 4);
+	else if (qn == 256) MSC_PG_GO(8, 4);
 	else return hipErrorInvalidValue;
 #undef MSC_PG_GO
 	return hipGetLastError();
