@@ -67,6 +67,10 @@ def parse():
                                                     "tests/golden/weights_cfg5_k9.txt for a `--feat slow` model with jensen_shannon")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
     ap.add_argument("--cpu-cands", type=int, default=16384, help="candidates per CPU get_close pass: enough for every host thread of a 256-thread box to get 64")
+    ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the sequences that carry a 400-base run (a homopolymer or a dinucleotide repeat, alternating): "
+                                                                "counts of ~390 / ~196 among counts of 1 .. 8, as ordinary FASTA has them (microsatellites, poly-A tails); 0.01 = VERDICT r03's case")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the three short 1 x M legs behind the timed region (dense get_close, "
+                                                                                   "sparse k = 9, sparse k = 13 / 64-bit / 20 kb) that go under `secondary` in the line")
     ap.add_argument("--check", action="store_true", help="add `check` to the line: per timed step, the number of close candidates of every query of the block (all ranks "
                                                          "summed) -- what two runs with different numbers of ranks must agree on")
     ap.add_argument("--check-world", type=int, default=0, help="single-rank run: choose each step's query block as a run over this many ranks would (with --check)")
@@ -93,7 +97,9 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
     # --exchange sequences: this rank's sequences as they go over the wire, 4 bases per byte, each padded to whole bytes, + their 1-mer counts
     # (the family members carry indels: lengths vary by a few bases around --length, so a row has room to spare and column 4 of the
     # second array holds the length)
-    lp4 = (args.length + args.length // 8 + 64 + 3) // 4
+    lp4 = (args.length + args.length // 8 + 64 + (400 if args.repeats > 0 else 0) + 3) // 4
+    period = max(1, int(round(1.0 / args.repeats))) if args.repeats > 0 else 0
+    runs = (np.zeros(400, dtype=np.uint8), np.tile(np.array([0, 1], dtype=np.uint8), 200))          # A x 400, AC x 200
     seq_rows = np.zeros((M, lp4), dtype=np.uint8)
     one_rows = np.zeros((M, 5), dtype=np.uint64)
     while done < M:
@@ -107,7 +113,11 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
                 tmpl = synth.template(seed, t, args.length)
                 for j in range(fam):
                     if g0 <= t * fam + j < g1:
-                        codes.append(synth.member(seed, t, j, tmpl))
+                        c = synth.member(seed, t, j, tmpl)
+                        g = t * fam + j
+                        if period and g % period == 7 % period:          # (the construction of tests/ring_variant_check.py: a run spliced in at base 300)
+                            c = np.concatenate([c[:300], runs[(g // period) % 2], c[300:]])
+                        codes.append(c)
         assert len(codes) == n
         b = synth.pack_batch(codes)
         c4 = np.zeros((n, lp4 * 4), dtype=np.uint8)
@@ -181,6 +191,67 @@ def cpu_baseline(args, synth, weights_text, weights_path):
                sample="%d get_close passes x %d candidates (k=%d, u%d, 1 kb), OpenMP over candidates on %d threads, %.1f s"
                       % (passes, n - 1, args.k, args.dtype, cores, dt))
     return out
+
+
+def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what):
+    """`passes` 1 x M passes of Trainer::get_close (cluster/Trainer.cpp:23-71: the loop the clustering runs) over a resident set; the
+    streaming kernel timed by the library's HIP events on its stream, the leg by the wall clock -> one row of `secondary`"""
+    for j in range(2):
+        trn.get_close(hs, None, hs, (j * 7919 + 1) % M, m=M)
+    ctx.synchronize()
+    ms, launches = [], []
+    t0 = time.perf_counter()
+    for j in range(passes):
+        trn.get_close(hs, None, hs, (j * 7919 + 3) % M, m=M)
+        ms.append(ctx.last_kernel_ms()[0])
+        launches.append(ctx.last_kernel_launches())
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    kernel, _ = ctx.last_kernel_info()
+    n_launch = max(int(np.sum(launches)), 1)
+    avg = float(np.sum(ms)) / n_launch
+    alg = (M + 1) * hist_bytes * len(ms) // n_launch
+    ach = alg / (avg * 1e-3) / 1e9
+    return {"workload": what, "metric": "sequence-pairs/sec identity-scored, 1 x M get_close passes", "value": passes * M / dt, "unit": "pairs/s", "passes": passes,
+            "candidates_per_pass": M, "ms_per_pass": dt / passes * 1e3,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg, "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch}}
+
+
+def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
+    """Three short legs behind the timed region, same process, same resident data where possible: the 1 x M pass the
+    clustering loop runs -- over the dense 32-bit set, over the sparse layout of the same sequences (k = 9), and over sparse 64-bit lists
+    of 8 000 x 20 kb sequences at k = 13 (BASELINE cfg4's shape). Algorithmic bytes per pass: SURVEY 8(d)'s 4^k sizeof(T) per candidate
+    for the dense set; 8 bytes per stored bin of the candidate's list for the sparse ones."""
+    rows = []
+    feat = api.Feature.from_text(ctx, wtext, 0)
+    trn = api.Trainer(ctx, feat, 0.9)
+    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, (4 ** args.k) * (args.dtype // 8),
+                              "the resident set of the main leg: %d x %d bp, k=%d, datatype=%d, dense" % (M, args.length, args.k, args.dtype)))
+    # the same sequences on the sparse layout, rebuilt from the 2-bit rows kept for the exchange
+    stride = seq_rows.shape[1] * 4
+    sp = api.HistogramSet(ctx, args.k, args.dtype, M, sparse_entries=M * (args.length + 64 + (400 if args.repeats > 0 else 0)))
+    for done in range(0, M, 20000):
+        n = min(20000, M - done)
+        lens = one_rows[done:done + n, 4].astype(np.uint64)
+        starts = np.arange(n, dtype=np.uint64) * np.uint64(stride)
+        sp.build_packed(done, n, seq_rows[done:done + n].reshape(-1), n * stride, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
+                        np.ascontiguousarray(one_rows[done:done + n, :4]).reshape(-1))
+    ent = int(8 * np.mean([sp.entries(i) for i in range(0, M, max(1, M // 500))]))
+    rows.append(get_close_leg(api, ctx, trn, sp, M, 20, ent, "the same %d sequences on the sparse layout (sorted (bin, count) lists), k=%d" % (M, args.k)))
+    del sp
+    # BASELINE cfg4's shape: 20 kb sequences at k = 13, 64-bit counts, sparse lists (a dense 4^13 histogram would be 512 MiB)
+    n4, len4, k4 = 8000, 20000, 13
+    codes, _ = synth.family_codes(20260004, n4, len4)
+    s4 = api.HistogramSet(ctx, k4, 64, n4, sparse_entries=n4 * (len4 + 64))
+    for done in range(0, n4, 2000):
+        b = synth.pack_batch(codes[done:done + 2000])
+        s4.build_packed(done, len(codes[done:done + 2000]), b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
+    w4 = wtext.replace("k: %d" % args.k, "k: %d" % k4).replace("uint%d_t" % args.dtype, "uint64_t")
+    trn4 = api.Trainer(ctx, api.Feature.from_text(ctx, w4, 0), 0.9)
+    ent4 = int(8 * np.mean([s4.entries(i) for i in range(0, n4, 16)]))
+    rows.append(get_close_leg(api, ctx, trn4, s4, n4, 20, ent4, "cfg4's shape: %d x %d bp, k=%d, datatype=64, sparse layout" % (n4, len4, k4)))
+    return rows
 
 
 def pmc_traffic(kernel_prefix, config_key):
@@ -294,11 +365,20 @@ def main():
         all_bins, all_scal = shard.device_tensors(hs, M + 2 * Q)      # [slot, bytes] views of the set's device memory
         ship_seq = args.exchange == "sequences" and args.mode == "allpairs"
         if ship_seq:
-            seq_dev, one_dev = torch.from_numpy(seq_rows).cuda(), torch.from_numpy(one_rows.view(np.int64)).cuda()
+            # What travels per step is the bases only. The lengths and 1-mer counts of EVERY sequence are exchanged once here (40 bytes
+            # each): the host then knows the segment table of any query block without reading device memory, and the block's histograms
+            # are built straight from the gathered device buffer (msc_hist_build_packed_dev) -- no D2H / H2D hop inside a step.
+            seq_dev = torch.from_numpy(seq_rows).cuda()
             qseq_dev = torch.zeros((2 * Q, seq_rows.shape[1]), dtype=torch.uint8, device="cuda")
-            qone_dev = torch.zeros((2 * Q, 5), dtype=torch.int64, device="cuda")
+            m_max = max(plan.local_count(r) for r in range(world))
+            mine = torch.zeros((m_max, 5), dtype=torch.int64)
+            mine[:M] = torch.from_numpy(one_rows.view(np.int64))
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            (dist if gloo_group is None else real).all_gather(every, mine, **({} if gloo_group is None else {"group": gloo_group}))
+            meta_of_rank = [t.numpy().view(np.uint64) for t in every]          # [rank][local slot] = (1-mer counts x 4, length)
 
         block_out = {}
+        first_of_base = {}          # query buffer half -> first local slot of the block that was gathered into it (every rank contributes first .. first + Q / N - 1)
 
         class GpuBackend:
             def query_buffers(self, j=0):
@@ -309,28 +389,29 @@ def main():
 
             def export_block(self, local_first, n):
                 if ship_seq:
-                    return [seq_dev[local_first:local_first + n], one_dev[local_first:local_first + n]]
+                    return [seq_dev[local_first:local_first + n]]
                 return [all_bins[local_first:local_first + n], all_scal[local_first:local_first + n]]
 
             def block_buffers(self, base, n_rows):
                 if ship_seq:
-                    return [qseq_dev[base:base + n_rows], qone_dev[base:base + n_rows]]
+                    return [qseq_dev[base:base + n_rows]]
                 return [all_bins[M + base:M + base + n_rows], all_scal[M + base:M + base + n_rows]]
+
 
             def import_query(self):
                 self.import_queries(1)
 
             def import_queries(self, n, base=0):
-                torch.cuda.synchronize()
+                torch.cuda.synchronize()          # the all-gather (issued a step ago on RCCL's stream) has landed; the library has its own stream
                 if ship_seq and n > 1:
-                    # the block arrived as sequences: its histograms are built here (the packed input of msc_hist_build_packed: one
-                    # segment per sequence, every sequence on its own bytes)
-                    pk = qseq_dev[base:base + n].cpu().numpy().reshape(-1)
-                    meta = qone_dev[base:base + n].cpu().numpy().astype(np.uint64)
+                    # the block arrived as sequences: its histograms are built here, from the device buffer the collective filled (one
+                    # segment per sequence, every sequence on its own bytes); lengths and 1-mer counts from the tables exchanged at setup
+                    first, per = first_of_base[base], n // world
+                    meta = np.concatenate([meta_of_rank[r][first:first + per] for r in range(world)])
                     starts = np.arange(n, dtype=np.uint64) * np.uint64(seq_rows.shape[1] * 4)
                     lens = meta[:, 4].copy()
-                    hs.build_packed(M + base, n, pk, n * seq_rows.shape[1] * 4, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
-                                    np.ascontiguousarray(meta[:, :4]).reshape(-1))
+                    hs.build_packed_dev(M + base, n, qseq_dev[base:base + n].data_ptr(), n * seq_rows.shape[1] * 4, np.arange(n, dtype=np.uint32), starts,
+                                        starts + lens - np.uint64(1), lens, np.ascontiguousarray(meta[:, :4]).reshape(-1))
                     return
                 hs.import_done(M + base, n)
 
@@ -374,6 +455,7 @@ def main():
         block = shard.ShardedBlockScorer(dist, plan, GpuBackend(), rank, device="cuda")
 
     tiles_ms, launches = [], []
+    totals = []                     # N > 1: the close counts' all-gathers in flight (shard.ShardedBlockScorer.score(defer=True))
     checks = []                     # --check: per timed step, close candidates per query of the block (all ranks)
     cw = args.check_world if world == 1 and args.check_world > 1 else 0
     if cw:
@@ -399,13 +481,20 @@ def main():
                 # first one); the NEXT block's all-gathers go out before this block is scored and run underneath it
                 cur, nxt = st % 2, (st + 1) % 2
                 if pending[cur] is None:
+                    first_of_base[cur * Q] = block_first(st)
                     pending[cur] = block.begin_packed(block_first(st), qpr, base=cur * Q)
                 block.finish(pending[cur], Q, base=cur * Q)
                 pending[cur] = None
+                first_of_base[nxt * Q] = block_first(st + 1)
                 pending[nxt] = block.begin_packed(block_first(st + 1), qpr, base=nxt * Q)
-                _, total = block.score(Q, base=cur * Q)
-                if args.check:
-                    checks.append([int(x) for x in total])
+                # the per-query close counts of the block (all ranks summed) are the step's result; their all-gather is issued here and
+                # waited for one step later (or at the end): nothing in this step needs them
+                _, total = block.score(Q, base=cur * Q, defer=True)
+                totals.append(total)
+                if len(totals) > 1:
+                    done = totals.pop(0).total()
+                    if args.check:
+                        checks.append([int(x) for x in done])
             else:
                 if cw:          # the block a cw-rank run assembles at this step: rank r's local slots first .. first + Q / cw - 1, rank-major
                     first = (st * (Q // cw) * 131) % (m_min_w - Q // cw + 1)
@@ -435,6 +524,9 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    for tt in totals:
+        tt.total()
+    totals.clear()
     tiles_ms.clear()
     launches.clear()
     checks.clear()
@@ -445,6 +537,11 @@ def main():
     for half in pending:             # the block issued by the last timed step: every rank issued it, so it completes
         for w in half or []:
             w.wait()
+    for tt in totals:                # the counts of the last step
+        done = tt.total()
+        if args.check:
+            checks.append([int(x) for x in done])
+    totals.clear()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -481,6 +578,8 @@ def main():
     alg_bytes = per_call * len(tiles_ms) // n_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     config_key = "nseq=%d,len=%d,k=%d,dtype=%d,queries=%d,mode=%s,kernel=%s" % (M, args.length, args.k, args.dtype, Q, args.mode, kernel)
+    if args.repeats:
+        config_key += ",repeats=%g" % args.repeats
     if args.weights:
         config_key += ",weights=" + os.path.basename(args.weights)
     if args.layout == "sparse":
@@ -497,7 +596,7 @@ def main():
         "dtype": "u%d" % args.dtype, "data": "synthetic",
         "config": {"workload": "%s: %d x %d bp synthetic sequences, %s, k=%d, datatype=%d, %s layout, resident in HBM; step = %d query histograms x all "
                                "histograms (model %s: %d single statistics + %d-combo GLM + close flag per pair), mode %s"
-                               % ("cfg2" if is_cfg2 else "custom (not a BASELINE config)", n_total, args.length, per_gpu, args.k, args.dtype, args.layout, Q, os.path.basename(wpath),
+                               % (("cfg2" if not args.repeats else "cfg2 with a 400-base repeat in %g %% of the sequences" % (100 * args.repeats)) if is_cfg2 else "custom (not a BASELINE config)", n_total, args.length, per_gpu, args.k, args.dtype, args.layout, Q, os.path.basename(wpath),
                                   feat.n_singles, feat.n_combos, args.mode),
                    "pairs_per_step": Q * n_total, "pairs_timed": pairs,
                    "projected_seconds_full_matrix": round(float(n_total) ** 2 / (pairs / dt), 1), "hist_bytes": hist_bytes if args.layout == "sparse" else (4 ** args.k) * esz,
@@ -537,6 +636,11 @@ def main():
                                  "algorithmic_ops_per_launch": ops})
     if args.check:
         line["check"] = checks
+    if world == 1 and args.secondary and args.mode == "allpairs" and args.layout == "dense":
+        try:
+            line["secondary"] = secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext)
+        except Exception as e:      # noqa: BLE001 -- the main line must not depend on the extra legs
+            line["secondary"] = [{"workload": "failed", "error": repr(e)}]
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:
             try:

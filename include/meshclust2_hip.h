@@ -176,6 +176,15 @@ int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, 
                           const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs,
                           const uint64_t* eff_len, const uint64_t* one_mers);
 
+/* The same with `packed` in THIS device's memory (every other array on the host, as above): the form a multi-GPU driver uses for
+ * sequences that arrived over xGMI -- fastcar's outer loop hands each chunk of queries to every database chunk
+ * (fastcar/FC_Runner.cpp:585-597); with the database sharded over GPUs the chunk's bases are all-gathered device to device and
+ * each rank builds the block's histograms itself. */
+int msc_hist_build_packed_dev(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs,
+                              const void* packed_dev, uint64_t n_bases,
+                              const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs,
+                              const uint64_t* eff_len, const uint64_t* one_mers);
+
 /* Debug / parity: bins in NATURAL k-mer order (first base most significant), 4^k * dtype/8 bytes. */
 int msc_hist_download(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, void* bins_out);
 int msc_hist_upload(msc_ctx* ctx, msc_hist_set* set, uint64_t slot, const void* bins, uint64_t length,

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "msc_hist_set_bytes": (_u64, [_vp]),
     "msc_hist_build": (_int, [_vp, _vp, _u64, _u64, C.POINTER(C.c_char_p), _pu64, _int]),
     "msc_hist_build_packed": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
+    "msc_hist_build_packed_dev": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
     "msc_hist_download": (_int, [_vp, _vp, _u64, _vp]),
     "msc_hist_upload": (_int, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "msc_hist_info_get": (_int, [_vp, _vp, _u64, C.POINTER(HistInfo)]),

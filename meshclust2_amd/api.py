@@ -143,6 +143,17 @@ class HistogramSet:
         self.ctx.check(self.ctx.lib.msc_hist_build_packed(self.ctx.h, self.h, first_slot, n_seqs, _ptr(packed), int(n_bases), _ptr(seg_seq),
                                                           _ptr(seg_start), _ptr(seg_end), len(seg_seq), _ptr(eff_len), _ptr(one_mers)))
 
+    def build_packed_dev(self, first_slot, n_seqs, packed_dev_ptr, n_bases, seg_seq, seg_start, seg_end, eff_len, one_mers):
+        """build_packed with the 2-bit stream already in this device's memory (packed_dev_ptr: an integer device address, e.g. a torch
+        tensor's data_ptr()); the segment table and the per-sequence scalars stay host arrays"""
+        seg_seq = np.ascontiguousarray(seg_seq, dtype=np.uint32)
+        seg_start = np.ascontiguousarray(seg_start, dtype=np.uint64)
+        seg_end = np.ascontiguousarray(seg_end, dtype=np.uint64)
+        eff_len = np.ascontiguousarray(eff_len, dtype=np.uint64)
+        one_mers = np.ascontiguousarray(one_mers, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.msc_hist_build_packed_dev(self.ctx.h, self.h, first_slot, n_seqs, C.c_void_p(int(packed_dev_ptr)), int(n_bases), _ptr(seg_seq),
+                                                              _ptr(seg_start), _ptr(seg_end), len(seg_seq), _ptr(eff_len), _ptr(one_mers)))
+
     def download(self, slot):
         out = np.zeros(self.nbins, dtype=NP_T[self.dtype])
         self.ctx.check(self.ctx.lib.msc_hist_download(self.ctx.h, self.h, slot, _ptr(out)))

@@ -652,7 +652,7 @@ static int build_sparse_sort(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slo
 	const size_t tail_off = round4 >= 4 ? round4 - 4 : 0;
 	if ((r = ensure(ctx, ctx->packed, padded_bytes))) return r;
 	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + tail_off, 0, padded_bytes - tail_off, ctx->stream));
-	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, ctx->packed_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
 	if ((r = ensure(ctx, ctx->seg_start, std::max<size_t>(n_segs, 1) * sizeof(uint64_t)))) return r;
 	if ((r = ensure(ctx, ctx->kmer_off, (n_segs + 1) * sizeof(uint64_t)))) return r;
 	if ((r = ensure(ctx, ctx->seq_seg, (n_seqs + 1) * sizeof(uint64_t)))) return r;
@@ -771,7 +771,7 @@ extern "C" int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t f
 	int r;
 	if ((r = ensure(ctx, ctx->packed, padded_bytes)) != MSC_OK) return r;
 	HIP_TRY(ctx, hipMemsetAsync((uint8_t*)ctx->packed.p + tail_off, 0, padded_bytes - tail_off, ctx->stream));
-	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+	if (packed_bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->packed.p, packed, packed_bytes, ctx->packed_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
 	if (n_segs) {
 		if ((r = ensure(ctx, ctx->seg_seq, n_segs * sizeof(uint32_t))) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->seg_start, n_segs * sizeof(uint64_t))) != MSC_OK) return r;
@@ -896,6 +896,17 @@ void encode_range(const char* const* seqs, const uint64_t* lens, int strip, uint
 	}
 }
 }  // namespace
+
+// the same with the 2-bit stream already on this device (a query block another rank sent over xGMI): no host hop for the bases
+extern "C" int msc_hist_build_packed_dev(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const void* packed_dev,
+                                         uint64_t n_bases, const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end,
+                                         uint64_t n_segs, const uint64_t* eff_len, const uint64_t* one_mers) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	ctx->packed_on_device = true;
+	const int r = msc_hist_build_packed(ctx, set, first_slot, n_seqs, (const uint8_t*)packed_dev, n_bases, seg_seq, seg_start, seg_end, n_segs, eff_len, one_mers);
+	ctx->packed_on_device = false;
+	return r;
+}
 
 extern "C" int msc_hist_build(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs, const char* const* seqs,
                               const uint64_t* lens, int strip) {

@@ -193,18 +193,26 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks(const uint32_t* __restrict
 		};
 		stage(0);
 		for (uint32_t g = 0; g < n_groups; g++) {          // two half-groups per turn: ring slots 0 and 1
-			landed();
-			stage(2 * g + 1);
-			walk(0, std::integral_constant<uint32_t, 0>());
-			landed();
-			if (g + 1 < n_groups) stage(2 * g + 2);
-			walk(1, std::integral_constant<uint32_t, 1>());
 			uint32_t nq_max = 0;
 			for (uint32_t q = 0; q < kQGroup; q++) {
 				const uint32_t qi = g * kQGroup + q;
 				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
 				nq_max = v > nq_max ? v : nq_max;
 			}
+			// a later round that lies past every list of this wave's candidates and of the group is all | nbins - nbins |: the wave
+			// keeps the ring's pace (barriers, its share of the pieces) and skips the walk -- one long list in a set makes every pass
+			// two rounds, and all but a few pairs end in the first
+			uint32_t reach = nq_max;
+#pragma unroll
+			for (uint32_t c = 0; c < kCandPerWave; c++) reach = nc[c] > reach ? nc[c] : reach;
+			const bool idle = base != 0 && base >= reach;
+			landed();
+			stage(2 * g + 1);
+			if (!idle) walk(0, std::integral_constant<uint32_t, 0>());
+			landed();
+			if (g + 1 < n_groups) stage(2 * g + 2);
+			if (idle) continue;
+			walk(1, std::integral_constant<uint32_t, 1>());
 			const uint32_t q0 = g * kQGroup;
 			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
 #pragma unroll

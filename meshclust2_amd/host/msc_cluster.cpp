@@ -350,7 +350,10 @@ int main(int argc, char** argv) {
 		return 1;
 	}
 	const msc::CommEnv env = msc::CommEnv::from_environment();
-	const bool sharded = env.world > 1;
+	// MSC_FORCE_SHARDED: the rank driver (ShardedBackend over RcclComm) also for WORLD_SIZE = 1 -- every collective of the RCCL transport
+	// then runs on one GPU (the 1-GPU test of that code path)
+	const bool sharded = env.world > 1 || std::getenv("MSC_FORCE_SHARDED") != nullptr;
+	if (sharded && no_ranges) { std::fprintf(stderr, "--no-ranges is a switch of the one-process driver: the rank driver always scores position ranges\n"); return 1; }
 	if (sharded && !std::getenv("MSC_ONE_GPU")) device = env.local_rank;
 	try {
 		const auto t_start = std::chrono::steady_clock::now();
@@ -364,11 +367,18 @@ int main(int argc, char** argv) {
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		std::unique_ptr<msc::TcpComm> boot;          // rendezvous of the ranks (and the whole transport under MSC_COMM=tcp)
 		if (sharded) boot.reset(new msc::TcpComm(env));
-		if (weights.empty() && sharded && env.rank != 0) {          // rank 0 chooses k and the histogram type and trains; the others wait for its file
-			int64_t kd[2] = {0, 0};
+		if (weights.empty() && sharded && env.rank != 0) {
+			// rank 0 chooses k and the histogram type and trains; the others wait for (k, type, length of the weights text) and then the
+			// text itself -- not for a file in a shared working directory -- with no deadline on this one wait (training has none)
+			int64_t kd[3] = {0, 0, 0};
+			boot->set_timeout(7 * 24 * 3600);
 			boot->broadcast(kd, sizeof kd, 0, false);
+			boot->set_timeout(300);
 			k = (int)kd[0]; dtype = (int)kd[1];
-			weights = dump;
+			std::string text((size_t)kd[2], '\0');
+			boot->broadcast(&text[0], text.size(), 0, false);
+			weights = dump + ".rank" + std::to_string(env.rank);
+			std::ofstream(weights.c_str()) << text;
 		}
 		if (weights.empty()) {
 			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average record size)) - 1, integer averages
@@ -393,7 +403,12 @@ int main(int argc, char** argv) {
 			std::ofstream(dump.c_str()) << text;       // the reference always leaves weights.txt behind (cluster/Trainer.cpp:188-190)
 			weights = dump;
 			std::cout << "timestamp GLM " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << std::endl;
-			if (sharded) { int64_t kd[2] = {k, dtype}; boot->broadcast(kd, sizeof kd, 0, false); }
+			if (sharded) {
+				int64_t kd[3] = {k, dtype, (int64_t)text.size()};
+				boot->broadcast(kd, sizeof kd, 0, false);
+				std::string copy = text;
+				boot->broadcast(&copy[0], copy.size(), 0, false);
+			}
 		}
 		msc::Trainer trn(ctx, weights, similarity);
 		if (k < 0) k = msc_model_k(trn.feature().get());

@@ -193,6 +193,13 @@ public:
 		if (dev) to_device(buf, h, n * 8);
 	}
 
+	// the receive / send deadline of every socket from now on (the wait for rank 0's trained model may take longer than a collective)
+	void set_timeout(int seconds) {
+		timeout_s_ = seconds;
+		for (int s : peers_) if (s >= 0) tune(s);
+		if (root_ >= 0) tune(root_);
+	}
+
 private:
 	uint8_t* host_view(void* buf, size_t bytes, bool dev, bool fill) {
 		if (!dev) return (uint8_t*)buf;

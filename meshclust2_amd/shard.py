@@ -150,7 +150,22 @@ class ShardedBlockScorer:
             w.wait()
         self.backend.import_queries(n, base)
 
-    def score(self, n, base=0):
+    class _Totals:
+        """the per-query close counts of a block, all ranks summed: the all-gather was only ISSUED by score(defer=True); total() waits
+        for it and brings the sums to the host"""
+        def __init__(self, work, out, world):
+            self.work, self.out, self.world, self.value = work, out, world, None
+
+        def total(self):
+            if self.value is None:
+                if self.work is not None:
+                    self.work.wait()
+                self.value = self.out.view(self.world, -1).sum(dim=0).cpu().numpy()
+            return self.value
+
+    def score(self, n, base=0, defer=False):
+        """-> (close flags of this rank's shard, per-query close counts over all ranks). defer=True: the counts' all-gather is issued
+        and a _Totals handle returned in their place -- the step does not wait for a collective it needs nothing from"""
         import torch
         close = self.backend.score_block(n, base)
         # a backend may hand back (flags, per-query counts): a block of 1 024 queries x 12 500 candidates is 12.8 MB of flags, 6-10 ms of
@@ -161,12 +176,12 @@ class ShardedBlockScorer:
             row_counts = np.einsum("ij->i", close, dtype=np.uint64)
         counts = torch.tensor(np.asarray(row_counts, dtype=np.float64), dtype=torch.float64, device=self.device)
         if self.plan.world > 1:
-            out = [torch.zeros_like(counts) for _ in range(self.plan.world)]
-            self.dist.all_gather(out, counts)
-            total = torch.stack(out).sum(dim=0).cpu().numpy()
+            out = torch.zeros(self.plan.world * counts.numel(), dtype=torch.float64, device=self.device)
+            work = self.dist.all_gather_into_tensor(out, counts, async_op=True)
+            totals = self._Totals(work, out, self.plan.world)
         else:
-            total = counts.cpu().numpy()
-        return close, total
+            totals = self._Totals(None, counts, 1)
+        return close, (totals if defer else totals.total())
 
     def score_block(self, query_globals):
         n = len(query_globals)

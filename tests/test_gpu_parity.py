@@ -1813,6 +1813,89 @@ def test_multi_rank_cluster_driver_on_the_gpu(tmp_path, case, ranks, extra):
     assert steps > 0 and coll <= 2 * steps + overflow
 
 
+def _cluster_case(case, tmp_path):
+    """(arguments, fixture name, shard block) of a .clstr fixture case for msc_cluster; writes in.fa"""
+    import os
+    from golden_util import cfg5_set
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    if case.startswith("cfg5"):
+        seqs, hdrs = cfg5_set(run_cap=900 if case == "cfg5" else 3000)
+        args = ["--recover", os.path.join(golden, "weights_%s_k9.txt" % case), "--id", "0.6", "--kmer", "9"]
+        clstr, block = case + ".clstr", 16
+    else:
+        seed, n, fam, wts, clstr = {"cfg1": (20260001, 1000, 20, "weights_k5_u16.txt", "cfg1.clstr"), "k9_u8": (61, 320, 16, "weights_k9_u8.txt", "k9_u8.clstr")}[case]
+        seqs, hdrs = synth.families(seed, n, 1000, family=fam)
+        args = ["--recover", os.path.join(golden, wts), "--id", "0.9"] + (["--kmer", "5", "--datatype", "16"] if case == "cfg1" else [])
+        block = 100 if case == "cfg1" else 40
+    fa = str(tmp_path / "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    return [fa] + args, os.path.join(golden, clstr), block
+
+
+@pytest.mark.parametrize("case,extra", [("k9_u8", []), ("k9_u8", ["--sparse"]), ("cfg5", ["--sparse"]), ("cfg5", []), ("cfg1", [])])
+def test_rank_driver_over_rccl_on_one_gpu(tmp_path, case, extra):
+    """The RCCL transport of the rank driver (host/msc_comm_rccl.hpp) EXECUTED: msc_cluster with MSC_FORCE_SHARDED and WORLD_SIZE = 1
+    takes ShardedBackend + RcclComm with the one-rank shortcuts off, so ncclCommInitRankConfig (non-blocking), the in-place
+    ncclAllGather, ncclBroadcast, ncclAllReduce(uint64) and the host staging all run on the ctx stream of a real GPU -- and the run
+    writes the reference CLI's .clstr byte for byte. (Every other sharded test moves its bytes over sockets: MSC_COMM=tcp.)"""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args, fixture, block = _cluster_case(case, tmp_path)
+    out = str(tmp_path / "out.clstr")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29711", MSC_FORCE_SHARDED="1", MSC_SHARD_BLOCK=str(block),
+               MSC_COMM_TIMEOUT_S="120")
+    env.pop("MSC_COMM", None)
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + args + ["--output", out] + extra, cwd=str(tmp_path), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    log = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, log[-3000:]
+    assert open(out, "rb").read() == open(fixture, "rb").read()
+    m = re.search(r"collectives: broadcast (\d+) all_gather (\d+) all_reduce (\d+)", log)
+    assert m, log[-1500:]
+    bc, ag, ar = (int(x) for x in m.groups())
+    assert ag > 0 and (bc > 0 or ar > 0), log[-1500:]          # the collectives ran through RCCL, they were not short-cut
+    steps, coll, overflow = _step_collectives(log)
+    assert steps > 0 and coll <= 2 * steps + overflow
+
+
+def test_rank_driver_over_rccl_on_two_gpus(tmp_path):
+    """Two ranks of msc_cluster on two GPUs over RCCL (xGMI) -- only where the box has two (this pool's boxes have one: skipped there)."""
+    import os
+    import socket
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args, fixture, block = _cluster_case("k9_u8", tmp_path)
+    out = str(tmp_path / "out.clstr")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSC_SHARD_BLOCK=str(block),
+                   MSC_COMM_TIMEOUT_S="120")
+        env.pop("MSC_COMM", None)
+        env.pop("MSC_ONE_GPU", None)
+        procs.append(subprocess.Popen([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + args + ["--output", out, "--sparse"], cwd=str(tmp_path), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p_ in procs:
+        try:
+            logs.append(p_.communicate(timeout=600)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(logs)[-3000:]
+    assert open(out, "rb").read() == open(fixture, "rb").read()
+
+
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, []), (2, ["--sparse"]), (3, ["--sparse"])])
 def test_multi_rank_cluster_driver_mixed_lengths(tmp_path, ranks, extra):
     """The fixtures above hold few real windows; here the lengths spread over 900-1100 bases, so every step scores a real window,
