@@ -41,15 +41,20 @@ typedef struct {
 	int (*update_centres)(void* user, const uint32_t* centres, uint64_t n, const uint32_t* points, const uint64_t* offsets, int64_t* nearest);
 	int (*centre_set_batch)(void* user, const uint32_t* centres, const uint32_t* points, uint64_t n);
 	int (*merge_all)(void* user, const uint32_t* centres, uint64_t n, int delta, int64_t* best);
-	/* optional (all three or none): the window of get_close kept on the callee's side (msc_window in meshclust2_hip.h).
-	 *   set_order: order[pos] = point at position pos of the sealed length-binned store; every position starts alive.
-	 *   get_close_range: get_close over the alive positions of [first, end) in position order; close[0..*n_close) (room for
-	 *     end - first) = the positions it marks, ascending -- they leave the store with the call; *best = position of the arg-max or -1.
-	 *   kill: a position that leaves the store otherwise (the next seed: bvec::erase / bvec::pop). */
+} msc_cluster_callbacks;
+
+/* The window of get_close kept on the callee's side (msc_window in meshclust2_hip.h): a struct and an entry point of their own, so that
+ * msc_cluster_callbacks keeps the layout clients were compiled against (a struct that grows at its tail is read past its end when an
+ * older client passes the shorter one). All three or none.
+ *   set_order: order[pos] = point at position pos of the sealed length-binned store; every position starts alive.
+ *   get_close_range: get_close over the alive positions of [first, end) in position order; close[0..*n_close) (room for
+ *     end - first) = the positions it marks, ascending -- they leave the store with the call; *best = position of the arg-max or -1.
+ *   kill: a position that leaves the store otherwise (the next seed: bvec::erase / bvec::pop). */
+typedef struct {
 	int (*set_order)(void* user, const uint32_t* order, uint64_t n);
 	int (*get_close_range)(void* user, uint32_t q, uint64_t first, uint64_t end, uint32_t* close, uint64_t* n_close, int64_t* best, int* is_min);
 	int (*kill)(void* user, uint64_t pos);
-} msc_cluster_callbacks;
+} msc_cluster_window_callbacks;
 
 /* do_run's tail + ClusterFactory::MS over n points (headers[i] = full header line incl. '>', lengths[i] = effective length).
  * output: .clstr path, or NULL to write nothing (ranks other than 0). log: path of the progress log ("timestamp ..." lines,
@@ -57,6 +62,10 @@ typedef struct {
  * Returns 0, a callback's status, or -1 (err says what). */
 int msc_cluster_run(const msc_cluster_callbacks* cb, uint64_t n, const char* const* headers, const uint64_t* lengths, double similarity,
                     int delta, int iterations, const char* output, const char* log, int batch_update, char* err, size_t cap);
+/* the same with the window callbacks (wcb may be NULL: then exactly msc_cluster_run); wcb's `user` is cb->user */
+int msc_cluster_run_windows(const msc_cluster_callbacks* cb, const msc_cluster_window_callbacks* wcb, uint64_t n, const char* const* headers,
+                            const uint64_t* lengths, double similarity, int delta, int iterations, const char* output, const char* log,
+                            int batch_update, char* err, size_t cap);
 
 /* ---- the length-binned store on its own (cluster/bvec.{h,cpp}, cluster/bvec_iterator.h), for the CPU fuzz that holds it to the
  * reference's bvec (tests/test_driver_cpu.py). Record i has length lengths[i]; records are added in index order, then sealed. */

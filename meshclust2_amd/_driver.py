@@ -26,12 +26,18 @@ KILL = C.CFUNCTYPE(_int, _vp, _u64)
 class Callbacks(C.Structure):
     _fields_ = [("user", _vp), ("get_close", GET_CLOSE), ("closest", CLOSEST), ("centre_new", CENTRE_NEW), ("centre_set", CENTRE_SET),
                 ("filter", FILTER), ("merge", MERGE), ("update_centres", UPDATE_CENTRES), ("centre_set_batch", CENTRE_SET_BATCH),
-                ("merge_all", MERGE_ALL), ("set_order", SET_ORDER), ("get_close_range", GET_CLOSE_RANGE), ("kill", KILL)]
+                ("merge_all", MERGE_ALL)]
+
+
+class WindowCallbacks(C.Structure):
+    _fields_ = [("set_order", SET_ORDER), ("get_close_range", GET_CLOSE_RANGE), ("kill", KILL)]
 
 
 PROTOTYPES = {
     "msc_cluster_run": (_int, [C.POINTER(Callbacks), _u64, C.POINTER(C.c_char_p), _pu64, C.c_double, _int, _int, C.c_char_p, C.c_char_p, _int,
                                C.c_char_p, C.c_size_t]),
+    "msc_cluster_run_windows": (_int, [C.POINTER(Callbacks), C.POINTER(WindowCallbacks), _u64, C.POINTER(C.c_char_p), _pu64, C.c_double, _int, _int, C.c_char_p,
+                                       C.c_char_p, _int, C.c_char_p, C.c_size_t]),
     "msc_bins_create": (_vp, [_pu64, _u64, _u64]),
     "msc_bins_destroy": (None, [_vp]),
     "msc_bins_count": (_u64, [_vp]),
@@ -159,15 +165,18 @@ def run(backend, headers, lengths, similarity, delta=5, iterations=15, output=No
     cb = Callbacks(None, GET_CLOSE(get_close), CLOSEST(closest), CENTRE_NEW(centre_new), CENTRE_SET(centre_set), FILTER(filter_), MERGE(merge),
                    UPDATE_CENTRES(update_centres) if hasattr(backend, "update_centres") else UPDATE_CENTRES(),
                    CENTRE_SET_BATCH(centre_set_batch) if hasattr(backend, "centre_set_batch") else CENTRE_SET_BATCH(),
-                   MERGE_ALL(merge_all) if hasattr(backend, "merge_all") else MERGE_ALL(),
-                   SET_ORDER(set_order) if ranged else SET_ORDER(), GET_CLOSE_RANGE(get_close_range) if ranged else GET_CLOSE_RANGE(),
-                   KILL(kill) if ranged else KILL())
+                   MERGE_ALL(merge_all) if hasattr(backend, "merge_all") else MERGE_ALL())
+    wcb = WindowCallbacks(SET_ORDER(set_order), GET_CLOSE_RANGE(get_close_range), KILL(kill)) if ranged else None
     n = len(headers)
     hdr = (C.c_char_p * max(n, 1))(*[h if isinstance(h, bytes) else h.encode() for h in headers])
     lens = (C.c_uint64 * max(n, 1))(*[int(x) for x in lengths])
     err = C.create_string_buffer(512)
-    rc = lib.msc_cluster_run(C.byref(cb), n, hdr, lens, float(similarity), int(delta), int(iterations), output.encode() if output else None,
-                             log.encode() if log else None, 1 if batch_update else 0, err, len(err))
+    if wcb is not None:
+        rc = lib.msc_cluster_run_windows(C.byref(cb), C.byref(wcb), n, hdr, lens, float(similarity), int(delta), int(iterations), output.encode() if output else None,
+                                         log.encode() if log else None, 1 if batch_update else 0, err, len(err))
+    else:
+        rc = lib.msc_cluster_run(C.byref(cb), n, hdr, lens, float(similarity), int(delta), int(iterations), output.encode() if output else None,
+                                 log.encode() if log else None, 1 if batch_update else 0, err, len(err))
     if failure:
         raise failure[0]
     if rc != 0:

@@ -32,6 +32,7 @@ class Context:
         self.h = h
         self.device = device
         self._children = []          # weakrefs to sets / models so that close() can release them before the ctx
+        self._pinned = []            # page-locked host arrays handed out by pinned_array
 
     def _adopt(self, obj):
         self._children.append(weakref.ref(obj))
@@ -75,6 +76,9 @@ class Context:
                 if obj is not None:
                     obj.close()
             self._children = []
+            for p in getattr(self, "_pinned", []):
+                self.lib.msc_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.lib.msc_destroy(self.h)
             self.h = None
 
@@ -318,6 +322,7 @@ def pinned_array(ctx, shape, dtype):
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
     p = C.c_void_p()
     ctx.check(ctx.lib.msc_host_alloc(ctx.h, n, C.byref(p)))
+    ctx._pinned.append(p.value)          # released by Context.close (msc_host_free); the array must not be used after that
     buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 

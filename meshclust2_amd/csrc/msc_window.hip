@@ -179,12 +179,17 @@ extern "C" int msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* posi
 	if (!ctx || !w || w->ctx != ctx || (!positions && n)) return MSC_ERR_INVALID_ARG;
 	if (n == 0) return MSC_OK;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// validate the whole call first, then apply it: a rejected call leaves the tree, the pending list and the device flags as they
+	// were (a half-applied one would leave the host's count below the number of alive flags, and the next range scored short)
+	std::vector<uint32_t> sorted(positions, positions + n);
+	std::sort(sorted.begin(), sorted.end());
 	for (uint64_t i = 0; i < n; i++) {
-		if (positions[i] >= w->n) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position out of range");
+		if (sorted[i] >= w->n) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position out of range");
+		if (i && sorted[i] == sorted[i - 1]) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position %u is listed twice", sorted[i]);
 		// (a position may die once: the tree holds what the device flags hold)
-		if (fen_prefix(w->fen, (uint64_t)positions[i] + 1) - fen_prefix(w->fen, positions[i]) == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position %u is already dead", positions[i]);
-		fen_add(w->fen, positions[i], -1);
+		if (fen_prefix(w->fen, (uint64_t)sorted[i] + 1) - fen_prefix(w->fen, sorted[i]) == 0) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_window_kill: position %u is already dead", sorted[i]);
 	}
+	for (uint64_t i = 0; i < n; i++) fen_add(w->fen, positions[i], -1);
 	w->pending.insert(w->pending.end(), positions, positions + n);
 	return MSC_OK;
 }

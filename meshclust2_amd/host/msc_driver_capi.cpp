@@ -15,7 +15,8 @@ struct CallbackError { int code; };
 
 struct CallbackBackend : msc::ClusterBackend {
 	const msc_cluster_callbacks& cb;
-	explicit CallbackBackend(const msc_cluster_callbacks& c) : cb(c) {}
+	const msc_cluster_window_callbacks wcb;          // (a copy: all NULL when the caller has no window callbacks)
+	CallbackBackend(const msc_cluster_callbacks& c, const msc_cluster_window_callbacks& w) : cb(c), wcb(w) {}
 	static void check(int rc) { if (rc) throw CallbackError{rc}; }
 	void get_close(uint32_t q, const std::vector<uint32_t>& window, std::vector<uint8_t>& flags, int64_t& pos, bool& is_min) override {
 		flags.assign(window.size(), 0);
@@ -62,8 +63,8 @@ struct CallbackBackend : msc::ClusterBackend {
 		return true;
 	}
 	bool set_order(const std::vector<uint32_t>& order) override {
-		if (!cb.set_order || !cb.get_close_range || !cb.kill) return false;
-		check(cb.set_order(cb.user, order.data(), order.size()));
+		if (!wcb.set_order || !wcb.get_close_range || !wcb.kill) return false;
+		check(wcb.set_order(cb.user, order.data(), order.size()));
 		return true;
 	}
 	void get_close_range(uint32_t q, uint64_t first, uint64_t end, std::vector<uint32_t>& close, int64_t& best, bool& is_min) override {
@@ -71,12 +72,12 @@ struct CallbackBackend : msc::ClusterBackend {
 		uint64_t n = 0;
 		int im = 1;
 		best = -1;
-		check(cb.get_close_range(cb.user, q, first, end, close.data(), &n, &best, &im));
+		check(wcb.get_close_range(cb.user, q, first, end, close.data(), &n, &best, &im));
 		if (n > close.size()) throw std::runtime_error("get_close_range callback returned more positions than the range holds");
 		close.resize((size_t)n);
 		is_min = im != 0;
 	}
-	void kill(uint64_t pos) override { check(cb.kill(cb.user, pos)); }
+	void kill(uint64_t pos) override { check(wcb.kill(cb.user, pos)); }
 };
 
 void put_error(char* err, size_t cap, const std::string& msg) {
@@ -95,6 +96,12 @@ struct Bins {
 
 extern "C" int msc_cluster_run(const msc_cluster_callbacks* cb, uint64_t n, const char* const* headers, const uint64_t* lengths, double similarity,
                                int delta, int iterations, const char* output, const char* log, int batch_update, char* err, size_t cap) {
+	return msc_cluster_run_windows(cb, nullptr, n, headers, lengths, similarity, delta, iterations, output, log, batch_update, err, cap);
+}
+
+extern "C" int msc_cluster_run_windows(const msc_cluster_callbacks* cb, const msc_cluster_window_callbacks* wcb, uint64_t n, const char* const* headers,
+                                       const uint64_t* lengths, double similarity, int delta, int iterations, const char* output, const char* log,
+                                       int batch_update, char* err, size_t cap) {
 	if (!cb || !cb->get_close || !cb->closest || !cb->centre_new || !cb->centre_set || !cb->filter || !cb->merge || (n && (!headers || !lengths))) {
 		put_error(err, cap, "msc_cluster_run: NULL argument or missing callback");
 		return -1;
@@ -104,7 +111,7 @@ extern "C" int msc_cluster_run(const msc_cluster_callbacks* cb, uint64_t n, cons
 		for (uint64_t i = 0; i < n; i++) { recs[i].header = headers[i]; recs[i].length = lengths[i]; }
 		std::ofstream logfile;
 		if (log) logfile.open(log);
-		CallbackBackend be(*cb);
+		CallbackBackend be(*cb, wcb ? *wcb : msc_cluster_window_callbacks{nullptr, nullptr, nullptr});
 		msc::MeanShift ms(be, log ? (std::ostream&)logfile : (std::ostream&)std::cout);
 		ms.batch_update = batch_update != 0;
 		if (n) ms.run(recs, similarity, iterations, delta, output);
