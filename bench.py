@@ -219,15 +219,22 @@ def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what):
 
 
 def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
-    """Three short legs behind the timed region, same process, same resident data where possible: the 1 x M pass the
+    """Four short legs behind the timed region, same process, same resident data where possible: the 1 x M pass the
     clustering loop runs -- over the dense 32-bit set, over the sparse layout of the same sequences (k = 9), and over sparse 64-bit lists
     of 8 000 x 20 kb sequences at k = 13 (BASELINE cfg4's shape). Algorithmic bytes per pass: SURVEY 8(d)'s 4^k sizeof(T) per candidate
     for the dense set; 8 bytes per stored bin of the candidate's list for the sparse ones."""
     rows = []
     feat = api.Feature.from_text(ctx, wtext, 0)
     trn = api.Trainer(ctx, feat, 0.9)
-    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, (4 ** args.k) * (args.dtype // 8),
-                              "the resident set of the main leg: %d x %d bp, k=%d, datatype=%d, dense" % (M, args.length, args.k, args.dtype)))
+    what = "the resident set of the main leg: %d x %d bp, k=%d, datatype=%d, dense" % (M, args.length, args.k, args.dtype)
+    # the streaming kernel over the bins (SURVEY 8(d)'s 1 x M shape), then what the library does by default since r04: the same pass
+    # over the dense set's sparse mirror (8 bytes per counted k-mer)
+    ctx.set_mirror_pass(False)
+    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, (4 ** args.k) * (args.dtype // 8), what + ", msc_set_mirror_pass(0): the streaming kernel over the bins"))
+    ctx.set_mirror_pass(True)
+    trn.get_close(hs, None, hs, 1, m=M)          # (builds the mirror: untimed)
+    ent0 = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
+    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, ent0, what + ", default: the lists of its sparse mirror"))
     # the same sequences on the sparse layout, rebuilt from the 2-bit rows kept for the exchange
     stride = seq_rows.shape[1] * 4
     sp = api.HistogramSet(ctx, args.k, args.dtype, M, sparse_entries=M * (args.length + 64 + (400 if args.repeats > 0 else 0)))

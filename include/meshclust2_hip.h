@@ -118,6 +118,12 @@ int         msc_last_kernel_ms(const msc_ctx* ctx, float* pair_tiles_ms, float* 
 /* The events behind msc_last_kernel_ms cost four records per 1 x M call: a step-serial caller (the accumulate loop issues one
  * Trainer::get_close per step) switches them off; msc_last_kernel_ms then fails with MSC_ERR_INVALID_ARG. Default: on. */
 int         msc_set_kernel_timing(msc_ctx* ctx, int on);
+/* A dense set whose histograms have a list form (64 KiB and more) keeps a sparse mirror of its slots, and its 1 x M passes
+ * (Trainer::get_close / filter / merge, Feature::compute: cluster/Trainer.cpp:23-141) merge the two lists -- 8 bytes per counted k-mer
+ * instead of 4^k bins per candidate, same integer reductions. on = 0 keeps those passes on the streaming kernel over the bins (the
+ * 1 x M shape SURVEY 8(d) prices at 4^k sizeof(T) bytes per pair); results are identical either way. Default: on
+ * (off at start with MSC_NO_MIRROR_1XM in the environment). */
+int         msc_set_mirror_pass(msc_ctx* ctx, int on);
 /* Number of streaming-kernel launches that pair_tiles_ms sums over (large calls are chunked). */
 int         msc_last_kernel_launches(const msc_ctx* ctx);
 /* Which streaming kernel the LAST scoring call ran (its name is copied to buf) and how many queries one HBM read of a
@@ -148,7 +154,7 @@ uint64_t msc_hist_set_bytes(const msc_hist_set* set);              /* HBM footpr
  * total number of k-mers). Needs 4^k * dtype/8 >= 64 KiB. msc_hist_upload and the mean_out of msc_mean_nearest are not available on sparse sets. */
 int      msc_hist_set_create_sparse(msc_ctx* ctx, int k, int dtype, uint64_t capacity, uint64_t max_entries, msc_hist_set** out);
 int      msc_hist_set_is_sparse(const msc_hist_set* set);
-uint64_t msc_hist_set_entries(const msc_hist_set* set, uint64_t slot);     /* stored bins of one slot */
+uint64_t msc_hist_set_entries(const msc_hist_set* set, uint64_t slot);     /* stored bins of one slot (a dense set: of its sparse mirror, 0 before it exists) */
 /* Empties a sparse set: every slot back to "never written", the whole entry arena free again. The entry arena is append-only
  * (a slot that is assigned again leaves its old list behind), so a store of moving centres is compacted by copying its live slots
  * into a second set (msc_hist_copy_batch) and clearing the first for the next time -- no allocation in the loop. The reference has

@@ -59,6 +59,10 @@ class Context:
         """the HIP events behind last_kernel_ms: off for step-serial loops (four event records per call)"""
         self.check(self.lib.msc_set_kernel_timing(self.h, 1 if on else 0))
 
+    def set_mirror_pass(self, on):
+        """dense sets: 1 x M passes over the sparse mirror (default) or over the bins with the streaming kernel; same results"""
+        self.check(self.lib.msc_set_mirror_pass(self.h, 1 if on else 0))
+
     def last_kernel_launches(self):
         return self.lib.msc_last_kernel_launches(self.h)
 

@@ -118,6 +118,7 @@ extern "C" int msc_create(int device, msc_ctx** out) {
 		delete ctx;
 		return fail(nullptr, MSC_ERR_HIP, "msc_create: stream/event creation failed");
 	}
+	ctx->mirror_pass = getenv("MSC_NO_MIRROR_1XM") == nullptr;
 	*out = ctx;
 	return MSC_OK;
 }
@@ -190,6 +191,12 @@ extern "C" int msc_device_name(const msc_ctx* ctx, char* buf, size_t cap) {
 extern "C" int msc_synchronize(msc_ctx* ctx) {
 	if (!ctx) return MSC_ERR_INVALID_ARG;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_set_mirror_pass(msc_ctx* ctx, int on) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	ctx->mirror_pass = on != 0;
 	return MSC_OK;
 }
 
@@ -419,7 +426,11 @@ extern "C" int msc_hist_set_clear(msc_ctx* ctx, msc_hist_set* s) {
 }
 
 extern "C" int msc_hist_set_is_sparse(const msc_hist_set* s) { return s && s->sparse ? 1 : 0; }
-extern "C" uint64_t msc_hist_set_entries(const msc_hist_set* s, uint64_t slot) { return s && s->sparse && slot < s->capacity ? s->hdr_host[slot].nnz : 0; }
+extern "C" uint64_t msc_hist_set_entries(const msc_hist_set* s, uint64_t slot) {
+	if (!s || slot >= s->capacity) return 0;
+	if (s->sparse) return s->hdr_host[slot].nnz;
+	return s->sp_mirror && slot < s->sp_mirror->hdr_host.size() ? s->sp_mirror->hdr_host[slot].nnz : 0;
+}
 
 extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (!s) return;
@@ -1467,30 +1478,39 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// evaluation order in every route); the dense streaming kernel then only produces the integer reductions. Histograms too small
 	// for the sparse layout (< 64 KiB) keep the table form inside the streaming kernel.
 	const msc_hist_set *c_sp = nullptr, *q_sp = nullptr;
+	// r04: a DENSE set's 1 x M pass runs over its sparse mirror too whenever the mirror exists (histograms of 64 KiB and more, narrow
+	// range): the merge kernels read 8 bytes per counted k-mer where k_pair_tiles streams 4^k bins (cfg2: ~8 KB against 1 MiB per
+	// candidate), and return the same integer reductions bit for bit (test_sparse_sets_equal_dense_sets). The streaming kernel keeps
+	// the histograms without a list form, the wide range, and msc_mean_nearest's pass against a mean (only_tiles).
+	static const bool no_mirror_env = getenv("MSC_NO_SPARSE_MIRROR") != nullptr;
+	const bool no_mirror_pass = no_mirror_env || !ctx->mirror_pass;
+	bool via = false;
 	if (sp) { c_sp = cs; q_sp = rq.qset; }
-	else if (need_div || need_grp) {
+	else if (need_div || need_grp || (!wide && !rq.only_tiles && !no_mirror_pass && L.nbins == L.padded_bins)) {
 		if ((r = ensure_sparse_mirror(ctx, cs, &c_sp)) || (r = ensure_sparse_mirror(ctx, rq.qset, &q_sp))) return r;
 		if (!c_sp || !q_sp) c_sp = q_sp = nullptr;
+		via = c_sp != nullptr && !wide && !rq.only_tiles && !no_mirror_pass;
 	}
+	const bool lists = sp || via;          // the pass is a merge of two lists
 	// sim_mm / rre_k_r: from the lists where they exist, else (histograms under 64 KiB) by the dense group kernels -- a given (k, dtype)
 	// always takes the same one of the two, so a pair has one evaluation order in every route
 	const bool grp_dense = need_grp && !c_sp;
 	if (grp_dense && std::max(rq.cands->max_count, rq.qset->max_count) > 0xffffffffull)
 		return fail(ctx, MSC_ERR_UNSUPPORTED, "sim_mm / rre_k_r: counts above 2^32 - 1 are not supported");
-	const bool mirror_div = need_div && !sp && c_sp != nullptr;      // (the mirror may be here for the group statistics alone)
-	const bool inline_div = need_div && !sp && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
+	const bool mirror_div = need_div && !lists && c_sp != nullptr;      // (the mirror may be here for the group statistics alone)
+	const bool inline_div = need_div && !lists && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
-	if (sp) ctx->last_kernel = spk == SPK_MP && !need_div && msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz) ? "k_pair_sparse_wl" : sparse_kernel_name(spk);
+	if (lists) ctx->last_kernel = spk == SPK_MP && !need_div && msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz) ? "k_pair_sparse_wl" : sparse_kernel_name(spk);
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
 	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
 	// ... and so is the divergence form (sparse sets and the mirror pass of dense ones): its FP64 sums leave per granule of the merged
 	// order and are added in granule order by the epilogue, whatever the number of waves that shared a pair
 	const uint64_t mp_entries = c_sp ? (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz : 0;
-	const uint32_t mp_parts = c_sp && spk == SPK_MP && (need_div ? true : sp && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
+	const uint32_t mp_parts = c_sp && spk == SPK_MP && (need_div ? true : lists && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
 	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), mp_entries, ctx->num_cus, need_div) : 1;
 	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
 	const uint32_t DVN = div_records(spk, mp_entries);                // ... and {jd, js} records per candidate
-	const uint32_t PS = sp ? SPN : L.S;                               // partial records per candidate
+	const uint32_t PS = lists ? SPN : L.S;                            // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
 	chunk = std::max<uint64_t>(chunk, 1024);
@@ -1534,8 +1554,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (d_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (d_slots ? 0 : off * cs->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		if (sp) {
-			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, cs, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.qset, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
+		if (lists) {
+			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
 			                                mp_parts, DVN));
 		} else if (wide) {
@@ -1573,7 +1593,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		if (need_div && c_sp) { ea.div_direct = (const double*)ctx->div_partials.p; ea.div_direct_n = DVN; ea.div_base = L.nbins; }
 		if (need_grp) { ea.grp_pairs = (const double*)ctx->grp_pairs.p; ea.grp_self_c = (const double*)ctx->grp_self.p; ea.grp_self_q = (const double*)ctx->grp_self.p + (uint64_t)chunk * 16; }
 		ea.S = PS;
-		ea.sparse_base = sp ? L.nbins : 0;
+		ea.sparse_base = lists ? L.nbins : 0;
 		ea.m = mc;
 		ea.cand_scalars = c_scal;
 		ea.cand_scalar_stride = cs->scalar_stride;

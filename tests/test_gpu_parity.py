@@ -996,6 +996,35 @@ def test_cluster_driver_k8_dense_and_sparse_layouts(tmp_path, layout):
     assert open(str(tmp_path / "out.clstr"), "rb").read() == open(os.path.join(golden, "k8.clstr"), "rb").read()
 
 
+def test_dense_one_by_m_passes_stream_the_bins_when_told_to(tmp_path):
+    """Since r04 a dense set's 1 x M passes merge the lists of its sparse mirror (histograms of 64 KiB and more). The streaming kernel
+    over the bins (k_pair_tiles: SURVEY 8(d)'s 1 x M shape) stays behind msc_set_mirror_pass(0) / MSC_NO_MIRROR_1XM: the fixture and
+    oracle tests of this file once more with the switch set, in a process of their own, and both forms side by side here."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    ctx = api.Context(0)
+    seqs, _ = synth.families(4242, 60, 1000, family=6, length_jitter=90)
+    hs = api.HistogramSet(ctx, 9, 32, len(seqs))
+    hs.build(seqs)
+    feat = api.Feature.from_text(ctx, weights_text("weights_k9_u32.txt"), 0)
+    a = api.pair_features_raw(ctx, hs, None, hs, 3, FAST_MASK, m=len(seqs))
+    ka = ctx.last_kernel_info()[0]
+    sa = feat.compute(hs, None, hs, 3, m=len(seqs))
+    ctx.set_mirror_pass(False)
+    b = api.pair_features_raw(ctx, hs, None, hs, 3, FAST_MASK, m=len(seqs))
+    kb = ctx.last_kernel_info()[0]
+    sb = feat.compute(hs, None, hs, 3, m=len(seqs))
+    assert ka.startswith("k_pair_sparse") and kb == "k_pair_tiles", (ka, kb)
+    assert np.array_equal(a, b) and np.array_equal(sa["sum"], sb["sum"]) and np.array_equal(sa["csum"], sb["csum"])
+    ctx.close()
+    env = dict(os.environ, MSC_NO_MIRROR_1XM="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "golden_vectors or against_oracle_seeded or appendix_d"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+
+
 def test_full_size_cfg2_properties(oracle):
     """BASELINE.json configs[1] at FULL size (100 000 x 1 kb, k = 9, datatype 32: 98 GiB of histograms + the digest mirror),
     checked through size-independent properties: sampled histograms against the oracle; the Q x M digest kernel against the
@@ -1030,7 +1059,7 @@ def test_full_size_cfg2_properties(oracle):
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
-        assert ctx.last_kernel_info()[0] == "k_pair_tiles"
+        assert ctx.last_kernel_info()[0] in ("k_pair_tiles", "k_pair_sparse_wl", "k_pair_sparse_mp"), ctx.last_kernel_info()          # (r04: the dense set's mirror pass)
         assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
         assert int(multi["close"][i].sum()) == int((np.round(single["csum"]) > 0).sum())
     # first-hand at full size: the pass's weighted sums, close flags and integer statistics for the kept candidates x all 16 queries
