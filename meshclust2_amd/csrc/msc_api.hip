@@ -128,9 +128,18 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipStreamSynchronize(ctx->copy_stream);
-	if (g_profile_calls && ctx->prof_calls)
+	if (g_profile_calls && ctx->prof_calls) {
 		fprintf(stderr, "[msc] 1 x M scoring calls: %llu (%llu candidates) | slot list %.3f s, launches %.3f s, stream wait %.3f s\n", (unsigned long long)ctx->prof_calls,
 		        (unsigned long long)ctx->prof_cands, ctx->prof_prep, ctx->prof_issue, ctx->prof_wait);
+		if (ctx->prof_nnz.p) {
+			uint64_t acc[2] = {0, 0};
+			if (hipMemcpy(acc, ctx->prof_nnz.p, sizeof acc, hipMemcpyDeviceToHost) == hipSuccess && acc[1])
+				fprintf(stderr, "[msc] list passes: %llu pairs scored inside their length windows, %.3f GB of candidate lists (8 bytes per stored bin) + %.3f GB of query lists"
+				        " (once per pass); over the %.3f s of stream wait above: %.1f M pairs/s, %.1f GB/s of candidate lists = %.3f of the 8 TB/s HBM peak\n",
+				        (unsigned long long)acc[1], 8.0 * acc[0] / 1e9, 8.0 * ctx->prof_q_nnz / 1e9, ctx->prof_wait, acc[1] / ctx->prof_wait / 1e6,
+				        8.0 * acc[0] / ctx->prof_wait / 1e9, 8.0 * acc[0] / ctx->prof_wait / 8e12);
+		}
+	}
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
 	if (ctx->sparse_scratch) msc_hist_set_destroy(ctx->sparse_scratch);
 	if (ctx->sparse_mean_set) msc_hist_set_destroy(ctx->sparse_mean_set);
@@ -148,6 +157,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->emd_out);
 	release(ctx->close_counts);
 	release(ctx->rk_bad);
+	release(ctx->prof_nnz);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
@@ -1554,6 +1564,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_bins = sp ? nullptr : cs->bins + (d_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cs->scalars + (d_slots ? 0 : off * cs->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		if (lists && g_profile_calls) {
+			if (!ctx->prof_nnz.p) { if ((r = ensure(ctx, ctx->prof_nnz, 16))) return r; HIP_TRY(ctx, hipMemsetAsync(ctx->prof_nnz.p, 0, 16, ctx->stream)); }
+			HIP_TRY(ctx, msc_launch_sparse_nnz_sum(ctx->stream, c_sp->hdr, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.use_window, rq.min_len, rq.max_len, (uint64_t*)ctx->prof_nnz.p));
+			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
+		}
 		if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,

@@ -255,6 +255,8 @@ hipError_t msc_launch_assign_scalars(hipStream_t st, uint8_t* dst_scalars, const
 hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, const MscSparseHdr* c_hdr, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                          const uint32_t* cand_slots, uint32_t m, const void* q_ent, const MscSparseHdr* q_hdr, int use_window, uint64_t min_len,
                                          uint64_t max_len, double* out);
+hipError_t msc_launch_sparse_nnz_sum(hipStream_t st, const MscSparseHdr* hdr, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* slots, uint64_t first_slot,
+                                     uint32_t m, int use_window, uint64_t min_len, uint64_t max_len, uint64_t* acc);
 hipError_t msc_launch_sparse_self_markov(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, uint64_t first_slot, uint32_t m, double* out);
 // the same records from tile-permuted dense slots, for histograms under 64 KiB (pair_features.hip)
 hipError_t msc_launch_pair_groups_dense(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* c_bins, const uint8_t* cand_scalars, uint64_t scalar_stride,

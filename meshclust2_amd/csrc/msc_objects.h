@@ -62,6 +62,9 @@ struct msc_ctx {
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the
 	// launches, and waiting for the stream (printed by msc_destroy)
 	double prof_prep = 0, prof_issue = 0, prof_wait = 0;
+	DevBuf prof_nnz;                       // {stored bins, candidates} the list passes scored inside their windows (device counters)
+	double prof_tiles_ms = 0;              // streaming-kernel time of those passes (HIP events; needs kernel timing on)
+	uint64_t prof_q_nnz = 0;               // sum over the passes of the query's stored bins
 	uint64_t prof_calls = 0, prof_cands = 0;
 };
 

@@ -415,6 +415,23 @@ __global__ void __launch_bounds__(256) k_pair_sparse_groups(
 	out[((uint64_t)c * kSub + r) * 2 + 1] = st.rre;
 }
 
+// MSC_PROFILE_CALLS: stored bins of the candidates of a pass that lie inside its length window, added to *acc (list bytes the pass
+// reads = 8 x that) -- the byte count behind a roofline figure of the merge kernels in a whole clustering run
+__global__ void __launch_bounds__(256) k_sparse_nnz_sum(const MscSparseHdr* __restrict__ hdr, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                        const uint32_t* __restrict__ slots, uint64_t first_slot, uint32_t m, int use_window, uint64_t min_len,
+                                                        uint64_t max_len, unsigned long long* __restrict__ acc) {
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long v = 0, n = 0;
+	if (c < m) {
+		const uint64_t slot = slots ? slots[c] : first_slot + c;
+		const uint64_t len = reinterpret_cast<const MscSlotScalars*>(cand_scalars + slot * scalar_stride)->length;
+		if (!use_window || (len >= min_len && len <= max_len)) { v = hdr[slot].nnz; n = 1; }
+	}
+	v = wave_sum_u64(v);
+	n = wave_sum_u64(n);
+	if ((threadIdx.x & 63) == 0 && n) { atomicAdd(acc, v); atomicAdd(acc + 1, n); }
+}
+
 // markov(a, a) of single histograms (the denominators of d_markov): out[c * 16 + r] = sum over the groups of sub-range r of
 // sum_j (a_j - 1) (log a_j - log group sum)  (= Feature<T>::markov(a, a), whose two equal terms per bin are halved at the end)
 __global__ void __launch_bounds__(256) k_sparse_self_markov(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
@@ -1510,6 +1527,13 @@ hipError_t msc_launch_pair_sparse_groups(hipStream_t st, const void* c_ent, cons
 	const uint64_t threads = (uint64_t)m * kSub;
 	k_pair_sparse_groups<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>((const uint2*)c_ent, c_hdr, cand_scalars, scalar_stride, cand_slots, m,
 	                                                                                    (const uint2*)q_ent, q_hdr, use_window, min_len, max_len, out);
+	return hipGetLastError();
+}
+
+hipError_t msc_launch_sparse_nnz_sum(hipStream_t st, const MscSparseHdr* hdr, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* slots, uint64_t first_slot,
+                                     uint32_t m, int use_window, uint64_t min_len, uint64_t max_len, uint64_t* acc) {
+	if (m == 0) return hipSuccess;
+	k_sparse_nnz_sum<<<dim3((m + 255) / 256), dim3(256), 0, st>>>(hdr, cand_scalars, scalar_stride, slots, first_slot, m, use_window, min_len, max_len, (unsigned long long*)acc);
 	return hipGetLastError();
 }
 
