@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4 matrix rate (v_mfma_f32_32x32x64_f8f6f4 with E2M1 operands): 4 x the bf16 rate per clock (same guide)
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 matrix rate: 2 x the bf16 rate per clock (same guide, Matrix cores: bf16 ~2.5 PF dense)
 
 
@@ -564,7 +565,8 @@ def main():
     # Per-rank figures (rank 0's shard: M candidates).
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
-    on_mfma = kernel.startswith("k_pair_gemm_bits")
+    on_mfma = kernel.startswith(("k_pair_gemm_fp4", "k_pair_gemm_bits"))
+    on_fp4 = kernel.startswith("k_pair_gemm_fp4")
     qblk = int(os.environ.get("MSC_GEMM_BLOCK", "128"))          # queries per pass over the candidates on the matrix cores (the library's block)
     qblk = qblk if qblk in (64, 256) else 128
     if on_mfma:   # everything from the matrix cores: the pass reads the presence-bit mirror, one BIT per bin, once per block of up to 128 queries
@@ -632,14 +634,17 @@ def main():
                      "profile_key": config_key},
     }
     if on_mfma and args.mode == "allpairs" and avg_ms == avg_ms:
-        # The pass on the matrix cores is bound by the int8 matrix pipe, not by HBM (it streams one bit per bin): 4^k multiply-adds per
+        # The pass on the matrix cores is bound by the matrix pipe (FP4 operands; int8 under MSC_GEMM_I8), not by HBM (it streams one bit per bin): 4^k multiply-adds per
         # pair = 2 * 4^k integer operations; a launch scores (candidates of the launch) x (rows of its query block, padded rows included
         # in the work the pipe does but NOT in the operations counted here).
         pairs_per_launch = float(M) * Q * len(tiles_ms) / n_launch
         ops = 2.0 * pairs_per_launch * (4 ** args.k)
         tops = ops / (avg_ms * 1e-3) / 1e12
-        line["roofline"].update({"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_I8_PEAK_TOPS,
-                                 "ops": "int8 multiply-adds counted as 2 operations each (v_mfma_i32_32x32x32_i8), exact int32 sums",
+        peak = MFMA_FP4_PEAK_TOPS if on_fp4 else MFMA_I8_PEAK_TOPS
+        line["roofline"].update({"bound": "mfma", "achieved": tops, "peak": peak, "unit": "TFLOP/s", "frac": tops / peak,
+                                 "ops": ("FP4 (E2M1) multiply-adds counted as 2 operations each (v_mfma_f32_32x32x64_f8f6f4, operands 0 / 0.5 / 1 / 2: every "
+                                         "product of two set presence bits is exactly 1.0), exact sums in f32 (< 2^24)") if on_fp4 else
+                                        "int8 multiply-adds counted as 2 operations each (v_mfma_i32_32x32x32_i8), exact int32 sums",
                                  "algorithmic_ops_per_launch": ops})
     if args.check:
         line["check"] = checks

@@ -178,8 +178,9 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	DevBuf* bufs[] = {&ctx->partials, &ctx->pair_out, &ctx->flags, &ctx->reduce_out, &ctx->slots, &ctx->raw, &ctx->singles, &ctx->combos,
 	                  &ctx->packed, &ctx->seg_seq, &ctx->seg_start, &ctx->kmer_off, &ctx->nat, &ctx->model_tmp, &ctx->floor_sum, &ctx->mean,
 	                  &ctx->div_tables, &ctx->div_partials, &ctx->qslots, &ctx->soa_sum, &ctx->soa_csum, &ctx->soa_close,
-	                  &ctx->err_word, &ctx->seq_seg, &ctx->seq_ids, &ctx->seq_meta};
+	                  &ctx->err_word, &ctx->seq_seg, &ctx->seq_ids, &ctx->seq_meta, &ctx->qslots_all};
 	for (DevBuf* b : bufs) release(*b);
+	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	(void)hipEventDestroy(ctx->ev_tiles0);
 	(void)hipEventDestroy(ctx->ev_tiles1);
 	(void)hipEventDestroy(ctx->ev_all0);
@@ -1868,6 +1869,41 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
                             const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                             uint8_t* close_out, uint64_t feat_mask, double* raw_out);
 
+// the epilogue's error word (the stream is idle): the first failing pair's status
+static int read_error_word(msc_ctx* ctx) {
+	int32_t first_err = 0;
+	HIP_TRY(ctx, hipMemcpy(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost));
+	if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
+	if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
+	if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
+	return MSC_OK;
+}
+
+// timing events of queued blocks (two per launch of the streaming kernel), kept for the life of the context
+static int pool_event(msc_ctx* ctx, hipEvent_t* e) {
+	if (ctx->ev_used == ctx->ev_pool.size()) {
+		hipEvent_t n = nullptr;
+		HIP_TRY(ctx, hipEventCreate(&n));
+		ctx->ev_pool.push_back(n);
+	}
+	*e = ctx->ev_pool[ctx->ev_used++];
+	return MSC_OK;
+}
+
+// the queued blocks of msc_score_multi: wait for them, add up their kernel times, read the error word they share
+static int flush_deferred(msc_ctx* ctx) {
+	if (ctx->defer != 2) return MSC_OK;
+	ctx->defer = 1;
+	const hipError_t e = hipStreamSynchronize(ctx->stream);
+	for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+		float t = 0;
+		if (e == hipSuccess && hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) { ctx->defer_ms += t; ctx->have_timing = true; }
+	}
+	ctx->ev_used = 0;
+	if (e != hipSuccess) return fail(ctx, MSC_ERR_HIP, "queued blocks failed: %s", hipGetErrorString(e));
+	return read_error_word(ctx);
+}
+
 extern "C" int msc_score_multi(msc_ctx* ctx, const msc_model* model, const msc_hist_set* cands, const uint32_t* cand_slots, uint64_t m,
                                const msc_hist_set* qset, const uint32_t* q_slots, uint64_t n_q, int order, double* sum_out, double* csum_out,
                                uint8_t* close_out, uint64_t feat_mask, double* raw_out) {
@@ -1922,17 +1958,40 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		const bool was_in = ctx->in_score_multi;
 		const uint64_t base0 = ctx->close_counts_base;
 		ctx->in_score_multi = true;
+		// the blocks of the matrix-core pass are queued back to back (score_multi_impl below, `deferred`): the whole call's query slots
+		// go up once, here
+		static const bool no_defer = getenv("MSC_GEMM_NO_QUEUE") != nullptr;
+		const bool defer = kb_fit && top_level && !no_defer;
+		if (defer) {
+			if ((r = ensure(ctx, ctx->qslots_all, n_q * sizeof(uint32_t)))) { ctx->in_score_multi = was_in; return r; }
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots_all.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			ctx->defer = 1;
+			ctx->defer_cands_up = false;
+			ctx->defer_ms = 0.f;
+			ctx->ev_used = 0;
+		}
 		for (uint64_t b = 0; b < n_q; b += blk) {
 			const uint64_t nb = std::min<uint64_t>(blk, n_q - b);
 			ctx->close_counts_base = base0 + b;
+			ctx->defer_q_off = b;
 			if ((r = score_multi_impl(ctx, model, cands, cand_slots, m, qset, q_slots + b, nb, order, sum_out ? sum_out + b * m : nullptr, csum_out ? csum_out + b * m : nullptr,
-			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr)))
-				{ ctx->in_score_multi = was_in; ctx->close_counts_base = base0; return r; }
+			                         close_out ? close_out + b * m : nullptr, feat_mask, raw_out ? raw_out + b * m * nf : nullptr))) {
+				if (defer) { (void)flush_deferred(ctx); ctx->defer = 0; }          // (nothing of this call may still be running when it returns)
+				ctx->in_score_multi = was_in;
+				ctx->close_counts_base = base0;
+				return r;
+			}
 			ms += ctx->tiles_ms_accum;
 			launches += ctx->tiles_launches;
 		}
+		if (defer) {
+			r = flush_deferred(ctx);
+			ctx->defer = 0;
+			ms += ctx->defer_ms;
+		}
 		ctx->in_score_multi = was_in;
 		ctx->close_counts_base = base0;
+		if (r) return r;
 		ctx->tiles_ms_accum = ms;
 		ctx->tiles_launches = launches;
 		return MSC_OK;
@@ -2054,14 +2113,6 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	ctx->tiles_ms_accum = 0.f;
 	ctx->tiles_launches = 0;
 	ctx->have_timing = false;
-	if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
-	if ((r = ensure(ctx, ctx->qslots, n_q * sizeof(uint32_t)))) return r;
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
-	if (cand_slots) {
-		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	}
 	int tq = n_q >= 4 ? 4 : 2;                     // TQ = 4 keeps the 32-bit register kernel HBM-bound
 	if (const char* e = getenv("MSC_MULTI_TQ")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) tq = v; }
 	if (tq > (int)n_q && n_q >= 2) tq = n_q >= 4 ? 4 : 2;
@@ -2091,12 +2142,33 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			manh_gemm = emd_ranks = cands->ranks && qset->ranks;
 		}
 	}
+	// (blocks of the matrix-core pass queued without a host wait between them: any other route first waits for them and reads their error word)
+	if (!manh_gemm && ctx->defer == 2 && (r = flush_deferred(ctx))) return r;
 	if (!manh_gemm && n_q > 64) {          // (a block of up to 256 was cut for the matrix cores: the older routes take it in blocks of 64)
 		ctx->no_kb_now = true;
 		r = score_multi_impl(ctx, model, cands, cand_slots, m, qset, q_slots, n_q, order, sum_out, csum_out, close_out, feat_mask, raw_out);
 		ctx->no_kb_now = false;
 		return r;
 	}
+	// A block of a larger call on the matrix cores is QUEUED: its query slots are part of the list the call sent up once, the error word is
+	// cleared by the first block and read after the last, and nothing here waits for the stream -- the scratch buffers the next block
+	// overwrites are ordered behind this block's kernels by the stream itself (a buffer that has to grow goes through hipFree, which waits).
+	const bool deferred = manh_gemm && ctx->defer != 0;
+	const uint32_t* dq_slots = nullptr;
+	if ((r = ensure(ctx, ctx->err_word, sizeof(int32_t)))) return r;
+	if (deferred) dq_slots = (const uint32_t*)ctx->qslots_all.p + ctx->defer_q_off;
+	else {
+		if ((r = ensure(ctx, ctx->qslots, n_q * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		dq_slots = (const uint32_t*)ctx->qslots.p;
+	}
+	if (!deferred || ctx->defer == 1) HIP_TRY(ctx, hipMemsetAsync(ctx->err_word.p, 0, sizeof(int32_t), ctx->stream));
+	if (cand_slots && !(deferred && ctx->defer_cands_up)) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+		if (deferred) ctx->defer_cands_up = true;
+	}
+	if (deferred) ctx->defer = 2;
 	// Digest form (pair_digest.hip): sets whose counts and excess prefixes fit 16 bits, from four queries up. Sixteen (or 32)
 	// queries share one HBM read of each candidate tile; the raw kernels below remain for everything else.
 	// (one digest tile per lane-run of 16 bins: wave totals of 1024 * max^2 must fit 32 bits)
@@ -2170,13 +2242,13 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			hot_cnt = hot_cursor + (nsteps + 1);
 		}
 		// the queries' side of the block, once for all chunks of candidates
-		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, kb_qn,
+		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
 		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)ctx->kb_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt));
 	}
 	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? kb_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
 	if (manh_gemm) {
-		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_gemm_bits<%u query rows, one int8 product per tile of presence bits%s>", kb_qn, emd_ranks ? ", emd by ranks" : ", no emd");
+		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "%s<%u query rows, one matrix product per tile of presence bits%s>", msc_pair_gemm_kernel_name(), kb_qn, emd_ranks ? ", emd by ranks" : ", no emd");
 		ctx->last_kernel = ctx->last_kernel_buf;
 	} else if (digest) {
 		snprintf(ctx->last_kernel_buf, sizeof ctx->last_kernel_buf, "k_pair_digest_multi<%s counts%s%s>", mc_ < 256 ? "u8" : "u16",
@@ -2193,23 +2265,25 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p + off : nullptr;
 		const uint8_t* c_bins = cands->bins + (cand_slots ? 0 : off * L.slot_bytes);
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
-		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
+		hipEvent_t ev_t0 = ctx->ev_tiles0, ev_t1 = ctx->ev_tiles1;
+		if (deferred && ctx->timing && ((r = pool_event(ctx, &ev_t0)) || (r = pool_event(ctx, &ev_t1)))) return r;      // (read when the call's last block is through)
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
 			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)ctx->kb_abits.p, kb_qn, gemm_slices, hot_ptr, ctx->kb_hot.p,
 			                                  (int32_t*)ctx->kb_min.p, (int32_t*)ctx->kb_diff.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
-			                                          (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
+			                                          dq_slots, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
 		else if (ring)
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi_ring(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
-			                                              qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
+			                                              qset->scalar_stride, dq_slots, (uint32_t)n_q, tq, prefix16, ctx->partials.p, ctx->num_cus));
 		else
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
-			                                         qset->scalar_stride, (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
-		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles1, ctx->stream));
+			                                         qset->scalar_stride, dq_slots, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t1, ctx->stream));
 		if (emd_ranks)
 			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
-			                                  (const uint32_t*)ctx->qslots.p, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
+			                                  dq_slots, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
 		if (want_div) {
 			for (uint64_t q = 0; q < n_q; q++)
 				HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cands->scalars, cands->scalar_stride, d_slots, off, mc, q_sp, q_slots[q],
@@ -2220,7 +2294,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			double* gp = (double*)ctx->grp_pairs.p;
 			double* gs_c = (double*)ctx->grp_self.p;
 			double* gs_q = gs_c + chunk * 16;
-			const uint32_t* d_q = (const uint32_t*)ctx->qslots.p;
+			const uint32_t* d_q = dq_slots;
 			if (grp_dense) {
 				HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, L, cands->dtype, cands->bins, d_slots, off, mc, gs_c));
 				HIP_TRY(ctx, msc_launch_self_markov_dense(ctx->stream, qset->L, qset->dtype, qset->bins, d_q, 0, (uint32_t)n_q, gs_q));
@@ -2262,7 +2336,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		ea.cand_slots = d_slots;
 		ea.n_queries = (uint32_t)n_q;
 		ea.m_per_query = mc;
-		ea.q_slots = (const uint32_t*)ctx->qslots.p;
+		ea.q_slots = dq_slots;
 		ea.qset_scalars = qset->scalars;
 		ea.q_scalar_stride = qset->scalar_stride;
 		ea.q_scalars = qset->scalars + (uint64_t)q_slots[0] * qset->scalar_stride;
@@ -2299,17 +2373,14 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			ctx->copy_pending = true;
 		} else if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->stream));
 		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (deferred) { ctx->tiles_launches++; continue; }
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;
-		if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
+		if (ctx->timing && hipEventElapsedTime(&t, ev_t0, ev_t1) == hipSuccess) { ctx->tiles_ms_accum += t; ctx->tiles_launches++; ctx->have_timing = true; }
 		(void)whole;
 	}
-	int32_t first_err = 0;
-	HIP_TRY(ctx, hipMemcpy(&first_err, ctx->err_word.p, sizeof first_err, hipMemcpyDeviceToHost));
-	if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
-	if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
-	if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);
-	return MSC_OK;
+	if (deferred) return MSC_OK;
+	return read_error_word(ctx);
 }
 
 extern "C" int msc_get_close(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* cands, const uint32_t* cand_slots,

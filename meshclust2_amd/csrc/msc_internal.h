@@ -196,6 +196,7 @@ uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity);
 hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* kb, uint64_t first_slot, uint64_t n_slots, void* mb,
                                uint32_t* mb_n, uint32_t pitch, int32_t* flags);
 uint32_t msc_pair_gemm_rows(uint32_t n_q);
+const char* msc_pair_gemm_kernel_name();          // "k_pair_gemm_fp4", or "k_pair_gemm_bits" under MSC_GEMM_I8
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
 uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn);
 uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn);

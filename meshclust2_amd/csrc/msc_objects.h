@@ -57,6 +57,15 @@ struct msc_ctx {
 	DevBuf close_counts;                   // msc_score_multi: close candidates per query of the call in progress / the last call (msc_last_close_counts)
 	uint64_t close_counts_n = 0, close_counts_base = 0;
 	bool in_score_multi = false;
+	// msc_score_multi queues the blocks of its matrix-core pass without waiting between them: 0 = off, 1 = the next queued block clears
+	// the error word, 2 = blocks are in flight (flush_deferred)
+	int defer = 0;
+	bool defer_cands_up = false;           // the call's candidate slot list is on the device
+	uint64_t defer_q_off = 0;              // first query of the block being queued, in qslots_all
+	float defer_ms = 0.f;
+	DevBuf qslots_all;                     // the query slots of the whole call
+	std::vector<hipEvent_t> ev_pool;       // timing events of the queued blocks
+	size_t ev_used = 0;
 	DevBuf emd_out, rk_bad;                // msc_emd_ranks.hip: the distances of a chunk, the build's error word
 	msc_hist_set* shard_gather = nullptr;
 	// MSC_PROFILE_CALLS: host wall clock of the 1 x M scoring calls, split into preparing + queueing the slot list, issuing the

@@ -94,9 +94,11 @@ __global__ void __launch_bounds__(256) k_kb_build(const T* __restrict__ bins, ui
 // One workgroup per 128-bin step, one thread per query row. abits[step][row] = 8 halfwords, halfword 2 kc + h = the bits of bins
 // 32 kc + 16 h .. + 15 of the step (what lane half h feeds k-chunk kc); rows past n_q are zero. qT[bin][row] = 0 / 1 (k_hot_fill then
 // writes the counts of the large bins over it).
+// fp4_image: the order k_pair_gemm_fp4 stages instead -- abits[super-step][row][segment 2 t + h] = dword t of half h of the row's 32 mirror
+// bytes of the super-step (what lane half h feeds the super-step's product t).
 template <int QN>
 __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ kb, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
-                                                   uint8_t* __restrict__ abits, uint8_t* __restrict__ qT) {
+                                                   uint8_t* __restrict__ abits, uint8_t* __restrict__ qT, int fp4_image) {
 	__shared__ v4i tile[QN * 8];          // [row][16-byte segment 2 kc + h]: the presence bytes of this step
 	const uint32_t step = blockIdx.x, row = threadIdx.x;
 	if (row < QN) {
@@ -114,7 +116,8 @@ __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ k
 		v4i packed;
 #pragma unroll
 		for (int d = 0; d < 4; d++) packed[d] = (int)(hwv[2 * d] | (hwv[2 * d + 1] << 16));
-		*reinterpret_cast<v4i*>(abits + ((uint64_t)step * QN + row) * 16) = packed;
+		if (fp4_image) *reinterpret_cast<v4i*>(abits + (((uint64_t)(step >> 1) * QN + row) * 8 + 4 * (step & 1)) * 4) = v4i{(int)(hwv[0] | (hwv[2] << 16)), (int)(hwv[1] | (hwv[3] << 16)), (int)(hwv[4] | (hwv[6] << 16)), (int)(hwv[5] | (hwv[7] << 16))};
+		else *reinterpret_cast<v4i*>(abits + ((uint64_t)step * QN + row) * 16) = packed;
 #pragma unroll
 		for (int sg = 0; sg < 8; sg++) tile[row * 8 + sg] = expand16(hwv[sg]);
 	}
@@ -275,7 +278,120 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : (NW == 8 ? 2 : 3)) k_p
 		for (int g = 0; g < 4; g++) *reinterpret_cast<v4i*>(o + 32 * rb + 8 * g) = v4i{acc[rb][4 * g], acc[rb][4 * g + 1], acc[rb][4 * g + 2], acc[rb][4 * g + 3]};
 }
 
+// ------------------------------------------------------------------------------------------------ the product, FP4 form
+// The same product on v_mfma_f32_32x32x64_f8f6f4 with both operands in FP4 (E2M1): 64 bins per instruction in the cycles the int8 form takes
+// for 32 (MI355X: ~10 POPS dense against ~5), half the LDS bytes per bin, and an expansion of bits that costs a v_and per EIGHT bins:
+// the product only needs both operands to agree on which bin sits in which K position, so nibble i of operand dword d takes bit 4 i + d of
+// the 32-bit word -- a mask. The nibble then holds 1, 2, 4 (or, shifted down, 1): as E2M1 0.5, 1.0, 2.0. The candidates' side uses
+// (0.5, 1, 2, 0.5) for d = 0 .. 3 and the queries' side (2, 1, 0.5, 2), so every product of two set bits is exactly 1.0; the sums (at most
+// the number of k-mers of a sequence) are exact in the f32 accumulators and are converted to int32 on the way out. (tools/probes/
+// fp4_mfma_probe.hip checks the identity D[i][j] = popcount(a_i & b_j) on the card; the non-scaled opcode -- both scale operands the
+// constant 0 -- scales by 1.) One tile step = 256 bins = one 16-byte load of a candidate = four products per row block.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr uint32_t kM1 = 0x11111111u, kM2 = 0x22222222u, kM4 = 0x44444444u;
+
+template <int NRB, int NW>
+__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                                     const uint8_t* __restrict__ abits, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
+                                                                     const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
+	constexpr int QN = 32 * NRB;
+	constexpr int NT = 64 * NW;
+	constexpr int SPT = QN * 8 / NT;         // 16-byte segments of the tile (= dwords of the bit image) a thread expands per step
+	constexpr int TPR = 8 / SPT;
+	static_assert(SPT >= 1 && SPT <= 8 && TPR * SPT == 8, "tile staging");
+	__shared__ v4i sA[2][QN * 8];          // [buffer][row][segment (2 t + h) ^ ((row >> 1) & 7)]: QN x 128 bytes = 256 bins of nibbles
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t ks = blockIdx.y;
+	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
+	const uint32_t n_ss = (uint32_t)(per / 256), gss0 = (uint32_t)(k0 / 256);
+	const uint32_t ci = (blockIdx.x * NW + wave) * 32 + (lane & 31);
+	const bool valid = ci < m;
+	const uint32_t cc = valid ? ci : m - 1;
+	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	const uint32_t u = tid / TPR, part = tid % TPR;
+	const uint32_t srow = (u & ~15u) | (2 * (u & 7) + ((u >> 3) & 1));
+	const uint8_t* asrc = abits + ((uint64_t)srow * 8 + part * SPT) * 4;
+	v16f acc[NRB];
+#pragma unroll
+	for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+		for (int i = 0; i < 16; i++) acc[rb][i] = 0.f;
+	uint32_t a_reg[SPT];
+	auto fetch_a = [&](uint32_t ss) {
+		const uint8_t* p = asrc + (uint64_t)(gss0 + (ss < n_ss ? ss : n_ss - 1)) * (QN * 32);
+		if constexpr (SPT == 8) {
+			const v4i v = *reinterpret_cast<const v4i*>(p), w = *reinterpret_cast<const v4i*>(p + 16);
+			a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; a_reg[4] = w.x; a_reg[5] = w.y; a_reg[6] = w.z; a_reg[7] = w.w;
+		} else if constexpr (SPT == 4) { const v4i v = *reinterpret_cast<const v4i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; }
+		else if constexpr (SPT == 2) { const v2i v = *reinterpret_cast<const v2i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; }
+		else a_reg[0] = *reinterpret_cast<const uint32_t*>(p);
+	};
+	auto park = [&](uint32_t buf) {
+#pragma unroll
+		for (int t = 0; t < SPT; t++) {
+			const uint32_t sg = part * SPT + t, w = a_reg[t];
+			sA[buf][srow * 8 + (sg ^ ((srow >> 1) & 7))] = v4i{(int)((w << 2) & kM4), (int)(w & kM2), (int)((w >> 2) & kM1), (int)((w >> 1) & kM4)};
+		}
+	};
+	auto fetch_b = [&](uint32_t ss) { return *reinterpret_cast<const v4i*>(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024); };
+	auto multiply = [&](uint32_t buf, const v4i& bq) {
+		const uint32_t r = lane & 31, sw = (r >> 1) & 7, hh = lane >> 5;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const uint32_t w = (uint32_t)bq[t];
+			const v8i B = {(int)(w & kM1), (int)(w & kM2), (int)(w & kM4), (int)((w >> 3) & kM1), 0, 0, 0, 0};
+#pragma unroll
+			for (int rb = 0; rb < NRB; rb++) {
+				const v4i a = sA[buf][(32 * rb + r) * 8 + ((2 * t + hh) ^ sw)];
+				const v8i A = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+				acc[rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[rb], 4, 4, 0, 0, 0, 0);
+			}
+		}
+	};
+	// P2 as in the int8 form: the hot entries of both 128-bin steps of this tile step
+	auto hotfix = [&](uint32_t ss, const v4i& bq) {
+		const uint32_t h0 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss)]), h1 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss) + 2]);
+		for (uint32_t e = h0; e < h1; e++) {
+			const uint2 en = hot[e];
+			const uint32_t bin = __builtin_amdgcn_readfirstlane(en.x), rg = __builtin_amdgcn_readfirstlane(en.y);
+			const uint32_t j = (bin >> 5) & 7, wsel = j >> 1;
+			const uint32_t w = (uint32_t)(wsel == 0 ? bq.x : wsel == 1 ? bq.y : wsel == 2 ? bq.z : bq.w);
+			const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
+			if (valid && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
+		}
+	};
+	v4i bcur = fetch_b(0);
+	fetch_a(0);
+	park(0);
+	__syncthreads();
+	for (uint32_t ss = 0; ss < n_ss; ss++) {
+		const uint32_t buf = ss & 1;
+		const v4i bnext = fetch_b(ss + 1);            // (the last one once more past the end: a load nobody uses is cheaper than a branch around it)
+		fetch_a(ss + 1);
+		multiply(buf, bcur);
+		if (hot_ptr) hotfix(ss, bcur);
+		park(buf ^ 1);
+		__syncthreads();
+		bcur = bnext;
+	}
+	if (!valid) return;
+	int32_t* o = out_min + ((uint64_t)ks * m + ci) * QN + 4 * (lane >> 5);
+#pragma unroll
+	for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+		for (int g = 0; g < 4; g++) *reinterpret_cast<v4i*>(o + 32 * rb + 8 * g) = v4i{(int)acc[rb][4 * g], (int)acc[rb][4 * g + 1], (int)acc[rb][4 * g + 2], (int)acc[rb][4 * g + 3]};
+}
+
 }  // namespace
+
+// MSC_GEMM_I8 keeps the int8 form (k_pair_gemm_bits) for A/B runs; the FP4 form is the default
+static bool pair_gemm_fp4() {
+	static const bool i8 = getenv("MSC_GEMM_I8") != nullptr;
+	return !i8;
+}
+const char* msc_pair_gemm_kernel_name() { return pair_gemm_fp4() ? "k_pair_gemm_fp4" : "k_pair_gemm_bits"; }
 
 uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 31) / 32 * msc_kb_block_bytes(L.padded_bins); }
 
@@ -298,11 +414,12 @@ hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, co
 // rows of queries one pass serves for a block of n_q: 32, 64, 128 or 256
 uint32_t msc_pair_gemm_rows(uint32_t n_q) { return n_q <= 32 ? 32 : n_q <= 64 ? 64 : n_q <= 128 ? 128 : 256; }
 
-// 128 candidates per workgroup (4 waves), or 256 (8 waves: the queries' tile is expanded into LDS once for twice the products) where that
-// still leaves every CU a few workgroups
+// 128 candidates per workgroup (4 waves). MSC_GEMM_WAVES=8 selects the 8-wave form (256 candidates: the queries' tile is expanded into LDS
+// once for twice the products) -- measured 2 % SLOWER over 100 000 candidates (3.33 against 3.40 G pairs/s: its barriers hold eight waves
+// instead of four), kept as a variant for A/B runs.
 static bool pair_gemm_wide(uint32_t qn, uint32_t m) {
 	static const int nw_env = [] { const char* e = getenv("MSC_GEMM_WAVES"); return e ? atoi(e) : 0; }();
-	return qn == 128 && (nw_env == 8 || (nw_env != 4 && m >= 16384));
+	return qn == 128 && nw_env == 8 && m >= 16384;
 }
 
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus) {
@@ -327,10 +444,11 @@ hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const ui
                                         uint32_t* hot_cursor, uint32_t* hot_cnt) {
 	if (n_q == 0 || n_q > qn || nbins % 256) return hipErrorInvalidValue;
 	const uint32_t nsteps = (uint32_t)(nbins / kStep);
-	if (qn == 32) k_kb_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
-	else if (qn == 64) k_kb_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
-	else if (qn == 128) k_kb_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
-	else if (qn == 256) k_kb_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT);
+	const int fp4 = pair_gemm_fp4() ? 1 : 0;
+	if (qn == 32) k_kb_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
+	else if (qn == 64) k_kb_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
+	else if (qn == 128) k_kb_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
+	else if (qn == 256) k_kb_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
 	else return hipErrorInvalidValue;
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || n_hot == 0) return e;
@@ -353,7 +471,11 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 	}
 	const bool wide = pair_gemm_wide(qn, m);
 	const dim3 grid((m + (wide ? 255 : 127)) / (wide ? 256 : 128), k_slices);
-#define MSC_PG_GO(NRB, NW) k_pair_gemm_bits<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
+#define MSC_PG_GO(NRB, NW)                                                                                                                                             \
+	do {                                                                                                                                                           \
+		if (pair_gemm_fp4()) k_pair_gemm_fp4<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
+		else k_pair_gemm_bits<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff);             \
+	} while (0)
 	if (qn == 32) MSC_PG_GO(1, 4);
 	else if (qn == 64) MSC_PG_GO(2, 4);
 	else if (qn == 128 && wide) MSC_PG_GO(4, 8);

@@ -73,11 +73,11 @@ def main():
     t0, n, gemm = time.time(), 0, 0
     while time.time() - t0 < budget:
         line = one_round(ctx, seed)
-        gemm += "k_pair_gemm_bits" in line
+        gemm += "k_pair_gemm_fp4" in line or "k_pair_gemm_bits" in line
         print(line, flush=True)
         seed += 1
         n += 1
-    print("fuzz ok: %d rounds, %d of them through k_pair_gemm_bits" % (n, gemm))
+    print("fuzz ok: %d rounds, %d of them through the matrix-core kernel" % (n, gemm))
 
 
 if __name__ == "__main__":

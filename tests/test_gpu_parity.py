@@ -1055,7 +1055,7 @@ def test_full_size_cfg2_properties(oracle):
     qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
     fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
     multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
-    assert ctx.last_kernel_info()[0].startswith("k_pair_gemm_bits"), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
+    assert ctx.last_kernel_info()[0].startswith(("k_pair_gemm_fp4", "k_pair_gemm_bits")), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
@@ -1283,7 +1283,7 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
     mask = FAST_MASK & ~((1 << 7) | (1 << 29))
     for rnd in range(2):
         multi = api.score_multi(ctx, feat, db, None, qs_set, q_slots, m=70, feat_mask=mask)
-        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_pair_gemm_bits"))
+        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_pair_gemm_fp4", "k_pair_gemm_bits"))
         for i, q in enumerate(q_slots):
             raw = api.pair_features_raw(ctx, db, None, qs_set, int(q), mask, m=70)
             single = feat.compute(db, None, qs_set, int(q), m=70)
