@@ -112,7 +112,10 @@ extern "C" int msc_create(int device, msc_ctx** out) {
 	snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->num_cus);
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ctx->ev_tiles0) != hipSuccess ||
 	    hipEventCreate(&ctx->ev_tiles1) != hipSuccess || hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess ||
-	    hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_head[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_head[1], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_product[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_product[1], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_scored[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scored[1], hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_copied[1], hipEventDisableTiming) != hipSuccess) {
 		delete ctx;
@@ -187,6 +190,11 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipEventDestroy(ctx->ev_all1);
 	for (int i = 0; i < 2; i++) { release(ctx->close_pp[i]); (void)hipEventDestroy(ctx->ev_scored[i]); (void)hipEventDestroy(ctx->ev_copied[i]); }
 	(void)hipStreamDestroy(ctx->copy_stream);
+	release(ctx->kb_qT2);
+	release(ctx->kb_min2);
+	release(ctx->kb_diff2);
+	for (int i = 0; i < 2; i++) { (void)hipEventDestroy(ctx->ev_head[i]); (void)hipEventDestroy(ctx->ev_product[i]); (void)hipEventDestroy(ctx->ev_tail[i]); }
+	(void)hipStreamDestroy(ctx->tail_stream);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1894,7 +1902,13 @@ static int pool_event(msc_ctx* ctx, hipEvent_t* e) {
 static int flush_deferred(msc_ctx* ctx) {
 	if (ctx->defer != 2) return MSC_OK;
 	ctx->defer = 1;
-	const hipError_t e = hipStreamSynchronize(ctx->stream);
+	hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (ctx->tail_used) {          // (the epilogues of the queued blocks run on the second stream)
+		const hipError_t e2 = hipStreamSynchronize(ctx->tail_stream);
+		if (e == hipSuccess) e = e2;
+		ctx->tail_used = false;
+		ctx->tail_busy[0] = ctx->tail_busy[1] = false;
+	}
 	for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
 		float t = 0;
 		if (e == hipSuccess && hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) { ctx->defer_ms += t; ctx->have_timing = true; }
@@ -2231,19 +2245,32 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	if (raw_out && (r = ensure(ctx, ctx->raw, n_q * chunk * nf * sizeof(double)))) return r;
 	const uint32_t gemm_slices = manh_gemm ? msc_pair_gemm_slices(L.nbins, (uint32_t)chunk, kb_qn, ctx->num_cus) : 0;
 	uint32_t *hot_ptr = nullptr, *hot_cursor = nullptr, *hot_cnt = nullptr;
+	// Queued blocks run in two stages on two streams (msc_objects.h): the product of block i on ctx->stream beside the rank walk of block i
+	// and the epilogue of block i - 1 on tail_stream -- the product is bound by the matrix pipe, the other two by vector arithmetic and
+	// latency. Blocks take turns on two copies of what both stages touch. (Single chunk, no divergence / group passes between the stages.)
+	static const bool no_pipe = getenv("MSC_GEMM_NO_PIPE") != nullptr;
+	const bool piped = deferred && chunk == m && !want_div && !want_grp && !no_pipe;
+	const int pb = piped ? (int)(ctx->pipe_next++ & 1) : 0;
+	hipStream_t tail = piped ? ctx->tail_stream : ctx->stream;
+	DevBuf& b_qT = pb ? ctx->kb_qT2 : ctx->kb_qT;
+	DevBuf& b_min = pb ? ctx->kb_min2 : ctx->kb_min;
+	DevBuf& b_diff = pb ? ctx->kb_diff2 : ctx->kb_diff;
+	if (ctx->tail_used)          // a block on ONE stream after piped ones waits for every epilogue in flight; a piped one for the epilogue that read its copy
+		for (int i = 0; i < 2; i++)
+			if (ctx->tail_busy[i] && (!piped || i == pb)) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[i], 0)); if (!piped) ctx->tail_busy[i] = false; }
 	if (manh_gemm) {
 		const uint64_t nsteps = L.nbins / 128;
-		if ((r = ensure(ctx, ctx->kb_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, ctx->kb_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, ctx->kb_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
+		if ((r = ensure(ctx, ctx->kb_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
 		if (n_hot) {
 			if ((r = ensure(ctx, ctx->kb_hot, n_hot * 8)) || (r = ensure(ctx, ctx->kb_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
-			    (r = ensure(ctx, ctx->kb_diff, chunk * kb_qn * sizeof(int32_t)))) return r;
+			    (r = ensure(ctx, b_diff, chunk * kb_qn * sizeof(int32_t)))) return r;
 			hot_ptr = (uint32_t*)ctx->kb_hot_idx.p;
 			hot_cursor = hot_ptr + (nsteps + 1);
 			hot_cnt = hot_cursor + (nsteps + 1);
 		}
 		// the queries' side of the block, once for all chunks of candidates
 		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
-		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)ctx->kb_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt));
+		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)b_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt));
 	}
 	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? kb_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
@@ -2267,10 +2294,14 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		const uint8_t* c_scal = cands->scalars + (cand_slots ? 0 : off * cands->scalar_stride);
 		hipEvent_t ev_t0 = ctx->ev_tiles0, ev_t1 = ctx->ev_tiles1;
 		if (deferred && ctx->timing && ((r = pool_event(ctx, &ev_t0)) || (r = pool_event(ctx, &ev_t1)))) return r;      // (read when the call's last block is through)
+		if (piped) {          // everything the tail needs from this stream so far (slot lists, the cleared error word) is behind this mark
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_head[pb], ctx->stream));
+			HIP_TRY(ctx, hipStreamWaitEvent(tail, ctx->ev_head[pb], 0));
+		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
 			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)ctx->kb_abits.p, kb_qn, gemm_slices, hot_ptr, ctx->kb_hot.p,
-			                                  (int32_t*)ctx->kb_min.p, (int32_t*)ctx->kb_diff.p));
+			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          dq_slots, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
@@ -2281,8 +2312,9 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, dq_slots, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t1, ctx->stream));
+		if (piped) HIP_TRY(ctx, hipEventRecord(ctx->ev_product[pb], ctx->stream));
 		if (emd_ranks)
-			HIP_TRY(ctx, msc_launch_emd_ranks(ctx->stream, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
+			HIP_TRY(ctx, msc_launch_emd_ranks(tail, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
 			                                  dq_slots, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
 		if (want_div) {
 			for (uint64_t q = 0; q < n_q; q++)
@@ -2317,14 +2349,14 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		ea.partials16 = ring ? ctx->partials.p : nullptr;
 		ea.partials_cq = digest ? ctx->partials.p : nullptr;
 		if (manh_gemm) {
-			ea.kb_min = (const int32_t*)ctx->kb_min.p;
-			ea.kb_diff = n_hot ? (const int32_t*)ctx->kb_diff.p : nullptr;
+			ea.kb_min = (const int32_t*)b_min.p;
+			ea.kb_diff = n_hot ? (const int32_t*)b_diff.p : nullptr;
 			ea.kb_slices = gemm_slices;
 			ea.kb_qn = kb_qn;
 			ea.kb_first = cand_slots ? 0 : off;
 			ea.kb_c_mb = cands->mb; ea.kb_c_mb_n = cands->mb_n; ea.kb_c_pitch = cands->mb_pitch;
 			ea.kb_q_mb = qset->mb; ea.kb_q_mb_n = qset->mb_n; ea.kb_q_pitch = qset->mb_pitch;
-			ea.kb_qT = (const uint8_t*)ctx->kb_qT.p;
+			ea.kb_qT = (const uint8_t*)b_qT.p;
 			ea.emd_stride = kb_qn;
 		}
 		ea.cq_group = 4 * dg_tq;
@@ -2353,26 +2385,32 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		uint8_t* d_close = !close_out ? nullptr : manh_gemm ? (uint8_t*)ctx->close_pp[pp].p : (uint8_t*)ctx->soa_close.p;
 		if (close_out && manh_gemm) {
 			ctx->close_pp_next ^= 1;
-			if (ctx->close_pp_busy[pp]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[pp], 0));
+			if (ctx->close_pp_busy[pp]) HIP_TRY(ctx, hipStreamWaitEvent(tail, ctx->ev_copied[pp], 0));
 		}
 		ea.close_soa = d_close;
 		ea.error_word = (int32_t*)ctx->err_word.p;
-		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
-		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(ctx->stream, d_close, (uint32_t)n_q, mc, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
+		if (piped) HIP_TRY(ctx, hipStreamWaitEvent(tail, ctx->ev_product[pb], 0));
+		HIP_TRY(ctx, msc_launch_epilogue(tail, ea));
+		if (close_out && ctx->close_counts_n) HIP_TRY(ctx, msc_launch_close_counts(tail, d_close, (uint32_t)n_q, mc, (uint64_t*)ctx->close_counts.p + ctx->close_counts_base));
+		if (piped) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_tail[pb], tail));
+			ctx->tail_busy[pb] = true;
+			ctx->tail_used = true;
+		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
 		const size_t rows = (size_t)n_q;
-		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
-		if (csum_out) HIP_TRY(ctx, hipMemcpy2DAsync(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
+		if (csum_out) HIP_TRY(ctx, hipMemcpy2DAsync(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
 		if (close_out && manh_gemm) {
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_scored[pp], ctx->stream));
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_scored[pp], tail));
 			HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_scored[pp], 0));
 			HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->copy_stream));
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_copied[pp], ctx->copy_stream));
 			ctx->close_pp_busy[pp] = true;
 			ctx->copy_pending = true;
-		} else if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->stream));
-		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, ctx->stream));
+		} else if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, tail));
+		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
 		if (deferred) { ctx->tiles_launches++; continue; }
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;

@@ -64,6 +64,16 @@ struct msc_ctx {
 	uint64_t defer_q_off = 0;              // first query of the block being queued, in qslots_all
 	float defer_ms = 0.f;
 	DevBuf qslots_all;                     // the query slots of the whole call
+	// ... and in two stages on two streams: a block's product (stream) runs beside the rank walk of the same block and the epilogue of
+	// the block before it (tail_stream). What both stages touch exists twice (second copies below; the first are kb_qT, kb_min, kb_diff):
+	// ev_head[i] = the product of a block using copy i is about to start, ev_product[i] = it is through, ev_tail[i] = the epilogue that
+	// read copy i is through
+	hipStream_t tail_stream = nullptr;
+	hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_product[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+	DevBuf kb_qT2, kb_min2, kb_diff2;
+	bool tail_busy[2] = {false, false};
+	bool tail_used = false;
+	uint32_t pipe_next = 0;
 	std::vector<hipEvent_t> ev_pool;       // timing events of the queued blocks
 	size_t ev_used = 0;
 	DevBuf emd_out, rk_bad;                // msc_emd_ranks.hip: the distances of a chunk, the build's error word
