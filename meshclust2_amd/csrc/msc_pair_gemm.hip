@@ -470,10 +470,12 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 		if (e != hipSuccess) return e;
 	}
 	const bool wide = pair_gemm_wide(qn, m);
+	// MSC_GEMM_LDS_PAD=KiB: unused LDS added to every workgroup of the product, i.e. fewer of them per CU -- room for the tail stream's kernels
+	static const unsigned lds_pad = [] { const char* e = getenv("MSC_GEMM_LDS_PAD"); return (unsigned)(e ? atoi(e) * 1024 : 0); }();
 	const dim3 grid((m + (wide ? 255 : 127)) / (wide ? 256 : 128), k_slices);
 #define MSC_PG_GO(NRB, NW)                                                                                                                                             \
 	do {                                                                                                                                                           \
-		if (pair_gemm_fp4()) k_pair_gemm_fp4<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
+		if (pair_gemm_fp4()) k_pair_gemm_fp4<NRB, NW><<<grid, dim3(64 * NW), lds_pad, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
 		else k_pair_gemm_bits<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff);             \
 	} while (0)
 	if (qn == 32) MSC_PG_GO(1, 4);
