@@ -438,6 +438,7 @@ extern "C" int msc_hist_set_clear(msc_ctx* ctx, msc_hist_set* s) {
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	s->hdr_host.assign(s->capacity, MscSparseHdr{});
 	s->ent_used = 0;
+	s->list_epoch++;
 	s->max_nnz = 0;
 	s->max_count = s->max_sum = 0;
 	forget_lengths(s, 0, s->capacity);
@@ -467,6 +468,9 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->ent) (void)hipFree(s->ent);
 	if (s->cum) (void)hipFree(s->cum);
 	if (s->hdr) (void)hipFree(s->hdr);
+	if (s->rkl) (void)hipFree(s->rkl);
+	if (s->rkl_off) (void)hipFree(s->rkl_off);
+	if (s->rkl_n) (void)hipFree(s->rkl_n);
 	delete s;
 }
 
@@ -574,6 +578,7 @@ static int sparsify_slots(msc_ctx* ctx, const msc_hist_set* dense, uint64_t d_fi
 			h.off = sp->ent_used;
 			sp->ent_used += cnt;
 			sp->hdr_host[s_first + b0 + i] = h;
+			sp->list_epoch++;
 			sp->max_nnz = std::max(sp->max_nnz, h.nnz);
 		}
 		HIP_TRY(ctx, hipMemcpyAsync(sp->hdr + s_first + b0, sp->hdr_host.data() + s_first + b0, nb * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
@@ -695,6 +700,7 @@ static int build_sparse_sort(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slo
 	                                          (const uint64_t*)ctx->seg_start.p, (const uint64_t*)ctx->kmer_off.p, (const uint64_t*)ctx->seq_seg.p,
 	                                          (const uint64_t*)ctx->sp_cumbase.p, P, set->scalars, set->scalar_stride, set->hdr, set->ent, set->cum));
 	set->ent_used += need;
+	set->list_epoch++;
 	HIP_TRY(ctx, hipMemcpyAsync(set->hdr_host.data() + first_slot, set->hdr + first_slot, n_seqs * sizeof(MscSparseHdr), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return refresh_bounds(ctx, set, first_slot, n_seqs);
@@ -1109,6 +1115,7 @@ static int copy_common(msc_ctx* ctx, msc_hist_set* dst, uint64_t ds, const msc_h
 			HIP_TRY(ctx, hipMemcpyAsync(dst->cum + dh.off, src->cum + sh.off, sh.nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
 		}
 		dst->hdr_host[ds] = dh;
+		dst->list_epoch++;
 		HIP_TRY(ctx, hipMemcpyAsync(dst->hdr + ds, &dst->hdr_host[ds], sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		return MSC_OK;
@@ -1212,6 +1219,7 @@ static int assign_or_copy_batch(msc_ctx* ctx, msc_hist_set* dst, const uint32_t*
 			else forget_lengths(dst, dst_slots[i], 1);
 		}
 		dst->ent_used = o;
+		dst->list_epoch++;
 		dst->max_count = std::max(dst->max_count, src->max_count);
 		dst->max_sum = std::max(dst->max_sum, src->max_sum);
 		return MSC_OK;
@@ -1461,6 +1469,40 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 	                              use_window, min_len, max_len, partials, div_tables, div_partials, order);
 }
 
+// The rank lists of the sparse set (or sparse mirror) `s`, for the 1 x M pass of msc_ranks_pass.hip: true when they are current. Built only
+// once the same state of the set has been asked for three times (msc_objects.h).
+bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err) {
+	*err = MSC_OK;
+	if (!s->sparse || s->rkl_unavailable) return false;
+	if (s->rkl && s->rkl_epoch == s->list_epoch) return true;
+	if (s->rkl_seen_epoch != s->list_epoch) { s->rkl_seen_epoch = s->list_epoch; s->rkl_seen = 0; }
+	// (MSC_RANKS_1XM_AFTER=n: build at the n-th request instead of the third; read on every call so that a test can switch it)
+	const char* after_env = getenv("MSC_RANKS_1XM_AFTER");
+	const uint32_t after = after_env && atoi(after_env) > 0 ? (uint32_t)atoi(after_env) : 3u;
+	if (++s->rkl_seen < after) return false;
+	auto give_up = [&]() { (void)hipGetLastError(); s->rkl_unavailable = true; return false; };
+	if (!s->rkl_off && (hipMalloc((void**)&s->rkl_off, (s->capacity + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&s->rkl_n, s->capacity * sizeof(uint32_t)) != hipSuccess))
+		return give_up();
+	if (msc_launch_rank_lists_sizes(ctx->stream, s->hdr, s->cum, s->capacity, s->rkl_n, s->rkl_off) != hipSuccess) { *err = fail(ctx, MSC_ERR_HIP, "rank lists: size pass failed"); return false; }
+	uint64_t total = 0;
+	if (hipMemcpyAsync(&total, s->rkl_off + s->capacity, sizeof total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+		*err = fail(ctx, MSC_ERR_HIP, "rank lists: size read-back failed");
+		return false;
+	}
+	if (total + 4 > s->rkl_entries) {
+		if (s->rkl) (void)hipFree(s->rkl);
+		s->rkl = nullptr;
+		s->rkl_entries = total + total / 8 + 1024;
+		if (hipMalloc((void**)&s->rkl, s->rkl_entries * sizeof(uint32_t)) != hipSuccess) { s->rkl_entries = 0; return give_up(); }
+	}
+	if (msc_launch_rank_lists_fill(ctx->stream, s->ent, s->cum, s->hdr, s->capacity, s->rkl_n, s->rkl_off, s->L.nbins, s->rkl) != hipSuccess) {
+		*err = fail(ctx, MSC_ERR_HIP, "rank lists: fill failed");
+		return false;
+	}
+	s->rkl_epoch = s->list_epoch;
+	return true;
+}
+
 // Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
 }  // namespace
 bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) { return needs_wide_impl(a, b); }
@@ -1520,12 +1562,23 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool inline_div = need_div && !lists && !mirror_div;       // table form inside k_pair_tiles / direct form inside the wide kernel
 	const SparseKernel spk = c_sp ? pick_sparse_kernel(c_sp, q_sp, rq.q_slot, std::max(rq.cands->max_count, rq.qset->max_count), wide) : SPK_GENERIC;
 	if (lists) ctx->last_kernel = spk == SPK_MP && !need_div && msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz) ? "k_pair_sparse_wl" : sparse_kernel_name(spk);
+	// r04: up to k = 9 the integer statistics of a list pass come from RANK lists -- no merge (msc_ranks_pass.hip): the query's histogram as
+	// two bits per bin in LDS, the candidates' k-mers streamed at 4 bytes each. Same records as the merge kernels, bit for bit.
+	const bool no_rank_pass = getenv("MSC_NO_RANKS_1XM") != nullptr;          // (read on every call: tests compare both routes in one process)
+	bool rank_pass = false;
+	if (lists && !need_div && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && msc_ranks_pass_lds(L.nbins) != 0 && rq.qset->max_sum >= L.nbins &&
+	    rq.qset->max_sum - L.nbins <= msc_ranks_pass_query_cap()) {
+		int e = MSC_OK;
+		rank_pass = rank_lists_ready(ctx, c_sp, &e);
+		if (e) return e;
+		if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
+	}
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
 	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
 	// ... and so is the divergence form (sparse sets and the mirror pass of dense ones): its FP64 sums leave per granule of the merged
 	// order and are added in granule order by the epilogue, whatever the number of waves that shared a pair
 	const uint64_t mp_entries = c_sp ? (uint64_t)q_sp->hdr_host[rq.q_slot].nnz + c_sp->max_nnz : 0;
-	const uint32_t mp_parts = c_sp && spk == SPK_MP && (need_div ? true : lists && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
+	const uint32_t mp_parts = c_sp && !rank_pass && spk == SPK_MP && (need_div ? true : lists && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
 	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), mp_entries, ctx->num_cus, need_div) : 1;
 	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
 	const uint32_t DVN = div_records(spk, mp_entries);                // ... and {jd, js} records per candidate
@@ -1578,7 +1631,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, msc_launch_sparse_nnz_sum(ctx->stream, c_sp->hdr, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.use_window, rq.min_len, rq.max_len, (uint64_t*)ctx->prof_nnz.p));
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
-		if (lists) {
+		if (lists && rank_pass) {
+			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
+			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus));
+		} else if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
 			                                mp_parts, DVN));
@@ -2605,6 +2661,7 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	h.off = 0;
 	rs->ent_used = n;
 	rs->hdr_host[0] = h;
+	rs->list_epoch++;
 	rs->max_nnz = std::max(rs->max_nnz, h.nnz);          // (every writer of hdr_host keeps max_nnz >= each list: the whole-list kernel sizes its LDS by it)
 	MscSlotScalars sc;
 	memset(&sc, 0, sizeof sc);
@@ -2825,6 +2882,7 @@ int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const u
 		if ((r = msc_hist_set_create_sparse(ctx, pts->k, pts->dtype, cap, arena, &ms))) return r;
 	}
 	ms->ent_used = used;
+	ms->list_epoch++;
 	ms->max_nnz = std::max(ms->max_nnz, max_nnz);
 	for (uint32_t c = 0; c < nc; c++) ms->hdr_host[c] = hdr[c];
 	HIP_TRY(ctx, hipMemcpyAsync(ms->hdr, hdr.data(), nc * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));

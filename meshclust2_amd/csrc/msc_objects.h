@@ -138,6 +138,17 @@ struct msc_hist_set {
 	std::vector<MscSparseHdr> hdr_host;   // mirror
 	uint64_t ent_capacity = 0, ent_used = 0;
 	uint32_t max_nnz = 0;                 // longest entry list ever stored (monotone)
+	// rank lists of a sparse set (msc_ranks_pass.hip): per slot the bins of its counted k-mers, value - 1 copies of each, at rkl_off[slot],
+	// rkl_n[slot] of them. A cache of the lists: every writer of a slot's list bumps list_epoch, the cache remembers the epoch it was built
+	// at, and it is (re)built only once the same epoch has been asked for three times -- point sets build theirs once, centre stores (a
+	// write every step) never do.
+	uint64_t list_epoch = 0;
+	mutable uint32_t* rkl = nullptr;
+	mutable uint64_t* rkl_off = nullptr;
+	mutable uint32_t* rkl_n = nullptr;
+	mutable uint64_t rkl_epoch = ~0ull, rkl_seen_epoch = ~0ull, rkl_entries = 0;
+	mutable uint32_t rkl_seen = 0;
+	mutable bool rkl_unavailable = false;
 };
 
 struct msc_model {

@@ -291,7 +291,11 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr uint32_t kM1 = 0x11111111u, kM2 = 0x22222222u, kM4 = 0x44444444u;
 
-template <int NRB, int NW>
+// QS = 1: a wave owns 32 candidates and all NRB row blocks (one LDS read of a queries' operand per product). QS = 2: the workgroup's tile
+// is dealt the other way -- a wave owns 64 candidates (two column tiles) and NRB / 2 row blocks, so that one LDS read serves TWO products
+// (the CU's LDS delivers 128 bytes per clock: exactly the operand bytes the matrix pipe consumes at its peak when every product reads its
+// own 16 bytes per lane); the price is that two waves expand the same candidate bits.
+template <int NRB, int NW, int QS>
 __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                                      const uint8_t* __restrict__ abits, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
                                                                      const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
@@ -299,25 +303,37 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(con
 	constexpr int NT = 64 * NW;
 	constexpr int SPT = QN * 8 / NT;         // 16-byte segments of the tile (= dwords of the bit image) a thread expands per step
 	constexpr int TPR = 8 / SPT;
+	constexpr int CT = QS;                   // column tiles (of 32 candidates) per wave
+	constexpr int RBW = NRB / QS;            // row blocks per wave
 	static_assert(SPT >= 1 && SPT <= 8 && TPR * SPT == 8, "tile staging");
+	static_assert(NRB % QS == 0 && NW % QS == 0, "tile deal");
 	__shared__ v4i sA[2][QN * 8];          // [buffer][row][segment (2 t + h) ^ ((row >> 1) & 7)]: QN x 128 bytes = 256 bins of nibbles
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t qg = wave % QS, cg = wave / QS;
 	const uint32_t ks = blockIdx.y;
 	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
 	const uint32_t n_ss = (uint32_t)(per / 256), gss0 = (uint32_t)(k0 / 256);
-	const uint32_t ci = (blockIdx.x * NW + wave) * 32 + (lane & 31);
-	const bool valid = ci < m;
-	const uint32_t cc = valid ? ci : m - 1;
-	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
-	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	uint32_t ci[CT];
+	bool valid[CT];
+	const uint8_t* brow[CT];
+#pragma unroll
+	for (int c = 0; c < CT; c++) {
+		ci[c] = (blockIdx.x * NW + cg * CT + c) * 32 + (lane & 31);
+		valid[c] = ci[c] < m;
+		const uint32_t cc = valid[c] ? ci[c] : m - 1;
+		const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+		brow[c] = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	}
 	const uint32_t u = tid / TPR, part = tid % TPR;
 	const uint32_t srow = (u & ~15u) | (2 * (u & 7) + ((u >> 3) & 1));
 	const uint8_t* asrc = abits + ((uint64_t)srow * 8 + part * SPT) * 4;
-	v16f acc[NRB];
+	v16f acc[RBW][CT];
 #pragma unroll
-	for (int rb = 0; rb < NRB; rb++)
+	for (int rb = 0; rb < RBW; rb++)
 #pragma unroll
-		for (int i = 0; i < 16; i++) acc[rb][i] = 0.f;
+		for (int c = 0; c < CT; c++)
+#pragma unroll
+			for (int i = 0; i < 16; i++) acc[rb][c][i] = 0.f;
 	uint32_t a_reg[SPT];
 	auto fetch_a = [&](uint32_t ss) {
 		const uint8_t* p = asrc + (uint64_t)(gss0 + (ss < n_ss ? ss : n_ss - 1)) * (QN * 32);
@@ -335,53 +351,69 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(con
 			sA[buf][srow * 8 + (sg ^ ((srow >> 1) & 7))] = v4i{(int)((w << 2) & kM4), (int)(w & kM2), (int)((w >> 2) & kM1), (int)((w >> 1) & kM4)};
 		}
 	};
-	auto fetch_b = [&](uint32_t ss) { return *reinterpret_cast<const v4i*>(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024); };
-	auto multiply = [&](uint32_t buf, const v4i& bq) {
+	auto fetch_b = [&](int c, uint32_t ss) { return *reinterpret_cast<const v4i*>(brow[c] + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024); };
+	auto multiply = [&](uint32_t buf, const v4i (&bq)[CT]) {
 		const uint32_t r = lane & 31, sw = (r >> 1) & 7, hh = lane >> 5;
 #pragma unroll
 		for (int t = 0; t < 4; t++) {
-			const uint32_t w = (uint32_t)bq[t];
-			const v8i B = {(int)(w & kM1), (int)(w & kM2), (int)(w & kM4), (int)((w >> 3) & kM1), 0, 0, 0, 0};
+			v8i B[CT];
 #pragma unroll
-			for (int rb = 0; rb < NRB; rb++) {
-				const v4i a = sA[buf][(32 * rb + r) * 8 + ((2 * t + hh) ^ sw)];
+			for (int c = 0; c < CT; c++) {
+				const uint32_t w = (uint32_t)bq[c][t];
+				B[c] = v8i{(int)(w & kM1), (int)(w & kM2), (int)(w & kM4), (int)((w >> 3) & kM1), 0, 0, 0, 0};
+			}
+#pragma unroll
+			for (int rb = 0; rb < RBW; rb++) {
+				const v4i a = sA[buf][(32 * (qg * RBW + rb) + r) * 8 + ((2 * t + hh) ^ sw)];
 				const v8i A = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
-				acc[rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[rb], 4, 4, 0, 0, 0, 0);
+#pragma unroll
+				for (int c = 0; c < CT; c++) acc[rb][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[c], acc[rb][c], 4, 4, 0, 0, 0, 0);
 			}
 		}
 	};
-	// P2 as in the int8 form: the hot entries of both 128-bin steps of this tile step
-	auto hotfix = [&](uint32_t ss, const v4i& bq) {
+	// P2 as in the int8 form: the hot entries of both 128-bin steps of this tile step (by the waves of query group 0: a column tile is
+	// held by QS waves)
+	auto hotfix = [&](uint32_t ss, const v4i (&bq)[CT]) {
 		const uint32_t h0 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss)]), h1 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss) + 2]);
 		for (uint32_t e = h0; e < h1; e++) {
 			const uint2 en = hot[e];
 			const uint32_t bin = __builtin_amdgcn_readfirstlane(en.x), rg = __builtin_amdgcn_readfirstlane(en.y);
 			const uint32_t j = (bin >> 5) & 7, wsel = j >> 1;
-			const uint32_t w = (uint32_t)(wsel == 0 ? bq.x : wsel == 1 ? bq.y : wsel == 2 ? bq.z : bq.w);
-			const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
-			if (valid && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
+#pragma unroll
+			for (int c = 0; c < CT; c++) {
+				const uint32_t w = (uint32_t)(wsel == 0 ? bq[c].x : wsel == 1 ? bq[c].y : wsel == 2 ? bq[c].z : bq[c].w);
+				const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
+				if (valid[c] && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci[c] * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
+			}
 		}
 	};
-	v4i bcur = fetch_b(0);
+	v4i bcur[CT], bnext[CT];
+#pragma unroll
+	for (int c = 0; c < CT; c++) bcur[c] = fetch_b(c, 0);
 	fetch_a(0);
 	park(0);
 	__syncthreads();
 	for (uint32_t ss = 0; ss < n_ss; ss++) {
 		const uint32_t buf = ss & 1;
-		const v4i bnext = fetch_b(ss + 1);            // (the last one once more past the end: a load nobody uses is cheaper than a branch around it)
+#pragma unroll
+		for (int c = 0; c < CT; c++) bnext[c] = fetch_b(c, ss + 1);            // (the last one once more past the end: a load nobody uses is cheaper than a branch around it)
 		fetch_a(ss + 1);
 		multiply(buf, bcur);
-		if (hot_ptr) hotfix(ss, bcur);
+		if (hot_ptr && qg == 0) hotfix(ss, bcur);
 		park(buf ^ 1);
 		__syncthreads();
-		bcur = bnext;
+#pragma unroll
+		for (int c = 0; c < CT; c++) bcur[c] = bnext[c];
 	}
-	if (!valid) return;
-	int32_t* o = out_min + ((uint64_t)ks * m + ci) * QN + 4 * (lane >> 5);
 #pragma unroll
-	for (int rb = 0; rb < NRB; rb++)
+	for (int c = 0; c < CT; c++) {
+		if (!valid[c]) continue;
+		int32_t* o = out_min + ((uint64_t)ks * m + ci[c]) * QN + 32 * (qg * RBW) + 4 * (lane >> 5);
 #pragma unroll
-		for (int g = 0; g < 4; g++) *reinterpret_cast<v4i*>(o + 32 * rb + 8 * g) = v4i{(int)acc[rb][4 * g], (int)acc[rb][4 * g + 1], (int)acc[rb][4 * g + 2], (int)acc[rb][4 * g + 3]};
+		for (int rb = 0; rb < RBW; rb++)
+#pragma unroll
+			for (int g = 0; g < 4; g++) *reinterpret_cast<v4i*>(o + 32 * rb + 8 * g) = v4i{(int)acc[rb][c][4 * g], (int)acc[rb][c][4 * g + 1], (int)acc[rb][c][4 * g + 2], (int)acc[rb][c][4 * g + 3]};
+	}
 }
 
 }  // namespace
@@ -471,11 +503,13 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 	}
 	const bool wide = pair_gemm_wide(qn, m);
 	// MSC_GEMM_LDS_PAD=KiB: unused LDS added to every workgroup of the product, i.e. fewer of them per CU -- room for the tail stream's kernels
+	static const bool qs2 = getenv("MSC_GEMM_QS2") != nullptr;          // (A/B: the 64-candidate-per-wave deal of the workgroup's tile)
 	static const unsigned lds_pad = [] { const char* e = getenv("MSC_GEMM_LDS_PAD"); return (unsigned)(e ? atoi(e) * 1024 : 0); }();
 	const dim3 grid((m + (wide ? 255 : 127)) / (wide ? 256 : 128), k_slices);
 #define MSC_PG_GO(NRB, NW)                                                                                                                                             \
 	do {                                                                                                                                                           \
-		if (pair_gemm_fp4()) k_pair_gemm_fp4<NRB, NW><<<grid, dim3(64 * NW), lds_pad, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
+		if (pair_gemm_fp4() && qs2 && NRB % 2 == 0) k_pair_gemm_fp4<NRB, NW, (NRB % 2 == 0 ? 2 : 1)><<<grid, dim3(64 * NW), lds_pad, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
+		else if (pair_gemm_fp4()) k_pair_gemm_fp4<NRB, NW, 1><<<grid, dim3(64 * NW), lds_pad, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff); \
 		else k_pair_gemm_bits<NRB, NW><<<grid, dim3(64 * NW), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff);             \
 	} while (0)
 	if (qn == 32) MSC_PG_GO(1, 4);

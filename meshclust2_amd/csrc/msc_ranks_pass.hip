@@ -1,0 +1,216 @@
+// msc_ranks_pass.hip -- the 1 x M pass of Trainer::get_close / filter (cluster/Trainer.cpp:26-61) over RANK LISTS, for histograms of up to
+// 4^9 bins: no merge of two sorted lists. r04.
+//
+// A rank list = the bins of a histogram's counted k-mers in bin order, a bin with count c listed e = c - 1 times (every bin starts at the
+// pseudocount 1, nonltr/KmerHashTable.cpp:69-72): 4 bytes per k-mer where the (bin, value) lists of sparse.hip take 8 bytes per stored bin
+// plus their prefix words, and -- what matters -- a form in which the three integer reductions of a pair (pair_features.hip: manhattan,
+// the dot product, the earth mover's distance; predict/Feature.cpp:859-871, 1113-1124, 1505-1518) need no co-ordination between the lists:
+//     emd           = sum_t |a_t - b_t|                     the t-th k-mer of either histogram, both lists padded with 4^k (msc_emd_ranks.hip)
+//     sum e_c e_q   = sum over the candidate's entries of e_q(bin)
+//     sum min(e_c, e_q) = sum over the candidate's entries, the r-th copy of a bin (r = 0, 1, ..) counting [r < e_q(bin)]
+// e_q(bin) is a LOOKUP: the query's histogram sits in LDS as two bits per bin -- present (e_q >= 1) and large (e_q >= 2) -- shared by the
+// sixteen waves of a workgroup for every candidate they walk. An entry whose bin is not large in the query (all but a handful: a 1 kb
+// sequence at k = 9 has ~2 large bins) contributes its present bit to the product and, if it is the first copy of its bin, to the minimum;
+// the rare entry that hits a large bin looks e_q up in the query's own rank list (LDS, binary search) and its copy number r in the
+// candidate's (global memory, binary search). Exact in integers; records as k_pair_sparse_wl writes them (manh, dot over the union of stored
+// bins, emd), so the epilogue and everything behind it are shared.
+//
+// Per candidate a wave reads its list once, 16 bytes per lane and load, coalesced: 4 KB for a 1 kb sequence (the merge kernels: 8 KB of
+// entries + 4 KB of prefix words, staged through LDS and walked by a data-dependent two-pointer loop). Roofline: HBM, 4 bytes per k-mer.
+#include "msc_internal.h"
+#include "msc_wave.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+constexpr uint32_t kRpBlock = 1024;          // sixteen waves share the query's tables
+constexpr uint32_t kRpQCap = 8192;           // longest query rank list (host-checked against the set's bound)
+
+// ------------------------------------------------------------------------------------------------ rank lists of a sparse set
+// n[slot] = the slot's k-mers = the last inclusive prefix of its excess counts; lists are padded to a multiple of four entries
+__global__ void __launch_bounds__(256) k_rkl_sizes(const MscSparseHdr* __restrict__ hdr, const uint32_t* __restrict__ cum, uint64_t capacity, uint32_t* __restrict__ n) {
+	const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= capacity) return;
+	const MscSparseHdr* h = hdr + s;
+	n[s] = h->nnz ? cum[h->off + h->nnz - 1] : 0u;
+}
+// exclusive scan of the padded sizes by one workgroup (a set is scanned once per build); off[capacity] = the total
+__global__ void __launch_bounds__(1024) k_rkl_scan(const uint32_t* __restrict__ n, uint64_t capacity, uint64_t* __restrict__ off) {
+	__shared__ uint64_t s_part[1024];
+	const uint64_t per = (capacity + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < capacity ? lo + per : capacity;
+	uint64_t s = 0;
+	for (uint64_t i = lo; i < hi; i++) s += (n[i] + 3u) & ~3u;
+	s_part[threadIdx.x] = s;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {
+		const uint64_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint64_t run = s_part[threadIdx.x] - s;
+	for (uint64_t i = lo; i < hi; i++) { off[i] = run; run += (n[i] + 3u) & ~3u; }
+	if (threadIdx.x == 1023) off[capacity] = s_part[1023];
+}
+// one wave per slot: entry j = (bin, value) puts value - 1 copies of bin at [cum[j] - (value - 1), cum[j]); the tail is padded with 4^k
+__global__ void __launch_bounds__(256) k_rkl_fill(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr, uint64_t capacity,
+                                                  const uint32_t* __restrict__ n, const uint64_t* __restrict__ off, uint32_t nbins, uint32_t* __restrict__ out) {
+	const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	if (s >= capacity) return;
+	const MscSparseHdr* h = hdr + s;
+	uint32_t* o = out + off[s];
+	const uint32_t tot = n[s], pad = (tot + 3u) & ~3u;
+	for (uint32_t j = lane; j < h->nnz; j += 64) {
+		const uint2 en = ent[h->off + j];
+		const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h->off + j];
+		for (uint32_t t = end - e; t < end; t++) o[t] = en.x;
+	}
+	if (lane < pad - tot) o[tot + lane] = nbins;
+}
+
+// ------------------------------------------------------------------------------------------------ the pass
+// first index in the sorted list v[0 .. n) whose value is >= x
+template <typename Load>
+__device__ __forceinline__ uint32_t lower_bound_u32(Load v, uint32_t n, uint32_t x) {
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (v(mid) < x) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+// LDS: [bits: nbins / 32 + 1 pairs (present word, large word)][query ranks: padded to 256 with nbins]
+__global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
+                                                              const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
+                                                              uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
+                                                              uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
+	const uint32_t words = nbins / 32 + 1;
+	uint2* sb = reinterpret_cast<uint2*>(s_rp);
+	uint32_t* rq = s_rp + 2 * words + ((2 * words) & 3 ? 4 - ((2 * words) & 3) : 0);          // 16-byte aligned
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint32_t nq = qh.nnz;
+	const uint2* Q = q_ent + qh.off;
+	const uint32_t* CQ = q_cum + qh.off;
+	const uint32_t nq_tot = nq ? CQ[nq - 1] : 0u;          // (<= kRpQCap: the host's bound on the set)
+	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
+	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = make_uint2(0u, 0u);
+	for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += kRpBlock) rq[i] = nbins;
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
+		const uint2 en = Q[j];
+		const uint32_t e = en.y ? en.y - 1u : 0u, end = CQ[j];
+		if (e >= 1) atomicOr(&sb[en.x >> 5].x, 1u << (en.x & 31));
+		if (e >= 2) atomicOr(&sb[en.x >> 5].y, 1u << (en.x & 31));
+		for (uint32_t t = end - e; t < end; t++) rq[t] = en.x;
+	}
+	__syncthreads();
+	const uint32_t total_waves = gridDim.x * (kRpBlock / 64);
+	for (uint32_t c = blockIdx.x * (kRpBlock / 64) + wave; c < m; c += total_waves) {
+		const uint64_t slot = cand_slots ? cand_slots[c] : first + c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const uint32_t nc = c_n[slot], nc_pad = (nc + 3u) & ~3u;
+		const uint32_t* P = c_rk + c_off[slot];
+		const uint32_t T = nc > nq_tot ? nc : nq_tot;
+		uint64_t emd = 0;
+		uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
+		uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
+		for (uint32_t t0 = 0; t0 < T; t0 += 256) {
+			const uint32_t t = t0 + 4 * lane;
+			uint4 a = make_uint4(nbins, nbins, nbins, nbins), b = a;
+			if (t < nc_pad) a = *reinterpret_cast<const uint4*>(P + t);
+			if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
+			uint32_t d = sad_u32(a.x, b.x, 0u);
+			d = sad_u32(a.y, b.y, d);
+			d = sad_u32(a.z, b.z, d);
+			d = sad_u32(a.w, b.w, d);
+			emd += d;
+			uint32_t before = __shfl_up(a.w, 1, 64);
+			if (lane == 0) before = carry;
+			carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
+			const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+			const uint32_t pv[4] = {before, a.x, a.y, a.z};
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t bin = av[j];
+				const uint2 w = sb[bin >> 5];          // (the padding value 4^k reads the zero pair behind the last word)
+				const uint32_t sh = bin & 31;
+				const uint32_t present = (w.x >> sh) & 1u, large = (w.y >> sh) & 1u;
+				prod += present;
+				mins += present & (bin != pv[j] ? 1u : 0u);
+				if (large) {          // rare: this k-mer is repeated in the query
+					const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
+					uint32_t e_q = 0;
+					while (lo + e_q < nq_tot && rq[lo + e_q] == bin) e_q++;
+					const uint32_t r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // this entry is the r-th copy of its bin
+					prod += e_q - 1;
+					if (r >= 1 && r < e_q) mins += 1;
+				}
+			}
+		}
+		const uint64_t emd_t = wave_sum_u64(emd);
+		const uint64_t prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
+		if (lane == 0) {
+			MscPartial out;
+			out.manh = (uint64_t)nc + nq_tot - 2 * mins_t;          // sum |e_c - e_q|
+			out.dot = prod_t + nc + nq_tot;                          // sum (c q - 1) over the union of stored bins (the epilogue adds 4^k)
+			out.emd = emd_t;
+			partials[c] = out;
+		}
+	}
+}
+
+}  // namespace
+
+// bytes of dynamic LDS the pass needs for 4^k = nbins; 0 when the histogram is too large for it
+size_t msc_ranks_pass_lds(uint64_t nbins) {
+	if (nbins > (1ull << 18) || nbins % 32) return 0;
+	const size_t words = nbins / 32 + 1;
+	return (2 * words + 4) * 4 + (size_t)kRpQCap * 4;
+}
+uint32_t msc_ranks_pass_query_cap() { return kRpQCap; }
+
+// sizes (n: capacity words) and offsets (off: capacity + 1 words) of the rank lists of a sparse set; the caller reads off[capacity], allocates, fills
+hipError_t msc_launch_rank_lists_sizes(hipStream_t st, const MscSparseHdr* hdr, const uint32_t* cum, uint64_t capacity, uint32_t* n, uint64_t* off) {
+	if (capacity == 0) return hipSuccess;
+	k_rkl_sizes<<<dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st>>>(hdr, cum, capacity, n);
+	k_rkl_scan<<<dim3(1), dim3(1024), 0, st>>>(n, capacity, off);
+	return hipGetLastError();
+}
+hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uint32_t* cum, const MscSparseHdr* hdr, uint64_t capacity, const uint32_t* n, const uint64_t* off,
+                                      uint64_t nbins, uint32_t* out) {
+	if (capacity == 0) return hipSuccess;
+	k_rkl_fill<<<dim3((unsigned)((capacity + 3) / 4)), dim3(256), 0, st>>>((const uint2*)ent, cum, hdr, capacity, n, off, (uint32_t)nbins, out);
+	return hipGetLastError();
+}
+
+// candidates [first, first + m) (or the device slot list cand_slots; cand_scalars then is the set's base) against the query list
+hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
+                                     const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+	if (m == 0) return hipSuccess;
+	const size_t lds = msc_ranks_pass_lds(nbins);
+	if (!lds) return hipErrorInvalidValue;
+	static bool attr_set = false;
+	if (!attr_set) {
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	// one workgroup per CU (its tables take most of the CU's LDS); fewer when the window is short: a workgroup's set-up is ~2 us
+	const uint32_t per_wg = kRpBlock / 64;
+	uint32_t blocks = (m + per_wg - 1) / per_wg;
+	if (blocks > (uint32_t)num_cus) blocks = (uint32_t)num_cus;
+	k_pair_ranks_1xm<<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
+	                                                            use_window, min_len, max_len, partials);
+	return hipGetLastError();
+}

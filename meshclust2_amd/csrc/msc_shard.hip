@@ -207,6 +207,7 @@ extern "C" int msc_hist_set_reset(msc_ctx* ctx, msc_hist_set* set) {
 	if (!set->sparse) return MSC_OK;
 	// (whatever is queued on the ctx stream still reads the old lists; what overwrites them is queued behind it on the same stream)
 	set->ent_used = 0;
+	set->list_epoch++;
 	for (MscSparseHdr& h : set->hdr_host) { h.nnz = 0; h.off = 0; }
 	return MSC_OK;
 }
@@ -249,6 +250,7 @@ extern "C" int msc_hist_unpack(msc_ctx* ctx, msc_hist_set* set, const uint32_t* 
 				HIP_TRY(ctx, hipMemcpyAsync(set->cum + h.off, p + up16((uint64_t)ph.nnz * 8), (uint64_t)ph.nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
 			}
 			set->ent_used += ph.nnz;
+			set->list_epoch++;
 			set->hdr_host[slot] = h;          // (the mirror outlives the copy below: it is the source)
 			HIP_TRY(ctx, hipMemcpyAsync(set->hdr + slot, &set->hdr_host[slot], sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
 			set->max_nnz = std::max(set->max_nnz, h.nnz);
@@ -314,6 +316,7 @@ extern "C" int msc_hist_unpack(msc_ctx* ctx, msc_hist_set* set, const uint32_t* 
 	if ((r = run_copies(ctx, segs))) return r;
 	if (set->sparse) {
 		set->ent_used = used;
+		set->list_epoch++;
 		for (uint64_t i = 0; i < n; i++) set->hdr_host[slots[i]] = new_hdr[i];
 	}
 	// 3. the host-side bounds and lengths follow the records that arrived (consecutive slots in one strided copy)

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(const uint8_t*
 // the same over many workgroups: counts per block, then every block adds up the counts in front of it
 __global__ void __launch_bounds__(kWinBlock) k_window_count(const uint8_t* __restrict__ alive, uint32_t first, uint32_t range, uint32_t* __restrict__ counts) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
-	const uint32_t base = blockIdx.x * kWinTile + threadIdx.x * kWinPer;
+	const uint32_t base = blockIdx.x * (blockDim.x * kWinPer) + threadIdx.x * kWinPer;
 	uint32_t c = 0;
 #pragma unroll
 	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
@@ -90,12 +90,12 @@ __global__ void __launch_bounds__(kWinBlock) k_window_write(const uint8_t* __res
 	__shared__ uint32_t s_base;
 	if (blockIdx.x == 0 && threadIdx.x == 0) *close_counter = 0;
 	uint32_t before = 0;
-	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kWinBlock) before += counts[b];
+	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x) before += counts[b];
 	uint32_t total;
 	(void)block_excl_scan(before, s_wave, &total);
 	if (threadIdx.x == 0) s_base = total;
 	__syncthreads();
-	const uint32_t base = blockIdx.x * kWinTile + threadIdx.x * kWinPer;
+	const uint32_t base = blockIdx.x * (blockDim.x * kWinPer) + threadIdx.x * kWinPer;
 	uint32_t c = 0;
 #pragma unroll
 	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
@@ -229,13 +229,16 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	if ((r = slot_length(ctx, qset, q_slot, &qlen))) return r;
 	if ((r = flush_kills(ctx, w))) return r;
 	const uint32_t range = (uint32_t)(end - first);
-	if (range <= 128 * kWinBlock) {
+	// One workgroup walking the range alone takes 50 us for 40 000 positions (a third of a step on a window-bearing set: profiles/
+	// r04_notes.md); from a few thousand positions on, many small workgroups count and then write (2 launches of a few us)
+	if (range <= 4 * kWinBlock) {
 		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
 	} else {
-		const uint32_t blocks = (range + kWinTile - 1) / kWinTile;
+		const uint32_t tb = range <= 64 * kWinTile ? 256 : kWinBlock, tile = tb * kWinPer;
+		const uint32_t blocks = (range + tile - 1) / tile;
 		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
-		k_window_count<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts);
-		k_window_write<<<dim3(blocks), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
+		k_window_count<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts);
+		k_window_write<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	if (w->h_close_cap < m + 2) {

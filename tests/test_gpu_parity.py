@@ -1059,7 +1059,7 @@ def test_full_size_cfg2_properties(oracle):
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
-        assert ctx.last_kernel_info()[0] in ("k_pair_tiles", "k_pair_sparse_wl", "k_pair_sparse_mp"), ctx.last_kernel_info()          # (r04: the dense set's mirror pass)
+        assert ctx.last_kernel_info()[0] in ("k_pair_tiles", "k_pair_sparse_wl", "k_pair_sparse_mp", "k_pair_ranks_1xm"), ctx.last_kernel_info()          # (r04: the dense set's mirror pass)
         assert np.array_equal(multi["sum"][i], single["sum"]) and np.array_equal(multi["csum"][i], single["csum"])
         assert int(multi["close"][i].sum()) == int((np.round(single["csum"]) > 0).sum())
     # first-hand at full size: the pass's weighted sums, close flags and integer statistics for the kept candidates x all 16 queries

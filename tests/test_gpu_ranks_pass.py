@@ -1,0 +1,132 @@
+"""The 1 x M pass over rank lists (csrc/msc_ranks_pass.hip: Trainer::get_close / filter shape, cluster/Trainer.cpp:26-61, for histograms of
+up to 4^9 bins) held to the CPU oracle's raw statistics (predict/Feature.cpp) and to the merge kernels it replaces -- sparse sets and the
+sparse mirrors of dense sets, repeat-bearing sequences (bins that are large in the query, in the candidate, in both), length windows,
+slot lists with repeats. The kernel the library ran is asserted by name."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import EXACT, FEATS, weights_text
+from meshclust2_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+FAST_MASK = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
+RTOL = 1e-9
+KERNEL = "k_pair_ranks_1xm"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def rank_pass_now(monkeypatch):
+    """the library builds a set's rank lists at the third request for the same state of the set; here at the first"""
+    monkeypatch.setenv("MSC_RANKS_1XM_AFTER", "1")
+    monkeypatch.delenv("MSC_NO_RANKS_1XM", raising=False)
+    return monkeypatch
+
+
+def _sequences(seed, n, length, kind):
+    seqs, _ = synth.families(seed, n, length, family=6, length_jitter=length // 10)
+    out = []
+    for i, s in enumerate(seqs):
+        s = bytes(s)
+        if kind and i % 5 == 1:          # a run spliced in: bins with large counts, shared by the members that carry the same run
+            run = {"homo": b"A" * 300, "di": b"AC" * 150, "unit3": b"ACG" * 40, "unit12": b"ACGTTGCAAGTC" * 9}[kind]
+            at = 50 + 7 * (i % 40)
+            s = s[:at] + run + s[at:]
+        out.append(s)
+    out.append(out[0][: length // 2])                          # a much shorter list than the query's
+    out.append(b"ACGT" * 30 + b"N" * 25 + out[1][:200])        # an interrupted one
+    out.append(b"A" * 12)                                      # one k-mer, or none
+    return out
+
+
+@pytest.mark.parametrize("dtype,k,n,length,kind,layout", [
+    (8, 9, 60, 1000, None, "sparse"),
+    (8, 9, 60, 1000, "homo", "sparse"),          # saturating 8-bit bins
+    (16, 9, 60, 1000, "di", "sparse"),
+    (32, 9, 60, 1000, "unit12", "dense"),        # the sparse mirror of a dense set
+    (32, 9, 60, 1000, "homo", "dense"),
+    (16, 8, 50, 2500, "unit3", "sparse"),        # 65 536 bins, lists of 2 500
+    (32, 7, 50, 400, None, "dense"),
+    (16, 8, 40, 600, "unit3", "dense"),
+])
+def test_rank_pass_against_the_oracle_and_the_merge_kernels(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
+    seqs = _sequences(7000 + 13 * k + dtype, n, length, kind)
+    n = len(seqs)
+    if layout == "sparse":
+        hs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=sum(len(s) for s in seqs) * 2 + 1000)
+    else:
+        hs = api.HistogramSet(ctx, k, dtype, n)
+    hs.build(seqs)
+    rng = np.random.default_rng(k * 100 + dtype)
+    cands = np.concatenate([np.arange(n, dtype=np.uint32)[::-1], rng.integers(0, n, 7).astype(np.uint32)])
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    fast = [(name, b) for name, b in FEATS if (1 << b) & FAST_MASK]
+    for q in (1, 0, 6, n - 3, n - 1):          # slot 1, 6: repeat-bearing queries; n - 3: half a sequence; n - 1: (almost) empty
+        for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+            got = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, order)
+            kernel = ctx.last_kernel_info()[0]
+            if 4 ** k >= 16384 and dtype != 64:          # (smaller histograms have no list form: the dense kernels take them)
+                assert kernel == KERNEL, (kernel, dtype, k, layout)
+            rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
+            ref = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, order)
+            assert ctx.last_kernel_info()[0] != KERNEL
+            rank_pass_now.delenv("MSC_NO_RANKS_1XM")
+            assert np.array_equal(got, ref), (q, order, kernel)          # the same integer records -> the same doubles, bit for bit
+            for ci in list(range(0, len(cands), 9)) + [len(cands) - 2]:
+                c = int(cands[ci])
+                a, b = (oh[c], oh[q]) if order == api.ORDER_CAND_FIRST else (oh[q], oh[c])
+                for col, (name, bit) in enumerate(fast):
+                    exp = oracle.raw_feature(1 << bit, a, b)
+                    if name in EXACT and name != "kulczynski2":
+                        assert got[ci][col] == exp, (name, q, c, order, kernel)
+                    else:
+                        assert got[ci][col] == pytest.approx(exp, rel=RTOL, abs=1e-13), (name, q, c, order, kernel)
+    for h in oh:
+        oracle.lib().orc_hist_free(h)
+
+
+@pytest.mark.parametrize("dtype,k,sparse", [(8, 9, True), (32, 9, False), (16, 8, True)])
+def test_get_close_and_filter_through_the_rank_pass(ctx, rank_pass_now, dtype, k, sparse):
+    """Trainer::get_close / filter with their length windows (cluster/Trainer.cpp:39-40): decisions, best candidate and its similarity equal
+    to the merge kernels'; a set that is written between two passes falls back until it has been asked for again."""
+    seqs = _sequences(8100 + k, 70, 1000, "di")
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n + 1, sparse_entries=sum(len(s) for s in seqs) * 2 + 5000) if sparse else api.HistogramSet(ctx, k, dtype, n + 1)
+    hs.build(seqs)
+    text = weights_text("weights_k9_u32.txt").replace("k: 9", "k: %d" % k).replace("uint32_t", "uint%d_t" % dtype)
+    feat = api.Feature.from_text(ctx, text, 0)
+    for cutoff in (0.9, 0.6):
+        tr = api.Trainer(ctx, feat, cutoff)
+        for q in (0, 1, 6, n - 3):
+            w = np.array([c for c in range(n) if c != q], dtype=np.uint32)
+            a = tr.get_close(hs, w, hs, q)
+            assert ctx.last_kernel_info()[0] == KERNEL
+            fa = tr.filter(hs, q, hs, w)
+            rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
+            b = tr.get_close(hs, w, hs, q)
+            assert ctx.last_kernel_info()[0] != KERNEL
+            fb = tr.filter(hs, q, hs, w)
+            rank_pass_now.delenv("MSC_NO_RANKS_1XM")
+            assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (q, cutoff)
+            assert np.array_equal(fa, fb)
+    # a write makes the lists stale: the next pass runs on the merge kernel (MSC_RANKS_1XM_AFTER=2: not yet asked for twice), the one
+    # after it on fresh rank lists -- same answers throughout
+    rank_pass_now.setenv("MSC_RANKS_1XM_AFTER", "2")
+    tr = api.Trainer(ctx, feat, 0.9)
+    w = np.arange(1, n + 1, dtype=np.uint32)
+    hs.clone_from(n, hs, 3)
+    first = tr.get_close(hs, w, hs, 0)
+    k1 = ctx.last_kernel_info()[0]
+    second = tr.get_close(hs, w, hs, 0)
+    k2 = ctx.last_kernel_info()[0]
+    assert k1 != KERNEL and k2 == KERNEL, (k1, k2)
+    assert np.array_equal(first[0], second[0]) and first[1:] == second[1:]
+    assert first[0][n - 1] == first[0][2]          # (slot n is a copy of slot 3 = window index 2)
