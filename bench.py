@@ -194,10 +194,10 @@ def cpu_baseline(args, synth, weights_text, weights_path):
     return out
 
 
-def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what):
+def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what, rank_bytes=None):
     """`passes` 1 x M passes of Trainer::get_close (cluster/Trainer.cpp:23-71: the loop the clustering runs) over a resident set; the
     streaming kernel timed by the library's HIP events on its stream, the leg by the wall clock -> one row of `secondary`"""
-    for j in range(2):
+    for j in range(3):          # (the third pass over an unchanged set builds its rank lists: untimed)
         trn.get_close(hs, None, hs, (j * 7919 + 1) % M, m=M)
     ctx.synchronize()
     ms, launches = [], []
@@ -211,6 +211,8 @@ def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what):
     kernel, _ = ctx.last_kernel_info()
     n_launch = max(int(np.sum(launches)), 1)
     avg = float(np.sum(ms)) / n_launch
+    if kernel.startswith("k_pair_ranks_1xm") and rank_bytes:          # the pass over rank lists reads 4 bytes per k-mer of a candidate
+        hist_bytes = rank_bytes
     alg = (M + 1) * hist_bytes * len(ms) // n_launch
     ach = alg / (avg * 1e-3) / 1e9
     return {"workload": what, "metric": "sequence-pairs/sec identity-scored, 1 x M get_close passes", "value": passes * M / dt, "unit": "pairs/s", "passes": passes,
@@ -223,7 +225,7 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
     """Four short legs behind the timed region, same process, same resident data where possible: the 1 x M pass the
     clustering loop runs -- over the dense 32-bit set, over the sparse layout of the same sequences (k = 9), and over sparse 64-bit lists
     of 8 000 x 20 kb sequences at k = 13 (BASELINE cfg4's shape). Algorithmic bytes per pass: SURVEY 8(d)'s 4^k sizeof(T) per candidate
-    for the dense set; 8 bytes per stored bin of the candidate's list for the sparse ones."""
+    for the dense set; 8 bytes per stored bin of the candidate's list for the merge kernels, 4 bytes per k-mer for k_pair_ranks_1xm."""
     rows = []
     feat = api.Feature.from_text(ctx, wtext, 0)
     trn = api.Trainer(ctx, feat, 0.9)
@@ -235,7 +237,8 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
     ctx.set_mirror_pass(True)
     trn.get_close(hs, None, hs, 1, m=M)          # (builds the mirror: untimed)
     ent0 = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
-    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, ent0, what + ", default: the lists of its sparse mirror"))
+    rank_bytes = 4 * (args.length - args.k + 1)
+    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, ent0, what + ", default: the lists of its sparse mirror (rank lists up to k = 9)", rank_bytes))
     # the same sequences on the sparse layout, rebuilt from the 2-bit rows kept for the exchange
     stride = seq_rows.shape[1] * 4
     sp = api.HistogramSet(ctx, args.k, args.dtype, M, sparse_entries=M * (args.length + 64 + (400 if args.repeats > 0 else 0)))
@@ -246,7 +249,7 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
         sp.build_packed(done, n, seq_rows[done:done + n].reshape(-1), n * stride, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
                         np.ascontiguousarray(one_rows[done:done + n, :4]).reshape(-1))
     ent = int(8 * np.mean([sp.entries(i) for i in range(0, M, max(1, M // 500))]))
-    rows.append(get_close_leg(api, ctx, trn, sp, M, 20, ent, "the same %d sequences on the sparse layout (sorted (bin, count) lists), k=%d" % (M, args.k)))
+    rows.append(get_close_leg(api, ctx, trn, sp, M, 20, ent, "the same %d sequences on the sparse layout (sorted (bin, count) lists; rank lists up to k = 9), k=%d" % (M, args.k), rank_bytes))
     del sp
     # BASELINE cfg4's shape: 20 kb sequences at k = 13, 64-bit counts, sparse lists (a dense 4^13 histogram would be 512 MiB)
     n4, len4, k4 = 8000, 20000, 13

@@ -135,12 +135,17 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 		fprintf(stderr, "[msc] 1 x M scoring calls: %llu (%llu candidates) | slot list %.3f s, launches %.3f s, stream wait %.3f s\n", (unsigned long long)ctx->prof_calls,
 		        (unsigned long long)ctx->prof_cands, ctx->prof_prep, ctx->prof_issue, ctx->prof_wait);
 		if (ctx->prof_nnz.p) {
-			uint64_t acc[2] = {0, 0};
-			if (hipMemcpy(acc, ctx->prof_nnz.p, sizeof acc, hipMemcpyDeviceToHost) == hipSuccess && acc[1])
-				fprintf(stderr, "[msc] list passes: %llu pairs scored inside their length windows, %.3f GB of candidate lists (8 bytes per stored bin) + %.3f GB of query lists"
+			// [0], [1]: stored bins and candidates of the merge passes; [2], [3]: of the passes over rank lists (4 bytes per k-mer; a stored bin
+			// is at least one k-mer, so 4 bytes per stored bin is a lower bound on what those read)
+			uint64_t acc[4] = {0, 0, 0, 0};
+			if (hipMemcpy(acc, ctx->prof_nnz.p, sizeof acc, hipMemcpyDeviceToHost) == hipSuccess && acc[1] + acc[3]) {
+				const double bytes = 8.0 * acc[0] + 4.0 * acc[2];
+				fprintf(stderr, "[msc] list passes: %llu pairs scored inside their length windows (%llu of them over rank lists), %.3f GB of candidate lists (8 bytes per stored bin"
+				        " in a merge pass, 4 per k-mer in a rank pass) + %.3f GB of query lists"
 				        " (once per pass); over the %.3f s of stream wait above: %.1f M pairs/s, %.1f GB/s of candidate lists = %.3f of the 8 TB/s HBM peak\n",
-				        (unsigned long long)acc[1], 8.0 * acc[0] / 1e9, 8.0 * ctx->prof_q_nnz / 1e9, ctx->prof_wait, acc[1] / ctx->prof_wait / 1e6,
-				        8.0 * acc[0] / ctx->prof_wait / 1e9, 8.0 * acc[0] / ctx->prof_wait / 8e12);
+				        (unsigned long long)(acc[1] + acc[3]), (unsigned long long)acc[3], bytes / 1e9, 8.0 * ctx->prof_q_nnz / 1e9, ctx->prof_wait, (acc[1] + acc[3]) / ctx->prof_wait / 1e6,
+				        bytes / ctx->prof_wait / 1e9, bytes / ctx->prof_wait / 8e12);
+			}
 		}
 	}
 	if (ctx->scratch_set) msc_hist_set_destroy(ctx->scratch_set);
@@ -1627,8 +1632,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const uint8_t* c_scal = cs->scalars + (d_slots ? 0 : off * cs->scalar_stride);
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		if (lists && g_profile_calls) {
-			if (!ctx->prof_nnz.p) { if ((r = ensure(ctx, ctx->prof_nnz, 16))) return r; HIP_TRY(ctx, hipMemsetAsync(ctx->prof_nnz.p, 0, 16, ctx->stream)); }
-			HIP_TRY(ctx, msc_launch_sparse_nnz_sum(ctx->stream, c_sp->hdr, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.use_window, rq.min_len, rq.max_len, (uint64_t*)ctx->prof_nnz.p));
+			if (!ctx->prof_nnz.p) { if ((r = ensure(ctx, ctx->prof_nnz, 32))) return r; HIP_TRY(ctx, hipMemsetAsync(ctx->prof_nnz.p, 0, 32, ctx->stream)); }
+			HIP_TRY(ctx, msc_launch_sparse_nnz_sum(ctx->stream, c_sp->hdr, cs->scalars, cs->scalar_stride, d_slots, off, mc, rq.use_window, rq.min_len, rq.max_len,
+			                                       (uint64_t*)ctx->prof_nnz.p + (rank_pass ? 2 : 0)));
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
 		if (lists && rank_pass) {
