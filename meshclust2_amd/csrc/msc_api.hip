@@ -166,6 +166,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->close_counts);
 	release(ctx->rk_bad);
 	release(ctx->prof_nnz);
+	if (ctx->rk_guard) (void)hipHostFree(ctx->rk_guard);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	release(ctx->segs);
@@ -1571,11 +1572,15 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// two bits per bin in LDS, the candidates' k-mers streamed at 4 bytes each. Same records as the merge kernels, bit for bit.
 	const bool no_rank_pass = getenv("MSC_NO_RANKS_1XM") != nullptr;          // (read on every call: tests compare both routes in one process)
 	bool rank_pass = false;
-	if (lists && !need_div && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && msc_ranks_pass_lds(L.nbins) != 0 && rq.qset->max_sum >= L.nbins &&
-	    rq.qset->max_sum - L.nbins <= msc_ranks_pass_query_cap()) {
+	const uint64_t q_kmers = rq.qset->max_sum >= L.nbins ? rq.qset->max_sum - L.nbins : ~0ull;          // bound on the k-mers of any histogram of the query's set
+	if (lists && !need_div && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
 		int e = MSC_OK;
 		rank_pass = rank_lists_ready(ctx, c_sp, &e);
 		if (e) return e;
+		if (rank_pass && !ctx->rk_guard) {
+			HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));
+			*ctx->rk_guard = 0;
+		}
 		if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
 	}
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
@@ -1639,7 +1644,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		if (lists && rank_pass) {
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
-			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus));
+			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard));
 		} else if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
@@ -1743,6 +1748,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 	}
 	if (rq.only_tiles) return MSC_OK;
+	if (rank_pass && *ctx->rk_guard) {
+		*ctx->rk_guard = 0;
+		return fail(ctx, MSC_ERR_HIP, "rank pass: the query's list is longer than its set's bound (max_sum not maintained by a writer of that set)");
+	}
 	if (rq.reduce_host && rq.reduce_host->first_error < first_err) first_err = rq.reduce_host->first_error;
 	if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
 	if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
@@ -2672,6 +2681,7 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	MscSlotScalars sc;
 	memset(&sc, 0, sizeof sc);
 	sc.sum = L.nbins + ex;          // sum of the rounded mean's bins
+	rs->max_sum = std::max<uint64_t>(rs->max_sum, sc.sum);
 	sc.mag = sc.sum;
 	sc.length = 1;
 	const uint64_t floor_sum = L.nbins + fl;
@@ -2856,7 +2866,7 @@ int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const u
 	std::vector<MscSlotScalars> sc(nc);
 	std::vector<uint64_t> floor_sum(nc), off((size_t)nc * n_chunks), cb((size_t)nc * n_chunks);
 	memset(sc.data(), 0, sizeof(MscSlotScalars) * nc);
-	uint64_t used = 0;
+	uint64_t used = 0, max_mean_sum = 0;
 	uint32_t max_nnz = 0;
 	for (uint32_t c = 0; c < nc; c++) {
 		MscSparseHdr h{};
@@ -2875,6 +2885,7 @@ int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const u
 		max_nnz = std::max(max_nnz, h.nnz);
 		hdr[c] = h;
 		sc[c].sum = L.nbins + ex;          // sum of the rounded mean's bins
+		max_mean_sum = std::max<uint64_t>(max_mean_sum, L.nbins + ex);
 		sc[c].mag = sc[c].sum;
 		sc[c].length = 1;
 		floor_sum[c] = L.nbins + fl;
@@ -2890,6 +2901,7 @@ int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const u
 	ms->ent_used = used;
 	ms->list_epoch++;
 	ms->max_nnz = std::max(ms->max_nnz, max_nnz);
+	ms->max_sum = std::max(ms->max_sum, max_mean_sum);          // (a rounded mean can hold more k-mers than any member: the bound travels with msc_hist_assign*)
 	for (uint32_t c = 0; c < nc; c++) ms->hdr_host[c] = hdr[c];
 	HIP_TRY(ctx, hipMemcpyAsync(ms->hdr, hdr.data(), nc * sizeof(MscSparseHdr), hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ms->scalars, sc.data(), nc * sizeof(MscSlotScalars), hipMemcpyHostToDevice, ctx->stream));

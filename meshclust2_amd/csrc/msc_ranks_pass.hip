@@ -8,7 +8,7 @@
 //     emd           = sum_t |a_t - b_t|                     the t-th k-mer of either histogram, both lists padded with 4^k (msc_emd_ranks.hip)
 //     sum e_c e_q   = sum over the candidate's entries of e_q(bin)
 //     sum min(e_c, e_q) = sum over the candidate's entries, the r-th copy of a bin (r = 0, 1, ..) counting [r < e_q(bin)]
-// e_q(bin) is a LOOKUP: the query's histogram sits in LDS as two bits per bin -- present (e_q >= 1) and large (e_q >= 2) -- shared by the
+// e_q(bin) is a LOOKUP: the query's histogram sits in LDS as two bits per bin -- present (e_q >= 1) and large (e_q >= 2), one word per 16 bins -- shared by the
 // sixteen waves of a workgroup for every candidate they walk. An entry whose bin is not large in the query (all but a handful: a 1 kb
 // sequence at k = 9 has ~2 large bins) contributes its present bit to the product and, if it is the first copy of its bin, to the minimum;
 // the rare entry that hits a large bin looks e_q up in the query's own rank list (LDS, binary search) and its copy number r in the
@@ -86,96 +86,151 @@ __device__ __forceinline__ uint32_t lower_bound_u32(Load v, uint32_t n, uint32_t
 	return lo;
 }
 
-// LDS: [bits: nbins / 32 + 1 pairs (present word, large word)][query ranks: padded to 256 with nbins]
+// LDS: [table: nbins / 16 + 1 words, two bits per bin (present, large)][query ranks: padded to 256 with nbins]
+//
+// A wave walks its candidates three deep: while candidate i is scored, the first KiB-entries of candidate i + 1 are on their way (its
+// list's place and length arrived an iteration earlier), the place and length of candidate i + 2 are being fetched (its slot arrived an
+// iteration earlier) and the slot of candidate i + 3 is read from the window's list. Without that every candidate cost its wave a chain of
+// three dependent round trips plus one per 256 entries -- 5 us per candidate, 0.16 ms per 100 000 however short the lists.
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
                                                               const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
                                                               uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
-                                                              uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials) {
+                                                              uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials, uint32_t q_cap,
+                                                              uint32_t* __restrict__ guard) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
-	const uint32_t words = nbins / 32 + 1;
-	uint2* sb = reinterpret_cast<uint2*>(s_rp);
-	uint32_t* rq = s_rp + 2 * words + ((2 * words) & 3 ? 4 - ((2 * words) & 3) : 0);          // 16-byte aligned
+	const uint32_t words = nbins / 16 + 1;
+	uint32_t* sb = s_rp;
+	uint32_t* rq = s_rp + ((words + 3u) & ~3u);          // 16-byte aligned
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
 	const uint2* Q = q_ent + qh.off;
 	const uint32_t* CQ = q_cum + qh.off;
-	const uint32_t nq_tot = nq ? CQ[nq - 1] : 0u;          // (<= kRpQCap: the host's bound on the set)
+	const uint32_t nq_tot = nq ? CQ[nq - 1] : 0u;          // (<= q_cap: the host's bound on the set, which sized the LDS)
+	if (nq_tot > q_cap) {          // the bound did not hold: say so (the host fails the call) and touch nothing
+		if (threadIdx.x == 0) atomicOr(guard, 1u);
+		return;
+	}
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
-	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = make_uint2(0u, 0u);
+	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = 0u;
 	for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += kRpBlock) rq[i] = nbins;
 	__syncthreads();
 	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
 		const uint2 en = Q[j];
 		const uint32_t e = en.y ? en.y - 1u : 0u, end = CQ[j];
-		if (e >= 1) atomicOr(&sb[en.x >> 5].x, 1u << (en.x & 31));
-		if (e >= 2) atomicOr(&sb[en.x >> 5].y, 1u << (en.x & 31));
+		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 2 ? 3u : 1u) << (2 * (en.x & 15)));
 		for (uint32_t t = end - e; t < end; t++) rq[t] = en.x;
 	}
 	__syncthreads();
-	const uint32_t total_waves = gridDim.x * (kRpBlock / 64);
-	for (uint32_t c = blockIdx.x * (kRpBlock / 64) + wave; c < m; c += total_waves) {
-		const uint64_t slot = cand_slots ? cand_slots[c] : first + c;
+	const uint32_t tw = gridDim.x * (kRpBlock / 64);
+	const uint32_t c0 = blockIdx.x * (kRpBlock / 64) + wave;
+	if (c0 >= m) return;
+	// stage 1: the slot of a candidate (identity without a slot list)
+	auto slot_of = [&](uint32_t c) -> uint64_t { return c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : ~0ull; };
+	// stage 2: where its rank list sits, how long it is, whether the length window keeps it (n = 0xffffffff: not scored)
+	struct Meta { uint64_t off; uint32_t n; };
+	auto meta_of = [&](uint32_t c, uint64_t slot) -> Meta {
+		Meta mt{0, 0xffffffffu};
+		if (c >= m) return mt;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
-		const uint32_t nc = c_n[slot], nc_pad = (nc + 3u) & ~3u;
-		const uint32_t* P = c_rk + c_off[slot];
-		const uint32_t T = nc > nq_tot ? nc : nq_tot;
-		uint64_t emd = 0;
-		uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
-		uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
-		for (uint32_t t0 = 0; t0 < T; t0 += 256) {
-			const uint32_t t = t0 + 4 * lane;
-			uint4 a = make_uint4(nbins, nbins, nbins, nbins), b = a;
-			if (t < nc_pad) a = *reinterpret_cast<const uint4*>(P + t);
-			if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
-			uint32_t d = sad_u32(a.x, b.x, 0u);
-			d = sad_u32(a.y, b.y, d);
-			d = sad_u32(a.z, b.z, d);
-			d = sad_u32(a.w, b.w, d);
-			emd += d;
-			uint32_t before = __shfl_up(a.w, 1, 64);
-			if (lane == 0) before = carry;
-			carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
-			const uint32_t av[4] = {a.x, a.y, a.z, a.w};
-			const uint32_t pv[4] = {before, a.x, a.y, a.z};
+		const uint64_t len = cs->length;
+		mt.off = c_off[slot];
+		mt.n = c_n[slot];
+		if (use_window && (len < min_len || len > max_len)) mt.n = 0xffffffffu;
+		return mt;
+	};
+	// stage 3: the first four chunks of 256 entries (16 bytes per lane each)
+	auto data_of = [&](const Meta& mt, uint4 (&d)[4]) {
+		const uint32_t n_pad = mt.n == 0xffffffffu ? 0u : (mt.n + 3u) & ~3u;
+		const uint32_t* P = c_rk + mt.off;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const uint32_t bin = av[j];
-				const uint2 w = sb[bin >> 5];          // (the padding value 4^k reads the zero pair behind the last word)
-				const uint32_t sh = bin & 31;
-				const uint32_t present = (w.x >> sh) & 1u, large = (w.y >> sh) & 1u;
-				prod += present;
-				mins += present & (bin != pv[j] ? 1u : 0u);
-				if (large) {          // rare: this k-mer is repeated in the query
-					const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
-					uint32_t e_q = 0;
-					while (lo + e_q < nq_tot && rq[lo + e_q] == bin) e_q++;
-					const uint32_t r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // this entry is the r-th copy of its bin
-					prod += e_q - 1;
-					if (r >= 1 && r < e_q) mins += 1;
+		for (uint32_t u = 0; u < 4; u++) {
+			const uint32_t t = 256 * u + 4 * lane;
+			d[u] = make_uint4(nbins, nbins, nbins, nbins);
+			if (t < n_pad) d[u] = *reinterpret_cast<const uint4*>(P + t);
+		}
+	};
+	uint64_t slot2 = slot_of(c0 + 2 * tw);
+	Meta meta1 = meta_of(c0 + tw, slot_of(c0 + tw));
+	Meta meta0 = meta_of(c0, slot_of(c0));
+	uint4 d0[4];
+	data_of(meta0, d0);
+	for (uint32_t c = c0; c < m; c += tw) {
+		const uint64_t slot3 = slot_of(c + 3 * tw);
+		const Meta meta2 = meta_of(c + 2 * tw, slot2);
+		uint4 d1[4];
+		data_of(meta1, d1);
+		if (meta0.n != 0xffffffffu) {
+			const uint32_t nc = meta0.n, nc_pad = (nc + 3u) & ~3u;
+			const uint32_t* P = c_rk + meta0.off;
+			const uint32_t T = nc > nq_tot ? nc : nq_tot;
+			uint64_t emd = 0;
+			uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
+			uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
+			auto chunk = [&](uint32_t t0, const uint4& a) {
+				const uint32_t t = t0 + 4 * lane;
+				uint4 b = make_uint4(nbins, nbins, nbins, nbins);
+				if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
+				uint32_t d = sad_u32(a.x, b.x, 0u);
+				d = sad_u32(a.y, b.y, d);
+				d = sad_u32(a.z, b.z, d);
+				d = sad_u32(a.w, b.w, d);
+				emd += d;
+				uint32_t before = __shfl_up(a.w, 1, 64);
+				if (lane == 0) before = carry;
+				carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
+				const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+				const uint32_t pv[4] = {before, a.x, a.y, a.z};
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const uint32_t bin = av[j];
+					const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;          // (the padding value 4^k reads the zero word behind the table)
+					const uint32_t present = two & 1u;
+					prod += present;
+					mins += present & (bin != pv[j] ? 1u : 0u);
+					if (two & 2u) {          // rare: this k-mer is repeated in the query
+						const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
+						uint32_t e_q = 0;
+						while (lo + e_q < nq_tot && rq[lo + e_q] == bin) e_q++;
+						const uint32_t r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // this entry is the r-th copy of its bin
+						prod += e_q - 1;
+						if (r >= 1 && r < e_q) mins += 1;
+					}
 				}
+			};
+#pragma unroll
+			for (uint32_t u = 0; u < 4; u++) if (256 * u < T) chunk(256 * u, d0[u]);          // the chunks that were fetched ahead
+			for (uint32_t t0 = 1024; t0 < T; t0 += 256) {                                      // longer lists: the rest as it comes
+				const uint32_t t = t0 + 4 * lane;
+				uint4 a = make_uint4(nbins, nbins, nbins, nbins);
+				if (t < nc_pad) a = *reinterpret_cast<const uint4*>(P + t);
+				chunk(t0, a);
+			}
+			const uint64_t emd_t = wave_sum_u64(emd);
+			const uint64_t prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
+			if (lane == 0) {
+				MscPartial out;
+				out.manh = (uint64_t)nc + nq_tot - 2 * mins_t;          // sum |e_c - e_q|
+				out.dot = prod_t + nc + nq_tot;                          // sum (c q - 1) over the union of stored bins (the epilogue adds 4^k)
+				out.emd = emd_t;
+				partials[c] = out;
 			}
 		}
-		const uint64_t emd_t = wave_sum_u64(emd);
-		const uint64_t prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
-		if (lane == 0) {
-			MscPartial out;
-			out.manh = (uint64_t)nc + nq_tot - 2 * mins_t;          // sum |e_c - e_q|
-			out.dot = prod_t + nc + nq_tot;                          // sum (c q - 1) over the union of stored bins (the epilogue adds 4^k)
-			out.emd = emd_t;
-			partials[c] = out;
-		}
+		meta0 = meta1;
+		meta1 = meta2;
+		slot2 = slot3;
+#pragma unroll
+		for (int u = 0; u < 4; u++) d0[u] = d1[u];
 	}
 }
 
 }  // namespace
 
-// bytes of dynamic LDS the pass needs for 4^k = nbins; 0 when the histogram is too large for it
-size_t msc_ranks_pass_lds(uint64_t nbins) {
-	if (nbins > (1ull << 18) || nbins % 32) return 0;
-	const size_t words = nbins / 32 + 1;
-	return (2 * words + 4) * 4 + (size_t)kRpQCap * 4;
+// bytes of dynamic LDS the pass needs for 4^k = nbins and query lists of up to q_kmers entries; 0 when the histogram is too large for it
+size_t msc_ranks_pass_lds(uint64_t nbins, uint64_t q_kmers) {
+	if (nbins > (1ull << 18) || nbins % 32 || q_kmers > kRpQCap) return 0;
+	const size_t words = nbins / 16 + 1;
+	return (words + 4) * 4 + (((size_t)q_kmers + 255) & ~(size_t)255) * 4;
 }
 uint32_t msc_ranks_pass_query_cap() { return kRpQCap; }
 
@@ -196,9 +251,9 @@ hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uin
 // candidates [first, first + m) (or the device slot list cand_slots; cand_scalars then is the set's base) against the query list
 hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                      const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus) {
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard) {
 	if (m == 0) return hipSuccess;
-	const size_t lds = msc_ranks_pass_lds(nbins);
+	const size_t lds = msc_ranks_pass_lds(nbins, q_kmers);
 	if (!lds) return hipErrorInvalidValue;
 	static bool attr_set = false;
 	if (!attr_set) {
@@ -206,11 +261,16 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	// one workgroup per CU (its tables take most of the CU's LDS); fewer when the window is short: a workgroup's set-up is ~2 us
+	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
+	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
-	uint32_t blocks = (m + per_wg - 1) / per_wg;
-	if (blocks > (uint32_t)num_cus) blocks = (uint32_t)num_cus;
+	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / lds);
+	// (MSC_RANKS_CPW=n: at least n candidates per wave, i.e. fewer workgroups for a short window. Measured on a window-bearing run,
+	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
+	static const uint32_t cpw = [] { const char* e = getenv("MSC_RANKS_CPW"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 1); }();
+	uint32_t blocks = (m + per_wg * cpw - 1) / (per_wg * cpw);
+	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
 	k_pair_ranks_1xm<<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
-	                                                            use_window, min_len, max_len, partials);
+	                                                            use_window, min_len, max_len, partials, (uint32_t)((q_kmers + 255) & ~255ull), guard);
 	return hipGetLastError();
 }
