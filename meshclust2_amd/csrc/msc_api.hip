@@ -1702,7 +1702,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		ea.singles_out = rq.singles_out ? (double*)ctx->singles.p : nullptr;
 		ea.combos_out = rq.combos_out ? (double*)ctx->combos.p : nullptr;
 		ea.pair_out = (MscPairOut*)ctx->pair_out.p;
-		HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
+		const bool need_po = rq.sum_out || rq.csum_out || rq.combo0_out || rq.status_out || (rq.flags_out && rq.reduce_mode < 0) || rq.reduce_mode < 0;
+		// a reduced pass that returns nothing per pair: epilogue, first reduce stage and the window's close pass in one kernel
+		const bool fused = rq.reduce_mode >= 0 && !need_po && !rq.raw_out && !rq.singles_out && !rq.combos_out && PS <= 4 && getenv("MSC_NO_FUSED_REDUCE") == nullptr;
+		if (fused) ea.pair_out = nullptr;
+		else HIP_TRY(ctx, msc_launch_epilogue(ctx->stream, ea));
 		if (rq.reduce_mode >= 0) {
 			// the reduce kernel writes its record and the close flags straight into page-locked host memory the device can address
 			// (no copy command behind the kernel): [reduce record (64 B)][close flags]
@@ -1712,15 +1716,19 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			uint8_t* down = nullptr;
 			HIP_TRY(ctx, hipHostGetDevicePointer((void**)&down, ctx->pin_down.p, 0));
 			if ((r = ensure(ctx, ctx->reduce_parts, msc_reduce_scratch_bytes())) != MSC_OK) return r;
-			HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin,
-			                               rq.dev_flags_out ? rq.dev_flags_out : rq.flags_out ? down + kRo : nullptr, (MscReduceOut*)down, ctx->reduce_parts.p));
-			if (rq.after_reduce) HIP_TRY(ctx, rq.after_reduce((const MscReduceOut*)down));
+			uint8_t* d_flags = rq.dev_flags_out ? rq.dev_flags_out : rq.flags_out ? down + kRo : nullptr;
+			if (fused) {
+				HIP_TRY(ctx, msc_launch_epilogue_reduce(ctx->stream, ea, rq.reduce_mode, rq.reduce_begin, d_flags, (MscReduceOut*)down, ctx->reduce_parts.p, rq.close_list));
+				if (rq.after_reduce && !rq.close_list.pos) HIP_TRY(ctx, rq.after_reduce((const MscReduceOut*)down));
+			} else {
+				HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin, d_flags, (MscReduceOut*)down, ctx->reduce_parts.p));
+				if (rq.after_reduce) HIP_TRY(ctx, rq.after_reduce((const MscReduceOut*)down));
+			}
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		if (rq.raw_out) HIP_TRY(ctx, hipMemcpyAsync(rq.raw_out + off * nf, ctx->raw.p, (size_t)mc * nf * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (rq.singles_out) HIP_TRY(ctx, hipMemcpyAsync(rq.singles_out + off * ns, ctx->singles.p, (size_t)mc * ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		if (rq.combos_out) HIP_TRY(ctx, hipMemcpyAsync(rq.combos_out + off * nc, ctx->combos.p, (size_t)mc * nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		const bool need_po = rq.sum_out || rq.csum_out || rq.combo0_out || rq.status_out || (rq.flags_out && rq.reduce_mode < 0) || rq.reduce_mode < 0;
 		if (need_po) {
 			po_host.resize(mc);
 			HIP_TRY(ctx, hipMemcpyAsync(po_host.data(), ctx->pair_out.p, (size_t)mc * sizeof(MscPairOut), hipMemcpyDeviceToHost, ctx->stream));

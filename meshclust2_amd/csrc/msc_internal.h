@@ -216,6 +216,16 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
                                 uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);
+// the window bookkeeping the fused epilogue + reduce kernels do for msc_get_close_window (msc_window.hip): pos[i] = position of candidate i,
+// alive[] = the window's flags, counter / out = the host-visible list of closed positions (out[0] = best position + 1, out[2 ..] = the list)
+struct MscCloseList {
+	const uint32_t* pos;
+	uint8_t* alive;
+	uint32_t* counter;
+	uint32_t* out;
+};
+hipError_t msc_launch_epilogue_reduce(hipStream_t st, const MscEpilogueArgs& a, int mode, int64_t begin, uint8_t* flags_out, MscReduceOut* out, void* parts_scratch,
+                                      const MscCloseList& cl);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);
 size_t msc_reduce_scratch_bytes();

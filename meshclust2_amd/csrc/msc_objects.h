@@ -219,6 +219,9 @@ struct ScoreRequest {
 	const uint32_t* dev_slots = nullptr;
 	uint8_t* dev_flags_out = nullptr;
 	std::function<hipError_t(const MscReduceOut* d_rec)> after_reduce;
+	// ... or, where the pass qualifies for the fused epilogue + reduce kernels, the window's close pass done inside them (pos != nullptr;
+	// after_reduce is then not called)
+	MscCloseList close_list{nullptr, nullptr, nullptr, nullptr};
 };
 
 int run_score(msc_ctx* ctx, ScoreRequest& rq);

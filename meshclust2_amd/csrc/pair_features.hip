@@ -898,7 +898,7 @@ __device__ __forceinline__ uint64_t shfl_sum_u64(uint64_t v) {
 // combos -> weighted sum -> logistic + bias -> close (predict/Feature.cpp:137-171, predict/Feature.h:205-239, cluster/Trainer.cpp:112-120).
 // c = the pair's index in the outputs; ci / qi = its candidate / query position (group and divergence records)
 __device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci, uint32_t qi, const Side& cand, const Side& qry, uint64_t min_len, uint64_t max_len,
-                              const PairTotals& t_in) {
+                              const PairTotals& t_in, MscPairOut* ret = nullptr) {
 	PairTotals t = t_in;
 	const Side& first = a.order == MSC_ORDER_CAND_FIRST ? cand : qry;
 	const Side& second = a.order == MSC_ORDER_CAND_FIRST ? qry : cand;
@@ -942,6 +942,7 @@ __device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci,
 		if (a.sum_soa) a.sum_soa[c] = NAN;
 		if (a.csum_soa) a.csum_soa[c] = NAN;
 		if (a.close_soa) a.close_soa[c] = 0;
+		if (ret) *ret = po;
 		return;
 	}
 	int err = 0;
@@ -989,9 +990,10 @@ __device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci,
 	if (a.csum_soa) a.csum_soa[c] = po.csum;
 	if (a.close_soa) a.close_soa[c] = (uint8_t)(err == 0 && po.close);
 	if (err < 0 && a.error_word) atomicMin(a.error_word, err);
+	if (ret) *ret = po;
 }
 
-__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t) {
+__device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t, MscPairOut* ret = nullptr) {
 	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
 	uint32_t ci = c, qi = 0;
 	if (a.n_queries > 1) { qi = c / a.m_per_query; ci = c % a.m_per_query; }
@@ -1009,7 +1011,7 @@ __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTot
 	}
 	const Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq};
 	const Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
-	epilogue_eval(a, c, ci, qi, cand, qry, min_len, max_len, t);
+	epilogue_eval(a, c, ci, qi, cand, qry, min_len, max_len, t, ret);
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_wave(const MscEpilogueArgs a) {
@@ -1300,6 +1302,100 @@ __global__ void __launch_bounds__(256) k_pair_reduce_fold(const ReducePart* __re
 		r.n_close = s_nclose;
 		r.first_error = s_err;
 		*out = r;
+	}
+}
+
+// Epilogue + first reduce stage (+ the window's close pass) in ONE kernel, for the step-serial loop: a get_close pass over a window is a
+// chain of small kernels the host waits for once per step (profiles/r04_notes.md 5), and k_pair_epilogue_thread -> k_pair_reduce_part ->
+// k_window_close were three of them that all make one pass over the same m pairs. A thread evaluates its pair (epilogue_one), keeps the
+// record in registers, folds it into its workgroup's part and -- cl.pos != nullptr: the window's bookkeeping, msc_window.hip -- takes
+// a close candidate's position off the alive list and appends it to the host's list. k_pair_reduce_fold2 folds the parts and turns the
+// best candidate's index into a position.
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_reduce_part(const MscEpilogueArgs a, int mode, int64_t begin, uint8_t* __restrict__ flags_out,
+                                                                      ReducePart* __restrict__ parts, const MscCloseList cl) {
+	__shared__ Best s_best[kBlock];
+	__shared__ unsigned long long s_nclose;
+	__shared__ int s_err;
+	if (threadIdx.x == 0) { s_nclose = 0; s_err = 0; }
+	__syncthreads();
+	Best b{mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0, -1};
+	unsigned long long nclose = 0;
+	int err = 0;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < a.m; c += gridDim.x * blockDim.x) {
+		PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+		for (uint32_t s = 0; s < a.S; s++) {
+			const MscPartial p = a.partials[(uint64_t)c * a.S + s];
+			t.manh += p.manh; t.dot += p.dot; t.emd += p.emd;
+			if (a.div_partials) {
+				const MscPartialDiv d = reinterpret_cast<const MscPartialDiv*>(a.div_partials)[(uint64_t)c * a.S + s];
+				t.jd += d.jd; t.js += d.js;
+			}
+		}
+		MscPairOut p;
+		epilogue_one(a, c, t, &p);
+		const bool scored = p.status == 0;
+		if (p.status < 0 && p.status < err) err = p.status;
+		const bool close = scored && p.close;
+		if (flags_out) flags_out[c] = close ? 1 : 0;
+		if (close && cl.pos) {
+			const uint32_t at = cl.pos[c];
+			cl.alive[at] = 0;
+			cl.out[2 + atomicAdd(cl.counter, 1u)] = at;
+		}
+		if (!scored) continue;
+		nclose += p.close ? 1 : 0;
+		if (mode == MSC_REDUCE_GET_CLOSE) {
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)c}, mode);
+		} else {
+			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)c}, mode);
+		}
+	}
+	s_best[threadIdx.x] = b;
+	if (nclose) atomicAdd(&s_nclose, nclose);
+	if (err) atomicMin(&s_err, err);
+	__syncthreads();
+	for (int stride = kBlock / 2; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) s_best[threadIdx.x] = better(s_best[threadIdx.x], s_best[threadIdx.x + stride], mode);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		ReducePart r;
+		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err; r.pad_ = 0;
+		parts[blockIdx.x] = r;
+	}
+}
+__global__ void __launch_bounds__(256) k_pair_reduce_fold2(const ReducePart* __restrict__ parts, uint32_t n_parts, int mode, MscReduceOut* __restrict__ out, const MscCloseList cl) {
+	__shared__ Best s_best[256];
+	__shared__ unsigned long long s_nclose;
+	__shared__ int s_err;
+	if (threadIdx.x == 0) { s_nclose = 0; s_err = 0; }
+	__syncthreads();
+	Best b{mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0, -1};
+	unsigned long long nclose = 0;
+	int err = 0;
+	for (uint32_t i = threadIdx.x; i < n_parts; i += 256) {
+		const ReducePart p = parts[i];
+		b = better(b, Best{p.sim, p.pos}, mode);
+		nclose += p.nclose;
+		if (p.err < err) err = p.err;
+	}
+	if (nclose) atomicAdd(&s_nclose, nclose);
+	if (err) atomicMin(&s_err, err);
+	s_best[threadIdx.x] = b;
+	__syncthreads();
+	for (int stride = 128; stride >= 1; stride >>= 1) {
+		if ((int)threadIdx.x < stride) s_best[threadIdx.x] = better(s_best[threadIdx.x], s_best[threadIdx.x + stride], mode);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		MscReduceOut r;
+		r.best_sim = s_best[0].pos >= 0 ? s_best[0].sim : (mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 2.2250738585072014e-308);
+		r.best_pos = s_best[0].pos >= 0 ? s_best[0].pos : (mode == MSC_REDUCE_GET_CLOSE ? -1 : 0);
+		r.any_close = s_nclose > 0;
+		r.n_close = s_nclose;
+		r.first_error = s_err;
+		*out = r;
+		if (cl.pos) cl.out[0] = s_best[0].pos >= 0 ? cl.pos[s_best[0].pos] + 1 : 0;          // (k_window_close's first line)
 	}
 }
 
@@ -1849,8 +1945,21 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	return hipGetLastError();
 }
 
-// parts_scratch (optional, msc_reduce_scratch_bytes()): long windows are folded by up to 256 workgroups first
-size_t msc_reduce_scratch_bytes() { return 256 * sizeof(ReducePart); }
+// epilogue + reduction (+ the window's close pass) of a 1 x M pass whose records are MscPartial (a.S of them per pair, <= 4) in two
+// launches; parts_scratch: msc_reduce_scratch_bytes()
+hipError_t msc_launch_epilogue_reduce(hipStream_t st, const MscEpilogueArgs& a, int mode, int64_t begin, uint8_t* flags_out, MscReduceOut* out, void* parts_scratch,
+                                      const MscCloseList& cl) {
+	if (a.m == 0 || a.S > 4 || a.partials16 || a.partials_cq || a.kb_min || !parts_scratch) return hipErrorInvalidValue;
+	const uint32_t n_parts = std::min<uint32_t>(1024, (a.m + kBlock - 1) / kBlock);
+	k_pair_epilogue_reduce_part<<<dim3(n_parts), dim3(kBlock), 0, st>>>(a, mode, begin, flags_out, (ReducePart*)parts_scratch, cl);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return e;
+	k_pair_reduce_fold2<<<dim3(1), dim3(256), 0, st>>>((const ReducePart*)parts_scratch, n_parts, mode, out, cl);
+	return hipGetLastError();
+}
+
+// parts_scratch (optional, msc_reduce_scratch_bytes()): long windows are folded by up to 256 workgroups first (1 024 in the fused form)
+size_t msc_reduce_scratch_bytes() { return 1024 * sizeof(ReducePart); }
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin, uint8_t* flags_out,
                              MscReduceOut* out, void* parts_scratch) {
 	if (parts_scratch && m > 8192) {
