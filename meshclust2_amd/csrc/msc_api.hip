@@ -2132,9 +2132,25 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, cand_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 		}
 		const uint32_t* d_slots = cand_slots ? (const uint32_t*)ctx->slots.p : nullptr;
+		// up to k = 9: the passes over the candidates' rank lists (msc_ranks_pass.hip), as in run_score
+		const uint64_t q_kmers = qset->max_sum >= L.nbins ? qset->max_sum - L.nbins : ~0ull;
+		bool rank_pass = false;
+		if (getenv("MSC_NO_RANKS_1XM") == nullptr && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
+			int e = MSC_OK;
+			rank_pass = rank_lists_ready(ctx, cands, &e);
+			if (e) return e;
+			if (rank_pass && !ctx->rk_guard) {
+				HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));
+				*ctx->rk_guard = 0;
+			}
+			if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
+		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
-		for (uint64_t q = 0; q < n_q; q++)
+		for (uint64_t q = 0; q < n_q && rank_pass; q++)
+			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, cands->rkl, cands->rkl_off, cands->rkl_n, cands->scalars, cands->scalar_stride, d_slots, 0, (uint32_t)m, qset->ent, qset->cum,
+			                                       qset->hdr + q_slots[q], L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->partials.p + q * m, ctx->num_cus, q_kmers, ctx->rk_guard));
+		for (uint64_t q = 0; q < n_q && !rank_pass; q++)
 			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
 			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,
 			                                       (MscPartial*)ctx->partials.p + q * m, nullptr, nullptr, order, ctx->num_cus,
@@ -2178,6 +2194,10 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;
 		if (ctx->timing && hipEventElapsedTime(&t, ctx->ev_tiles0, ctx->ev_tiles1) == hipSuccess) { ctx->tiles_ms_accum = t; ctx->tiles_launches = (int)n_q; ctx->have_timing = true; }
+		if (rank_pass && *ctx->rk_guard) {
+			*ctx->rk_guard = 0;
+			return fail(ctx, MSC_ERR_HIP, "rank pass: a query's list is longer than its set's bound (max_sum not maintained by a writer of that set)");
+		}
 		if (first_err == MSC_ERR_ZERO_LENGTH) return fail(ctx, first_err, "length_difference: a point has length 0 (the reference throws 123, predict/Feature.cpp:878-886)");
 		if (first_err == MSC_ERR_NAN) return fail(ctx, first_err, "normalisation produced NaN (the reference throws, predict/Feature.cpp:143-146)");
 		if (first_err < 0) return fail(ctx, first_err, "feature evaluation failed with status %d", first_err);

@@ -31,9 +31,10 @@ struct msc_window {
 	// positions msc_window_kill took out of the tree but not yet out of d_alive: most steps of an accumulate loop score nothing (empty
 	// windows), so the device flags are brought up to date in ONE launch before the next range is compacted (a memset per kill was
 	// 200 000 launches = 0.76 s of device time and most of "mark + take" in a 200 000-sequence run)
-	std::vector<uint32_t> pending, in_flight;
-	uint32_t* d_kill = nullptr;
+	std::vector<uint32_t> pending;
+	uint32_t* d_kill = nullptr;       // page-locked host memory the kill kernel reads
 	uint64_t d_kill_cap = 0;
+	hipEvent_t ev_kill = nullptr;     // behind the last kill kernel: the list is rewritten only once that kernel is through
 };
 
 namespace {
@@ -134,7 +135,8 @@ extern "C" void msc_window_destroy(msc_window* w) {
 	if (w->ctx) (void)hipSetDevice(w->ctx->device);
 	(void)hipFree(w->d_order); (void)hipFree(w->d_alive); (void)hipFree(w->d_slots); (void)hipFree(w->d_pos); (void)hipFree(w->d_counts); (void)hipFree(w->d_flags);
 	if (w->h_close) (void)hipHostFree(w->h_close);
-	if (w->d_kill) (void)hipFree(w->d_kill);
+	if (w->d_kill) (void)hipHostFree(w->d_kill);
+	if (w->ev_kill) (void)hipEventDestroy(w->ev_kill);
 	delete w;
 }
 
@@ -198,18 +200,23 @@ extern "C" int msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* posi
 static int flush_kills(msc_ctx* ctx, msc_window* w) {
 	if (w->pending.empty()) return MSC_OK;
 	const uint64_t n = w->pending.size();
+	// the list sits in page-locked memory the kernel reads directly (a pageable hipMemcpyAsync of a handful of words was a copy command
+	// and a staging stall per step); it stays untouched until the next flush, which comes after the stream was waited for by a scoring call
 	if (w->d_kill_cap < n) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (w->d_kill) (void)hipFree(w->d_kill);
+		if (w->d_kill) (void)hipHostFree(w->d_kill);
 		w->d_kill = nullptr;
 		w->d_kill_cap = std::max<uint64_t>(2 * n, 4096);
-		HIP_TRY(ctx, hipMalloc((void**)&w->d_kill, w->d_kill_cap * 4));
+		HIP_TRY(ctx, hipHostMalloc((void**)&w->d_kill, w->d_kill_cap * 4, hipHostMallocDefault));
 	}
-	// (the list stays untouched in in_flight until the next flush, which comes after the stream was waited for by a scoring call)
-	w->in_flight.swap(w->pending);
+	if (!w->ev_kill) HIP_TRY(ctx, hipEventCreateWithFlags(&w->ev_kill, hipEventDisableTiming));
+	else HIP_TRY(ctx, hipEventSynchronize(w->ev_kill));          // (already complete whenever a scoring call waited for the stream in between)
+	memcpy(w->d_kill, w->pending.data(), n * 4);
 	w->pending.clear();
-	HIP_TRY(ctx, hipMemcpyAsync(w->d_kill, w->in_flight.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-	k_window_kill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_alive, w->d_kill, (uint32_t)n);
+	uint32_t* d_list = nullptr;
+	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_list, w->d_kill, 0));
+	k_window_kill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_alive, d_list, (uint32_t)n);
+	HIP_TRY(ctx, hipEventRecord(w->ev_kill, ctx->stream));
 	HIP_TRY(ctx, hipGetLastError());
 	return MSC_OK;
 }

@@ -117,6 +117,17 @@ def test_get_close_and_filter_through_the_rank_pass(ctx, rank_pass_now, dtype, k
             rank_pass_now.delenv("MSC_NO_RANKS_1XM")
             assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (q, cutoff)
             assert np.array_equal(fa, fb)
+    if sparse:          # the Q x M shape on sparse sets: one rank pass per query, queued back to back (msc_score_multi)
+        cands = np.arange(n, dtype=np.uint32)[::-1].copy()
+        qs = np.array([0, 1, 6, n - 3, n - 1], dtype=np.uint32)
+        a = api.score_multi(ctx, feat, hs, cands, hs, qs, want=("sum", "csum", "close", "counts"))
+        assert ctx.last_kernel_info()[0] == KERNEL
+        rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
+        b = api.score_multi(ctx, feat, hs, cands, hs, qs, want=("sum", "csum", "close", "counts"))
+        assert ctx.last_kernel_info()[0] != KERNEL
+        rank_pass_now.delenv("MSC_NO_RANKS_1XM")
+        for key in ("sum", "csum", "close", "counts"):
+            assert np.array_equal(a[key], b[key]), key
     # a write makes the lists stale: the next pass runs on the merge kernel (MSC_RANKS_1XM_AFTER=2: not yet asked for twice), the one
     # after it on fresh rank lists -- same answers throughout
     rank_pass_now.setenv("MSC_RANKS_1XM_AFTER", "2")
