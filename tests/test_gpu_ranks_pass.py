@@ -141,3 +141,43 @@ def test_get_close_and_filter_through_the_rank_pass(ctx, rank_pass_now, dtype, k
     assert k1 != KERNEL and k2 == KERNEL, (k1, k2)
     assert np.array_equal(first[0], second[0]) and first[1:] == second[1:]
     assert first[0][n - 1] == first[0][2]          # (slot n is a copy of slot 3 = window index 2)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6, 7, 8, 9, 10])
+def test_rank_pass_randomised(ctx, rank_pass_now, seed):
+    """Seeded random sets (k, bin type, layout, lengths, repeat units, slot lists with repeats and gaps, cut-offs): get_close decisions and
+    the model's sums through the rank pass equal to the merge kernels' -- bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([8, 9, 9]))
+    dtype = int(rng.choice([8, 16, 32]))
+    sparse = bool(rng.integers(0, 2)) or dtype == 8 and k == 8          # (a dense 8-bit set at k = 8 is 64 KiB: the smallest with a list form)
+    length = int(rng.choice([300, 1000, 2200]))
+    n = int(rng.integers(30, 90))
+    seqs, _ = synth.families(5000 + seed, n, length, family=int(rng.integers(2, 9)), length_jitter=length // int(rng.choice([5, 10, 40])))
+    seqs = [bytes(s) for s in seqs]
+    units = [b"A", b"AC", b"ACG", b"ACGTTGCAAGTC", b"GGGGGGGGGT"]
+    for i in rng.choice(n, size=n // 4, replace=False):
+        u = units[int(rng.integers(0, len(units)))]
+        run = u * int(rng.integers(2, 60))
+        run = run[: max(k, min(len(run), 250 if dtype == 8 else 600))]
+        at = int(rng.integers(0, len(seqs[i])))
+        seqs[i] = seqs[i][:at] + run + seqs[i][at:]
+    hs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=sum(len(s) for s in seqs) * 2 + 1000) if sparse else api.HistogramSet(ctx, k, dtype, n)
+    hs.build(seqs)
+    text = weights_text("weights_k9_u32.txt").replace("k: 9", "k: %d" % k).replace("uint32_t", "uint%d_t" % dtype)
+    feat = api.Feature.from_text(ctx, text, 0)
+    for trial in range(6):
+        q = int(rng.integers(0, n))
+        w = rng.integers(0, n, int(rng.integers(1, 2 * n))).astype(np.uint32)
+        tr = api.Trainer(ctx, feat, float(rng.choice([0.95, 0.9, 0.7, 0.5])))
+        a = tr.get_close(hs, w, hs, q)
+        ka = ctx.last_kernel_info()[0]
+        sa = feat.compute(hs, w, hs, q)
+        rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
+        b = tr.get_close(hs, w, hs, q)
+        kb = ctx.last_kernel_info()[0]
+        sb = feat.compute(hs, w, hs, q)
+        rank_pass_now.delenv("MSC_NO_RANKS_1XM")
+        assert ka == KERNEL and kb != KERNEL, (ka, kb, k, dtype, sparse)
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (seed, trial, k, dtype, sparse)
+        assert np.array_equal(sa["sum"], sb["sum"]) and np.array_equal(sa["csum"], sb["csum"]), (seed, trial)
