@@ -2499,17 +2499,23 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all1, ctx->stream));
 		// query-major [n_q][mc] on the device -> [n_q][m] at column `off` on the host
 		const size_t rows = (size_t)n_q;
-		if (sum_out) HIP_TRY(ctx, hipMemcpy2DAsync(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
-		if (csum_out) HIP_TRY(ctx, hipMemcpy2DAsync(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), (size_t)mc * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
+		// (one chunk: the rows are contiguous on both sides -- a plain copy. A 2-D copy whose width is not a multiple of four bytes goes row
+		// by row inside the runtime: 1 024 rows of 6 250 flags took 9 ms of a 1.7 ms step)
+		auto rows_home = [&](void* dst, size_t dpitch, const void* src, size_t width, hipStream_t st) -> hipError_t {
+			if (dpitch == width) return hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToHost, st);
+			return hipMemcpy2DAsync(dst, dpitch, src, width, width, rows, hipMemcpyDeviceToHost, st);
+		};
+		if (sum_out) HIP_TRY(ctx, rows_home(sum_out + off, m * sizeof(double), ctx->soa_sum.p, (size_t)mc * sizeof(double), tail));
+		if (csum_out) HIP_TRY(ctx, rows_home(csum_out + off, m * sizeof(double), ctx->soa_csum.p, (size_t)mc * sizeof(double), tail));
 		if (close_out && manh_gemm) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_scored[pp], tail));
 			HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_scored[pp], 0));
-			HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, ctx->copy_stream));
+			HIP_TRY(ctx, rows_home(close_out + off, m, d_close, (size_t)mc, ctx->copy_stream));
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_copied[pp], ctx->copy_stream));
 			ctx->close_pp_busy[pp] = true;
 			ctx->copy_pending = true;
-		} else if (close_out) HIP_TRY(ctx, hipMemcpy2DAsync(close_out + off, m, d_close, (size_t)mc, (size_t)mc, rows, hipMemcpyDeviceToHost, tail));
-		if (raw_out) HIP_TRY(ctx, hipMemcpy2DAsync(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), (size_t)mc * nf * sizeof(double), rows, hipMemcpyDeviceToHost, tail));
+		} else if (close_out) HIP_TRY(ctx, rows_home(close_out + off, m, d_close, (size_t)mc, tail));
+		if (raw_out) HIP_TRY(ctx, rows_home(raw_out + off * nf, m * nf * sizeof(double), ctx->raw.p, (size_t)mc * nf * sizeof(double), tail));
 		if (deferred) { ctx->tiles_launches++; continue; }
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t = 0;

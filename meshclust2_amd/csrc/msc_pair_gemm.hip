@@ -455,11 +455,18 @@ static bool pair_gemm_wide(uint32_t qn, uint32_t m) {
 }
 
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus) {
-	// enough workgroups for a few rounds of the chip (16 waves per CU); a slice is an even number of 128-bin steps
+	// As few slices as give every CU about three workgroups (12 waves of its 16): the first rule here asked for six ROUNDS of the chip
+	// (24 workgroups per CU) and paid for them twice -- every slice is another int32 per pair written by the product and read and added
+	// by the epilogue, and a workgroup's set-up is spread over fewer steps. Measured (G pairs/s, cfg2's sequences, FP4 form):
+	//   100 000 candidates (782 workgroups per slice): 1 / 2 / 4 / 8 slices -> 5.10 / 5.08 / 4.97 / 4.76
+	//    50 000: 2 / 4 -> 4.88 / 4.77        25 000: 2 / 4 / 8 -> 3.55 / 4.32 / 4.16        12 500: 4 / 8 / 16 / 32 / 64 -> 3.29 / 3.72 / 3.62 / 3.12 / 2.40
+	// -- the best is always the count that brings the grid to ~780 workgroups. A slice is an even number of 128-bin steps.
+	// MSC_GEMM_MAX_SLICES / MSC_GEMM_SLICES bound the count from above / below for A/B runs.
 	const uint32_t per_wg = pair_gemm_wide(qn, m) ? 256 : 128;
 	uint32_t s = 1;
-	auto can_split = [&] { return s < 64 && nbins / (2 * s) >= 2 * kStep && nbins % (2 * s * 2 * kStep) == 0; };
-	while (can_split() && (uint64_t)((m + per_wg - 1) / per_wg) * s < (uint64_t)num_cus * (per_wg == 256 ? 12 : 24)) s *= 2;
+	static const uint32_t s_max = [] { const char* e = getenv("MSC_GEMM_MAX_SLICES"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 64); }();
+	auto can_split = [&] { return s < s_max && nbins / (2 * s) >= 2 * kStep && nbins % (2 * s * 2 * kStep) == 0; };
+	while (can_split() && (uint64_t)((m + per_wg - 1) / per_wg) * s < (uint64_t)num_cus * (per_wg == 256 ? 2 : 3)) s *= 2;
 	static const uint32_t s_min = [] { const char* e = getenv("MSC_GEMM_SLICES"); return (uint32_t)(e ? std::max(1, atoi(e)) : 1); }();
 	while (can_split() && s < s_min) s *= 2;
 	return s;
