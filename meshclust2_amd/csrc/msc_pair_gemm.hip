@@ -416,12 +416,129 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(con
 	}
 }
 
+// The same product with the WORK, not the output, dealt out ("stream-K"): the pass is tiles x super-steps units of work (a tile = the
+// workgroup's 128 candidates, a unit = one 256-bin super-step of it); workgroup w of G takes units [w L, (w + 1) L), L = ceil(units / G),
+// i.e. the tail of one tile's bins, whole tiles, the head of another -- every workgroup the same amount whatever the number of candidates,
+// and G = what the chip holds at once (4 per CU). A workgroup adds each piece into ONE zeroed int32 array [candidate][QN] with atomics
+// (an element gets one or two adds), so there are no slices for the epilogue to add up. With slices the grid was tiles x slices
+// workgroups: 782 at 100 000 candidates and one slice (three quarters of the chip's 1 024 places), and a small shard needed 8 - 64 slices
+// to fill the chip at all.
+template <int NRB, int NW>
+__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4_sk(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                                 const uint8_t* __restrict__ abits, uint64_t nbins, uint32_t per_wg, const uint32_t* __restrict__ hot_ptr,
+                                                                 const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
+	constexpr int QN = 32 * NRB;
+	constexpr int NT = 64 * NW;
+	constexpr int SPT = QN * 8 / NT;
+	constexpr int TPR = 8 / SPT;
+	static_assert(SPT >= 1 && SPT <= 8 && TPR * SPT == 8, "tile staging");
+	__shared__ v4i sA[2][QN * 8];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t n_ss = (uint32_t)(nbins / 256);
+	const uint32_t tiles = (m + 32 * NW - 1) / (32 * NW);
+	const uint64_t total = (uint64_t)tiles * n_ss;
+	uint64_t pos = (uint64_t)blockIdx.x * per_wg;
+	const uint64_t pos_end = pos + per_wg < total ? pos + per_wg : total;
+	const uint32_t u = tid / TPR, part = tid % TPR;
+	const uint32_t srow = (u & ~15u) | (2 * (u & 7) + ((u >> 3) & 1));
+	const uint8_t* asrc = abits + ((uint64_t)srow * 8 + part * SPT) * 4;
+	uint32_t a_reg[SPT];
+	auto fetch_a = [&](uint32_t ss) {
+		const uint8_t* p = asrc + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * (QN * 32);
+		if constexpr (SPT == 8) {
+			const v4i v = *reinterpret_cast<const v4i*>(p), w = *reinterpret_cast<const v4i*>(p + 16);
+			a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; a_reg[4] = w.x; a_reg[5] = w.y; a_reg[6] = w.z; a_reg[7] = w.w;
+		} else if constexpr (SPT == 4) { const v4i v = *reinterpret_cast<const v4i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; a_reg[2] = v.z; a_reg[3] = v.w; }
+		else if constexpr (SPT == 2) { const v2i v = *reinterpret_cast<const v2i*>(p); a_reg[0] = v.x; a_reg[1] = v.y; }
+		else a_reg[0] = *reinterpret_cast<const uint32_t*>(p);
+	};
+	auto park = [&](uint32_t buf) {
+#pragma unroll
+		for (int t = 0; t < SPT; t++) {
+			const uint32_t sg = part * SPT + t, w = a_reg[t];
+			sA[buf][srow * 8 + (sg ^ ((srow >> 1) & 7))] = v4i{(int)((w << 2) & kM4), (int)(w & kM2), (int)((w >> 2) & kM1), (int)((w >> 1) & kM4)};
+		}
+	};
+	while (pos < pos_end) {
+		const uint32_t tile = (uint32_t)(pos / n_ss), ss0 = (uint32_t)(pos % n_ss);
+		const uint32_t ss1 = (uint32_t)((uint64_t)(n_ss - ss0) < pos_end - pos ? n_ss : ss0 + (pos_end - pos));          // this piece: super-steps [ss0, ss1) of the tile
+		const uint32_t ci = (tile * NW + wave) * 32 + (lane & 31);
+		const bool valid = ci < m;
+		const uint32_t cc = valid ? ci : m - 1;
+		const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+		const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16;
+		auto fetch_b = [&](uint32_t ss) { return *reinterpret_cast<const v4i*>(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024); };
+		v16f acc[NRB];
+#pragma unroll
+		for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+			for (int i = 0; i < 16; i++) acc[rb][i] = 0.f;
+		v4i bcur = fetch_b(ss0);
+		fetch_a(ss0);
+		__syncthreads();          // (the previous piece's last reads of sA are through)
+		park(0);
+		__syncthreads();
+		for (uint32_t ss = ss0; ss < ss1; ss++) {
+			const uint32_t buf = (ss - ss0) & 1;
+			const v4i bnext = fetch_b(ss + 1);
+			fetch_a(ss + 1);
+			{
+				const uint32_t r = lane & 31, sw = (r >> 1) & 7, hh = lane >> 5;
+#pragma unroll
+				for (int t = 0; t < 4; t++) {
+					const uint32_t w = (uint32_t)bcur[t];
+					const v8i B = {(int)(w & kM1), (int)(w & kM2), (int)(w & kM4), (int)((w >> 3) & kM1), 0, 0, 0, 0};
+#pragma unroll
+					for (int rb = 0; rb < NRB; rb++) {
+						const v4i a = sA[buf][(32 * rb + r) * 8 + ((2 * t + hh) ^ sw)];
+						const v8i A = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+						acc[rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[rb], 4, 4, 0, 0, 0, 0);
+					}
+				}
+			}
+			if (hot_ptr) {          // P2 (see k_pair_gemm_fp4): the hot entries of both 128-bin steps of this super-step
+				const uint32_t h0 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * ss]), h1 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * ss + 2]);
+				for (uint32_t e = h0; e < h1; e++) {
+					const uint2 en = hot[e];
+					const uint32_t bin = __builtin_amdgcn_readfirstlane(en.x), rg = __builtin_amdgcn_readfirstlane(en.y);
+					const uint32_t j = (bin >> 5) & 7, wsel = j >> 1;
+					const uint32_t w = (uint32_t)(wsel == 0 ? bcur.x : wsel == 1 ? bcur.y : wsel == 2 ? bcur.z : bcur.w);
+					const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
+					if (valid && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
+				}
+			}
+			park(buf ^ 1);
+			__syncthreads();
+			bcur = bnext;
+		}
+		if (valid) {
+			int32_t* o = out_min + (uint64_t)ci * QN + 4 * (lane >> 5);
+#pragma unroll
+			for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+				for (int i = 0; i < 16; i++) {
+					const int v = (int)acc[rb][i];
+					if (v) atomicAdd(o + 32 * rb + 8 * (i >> 2) + (i & 3), v);          // (most pairs of unrelated sequences share no k-mer in a piece)
+				}
+		}
+		pos += ss1 - ss0;
+	}
+}
+
 }  // namespace
 
 // MSC_GEMM_I8 keeps the int8 form (k_pair_gemm_bits) for A/B runs; the FP4 form is the default
 static bool pair_gemm_fp4() {
 	static const bool i8 = getenv("MSC_GEMM_I8") != nullptr;
 	return !i8;
+}
+// MSC_GEMM_STREAMK: the work-dealing grid (k_pair_gemm_fp4_sk) instead of the sliced one. Measured SLOWER and therefore off: 4.85 against
+// 5.11 G pairs/s at 100 000 candidates (the product alone 1.38 against 1.49 ms, but a grid that fills every place of the chip leaves the
+// tail stream's kernels nowhere to run: 2.04 ms beside them), 3.41 against 3.74 at 12 500; 2 / 3 / 6 / 8 workgroups per CU
+// (MSC_GEMM_SK_PER_CU) no better. Kept for A/B runs.
+static bool pair_gemm_streamk() {
+	static const bool on = getenv("MSC_GEMM_STREAMK") != nullptr && getenv("MSC_GEMM_QS2") == nullptr && getenv("MSC_GEMM_WAVES") == nullptr;
+	return pair_gemm_fp4() && on;
 }
 const char* msc_pair_gemm_kernel_name() { return pair_gemm_fp4() ? "k_pair_gemm_fp4" : "k_pair_gemm_bits"; }
 
@@ -462,6 +579,7 @@ uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_c
 	//    50 000: 2 / 4 -> 4.88 / 4.77        25 000: 2 / 4 / 8 -> 3.55 / 4.32 / 4.16        12 500: 4 / 8 / 16 / 32 / 64 -> 3.29 / 3.72 / 3.62 / 3.12 / 2.40
 	// -- the best is always the count that brings the grid to ~780 workgroups. A slice is an even number of 128-bin steps.
 	// MSC_GEMM_MAX_SLICES / MSC_GEMM_SLICES bound the count from above / below for A/B runs.
+	if (pair_gemm_streamk()) return 1;          // (the work is dealt out by units, the output is one array)
 	const uint32_t per_wg = pair_gemm_wide(qn, m) ? 256 : 128;
 	uint32_t s = 1;
 	static const uint32_t s_max = [] { const char* e = getenv("MSC_GEMM_MAX_SLICES"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 64); }();
@@ -507,6 +625,25 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 	if (hot_ptr) {
 		const hipError_t e = hipMemsetAsync(out_diff, 0, (size_t)m * qn * sizeof(int32_t), st);
 		if (e != hipSuccess) return e;
+	}
+	if (pair_gemm_streamk()) {
+		if (k_slices != 1) return hipErrorInvalidValue;
+		hipError_t e = hipMemsetAsync(out_min, 0, (size_t)m * qn * sizeof(int32_t), st);
+		if (e != hipSuccess) return e;
+		const uint64_t total = (uint64_t)((m + 127) / 128) * (nbins / 256);
+		static const int num_cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount <= 0) return 256; return p.multiProcessorCount; }();
+		static const int per_cu = [] { const char* e = getenv("MSC_GEMM_SK_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+		const uint64_t places = (uint64_t)num_cus * per_cu;          // four workgroups of four waves per CU at most (108 registers, 32 KiB of LDS each)
+		const uint32_t per_wg = (uint32_t)((total + places - 1) / places);
+		const dim3 grid((unsigned)((total + per_wg - 1) / per_wg));
+#define MSC_SK_GO(NRB) k_pair_gemm_fp4_sk<NRB, 4><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, abits, nbins, per_wg, hot_ptr, (const uint2*)hot, out_min, out_diff)
+		if (qn == 32) MSC_SK_GO(1);
+		else if (qn == 64) MSC_SK_GO(2);
+		else if (qn == 128) MSC_SK_GO(4);
+		else if (qn == 256) MSC_SK_GO(8);
+		else return hipErrorInvalidValue;
+#undef MSC_SK_GO
+		return hipGetLastError();
 	}
 	const bool wide = pair_gemm_wide(qn, m);
 	// MSC_GEMM_LDS_PAD=KiB: unused LDS added to every workgroup of the product, i.e. fewer of them per CU -- room for the tail stream's kernels
