@@ -485,7 +485,7 @@ extern "C" int msc_hist_set_k(const msc_hist_set* s) { return s ? s->k : 0; }
 extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype : 0; }
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
-	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity;
+	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity + (s->rkl ? s->rkl_entries * 4 + s->capacity * 12 : 0);
 	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->kb ? s->L.padded_bins / 8 + 32 + (uint64_t)s->mb_pitch * 8 + 4 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
