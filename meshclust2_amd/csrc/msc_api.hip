@@ -157,6 +157,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->shard_payload);
 	release(ctx->shard_hdrs);
 	release(ctx->kb_abits);
+	release(ctx->kb_anib);
 	release(ctx->kb_qT);
 	release(ctx->kb_hot);
 	release(ctx->kb_hot_idx);
@@ -2359,6 +2360,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			if (ctx->tail_busy[i] && (!piped || i == pb)) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[i], 0)); if (!piped) ctx->tail_busy[i] = false; }
 	if (manh_gemm) {
 		const uint64_t nsteps = L.nbins / 128;
+		if (msc_pair_gemm_anib_bytes(L.nbins, kb_qn) && (r = ensure(ctx, ctx->kb_anib, msc_pair_gemm_anib_bytes(L.nbins, kb_qn)))) return r;
 		if ((r = ensure(ctx, ctx->kb_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
 		if (n_hot) {
 			if ((r = ensure(ctx, ctx->kb_hot, n_hot * 8)) || (r = ensure(ctx, ctx->kb_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
@@ -2369,7 +2371,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		}
 		// the queries' side of the block, once for all chunks of candidates
 		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
-		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)b_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt));
+		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)b_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt, (uint8_t*)ctx->kb_anib.p));
 	}
 	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? kb_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
@@ -2400,7 +2402,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
 			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)ctx->kb_abits.p, kb_qn, gemm_slices, hot_ptr, ctx->kb_hot.p,
-			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p));
+			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p, (const uint8_t*)ctx->kb_anib.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          dq_slots, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));

@@ -209,11 +209,12 @@ const char* msc_pair_gemm_kernel_name();          // "k_pair_gemm_fp4", or "k_pa
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
 uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn);
 uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn);
+uint64_t msc_pair_gemm_anib_bytes(uint64_t nbins, uint32_t qn);          // the queries' nibble tiles for the LDS-DMA form of the product (0: off)
 hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_kb, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
                                         const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* abits, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
-                                        uint32_t* hot_cursor, uint32_t* hot_cnt);
+                                        uint32_t* hot_cursor, uint32_t* hot_cnt, uint8_t* anib);
 hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* abits,
-                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff);
+                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff, const uint8_t* anib);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);
 // the window bookkeeping the fused epilogue + reduce kernels do for msc_get_close_window (msc_window.hip): pos[i] = position of candidate i,

@@ -43,7 +43,7 @@ struct msc_ctx {
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
 	// msc_pair_gemm.hip: the queries' side of a block (bit image, transposed counts, hot list + its three step arrays), P1 per slice, P2
-	DevBuf kb_abits, kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff;
+	DevBuf kb_abits, kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff, kb_anib;          // (kb_anib: the queries' tiles as nibbles, for the LDS-DMA form of the product)
 	// the close flags of a block of the matrix-core pass go back to the host on a stream of their own, under the next block's kernels:
 	// two device buffers take turns; msc_score_multi waits for the copies before it returns
 	hipStream_t copy_stream = nullptr;

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_kb_build(const T* __restrict__ bins, ui
 // bytes of the super-step (what lane half h feeds the super-step's product t).
 template <int QN>
 __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ kb, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
-                                                   uint8_t* __restrict__ abits, uint8_t* __restrict__ qT, int fp4_image) {
+                                                   uint8_t* __restrict__ abits, uint8_t* __restrict__ qT, int fp4_image, uint8_t* __restrict__ anib) {
 	__shared__ v4i tile[QN * 8];          // [row][16-byte segment 2 kc + h]: the presence bytes of this step
 	const uint32_t step = blockIdx.x, row = threadIdx.x;
 	if (row < QN) {
@@ -117,6 +117,14 @@ __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ k
 #pragma unroll
 		for (int d = 0; d < 4; d++) packed[d] = (int)(hwv[2 * d] | (hwv[2 * d + 1] << 16));
 		if (fp4_image) *reinterpret_cast<v4i*>(abits + (((uint64_t)(step >> 1) * QN + row) * 8 + 4 * (step & 1)) * 4) = v4i{(int)(hwv[0] | (hwv[2] << 16)), (int)(hwv[1] | (hwv[3] << 16)), (int)(hwv[4] | (hwv[6] << 16)), (int)(hwv[5] | (hwv[7] << 16))};
+		if (anib) {          // the queries' tile as k_pair_gemm_fp4_dma copies it into LDS: nibbles, segments already swizzled
+			v4i* tile_row = reinterpret_cast<v4i*>(anib) + ((uint64_t)(step >> 1) * QN + row) * 8;
+#pragma unroll
+			for (uint32_t x = 0; x < 4; x++) {          // x = 2 (t & 1) + h of this step's two products
+				const uint32_t h = x & 1, t = 2 * (step & 1) + (x >> 1), w = hwv[4 * (x >> 1) + h] | (hwv[4 * (x >> 1) + 2 + h] << 16);
+				tile_row[(2 * t + h) ^ ((row >> 1) & 7)] = v4i{(int)((w << 2) & 0x44444444u), (int)(w & 0x22222222u), (int)((w >> 2) & 0x11111111u), (int)((w >> 1) & 0x44444444u)};
+			}
+		}
 		else *reinterpret_cast<v4i*>(abits + ((uint64_t)step * QN + row) * 16) = packed;
 #pragma unroll
 		for (int sg = 0; sg < 8; sg++) tile[row * 8 + sg] = expand16(hwv[sg]);
@@ -416,6 +424,112 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4(con
 	}
 }
 
+// The same product with the queries' tile brought into LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU) from an image
+// k_kb_gather wrote once per block in the tile's own byte order (nibbles, swizzled segments): the 33 vector operations per thread and
+// super-step that expanded bits into the tile in every one of the grid's workgroups are gone. A wave copies its QN / NW rows of the
+// next super-step (1 KiB per instruction) while the current one is multiplied; vector-memory operations retire in order, so the
+// s_waitcnt vmcnt(0) in front of the barrier covers the copy and the candidates' next 16 bytes alike.
+__device__ __forceinline__ void lds_dma_1k(const uint8_t* lane_src, uint32_t lds_wave_base) {
+	uint32_t keep;      // m0 is the compiler's: saved and restored around the copy
+	asm volatile(
+	    "s_mov_b32 %0, m0\n\t"
+	    "s_mov_b32 m0, %2\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dwordx4 %1, off\n\t"
+	    "s_mov_b32 m0, %0"
+	    : "=&s"(keep)
+	    : "v"(lane_src), "s"(lds_wave_base)
+	    : "memory");
+}
+
+// The candidates' 16 bytes per lane and super-step come by LDS-DMA too, into a ring of kBDepth KiB per wave, kBDepth - 1 super-steps
+// ahead: a register destination can only be one super-step ahead (the wait in front of the barrier would have to let exactly that load
+// through, and a register still in flight cannot be handed on), and one super-step -- 0.2-0.5 us -- is less than a trip to HBM.
+// Order of issue per super-step: the tile's pieces, THEN the candidates' KiB; vector-memory operations retire in order, so
+// s_waitcnt vmcnt(1) in front of the barrier lets only that youngest copy stay in flight.
+template <int NRB, int NW>
+__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 3) k_pair_gemm_fp4_dma(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                                         const uint8_t* __restrict__ anib, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
+                                                                         const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
+	constexpr int QN = 32 * NRB;
+	constexpr uint32_t kTile = QN * 128;              // bytes of the queries' tile of a super-step
+	constexpr uint32_t kPieces = kTile / NW / 1024;   // KiB a wave copies per super-step
+	constexpr uint32_t kBDepth = 4;                   // ring slots of the candidates' bits per wave
+	static_assert(kPieces >= 1 && kPieces * NW * 1024 == kTile, "tile copy");
+	__shared__ v4i sA[2][QN * 8];
+	__shared__ v4i sB[NW][kBDepth][64];
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t ks = blockIdx.y;
+	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
+	const uint32_t n_ss = (uint32_t)(per / 256), gss0 = (uint32_t)(k0 / 256);
+	const uint32_t ci = (blockIdx.x * NW + wave) * 32 + (lane & 31);
+	const bool valid = ci < m;
+	const uint32_t cc = valid ? ci : m - 1;
+	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
+	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	const uint8_t* asrc = anib + (uint64_t)gss0 * kTile + wave * (kPieces * 1024) + lane * 16;
+	const uint32_t lds_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sA[0][0] + wave * (kPieces * 1024));
+	const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sB[wave][0][0]);
+	v16f acc[NRB];
+#pragma unroll
+	for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+		for (int i = 0; i < 16; i++) acc[rb][i] = 0.f;
+	auto copy_a = [&](uint32_t buf, uint32_t ss) {
+		const uint8_t* p = asrc + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * kTile;
+#pragma unroll
+		for (uint32_t i = 0; i < kPieces; i++) lds_dma_1k(p + i * 1024, lds_a + buf * kTile + i * 1024);
+	};
+	// a lane's source is its own candidate's 16 bytes: one wave-instruction gathers the 64 of them into one KiB of the ring
+	auto copy_b = [&](uint32_t ss) { lds_dma_1k(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024, lds_b + (ss % kBDepth) * 1024); };
+	// prologue: the candidates' bits of the first kBDepth - 1 super-steps, the first tile; everything has landed behind the wait
+#pragma unroll
+	for (uint32_t d = 0; d + 1 < kBDepth; d++) copy_b(d);
+	copy_a(0, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	for (uint32_t ss = 0; ss < n_ss; ss++) {
+		const uint32_t buf = ss & 1;
+		copy_a(buf ^ 1, ss + 1);          // (the buffer the previous super-step read: every wave is past that super-step's barrier)
+		copy_b(ss + kBDepth - 1);         // (the slot super-step ss - 1 read)
+		const v4i bcur = sB[wave][ss % kBDepth][lane];
+		{
+			const uint32_t r = lane & 31, sw = (r >> 1) & 7, hh = lane >> 5;
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const uint32_t w = (uint32_t)bcur[t];
+				const v8i B = {(int)(w & kM1), (int)(w & kM2), (int)(w & kM4), (int)((w >> 3) & kM1), 0, 0, 0, 0};
+#pragma unroll
+				for (int rb = 0; rb < NRB; rb++) {
+					const v4i a = sA[buf][(32 * rb + r) * 8 + ((2 * t + hh) ^ sw)];
+					const v8i A = {a.x, a.y, a.z, a.w, 0, 0, 0, 0};
+					acc[rb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[rb], 4, 4, 0, 0, 0, 0);
+				}
+			}
+		}
+		if (hot_ptr) {          // P2 (see k_pair_gemm_fp4)
+			const uint32_t h0 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss)]), h1 = __builtin_amdgcn_readfirstlane(hot_ptr[2 * (gss0 + ss) + 2]);
+			for (uint32_t e = h0; e < h1; e++) {
+				const uint2 en = hot[e];
+				const uint32_t bin = __builtin_amdgcn_readfirstlane(en.x), rg = __builtin_amdgcn_readfirstlane(en.y);
+				const uint32_t j = (bin >> 5) & 7, wsel = j >> 1;
+				const uint32_t w = (uint32_t)(wsel == 0 ? bcur.x : wsel == 1 ? bcur.y : wsel == 2 ? bcur.z : bcur.w);
+				const uint32_t bit = (w >> (16 * (j & 1) + (bin & 15))) & 1u;
+				if (valid && (lane >> 5) == ((bin >> 4) & 1) && bit) atomicAdd(out_diff + (uint64_t)ci * QN + (rg >> 16), (int32_t)(rg & 0xffffu));
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+		__syncthreads();
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (nothing of this wave may still be writing LDS when the workgroup ends)
+	if (!valid) return;
+	int32_t* o = out_min + ((uint64_t)ks * m + ci) * QN + 4 * (lane >> 5);
+#pragma unroll
+	for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+		for (int g = 0; g < 4; g++) *reinterpret_cast<v4i*>(o + 32 * rb + 8 * g) = v4i{(int)acc[rb][4 * g], (int)acc[rb][4 * g + 1], (int)acc[rb][4 * g + 2], (int)acc[rb][4 * g + 3]};
+}
+
 // The same product with the WORK, not the output, dealt out ("stream-K"): the pass is tiles x super-steps units of work (a tile = the
 // workgroup's 128 candidates, a unit = one 256-bin super-step of it); workgroup w of G takes units [w L, (w + 1) L), L = ceil(units / G),
 // i.e. the tail of one tile's bins, whole tiles, the head of another -- every workgroup the same amount whatever the number of candidates,
@@ -532,6 +646,11 @@ static bool pair_gemm_fp4() {
 	static const bool i8 = getenv("MSC_GEMM_I8") != nullptr;
 	return !i8;
 }
+// MSC_GEMM_NO_DMA: the queries' tile expanded from bits by every workgroup (k_pair_gemm_fp4) instead of copied by LDS-DMA (k_pair_gemm_fp4_dma)
+static bool pair_gemm_dma() {
+	static const bool off = getenv("MSC_GEMM_NO_DMA") != nullptr || getenv("MSC_GEMM_QS2") != nullptr || getenv("MSC_GEMM_WAVES") != nullptr || getenv("MSC_GEMM_STREAMK") != nullptr;
+	return pair_gemm_fp4() && !off;
+}
 // MSC_GEMM_STREAMK: the work-dealing grid (k_pair_gemm_fp4_sk) instead of the sliced one. Measured SLOWER and therefore off: 4.85 against
 // 5.11 G pairs/s at 100 000 candidates (the product alone 1.38 against 1.49 ms, but a grid that fills every place of the chip leaves the
 // tail stream's kernels nowhere to run: 2.04 ms beside them), 3.41 against 3.74 at 12 500; 2 / 3 / 6 / 8 workgroups per CU
@@ -540,7 +659,7 @@ static bool pair_gemm_streamk() {
 	static const bool on = getenv("MSC_GEMM_STREAMK") != nullptr && getenv("MSC_GEMM_QS2") == nullptr && getenv("MSC_GEMM_WAVES") == nullptr;
 	return pair_gemm_fp4() && on;
 }
-const char* msc_pair_gemm_kernel_name() { return pair_gemm_fp4() ? "k_pair_gemm_fp4" : "k_pair_gemm_bits"; }
+const char* msc_pair_gemm_kernel_name() { return pair_gemm_streamk() ? "k_pair_gemm_fp4_sk" : pair_gemm_dma() ? "k_pair_gemm_fp4_dma" : pair_gemm_fp4() ? "k_pair_gemm_fp4" : "k_pair_gemm_bits"; }
 
 uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity) { return (capacity + 31) / 32 * msc_kb_block_bytes(L.padded_bins); }
 
@@ -593,19 +712,21 @@ uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_c
 // bytes of the queries' side of a block: the bit image (16 bytes per row and step) and the transposed counts (a byte per bin and row)
 uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn) { return nbins / 8 * qn; }
 uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn) { return nbins * qn; }
+// ... and the nibble image of the queries' tiles for the LDS-DMA form of the product (0: that form is off)
+uint64_t msc_pair_gemm_anib_bytes(uint64_t nbins, uint32_t qn) { return pair_gemm_dma() ? nbins / 2 * qn : 0; }
 
 // The queries' side: abits and qT of rows q_slots[0 .. n_q) of the mirror q_kb; when n_hot > 0 also the hot list (hot: n_hot entries;
 // hot_ptr, hot_cursor, hot_cnt: nbins / 128 + 1 words each) from the queries' lists of large bins.
 hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_kb, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
                                         const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* abits, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
-                                        uint32_t* hot_cursor, uint32_t* hot_cnt) {
+                                        uint32_t* hot_cursor, uint32_t* hot_cnt, uint8_t* anib) {
 	if (n_q == 0 || n_q > qn || nbins % 256) return hipErrorInvalidValue;
 	const uint32_t nsteps = (uint32_t)(nbins / kStep);
 	const int fp4 = pair_gemm_fp4() ? 1 : 0;
-	if (qn == 32) k_kb_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
-	else if (qn == 64) k_kb_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
-	else if (qn == 128) k_kb_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
-	else if (qn == 256) k_kb_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4);
+	if (qn == 32) k_kb_gather<32><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4, pair_gemm_dma() ? anib : nullptr);
+	else if (qn == 64) k_kb_gather<64><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4, pair_gemm_dma() ? anib : nullptr);
+	else if (qn == 128) k_kb_gather<128><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4, pair_gemm_dma() ? anib : nullptr);
+	else if (qn == 256) k_kb_gather<256><<<dim3(nsteps), dim3(256), 0, st>>>(q_kb, q_slots_dev, n_q, nbins, abits, qT, fp4, pair_gemm_dma() ? anib : nullptr);
 	else return hipErrorInvalidValue;
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || n_hot == 0) return e;
@@ -619,12 +740,23 @@ hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const ui
 // P1 [k_slices][m][qn] and, with a hot list, P2 [m][qn] (zeroed here) of the block's queries against m candidates (slot list, or slots
 // first .. first + m - 1) of the mirror cand_kb
 hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* abits,
-                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff) {
+                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff, const uint8_t* anib) {
 	if (m == 0) return hipSuccess;
 	if (k_slices == 0 || nbins % ((uint64_t)k_slices * 2 * kStep)) return hipErrorInvalidValue;
 	if (hot_ptr) {
 		const hipError_t e = hipMemsetAsync(out_diff, 0, (size_t)m * qn * sizeof(int32_t), st);
 		if (e != hipSuccess) return e;
+	}
+	if (pair_gemm_dma() && anib) {
+		const dim3 grid((m + 127) / 128, k_slices);
+#define MSC_DMA_GO(NRB) k_pair_gemm_fp4_dma<NRB, 4><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, anib, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
+		if (qn == 32) MSC_DMA_GO(1);
+		else if (qn == 64) MSC_DMA_GO(2);
+		else if (qn == 128) MSC_DMA_GO(4);
+		else if (qn == 256) MSC_DMA_GO(8);
+		else return hipErrorInvalidValue;
+#undef MSC_DMA_GO
+		return hipGetLastError();
 	}
 	if (pair_gemm_streamk()) {
 		if (k_slices != 1) return hipErrorInvalidValue;
