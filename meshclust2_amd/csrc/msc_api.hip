@@ -158,6 +158,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->shard_hdrs);
 	release(ctx->kb_abits);
 	release(ctx->kb_anib);
+	release(ctx->rk_q);
 	release(ctx->kb_qT);
 	release(ctx->kb_hot);
 	release(ctx->kb_hot_idx);
@@ -1582,6 +1583,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));
 			*ctx->rk_guard = 0;
 		}
+		if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
 		if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
 	}
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
@@ -1645,7 +1647,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		if (lists && rank_pass) {
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
-			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard));
+			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p));
 		} else if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,
@@ -2144,13 +2146,14 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 				HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));
 				*ctx->rk_guard = 0;
 			}
+			if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
 			if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_tiles0, ctx->stream));
 		for (uint64_t q = 0; q < n_q && rank_pass; q++)
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, cands->rkl, cands->rkl_off, cands->rkl_n, cands->scalars, cands->scalar_stride, d_slots, 0, (uint32_t)m, qset->ent, qset->cum,
-			                                       qset->hdr + q_slots[q], L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->partials.p + q * m, ctx->num_cus, q_kmers, ctx->rk_guard));
+			                                       qset->hdr + q_slots[q], L.nbins, 0, 0, ~0ull, (MscPartial*)ctx->partials.p + q * m, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p));
 		for (uint64_t q = 0; q < n_q && !rank_pass; q++)
 			HIP_TRY(ctx, msc_launch_pair_sparse_mp(ctx->stream, cands->ent, cands->cum, cands->hdr, cands->scalars, cands->scalar_stride, d_slots, (uint32_t)m, qset->ent,
 			                                       qset->cum, qset->hdr + q_slots[q], qset->scalars + (uint64_t)q_slots[q] * qset->scalar_stride, L.nbins, 0, 0, ~0ull,

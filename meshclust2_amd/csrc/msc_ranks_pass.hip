@@ -74,6 +74,19 @@ __global__ void __launch_bounds__(256) k_rkl_fill(const uint2* __restrict__ ent,
 	if (lane < pad - tot) o[tot + lane] = nbins;
 }
 
+// the rank list of ONE slot into out[0 .. n), padded with 4^k to a multiple of 256 (the query of a pass when it is too long for LDS)
+__global__ void __launch_bounds__(1024) k_rank_expand_one(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
+                                                          uint32_t* __restrict__ out) {
+	const MscSparseHdr h = *hdr_p;
+	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
+		const uint2 en = ent[h.off + j];
+		const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
+		for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
+	}
+	if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
+}
+
 // ------------------------------------------------------------------------------------------------ the pass
 // first index in the sorted list v[0 .. n) whose value is >= x
 template <typename Load>
@@ -92,15 +105,19 @@ __device__ __forceinline__ uint32_t lower_bound_u32(Load v, uint32_t n, uint32_t
 // list's place and length arrived an iteration earlier), the place and length of candidate i + 2 are being fetched (its slot arrived an
 // iteration earlier) and the slot of candidate i + 3 is read from the window's list. Without that every candidate cost its wave a chain of
 // three dependent round trips plus one per 256 entries -- 5 us per candidate, 0.16 ms per 100 000 however short the lists.
+template <bool QG>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
                                                               const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
                                                               uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
                                                               uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials, uint32_t q_cap,
-                                                              uint32_t* __restrict__ guard) {
+                                                              uint32_t* __restrict__ guard, const uint32_t* __restrict__ q_ranks_g) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	const uint32_t words = nbins / 16 + 1;
 	uint32_t* sb = s_rp;
-	uint32_t* rq = s_rp + ((words + 3u) & ~3u);          // 16-byte aligned
+	// the query's own rank list: in LDS, or (QG: a query of more than kRpQCap k-mers) the copy k_rank_expand_one left in global memory,
+	// read through L2 by every wave alike
+	uint32_t* rq_l = s_rp + ((words + 3u) & ~3u);          // 16-byte aligned
+	const uint32_t* rq = QG ? q_ranks_g : rq_l;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
@@ -113,13 +130,13 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	}
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
 	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = 0u;
-	for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += kRpBlock) rq[i] = nbins;
+	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += kRpBlock) rq_l[i] = nbins;
 	__syncthreads();
 	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
 		const uint2 en = Q[j];
 		const uint32_t e = en.y ? en.y - 1u : 0u, end = CQ[j];
 		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 2 ? 3u : 1u) << (2 * (en.x & 15)));
-		for (uint32_t t = end - e; t < end; t++) rq[t] = en.x;
+		if constexpr (!QG) for (uint32_t t = end - e; t < end; t++) rq_l[t] = en.x;
 	}
 	__syncthreads();
 	const uint32_t tw = gridDim.x * (kRpBlock / 64);
@@ -228,11 +245,13 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 
 // bytes of dynamic LDS the pass needs for 4^k = nbins and query lists of up to q_kmers entries; 0 when the histogram is too large for it
 size_t msc_ranks_pass_lds(uint64_t nbins, uint64_t q_kmers) {
-	if (nbins > (1ull << 18) || nbins % 32 || q_kmers > kRpQCap) return 0;
+	if (nbins > (1ull << 18) || nbins % 32 || q_kmers > (1ull << 26)) return 0;
 	const size_t words = nbins / 16 + 1;
-	return (words + 4) * 4 + (((size_t)q_kmers + 255) & ~(size_t)255) * 4;
+	return (words + 4) * 4 + (q_kmers > kRpQCap ? 0 : (((size_t)q_kmers + 255) & ~(size_t)255) * 4);          // (a longer query's ranks stay in global memory)
 }
-uint32_t msc_ranks_pass_query_cap() { return kRpQCap; }
+// entries of global scratch a pass needs for the query's rank list (0: the list fits LDS)
+uint64_t msc_ranks_pass_query_scratch(uint64_t q_kmers) { return q_kmers > kRpQCap ? ((q_kmers + 255) & ~255ull) : 0; }
+uint32_t msc_ranks_pass_query_cap() { return 1u << 26; }
 
 // sizes (n: capacity words) and offsets (off: capacity + 1 words) of the rank lists of a sparse set; the caller reads off[capacity], allocates, fills
 hipError_t msc_launch_rank_lists_sizes(hipStream_t st, const MscSparseHdr* hdr, const uint32_t* cum, uint64_t capacity, uint32_t* n, uint64_t* off) {
@@ -251,16 +270,20 @@ hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uin
 // candidates [first, first + m) (or the device slot list cand_slots; cand_scalars then is the set's base) against the query list
 hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                      const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard) {
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch) {
 	if (m == 0) return hipSuccess;
 	const size_t lds = msc_ranks_pass_lds(nbins, q_kmers);
 	if (!lds) return hipErrorInvalidValue;
+	const bool qg = q_kmers > kRpQCap;
+	if (qg && !q_scratch) return hipErrorInvalidValue;
 	static bool attr_set = false;
 	if (!attr_set) {
-		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
+	if (qg) k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch);
 	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
@@ -270,7 +293,10 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	static const uint32_t cpw = [] { const char* e = getenv("MSC_RANKS_CPW"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 1); }();
 	uint32_t blocks = (m + per_wg * cpw - 1) / (per_wg * cpw);
 	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
-	k_pair_ranks_1xm<<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
-	                                                            use_window, min_len, max_len, partials, (uint32_t)((q_kmers + 255) & ~255ull), guard);
+	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
+	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
+	                                                                          (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, q_scratch);
+	else k_pair_ranks_1xm<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
+	                                                                        (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, nullptr);
 	return hipGetLastError();
 }

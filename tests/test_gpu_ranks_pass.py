@@ -56,6 +56,7 @@ def _sequences(seed, n, length, kind):
     (16, 8, 50, 2500, "unit3", "sparse"),        # 65 536 bins, lists of 2 500
     (32, 7, 50, 400, None, "dense"),
     (16, 8, 40, 600, "unit3", "dense"),
+    (16, 9, 24, 12000, "unit12", "sparse"),      # queries of more than 8 192 k-mers: their rank lists stay in global memory
 ])
 def test_rank_pass_against_the_oracle_and_the_merge_kernels(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
     seqs = _sequences(7000 + 13 * k + dtype, n, length, kind)
