@@ -159,6 +159,10 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->kb_abits);
 	release(ctx->kb_anib);
 	release(ctx->rk_q);
+	release(ctx->rk_cells);
+	release(ctx->rk_extras);
+	release(ctx->rk_hq);
+	release(ctx->rk_big);
 	release(ctx->kb_qT);
 	release(ctx->kb_hot);
 	release(ctx->kb_hot_idx);
@@ -1575,7 +1579,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool no_rank_pass = getenv("MSC_NO_RANKS_1XM") != nullptr;          // (read on every call: tests compare both routes in one process)
 	bool rank_pass = false;
 	const uint64_t q_kmers = rq.qset->max_sum >= L.nbins ? rq.qset->max_sum - L.nbins : ~0ull;          // bound on the k-mers of any histogram of the query's set
-	if (lists && !need_div && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
+	// (the divergence statistics too: counted per cell of (copy, query count) by the pass, evaluated per candidate in one fixed order by
+	// k_rank_div_finish -- msc_ranks_pass.hip; MSC_NO_RANKS_DIV keeps such passes on the merge kernel)
+	const bool no_rank_div = getenv("MSC_NO_RANKS_DIV") != nullptr;
+	if (lists && (!need_div || !no_rank_div) && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
 		int e = MSC_OK;
 		rank_pass = rank_lists_ready(ctx, c_sp, &e);
 		if (e) return e;
@@ -1594,7 +1601,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const uint32_t mp_parts = c_sp && !rank_pass && spk == SPK_MP && (need_div ? true : lists && !msc_sparse_wl_fits(q_sp->hdr_host[rq.q_slot].nnz, c_sp->max_nnz))
 	                              ? msc_sparse_mp_parts((uint32_t)std::min<uint64_t>(m, 0xffffffffu), mp_entries, ctx->num_cus, need_div) : 1;
 	const uint32_t SPN = sparse_records(spk, mp_parts);               // records per candidate the merge kernel writes
-	const uint32_t DVN = div_records(spk, mp_entries);                // ... and {jd, js} records per candidate
+	const bool rank_div = rank_pass && need_div;
+	const uint32_t DVN = rank_div ? 1 : div_records(spk, mp_entries);                // ... and {jd, js} records per candidate
 	const uint32_t PS = lists ? SPN : L.S;                            // partial records per candidate
 	ctx->last_partial_stride = PS;
 	uint64_t chunk = (256ull << 20) / ((uint64_t)PS * sizeof(MscPartial));
@@ -1609,8 +1617,13 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
+	if (rank_div) {
+		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * 2 * sizeof(double))) ||
+		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
+			return r;
+	}
 	if (need_div) {
-		if ((r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
+		if (!rank_div && (r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? DVN : PS) * 16)) != MSC_OK) return r;
 		if (mirror_div && (r = ensure(ctx, ctx->sp_partials, chunk * SPN * sizeof(MscPartial))) != MSC_OK) return r;
 	}
@@ -1646,8 +1659,10 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
 		if (lists && rank_pass) {
+			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
-			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p));
+			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p,
+			                                       rank_div ? &dv : nullptr));
 		} else if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,

@@ -87,6 +87,84 @@ __global__ void __launch_bounds__(1024) k_rank_expand_one(const uint2* __restric
 	if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
 }
 
+// ------------------------------------------------------------------------------------------------ the divergence statistics in rank form
+// jefferey_divergence / jensen_shannon (predict/Feature.cpp:1235-1262, 988-1008) are sums over bins of a term that depends on the pair of
+// counts (c, q) of the bin and on the two magnitudes only; every bin outside the union of the two lists holds (1, 1). The merge kernels add
+// term(c, q) - term(1, 1) per bin of the union in FP64 as they walk it. Here the candidate's rank list is streamed without a walk of the
+// query's, so the sum is re-arranged by COPIES: the r-th copy (r = 0, 1, ..) of a bin whose count in the query is b contributes
+//     r = 0:  F(2, b)                      r >= 1:  F(r + 2, b) - F(r + 1, b)              with F(x, b) = term(x, b) - term(1, 1)
+// (they telescope to F(e_c + 1, b)), and the query's bins the candidate does not hold contribute F(1, b). The pass only COUNTS copies per
+// cell (r, b) -- integers: registers for the two cells that hold nearly everything, (0, 1) and (0, 2), LDS atomics for the rest, FP64 on
+// the spot for r >= 7 or b >= 8 -- and k_rank_div_finish evaluates each candidate's sums from its cell counts in one fixed order.
+struct RkDivTerm { double jd, js; };
+__device__ __forceinline__ RkDivTerm rk_div_term(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {          // = div_term_sp of sparse.hip
+	RkDivTerm t;
+	const bool cf = order == MSC_ORDER_CAND_FIRST;
+	const double pp = cf ? (double)cand_count / cand_mag : (double)q_count / q_mag;
+	const double pq = cf ? (double)q_count / q_mag : (double)cand_count / cand_mag;
+	t.jd = (pp - pq) * log(pp / pq);
+	const double avg = 0.5 * (pp + pq);
+	t.js = pp * log(pp / avg) + pq * log(pq / avg);
+	return t;
+}
+__device__ __noinline__ RkDivTerm rk_div_term_call(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {
+	return rk_div_term(cand_count, q_count, cand_mag, q_mag, order);
+}
+constexpr uint32_t kRkCells = 64;          // cell (r, b) at r * 8 + b, r < 7 (7: unused), 1 <= b < 8 (0: unused)
+
+// the query's side of a divergence pass: hq[v] = its bins with count v (2 <= v < 8), hq[8] = the number of its bins with count >= 8 and
+// big[..] their counts (any order: the finish kernel adds them up per candidate in list order, the same for every candidate)
+__global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr_p, uint32_t* __restrict__ hq, uint32_t* __restrict__ big) {
+	const MscSparseHdr h = *hdr_p;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
+		const uint32_t v = ent[h.off + j].y;
+		if (v >= 2 && v < 8) atomicAdd(&hq[v], 1u);
+		else if (v >= 8) big[atomicAdd(&hq[8], 1u)] = v;
+	}
+}
+
+// one thread per candidate: its two sums from its cell counts
+__global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restrict__ cells, const double* __restrict__ extras, const uint32_t* __restrict__ hq,
+                                                         const uint32_t* __restrict__ big, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                         const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_scalars, int order,
+                                                         double* __restrict__ div_out) {
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= m) return;
+	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : (uint64_t)c;
+	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + slot * scalar_stride)->mag;
+	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
+	const uint32_t* n = cells + (uint64_t)c * kRkCells;
+	double jd = 0.0, js = 0.0;
+	for (uint32_t b = 1; b < 8; b++) {
+		for (uint32_t r = 0; r < 7; r++) {
+			const uint32_t k = n[r * 8 + b];
+			if (!k) continue;
+			RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
+			if (r) { const RkDivTerm g = rk_div_term_call(r + 1, b, cm, qm, order); f.jd -= g.jd; f.js -= g.js; }
+			else { f.jd -= t11.jd; f.js -= t11.js; }
+			jd += (double)k * f.jd;
+			js += (double)k * f.js;
+		}
+		if (b >= 2) {          // the query's bins with count b that the candidate does not hold
+			const uint32_t k = hq[b] - n[b];
+			if (k) {
+				const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
+				jd += (double)k * (f.jd - t11.jd);
+				js += (double)k * (f.js - t11.js);
+			}
+		}
+	}
+	const uint32_t n_big = hq[8];
+	for (uint32_t i = 0; i < n_big; i++) {          // ... and those with count >= 8 (the pass took back the ones the candidate holds)
+		const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
+		jd += f.jd - t11.jd;
+		js += f.js - t11.js;
+	}
+	div_out[2 * (uint64_t)c] = jd + extras[2 * (uint64_t)c];
+	div_out[2 * (uint64_t)c + 1] = js + extras[2 * (uint64_t)c + 1];
+}
+
 // ------------------------------------------------------------------------------------------------ the pass
 // first index in the sorted list v[0 .. n) whose value is >= x
 template <typename Load>
@@ -105,12 +183,13 @@ __device__ __forceinline__ uint32_t lower_bound_u32(Load v, uint32_t n, uint32_t
 // list's place and length arrived an iteration earlier), the place and length of candidate i + 2 are being fetched (its slot arrived an
 // iteration earlier) and the slot of candidate i + 3 is read from the window's list. Without that every candidate cost its wave a chain of
 // three dependent round trips plus one per 256 entries -- 5 us per candidate, 0.16 ms per 100 000 however short the lists.
-template <bool QG>
+template <bool QG, bool DIV>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
                                                               const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
                                                               uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
                                                               uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials, uint32_t q_cap,
-                                                              uint32_t* __restrict__ guard, const uint32_t* __restrict__ q_ranks_g) {
+                                                              uint32_t* __restrict__ guard, const uint32_t* __restrict__ q_ranks_g, uint32_t* __restrict__ cells,
+                                                              double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	const uint32_t words = nbins / 16 + 1;
 	uint32_t* sb = s_rp;
@@ -118,6 +197,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	// read through L2 by every wave alike
 	uint32_t* rq_l = s_rp + ((words + 3u) & ~3u);          // 16-byte aligned
 	const uint32_t* rq = QG ? q_ranks_g : rq_l;
+	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of its candidate
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
@@ -145,12 +225,13 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	// stage 1: the slot of a candidate (identity without a slot list)
 	auto slot_of = [&](uint32_t c) -> uint64_t { return c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : ~0ull; };
 	// stage 2: where its rank list sits, how long it is, whether the length window keeps it (n = 0xffffffff: not scored)
-	struct Meta { uint64_t off; uint32_t n; };
+	struct Meta { uint64_t off; uint32_t n; uint64_t mag; };
 	auto meta_of = [&](uint32_t c, uint64_t slot) -> Meta {
-		Meta mt{0, 0xffffffffu};
+		Meta mt{0, 0xffffffffu, 0};
 		if (c >= m) return mt;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
 		const uint64_t len = cs->length;
+		if constexpr (DIV) mt.mag = cs->mag;
 		mt.off = c_off[slot];
 		mt.n = c_n[slot];
 		if (use_window && (len < min_len || len > max_len)) mt.n = 0xffffffffu;
@@ -167,6 +248,11 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			if (t < n_pad) d[u] = *reinterpret_cast<const uint4*>(P + t);
 		}
 	};
+	double qm = 0.0;
+	if constexpr (DIV) {
+		qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+		s_cnt[wave][lane] = 0u;
+	}
 	uint64_t slot2 = slot_of(c0 + 2 * tw);
 	Meta meta1 = meta_of(c0 + tw, slot_of(c0 + tw));
 	Meta meta0 = meta_of(c0, slot_of(c0));
@@ -184,6 +270,10 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			uint64_t emd = 0;
 			uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
 			uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
+			// DIV: copies per cell (r, b) -- see the note above k_rank_div_finish
+			uint32_t c01 = 0, c02 = 0, carry_x = 0xffffffffu, carry_y = 0xffffffffu, carry_z = 0xffffffffu;
+			double xjd = 0.0, xjs = 0.0;
+			const double cm = DIV ? (double)meta0.mag : 0.0;
 			auto chunk = [&](uint32_t t0, const uint4& a) {
 				const uint32_t t = t0 + 4 * lane;
 				uint4 b = make_uint4(nbins, nbins, nbins, nbins);
@@ -198,6 +288,14 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
 				const uint32_t av[4] = {a.x, a.y, a.z, a.w};
 				const uint32_t pv[4] = {before, a.x, a.y, a.z};
+				uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // DIV: the seven entries in front of a lane's last
+				if constexpr (DIV) {
+					seq[0] = __shfl_up(a.x, 1, 64); seq[1] = __shfl_up(a.y, 1, 64); seq[2] = __shfl_up(a.z, 1, 64);
+					if (lane == 0) { seq[0] = carry_x; seq[1] = carry_y; seq[2] = carry_z; }
+					carry_x = (uint32_t)__builtin_amdgcn_readlane((int)a.x, 63);
+					carry_y = (uint32_t)__builtin_amdgcn_readlane((int)a.y, 63);
+					carry_z = (uint32_t)__builtin_amdgcn_readlane((int)a.z, 63);
+				}
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
 					const uint32_t bin = av[j];
@@ -205,13 +303,36 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 					const uint32_t present = two & 1u;
 					prod += present;
 					mins += present & (bin != pv[j] ? 1u : 0u);
+					uint32_t e_q = present, r_known = 0xffffffffu;
 					if (two & 2u) {          // rare: this k-mer is repeated in the query
 						const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
-						uint32_t e_q = 0;
+						e_q = 0;
 						while (lo + e_q < nq_tot && rq[lo + e_q] == bin) e_q++;
 						const uint32_t r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // this entry is the r-th copy of its bin
 						prod += e_q - 1;
 						if (r >= 1 && r < e_q) mins += 1;
+						r_known = r;
+					}
+					if constexpr (DIV) {
+						const bool real = bin < nbins, first_copy = bin != pv[j];
+						const uint32_t b = e_q + 1;          // the bin's count in the query
+						const bool plain = real && first_copy && b <= 2;
+						c01 += plain && b == 1 ? 1u : 0u;
+						c02 += plain && b == 2 ? 1u : 0u;
+						if (real && !plain) {          // rare: a further copy of a bin, or a bin the query holds more than once
+							uint32_t r = first_copy ? 0u : r_known;
+							if (r == 0xffffffffu) {
+								r = 0;
+								for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
+								if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
+							}
+							if (r < 7 && b < 8) atomicAdd(&s_cnt[wave][r * 8 + b], 1u);
+							else {
+								const RkDivTerm hi = rk_div_term_call(r + 2, b, cm, qm, order), lo = rk_div_term_call(r + 1, b, cm, qm, order);
+								xjd += hi.jd - lo.jd;
+								xjs += hi.js - lo.js;
+							}
+						}
 					}
 				}
 			};
@@ -231,6 +352,21 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				out.dot = prod_t + nc + nq_tot;                          // sum (c q - 1) over the union of stored bins (the epilogue adds 4^k)
 				out.emd = emd_t;
 				partials[c] = out;
+			}
+			if constexpr (DIV) {
+				const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
+#pragma unroll
+				for (int off = 32; off >= 1; off >>= 1) { xjd += __shfl_xor(xjd, off, 64); xjs += __shfl_xor(xjs, off, 64); }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				uint32_t v = s_cnt[wave][lane];
+				s_cnt[wave][lane] = 0u;
+				if (lane == 1) v += c01_t;
+				if (lane == 2) v += c02_t;
+				cells[(uint64_t)c * kRkCells + lane] = v;
+				if (lane == 0) { extras[2 * (uint64_t)c] = xjd; extras[2 * (uint64_t)c + 1] = xjs; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
 		}
 		meta0 = meta1;
@@ -270,7 +406,8 @@ hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uin
 // candidates [first, first + m) (or the device slot list cand_slots; cand_scalars then is the set's base) against the query list
 hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                      const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch) {
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch,
+                                     const MscRankDiv* dv) {
 	if (m == 0) return hipSuccess;
 	const size_t lds = msc_ranks_pass_lds(nbins, q_kmers);
 	if (!lds) return hipErrorInvalidValue;
@@ -278,8 +415,10 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	if (qg && !q_scratch) return hipErrorInvalidValue;
 	static bool attr_set = false;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -287,16 +426,29 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
-	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / lds);
+	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (lds + (dv ? 4096 : 0)));
+	if (dv) {          // the query's counts of counts, for k_rank_div_finish
+		hipError_t e = hipMemsetAsync(dv->hq, 0, 16 * sizeof(uint32_t), st);
+		if (e != hipSuccess) return e;
+		k_rank_query_counts<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_hdr, dv->hq, dv->big);
+	}
 	// (MSC_RANKS_CPW=n: at least n candidates per wave, i.e. fewer workgroups for a short window. Measured on a window-bearing run,
 	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
 	static const uint32_t cpw = [] { const char* e = getenv("MSC_RANKS_CPW"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 1); }();
 	uint32_t blocks = (m + per_wg * cpw - 1) / (per_wg * cpw);
 	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
 	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
-	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                          (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, q_scratch);
-	else k_pair_ranks_1xm<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                        (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, nullptr);
+#define MSC_RP_GO(QGV, DV)                                                                                                                                                \
+	k_pair_ranks_1xm<QGV, DV><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,   \
+	                                                                     (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, QGV ? q_scratch : nullptr,           \
+	                                                                     DV ? dv->cells : nullptr, DV ? dv->extras : nullptr, DV ? dv->q_scalars : nullptr, DV ? dv->order : 0)
+	if (qg && dv) MSC_RP_GO(true, true);
+	else if (qg) MSC_RP_GO(true, false);
+	else if (dv) MSC_RP_GO(false, true);
+	else MSC_RP_GO(false, false);
+#undef MSC_RP_GO
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess || !dv) return e;
+	k_rank_div_finish<<<dim3((m + 255) / 256), dim3(256), 0, st>>>(dv->cells, dv->extras, dv->hq, dv->big, cand_scalars, scalar_stride, cand_slots, m, dv->q_scalars, dv->order, dv->div_out);
 	return hipGetLastError();
 }

@@ -182,3 +182,48 @@ def test_rank_pass_randomised(ctx, rank_pass_now, seed):
         assert ka == KERNEL and kb != KERNEL, (ka, kb, k, dtype, sparse)
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (seed, trial, k, dtype, sparse)
         assert np.array_equal(sa["sum"], sb["sum"]) and np.array_equal(sa["csum"], sb["csum"]), (seed, trial)
+
+
+ALL_MASK = sum(1 << b for _, b in FEATS)
+
+
+@pytest.mark.parametrize("dtype,k,n,length,kind,layout", [
+    (16, 9, 50, 1000, None, "sparse"),
+    (16, 9, 50, 1000, "homo", "sparse"),          # counts of ~290 in the query and in candidates: cells beyond the table, evaluated on the spot
+    (8, 9, 50, 1000, "di", "sparse"),
+    (32, 9, 40, 1000, "unit12", "dense"),
+    (16, 9, 24, 12000, "unit3", "sparse"),        # long lists: the query's ranks from global memory
+    (16, 8, 40, 2500, "unit12", "sparse"),
+])
+def test_divergence_statistics_through_the_rank_pass(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
+    """jefferey_divergence / jensen_shannon (predict/Feature.cpp:1235-1262, 988-1008) counted per cell by k_pair_ranks_1xm and evaluated by
+    k_rank_div_finish: next to the oracle (1e-9) and to the merge kernel (same terms, another order of addition: 1e-12); every other
+    statistic of the same pass bit-equal."""
+    seqs = _sequences(9000 + 17 * k + dtype, n, length, kind)
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n, sparse_entries=sum(len(s) for s in seqs) * 2 + 1000) if layout == "sparse" else api.HistogramSet(ctx, k, dtype, n)
+    hs.build(seqs)
+    cands = np.arange(n, dtype=np.uint32)[::-1].copy()
+    oh = [oracle.hist(s, k, dtype) for s in seqs]
+    div_cols = [c for c, (name, _) in enumerate(FEATS) if name in ("jefferey_divergence", "jensen_shannon")]
+    for q in (1, 0, 6, n - 3):
+        for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+            got = api.pair_features_raw(ctx, hs, cands, hs, q, ALL_MASK, order)
+            assert ctx.last_kernel_info()[0] == KERNEL
+            rank_pass_now.setenv("MSC_NO_RANKS_DIV", "1")
+            ref = api.pair_features_raw(ctx, hs, cands, hs, q, ALL_MASK, order)
+            assert ctx.last_kernel_info()[0] != KERNEL
+            rank_pass_now.delenv("MSC_NO_RANKS_DIV")
+            for c, (name, bit) in enumerate(FEATS):
+                if c in div_cols:
+                    assert np.allclose(got[:, c], ref[:, c], rtol=1e-12, atol=1e-15), (name, q, order)
+                else:
+                    assert np.array_equal(got[:, c], ref[:, c]), (name, q, order)
+            for ci in range(0, n, 7):
+                cc = int(cands[ci])
+                a, b = (oh[cc], oh[q]) if order == api.ORDER_CAND_FIRST else (oh[q], oh[cc])
+                for c in div_cols:
+                    exp = oracle.raw_feature(1 << FEATS[c][1], a, b)
+                    assert got[ci][c] == pytest.approx(exp, rel=RTOL, abs=1e-13), (FEATS[c][0], q, cc, order)
+    for h in oh:
+        oracle.lib().orc_hist_free(h)
