@@ -1582,7 +1582,18 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// (the divergence statistics too: counted per cell of (copy, query count) by the pass, evaluated per candidate in one fixed order by
 	// k_rank_div_finish -- msc_ranks_pass.hip; MSC_NO_RANKS_DIV keeps such passes on the merge kernel)
 	const bool no_rank_div = getenv("MSC_NO_RANKS_DIV") != nullptr;
-	if (lists && (!need_div || !no_rank_div) && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
+	// The divergence form only where lists are short (the query set's bound within what LDS holds, i.e. sequences of up to ~8 kb): a wave takes a
+	// whole candidate, and on cfg5's shape -- lists of 10 000 .. 50 000 k-mers, 1 600 .. 8 000 candidates per pass, homopolymer runs of
+	// thousands of copies -- that is 40 dependent chunk loads per wave with most of the chip idle (13.3 s against the merge kernel's 4.0 at
+	// 20 000 sequences): such passes stay with the merge kernel, which shares a candidate among waves.
+	// ... and only in the step-serial loop's own call (msc_get_close_window: rq.close_list) unless MSC_RANKS_DIV asks for it everywhere: the
+	// two FP64 sums of the rank form add the same terms in another order than the merge kernel's (they agree to ~1e-15 relative), and every
+	// OTHER route -- 1 x M by slot list, Q x M, the batched update stage, dense or sparse -- keeps returning bit-identical values for a pair
+	// (test_divergence_statistics_are_the_same_in_every_route). Within a window pass all candidates come from one kernel, so
+	// ties among them are decided as before.
+	const bool rank_div_wanted = rq.close_list.pos != nullptr || getenv("MSC_RANKS_DIV") != nullptr;
+	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && msc_ranks_pass_query_scratch(q_kmers) == 0 && c_sp && c_sp->max_nnz <= 8192);
+	if (lists && div_fits && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
 		int e = MSC_OK;
 		rank_pass = rank_lists_ready(ctx, c_sp, &e);
 		if (e) return e;

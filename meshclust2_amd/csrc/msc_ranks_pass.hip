@@ -8,7 +8,7 @@
 //     emd           = sum_t |a_t - b_t|                     the t-th k-mer of either histogram, both lists padded with 4^k (msc_emd_ranks.hip)
 //     sum e_c e_q   = sum over the candidate's entries of e_q(bin)
 //     sum min(e_c, e_q) = sum over the candidate's entries, the r-th copy of a bin (r = 0, 1, ..) counting [r < e_q(bin)]
-// e_q(bin) is a LOOKUP: the query's histogram sits in LDS as two bits per bin -- present (e_q >= 1) and large (e_q >= 2), one word per 16 bins -- shared by the
+// e_q(bin) is a LOOKUP: the query's histogram sits in LDS as two bits per bin -- e_q = 0, 1, 2 or "three and more" --, one word per 16 bins, shared by the
 // sixteen waves of a workgroup for every candidate they walk. An entry whose bin is not large in the query (all but a handful: a 1 kb
 // sequence at k = 9 has ~2 large bins) contributes its present bit to the product and, if it is the first copy of its bin, to the minimum;
 // the rare entry that hits a large bin looks e_q up in the query's own rank list (LDS, binary search) and its copy number r in the
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
 		const uint2 en = Q[j];
 		const uint32_t e = en.y ? en.y - 1u : 0u, end = CQ[j];
-		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 2 ? 3u : 1u) << (2 * (en.x & 15)));
+		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));          // two bits per bin: e_q = 0, 1, 2, or 3 = "three and more: look it up"
 		if constexpr (!QG) for (uint32_t t = end - e; t < end; t++) rq_l[t] = en.x;
 	}
 	__syncthreads();
@@ -288,44 +288,39 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
 				const uint32_t av[4] = {a.x, a.y, a.z, a.w};
 				const uint32_t pv[4] = {before, a.x, a.y, a.z};
-				uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // DIV: the seven entries in front of a lane's last
-				if constexpr (DIV) {
-					seq[0] = __shfl_up(a.x, 1, 64); seq[1] = __shfl_up(a.y, 1, 64); seq[2] = __shfl_up(a.z, 1, 64);
-					if (lane == 0) { seq[0] = carry_x; seq[1] = carry_y; seq[2] = carry_z; }
-					carry_x = (uint32_t)__builtin_amdgcn_readlane((int)a.x, 63);
-					carry_y = (uint32_t)__builtin_amdgcn_readlane((int)a.y, 63);
-					carry_z = (uint32_t)__builtin_amdgcn_readlane((int)a.z, 63);
-				}
+				uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // the seven entries in front of a lane's last: an entry's copy index
+				seq[0] = __shfl_up(a.x, 1, 64); seq[1] = __shfl_up(a.y, 1, 64); seq[2] = __shfl_up(a.z, 1, 64);
+				if (lane == 0) { seq[0] = carry_x; seq[1] = carry_y; seq[2] = carry_z; }
+				carry_x = (uint32_t)__builtin_amdgcn_readlane((int)a.x, 63);
+				carry_y = (uint32_t)__builtin_amdgcn_readlane((int)a.y, 63);
+				carry_z = (uint32_t)__builtin_amdgcn_readlane((int)a.z, 63);
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
 					const uint32_t bin = av[j];
 					const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;          // (the padding value 4^k reads the zero word behind the table)
-					const uint32_t present = two & 1u;
+					const bool first_copy = bin != pv[j];
+					const uint32_t present = two ? 1u : 0u;
 					prod += present;
-					mins += present & (bin != pv[j] ? 1u : 0u);
-					uint32_t e_q = present, r_known = 0xffffffffu;
-					if (two & 2u) {          // rare: this k-mer is repeated in the query
+					mins += present & (first_copy ? 1u : 0u);
+					uint32_t e_q = two;
+					if (two == 3u) {          // very rare: the query holds this k-mer three times or more -- how often, says its own rank list
 						const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
-						e_q = 0;
-						while (lo + e_q < nq_tot && rq[lo + e_q] == bin) e_q++;
-						const uint32_t r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // this entry is the r-th copy of its bin
-						prod += e_q - 1;
-						if (r >= 1 && r < e_q) mins += 1;
-						r_known = r;
+						e_q = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin + 1) - lo;          // (two searches: a homopolymer run is thousands of copies)
+					}
+					if (e_q >= 2) prod += e_q - 1;
+					uint32_t r = 0;
+					const bool real = bin < nbins;          // (not the padding behind the list's end)
+					if (real && !first_copy && (DIV || e_q >= 2)) {          // rare: a further copy of a bin: its copy index from the entries in front of it
+						for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
+						if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
+						if (r < e_q) mins += 1;
 					}
 					if constexpr (DIV) {
-						const bool real = bin < nbins, first_copy = bin != pv[j];
 						const uint32_t b = e_q + 1;          // the bin's count in the query
 						const bool plain = real && first_copy && b <= 2;
 						c01 += plain && b == 1 ? 1u : 0u;
 						c02 += plain && b == 2 ? 1u : 0u;
 						if (real && !plain) {          // rare: a further copy of a bin, or a bin the query holds more than once
-							uint32_t r = first_copy ? 0u : r_known;
-							if (r == 0xffffffffu) {
-								r = 0;
-								for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
-								if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
-							}
 							if (r < 7 && b < 8) atomicAdd(&s_cnt[wave][r * 8 + b], 1u);
 							else {
 								const RkDivTerm hi = rk_div_term_call(r + 2, b, cm, qm, order), lo = rk_div_term_call(r + 1, b, cm, qm, order);

@@ -14,8 +14,8 @@ from meshclust2_amd import synth
 seqs, hdrs = synth.families(777, $N, 1000, length_jitter=100)
 synth.write_fasta("/tmp/jit_$N.fa", seqs, hdrs)
 PY
-W=$R/tests/golden/weights_k9_u8.txt
-ARGS="/tmp/jit_$N.fa --recover $W --id 0.9 --kmer 9 --datatype 8"
+W=${JITTER_WEIGHTS:-$R/tests/golden/weights_k9_u8.txt}
+ARGS="/tmp/jit_$N.fa --recover $W --id 0.9 --kmer 9 --datatype ${JITTER_DTYPE:-8}"
 MSC_CLUSTER_PROFILE=1 MSC_PROFILE_CALLS=1 $R/meshclust2_amd/host/msc_cluster $ARGS --output /tmp/jit.clstr "$@" > $O/plain.log 2>&1
 grep -E "timestamp|Number of clusters|profile|\[msc\]" $O/plain.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- $R/meshclust2_amd/host/msc_cluster $ARGS --output /tmp/jit2.clstr "$@" > $O/stats.log 2>&1
