@@ -123,25 +123,27 @@ __global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restr
 	}
 }
 
-// one thread per candidate: its two sums from its cell counts
+// eight lanes per candidate, lane b = the cells of query count b (b = 0: the counts >= 8 of the query's own list): each lane adds its
+// column, the eight partial sums are added in a fixed tree -- a candidate's result does not depend on who its neighbours in the launch are
 __global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restrict__ cells, const double* __restrict__ extras, const uint32_t* __restrict__ hq,
                                                          const uint32_t* __restrict__ big, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
                                                          const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_scalars, int order,
                                                          double* __restrict__ div_out) {
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= m) return;
-	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : (uint64_t)c;
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
+	const bool live = c < m;
+	const uint32_t cc = live ? c : m - 1;
+	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[cc] : (uint64_t)cc;
 	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + slot * scalar_stride)->mag;
 	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
 	const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
-	const uint32_t* n = cells + (uint64_t)c * kRkCells;
+	const uint32_t* n = cells + (uint64_t)cc * kRkCells;
 	double jd = 0.0, js = 0.0;
-	for (uint32_t b = 1; b < 8; b++) {
+	if (b >= 1) {
 		for (uint32_t r = 0; r < 7; r++) {
 			const uint32_t k = n[r * 8 + b];
 			if (!k) continue;
 			RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
-			if (r) { const RkDivTerm g = rk_div_term_call(r + 1, b, cm, qm, order); f.jd -= g.jd; f.js -= g.js; }
+			if (r) { const RkDivTerm g2 = rk_div_term_call(r + 1, b, cm, qm, order); f.jd -= g2.jd; f.js -= g2.js; }
 			else { f.jd -= t11.jd; f.js -= t11.js; }
 			jd += (double)k * f.jd;
 			js += (double)k * f.js;
@@ -154,15 +156,19 @@ __global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restr
 				js += (double)k * (f.js - t11.js);
 			}
 		}
+	} else {
+		const uint32_t n_big = hq[8];
+		for (uint32_t i = 0; i < n_big; i++) {          // ... and those with count >= 8 (the pass took back the ones the candidate holds)
+			const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
+			jd += f.jd - t11.jd;
+			js += f.js - t11.js;
+		}
+		jd += extras[2 * (uint64_t)cc];
+		js += extras[2 * (uint64_t)cc + 1];
 	}
-	const uint32_t n_big = hq[8];
-	for (uint32_t i = 0; i < n_big; i++) {          // ... and those with count >= 8 (the pass took back the ones the candidate holds)
-		const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
-		jd += f.jd - t11.jd;
-		js += f.js - t11.js;
-	}
-	div_out[2 * (uint64_t)c] = jd + extras[2 * (uint64_t)c];
-	div_out[2 * (uint64_t)c + 1] = js + extras[2 * (uint64_t)c + 1];
+#pragma unroll
+	for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+	if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
 }
 
 // ------------------------------------------------------------------------------------------------ the pass
@@ -444,6 +450,6 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 #undef MSC_RP_GO
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || !dv) return e;
-	k_rank_div_finish<<<dim3((m + 255) / 256), dim3(256), 0, st>>>(dv->cells, dv->extras, dv->hq, dv->big, cand_scalars, scalar_stride, cand_slots, m, dv->q_scalars, dv->order, dv->div_out);
+	k_rank_div_finish<<<dim3((unsigned)(((uint64_t)m * 8 + 255) / 256)), dim3(256), 0, st>>>(dv->cells, dv->extras, dv->hq, dv->big, cand_scalars, scalar_stride, cand_slots, m, dv->q_scalars, dv->order, dv->div_out);
 	return hipGetLastError();
 }
