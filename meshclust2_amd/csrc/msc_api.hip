@@ -159,6 +159,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->kb_abits);
 	release(ctx->kb_anib);
 	release(ctx->rk_q);
+	release(ctx->rk_acc);
 	release(ctx->rk_cells);
 	release(ctx->rk_extras);
 	release(ctx->rk_hq);
@@ -1592,7 +1593,15 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// (test_divergence_statistics_are_the_same_in_every_route). Within a window pass all candidates come from one kernel, so
 	// ties among them are decided as before.
 	const bool rank_div_wanted = rq.close_list.pos != nullptr || getenv("MSC_RANKS_DIV") != nullptr;
-	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && msc_ranks_pass_query_scratch(q_kmers) == 0 && c_sp && c_sp->max_nnz <= 8192);
+	// Long lists (more than 8 192 k-mers on either side) go through k_pair_ranks_items: the unit of work is a round of 1 024 entries of a
+	// candidate, so a window of a few thousand long candidates still fills the chip (MSC_NO_RANKS_ITEMS: such passes stay on the merge kernel
+	// when they carry divergence statistics, on k_pair_ranks_1xm otherwise).
+	const uint64_t c_kmers = c_sp && c_sp->max_sum >= L.nbins ? c_sp->max_sum - L.nbins : ~0ull;          // bound on the k-mers of any candidate
+	const bool long_lists = q_kmers > 8192 || c_kmers > 8192;
+	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26);
+	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
+	bool rank_items = false;
+	uint32_t rank_rounds = 0;
 	if (lists && div_fits && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
 		int e = MSC_OK;
 		rank_pass = rank_lists_ready(ctx, c_sp, &e);
@@ -1601,8 +1610,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));
 			*ctx->rk_guard = 0;
 		}
-		if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
-		if (rank_pass) ctx->last_kernel = "k_pair_ranks_1xm";
+		rank_items = rank_pass && long_lists && items_ok;
+		if (rank_items) {
+			rank_rounds = (uint32_t)((std::max(q_kmers, c_kmers) + msc_ranks_items_round() - 1) / msc_ranks_items_round());
+			if ((r = ensure(ctx, ctx->rk_q, ((q_kmers + 255) & ~255ull) * sizeof(uint32_t) + 1024))) return r;
+		} else if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
+		if (rank_pass) ctx->last_kernel = rank_items ? "k_pair_ranks_items" : "k_pair_ranks_1xm";
 	}
 	// a sparse set's integer statistics through the merge-path kernel: a short window is shared out, several waves per candidate
 	// (never the divergence form: its FP64 sums keep one evaluation order whatever the window)
@@ -1628,8 +1641,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
+	if (rank_items && (r = ensure(ctx, ctx->rk_acc, chunk * 4 * sizeof(uint64_t)))) return r;
 	if (rank_div) {
-		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * 2 * sizeof(double))) ||
+		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * std::max<uint32_t>(1, rank_rounds) * 2 * sizeof(double))) ||
 		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
 			return r;
 	}
@@ -1669,7 +1683,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			                                       (uint64_t*)ctx->prof_nnz.p + (rank_pass ? 2 : 0)));
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
-		if (lists && rank_pass) {
+		if (lists && rank_items) {
+			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
+			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
+			                                         q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus,
+			                                         (uint32_t*)ctx->rk_q.p, rank_rounds, (unsigned long long*)ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard));
+		} else if (lists && rank_pass) {
 			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
 			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p,

@@ -76,9 +76,13 @@ __global__ void __launch_bounds__(256) k_rkl_fill(const uint2* __restrict__ ent,
 
 // the rank list of ONE slot into out[0 .. n), padded with 4^k to a multiple of 256 (the query of a pass when it is too long for LDS)
 __global__ void __launch_bounds__(1024) k_rank_expand_one(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
-                                                          uint32_t* __restrict__ out) {
+                                                          uint32_t* __restrict__ out, uint32_t cap, uint32_t* __restrict__ guard) {
 	const MscSparseHdr h = *hdr_p;
 	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
+	if (pad > cap) {          // the set's bound did not hold: say so and write nothing
+		if (blockIdx.x == 0 && threadIdx.x == 0 && guard) atomicOr(guard, 1u);
+		return;
+	}
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
 		const uint2 en = ent[h.off + j];
 		const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
@@ -378,6 +382,239 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ long lists: (candidate, round) items
+// k_pair_ranks_1xm gives a candidate to ONE wave. With lists of tens of thousands of k-mers and windows of a few thousand candidates
+// (BASELINE cfg5: sequences of 500 b - 50 kb) that is forty dependent loads per wave and most of the chip idle. Here the unit of work is a
+// ROUND of a candidate -- kRiRound consecutive entries of its rank list -- and any wave takes any round:
+//   * an entry's role depends on its neighbours only (first / last copy of its bin), which a round reads from global memory at its two
+//     ends; a run of copies that began before the round is found by one binary search per run;
+//   * every BIN is accounted for once, at its LAST copy, with its count e_c = the copy index + 1 (from a prefix maximum of first-copy
+//     positions over the round) and the query's e_q (two bits in LDS; three and more: a hash table in LDS of the query's few such bins):
+//     e_c e_q into the product, min(e_c, e_q) into the minimum, the pair of counts into the divergence cells;
+//   * a round's integer sums go into its candidate's accumulators with atomics (integers: any order), its divergence spot terms into a
+//     slot of its own; k_rank_items_finish turns accumulators, cells and slots into the candidate's records in a fixed order.
+constexpr uint32_t kRiRound = 1024;
+constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the query's bins with e_q >= 3 (at most half are used)
+
+template <bool DIV>
+__global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
+                                                                const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
+                                                                uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
+                                                                uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, const uint32_t* __restrict__ rq, uint32_t rounds,
+                                                                unsigned long long* __restrict__ acc, uint32_t* __restrict__ cells, double* __restrict__ extras,
+                                                                const uint8_t* __restrict__ q_scalars, int order) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
+	__shared__ uint32_t s_key[kRiHash], s_val[kRiHash];
+	__shared__ uint32_t s_nbig;
+	const uint32_t words = nbins / 16 + 1;
+	uint32_t* sb = s_rp;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint32_t nq = qh.nnz;
+	const uint2* Q = q_ent + qh.off;
+	const uint32_t nq_tot = nq ? q_cum[qh.off + nq - 1] : 0u;
+	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
+	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = 0u;
+	for (uint32_t i = threadIdx.x; i < kRiHash; i += kRpBlock) s_key[i] = 0xffffffffu;
+	if (threadIdx.x == 0) s_nbig = 0;
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
+		const uint2 en = Q[j];
+		const uint32_t e = en.y ? en.y - 1u : 0u;
+		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
+		if (e >= 3 && atomicAdd(&s_nbig, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
+			uint32_t h = (en.x * 2654435761u) >> 22;
+			for (;;) {
+				const uint32_t old = atomicCAS(&s_key[h], 0xffffffffu, en.x);
+				if (old == 0xffffffffu || old == en.x) { s_val[h] = e; break; }
+				h = (h + 1) & (kRiHash - 1);
+			}
+		}
+	}
+	__syncthreads();
+	const bool hash_ok = s_nbig <= kRiHash / 2;
+	auto e_q_of = [&](uint32_t bin) -> uint32_t {          // a bin the table marks "three and more"
+		if (hash_ok) {
+			uint32_t h = (bin * 2654435761u) >> 22;
+			while (s_key[h] != bin) h = (h + 1) & (kRiHash - 1);
+			return s_val[h];
+		}
+		const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
+		return lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin + 1) - lo;
+	};
+	double qm = 0.0;
+	if constexpr (DIV) qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	const uint64_t n_items = (uint64_t)m * rounds;
+	const uint64_t n_waves = (uint64_t)gridDim.x * (kRpBlock / 64);
+	for (uint64_t it = (uint64_t)blockIdx.x * (kRpBlock / 64) + wave; it < n_items; it += n_waves) {
+		const uint32_t c = (uint32_t)(it / rounds), rd = (uint32_t)(it % rounds);
+		const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
+		const uint32_t nc = c_n[slot], nc_pad = (nc + 3u) & ~3u;
+		const uint32_t T = nc > nq_tot ? nc : nq_tot;
+		const uint32_t t0 = rd * kRiRound;
+		if (t0 >= T) continue;
+		const uint32_t* P = c_rk + c_off[slot];
+		const double cm = DIV ? (double)cs->mag : 0.0;
+		RkDivTerm t11{0.0, 0.0};
+		if constexpr (DIV) t11 = rk_div_term_call(1, 1, cm, qm, order);
+		uint4 a[4], b[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) {
+			const uint32_t t = t0 + 256 * u + 4 * lane;
+			a[u] = make_uint4(nbins, nbins, nbins, nbins);
+			b[u] = a[u];
+			if (t < nc_pad) a[u] = *reinterpret_cast<const uint4*>(P + t);
+			if (t < nq_pad) b[u] = *reinterpret_cast<const uint4*>(rq + t);
+		}
+		const uint32_t before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
+		const uint32_t after_round = t0 + kRiRound < nc ? P[t0 + kRiRound] : nbins;           // ... and the one behind it
+		uint64_t emd = 0, prod = 0;
+		uint32_t mins = 0, c01 = 0, c02 = 0;
+		double xjd = 0.0, xjs = 0.0;
+		uint32_t run_carry = 0;          // 1 + the round-local position of the latest first copy so far (0: none yet in this round)
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) {
+			if (t0 + 256 * u >= T) break;
+			const uint4 av = a[u], bv = b[u];
+			uint32_t d = sad_u32(av.x, bv.x, 0u);
+			d = sad_u32(av.y, bv.y, d);
+			d = sad_u32(av.z, bv.z, d);
+			d = sad_u32(av.w, bv.w, d);
+			emd += d;
+			uint32_t prev = __shfl_up(av.w, 1, 64), next = __shfl_down(av.x, 1, 64);
+			if (lane == 0) prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)a[u ? u - 1 : 0].w, 63) : before_round;
+			if (lane == 63) next = u < 3 ? (uint32_t)__builtin_amdgcn_readlane((int)a[u < 3 ? u + 1 : 3].x, 0) : after_round;
+			const uint32_t e4[4] = {av.x, av.y, av.z, av.w};
+			const uint32_t p4[4] = {prev, av.x, av.y, av.z};
+			const uint32_t n4[4] = {av.y, av.z, av.w, next};
+			const uint32_t tl = 256 * u + 4 * lane;          // round-local position of e4[0]
+			// where the run an entry belongs to began: the latest first copy at or before it (prefix maximum over the round)
+			uint32_t pf[4], lane_max = 0;
+#pragma unroll
+			for (int j = 0; j < 4; j++) { pf[j] = e4[j] != p4[j] ? tl + j + 1 : 0u; lane_max = pf[j] > lane_max ? pf[j] : lane_max; }
+			uint32_t incl = lane_max;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off && o > incl) incl = o; }
+			uint32_t run = __shfl_up(incl, 1, 64);
+			if (lane == 0) run = 0;
+			run = run > run_carry ? run : run_carry;
+			const uint32_t last_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			run_carry = last_incl > run_carry ? last_incl : run_carry;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				run = pf[j] ? pf[j] : run;
+				const uint32_t bin = e4[j];
+				if (bin >= nbins || bin == n4[j]) continue;          // padding, or not the last copy of its bin
+				uint32_t e_c = 1;
+				if (!pf[j]) {          // a run of copies ends here
+					const uint32_t begin = run ? t0 + run - 1 : lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (run == 0: it began before the round)
+					e_c = t0 + tl + j - begin + 1;
+				}
+				const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;
+				const uint32_t e_q = two < 3 ? two : e_q_of(bin);
+				prod += (uint64_t)e_c * e_q;
+				mins += e_c < e_q ? e_c : e_q;
+				if constexpr (DIV) {
+					const uint32_t ca = e_c + 1, cb = e_q + 1;          // the bin's counts in the candidate and in the query
+					const bool plain = ca == 2 && cb <= 2;
+					c01 += plain && cb == 1 ? 1u : 0u;
+					c02 += plain && cb == 2 ? 1u : 0u;
+					if (!plain) {
+						if (cb < 8) atomicAdd(&cells[(uint64_t)c * kRkCells + (ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);          // (row 7: counted as held, evaluated here)
+						if (ca >= 9 || cb >= 8) {
+							const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
+							RkDivTerm lo = t11;
+							if (cb >= 8) lo = rk_div_term_call(1, cb, cm, qm, order);          // (the finish adds F(1, b) for every such bin of the query)
+							xjd += hi.jd - lo.jd;
+							xjs += hi.js - lo.js;
+						}
+					}
+				}
+			}
+		}
+		const uint64_t emd_t = wave_sum_u64(emd), prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
+		if (lane == 0) {
+			atomicAdd(&acc[4 * (uint64_t)c], (unsigned long long)emd_t);
+			atomicAdd(&acc[4 * (uint64_t)c + 1], (unsigned long long)prod_t);
+			atomicAdd(&acc[4 * (uint64_t)c + 2], (unsigned long long)mins_t);
+		}
+		if constexpr (DIV) {
+			const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
+#pragma unroll
+			for (int off = 32; off >= 1; off >>= 1) { xjd += __shfl_xor(xjd, off, 64); xjs += __shfl_xor(xjs, off, 64); }
+			if (lane == 0) {
+				if (c01_t) atomicAdd(&cells[(uint64_t)c * kRkCells + 1], c01_t);
+				if (c02_t) atomicAdd(&cells[(uint64_t)c * kRkCells + 2], c02_t);
+				extras[2 * ((uint64_t)c * rounds + rd)] = xjd;
+				extras[2 * ((uint64_t)c * rounds + rd) + 1] = xjs;
+			}
+		}
+	}
+}
+
+// eight lanes per candidate: the integer record from the accumulators; DIV: the two sums from the cells (row a' = candidate count a' + 2,
+// row 7 = bins evaluated on the spot, counted as held), the query's counts of counts and the rounds' spot terms in round order
+template <bool DIV>
+__global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long long* __restrict__ acc, const uint32_t* __restrict__ cells, const double* __restrict__ extras, uint32_t rounds,
+                                                           const uint32_t* __restrict__ hq, const uint32_t* __restrict__ big, const uint32_t* __restrict__ c_n,
+                                                           const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                           const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order,
+                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard) {
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
+	const bool live = c < m;
+	const uint32_t cc = live ? c : m - 1;
+	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[cc] : first + cc;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)cc) * scalar_stride);
+	if (live && b == 0) {
+		const MscSparseHdr qh = *q_hdr_p;
+		const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = c_n[slot];
+		if (nc > (uint64_t)rounds * kRiRound || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);          // (a list longer than its set's bound: the host fails the call)
+		MscPartial out;
+		out.manh = nc + nq_tot - 2 * acc[4 * (uint64_t)c + 2];
+		out.dot = acc[4 * (uint64_t)c + 1] + nc + nq_tot;
+		out.emd = acc[4 * (uint64_t)c];
+		partials[c] = out;
+	}
+	if constexpr (DIV) {
+		const double cm = (double)cs->mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+		const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
+		const uint32_t* n = cells + (uint64_t)cc * kRkCells;
+		double jd = 0.0, js = 0.0;
+		if (b >= 1) {
+			uint32_t held = n[7 * 8 + b];
+			for (uint32_t r = 0; r < 7; r++) {
+				const uint32_t k = n[r * 8 + b];
+				if (!k) continue;
+				held += k;
+				const RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
+				jd += (double)k * (f.jd - t11.jd);
+				js += (double)k * (f.js - t11.js);
+			}
+			if (b >= 2) {          // the query's bins with count b that the candidate does not hold
+				const uint32_t k = hq[b] - held;
+				if (k) {
+					const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
+					jd += (double)k * (f.jd - t11.jd);
+					js += (double)k * (f.js - t11.js);
+				}
+			}
+		} else {
+			const uint32_t n_big = hq[8];
+			for (uint32_t i = 0; i < n_big; i++) {
+				const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
+				jd += f.jd - t11.jd;
+				js += f.js - t11.js;
+			}
+			for (uint32_t r = 0; r < rounds; r++) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }
+		}
+#pragma unroll
+		for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+		if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
+	}
+}
+
 }  // namespace
 
 // bytes of dynamic LDS the pass needs for 4^k = nbins and query lists of up to q_kmers entries; 0 when the histogram is too large for it
@@ -423,7 +660,7 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	if (qg) k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch);
+	if (qg) k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard);
 	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
@@ -451,5 +688,48 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess || !dv) return e;
 	k_rank_div_finish<<<dim3((unsigned)(((uint64_t)m * 8 + 255) / 256)), dim3(256), 0, st>>>(dv->cells, dv->extras, dv->hq, dv->big, cand_scalars, scalar_stride, cand_slots, m, dv->q_scalars, dv->order, dv->div_out);
+	return hipGetLastError();
+}
+
+// The pass over long lists: (candidate, round) items. rounds = rounds of kRiRound entries that cover the longest list involved (host
+// bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; acc: m x 4 uint64_t; dv (optional): the divergence scratch --
+// cells m x 64, extras m x rounds x 2 -- all zeroed here.
+uint32_t msc_ranks_items_round() { return kRiRound; }
+hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
+                                       const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
+                                       int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
+                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard) {
+	if (m == 0) return hipSuccess;
+	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc || rounds == 0) return hipErrorInvalidValue;
+	const size_t lds = (nbins / 16 + 1 + 4) * 4;
+	hipError_t e = hipMemsetAsync(acc, 0, (size_t)m * 4 * sizeof(unsigned long long), st);
+	if (e != hipSuccess) return e;
+	if (dv) {
+		if ((e = hipMemsetAsync(dv->cells, 0, (size_t)m * kRkCells * sizeof(uint32_t), st)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(dv->extras, 0, (size_t)m * rounds * 2 * sizeof(double), st)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(dv->hq, 0, 16 * sizeof(uint32_t), st)) != hipSuccess) return e;
+		k_rank_query_counts<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_hdr, dv->hq, dv->big);
+	}
+	k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard);
+	static bool attr_set = false;
+	if (!attr_set) {
+		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	const uint64_t items = (uint64_t)m * rounds;
+	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
+	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
+	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
+	                                                                             (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, dv->cells, dv->extras, dv->q_scalars, dv->order);
+	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
+	                                                                          (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, nullptr, nullptr, nullptr, 0);
+	if ((e = hipGetLastError()) != hipSuccess) return e;
+	const dim3 fgrid((unsigned)(((uint64_t)m * 8 + 255) / 256));
+	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, dv->cells, dv->extras, rounds, dv->hq, dv->big, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
+	                                                                dv->q_scalars, dv->order, partials, dv->div_out, guard);
+	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(acc, nullptr, nullptr, rounds, nullptr, nullptr, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
+	                                                             nullptr, 0, partials, nullptr, guard);
 	return hipGetLastError();
 }
