@@ -30,6 +30,7 @@ struct msc_ctx {
 	// growable device scratch
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
 	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg, seq_ids, seq_meta;
+	DevBuf rk_items;                       // ... its list of (candidate, round) items
 	DevBuf rk_acc;                         // ... of its long-list form: a candidate's integer accumulators (k_pair_ranks_items)
 	DevBuf rk_cells, rk_extras, rk_hq, rk_big;          // ... and the scratch of its divergence form (MscRankDiv)
 	DevBuf rk_q;                           // the rank list of a pass's query when it is too long for LDS (msc_ranks_pass.hip)

@@ -28,6 +28,26 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 	return v;
 }
 
+// neighbours in the wave by DPP (gfx9 wave shifts): __shfl_up / __shfl_down compile to ds_bpermute_b32, an LDS round trip each, and the
+// walks below take a neighbour or a prefix for every 256 entries. Lanes without a source read 0.
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }          // wave_shr:1: lane l <- lane l - 1
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }          // wave_shl:1: lane l <- lane l + 1
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+	const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+	return o > v ? o : v;
+}
+// inclusive prefix maximum over the 64 lanes (row_shr 1, 2, 4, 8, then row_bcast 15 / 31: the steps of wave_incl_scan)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+	v = dpp_max<0x111, 0xf>(v);
+	v = dpp_max<0x112, 0xf>(v);
+	v = dpp_max<0x114, 0xf>(v);
+	v = dpp_max<0x118, 0xf>(v);
+	v = dpp_max<0x142, 0xa>(v);
+	v = dpp_max<0x143, 0xc>(v);
+	return v;
+}
+
 constexpr uint32_t kRpBlock = 1024;          // sixteen waves share the query's tables
 constexpr uint32_t kRpQCap = 8192;           // longest query rank list (host-checked against the set's bound)
 
@@ -120,10 +140,17 @@ constexpr uint32_t kRkCells = 64;          // cell (r, b) at r * 8 + b, r < 7 (7
 // big[..] their counts (any order: the finish kernel adds them up per candidate in list order, the same for every candidate)
 __global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr_p, uint32_t* __restrict__ hq, uint32_t* __restrict__ big) {
 	const MscSparseHdr h = *hdr_p;
+	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // (one atomic per wave and count: ten thousand adds to six addresses took 109 us)
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
 		const uint32_t v = ent[h.off + j].y;
-		if (v >= 2 && v < 8) atomicAdd(&hq[v], 1u);
-		else if (v >= 8) big[atomicAdd(&hq[8], 1u)] = v;
+#pragma unroll
+		for (uint32_t x = 2; x < 8; x++) cnt[x] += v == x ? 1u : 0u;
+		if (v >= 8) big[atomicAdd(&hq[8], 1u)] = v;
+	}
+#pragma unroll
+	for (uint32_t x = 2; x < 8; x++) {
+		const uint32_t t = (uint32_t)wave_sum_u64(cnt[x]);
+		if ((threadIdx.x & 63) == 0 && t) atomicAdd(&hq[x], t);
 	}
 }
 
@@ -293,13 +320,13 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				d = sad_u32(a.z, b.z, d);
 				d = sad_u32(a.w, b.w, d);
 				emd += d;
-				uint32_t before = __shfl_up(a.w, 1, 64);
+				uint32_t before = lane_prev(a.w);
 				if (lane == 0) before = carry;
 				carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
 				const uint32_t av[4] = {a.x, a.y, a.z, a.w};
 				const uint32_t pv[4] = {before, a.x, a.y, a.z};
 				uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // the seven entries in front of a lane's last: an entry's copy index
-				seq[0] = __shfl_up(a.x, 1, 64); seq[1] = __shfl_up(a.y, 1, 64); seq[2] = __shfl_up(a.z, 1, 64);
+				seq[0] = lane_prev(a.x); seq[1] = lane_prev(a.y); seq[2] = lane_prev(a.z);
 				if (lane == 0) { seq[0] = carry_x; seq[1] = carry_y; seq[2] = carry_z; }
 				carry_x = (uint32_t)__builtin_amdgcn_readlane((int)a.x, 63);
 				carry_y = (uint32_t)__builtin_amdgcn_readlane((int)a.y, 63);
@@ -396,13 +423,57 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 constexpr uint32_t kRiRound = 1024;
 constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the query's bins with e_q >= 3 (at most half are used)
 
+// The items of a pass, as a list: a candidate's rounds are counted (0 for a candidate the length window drops), scanned, written out -- the
+// pass then walks real items only (with the host's bound, rounds per candidate = that of the LONGEST list of the set: on mixed lengths
+// four items in five were empty, and finding that out cost a wave three dependent loads each).
+struct RkItemMeta { uint64_t off; uint32_t n, rounds; };
+__global__ void __launch_bounds__(256) k_rank_items_meta(const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                         const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m, const uint32_t* __restrict__ q_cum,
+                                                         const MscSparseHdr* __restrict__ q_hdr_p, int use_window, uint64_t min_len, uint64_t max_len, RkItemMeta* __restrict__ meta) {
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= m) return;
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint32_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
+	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+	RkItemMeta mt{c_off[slot], c_n[slot], 0};
+	if (!(use_window && (cs->length < min_len || cs->length > max_len))) {
+		const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
+		mt.rounds = (T + kRiRound - 1) / kRiRound;
+	}
+	meta[c] = mt;
+}
+// one workgroup: start[c] = items in front of candidate c, start[m] = their number; then every thread writes its candidates' items
+__global__ void __launch_bounds__(1024) k_rank_items_list(const RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ start, uint2* __restrict__ items) {
+	__shared__ uint32_t s_part[1024];
+	const uint32_t per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+	uint32_t sum = 0;
+	for (uint32_t c = lo; c < hi; c++) sum += meta[c].rounds;
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) {
+		const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = s_part[threadIdx.x] - sum;
+	for (uint32_t c = lo; c < hi; c++) {
+		const uint32_t r = meta[c].rounds;
+		for (uint32_t rd = 0; rd < r; rd++) items[run + rd] = make_uint2(c, rd);
+		run += r;
+	}
+	if (threadIdx.x == 1023) start[0] = s_part[1023];          // the number of items
+}
+
 template <bool DIV>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
                                                                 const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
                                                                 uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
                                                                 uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, const uint32_t* __restrict__ rq, uint32_t rounds,
                                                                 unsigned long long* __restrict__ acc, uint32_t* __restrict__ cells, double* __restrict__ extras,
-                                                                const uint8_t* __restrict__ q_scalars, int order) {
+                                                                const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta, const uint2* __restrict__ items,
+                                                                const uint32_t* __restrict__ n_items_p) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	__shared__ uint32_t s_key[kRiHash], s_val[kRiHash];
 	__shared__ uint32_t s_nbig;
@@ -444,19 +515,26 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	};
 	double qm = 0.0;
 	if constexpr (DIV) qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
-	const uint64_t n_items = (uint64_t)m * rounds;
-	const uint64_t n_waves = (uint64_t)gridDim.x * (kRpBlock / 64);
-	for (uint64_t it = (uint64_t)blockIdx.x * (kRpBlock / 64) + wave; it < n_items; it += n_waves) {
-		const uint32_t c = (uint32_t)(it / rounds), rd = (uint32_t)(it % rounds);
-		const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
-		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-		if (use_window && (cs->length < min_len || cs->length > max_len)) continue;
-		const uint32_t nc = c_n[slot], nc_pad = (nc + 3u) & ~3u;
+	const uint32_t n_items = *n_items_p;
+	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
+	(void)use_window; (void)min_len; (void)max_len; (void)c_off; (void)c_n;
+	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
+	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
+	RkItemMeta mt_n = meta[item_n.x];
+	for (; it < n_items; it += n_waves) {
+		const uint2 item = item_n;
+		const RkItemMeta mt = mt_n;
+		if (it + n_waves < n_items) { item_n = items[it + n_waves]; mt_n = meta[item_n.x]; }          // (the next item's record while this one is scored)
+		const uint32_t c = item.x, rd = item.y;
+		const uint32_t nc = mt.n, nc_pad = (nc + 3u) & ~3u;
 		const uint32_t T = nc > nq_tot ? nc : nq_tot;
 		const uint32_t t0 = rd * kRiRound;
-		if (t0 >= T) continue;
-		const uint32_t* P = c_rk + c_off[slot];
-		const double cm = DIV ? (double)cs->mag : 0.0;
+		const uint32_t* P = c_rk + mt.off;
+		double cm = 0.0;
+		if constexpr (DIV) {
+			const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+			cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride)->mag;
+		}
 		RkDivTerm t11{0.0, 0.0};
 		if constexpr (DIV) t11 = rk_div_term_call(1, 1, cm, qm, order);
 		uint4 a[4], b[4];
@@ -483,7 +561,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			d = sad_u32(av.z, bv.z, d);
 			d = sad_u32(av.w, bv.w, d);
 			emd += d;
-			uint32_t prev = __shfl_up(av.w, 1, 64), next = __shfl_down(av.x, 1, 64);
+			uint32_t prev = lane_prev(av.w), next = lane_next(av.x);
 			if (lane == 0) prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)a[u ? u - 1 : 0].w, 63) : before_round;
 			if (lane == 63) next = u < 3 ? (uint32_t)__builtin_amdgcn_readlane((int)a[u < 3 ? u + 1 : 3].x, 0) : after_round;
 			const uint32_t e4[4] = {av.x, av.y, av.z, av.w};
@@ -494,11 +572,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			uint32_t pf[4], lane_max = 0;
 #pragma unroll
 			for (int j = 0; j < 4; j++) { pf[j] = e4[j] != p4[j] ? tl + j + 1 : 0u; lane_max = pf[j] > lane_max ? pf[j] : lane_max; }
-			uint32_t incl = lane_max;
-#pragma unroll
-			for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off && o > incl) incl = o; }
-			uint32_t run = __shfl_up(incl, 1, 64);
-			if (lane == 0) run = 0;
+			const uint32_t incl = wave_incl_max(lane_max);
+			uint32_t run = lane_prev(incl);          // (lane 0: 0)
 			run = run > run_carry ? run : run_carry;
 			const uint32_t last_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 			run_carry = last_incl > run_carry ? last_incl : run_carry;
@@ -607,8 +682,8 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 				jd += f.jd - t11.jd;
 				js += f.js - t11.js;
 			}
-			for (uint32_t r = 0; r < rounds; r++) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }
 		}
+		for (uint32_t r = b; r < rounds; r += 8) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }          // (lane b: rounds b, b + 8, ..)
 #pragma unroll
 		for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
 		if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
@@ -698,7 +773,7 @@ uint32_t msc_ranks_items_round() { return kRiRound; }
 hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                        const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
                                        int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
-                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard) {
+                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch) {
 	if (m == 0) return hipSuccess;
 	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc || rounds == 0) return hipErrorInvalidValue;
 	const size_t lds = (nbins / 16 + 1 + 4) * 4;
@@ -718,13 +793,25 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	const uint64_t items = (uint64_t)m * rounds;
-	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
+	// item_scratch: [the number of items (16 bytes)][m records of 16 bytes][m x rounds items of 8 bytes]
+	if (!item_scratch) return hipErrorInvalidValue;
+	uint32_t* n_items = (uint32_t*)item_scratch;
+	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>((uint8_t*)item_scratch + 16);
+	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + 16 + (size_t)m * sizeof(RkItemMeta));
+	k_rank_items_meta<<<dim3((m + 255) / 256), dim3(256), 0, st>>>(c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr, use_window, min_len, max_len, meta);
+	k_rank_items_list<<<dim3(1), dim3(1024), 0, st>>>(meta, m, n_items, items_list);
+	const uint64_t items = (uint64_t)m * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
+	// (the divergence form takes 128 registers: sixteen waves of it fill a CU's register file, so one workgroup per CU -- a second one
+	// would only queue behind the first and pay its set-up again)
+	static const uint32_t per_cu_env = [] { const char* e = getenv("MSC_RANKS_ITEMS_PER_CU"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
+	const uint32_t per_cu = per_cu_env ? per_cu_env : dv ? 1u : (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
 	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
 	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                             (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, dv->cells, dv->extras, dv->q_scalars, dv->order);
+	                                                                             (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, dv->cells, dv->extras, dv->q_scalars, dv->order,
+	                                                                             meta, items_list, n_items);
 	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                          (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, nullptr, nullptr, nullptr, 0);
+	                                                                          (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, nullptr, nullptr, nullptr, 0,
+	                                                                          meta, items_list, n_items);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	const dim3 fgrid((unsigned)(((uint64_t)m * 8 + 255) / 256));
 	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, dv->cells, dv->extras, rounds, dv->hq, dv->big, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
