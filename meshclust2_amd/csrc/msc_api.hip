@@ -1642,7 +1642,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
-	if (rank_items && ((r = ensure(ctx, ctx->rk_acc, chunk * 4 * sizeof(uint64_t))) || (r = ensure(ctx, ctx->rk_items, 16 + chunk * 16 + chunk * (size_t)rank_rounds * 8)))) return r;
+	// (long lists: accumulators, cells, spot-term slots and the query's counts sit in ONE buffer, cleared by one command per pass)
+	if (rank_items && ((r = ensure(ctx, ctx->rk_acc, chunk * (32 + (rank_div ? 256 + (size_t)rank_rounds * 16 : 0)) + 64)) || (r = ensure(ctx, ctx->rk_items, 16 + chunk * 16 + chunk * (size_t)rank_rounds * 8)))) return r;
 	if (rank_div) {
 		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * std::max<uint32_t>(1, rank_rounds) * 2 * sizeof(double))) ||
 		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
@@ -1685,10 +1686,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
 		if (lists && rank_items) {
-			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
+			uint8_t* zb = (uint8_t*)ctx->rk_acc.p;
+			const size_t z_acc = (size_t)mc * 32, z_cells = rank_div ? (size_t)mc * 256 : 0, z_extras = rank_div ? (size_t)mc * rank_rounds * 16 : 0;
+			MscRankDiv dv{(uint32_t*)(zb + z_acc), (double*)(zb + z_acc + z_cells), (uint32_t*)(zb + z_acc + z_cells + z_extras), (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
 			                                         q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus,
-			                                         (uint32_t*)ctx->rk_q.p, rank_rounds, (unsigned long long*)ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard, ctx->rk_items.p));
+			                                         (uint32_t*)ctx->rk_q.p, rank_rounds, (unsigned long long*)ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard, ctx->rk_items.p, z_acc + z_cells + z_extras + (rank_div ? 64 : 0)));
 		} else if (lists && rank_pass) {
 			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,

@@ -220,7 +220,7 @@ uint32_t msc_ranks_items_round();
 hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                        const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
                                        int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
-                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch);
+                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch, size_t zero_bytes = 0);
 const char* msc_pair_gemm_kernel_name();          // "k_pair_gemm_fp4", or "k_pair_gemm_bits" under MSC_GEMM_I8
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
 uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn);

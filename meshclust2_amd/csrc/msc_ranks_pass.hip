@@ -154,6 +154,36 @@ __global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restr
 	}
 }
 
+// k_rank_expand_one and k_rank_query_counts in one launch (the long-list pass needs both of every query)
+__global__ void __launch_bounds__(1024) k_rank_query_prep(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
+                                                          uint32_t* __restrict__ out, uint32_t cap, uint32_t* __restrict__ guard, uint32_t* __restrict__ hq, uint32_t* __restrict__ big) {
+	const MscSparseHdr h = *hdr_p;
+	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
+	if (pad > cap) {
+		if (blockIdx.x == 0 && threadIdx.x == 0 && guard) atomicOr(guard, 1u);
+		return;
+	}
+	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
+		const uint2 en = ent[h.off + j];
+		const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
+		for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
+		if (hq) {
+#pragma unroll
+			for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
+			if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
+		}
+	}
+	if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
+	if (hq) {
+#pragma unroll
+		for (uint32_t x = 2; x < 8; x++) {
+			const uint32_t t = (uint32_t)wave_sum_u64(cnt[x]);
+			if ((threadIdx.x & 63) == 0 && t) atomicAdd(&hq[x], t);
+		}
+	}
+}
+
 // eight lanes per candidate, lane b = the cells of query count b (b = 0: the counts >= 8 of the query's own list): each lane adds its
 // column, the eight partial sums are added in a fixed tree -- a candidate's result does not depend on who its neighbours in the launch are
 __global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restrict__ cells, const double* __restrict__ extras, const uint32_t* __restrict__ hq,
@@ -444,8 +474,28 @@ __global__ void __launch_bounds__(256) k_rank_items_meta(const uint64_t* __restr
 	meta[c] = mt;
 }
 // one workgroup: start[c] = items in front of candidate c, start[m] = their number; then every thread writes its candidates' items
-__global__ void __launch_bounds__(1024) k_rank_items_list(const RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ start, uint2* __restrict__ items) {
+__global__ void __launch_bounds__(1024) k_rank_items_list(RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ start, uint2* __restrict__ items,
+                                                          const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                          const uint32_t* __restrict__ cand_slots, uint64_t first, const uint32_t* __restrict__ q_cum,
+                                                          const MscSparseHdr* __restrict__ q_hdr_p, int use_window, uint64_t min_len, uint64_t max_len) {
 	__shared__ uint32_t s_part[1024];
+	// the candidates' records first (a launch of its own was 5 us of every step), dealt thread by thread so that the loads coalesce
+	{
+		const MscSparseHdr qh = *q_hdr_p;
+		const uint32_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
+		for (uint32_t c = threadIdx.x; c < m; c += 1024) {
+			const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+			const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+			RkItemMeta mt{c_off[slot], c_n[slot], 0};
+			if (!(use_window && (cs->length < min_len || cs->length > max_len))) {
+				const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
+				mt.rounds = (T + kRiRound - 1) / kRiRound;
+			}
+			meta[c] = mt;
+		}
+	}
+	__threadfence_block();
+	__syncthreads();
 	const uint32_t per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
 	uint32_t sum = 0;
 	for (uint32_t c = lo; c < hi; c++) sum += meta[c].rounds;
@@ -773,19 +823,20 @@ uint32_t msc_ranks_items_round() { return kRiRound; }
 hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                        const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
                                        int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
-                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch) {
+                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch, size_t zero_bytes) {
 	if (m == 0) return hipSuccess;
 	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc || rounds == 0) return hipErrorInvalidValue;
 	const size_t lds = (nbins / 16 + 1 + 4) * 4;
-	hipError_t e = hipMemsetAsync(acc, 0, (size_t)m * 4 * sizeof(unsigned long long), st);
+	// acc, and the divergence scratch behind it when the caller laid them out in one piece (zero_bytes: from acc on), are cleared in ONE command
+	hipError_t e = hipMemsetAsync(acc, 0, zero_bytes ? zero_bytes : (size_t)m * 4 * sizeof(unsigned long long), st);
 	if (e != hipSuccess) return e;
-	if (dv) {
+	if (dv && !zero_bytes) {
 		if ((e = hipMemsetAsync(dv->cells, 0, (size_t)m * kRkCells * sizeof(uint32_t), st)) != hipSuccess) return e;
 		if ((e = hipMemsetAsync(dv->extras, 0, (size_t)m * rounds * 2 * sizeof(double), st)) != hipSuccess) return e;
 		if ((e = hipMemsetAsync(dv->hq, 0, 16 * sizeof(uint32_t), st)) != hipSuccess) return e;
-		k_rank_query_counts<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_hdr, dv->hq, dv->big);
 	}
-	k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard);
+	k_rank_query_prep<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard, dv ? dv->hq : nullptr,
+	                                                  dv ? dv->big : nullptr);
 	static bool attr_set = false;
 	if (!attr_set) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
@@ -798,8 +849,7 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	uint32_t* n_items = (uint32_t*)item_scratch;
 	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>((uint8_t*)item_scratch + 16);
 	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + 16 + (size_t)m * sizeof(RkItemMeta));
-	k_rank_items_meta<<<dim3((m + 255) / 256), dim3(256), 0, st>>>(c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr, use_window, min_len, max_len, meta);
-	k_rank_items_list<<<dim3(1), dim3(1024), 0, st>>>(meta, m, n_items, items_list);
+	k_rank_items_list<<<dim3(1), dim3(1024), 0, st>>>(meta, m, n_items, items_list, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, q_cum, q_hdr, use_window, min_len, max_len);
 	const uint64_t items = (uint64_t)m * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
 	// (the divergence form takes 128 registers: sixteen waves of it fill a CU's register file, so one workgroup per CU -- a second one
 	// would only queue behind the first and pay its set-up again)
