@@ -483,15 +483,29 @@ __global__ void __launch_bounds__(1024) k_rank_items_list(RkItemMeta* __restrict
 	{
 		const MscSparseHdr qh = *q_hdr_p;
 		const uint32_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
-		for (uint32_t c = threadIdx.x; c < m; c += 1024) {
-			const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
-			const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-			RkItemMeta mt{c_off[slot], c_n[slot], 0};
-			if (!(use_window && (cs->length < min_len || cs->length > max_len))) {
-				const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
-				mt.rounds = (T + kRiRound - 1) / kRiRound;
+		for (uint32_t c0 = threadIdx.x; c0 < m; c0 += 8 * 1024) {          // eight candidates per turn: their loads go out together, level by level
+			uint64_t slot[8], off[8], len[8];
+			uint32_t n[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) { const uint32_t c = c0 + 1024 * i; slot[i] = c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : 0; }
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const uint32_t c = c0 + 1024 * i;
+				if (c >= m) continue;
+				const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot[i] : (uint64_t)c) * scalar_stride);
+				len[i] = cs->length; off[i] = c_off[slot[i]]; n[i] = c_n[slot[i]];
 			}
-			meta[c] = mt;
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const uint32_t c = c0 + 1024 * i;
+				if (c >= m) continue;
+				RkItemMeta mt{off[i], n[i], 0};
+				if (!(use_window && (len[i] < min_len || len[i] > max_len))) {
+					const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
+					mt.rounds = (T + kRiRound - 1) / kRiRound;
+				}
+				meta[c] = mt;
+			}
 		}
 	}
 	__threadfence_block();
@@ -499,21 +513,25 @@ __global__ void __launch_bounds__(1024) k_rank_items_list(RkItemMeta* __restrict
 	const uint32_t per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
 	uint32_t sum = 0;
 	for (uint32_t c = lo; c < hi; c++) sum += meta[c].rounds;
-	s_part[threadIdx.x] = sum;
+	// exclusive scan over the 1 024 threads: a DPP scan per wave, one more over the sixteen wave totals (two barriers instead of twenty)
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t incl = wave_incl_scan(sum);
+	if (lane == 63) s_part[wave] = incl;
 	__syncthreads();
-	for (uint32_t d = 1; d < 1024; d <<= 1) {
-		const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-		__syncthreads();
-		s_part[threadIdx.x] += v;
-		__syncthreads();
+	if (wave == 0) {
+		const uint32_t t = lane < 16 ? s_part[lane] : 0u;
+		const uint32_t ti = wave_incl_scan(t);
+		if (lane < 16) s_part[16 + lane] = ti - t;
+		if (lane == 15) s_part[32] = ti;
 	}
-	uint32_t run = s_part[threadIdx.x] - sum;
+	__syncthreads();
+	uint32_t run = s_part[16 + wave] + incl - sum;
 	for (uint32_t c = lo; c < hi; c++) {
 		const uint32_t r = meta[c].rounds;
 		for (uint32_t rd = 0; rd < r; rd++) items[run + rd] = make_uint2(c, rd);
 		run += r;
 	}
-	if (threadIdx.x == 1023) start[0] = s_part[1023];          // the number of items
+	if (threadIdx.x == 0) start[0] = s_part[32];          // the number of items
 }
 
 template <bool DIV>
@@ -725,15 +743,16 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 					js += (double)k * (f.js - t11.js);
 				}
 			}
-		} else {
+		}
+		{          // the query's bins with a count >= 8 and the rounds' spot terms, dealt over the eight lanes (lane b: entries b, b + 8, ..)
 			const uint32_t n_big = hq[8];
-			for (uint32_t i = 0; i < n_big; i++) {
+			for (uint32_t i = b; i < n_big; i += 8) {
 				const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
 				jd += f.jd - t11.jd;
 				js += f.js - t11.js;
 			}
 		}
-		for (uint32_t r = b; r < rounds; r += 8) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }          // (lane b: rounds b, b + 8, ..)
+		for (uint32_t r = b; r < rounds; r += 8) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }
 #pragma unroll
 		for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
 		if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
