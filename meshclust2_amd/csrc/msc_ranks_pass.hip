@@ -22,10 +22,24 @@
 
 namespace {
 
+// wave totals by DPP (msc_wave.h: wave_total_u32, six row operations + a readlane): a __shfl_xor butterfly is twelve ds_bpermute_b32 per
+// 64-bit value, LDS round trips one behind the other -- five such totals were a third of what a 1 kb candidate costs its wave.
+// 64-bit per-lane values: the four 16-bit pieces are totalled separately.
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+	const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+	const uint64_t a = wave_total_u32(lo & 0xffffu), b = wave_total_u32(lo >> 16);
+	uint64_t r = a + (b << 16);
+	if (__builtin_amdgcn_readfirstlane((int)(__ballot(hi != 0) != 0))) {          // (rarely: a lane past 2^32)
+		const uint64_t c = wave_total_u32(hi & 0xffffu), d = wave_total_u32(hi >> 16);
+		r += (c << 32) + (d << 48);
+	}
+	return r;
+}
+// the two FP64 spot sums of a wave: a butterfly only when some lane holds one (fixed order: the butterfly's)
+__device__ __forceinline__ void wave_sum_f64_pair(double& x, double& y) {
+	if (__ballot(x != 0.0 || y != 0.0) == 0) return;
 #pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
+	for (int off = 32; off >= 1; off >>= 1) { x += __shfl_xor(x, off, 64); y += __shfl_xor(y, off, 64); }
 }
 
 // neighbours in the wave by DPP (gfx9 wave shifts): __shfl_up / __shfl_down compile to ds_bpermute_b32, an LDS round trip each, and the
@@ -418,7 +432,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			if constexpr (DIV) {
 				const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
 #pragma unroll
-				for (int off = 32; off >= 1; off >>= 1) { xjd += __shfl_xor(xjd, off, 64); xjs += __shfl_xor(xjs, off, 64); }
+				for (int off = 0; off < 1; off++) wave_sum_f64_pair(xjd, xjs);
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				uint32_t v = s_cnt[wave][lane];
@@ -545,6 +559,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	__shared__ uint32_t s_key[kRiHash], s_val[kRiHash];
 	__shared__ uint32_t s_nbig;
+	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the round in hand (flushed per round: a
+	                                                                                  // global atomic per entry was ~400 per candidate on three or four addresses)
 	const uint32_t words = nbins / 16 + 1;
 	uint32_t* sb = s_rp;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -582,17 +598,26 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		return lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin + 1) - lo;
 	};
 	double qm = 0.0;
-	if constexpr (DIV) qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+	if constexpr (DIV) {
+		qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+		s_cnt[wave][lane] = 0u;
+	}
 	const uint32_t n_items = *n_items_p;
 	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
 	(void)use_window; (void)min_len; (void)max_len; (void)c_off; (void)c_n;
+	// Records of the items two ahead; and the candidate ranks of the NEXT item touched (one dword per 64-byte line) right behind this
+	// item's own loads, so that they come out of L2 when their turn comes: the divergence form has no registers to hold a second round.
 	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
 	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
 	RkItemMeta mt_n = meta[item_n.x];
+	uint2 item_n2 = it + n_waves < n_items ? items[it + n_waves] : make_uint2(0u, 0u);
+	RkItemMeta mt_n2 = meta[item_n2.x];
 	for (; it < n_items; it += n_waves) {
 		const uint2 item = item_n;
 		const RkItemMeta mt = mt_n;
-		if (it + n_waves < n_items) { item_n = items[it + n_waves]; mt_n = meta[item_n.x]; }          // (the next item's record while this one is scored)
+		item_n = item_n2; mt_n = mt_n2;
+		const bool has_next = it + n_waves < n_items;
+		if (it + 2 * n_waves < n_items) { item_n2 = items[it + 2 * n_waves]; mt_n2 = meta[item_n2.x]; }
 		const uint32_t c = item.x, rd = item.y;
 		const uint32_t nc = mt.n, nc_pad = (nc + 3u) & ~3u;
 		const uint32_t T = nc > nq_tot ? nc : nq_tot;
@@ -616,6 +641,14 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		}
 		const uint32_t before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
 		const uint32_t after_round = t0 + kRiRound < nc ? P[t0 + kRiRound] : nbins;           // ... and the one behind it
+		uint32_t warm = 0;
+		if (has_next) {          // the next item's 4 KiB of ranks: 64 lines, one dword each
+			const uint32_t tn = item_n.y * kRiRound + 16 * lane;
+			if (tn < mt_n.n) {
+				const uint32_t* pw = c_rk + mt_n.off + tn;
+				asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(pw) : "memory");
+			}
+		}
 		uint64_t emd = 0, prod = 0;
 		uint32_t mins = 0, c01 = 0, c02 = 0;
 		double xjd = 0.0, xjs = 0.0;
@@ -665,7 +698,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 					c01 += plain && cb == 1 ? 1u : 0u;
 					c02 += plain && cb == 2 ? 1u : 0u;
 					if (!plain) {
-						if (cb < 8) atomicAdd(&cells[(uint64_t)c * kRkCells + (ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);          // (row 7: counted as held, evaluated here)
+						if (cb < 8) atomicAdd(&s_cnt[wave][(ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);          // (row 7: counted as held, evaluated here)
 						if (ca >= 9 || cb >= 8) {
 							const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
 							RkDivTerm lo = t11;
@@ -677,6 +710,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 				}
 			}
 		}
+		asm volatile("s_waitcnt vmcnt(0)" ::"v"(warm) : "memory");          // (the touch has landed; its register is free again)
 		const uint64_t emd_t = wave_sum_u64(emd), prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
 		if (lane == 0) {
 			atomicAdd(&acc[4 * (uint64_t)c], (unsigned long long)emd_t);
@@ -686,13 +720,20 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		if constexpr (DIV) {
 			const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
 #pragma unroll
-			for (int off = 32; off >= 1; off >>= 1) { xjd += __shfl_xor(xjd, off, 64); xjs += __shfl_xor(xjs, off, 64); }
+			for (int off = 0; off < 1; off++) wave_sum_f64_pair(xjd, xjs);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			uint32_t v = s_cnt[wave][lane];
+			s_cnt[wave][lane] = 0u;
+			if (lane == 1) v += c01_t;
+			if (lane == 2) v += c02_t;
+			if (v) atomicAdd(&cells[(uint64_t)c * kRkCells + lane], v);
 			if (lane == 0) {
-				if (c01_t) atomicAdd(&cells[(uint64_t)c * kRkCells + 1], c01_t);
-				if (c02_t) atomicAdd(&cells[(uint64_t)c * kRkCells + 2], c02_t);
 				extras[2 * ((uint64_t)c * rounds + rd)] = xjd;
 				extras[2 * ((uint64_t)c * rounds + rd) + 1] = xjs;
 			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
 	}
 }
