@@ -1485,7 +1485,7 @@ hipError_t launch_sparse_pass(msc_ctx* ctx, SparseKernel k, const msc_hist_set* 
 
 // The rank lists of the sparse set (or sparse mirror) `s`, for the 1 x M pass of msc_ranks_pass.hip: true when they are current. Built only
 // once the same state of the set has been asked for three times (msc_objects.h).
-bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err) {
+bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err, bool eager = false) {
 	*err = MSC_OK;
 	if (!s->sparse || s->rkl_unavailable) return false;
 	if (s->rkl && s->rkl_epoch == s->list_epoch) return true;
@@ -1493,7 +1493,10 @@ bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err) {
 	// (MSC_RANKS_1XM_AFTER=n: build at the n-th request instead of the third; read on every call so that a test can switch it)
 	const char* after_env = getenv("MSC_RANKS_1XM_AFTER");
 	const uint32_t after = after_env && atoi(after_env) > 0 ? (uint32_t)atoi(after_env) : 3u;
-	if (++s->rkl_seen < after) return false;
+	// eager: the step-serial loop's own call (msc_get_close_window over a sealed store) builds at its FIRST pass -- which kernel scores a
+	// candidate must not depend on how many passes its rank has seen (a rank whose window was empty for a step would otherwise switch a
+	// step later than the others, and two identical sequences on two ranks would differ in the last bit of a divergence sum)
+	if (!eager && ++s->rkl_seen < after) return false;
 	auto give_up = [&]() { (void)hipGetLastError(); s->rkl_unavailable = true; return false; };
 	if (!s->rkl_off && (hipMalloc((void**)&s->rkl_off, (s->capacity + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&s->rkl_n, s->capacity * sizeof(uint32_t)) != hipSuccess))
 		return give_up();
@@ -1598,14 +1601,17 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// candidate, so a window of a few thousand long candidates still fills the chip (MSC_NO_RANKS_ITEMS: such passes stay on the merge kernel
 	// when they carry divergence statistics, on k_pair_ranks_1xm otherwise).
 	const uint64_t c_kmers = c_sp && c_sp->max_sum >= L.nbins ? c_sp->max_sum - L.nbins : ~0ull;          // bound on the k-mers of any candidate
-	const bool long_lists = q_kmers > 8192 || c_kmers > 8192;
+	// (which of the two rank kernels takes a pass is decided by the QUERY alone -- its stored bins, the same number on every rank of a sharded
+	// run and in a one-rank run -- never by a bound of the set or shard at hand: the two kernels add the divergence terms in different orders,
+	// and two identical sequences scored for one query must not come out one bit apart because they sit on different ranks)
+	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > 8000;
 	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26);
 	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
 	bool rank_items = false;
 	uint32_t rank_rounds = 0;
 	if (lists && div_fits && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
 		int e = MSC_OK;
-		rank_pass = rank_lists_ready(ctx, c_sp, &e);
+		rank_pass = rank_lists_ready(ctx, c_sp, &e, rq.close_list.pos != nullptr);
 		if (e) return e;
 		if (rank_pass && !ctx->rk_guard) {
 			HIP_TRY(ctx, hipHostMalloc((void**)&ctx->rk_guard, 64, hipHostMallocDefault));

@@ -76,7 +76,7 @@ def test_rank_pass_against_the_oracle_and_the_merge_kernels(ctx, oracle, rank_pa
             got = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, order)
             kernel = ctx.last_kernel_info()[0]
             if 4 ** k >= 16384 and dtype != 64:          # (smaller histograms have no list form: the dense kernels take them)
-                assert kernel == ("k_pair_ranks_items" if length > 8192 else KERNEL), (kernel, dtype, k, layout)
+                assert kernel == ("k_pair_ranks_items" if hs.entries(q) > 8000 else KERNEL), (kernel, dtype, k, layout, q)          # (the query's own size decides)
             rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
             ref = api.pair_features_raw(ctx, hs, cands, hs, q, FAST_MASK, order)
             assert ctx.last_kernel_info()[0] not in RANK_KERNELS
@@ -196,7 +196,7 @@ ALL_MASK = sum(1 << b for _, b in FEATS)
     (16, 9, 24, 6000, "unit3", "sparse"),         # lists of 6 000
     (16, 8, 40, 2500, "unit12", "sparse"),
     (16, 9, 20, 12000, "homo", "sparse"),         # long lists: (candidate, round) items; runs of 300 copies across round boundaries
-    (32, 9, 20, 9000, "unit3", "dense"),
+    (32, 9, 20, 10500, "unit3", "dense"),
 ])
 def test_divergence_statistics_through_the_rank_pass(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
     """jefferey_divergence / jensen_shannon (predict/Feature.cpp:1235-1262, 988-1008) counted per cell by k_pair_ranks_1xm and evaluated by
@@ -213,7 +213,7 @@ def test_divergence_statistics_through_the_rank_pass(ctx, oracle, rank_pass_now,
     for q in (1, 0, 6, n - 3):
         for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
             got = api.pair_features_raw(ctx, hs, cands, hs, q, ALL_MASK, order)
-            assert ctx.last_kernel_info()[0] == ("k_pair_ranks_items" if length > 8192 else KERNEL)
+            assert ctx.last_kernel_info()[0] == ("k_pair_ranks_items" if hs.entries(q) > 8000 else KERNEL), q
             rank_pass_now.setenv("MSC_NO_RANKS_DIV", "1")
             ref = api.pair_features_raw(ctx, hs, cands, hs, q, ALL_MASK, order)
             assert ctx.last_kernel_info()[0] not in RANK_KERNELS
