@@ -1604,7 +1604,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// (which of the two rank kernels takes a pass is decided by the QUERY alone -- its stored bins, the same number on every rank of a sharded
 	// run and in a one-rank run -- never by a bound of the set or shard at hand: the two kernels add the divergence terms in different orders,
 	// and two identical sequences scored for one query must not come out one bit apart because they sit on different ranks)
-	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > 8000;
+	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > 2000;          // (2 000: a wave of k_pair_ranks_1xm takes a whole candidate, fine up to a few rounds of 256 entries)
 	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26);
 	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
 	bool rank_items = false;
