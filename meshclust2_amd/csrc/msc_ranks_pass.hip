@@ -431,8 +431,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			}
 			if constexpr (DIV) {
 				const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
-#pragma unroll
-				for (int off = 0; off < 1; off++) wave_sum_f64_pair(xjd, xjs);
+				wave_sum_f64_pair(xjd, xjs);
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				uint32_t v = s_cnt[wave][lane];
@@ -471,22 +470,6 @@ constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the quer
 // pass then walks real items only (with the host's bound, rounds per candidate = that of the LONGEST list of the set: on mixed lengths
 // four items in five were empty, and finding that out cost a wave three dependent loads each).
 struct RkItemMeta { uint64_t off; uint32_t n, rounds; };
-__global__ void __launch_bounds__(256) k_rank_items_meta(const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
-                                                         const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m, const uint32_t* __restrict__ q_cum,
-                                                         const MscSparseHdr* __restrict__ q_hdr_p, int use_window, uint64_t min_len, uint64_t max_len, RkItemMeta* __restrict__ meta) {
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= m) return;
-	const MscSparseHdr qh = *q_hdr_p;
-	const uint32_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
-	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
-	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-	RkItemMeta mt{c_off[slot], c_n[slot], 0};
-	if (!(use_window && (cs->length < min_len || cs->length > max_len))) {
-		const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
-		mt.rounds = (T + kRiRound - 1) / kRiRound;
-	}
-	meta[c] = mt;
-}
 // one workgroup: start[c] = items in front of candidate c, start[m] = their number; then every thread writes its candidates' items
 __global__ void __launch_bounds__(1024) k_rank_items_list(RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ start, uint2* __restrict__ items,
                                                           const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
@@ -719,8 +702,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		}
 		if constexpr (DIV) {
 			const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
-#pragma unroll
-			for (int off = 0; off < 1; off++) wave_sum_f64_pair(xjd, xjs);
+			wave_sum_f64_pair(xjd, xjs);
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			uint32_t v = s_cnt[wave][lane];
