@@ -58,9 +58,15 @@ def parse():
                          "rank builds the block's histograms itself, bit-identical to the owner's) or their HISTOGRAMS as they sit in HBM (4^k x sizeof(T) "
                          "bytes each: SURVEY 8(e)'s exchange -- at 1 MiB per query the ring all-gather takes longer than scoring the block once the pass "
                          "runs on the matrix cores)")
-    ap.add_argument("--queries", type=int, default=1024, help="query histograms per step (a multiple of the number of ranks); the library scores them in blocks of 128 (64 off the matrix cores), "
-                                                             "one pass over the candidates each -- a step of 16 blocks keeps the per-step exchange and host work of an 8-rank run "
-                                                             "(12 500 candidates per rank) small next to the scoring")
+    ap.add_argument("--queries", type=int, default=8192, help="query histograms per step IN TOTAL (a multiple of the number of ranks); the library scores them in blocks of 128 "
+                                                             "(64 off the matrix cores), one pass over the candidates each, queued on two streams -- 8 192 leaves each of 8 ranks "
+                                                             "eight blocks per step, enough for that pipeline to fill (r04 and before: 1 024)")
+    ap.add_argument("--shard", choices=("rows", "candidates"), default="rows",
+                    help="how an N > 1 all-pairs run is cut. rows (default): every rank holds ALL candidates (one set-up all-gather of the 2-bit sequences, each "
+                         "rank builds the whole set: 103 GiB of 288 at cfg2) and scores queries / N rows of each step against all of them -- fastcar's own cut "
+                         "(a worker takes a chunk of one side and all of the other, fastcar/FC_Runner.cpp:585-597); no collective on the data path, only the "
+                         "per-query close counts are all-gathered, one step late. candidates: SURVEY 8(e)'s cut -- every rank holds nseq / N candidates and the "
+                         "step's query block is all-gathered (r01-r04)")
     ap.add_argument("--mode", choices=("allpairs", "get_close"), default="allpairs")
     ap.add_argument("--layout", choices=("dense", "sparse"), default="dense",
                     help="sparse: the same workload on sorted (bin, value) lists (DESIGN 3b; single GPU only) -- algorithmic bytes are then the list bytes")
@@ -81,13 +87,15 @@ def parse():
 BLOCK = 1000          # sequences per shard block = one bvec bin (cluster/CRunner.cpp:585)
 
 
-def build_resident_set(api, synth, ctx, args, plan, rank):
+def build_resident_set(api, synth, ctx, args, plan, rank, build=True, tail=None):
     """This rank's shard resident in HBM before the clock starts: global sequence g = plan.global_index(rank, local) -- the same
-    sequence whatever the number of ranks. Sequences are generated and packed on the host in chunks of whole shard blocks."""
+    sequence whatever the number of ranks. Sequences are generated and packed on the host in chunks of whole shard blocks.
+    build=False: only the host side -- the shard's 2-bit rows and 1-mer / length records (--shard rows: the set is built from the
+    rows of ALL ranks after the set-up exchange, build_replicated_set)."""
     M = plan.local_count(rank)
-    Q = args.queries
+    Q = args.queries if tail is None else tail
     sparse_entries = (M + 2 * Q) * (args.length + 64) if args.layout == "sparse" else 0
-    hs = api.HistogramSet(ctx, args.k, args.dtype, M + 2 * Q, sparse_entries=sparse_entries)      # tail slots = two blocks of gathered queries
+    hs = api.HistogramSet(ctx, args.k, args.dtype, M + 2 * Q, sparse_entries=sparse_entries) if build else None     # tail slots = two blocks of gathered queries
     seed = 20260002
     fam = 20
     assert BLOCK % fam == 0
@@ -129,17 +137,20 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
         seq_rows[done:done + n] = c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6)
         one_rows[done:done + n, :4] = b["one_mers"].reshape(n, 4)
         one_rows[done:done + n, 4] = b["eff_len"]
-        t1 = time.perf_counter()
-        hs.build_packed(done, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
-        ctx.synchronize()
-        t_dev.append((n, time.perf_counter() - t1))
+        if build:
+            t1 = time.perf_counter()
+            hs.build_packed(done, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
+            ctx.synchronize()
+            t_dev.append((n, time.perf_counter() - t1))
         last = (done, n, b)
         done += n
+    if not build:
+        return None, time.time() - t0, None, (seq_rows, one_rows)
     # Between chunks the host spends ~1 s generating sequences, so every chunk above starts on an idle GPU (and the first ones
     # allocate the library's scratch buffers). Steady state = the last chunk rebuilt in place three times back to back (same
     # bytes into the same slots). Dense only: a sparse set's entry arena is append-only, a rebuilt slot reserves its entries again.
     steady = []
-    for _ in range(3 if args.layout == "dense" else 0):
+    for _ in range(3 if args.layout == "dense" and M else 0):
         first, n, b = last
         t1 = time.perf_counter()
         hs.build_packed(first, n, b["packed"], b["n_bases"], b["seg_seq"], b["seg_start"], b["seg_end"], b["eff_len"], b["one_mers"])
@@ -147,6 +158,57 @@ def build_resident_set(api, synth, ctx, args, plan, rank):
         steady.append(n / (time.perf_counter() - t1))
     rate_all = sum(n_ for n_, _ in t_dev) / sum(s_ for _, s_ in t_dev)
     return hs, time.time() - t0, {"all": rate_all, "median_chunk": max(steady) if steady else rate_all}, (seq_rows, one_rows)
+
+
+def build_replicated_set(api, shard, torch, dist, ctx, args, plan, rank, seq_rows, one_rows):
+    """--shard rows, N > 1: the set-up exchange and the build of ALL candidates on this rank. Every rank contributes the 2-bit rows
+    and the (1-mer counts, length) records of the sequences it generated; one all-gather per region (RCCL, device buffers) lands
+    them on every rank, a device gather puts them in global order (slot = global sequence index, as on one GPU), and the histograms
+    are built straight from that device buffer (msc_hist_build_packed_dev) in chunks of 20 000. -> (set, seconds, sequences per second
+    of the build calls)"""
+    t0 = time.time()
+    n_total, lp4 = plan.n_total, seq_rows.shape[1]
+    hs = api.HistogramSet(ctx, args.k, args.dtype, n_total)
+    state = {}
+
+    class Backend:
+        def shard_payload(self, n_pad):
+            a = torch.zeros((n_pad, lp4), dtype=torch.uint8, device="cuda")
+            a[:seq_rows.shape[0]] = torch.from_numpy(seq_rows).cuda()
+            b = torch.zeros((n_pad, 5), dtype=torch.int64, device="cuda")
+            b[:one_rows.shape[0]] = torch.from_numpy(one_rows.view(np.int64)).cuda()
+            return [a, b]
+
+        def gather_buffers(self, n_rows):
+            state["seq"] = torch.zeros((n_rows, lp4), dtype=torch.uint8, device="cuda")
+            state["one"] = torch.zeros((n_rows, 5), dtype=torch.int64, device="cuda")
+            return [state["seq"], state["one"]]
+
+        def import_rows(self, rows):
+            idx = torch.from_numpy(rows).cuda()
+            state["seq"] = state["seq"].index_select(0, idx).contiguous()
+            state["meta"] = state["one"].index_select(0, idx).cpu().numpy().view(np.uint64)
+            torch.cuda.synchronize()          # the library reads the buffer on its own stream (msc_hist_build_packed_dev: the bytes must be complete)
+
+        def score_rows(self, globals_):
+            raise NotImplementedError
+
+    rr = shard.ReplicatedRows(dist, plan, Backend(), rank, device="cuda")
+    rr.replicate()
+    meta, stride = state["meta"], lp4 * 4
+    t_dev = []
+    for done in range(0, n_total, 20000):
+        n = min(20000, n_total - done)
+        lens = meta[done:done + n, 4].copy()
+        starts = np.arange(n, dtype=np.uint64) * np.uint64(stride)
+        t1 = time.perf_counter()
+        hs.build_packed_dev(done, n, state["seq"][done:].data_ptr(), n * stride, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
+                            np.ascontiguousarray(meta[done:done + n, :4]).reshape(-1))
+        ctx.synchronize()
+        t_dev.append((n, time.perf_counter() - t1))
+    rate = sum(n_ for n_, _ in t_dev) / sum(s_ for _, s_ in t_dev)
+    # the gathered rows stay alive for the secondary-free N > 1 run only as long as this frame: the set owns its histograms
+    return hs, time.time() - t0, {"all": rate, "median_chunk": max(n_ / s_ for n_, s_ in t_dev)}, rr
 
 
 def cpu_baseline(args, synth, weights_text, weights_path):
@@ -361,8 +423,17 @@ def main():
     if Q % world:
         raise SystemExit("--queries must be a multiple of the number of ranks (every rank contributes queries / N per step)")
     ctx = api.Context(local_rank)
-    hs, build_s, build_dev_s, (seq_rows, one_rows) = build_resident_set(api, synth, ctx, args, plan, rank)
-    M = plan.local_count(rank)                                  # this rank's shard
+    by_rows = args.shard == "rows" and args.mode == "allpairs" and args.layout == "dense"
+    rows_job = None
+    if by_rows and world > 1:
+        # every rank generates its share of the sequences on the host, then all of them build ALL candidates (slot = global index)
+        _, gen_s, _, (seq_rows, one_rows) = build_resident_set(api, synth, ctx, args, plan, rank, build=False)
+        hs, build_s, build_dev_s, rows_job = build_replicated_set(api, shard, torch, dist, ctx, args, plan, rank, seq_rows, one_rows)
+        build_s += gen_s
+        M = n_total
+    else:
+        hs, build_s, build_dev_s, (seq_rows, one_rows) = build_resident_set(api, synth, ctx, args, plan, rank, tail=0 if world == 1 else None)
+        M = plan.local_count(rank)                              # this rank's shard
     m_min = min(plan.local_count(r) for r in range(world))
     wpath = args.weights or os.path.join(ROOT, "tests", "golden", "weights_k9_u32.txt" if args.k == 9 else "weights_k5_u16.txt")
     wtext = open(wpath).read()
@@ -372,7 +443,7 @@ def main():
     # N > 1: the exchange of SURVEY 8(e) through meshclust2_amd/shard.py; the collectives land directly in slots M .. M + 2Q - 1 (two
     # blocks: the next step's queries arrive while this step's are scored)
     sharded = block = None
-    if world > 1:
+    if world > 1 and rows_job is None:
         all_bins, all_scal = shard.device_tensors(hs, M + 2 * Q)      # [slot, bytes] views of the set's device memory
         ship_seq = args.exchange == "sequences" and args.mode == "allpairs"
         if ship_seq:
@@ -473,10 +544,15 @@ def main():
         plan_w = shard.ShardPlan(n_total, cw, block=BLOCK)
         m_min_w = min(plan_w.local_count(r) for r in range(cw))
     # the step's product -- one close flag per pair, Q x M bytes -- lands in page-locked host memory allocated once
-    out_close = {"close": api.pinned_array(ctx, (Q, M), np.uint8)} if args.mode == "allpairs" and world == 1 else None
+    qpr = Q // world                # queries every rank contributes per step (--shard candidates) / scores per step (--shard rows)
+    out_close = {"close": api.pinned_array(ctx, (qpr if rows_job else Q, M), np.uint8)} if args.mode == "allpairs" and (world == 1 or rows_job) else None
     step_no = [0]
     pending = [None, None]          # RCCL work handles of the query block in flight per buffer half (N > 1, allpairs)
-    qpr = Q // world                # queries every rank contributes per step
+    if rows_job is not None:
+        def score_rows(globals_):
+            res = api.score_multi(ctx, feat, hs, None, hs, np.asarray(globals_, dtype=np.uint32), m=M, want=("close", "counts"), out=out_close)
+            return res["counts"]
+        rows_job.backend.score_rows = score_rows
 
     def block_first(st):
         """first local slot of the queries / N consecutive histograms every rank contributes to the block of step st"""
@@ -487,7 +563,16 @@ def main():
         st = step_no[0]
         step_no[0] += 1
         if args.mode == "allpairs":
-            if block is not None:
+            if rows_job is not None:
+                # --shard rows: this rank's queries / N rows of the step's query list (the list one rank would score) against ALL
+                # candidates; the counts' all-gather is issued here and read one step later
+                qs = [((st * Q + j) * 7919) % n_total for j in range(Q)]
+                totals.append(rows_job.score(qs, defer=True))
+                if len(totals) > 1:
+                    done = totals.pop(0).total()
+                    if args.check:
+                        checks.append([int(x) for x in done])
+            elif block is not None:
                 # double-buffered exchange: this block's queries were issued during the previous step (or are issued now, on the
                 # first one); the NEXT block's all-gathers go out before this block is scored and run underneath it
                 cur, nxt = st % 2, (st + 1) % 2
@@ -580,10 +665,11 @@ def main():
         hist_bytes = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
     n_launch = max(int(np.sum(launches)), 1)
     avg_ms = float(np.sum(tiles_ms)) / n_launch if tiles_ms else float("nan")
+    q_call = qpr if rows_job is not None else Q          # query rows one library call of this rank scores
     if args.mode == "allpairs" and args.layout == "sparse":
         per_call = Q * (M + 1) * hist_bytes          # one 1 x M merge pass per query
     elif args.mode == "allpairs":
-        per_call = (M * -(-Q // qtile) + Q) * hist_bytes      # (qtile <= 128: a call with more queries is that many passes)
+        per_call = (M * -(-q_call // qtile) + q_call) * hist_bytes      # (qtile <= 128: a call with more queries is that many passes)
     else:
         per_call = (M + 1) * hist_bytes
     # one timed call may be several launches of the streaming kernel (candidate chunks): report per launch
@@ -597,7 +683,7 @@ def main():
     if args.layout == "sparse":
         config_key += ",layout=sparse"
     traffic, valu_busy = pmc_traffic(kernel.split("<")[0], config_key)
-    per_gpu = "%d per GPU" % args.nseq if args.scaling == "weak" else "%d in total (%d on rank 0)" % (n_total, M)
+    per_gpu = "%d per GPU" % args.nseq if args.scaling == "weak" and rows_job is None else "%d in total (%d on rank 0)" % (n_total, M)
     length_name = "%gkb" % (args.length / 1000.0) if args.length % 100 == 0 else "%d bp" % args.length
     is_cfg2 = (n_total, args.length, args.k, args.dtype, args.layout) == (100000, 1000, 9, 32, "dense")
     calls_per_launch = len(tiles_ms) / n_launch if tiles_ms else 1.0          # < 1: a call is cut into candidate chunks, one launch each
@@ -620,9 +706,13 @@ def main():
                                   "note": "msc_hist_build_packed only (2-bit bases over PCIe + build kernel): the last chunk rebuilt in place back to "
                                           "back; all_chunks = the chunks as first built, each after ~1 s of host-side sequence generation on an idle GPU; "
                                           "untimed setup"},
-                   "sharding": ("sequence blocks of %d, block-cyclic; per step 2 all-gathers assemble the query block (RCCL) as %s, per-query close counts all-gathered"
+                   "sharding": ("query rows: every rank holds all %d candidates (set-up: one RCCL all-gather of the 2-bit sequences + one of their 1-mer / length records, "
+                                "each rank builds every histogram) and scores %d of each step's %d query rows against all of them; no collective on the data path, "
+                                "the per-query close counts are all-gathered one step late" % (n_total, qpr, Q)) if rows_job is not None else
+                               ("sequence blocks of %d, block-cyclic; per step 2 all-gathers assemble the query block (RCCL) as %s, per-query close counts all-gathered"
                                 % (BLOCK, "2-bit packed sequences + 1-mer counts (every rank builds the block's histograms)" if args.exchange == "sequences" else "histograms"))
                                if world > 1 else "single GPU",
+                   "ms_per_1024_queries": dt / args.steps * 1e3 * 1024.0 / Q,
                    "queries_per_candidate_read": qtile},
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
@@ -632,15 +722,15 @@ def main():
                      # is tiled -- query groups that share a candidate mostly hit in L2); valu_busy = VALU cycles / busy cycles
                      "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms == avg_ms else None, "valu_busy": valu_busy,
                      # a call scores its queries in blocks of 128 (matrix cores) or 64 (one pass over the candidates each) and may cut a pass into candidate chunks
-                     "candidates_per_launch": int(round(M * calls_per_launch * (-(-Q // (qblk if on_mfma else 64)) if args.mode == "allpairs" and args.layout == "dense" else 1))),
-                     "query_groups_per_launch": -(-min(Q, qblk if on_mfma else 64) // qtile) if args.mode == "allpairs" else 1,
+                     "candidates_per_launch": int(round(M * calls_per_launch * (-(-q_call // (qblk if on_mfma else 64)) if args.mode == "allpairs" and args.layout == "dense" else 1))),
+                     "query_groups_per_launch": -(-min(q_call, qblk if on_mfma else 64) // qtile) if args.mode == "allpairs" else 1,
                      "profile_key": config_key},
     }
     if on_mfma and args.mode == "allpairs" and avg_ms == avg_ms:
         # The pass on the matrix cores is bound by the matrix pipe (FP4 operands; int8 under MSC_GEMM_I8), not by HBM (it streams one bit per bin): 4^k multiply-adds per
         # pair = 2 * 4^k integer operations; a launch scores (candidates of the launch) x (rows of its query block, padded rows included
         # in the work the pipe does but NOT in the operations counted here).
-        pairs_per_launch = float(M) * Q * len(tiles_ms) / n_launch
+        pairs_per_launch = float(M) * q_call * len(tiles_ms) / n_launch
         ops = 2.0 * pairs_per_launch * (4 ** args.k)
         tops = ops / (avg_ms * 1e-3) / 1e12
         peak = MFMA_FP4_PEAK_TOPS if on_fp4 else MFMA_I8_PEAK_TOPS

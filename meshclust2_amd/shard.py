@@ -189,6 +189,79 @@ class ShardedBlockScorer:
         return self.score(n)
 
 
+class ReplicatedRows:
+    """The all-pairs job sharded by QUERY ROWS with the candidates replicated: the shape of fastcar's outer loop as the reference runs
+    it -- a worker takes a chunk of one side and ALL of the other (fastcar/FC_Runner.cpp:585-597 over work() :426-471). Every rank
+    generates (or reads) only its own shard of the sequences; ONE set-up exchange (an all-gather per payload region) gives every
+    rank all of them, each rank builds the whole candidate set locally, and from then on a step needs no collective on its data
+    path: rank r scores rows r * n / N .. (r + 1) * n / N - 1 of the step's query list against every candidate. Only the per-query
+    close counts travel (one small all-gather per step, issued asynchronously and read a step later).
+
+    backend.shard_payload(n_pad)   -> list of tensors [n_pad, row_bytes]: this rank's sequences in local order (rows past its count: padding)
+    backend.gather_buffers(n_rows) -> list of tensors [n_rows, row_bytes] the gathered rows land in (n_rows = world * n_pad)
+    backend.import_rows(rows)      -> rows[g] = gathered row of global sequence g; builds the resident set of ALL sequences, slot = g
+    backend.score_rows(globals_)   -> per-query close counts (np array, len(globals_)) of those query rows against ALL candidates
+    """
+
+    def __init__(self, dist, plan, backend, rank, device="cpu"):
+        self.dist, self.plan, self.backend, self.rank, self.device = dist, plan, backend, rank, device
+
+    def replicate(self):
+        """the set-up exchange -> rows (np.int64, one per global sequence: its row in the gathered buffers)"""
+        return ShardedCentres(self.dist, self.plan, _RowsAsCentres(self.backend), self.rank, self.device).gather()
+
+    def rows_of(self, query_globals, rank=None):
+        """the slice of a step's query list a rank scores (equal shares, rank-major)"""
+        rank = self.rank if rank is None else rank
+        n, world = len(query_globals), self.plan.world
+        if n % world:
+            raise ValueError("a step's queries (%d) must divide evenly over %d ranks" % (n, world))
+        per = n // world
+        return query_globals[rank * per:(rank + 1) * per]
+
+    class _Counts:
+        """the per-query close counts of a step in the order of its query list; the all-gather was only issued by score(defer=True)"""
+        def __init__(self, work, out):
+            self.work, self.out, self.value = work, out, None
+
+        def total(self):
+            if self.value is None:
+                if self.work is not None:
+                    self.work.wait()
+                self.value = self.out.cpu().numpy()
+            return self.value
+
+    def score(self, query_globals, defer=False):
+        """this rank's rows of the step against every candidate -> the step's per-query close counts (all ranks, query-list order), or
+        with defer=True a handle whose total() waits for the counts' all-gather"""
+        import torch
+        mine = self.rows_of(query_globals)
+        counts = torch.as_tensor(np.asarray(self.backend.score_rows(mine), dtype=np.int64), device=self.device)
+        if self.plan.world > 1:
+            out = torch.zeros(self.plan.world * counts.numel(), dtype=torch.int64, device=self.device)
+            work = self.dist.all_gather_into_tensor(out, counts, async_op=True)
+            handle = self._Counts(work, out)
+        else:
+            handle = self._Counts(None, counts)
+        return handle if defer else handle.total()
+
+
+class _RowsAsCentres:
+    """adapter: ReplicatedRows' backend seen through the names ShardedCentres.gather() calls (the exchange is the same: every rank's
+    rows, padded to the longest share, all-gathered per payload region, then a global-index -> gathered-row map)"""
+    def __init__(self, backend):
+        self.backend = backend
+
+    def centre_payload(self, n_pad):
+        return self.backend.shard_payload(n_pad)
+
+    def gather_buffers(self, n_rows):
+        return self.backend.gather_buffers(n_rows)
+
+    def import_centres(self, rows):
+        return self.backend.import_rows(rows)
+
+
 def device_tensors(hist_set, n_slots):
     """torch uint8 views [n_slots, slot_bytes] / [n_slots, scalar_bytes] over a dense set's device memory
     (msc_hist_set_device_view), so that RCCL collectives read and write histogram slots in place.

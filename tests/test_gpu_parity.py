@@ -1984,7 +1984,7 @@ def test_bench_two_ranks_packed_exchange(tmp_path, exchange):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0", "--check", "--exchange", exchange]
+    common = ["--nseq", "8000", "--steps", "3", "--warmup", "1", "--queries", "16", "--cpu-seconds", "0", "--check", "--shard", "candidates", "--exchange", exchange]
     r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2"] + common, 2, tmp_path)
     assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
     line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
@@ -1997,6 +1997,32 @@ def test_bench_two_ranks_packed_exchange(tmp_path, exchange):
     assert len(line["check"]) == 3 and all(len(c) == 16 for c in line["check"])
     assert line["check"] == ref_line["check"]
     assert sum(sum(c) for c in line["check"]) >= 3 * 16          # every query is at least close to itself
+
+
+def test_bench_two_ranks_row_shards(tmp_path):
+    """bench.py --gpus 2 as it runs by default since r05 (--shard rows): the candidates replicated by ONE set-up exchange (every rank
+    generates half of the sequences, all-gathers the 2-bit rows and builds all 6 000 histograms from the gathered device buffer),
+    each rank scoring half of every step's query rows against ALL candidates -- fastcar's own cut of the job
+    (fastcar/FC_Runner.cpp:585-597). Two ranks sharing this GPU against ONE rank running the very same command: with --check both
+    lines carry the per-query close counts of every timed step, which must be equal -- the same pairs, the same decisions."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--nseq", "6000", "--steps", "3", "--warmup", "1", "--queries", "272", "--cpu-seconds", "0", "--check", "--no-secondary"]
+    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2"] + common, 2, tmp_path)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["pairs_per_step"] == 272 * 6000
+    assert line["config"]["sharding"].startswith("query rows") and line["roofline"]["kernel"].startswith("k_pair_gemm_fp4_dma")
+    assert line["roofline"]["candidates_per_launch"] == 6000          # every rank scores its rows against ALL candidates
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert one.returncode == 0, one.stdout.decode(errors="replace")[-3000:]
+    ref_line = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert len(line["check"]) == 3 and all(len(c) == 272 for c in line["check"])
+    assert line["check"] == ref_line["check"]
+    assert sum(sum(c) for c in line["check"]) >= 3 * 272          # every query is at least close to itself
 
 
 @pytest.mark.parametrize("dtype,k,wts,sparse,n", [(16, 5, "weights_k5_u16.txt", False, 3000), (32, 9, "weights_k9_u32.txt", False, 400), (8, 9, "weights_k9_u8.txt", True, 2500),

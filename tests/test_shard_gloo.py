@@ -233,6 +233,75 @@ def _packed_steps(dist, rank, plan, hists, pred, nb):
     return out
 
 
+ROW_Q, ROW_STEPS = 6, 3
+
+
+def _row_queries(step, total):
+    return [((step * ROW_Q + j) * 11) % total for j in range(ROW_Q)]
+
+
+def _row_steps(dist, rank, plan, hists, pred, nb):
+    """the all-pairs job sharded by QUERY rows (bench.py's default since r05): one set-up all-gather replicates every rank's
+    histograms' source rows, each rank rebuilds ALL candidates locally, then scores its share of each step's rows against all
+    of them; the only per-step collective is the counts' all-gather (left in flight on odd steps)"""
+    import ctypes as C
+    import torch
+    from oracle import oracle_py
+    calls = {"all_gather_into_tensor": 0, "broadcast": 0, "all_gather": 0}
+
+    class CountingDist:
+        def __getattr__(self, name):
+            fn = getattr(dist, name)
+            if name in calls:
+                def counted(*a, **kw):
+                    calls[name] += 1
+                    return fn(*a, **kw)
+                return counted
+            return fn
+
+    class Backend:
+        def shard_payload(self, n_pad):
+            bins = torch.zeros(n_pad, nb, dtype=torch.int32)
+            meta = torch.zeros(n_pad, 2, dtype=torch.int64)
+            for i, h in enumerate(hists):
+                bins[i] = torch.from_numpy(h.array().astype(np.int32))
+                meta[i] = torch.tensor([h.mag, h.length])
+            return [bins, meta]
+
+        def gather_buffers(self, n_rows):
+            self.bins, self.meta = torch.full((n_rows, nb), -1, dtype=torch.int32), torch.zeros(n_rows, 2, dtype=torch.int64)
+            return [self.bins, self.meta]
+
+        def import_rows(self, rows):
+            self.keep, self.all = [], []
+            for r in rows:
+                a = np.ascontiguousarray(self.bins[r].numpy().astype(np.uint16))
+                h = oracle_py.Hist()
+                h.dtype, h.k, h.nbins = DT, K, nb
+                h.bins = a.ctypes.data_as(C.c_void_p).value
+                h.mag, h.length = int(self.meta[r, 0]), int(self.meta[r, 1])
+                self.keep.append(a)
+                self.all.append(h)
+
+        def score_rows(self, globals_):
+            return [int(oracle_py.get_close(pred, CUTOFF, self.all[g], self.all)[0].sum()) for g in globals_]
+
+    be = Backend()
+    rr = shard.ReplicatedRows(CountingDist(), plan, be, rank)
+    rows = rr.replicate()
+    assert len(set(rows.tolist())) == plan.n_total and len(be.all) == plan.n_total
+    setup = dict(calls)
+    out = []
+    for st in range(ROW_STEPS):
+        qs = _row_queries(st, plan.n_total)
+        assert sum(len(rr.rows_of(qs, r)) for r in range(plan.world)) == ROW_Q
+        out.append(rr.score(qs, defer=bool(st % 2)))
+    out = [(t.total() if hasattr(t, "total") else t).tolist() for t in out]
+    # set-up: one all-gather per payload region; per step: the counts only
+    assert setup["all_gather_into_tensor"] == 2 and calls["all_gather_into_tensor"] == 2 + ROW_STEPS and calls["broadcast"] == 0 and calls["all_gather"] == 0, calls
+    return out
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -282,7 +351,7 @@ def _worker(rank, world, port, q):
             flags, g, sim, is_min, n_close = trn.get_close(qg)
             out.append((qg, flags.tolist(), g, sim, is_min, n_close))
         q.put((rank, mine.tolist(), out, _centre_round(dist, rank, world, seqs, pred, nb), _block_steps(dist, rank, plan, hists, pred, nb),
-               _packed_steps(dist, rank, plan, hists, pred, nb)))
+               _packed_steps(dist, rank, plan, hists, pred, nb), _row_steps(dist, rank, plan, hists, pred, nb)))
     finally:
         dist.destroy_process_group()
 
@@ -301,8 +370,8 @@ def test_sharded_passes_match_single_process(oracle, world):
         p.start()
     res = {}
     for _ in range(world):
-        r, mine, out, merged, blocks, packed = q.get(timeout=180)
-        res[r] = (mine, out, merged, blocks, packed)
+        r, mine, out, merged, blocks, packed, by_rows = q.get(timeout=180)
+        res[r] = (mine, out, merged, blocks, packed, by_rows)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -337,3 +406,8 @@ def test_sharded_passes_match_single_process(oracle, world):
         want_counts = [float(oracle.get_close(pred, CUTOFF, hs[g], hs)[0].sum()) for g in globals_]
         for r in range(world):
             assert res[r][4][st] == (globals_, want_counts), (st, r)
+    # sharded by query rows over replicated candidates: every rank reports the single-process counts of the step's whole query list
+    for st in range(ROW_STEPS):
+        want_counts = [int(oracle.get_close(pred, CUTOFF, hs[g], hs)[0].sum()) for g in _row_queries(st, len(seqs))]
+        for r in range(world):
+            assert res[r][5][st] == want_counts, (st, r)
