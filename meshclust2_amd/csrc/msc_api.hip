@@ -117,7 +117,9 @@ extern "C" int msc_create(int device, msc_ctx** out) {
 	    hipEventCreateWithFlags(&ctx->ev_product[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_product[1], hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_scored[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scored[1], hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&ctx->ev_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_copied[1], hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&ctx->ev_copied[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_copied[1], hipEventDisableTiming) != hipSuccess ||
+	    hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_call, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_prep[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_prep[1], hipEventDisableTiming) != hipSuccess) {
 		delete ctx;
 		return fail(nullptr, MSC_ERR_HIP, "msc_create: stream/event creation failed");
 	}
@@ -131,7 +133,9 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)hipStreamSynchronize(ctx->copy_stream);
-	if (g_profile_calls && ctx->prof_calls) {
+	(void)hipStreamSynchronize(ctx->tail_stream);          // (nothing may still be running on any of the context's streams when its buffers go)
+	(void)hipStreamSynchronize(ctx->prep_stream);
+	if (g_profile_calls && ctx->prof_calls && ctx->prof_wait > 0) {
 		fprintf(stderr, "[msc] 1 x M scoring calls: %llu (%llu candidates) | slot list %.3f s, launches %.3f s, stream wait %.3f s\n", (unsigned long long)ctx->prof_calls,
 		        (unsigned long long)ctx->prof_cands, ctx->prof_prep, ctx->prof_issue, ctx->prof_wait);
 		if (ctx->prof_nnz.p) {
@@ -207,6 +211,13 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->kb_qT2);
 	release(ctx->kb_min2);
 	release(ctx->kb_diff2);
+	release(ctx->kb_abits2);
+	release(ctx->kb_anib2);
+	release(ctx->kb_hot2);
+	release(ctx->kb_hot_idx2);
+	(void)hipEventDestroy(ctx->ev_call);
+	for (int i = 0; i < 2; i++) (void)hipEventDestroy(ctx->ev_prep[i]);
+	(void)hipStreamDestroy(ctx->prep_stream);
 	for (int i = 0; i < 2; i++) { (void)hipEventDestroy(ctx->ev_head[i]); (void)hipEventDestroy(ctx->ev_product[i]); (void)hipEventDestroy(ctx->ev_tail[i]); }
 	(void)hipStreamDestroy(ctx->tail_stream);
 	(void)hipStreamDestroy(ctx->stream);
@@ -477,6 +488,7 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->mb) (void)hipFree(s->mb);
 	if (s->mb_n) (void)hipFree(s->mb_n);
 	if (s->ranks) (void)hipFree(s->ranks);
+	if (s->ranks16) (void)hipFree(s->ranks16);
 	if (s->rk_n) (void)hipFree(s->rk_n);
 	if (s->sp_mirror) msc_hist_set_destroy(s->sp_mirror);
 	if (s->ent) (void)hipFree(s->ent);
@@ -1301,6 +1313,26 @@ static int model_index_of(const MscDevModel& m, uint64_t f) {
 	return -1;
 }
 
+// The f32 image behind the close-flag screen (pair_features.hip, screen_close): every single statistic must be one of the nine integer
+// reductions' functions, every constant finite in f32, the bias 0 (the screen's threshold is s >= 0, GLM::logistic at 0.5).
+static void model_screen_image(MscDevModel& h) {
+	h.screen_ok = 0;
+	if (h.bias != 0.0 || h.n_singles < 1 || h.n_singles > 8 || h.n_combos < 1) return;          // (kScreenSingles)
+	for (int i = 0; i < h.n_singles; i++) {
+		if (!(h.single_flag[i] & MSC_FEAT_FAST)) return;
+		const double range = h.maxs[i] - h.mins[i];
+		const float mn = (float)h.mins[i], inv = (float)(1.0 / range);
+		if (!(range != 0.0) || !std::isfinite(mn) || !std::isfinite(inv) || inv == 0.f) return;
+		h.s_min[i] = mn;
+		h.s_inv[i] = inv;
+	}
+	for (int c = 0; c <= h.n_combos; c++) {
+		h.s_w[c] = (float)h.weights[c];
+		if (!std::isfinite(h.s_w[c])) return;
+	}
+	h.screen_ok = 1;
+}
+
 extern "C" int msc_model_create(msc_ctx* ctx, int k, int n_combos, const int* combo_kind, const uint64_t* combo_flags, const double* weights,
                                 int n_singles, const uint64_t* single_flags, const double* mins, const double* maxs, double bias,
                                 msc_model** out) {
@@ -1345,6 +1377,7 @@ extern "C" int msc_model_create(msc_ctx* ctx, int k, int n_combos, const int* co
 		h.mins[idx] = mins[i];
 		h.maxs[idx] = maxs[i];
 	}
+	model_screen_image(h);
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	msc_model* m = new msc_model();
 	m->ctx = ctx;
@@ -1417,6 +1450,7 @@ extern "C" int msc_model_single_flags(const msc_model* m, uint64_t* out) {
 extern "C" void msc_model_set_bias(msc_model* m, double bias) {
 	if (!m) return;
 	m->h.bias = bias;
+	model_screen_image(m->h);
 	(void)hipMemcpy(m->d, &m->h, sizeof(MscDevModel), hipMemcpyHostToDevice);
 }
 
@@ -1955,6 +1989,8 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		(void)hipFree(set->ranks);
 		set->ranks = nullptr;
+		if (set->ranks16) { (void)hipFree(set->ranks16); set->ranks16 = nullptr; }
+		set->rk16_off = false;
 	}
 	if (!set->ranks) {
 		void *p = nullptr, *pn = set->rk_n;
@@ -1970,10 +2006,16 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 		set->rk_lo = 0;
 		set->rk_hi = set->capacity;
 	}
+	static const bool no_rk16 = getenv("MSC_NO_RANKS16") != nullptr;
+	if (!set->ranks16 && !set->rk16_off && !no_rk16 && set->rk_pitch % 1024 == 0) {          // the 16-bit form beside it (k_emd_ranks16)
+		void* p16 = nullptr;
+		if (hipMalloc(&p16, set->rk_pitch * 2 * set->capacity) != hipSuccess) { (void)hipGetLastError(); set->rk16_off = true; }
+		else { set->ranks16 = (uint16_t*)p16; set->rk_lo = 0; set->rk_hi = set->capacity; }
+	}
 	if (set->rk_lo < set->rk_hi) {
 		int r;
-		if ((r = ensure(ctx, ctx->rk_bad, sizeof(int32_t)))) return r;
-		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, sizeof(int32_t), ctx->stream));
+		if ((r = ensure(ctx, ctx->rk_bad, 2 * sizeof(int32_t)))) return r;
+		HIP_TRY(ctx, hipMemsetAsync(ctx->rk_bad.p, 0, 2 * sizeof(int32_t), ctx->stream));
 		// runs of slots that hold a histogram (an unwritten slot's digest is whatever the allocation held)
 		const uint64_t hi = std::min<uint64_t>(set->rk_hi, set->written.size());
 		for (uint64_t i = set->rk_lo; i < hi;) {
@@ -1981,16 +2023,22 @@ static int ensure_ranks(msc_ctx* ctx, const msc_hist_set* set) {
 			uint64_t j = i;
 			while (j < hi && set->written[j]) j++;
 			HIP_TRY(ctx, msc_launch_ranks_build(ctx->stream, set->L, set->dtype, set->bins, set->scalars, set->ranks, set->rk_n, set->rk_pitch, i, j - i, (int32_t*)ctx->rk_bad.p));
+			if (set->ranks16) HIP_TRY(ctx, msc_launch_ranks16_build(ctx->stream, set->L.nbins, set->ranks, set->ranks16, set->rk_pitch, i, j - i, (int32_t*)ctx->rk_bad.p + 1));
 			i = j;
 		}
-		int32_t bad = 0;
-		HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->rk_bad.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+		int32_t bad[2] = {0, 0};
+		HIP_TRY(ctx, hipMemcpyAsync(bad, ctx->rk_bad.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		set->rk_lo = set->rk_hi = 0;
-		if (bad) {
+		if (bad[0]) {
 			(void)hipFree(set->ranks);
 			set->ranks = nullptr;
 			set->ranks_unavailable = true;
+		}
+		if ((bad[0] || bad[1]) && set->ranks16) {          // a reduced rank that does not fit 16 bits: this set keeps the 32-bit walk
+			(void)hipFree(set->ranks16);
+			set->ranks16 = nullptr;
+			set->rk16_off = true;
 		}
 	}
 	return MSC_OK;
@@ -2045,6 +2093,7 @@ static int flush_deferred(msc_ctx* ctx) {
 		if (e == hipSuccess) e = e2;
 		ctx->tail_used = false;
 		ctx->tail_busy[0] = ctx->tail_busy[1] = false;
+		ctx->product_busy[0] = ctx->product_busy[1] = false;          // (every product waited for its queries' side: the prep stream is idle too)
 	}
 	for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
 		float t = 0;
@@ -2116,6 +2165,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		if (defer) {
 			if ((r = ensure(ctx, ctx->qslots_all, n_q * sizeof(uint32_t)))) { ctx->in_score_multi = was_in; return r; }
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->qslots_all.p, q_slots, n_q * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_call, ctx->stream));
 			ctx->defer = 1;
 			ctx->defer_cands_up = false;
 			ctx->defer_ms = 0.f;
@@ -2413,23 +2463,42 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	DevBuf& b_qT = pb ? ctx->kb_qT2 : ctx->kb_qT;
 	DevBuf& b_min = pb ? ctx->kb_min2 : ctx->kb_min;
 	DevBuf& b_diff = pb ? ctx->kb_diff2 : ctx->kb_diff;
+	DevBuf& b_abits = pb ? ctx->kb_abits2 : ctx->kb_abits;
+	DevBuf& b_anib = pb ? ctx->kb_anib2 : ctx->kb_anib;
+	DevBuf& b_hot = pb ? ctx->kb_hot2 : ctx->kb_hot;
+	DevBuf& b_hot_idx = pb ? ctx->kb_hot_idx2 : ctx->kb_hot_idx;
+	// the queries' side of a piped block goes on the prep stream, under the product of the block before it (MSC_GEMM_NO_PREP: on the product's stream, as in r04)
+	static const bool no_prep = getenv("MSC_GEMM_NO_PREP") != nullptr;
+	hipStream_t prep = piped && !no_prep ? ctx->prep_stream : ctx->stream;
 	if (ctx->tail_used)          // a block on ONE stream after piped ones waits for every epilogue in flight; a piped one for the epilogue that read its copy
 		for (int i = 0; i < 2; i++)
-			if (ctx->tail_busy[i] && (!piped || i == pb)) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[i], 0)); if (!piped) ctx->tail_busy[i] = false; }
+			if (ctx->tail_busy[i] && (!piped || i == pb)) {
+				HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[i], 0));
+				if (prep != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(prep, ctx->ev_tail[i], 0));          // (it rewrites the transposed image that epilogue read)
+				if (!piped) ctx->tail_busy[i] = false;
+			}
 	if (manh_gemm) {
 		const uint64_t nsteps = L.nbins / 128;
-		if (msc_pair_gemm_anib_bytes(L.nbins, kb_qn) && (r = ensure(ctx, ctx->kb_anib, msc_pair_gemm_anib_bytes(L.nbins, kb_qn)))) return r;
-		if ((r = ensure(ctx, ctx->kb_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
+		if (msc_pair_gemm_anib_bytes(L.nbins, kb_qn) && (r = ensure(ctx, b_anib, msc_pair_gemm_anib_bytes(L.nbins, kb_qn)))) return r;
+		if ((r = ensure(ctx, b_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
 		if (n_hot) {
-			if ((r = ensure(ctx, ctx->kb_hot, n_hot * 8)) || (r = ensure(ctx, ctx->kb_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
+			if ((r = ensure(ctx, b_hot, n_hot * 8)) || (r = ensure(ctx, b_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
 			    (r = ensure(ctx, b_diff, chunk * kb_qn * sizeof(int32_t)))) return r;
-			hot_ptr = (uint32_t*)ctx->kb_hot_idx.p;
+			hot_ptr = (uint32_t*)b_hot_idx.p;
 			hot_cursor = hot_ptr + (nsteps + 1);
 			hot_cnt = hot_cursor + (nsteps + 1);
 		}
+		if (prep != ctx->stream) {
+			HIP_TRY(ctx, hipStreamWaitEvent(prep, ctx->ev_call, 0));          // the call's query slots are up
+			if (ctx->product_busy[pb]) HIP_TRY(ctx, hipStreamWaitEvent(prep, ctx->ev_product[pb], 0));      // the product that read this copy is through
+		}
 		// the queries' side of the block, once for all chunks of candidates
-		HIP_TRY(ctx, msc_launch_pair_gemm_queries(ctx->stream, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
-		                                          (uint8_t*)ctx->kb_abits.p, (uint8_t*)b_qT.p, n_hot, ctx->kb_hot.p, hot_ptr, hot_cursor, hot_cnt, (uint8_t*)ctx->kb_anib.p));
+		HIP_TRY(ctx, msc_launch_pair_gemm_queries(prep, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
+		                                          (uint8_t*)b_abits.p, (uint8_t*)b_qT.p, n_hot, b_hot.p, hot_ptr, hot_cursor, hot_cnt, (uint8_t*)b_anib.p));
+		if (prep != ctx->stream) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_prep[pb], prep));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep[pb], 0));
+		}
 	}
 	if (emd_ranks && (r = ensure(ctx, ctx->emd_out, chunk * (manh_gemm ? kb_qn : 64) * sizeof(uint64_t)))) return r;
 	const bool count_only = digest && tps == 2 && !digest_emd;
@@ -2459,8 +2528,8 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
-			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)ctx->kb_abits.p, kb_qn, gemm_slices, hot_ptr, ctx->kb_hot.p,
-			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p, (const uint8_t*)ctx->kb_anib.p));
+			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)b_abits.p, kb_qn, gemm_slices, hot_ptr, b_hot.p,
+			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p, (const uint8_t*)b_anib.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,
 			                                          dq_slots, (uint32_t)n_q, mc_ < 256, tps, digest_emd, ctx->partials.p, ctx->num_cus, !gemm_dot, dg_tq));
@@ -2471,8 +2540,11 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			HIP_TRY(ctx, msc_launch_pair_tiles_multi(ctx->stream, L, cands->dtype, c_bins, c_scal, d_slots, mc, qset->bins, qset->L.slot_bytes, qset->scalars,
 			                                         qset->scalar_stride, dq_slots, (uint32_t)n_q, tq, compact, (MscPartial*)ctx->partials.p, ctx->num_cus));
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t1, ctx->stream));
-		if (piped) HIP_TRY(ctx, hipEventRecord(ctx->ev_product[pb], ctx->stream));
-		if (emd_ranks)
+		if (piped) { HIP_TRY(ctx, hipEventRecord(ctx->ev_product[pb], ctx->stream)); ctx->product_busy[pb] = true; }
+		if (emd_ranks && cands->ranks16 && qset->ranks16 && cands->rk_pitch == qset->rk_pitch)          // every reduced rank of both sets fits 16 bits: two per v_sad_u16
+			HIP_TRY(ctx, msc_launch_emd_ranks16(tail, L.nbins, cands->ranks16, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks16, qset->rk_n,
+			                                    dq_slots, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
+		else if (emd_ranks)
 			HIP_TRY(ctx, msc_launch_emd_ranks(tail, L.nbins, cands->ranks, cands->rk_pitch, cands->rk_n, d_slots, off, mc, qset->ranks, qset->rk_pitch, qset->rk_n,
 			                                  dq_slots, (uint32_t)n_q, (uint64_t*)ctx->emd_out.p, manh_gemm ? kb_qn : 64));
 		if (want_div) {
@@ -2547,6 +2619,10 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			if (ctx->close_pp_busy[pp]) HIP_TRY(ctx, hipStreamWaitEvent(tail, ctx->ev_copied[pp], 0));
 		}
 		ea.close_soa = d_close;
+		// only the close flags are wanted: k_pair_epilogue_bits decides them in f32 with an error bound and evaluates in FP64 only the
+		// pairs the bound leaves open -- the same flags (MSC_NO_SCREEN: FP64 for every pair)
+		static const bool no_screen = getenv("MSC_NO_SCREEN") != nullptr;
+		ea.screen = manh_gemm && model && model->h.screen_ok && d_close && !sum_out && !csum_out && !raw_out && !want_div && !want_grp && !no_screen;
 		ea.error_word = (int32_t*)ctx->err_word.p;
 		if (piped) HIP_TRY(ctx, hipStreamWaitEvent(tail, ctx->ev_product[pb], 0));
 		HIP_TRY(ctx, msc_launch_epilogue(tail, ea));

@@ -230,6 +230,123 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks(const uint32_t* __restrict
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------ the 16-bit form (r05)
+// | a_t - b_t | does not change when the same number is taken from both ranks. With base_t = floor(t * nbins / pitch) -- where the t-th
+// k-mer of a sequence whose k-mers were spread evenly over the bins would sit -- the reduced rank a_t - base_t + 32768 of ordinary
+// sequences fits 16 bits (a 1 kb sequence at k = 9 strays a few thousand bins from the even spread; the padding nbins - base_t fits
+// once a list fills 7/8 of the pitch; up to k = 7 everything fits), and v_sad_u16 then takes TWO ranks per instruction and lane: half
+// the vector instructions, half the LDS bytes and half the registers per candidate of the 32-bit walk above, so a wave holds four
+// candidates and one LDS read of a query's ranks serves four of them. Exact: the sums are the same integers. A set whose every slot
+// fits carries the mirror (k_ranks16_build reports a slot that does not, and the set then keeps the 32-bit walk); both sets of a pass
+// must share one pitch (one base_t).
+__global__ void __launch_bounds__(256) k_ranks16_build(const uint32_t* __restrict__ ranks, uint64_t pitch, uint16_t* __restrict__ out, uint64_t nbins, uint64_t first_slot,
+                                                       uint64_t n_slots, int32_t* __restrict__ bad) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_slots * pitch) return;
+	const uint64_t slot = first_slot + i / pitch, t = i % pitch;
+	const int64_t v = (int64_t)ranks[slot * pitch + t] - (int64_t)(t * nbins / pitch) + 32768;
+	if (v < 0 || v > 65535) atomicOr(bad, 1);
+	out[slot * pitch + t] = (uint16_t)v;
+}
+
+constexpr uint32_t kCand16 = 4;          // candidates per wave
+__global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restrict__ c_rk, uint64_t pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
+                                                        uint64_t first, uint32_t m, const uint16_t* __restrict__ q_rk, const uint32_t* __restrict__ q_n,
+                                                        const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
+	__shared__ v4i_ sQ[2][kQHalf][kRound / 8];          // 2 x 16 KiB: a list's round = 1 024 reduced ranks = 2 KiB
+	const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t c0 = (blockIdx.x * kWaves + wave) * kCand16;
+	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup;
+	uint64_t slot[kCand16];
+	uint32_t nc[kCand16];
+#pragma unroll
+	for (uint32_t c = 0; c < kCand16; c++) {
+		const uint32_t ci = c0 + c < m ? c0 + c : m - 1;
+		slot[c] = cand_slots ? cand_slots[ci] : first + ci;
+		nc[c] = c_n[slot[c]];
+	}
+	const uint32_t my_q = ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
+	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sQ[0][0][0]);
+	for (uint64_t base = 0; base < pitch; base += kRound) {
+		v4i_ a[kCand16][2];          // lane l: reduced ranks 512 j + 8 l .. + 7 of the round, two per register
+#pragma unroll
+		for (uint32_t c = 0; c < kCand16; c++)
+#pragma unroll
+			for (int j = 0; j < 2; j++) a[c][j] = *reinterpret_cast<const v4i_*>(c_rk + slot[c] * pitch + base + 512 * j + 8 * lane);          // (pitch is a multiple of 1 024 here)
+#pragma unroll
+		for (uint32_t c = 0; c < kCand16; c++)
+#pragma unroll
+			for (int j = 0; j < 2; j++) asm volatile("" : "+v"(a[c][j]));
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		auto stage = [&](uint32_t h) {          // half-group h -> ring slot h % 2: wave q moves list q's round, two pieces of 1 KiB
+			const uint32_t q = wave, qi = h * kQHalf + q;
+			const uint32_t qs = q_slots[qi < n_q ? qi : n_q - 1];          // (rows past n_q: some list, never stored)
+#pragma unroll
+			for (uint32_t part = 0; part < 2; part++)
+				dma_piece((uint64_t)(q_rk + (uint64_t)qs * pitch + base + 512 * part), lane * 16u, lds0 + (((h & 1) * kQHalf + q) * (kRound / 8) + 64 * part) * 16);
+		};
+		uint32_t sum[kCand16][kQGroup];
+		auto walk = [&](uint32_t buf, auto half) {
+			constexpr uint32_t H = decltype(half)::value;
+#pragma unroll
+			for (uint32_t q = 0; q < kQHalf; q++) {
+				v4i_ b[2];
+#pragma unroll
+				for (int j = 0; j < 2; j++) b[j] = sQ[buf][q][64 * j + lane];
+#pragma unroll
+				for (uint32_t c = 0; c < kCand16; c++) {
+					uint32_t t = 0;          // 16 terms of < 2^17 per lane; 64 lanes in the fold: < 2^27
+#pragma unroll
+					for (int j = 0; j < 2; j++) {
+						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].x), "v"(b[j].x));
+						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].y), "v"(b[j].y));
+						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
+						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
+					}
+					sum[c][H * kQHalf + q] = t;
+				}
+			}
+		};
+		auto landed = [&] {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+		};
+		stage(0);
+		for (uint32_t g = 0; g < n_groups; g++) {
+			uint32_t nq_max = 0;
+			for (uint32_t q = 0; q < kQGroup; q++) {
+				const uint32_t qi = g * kQGroup + q;
+				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
+				nq_max = v > nq_max ? v : nq_max;
+			}
+			uint32_t reach = nq_max;
+#pragma unroll
+			for (uint32_t c = 0; c < kCand16; c++) reach = nc[c] > reach ? nc[c] : reach;
+			const bool idle = base != 0 && base >= reach;          // (a later round past every list of the wave and the group: all terms | pad - pad |)
+			landed();
+			stage(2 * g + 1);
+			if (!idle) walk(0, std::integral_constant<uint32_t, 0>());
+			landed();
+			if (g + 1 < n_groups) stage(2 * g + 2);
+			if (idle) continue;
+			walk(1, std::integral_constant<uint32_t, 1>());
+			const uint32_t q0 = g * kQGroup;
+			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
+#pragma unroll
+			for (uint32_t c = 0; c < kCand16; c++) {
+				const uint32_t tot = fold16q(sum[c]);
+				if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
+					uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
+					*o = base ? *o + tot : (uint64_t)tot;
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	}
+}
+
 }  // namespace
 
 // ranks per slot of a set whose longest list holds `max_excess` k-mers
@@ -257,5 +374,22 @@ hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* 
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > out_stride || nbins > (1u << 20) || c_pitch % 256 || q_pitch % 256) return hipErrorInvalidValue;
 	k_emd_ranks<<<dim3((m + kWaves * kCandPerWave - 1) / (kWaves * kCandPerWave)), dim3(64 * kWaves), 0, st>>>(c_ranks, c_pitch, c_n, cand_slots, first, m, q_ranks, q_pitch, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
+	return hipGetLastError();
+}
+
+// the 16-bit mirror of slots [first_slot, first_slot + n_slots) from their ranks; *bad |= 1 when a reduced rank does not fit
+hipError_t msc_launch_ranks16_build(hipStream_t st, uint64_t nbins, const uint32_t* ranks, uint16_t* ranks16, uint64_t pitch, uint64_t first_slot, uint64_t n_slots, int32_t* bad) {
+	if (n_slots == 0) return hipSuccess;
+	const uint64_t n = n_slots * pitch;
+	k_ranks16_build<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(ranks, pitch, ranks16, nbins, first_slot, n_slots, bad);
+	return hipGetLastError();
+}
+
+// as msc_launch_emd_ranks over the 16-bit mirrors of two sets that share one pitch (a multiple of 1 024)
+hipError_t msc_launch_emd_ranks16(hipStream_t st, uint64_t nbins, const uint16_t* c_ranks, uint64_t pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
+                                  uint32_t m, const uint16_t* q_ranks, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out, uint32_t out_stride) {
+	if (m == 0 || n_q == 0) return hipSuccess;
+	if (n_q > out_stride || nbins > (1u << 20) || pitch % kRound) return hipErrorInvalidValue;
+	k_emd_ranks16<<<dim3((m + kWaves * kCand16 - 1) / (kWaves * kCand16)), dim3(64 * kWaves), 0, st>>>(c_ranks, pitch, c_n, cand_slots, first, m, q_ranks, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
 	return hipGetLastError();
 }

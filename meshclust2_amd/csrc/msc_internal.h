@@ -31,6 +31,13 @@ struct MscDevModel {
 	int32_t  combo_idx[MSC_MAX_COMBOS][2];
 	double   weights[MSC_MAX_COMBOS + 1];
 	double   bias;
+	// f32 image of the same model for the close-flag screen of k_pair_epilogue_bits (pair_features.hip, screen_close): filled by
+	// msc_model_create; screen_ok = 0 when the model is outside what the screen bounds (a statistic that is not an integer reduction,
+	// a bias, a non-finite constant)
+	int32_t  screen_ok;
+	float    s_min[MSC_MAX_SINGLES];          // mins[i]
+	float    s_inv[MSC_MAX_SINGLES];          // 1 / (maxs[i] - mins[i])
+	float    s_w[MSC_MAX_COMBOS + 1];         // weights
 };
 
 // One 1 x M problem of a batched launch (k_pair_tiles_batch, k_colsum_batch): query slot, its candidates' positions in the
@@ -119,6 +126,7 @@ struct MscEpilogueArgs {
 	double*  sum_soa;
 	double*  csum_soa;
 	uint8_t* close_soa;
+	int32_t  screen;                  // k_pair_epilogue_bits: only close_soa is wanted and the model has an f32 image -- decide in f32 with an error bound, FP64 where that does not decide
 	int32_t* error_word;              // atomicMin of negative statuses
 	// batched launch (k_pair_tiles_batch): candidate c belongs to segment pair_seg[c]; query slot and window come from it
 	const MscBatchSeg* segs;
@@ -191,6 +199,9 @@ hipError_t msc_launch_ranks_build(hipStream_t st, const MscLayout& L, int dtype,
 hipError_t msc_launch_emd_ranks(hipStream_t st, uint64_t nbins, const uint32_t* c_ranks, uint64_t c_pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
                                 uint32_t m, const uint32_t* q_ranks, uint64_t q_pitch, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out,
                                 uint32_t out_stride = 64);
+hipError_t msc_launch_ranks16_build(hipStream_t st, uint64_t nbins, const uint32_t* ranks, uint16_t* ranks16, uint64_t pitch, uint64_t first_slot, uint64_t n_slots, int32_t* bad);
+hipError_t msc_launch_emd_ranks16(hipStream_t st, uint64_t nbins, const uint16_t* c_ranks, uint64_t pitch, const uint32_t* c_n, const uint32_t* cand_slots, uint64_t first,
+                                  uint32_t m, const uint16_t* q_ranks, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out, uint32_t out_stride);
 // the r04 form of that pass (msc_pair_gemm.hip): presence-bit mirror + lists of large bins, the queries' side of a block, the product
 uint64_t msc_kb_bytes(const MscLayout& L, uint64_t capacity);
 hipError_t msc_launch_kb_build(hipStream_t st, const MscLayout& L, int dtype, const uint8_t* bins, uint8_t* kb, uint64_t first_slot, uint64_t n_slots, void* mb,

@@ -11,7 +11,13 @@
 #pragma once
 #include <stdint.h>
 
-#define MSC_KB_QCAP 127u      // largest excess count a byte of the queries' transposed image holds; larger ones are looked up in the list
+// The queries' transposed image of a block (k_kb_gather): per bin two planes of qn bits (each padded to 16 bytes): plane 0 = the query's
+// presence bit, plane 1 = "its excess count is >= 2" (the exact count then sits in the query's list of large bins).
+// -> index of the 32-bit word that holds row `row` of plane `plane` of bin `bin`; its bit: row & 31
+__host__ __device__ __forceinline__ uint64_t msc_qt_word(uint64_t bin, uint32_t plane, uint32_t row, uint32_t qn) {
+	const uint32_t wpp = qn < 128 ? 4 : qn / 32;          // words per plane
+	return (bin * 2 + plane) * wpp + (row >> 5);
+}
 
 __host__ __device__ __forceinline__ uint64_t msc_kb_block_bytes(uint64_t nbins) { return nbins * 4 + 1024; }
 // byte offset of the halfword that holds bin `bin` of `slot` (its bit: bin & 15)

@@ -76,6 +76,14 @@ struct msc_ctx {
 	hipStream_t tail_stream = nullptr;
 	hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_product[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
 	DevBuf kb_qT2, kb_min2, kb_diff2;
+	// r05: the queries' side of a block (k_kb_gather, k_hot_*) is prepared on a third stream while the product of the block before it
+	// runs, so the product stream goes from product to product. Everything that side writes exists twice (the first copies are kb_abits,
+	// kb_anib, kb_hot, kb_hot_idx, kb_qT). ev_call = this call's query slots are on the device; ev_prep[i] = the queries' side in copy i
+	// is ready; product_busy[i] = a product that reads copy i has been queued and ev_product[i] says when it is through
+	hipStream_t prep_stream = nullptr;
+	hipEvent_t ev_call = nullptr, ev_prep[2] = {nullptr, nullptr};
+	DevBuf kb_abits2, kb_anib2, kb_hot2, kb_hot_idx2;
+	bool product_busy[2] = {false, false};
 	bool tail_busy[2] = {false, false};
 	bool tail_used = false;
 	uint32_t pipe_next = 0;
@@ -125,6 +133,10 @@ struct msc_hist_set {
 	mutable uint32_t* rk_n = nullptr;
 	mutable uint64_t rk_pitch = 0, rk_lo = 0, rk_hi = 0;
 	mutable bool ranks_unavailable = false;
+	// ... and their 16-bit form (rank - floor(t * 4^k / pitch) + 32768; msc_emd_ranks.hip, k_emd_ranks16), kept while every slot's reduced
+	// ranks fit and the pitch is a multiple of 1 024; rk16_off: a slot did not fit (or the allocation failed): the 32-bit walk stays
+	mutable uint16_t* ranks16 = nullptr;
+	mutable bool rk16_off = false;
 	// sparse mirror of a DENSE set: the sorted (bin, value) lists of its slots, kept so that the divergence
 	// statistics of every route come from the one merge kernel; slots [sm_lo, sm_hi) are stale. Built on first use.
 	mutable msc_hist_set* sp_mirror = nullptr;

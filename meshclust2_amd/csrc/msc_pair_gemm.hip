@@ -99,8 +99,9 @@ __global__ void __launch_bounds__(256) k_kb_build(const T* __restrict__ bins, ui
 template <int QN>
 __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ kb, const uint32_t* __restrict__ q_slots, uint32_t n_q, uint64_t nbins,
                                                    uint8_t* __restrict__ abits, uint8_t* __restrict__ qT, int fp4_image, uint8_t* __restrict__ anib) {
-	__shared__ v4i tile[QN * 8];          // [row][16-byte segment 2 kc + h]: the presence bytes of this step
+	__shared__ uint32_t qbits[kStep * (QN / 32)];          // [bin of the step][word of 32 rows]
 	const uint32_t step = blockIdx.x, row = threadIdx.x;
+	uint32_t hwv_keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	if (row < QN) {
 		uint32_t hwv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		if (row < n_q) {
@@ -127,17 +128,42 @@ __global__ void __launch_bounds__(256) k_kb_gather(const uint8_t* __restrict__ k
 		}
 		else *reinterpret_cast<v4i*>(abits + ((uint64_t)step * QN + row) * 16) = packed;
 #pragma unroll
-		for (int sg = 0; sg < 8; sg++) tile[row * 8 + sg] = expand16(hwv[sg]);
+		for (int sg = 0; sg < 8; sg++) hwv_keep[sg] = hwv[sg];
+	}
+	// transposed, as BITS: bin p of the step (halfword p / 16 of the row, bit p % 16) -> one ballot per bin and wave of 64 rows; lane l of a
+	// wave keeps the ballots of bins l and l + 64. Record of a bin = [plane][QN / 32 words]: plane 0 = "the query holds this k-mer"
+	// (e >= 1), plane 1 = "... more than once" (e >= 2: set by k_hot_fill; the epilogue then reads the count in the query's own list).
+	if (row < ((QN + 63u) & ~63u)) {          // (whole waves: a lane past QN holds zeros and keeps the ballots of its two bins like any other)
+		const uint32_t lane = row & 63, wv = row >> 6;
+		uint32_t lo[2] = {0, 0}, hi[2] = {0, 0};
+#pragma unroll
+		for (uint32_t pth = 0; pth < kStep; pth++) {
+			const unsigned long long b = __builtin_amdgcn_ballot_w64((hwv_keep[pth >> 4] >> (pth & 15)) & 1u);
+			// (a select, not v_writelane from inline asm: the compiler pads no wait states between the compare that writes the ballot's
+			// scalar registers and an asm statement that reads them, and the lane then keeps the PREVIOUS bin's ballot now and then)
+			const bool mine = lane == (pth & 63);
+			lo[pth >> 6] = mine ? (uint32_t)b : lo[pth >> 6];
+			hi[pth >> 6] = mine ? (uint32_t)(b >> 32) : hi[pth >> 6];
+		}
+#pragma unroll
+		for (uint32_t hf = 0; hf < 2; hf++) {
+			qbits[(64 * hf + lane) * (QN / 32) + 2 * wv] = lo[hf];
+			if (QN >= 64) qbits[(64 * hf + lane) * (QN / 32) + 2 * wv + 1] = hi[hf];
+		}
 	}
 	__syncthreads();
-	// transposed: bin p of the step (k-chunk p / 32, half (p / 16) % 2, bit p % 16) x 16 rows per 16-byte store
-	const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
-	for (uint32_t it = threadIdx.x; it < kStep * (QN / 16); it += 256) {
-		const uint32_t p = it / (QN / 16), r0 = (it % (QN / 16)) * 16;
-		uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-		for (int j = 0; j < 16; j++) w[j >> 2] |= (uint32_t)tb[(r0 + j) * kStep + p] << (8 * (j & 3));
-		*reinterpret_cast<uint4*>(qT + ((uint64_t)step * kStep + p) * QN + r0) = make_uint4(w[0], w[1], w[2], w[3]);
+	// one 16-byte piece per thread: (bin, plane, piece) in the record's own order; plane 1 leaves here as zeros
+	constexpr uint32_t PPB = QN / 128 ? QN / 128 : 1;          // 16-byte pieces per plane of a record (QN < 128: the record is padded to 16 bytes per plane)
+	for (uint32_t it = threadIdx.x; it < kStep * 2 * PPB; it += 256) {
+		const uint32_t pbin = it / (2 * PPB), plane = (it / PPB) & 1, piece = it % PPB;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (plane == 0) {
+			const uint32_t* src = qbits + pbin * (QN / 32) + 4 * piece;
+			v.x = src[0];
+			if (QN >= 64) v.y = src[1];
+			if (QN >= 128) { v.z = src[2]; v.w = src[3]; }
+		}
+		*reinterpret_cast<uint4*>(qT + (((uint64_t)step * kStep + pbin) * 2 * PPB + plane * PPB + piece) * 16) = v;
 	}
 }
 
@@ -178,7 +204,7 @@ __global__ void __launch_bounds__(256) k_hot_fill(const uint2* __restrict__ mb, 
 		const uint2 en = mb[(uint64_t)slot * pitch + i];
 		const uint32_t g = en.y - 1 > 0xffffu ? 0xffffu : en.y - 1;          // (counts of the narrow range are <= 8191)
 		hot[atomicAdd(&cursor[en.x / kStep], 1u)] = make_uint2(en.x, (row << 16) | g);
-		qT[(uint64_t)en.x * qn + row] = (uint8_t)(en.y > MSC_KB_QCAP ? MSC_KB_QCAP : en.y);
+		atomicOr(reinterpret_cast<uint32_t*>(qT) + msc_qt_word(en.x, 1, row, qn), 1u << (row & 31));
 	}
 }
 
@@ -711,7 +737,7 @@ uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_c
 
 // bytes of the queries' side of a block: the bit image (16 bytes per row and step) and the transposed counts (a byte per bin and row)
 uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn) { return nbins / 8 * qn; }
-uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn) { return nbins * qn; }
+uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn) { return nbins * 2 * (qn < 128 ? 16 : qn / 8); }
 // ... and the nibble image of the queries' tiles for the LDS-DMA form of the product (0: that form is off)
 uint64_t msc_pair_gemm_anib_bytes(uint64_t nbins, uint32_t qn) { return pair_gemm_dma() ? nbins / 2 * qn : 0; }
 

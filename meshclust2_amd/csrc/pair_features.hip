@@ -993,6 +993,94 @@ __device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci,
 	if (ret) *ret = po;
 }
 
+// ---------------------------------------------------------------------------------------- the close flag in f32, with an error bound
+// When a Q x M call wants nothing but the close flags (fastcar's Predictor::close loop, fastcar/FC_Runner.cpp:446-458; the bench's step),
+// the FP64 evaluation above -- ~1 200 vector instructions per pair, most of them the Newton sequences of FP64 divide / sqrt / exp -- is
+// far more than the decision needs: close <=> round(1 / (1 + exp(-s)) + 0) > 0 <=> s >= 0 up to FP64 rounding of s itself
+// (predict/GLM.cpp:26-29, cluster/Trainer.cpp:112-120). screen_close evaluates s in f32 from the same EXACT integer reductions and carries
+// an upper bound B of |s_f32 - s| along: every raw statistic is a short chain of well-conditioned f32 operations on exactly formed
+// integers (every difference is taken in integer or FP64 arithmetic BEFORE the conversion), so its relative error is below
+// kScreenEps = 2^-20 (16 units of f32 roundoff; the chains have at most 7 roundings of <= 1 ulp each); the bound then follows
+// normalisation, products and the weighted sum by ordinary interval arithmetic. s_f32 > B: close. s_f32 < -B: not close. Otherwise
+// (|s| within B of 0, a NaN or an infinity anywhere -- comparisons with NaN are false) the pair is UNDECIDED and the caller evaluates it
+// in FP64 as before, so the flags are those of the FP64 path, pair for pair (tests/test_gpu_qxm_direct.py compares them).
+constexpr float kScreenEps = 9.5367431640625e-07f;      // 2^-20
+constexpr int kScreenSingles = 8;                       // single statistics of a model with an f32 image (msc_model_create; the reference's models hold at most 8)
+
+__device__ __forceinline__ float screen_raw(uint64_t flag, const PairTotals& t, const Side& a, const Side& b, uint64_t nbins, int dtype) {
+	const float N = (float)nbins;
+	switch (flag) {
+	case MSC_FEAT_MANHATTAN:
+		return (float)(int32_t)(uint32_t)t.manh;
+	case MSC_FEAT_EUCLIDEAN:
+		return __builtin_amdgcn_sqrtf((float)(a.sq + b.sq - 2 * t.dot));
+	case MSC_FEAT_NORMALIZED_VECTORS:
+		return (float)t.dot * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(a.sq * b.sq)));
+	case MSC_FEAT_PEARSON_COEFF: {     // the three cancelling sums in FP64 as raw_stat forms them (adds and multiplies only), then f32
+		const double Nd = (double)nbins, dap = (double)a.mag / Nd, daq = (double)b.mag / Nd;
+		const double np = (double)a.sq - 2.0 * dap * (double)a.sum + Nd * dap * dap;
+		const double nq = (double)b.sq - 2.0 * daq * (double)b.sum + Nd * daq * daq;
+		const double dt = (double)t.dot - daq * (double)a.sum - dap * (double)b.sum + Nd * dap * daq;
+		return (float)dt * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)np * (float)nq));
+	}
+	case MSC_FEAT_INTERSECTION:
+		return (float)(2 * ((a.sum + b.sum - t.manh) >> 1)) * __builtin_amdgcn_rcpf((float)(a.mag + b.mag));
+	case MSC_FEAT_EMD:
+		return (float)t.emd;
+	case MSC_FEAT_LENGTHD:
+		return (float)(a.len > b.len ? a.len - b.len : b.len - a.len);
+	case MSC_FEAT_KULCZYNSKI2: {
+		const float ap = (float)a.mag * __builtin_amdgcn_rcpf(N), aq = (float)b.mag * __builtin_amdgcn_rcpf(N);
+		return N * (ap + aq) * __builtin_amdgcn_rcpf(2.f * ap * aq) * (float)((a.sum + b.sum - t.manh) >> 1);
+	}
+	case MSC_FEAT_SIMRATIO: {
+		uint64_t norm2 = a.sq + b.sq - 2 * t.dot;
+		if (dtype == 32) {          // (the wrap of raw_stat, in exact integers)
+			const int64_t sdiff = (int64_t)a.sum - (int64_t)b.sum;
+			norm2 -= (uint64_t)(((int64_t)t.manh - sdiff) >> 1) << 33;
+		}
+		const float d = (float)t.dot;
+		return d * __builtin_amdgcn_rcpf(d + __builtin_amdgcn_sqrtf((float)norm2));
+	}
+	default:
+		return NAN;          // (msc_model_create gives such a model no f32 image; a NaN leaves every pair undecided)
+	}
+}
+
+// -> 1 close, 0 not close, -1 undecided. a / b = first / second argument of the reference call.
+__device__ __forceinline__ int screen_close(const MscDevModel& md, const PairTotals& t, const Side& a, const Side& b, uint64_t nbins, int dtype) {
+	if (a.len == 0 || b.len == 0) return -1;          // (length_difference throws: the FP64 path reports it)
+	float v[kScreenSingles], dv[kScreenSingles];
+	for (int i = 0; i < md.n_singles && i < kScreenSingles; i++) {
+		const float r = screen_raw(md.single_flag[i], t, a, b, nbins, dtype);
+		const float u = (r - md.s_min[i]) * md.s_inv[i];
+		const float du = (kScreenEps * (fabsf(r) + fabsf(md.s_min[i])) + 1e-30f) * fabsf(md.s_inv[i]) + kScreenEps * fabsf(u);
+		v[i] = md.is_sim[i] ? u : 1.f - u;
+		dv[i] = du + kScreenEps * fabsf(v[i]);
+	}
+	float s = md.s_w[0], B = kScreenEps * fabsf(md.s_w[0]) + 1e-12f;
+	for (int col = 0; col < md.n_combos; col++) {
+		const int i0 = md.combo_idx[col][0], i1 = md.combo_idx[col][1], n = md.combo_n[col];
+		const float x = v[i0], ax = fabsf(x), hx = ax + dv[i0];
+		const float y = n == 2 || md.combo_kind[col] == MSC_COMBO_XY2 || md.combo_kind[col] == MSC_COMBO_X2Y ? v[i1] : 1.f;
+		const float ay = fabsf(y), hy = n == 2 || md.combo_kind[col] == MSC_COMBO_XY2 || md.combo_kind[col] == MSC_COMBO_X2Y ? ay + dv[i1] : 1.f;
+		float d, p, h;          // the product, of absolute values, of their upper bounds
+		switch (md.combo_kind[col]) {
+		case MSC_COMBO_XY:   d = x * y;         p = ax * ay;           h = hx * hy; break;
+		case MSC_COMBO_X2Y2: d = x * x * y * y; p = ax * ax * ay * ay; h = hx * hx * hy * hy; break;
+		case MSC_COMBO_XY2:  d = x * y * y;     p = ax * ay * ay;      h = hx * hy * hy; break;
+		default:             d = x * x * y;     p = ax * ax * ay;      h = hx * hx * hy; break;
+		}
+		const float w = md.s_w[col + 1];
+		s += w * d;
+		B += fabsf(w) * ((h - p) + 2.f * kScreenEps * h);
+	}
+	B += kScreenEps * fabsf(s);
+	if (s > B) return 1;
+	if (s < -B) return 0;
+	return -1;
+}
+
 __device__ void epilogue_one(const MscEpilogueArgs& a, uint32_t c, const PairTotals& t, MscPairOut* ret = nullptr) {
 	// c is a virtual index: query-major [n_queries][m_per_query] when several queries were scored in one launch
 	uint32_t ci = c, qi = 0;
@@ -1091,6 +1179,42 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_cq(const MscEpilogueAr
 // (e = count - 1 >= 2) -- see the head of that file. One wave per (candidate, 64 queries), lane = query: the list is walked by the wave
 // (entries are wave-uniform, the queries' counts at an entry's bin are one coalesced 64-byte read of the transposed image).
 // Everything in exact 64-bit integers.
+// The integer reductions of one (candidate, query) pair from the product's output and the two lists of large bins. Wave-uniform: ci, slot,
+// cmb, c_n (the candidate's list goes through the scalar cache); per lane: qq (its query row), q_slot.
+__device__ __forceinline__ void bits_pair_totals(const MscEpilogueArgs& a, uint32_t ci, const uint2* cmb, uint32_t c_n, uint32_t qq, uint32_t q_slot, int64_t min_e, int64_t diff_e,
+                                                 uint64_t emd, const Side& cand, const Side& qry, PairTotals& t) {
+	int64_t dot_e = min_e + diff_e;
+	// the candidate's large bins, four at a time: e_q (e_c - 1) for the products; min(e_q, e_c) - 1 where the query's bin is large too
+	for (uint32_t i0 = 0; i0 < c_n; i0 += 4) {
+		uint2 en[4];
+		uint32_t x_q[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) en[j] = cmb[i0 + j < c_n ? i0 + j : c_n - 1];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {          // bit 0: the query holds the k-mer; bit 1: more than once
+			const uint32_t* qt = reinterpret_cast<const uint32_t*>(a.kb_qT);
+			x_q[j] = ((qt[msc_qt_word(en[j].x, 0, qq, a.kb_qn)] >> (qq & 31)) & 1u) | (((qt[msc_qt_word(en[j].x, 1, qq, a.kb_qn)] >> (qq & 31)) & 1u) << 1);
+		}
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			if (i0 + j >= c_n) break;
+			const int64_t e_c = en[j].y;
+			int64_t e_q = x_q[j] & 1u;
+			if (x_q[j] & 2u) {          // a large bin of the query too: its own list has the count
+				const uint2* qmb = reinterpret_cast<const uint2*>(a.kb_q_mb) + (uint64_t)q_slot * a.kb_q_pitch;
+				const uint32_t q_n = a.kb_q_mb_n[q_slot] < a.kb_q_pitch ? a.kb_q_mb_n[q_slot] : a.kb_q_pitch;
+				for (uint32_t t_ = 0; t_ < q_n; t_++) if (qmb[t_].x == en[j].x) { e_q = qmb[t_].y; break; }
+			}
+			dot_e += (e_c - 1) * e_q;
+			if (e_q >= 2) min_e += (e_q < e_c ? e_q : e_c) - 1;
+		}
+	}
+	const uint64_t ex_c = cand.sum - a.nbins, ex_q = qry.sum - a.nbins;          // sum of the excess counts
+	t.manh = ex_c + ex_q - 2 * (uint64_t)min_e;
+	t.dot = a.nbins + ex_c + ex_q + (uint64_t)dot_e;
+	t.emd = emd;
+}
+
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits(const MscEpilogueArgs a) {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t groups = (a.n_queries + 63) / 64;
@@ -1117,40 +1241,114 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits(const MscEpilogue
 #pragma unroll
 		for (uint32_t j = 0; j < 16; j++) min_e += part[j];
 	}
-	int64_t dot_e = min_e;
-	if (a.kb_diff) dot_e += a.kb_diff[(uint64_t)ci * a.kb_qn + qq];
+	const int64_t diff_e = a.kb_diff ? a.kb_diff[(uint64_t)ci * a.kb_qn + qq] : 0;
 	const uint64_t emd = a.emd_ranks ? a.emd_ranks[(uint64_t)ci * (a.emd_stride ? a.emd_stride : 64) + qq] : 0;
 	const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)q_slot * a.q_scalar_stride);
 	const Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
-	// the candidate's large bins, four at a time: e_q (e_c - 1) for the products; min(e_q, e_c) - 1 where the query's bin is large too
-	for (uint32_t i0 = 0; i0 < c_n; i0 += 4) {
-		uint2 en[4];
-		uint32_t x_q[4];
+	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+	bits_pair_totals(a, ci, cmb, c_n, qq, q_slot, min_e, diff_e, emd, cand, qry, t);
+	if (!live) return;
+	epilogue_eval(a, q * a.m_per_query + ci, ci, q, cand, qry, a.min_len, a.max_len, t);
+}
+
+// The same pass when only the close flags are wanted and the model has an f32 image (screen_close above): a wave takes kScreenChunk
+// CONSECUTIVE candidates x 64 queries (lane = query), so that the queries' side -- slot, scalar record, everything the compiler derives
+// from them -- is fetched once per chunk instead of once per candidate, and a lane's flags of the chunk leave as ONE 16-byte store into its
+// query's row (a byte per (lane, candidate) was 64 partial lines per store instruction). A pair the screen leaves undecided gets the
+// flag byte kScreenOpen; k_pair_epilogue_bits_open, queued behind this kernel, finds those bytes and evaluates their pairs in FP64 --
+// as its own launch, because the FP64 evaluation inlined here took the kernel from 131 to 212 registers for one pair in thousands.
+constexpr uint32_t kScreenOpen = 2;          // flag byte of a pair the screen left undecided, until k_pair_epilogue_bits_open has evaluated it
+template <uint32_t kScreenChunk>
+__global__ void __launch_bounds__(kBlock, 4) k_pair_epilogue_bits_screen(const MscEpilogueArgs a) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t groups = (a.n_queries + 63) / 64;
+	const uint32_t chunks = (a.m_per_query + kScreenChunk - 1) / kScreenChunk;
+	const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+	if (w >= chunks * groups) return;
+	const uint32_t c0 = (w / groups) * kScreenChunk, q = (w % groups) * 64 + lane;
+	const uint32_t nc = a.m_per_query - c0 < kScreenChunk ? a.m_per_query - c0 : kScreenChunk;
+	const bool live = q < a.n_queries;
+	const uint32_t qq = live ? q : 0;
+	const uint32_t q_slot = a.q_slots[qq];
+	const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)q_slot * a.q_scalar_stride);
+	const Side qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
+	const uint32_t ns = a.kb_slices, estride = a.emd_stride ? a.emd_stride : 64;
+	uint32_t fl[4] = {0, 0, 0, 0};
+	// one candidate's loads and integer reductions (the candidate's record and list are wave-uniform: scalar cache)
+	auto totals_of = [&](uint32_t ci, int64_t min_e, int64_t diff_e, uint64_t emd, Side& cand, PairTotals& t) {
+		const uint32_t slot_rel = a.cand_slots ? a.cand_slots[ci] : ci;
+		const uint64_t slot = a.cand_slots ? (uint64_t)slot_rel : a.kb_first + ci;
+		const uint2* cmb = reinterpret_cast<const uint2*>(a.kb_c_mb) + slot * a.kb_c_pitch;
+		const uint32_t c_n = a.kb_c_mb_n[slot] < a.kb_c_pitch ? a.kb_c_mb_n[slot] : a.kb_c_pitch;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot_rel * a.cand_scalar_stride);
+		cand = Side{cs->mag, cs->length, cs->sum, cs->sum_sq};
+		bits_pair_totals(a, ci, cmb, c_n, qq, q_slot, min_e, diff_e, emd, cand, qry, t);
+	};
+	auto sums_of = [&](uint32_t ci, int64_t& min_e, int64_t& diff_e, uint64_t& emd) {
+		int64_t v = a.kb_min[(uint64_t)ci * a.kb_qn + qq];
+		for (uint32_t s_ = 1; s_ < ns; s_++) v += a.kb_min[((uint64_t)s_ * a.m_per_query + ci) * a.kb_qn + qq];
+		min_e = v;
+		diff_e = a.kb_diff ? a.kb_diff[(uint64_t)ci * a.kb_qn + qq] : 0;
+		emd = a.emd_ranks ? a.emd_ranks[(uint64_t)ci * estride + qq] : 0;
+	};
+#pragma unroll 1
+	for (uint32_t j0 = 0; j0 < nc; j0 += 4) {
+		int64_t min4[4], diff4[4];          // four candidates' loads in flight together
+		uint64_t emd4[4];
 #pragma unroll
-		for (uint32_t j = 0; j < 4; j++) en[j] = cmb[i0 + j < c_n ? i0 + j : c_n - 1];
-#pragma unroll
-		for (uint32_t j = 0; j < 4; j++) x_q[j] = a.kb_qT[(uint64_t)en[j].x * a.kb_qn + qq];
+		for (uint32_t j = 0; j < 4; j++) sums_of(c0 + (j0 + j < nc ? j0 + j : nc - 1), min4[j], diff4[j], emd4[j]);
 #pragma unroll
 		for (uint32_t j = 0; j < 4; j++) {
-			if (i0 + j >= c_n) break;
-			const int64_t e_c = en[j].y;
-			int64_t e_q = x_q[j];
-			if (x_q[j] == MSC_KB_QCAP) {          // clamped (or exactly 127): the query's own list has the count
-				const uint2* qmb = reinterpret_cast<const uint2*>(a.kb_q_mb) + (uint64_t)q_slot * a.kb_q_pitch;
-				const uint32_t q_n = a.kb_q_mb_n[q_slot] < a.kb_q_pitch ? a.kb_q_mb_n[q_slot] : a.kb_q_pitch;
-				for (uint32_t t_ = 0; t_ < q_n; t_++) if (qmb[t_].x == en[j].x) { e_q = qmb[t_].y; break; }
-			}
-			dot_e += (e_c - 1) * e_q;
-			if (e_q >= 2) min_e += (e_q < e_c ? e_q : e_c) - 1;
+			if (j0 + j >= nc) break;
+			Side cand;
+			PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+			totals_of(c0 + j0 + j, min4[j], diff4[j], emd4[j], cand, t);
+			const int verdict = a.order == MSC_ORDER_CAND_FIRST ? screen_close(*a.model, t, cand, qry, a.nbins, a.dtype) : screen_close(*a.model, t, qry, cand, a.nbins, a.dtype);
+			fl[(j0 + j) >> 2] |= (uint32_t)(verdict < 0 ? kScreenOpen : verdict) << (8 * ((j0 + j) & 3));
+			__builtin_amdgcn_sched_barrier(0);          // (one candidate's evaluation at a time: interleaved, the four take 212 registers)
 		}
 	}
 	if (!live) return;
-	PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-	const uint64_t ex_c = cand.sum - a.nbins, ex_q = qry.sum - a.nbins;          // sum of the excess counts
-	t.manh = ex_c + ex_q - 2 * (uint64_t)min_e;
-	t.dot = a.nbins + ex_c + ex_q + (uint64_t)dot_e;
-	t.emd = emd;
-	epilogue_eval(a, q * a.m_per_query + ci, ci, q, cand, qry, a.min_len, a.max_len, t);
+	uint8_t* row = a.close_soa + (uint64_t)q * a.m_per_query + c0;
+	if (kScreenChunk == 16 && nc == kScreenChunk && ((uintptr_t)row & 15) == 0) *reinterpret_cast<uint4*>(row) = make_uint4(fl[0], fl[1], fl[2], fl[3]);
+	else if (kScreenChunk == 8 && nc == kScreenChunk && ((uintptr_t)row & 7) == 0) *reinterpret_cast<uint2*>(row) = make_uint2(fl[0], fl[1]);
+	else if (kScreenChunk == 4 && nc == kScreenChunk && ((uintptr_t)row & 3) == 0) *reinterpret_cast<uint32_t*>(row) = fl[0];
+	else for (uint32_t j = 0; j < nc; j++) row[j] = (uint8_t)((fl[j >> 2] >> (8 * (j & 3))) & 0xffu);
+}
+
+// Behind k_pair_epilogue_bits_screen: a thread reads 16 flags of one query's row; where a byte says kScreenOpen, the pair's integer
+// reductions are formed again and evaluated in FP64 (epilogue_eval writes the flag).
+__global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits_open(const MscEpilogueArgs a) {
+	const uint64_t total = (uint64_t)a.n_queries * a.m_per_query;
+	const uint64_t at = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+	if (at >= total) return;
+	const uint32_t n = total - at < 16 ? (uint32_t)(total - at) : 16;
+	uint32_t w[4] = {0, 0, 0, 0};
+	if (n == 16 && ((uintptr_t)(a.close_soa + at) & 15) == 0) {
+		const uint4 v = *reinterpret_cast<const uint4*>(a.close_soa + at);
+		w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+	} else for (uint32_t j = 0; j < n; j++) w[j >> 2] |= (uint32_t)a.close_soa[at + j] << (8 * (j & 3));
+	if (!(((w[0] | w[1] | w[2] | w[3]) >> 1) & 0x01010101u)) return;          // no byte holds 2
+	const uint32_t ns = a.kb_slices, estride = a.emd_stride ? a.emd_stride : 64;
+	for (uint32_t j = 0; j < n; j++) {
+		if (((w[j >> 2] >> (8 * (j & 3))) & 0xffu) != kScreenOpen) continue;
+		const uint32_t q = (uint32_t)((at + j) / a.m_per_query), ci = (uint32_t)((at + j) % a.m_per_query);
+		const uint32_t q_slot = a.q_slots[q];
+		const uint32_t slot_rel = a.cand_slots ? a.cand_slots[ci] : ci;
+		const uint64_t slot = a.cand_slots ? (uint64_t)slot_rel : a.kb_first + ci;
+		const uint2* cmb = reinterpret_cast<const uint2*>(a.kb_c_mb) + slot * a.kb_c_pitch;
+		const uint32_t c_n = a.kb_c_mb_n[slot] < a.kb_c_pitch ? a.kb_c_mb_n[slot] : a.kb_c_pitch;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(a.cand_scalars + (uint64_t)slot_rel * a.cand_scalar_stride);
+		const MscSlotScalars* qs = reinterpret_cast<const MscSlotScalars*>(a.qset_scalars + (uint64_t)q_slot * a.q_scalar_stride);
+		const Side cand{cs->mag, cs->length, cs->sum, cs->sum_sq}, qry{qs->mag, qs->length, qs->sum, qs->sum_sq};
+		int64_t min_e = 0;
+		for (uint32_t s_ = 0; s_ < ns; s_++) min_e += a.kb_min[((uint64_t)s_ * a.m_per_query + ci) * a.kb_qn + q];
+		const int64_t diff_e = a.kb_diff ? a.kb_diff[(uint64_t)ci * a.kb_qn + q] : 0;
+		const uint64_t emd = a.emd_ranks ? a.emd_ranks[(uint64_t)ci * estride + q] : 0;
+		PairTotals t{0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+		bits_pair_totals(a, ci, cmb, c_n, q, q_slot, min_e, diff_e, emd, cand, qry, t);
+		epilogue_eval(a, q * a.m_per_query + ci, ci, q, cand, qry, a.min_len, a.max_len, t);
+	}
 }
 
 __global__ void __launch_bounds__(kBlock) k_pair_epilogue_thread(const MscEpilogueArgs a) {
@@ -1930,7 +2128,19 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 	if (a.kb_min) {
 		if (a.n_queries < 2 || a.n_queries > a.kb_qn || !a.kb_c_mb || !a.kb_q_mb || !a.kb_qT) return hipErrorInvalidValue;      // (epilogue_one's query-major index needs n_queries > 1)
 		const uint64_t waves = (uint64_t)a.m_per_query * ((a.n_queries + 63) / 64);
-		hipLaunchKernelGGL(k_pair_epilogue_bits, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
+		const bool screen = a.screen && a.model && a.close_soa && !a.sum_soa && !a.csum_soa && !a.raw_out && !a.singles_out && !a.combos_out && !a.pair_out && !a.use_window &&
+		                    !a.div_direct && !a.grp_pairs && !a.sparse_base;
+		if (screen) {
+			static const uint32_t chunk = [] { const char* e = getenv("MSC_SCREEN_CHUNK"); const int v = e ? atoi(e) : 4; return (uint32_t)(v == 1 || v == 4 || v == 8 || v == 16 ? v : 4); }();
+			const uint64_t cw = (uint64_t)((a.m_per_query + chunk - 1) / chunk) * ((a.n_queries + 63) / 64);
+			const dim3 grid((unsigned)((cw + kWavesPerBlock - 1) / kWavesPerBlock));
+			if (chunk == 1) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<1>, grid, dim3(kBlock), 0, st, a);
+			else if (chunk == 4) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<4>, grid, dim3(kBlock), 0, st, a);
+			else if (chunk == 8) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<8>, grid, dim3(kBlock), 0, st, a);
+			else hipLaunchKernelGGL(k_pair_epilogue_bits_screen<16>, grid, dim3(kBlock), 0, st, a);
+			const uint64_t threads = ((uint64_t)a.n_queries * a.m_per_query + 15) / 16;
+			hipLaunchKernelGGL(k_pair_epilogue_bits_open, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
+		} else hipLaunchKernelGGL(k_pair_epilogue_bits, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
 	} else if (a.partials_cq) {
 		if (a.cq_group != 16 && (a.cq_group != 32 || !a.dot_gemm)) return hipErrorInvalidValue;      // (manh-only records: the products must come from the GEMM)
 		const unsigned waves = a.m_per_query * ((a.n_queries + a.cq_group - 1) / a.cq_group);

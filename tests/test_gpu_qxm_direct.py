@@ -187,3 +187,77 @@ def test_fastcar_k5_u16_fixture_route(tmp_path):
     assert open(str(tmp_path / "fc_out0"), "rb").read() == open(os.path.join(golden, "fastcar_k5_u16.out"), "rb").read()
     kernels = [ln.split(": ", 1)[1] for ln in r.stderr.decode().splitlines() if ln.startswith("kernel: ")]
     assert kernels and all(kn.startswith("k_pair_tiles_multi") for kn in kernels), kernels
+
+
+def _shifted(text, w0):
+    """the classification block of a weights file with its intercept replaced (the line after the first `n_combos:`)"""
+    lines = text.splitlines()
+    at = next(i for i, ln in enumerate(lines) if ln.startswith("n_combos:")) + 1
+    lines[at] = repr(float(w0))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("dtype,k,wts,repeats", [(32, 9, "weights_k9_u32.txt", None), (32, 9, "weights_k9_u32.txt", "di"), (16, 9, "weights_cfg5_u16_k9.txt", None),
+                                                 (8, 9, "weights_k9_u8.txt", "homo")])
+def test_close_flags_alone_are_the_flags_of_the_fp64_evaluation(ctx, dtype, k, wts, repeats):
+    """A Q x M call that wants nothing but the close flags (fastcar's Predictor::close loop, fastcar/FC_Runner.cpp:446-458; bench.py's step)
+    decides them in f32 with an error bound and evaluates in FP64 only the pairs the bound leaves open (pair_features.hip, screen_close).
+    The flags must be those of the FP64 evaluation pair for pair: against the same call with the sums requested (FP64 for every pair),
+    against the CPU oracle, and -- with the model's intercept moved so that the weighted sums of this very set straddle 0, i.e. as many
+    pairs as possible sit at the decision boundary -- against the FP64 path again. A `--feat slow` model has no f32 image: same flags
+    through the unscreened kernel."""
+    from oracle import oracle_py
+    seqs, _ = synth.families(4242 + k + dtype, 700, 1000, family=20)
+    if repeats:
+        seqs = _repeat_bearing(seqs, 9, repeats)
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, k, dtype, n)
+    for off in range(0, n, 256):
+        hs.build(seqs[off:off + 256], first_slot=off)
+    text = weights_text(wts)
+    feat = api.Feature.from_text(ctx, text, 0)
+    qs = np.arange(0, n, 2, dtype=np.uint32)[:300]
+    for order in (api.ORDER_CAND_FIRST, api.ORDER_QUERY_FIRST):
+        full = api.score_multi(ctx, feat, hs, None, hs, qs, order=order, m=n, want=("sum", "close", "counts"))
+        assert ctx.last_kernel_info()[0].startswith("k_pair_gemm_fp4_dma"), ctx.last_kernel_info()
+        only = api.score_multi(ctx, feat, hs, None, hs, qs, order=order, m=n, want=("close", "counts"))
+        assert ctx.last_kernel_info()[0].startswith("k_pair_gemm_fp4_dma"), ctx.last_kernel_info()
+        assert np.array_equal(only["close"], full["close"]) and np.array_equal(only["counts"], full["counts"]), (wts, order)
+        assert np.array_equal(full["close"], (full["sum"] >= 0).astype(np.uint8))          # (bias 0: close <=> s >= 0 for every s this far from 1e-16)
+        assert int(only["close"].sum()) >= 300          # every query is close to itself
+    # the oracle on a sample of rows
+    pred = oracle_py.predictor(text)
+    oh = [oracle_py.hist(s, k, dtype) for s in seqs]
+    only = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, want=("close",))
+    for row in (0, 7, 150, 299):          # (candidate, query) per pair, no length window: Predictor::p_close, predict/Predictor.cpp:284-333
+        f = np.array([oracle_py.score(pred.cls, oh[c], oh[int(qs[row])])[2] >= 0 for c in range(n)], dtype=np.uint8)
+        assert np.array_equal(only["close"][row], f), row
+    # the same set with its sums centred on the threshold: the intercept moved by the median sum
+    full = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, want=("sum",))
+    w0 = float(text.splitlines()[next(i for i, ln in enumerate(text.splitlines()) if ln.startswith("n_combos:")) + 1])
+    for quantile in (0.5, 0.02, 0.98):
+        moved = api.Feature.from_text(ctx, _shifted(text, w0 - float(np.quantile(full["sum"], quantile))), 0)
+        a = api.score_multi(ctx, moved, hs, None, hs, qs, m=n, want=("sum", "close"))
+        b = api.score_multi(ctx, moved, hs, None, hs, qs, m=n, want=("close",))
+        frac = float(a["close"].mean())
+        assert abs(frac - (1 - quantile)) < 0.02, (quantile, frac)          # the boundary really runs through the set
+        assert np.array_equal(a["close"], b["close"]), quantile
+        assert np.array_equal(a["close"], (a["sum"] >= 0).astype(np.uint8))
+
+
+def test_close_flags_alone_with_a_slow_model_and_with_a_bias(ctx):
+    """models the f32 screen does not cover -- a divergence statistic, a bias (Predictor::set_bias) -- keep the FP64 evaluation: same flags"""
+    seqs, _ = synth.families(991, 300, 1000, family=10)
+    hs = api.HistogramSet(ctx, 9, 16, len(seqs))
+    hs.build(seqs)
+    qs = np.arange(130, dtype=np.uint32)
+    slow = api.Feature.from_text(ctx, weights_text("weights_cfg5_k9.txt"), 0)
+    a = api.score_multi(ctx, slow, hs, None, hs, qs, m=len(seqs), want=("sum", "close"))
+    b = api.score_multi(ctx, slow, hs, None, hs, qs, m=len(seqs), want=("close",))
+    assert np.array_equal(a["close"], b["close"])
+    biased = api.Feature.from_text(ctx, weights_text("weights_k9_u8.txt"), 0)          # (a `fast` model: screened while its bias is 0)
+    for bias in (0.2, -0.3, 0.0):
+        biased.set_bias(bias)
+        a = api.score_multi(ctx, biased, hs, None, hs, qs, m=len(seqs), want=("csum", "close"))
+        b = api.score_multi(ctx, biased, hs, None, hs, qs, m=len(seqs), want=("close",))
+        assert np.array_equal(a["close"], b["close"]) and np.array_equal(a["close"], (np.round(a["csum"]) > 0).astype(np.uint8)), bias
