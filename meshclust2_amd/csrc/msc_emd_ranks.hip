@@ -92,6 +92,25 @@ __device__ __forceinline__ uint32_t fold16q(const uint32_t (&s)[16]) {
 	return R;
 }
 
+// 8 per-lane sums -> one register: lane l ends up with the wave total of query 2 (l / 16) + (l / 8) % 2 in all eight lanes of its half
+// row. permlane32 / 16 swaps take 8 -> 4 -> 2 registers (row r of register i then holds 16 partial sums of query i + 2 r), DPP adds and
+// one bank-masked merge the rest: 18 operations for 8 totals.
+__device__ __forceinline__ uint32_t fold8q(const uint32_t (&s)[8]) {
+	auto fold32 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false); return r.x + r.y; };
+	auto fold16 = [](uint32_t a, uint32_t b) { const u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return r.x + r.y; };
+	uint32_t w[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) w[i] = fold16(fold32(s[i], s[i + 4]), fold32(s[i + 2], s[i + 6]));
+	uint32_t X[2];
+#pragma unroll
+	for (int i = 0; i < 2; i++) X[i] = w[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[i], 0x128, 0xf, 0xf, false);      // row_ror:8
+	uint32_t P = (uint32_t)__builtin_amdgcn_update_dpp((int)X[0], (int)X[1], 0xe4, 0xf, 0xc, false);      // lanes 8-15 of every row <- register 1
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x141, 0xf, 0xf, false);                        // row_half_mirror
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xb1, 0xf, 0xf, false);
+	P += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x4e, 0xf, 0xf, false);
+	return P;
+}
+
 // one wave-instruction of LDS-DMA: 64 lanes x 16 bytes from global memory (wave-uniform base in SGPRs + per-lane byte offset) straight
 // into LDS at lds_dst + 16 lane (no destination VGPRs); m0 is the compiler's: saved and restored
 __device__ __forceinline__ void dma_piece(uint64_t sbase, uint32_t lane_off, uint32_t lds_dst) {
@@ -257,7 +276,6 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 	__shared__ v4i_ sQ[2][kQHalf][kRound / 8];          // 2 x 16 KiB: a list's round = 1 024 reduced ranks = 2 KiB
 	const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t c0 = (blockIdx.x * kWaves + wave) * kCand16;
-	const uint32_t n_groups = (n_q + kQGroup - 1) / kQGroup;
 	uint64_t slot[kCand16];
 	uint32_t nc[kCand16];
 #pragma unroll
@@ -266,8 +284,9 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 		slot[c] = cand_slots ? cand_slots[ci] : first + ci;
 		nc[c] = c_n[slot[c]];
 	}
-	const uint32_t my_q = ((0x3120u >> (4 * ((lane >> 2) & 3))) & 3) + 4 * (lane >> 4);
+	const uint32_t my_q = 2 * (lane >> 4) + ((lane >> 3) & 1);          // the query of a half-group whose total fold8q leaves in this lane
 	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sQ[0][0][0]);
+	const uint32_t n_halves = (n_q + kQHalf - 1) / kQHalf;
 	for (uint64_t base = 0; base < pitch; base += kRound) {
 		v4i_ a[kCand16][2];          // lane l: reduced ranks 512 j + 8 l .. + 7 of the round, two per register
 #pragma unroll
@@ -286,9 +305,24 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 			for (uint32_t part = 0; part < 2; part++)
 				dma_piece((uint64_t)(q_rk + (uint64_t)qs * pitch + base + 512 * part), lane * 16u, lds0 + (((h & 1) * kQHalf + q) * (kRound / 8) + 64 * part) * 16);
 		};
-		uint32_t sum[kCand16][kQGroup];
-		auto walk = [&](uint32_t buf, auto half) {
-			constexpr uint32_t H = decltype(half)::value;
+		stage(0);
+		for (uint32_t h = 0; h < n_halves; h++) {          // one half-group of 8 queries per turn; its 8 totals per candidate are folded and stored at once
+			uint32_t nq_max = 0;
+			for (uint32_t q = 0; q < kQHalf; q++) {
+				const uint32_t qi = h * kQHalf + q;
+				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
+				nq_max = v > nq_max ? v : nq_max;
+			}
+			uint32_t reach = nq_max;
+#pragma unroll
+			for (uint32_t c = 0; c < kCand16; c++) reach = nc[c] > reach ? nc[c] : reach;
+			const bool idle = base != 0 && base >= reach;          // (a later round past every list of the wave and the half-group: all terms | pad - pad |)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed (and its stores have left)
+			__syncthreads();                                       // everybody's have, and everybody is done with the slot refilled next
+			if (h + 1 < n_halves) stage(h + 1);
+			if (idle) continue;
+			uint32_t sum[kCand16][kQHalf];
+			const uint32_t buf = h & 1;
 #pragma unroll
 			for (uint32_t q = 0; q < kQHalf; q++) {
 				v4i_ b[2];
@@ -304,38 +338,14 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
 						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
 					}
-					sum[c][H * kQHalf + q] = t;
+					sum[c][q] = t;
 				}
 			}
-		};
-		auto landed = [&] {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-		};
-		stage(0);
-		for (uint32_t g = 0; g < n_groups; g++) {
-			uint32_t nq_max = 0;
-			for (uint32_t q = 0; q < kQGroup; q++) {
-				const uint32_t qi = g * kQGroup + q;
-				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
-				nq_max = v > nq_max ? v : nq_max;
-			}
-			uint32_t reach = nq_max;
-#pragma unroll
-			for (uint32_t c = 0; c < kCand16; c++) reach = nc[c] > reach ? nc[c] : reach;
-			const bool idle = base != 0 && base >= reach;          // (a later round past every list of the wave and the group: all terms | pad - pad |)
-			landed();
-			stage(2 * g + 1);
-			if (!idle) walk(0, std::integral_constant<uint32_t, 0>());
-			landed();
-			if (g + 1 < n_groups) stage(2 * g + 2);
-			if (idle) continue;
-			walk(1, std::integral_constant<uint32_t, 1>());
-			const uint32_t q0 = g * kQGroup;
-			const bool owner = (lane & 3) == 0 && q0 + my_q < n_q;
+			const uint32_t q0 = h * kQHalf;
+			const bool owner = (lane & 7) == 0 && q0 + my_q < n_q;
 #pragma unroll
 			for (uint32_t c = 0; c < kCand16; c++) {
-				const uint32_t tot = fold16q(sum[c]);
+				const uint32_t tot = fold8q(sum[c]);
 				if (owner && c0 + c < m && (base == 0 || base < (nc[c] > nq_max ? nc[c] : nq_max))) {
 					uint64_t* o = out + (uint64_t)(c0 + c) * out_stride + q0 + my_q;
 					*o = base ? *o + tot : (uint64_t)tot;
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 			}
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();
+		__syncthreads();          // the ring is free for the next round's first half-group
 	}
 }
 

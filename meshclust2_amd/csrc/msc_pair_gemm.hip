@@ -474,9 +474,10 @@ __device__ __forceinline__ void lds_dma_1k(const uint8_t* lane_src, uint32_t lds
 // Order of issue per super-step: the tile's pieces, THEN the candidates' KiB; vector-memory operations retire in order, so
 // s_waitcnt vmcnt(1) in front of the barrier lets only that youngest copy stay in flight.
 template <int NRB, int NW>
-__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 3) k_pair_gemm_fp4_dma(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+__global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 4) k_pair_gemm_fp4_dma(const uint8_t* __restrict__ cand_kb, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                                          const uint8_t* __restrict__ anib, uint64_t nbins, uint32_t k_slices, const uint32_t* __restrict__ hot_ptr,
-                                                                         const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff) {
+                                                                         const uint2* __restrict__ hot, int32_t* __restrict__ out_min, int32_t* __restrict__ out_diff, uint32_t n_whole,
+                                                                         uint32_t piece_ss) {
 	constexpr int QN = 32 * NRB;
 	constexpr uint32_t kTile = QN * 128;              // bytes of the queries' tile of a super-step
 	constexpr uint32_t kPieces = kTile / NW / 1024;   // KiB a wave copies per super-step
@@ -485,14 +486,25 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 3) k_pair_gemm_fp4_dma
 	__shared__ v4i sA[2][QN * 8];
 	__shared__ v4i sB[NW][kBDepth][64];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	// Workgroups 0 .. n_whole - 1 take a whole tile of 128 candidates each (one slice of the bins: blockIdx.y). With piece_ss > 0 the tiles
+	// past n_whole -- what is left when the tiles do not fill the chip's places a whole number of times -- are cut into pieces of piece_ss
+	// super-steps, one workgroup each, which ADD their sums into rows the host zeroed: 782 tiles on 768 places ran a second round of 14
+	// workgroups on an otherwise idle chip (1.60 ms against 1.06 for 768 tiles); as ~730 short pieces they are one more twentieth of a round.
 	const uint32_t ks = blockIdx.y;
-	const uint64_t per = nbins / k_slices, k0 = (uint64_t)ks * per;
-	const uint32_t n_ss = (uint32_t)(per / 256), gss0 = (uint32_t)(k0 / 256);
-	const uint32_t ci = (blockIdx.x * NW + wave) * 32 + (lane & 31);
+	const uint64_t per = nbins / k_slices;
+	uint32_t tile = blockIdx.x, n_ss = (uint32_t)(per / 256), gss0 = (uint32_t)((uint64_t)ks * per / 256);
+	const bool piece = piece_ss && blockIdx.x >= n_whole;
+	if (piece) {
+		const uint32_t ppt = (n_ss + piece_ss - 1) / piece_ss, p = blockIdx.x - n_whole;
+		tile = n_whole + p / ppt;
+		gss0 = (p % ppt) * piece_ss;
+		n_ss = n_ss - gss0 < piece_ss ? n_ss - gss0 : piece_ss;
+	}
+	const uint32_t ci = (tile * NW + wave) * 32 + (lane & 31);
 	const bool valid = ci < m;
 	const uint32_t cc = valid ? ci : m - 1;
 	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
-	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (k0 >> 8) * 1024;
+	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (uint64_t)gss0 * 1024;
 	const uint8_t* asrc = anib + (uint64_t)gss0 * kTile + wave * (kPieces * 1024) + lane * 16;
 	const uint32_t lds_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sA[0][0] + wave * (kPieces * 1024));
 	const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sB[wave][0][0]);
@@ -550,6 +562,16 @@ __global__ void __launch_bounds__(64 * NW, NRB == 8 ? 2 : 3) k_pair_gemm_fp4_dma
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (nothing of this wave may still be writing LDS when the workgroup ends)
 	if (!valid) return;
 	int32_t* o = out_min + ((uint64_t)ks * m + ci) * QN + 4 * (lane >> 5);
+	if (piece) {          // (most pairs of unrelated sequences share no k-mer inside a piece)
+#pragma unroll
+		for (int rb = 0; rb < NRB; rb++)
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				const int v = (int)acc[rb][i];
+				if (v) atomicAdd(o + 32 * rb + 8 * (i >> 2) + (i & 3), v);
+			}
+		return;
+	}
 #pragma unroll
 	for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
@@ -774,8 +796,25 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 		if (e != hipSuccess) return e;
 	}
 	if (pair_gemm_dma() && anib) {
-		const dim3 grid((m + 127) / 128, k_slices);
-#define MSC_DMA_GO(NRB) k_pair_gemm_fp4_dma<NRB, 4><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, anib, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff)
+		static const unsigned dma_pad = [] { const char* e = getenv("MSC_GEMM_LDS_PAD"); return (unsigned)(e ? atoi(e) * 1024 : 0); }();
+		// the tiles that do not fill the chip's places a whole number of times go as short pieces (see the kernel); one slice only
+		static const bool no_pieces = getenv("MSC_GEMM_NO_PIECES") != nullptr;
+		static const int num_cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount <= 0) return 256; return p.multiProcessorCount; }();
+		const uint32_t tiles = (m + 127) / 128, places = (uint32_t)num_cus * (qn == 256 ? 2 : 3), n_ss_all = (uint32_t)(nbins / 256);
+		uint32_t n_whole = tiles, piece_ss = 0, grid_x = tiles;
+		if (k_slices == 1 && !no_pieces && tiles > places && tiles % places && (tiles % places) * 4 <= places) {          // (a leftover of more than a quarter round is better off as a round of whole tiles: 1.87 against 1.95 ms at 150 000 candidates)
+			n_whole = tiles / places * places;
+			const uint32_t left = tiles - n_whole;
+			piece_ss = std::max<uint32_t>(16, (uint32_t)(((uint64_t)left * n_ss_all + places - 1) / places));
+			if (piece_ss >= n_ss_all) { n_whole = tiles; piece_ss = 0; }
+			else {
+				grid_x = n_whole + left * ((n_ss_all + piece_ss - 1) / piece_ss);
+				const hipError_t e = hipMemsetAsync(out_min + (size_t)n_whole * 128 * qn, 0, (size_t)(m - n_whole * 128) * qn * sizeof(int32_t), st);
+				if (e != hipSuccess) return e;
+			}
+		}
+		const dim3 grid(grid_x, k_slices);
+#define MSC_DMA_GO(NRB) k_pair_gemm_fp4_dma<NRB, 4><<<grid, dim3(256), dma_pad, st>>>(cand_kb, cand_slots, first, m, anib, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff, n_whole, piece_ss)
 		if (qn == 32) MSC_DMA_GO(1);
 		else if (qn == 64) MSC_DMA_GO(2);
 		else if (qn == 128) MSC_DMA_GO(4);

@@ -1027,9 +1027,11 @@ def test_dense_one_by_m_passes_stream_the_bins_when_told_to(tmp_path):
 
 def test_full_size_cfg2_properties(oracle):
     """BASELINE.json configs[1] at FULL size (100 000 x 1 kb, k = 9, datatype 32: 98 GiB of histograms + the digest mirror),
-    checked through size-independent properties: sampled histograms against the oracle; the Q x M digest kernel against the
-    independent 1 x M raw-bin kernel bit for bit over all 100 000 candidates; symmetry of the score; the self pair; the
-    family structure of the synthetic set (20 relatives per template, ~96 % identical) in the close flags."""
+    checked through size-independent properties: sampled histograms against the oracle; the Q x M pass on the matrix cores
+    (k_pair_gemm_fp4_dma: 768 whole tiles of 128 candidates + the 14 left over cut into short pieces that add their sums) against the
+    independent 1 x M kernel bit for bit over all 100 000 candidates; the close flags of a flags-only call (f32 screen + FP64 for the
+    undecided) against those of the FP64 evaluation; symmetry of the statistics; the self pair; the family structure of the synthetic
+    set (20 relatives per template, ~96 % identical)."""
     ctx = api.Context(0)
     n, k, dtype, fam = 100000, 9, 32, 20
     seed = 20260002
@@ -1055,7 +1057,9 @@ def test_full_size_cfg2_properties(oracle):
     qs = (np.arange(16, dtype=np.uint32) * 6151 + 3) % n
     fast_mask = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
     multi = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, feat_mask=(1 << 2) | (1 << 13))
-    assert ctx.last_kernel_info()[0].startswith(("k_pair_gemm_fp4", "k_pair_gemm_bits")), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route
+    assert ctx.last_kernel_info()[0].startswith("k_pair_gemm_fp4_dma<32 query rows"), ctx.last_kernel_info()          # cfg2 itself: the matrix-core route, its default kernel
+    only = api.score_multi(ctx, feat, hs, None, hs, qs, m=n, want=("close", "counts"))
+    assert np.array_equal(only["close"], multi["close"]) and np.array_equal(only["counts"], multi["close"].sum(axis=1, dtype=np.uint64))
     # independent kernel, same answers (every candidate, three of the queries)
     for i in (0, 5, 15):
         single = feat.compute(hs, None, hs, int(qs[i]), m=n)
