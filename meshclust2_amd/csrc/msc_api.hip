@@ -1639,7 +1639,18 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// run and in a one-rank run -- never by a bound of the set or shard at hand: the two kernels add the divergence terms in different orders,
 	// and two identical sequences scored for one query must not come out one bit apart because they sit on different ranks)
 	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > 2000;          // (2 000: a wave of k_pair_ranks_1xm takes a whole candidate, fine up to a few rounds of 256 entries)
-	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26);
+	// Rounds of 1 024 entries that cover the longest list THIS PASS can meet: a candidate the length window drops takes no
+	// round, so inside a window no list is longer than max_len k-mers (nor the query's own); only without a window does the set's bound
+	// count. One 50 Mb scaffold among short sequences used to size -- and clear, every step -- the accumulators of every pass for 50 000
+	// rounds per candidate. And a pass whose scratch would still pass 2 GiB stays with the merge kernels instead of failing with OOM.
+	uint64_t pass_kmers = std::max(q_kmers, c_kmers);
+	if (rq.use_window && long_lists) {
+		uint64_t q_len = 0;
+		if ((r = slot_length(ctx, rq.qset, rq.q_slot, &q_len))) return r;
+		pass_kmers = std::min(pass_kmers, std::max(rq.max_len, q_len));
+	}
+	const uint64_t pass_rounds = (pass_kmers + msc_ranks_items_round() - 1) / msc_ranks_items_round();
+	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (312 + pass_rounds * 40) <= (2048ull << 20);
 	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
 	bool rank_items = false;
 	uint32_t rank_rounds = 0;
@@ -1653,7 +1664,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		rank_items = rank_pass && long_lists && items_ok;
 		if (rank_items) {
-			rank_rounds = (uint32_t)((std::max(q_kmers, c_kmers) + msc_ranks_items_round() - 1) / msc_ranks_items_round());
+			rank_rounds = (uint32_t)pass_rounds;
 			if ((r = ensure(ctx, ctx->rk_q, ((q_kmers + 255) & ~255ull) * sizeof(uint32_t) + 1024))) return r;
 		} else if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
 		if (rank_pass) ctx->last_kernel = rank_items ? "k_pair_ranks_items" : "k_pair_ranks_1xm";

@@ -727,7 +727,8 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
                                                            const uint32_t* __restrict__ hq, const uint32_t* __restrict__ big, const uint32_t* __restrict__ c_n,
                                                            const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
                                                            const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order,
-                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard) {
+                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard, int use_window, uint64_t min_len,
+                                                           uint64_t max_len) {
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
 	const bool live = c < m;
 	const uint32_t cc = live ? c : m - 1;
@@ -736,7 +737,9 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 	if (live && b == 0) {
 		const MscSparseHdr qh = *q_hdr_p;
 		const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = c_n[slot];
-		if (nc > (uint64_t)rounds * kRiRound || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);          // (a list longer than its set's bound: the host fails the call)
+		// a list longer than the pass's bound: the host fails the call (a candidate the length window dropped took no round: any length)
+		const bool dropped = use_window && (cs->length < min_len || cs->length > max_len);
+		if ((!dropped && nc > (uint64_t)rounds * kRiRound) || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);
 		MscPartial out;
 		out.manh = nc + nq_tot - 2 * acc[4 * (uint64_t)c + 2];
 		out.dot = acc[4 * (uint64_t)c + 1] + nc + nq_tot;
@@ -907,8 +910,8 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	const dim3 fgrid((unsigned)(((uint64_t)m * 8 + 255) / 256));
 	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, dv->cells, dv->extras, rounds, dv->hq, dv->big, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
-	                                                                dv->q_scalars, dv->order, partials, dv->div_out, guard);
+	                                                                dv->q_scalars, dv->order, partials, dv->div_out, guard, use_window, min_len, max_len);
 	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(acc, nullptr, nullptr, rounds, nullptr, nullptr, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
-	                                                             nullptr, 0, partials, nullptr, guard);
+	                                                             nullptr, 0, partials, nullptr, guard, use_window, min_len, max_len);
 	return hipGetLastError();
 }

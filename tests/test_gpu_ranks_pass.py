@@ -231,3 +231,32 @@ def test_divergence_statistics_through_the_rank_pass(ctx, oracle, rank_pass_now,
                     assert got[ci][c] == pytest.approx(exp, rel=RTOL, abs=1e-13), (FEATS[c][0], q, cc, order)
     for h in oh:
         oracle.lib().orc_hist_free(h)
+
+
+def test_long_outlier_does_not_size_every_pass(ctx, rank_pass_now):
+    """One long scaffold among mixed-length sequences: the (candidate, round) pass sizes its accumulators by what the pass's
+    length window can meet, not by the set's longest list -- the window path (Trainer::get_close over the accumulate loop's window,
+    cluster/ClusterFactory.cpp:553-610) with the `--feat slow` model gives the merge kernels' decisions with the outlier inside the window's
+    candidate list (dropped by its length) and as the query itself."""
+    rng = np.random.default_rng(77)
+    seqs, _ = synth.families(31337, 60, 6000, family=5, length_jitter=2500)
+    seqs = [bytes(s) for s in seqs]
+    seqs[17] = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 400000)])          # 400 kb: 391 rounds of 1 024
+    n = len(seqs)
+    hs = api.HistogramSet(ctx, 9, 16, n, sparse_entries=sum(len(s) for s in seqs) + 4096)
+    hs.build(seqs)
+    feat = api.Feature.from_text(ctx, weights_text("weights_cfg5_k9.txt").replace("uint8_t", "uint16_t"), 0)
+    tr = api.Trainer(ctx, feat, 0.6)
+    order = np.argsort([len(s) for s in seqs], kind="stable").astype(np.uint32)
+    win = api.Window(ctx, hs, order)
+    for q in (3, 40, 17):
+        alive = np.array([p for p in range(n) if win.alive(p, p + 1)], dtype=np.int64)          # positions of the window before the pass
+        close, bp, bs, im = win.get_close(tr, 0, n, hs, q)
+        kernel = ctx.last_kernel_info()[0]
+        assert kernel == "k_pair_ranks_items", kernel
+        rank_pass_now.setenv("MSC_NO_RANKS_1XM", "1")
+        ref = tr.get_close(hs, order[alive], hs, q)
+        rank_pass_now.delenv("MSC_NO_RANKS_1XM")
+        assert ctx.last_kernel_info()[0] not in RANK_KERNELS
+        assert np.array_equal(np.sort(close), alive[np.flatnonzero(ref[0])]), q
+        assert im == ref[3] and (ref[1] < 0 or (bp == int(alive[ref[1]]) and bs == pytest.approx(ref[2], rel=1e-9)))
