@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from meshclust2_amd import synth  # noqa: E402
 from oracle import ref_py  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from golden_util import cfg5_set, training_set, weights_with_mode  # noqa: E402
+from golden_util import cfg5_set, long_fragment_set, training_set, weights_with_mode  # noqa: E402
 
 FEATS = [("manhattan", 2), ("euclidean", 3), ("normalized_vectors", 5), ("jefferey_divergence", 7), ("pearson", 9),
          ("intersection", 13), ("emd", 18), ("length_difference", 21), ("kulczynski2", 27), ("simratio", 28), ("jensen_shannon", 29)]
@@ -506,6 +506,23 @@ def make_fastcar_k9_output():
     print("wrote weights_k9_u32_fc.txt and fastcar_k9_u32.out")
 
 
+def make_long_fragments():
+    seqs = long_fragment_set()
+    out = {"n": len(seqs), "lengths": np.array([len(s) for s in seqs])}
+    for i, s in enumerate(seqs):
+        codes, segs, eff = ref_py.encode(s)
+        out["segs_%d" % i] = np.array(segs, dtype=np.int64)
+        out["eff_%d" % i] = eff
+        for k, dt in ((5, 32), (7, 16)):
+            p = ref_py.Point(dt, s, k)
+            m = p.meta()
+            out["bins_k%d_%d" % (k, i)] = p.bins()
+            out["meta_k%d_%d" % (k, i)] = np.array([m["mag"], m["length"]] + m["one_mers"], dtype=np.uint64)
+            out["stddev_k%d_%d" % (k, i)] = m["stddev"]
+    np.savez_compressed(os.path.join(HERE, "long_fragments.npz"), **out)
+    print("wrote long_fragments.npz", [(len(s), out["segs_%d" % i].tolist()) for i, s in enumerate(seqs)])
+
+
 FAST_FLAGS = sum(1 << b for b in (2, 3, 5, 9, 13, 18, 21, 27, 28))
 SLOW_FLAGS = FAST_FLAGS | (1 << 7) | (1 << 29)
 
@@ -538,6 +555,7 @@ if __name__ == "__main__":
     make_fastcar_mode_outputs()
     make_regr_weights_and_fastcar()
     make_fastcar_k9_output()
+    make_long_fragments()
     make_cfg5_clstr()
     make_cfg5_u16_clstr()
     make_k8_clstr()

@@ -1098,6 +1098,37 @@ def test_full_size_cfg2_properties(oracle):
     ctx.close()
 
 
+def test_runs_of_more_than_a_million_bases_through_the_build(ctx, oracle):
+    """msc_hist_build on sequences whose runs of unambiguous bases pass 1 000 000 (Chromosome::makeSegmentList under help(1000000),
+    nonltr/Chromosome.cpp:355-385,115-128: fragments of 1 000 000, the last one longer; k-mers across a cut are not counted): segments
+    from msc_encode, histograms, magnitude, length and 1-mers next to the reference's own (tests/golden/long_fragments.npz), dense and
+    sparse, and the 9-mer histograms next to the oracle (the k-mer count drops by k - 1 per cut)."""
+    import os
+    from golden_util import long_fragment_set
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_fragments.npz"))
+    seqs = long_fragment_set()
+    for i, s in enumerate(seqs):
+        _, segs, eff = api.encode(s)
+        assert [list(x) for x in segs] == v["segs_%d" % i].tolist() and eff == int(v["eff_%d" % i])
+    for k, dt in ((5, 32), (7, 16)):
+        hs = api.HistogramSet(ctx, k, dt, len(seqs))
+        hs.build(seqs)
+        for i in range(len(seqs)):
+            assert np.array_equal(hs.download(i), v["bins_k%d_%d" % (k, i)]), (k, i)
+            meta, inf = v["meta_k%d_%d" % (k, i)], hs.info(i)
+            assert (inf["mag"], inf["length"]) == (int(meta[0]), int(meta[1])) and inf["one_mers"] == meta[2:].tolist()
+            assert inf["stddev"] == pytest.approx(float(v["stddev_k%d_%d" % (k, i)]), rel=1e-12)
+    for sparse in (False, True):          # (the list form exists from 64 KiB histograms up)
+        hs = api.HistogramSet(ctx, 9, 32, 2, sparse_entries=2 * 4 ** 9 if sparse else 0)
+        hs.build(seqs[1:])
+        for i, s in enumerate(seqs[1:]):
+            oh = oracle.hist(s, 9, 32)
+            assert np.array_equal(hs.download(i), oh.array()), (i, sparse)
+            _, segs, _ = api.encode(s)
+            assert hs.info(i)["sum"] - 4 ** 9 == sum(e - b + 1 - 8 for b, e in segs if e - b + 1 >= 9)
+            oracle.lib().orc_hist_free(oh)
+
+
 @pytest.mark.parametrize("dtype,k,wts,sparse", [(16, 5, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", False), (16, 5, "weights_k5_u16_slow.txt", False),
                                                  (8, 3, "weights_k5_u16.txt", False), (32, 9, "weights_k9_u32.txt", True), (16, 8, "weights_k8_u16.txt", True),
                                                  (8, 9, "weights_k9_u8.txt", True), (64, 10, "weights_k5_u16.txt", True),

@@ -3,7 +3,7 @@ real reference (tests/golden/gen_golden.py). Runs anywhere (no GPU, no /root/ref
 import numpy as np
 import pytest
 
-from golden_util import EXACT, FEATS, VECTOR_SETS, cfg4_sequences, dense_bins, kat, load_vectors, weights_text
+from golden_util import EXACT, FEATS, VECTOR_SETS, cfg4_sequences, dense_bins, kat, load_vectors, long_fragment_set, weights_text
 
 
 def test_appendix_d_known_answers(oracle):
@@ -125,3 +125,27 @@ def test_k13_u64_vectors_printed_by_the_reference(oracle):
     assert np.allclose(d, v["mean_dist"], rtol=1e-9, atol=0) and near == int(v["mean_nearest"])
     for h in hs:
         oracle.lib().orc_hist_free(h)
+
+
+def test_runs_of_more_than_a_million_bases_are_cut_as_the_reference_cuts_them(oracle):
+    """Chromosome::makeSegmentList under help(1000000) (nonltr/Chromosome.cpp:355-385,115-128): floor(len / 1e6) fragments per run of
+    unambiguous bases, the last one taking the remainder; k-mers across a cut are not counted. Segments, effective length, histograms
+    (k = 5 / 32-bit, k = 7 / 16-bit), magnitude, 1-mers and stddev next to what the reference itself produced (long_fragments.npz)."""
+    import os
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_fragments.npz"))
+    seqs = long_fragment_set()
+    assert [len(s) for s in seqs] == v["lengths"].tolist()
+    for i, s in enumerate(seqs):
+        _, segs, eff = oracle.encode(s)
+        assert [list(x) for x in segs] == v["segs_%d" % i].tolist() and eff == int(v["eff_%d" % i])
+        for k, dt in ((5, 32), (7, 16)):
+            h = oracle.hist(s, k, dt)
+            assert np.array_equal(h.array(), v["bins_k%d_%d" % (k, i)]), (i, k)
+            meta = v["meta_k%d_%d" % (k, i)]
+            assert (h.mag, h.length) == (int(meta[0]), int(meta[1])) and list(h.one_mers) == meta[2:].tolist()
+            assert h.stddev == pytest.approx(float(v["stddev_k%d_%d" % (k, i)]), rel=1e-12)
+            # the cut is visible in the counts: one fragment boundary = k - 1 k-mers fewer than an uncut run would give
+            n_kmers = int(h.array().astype(np.int64).sum()) - 4 ** k
+            assert n_kmers == sum(e - b + 1 - (k - 1) for b, e in segs if e - b + 1 >= k)
+            oracle.lib().orc_hist_free(h)
+    assert len(v["segs_1"]) == 2 and len(v["segs_2"]) == 4          # the cuts really are there
