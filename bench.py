@@ -653,10 +653,8 @@ def main():
     # Per-rank figures (rank 0's shard: M candidates).
     kernel, qtile = ctx.last_kernel_info()
     hist_bytes = (4 ** args.k) * esz
-    on_mfma = kernel.startswith(("k_pair_gemm_fp4", "k_pair_gemm_bits"))
-    on_fp4 = kernel.startswith("k_pair_gemm_fp4")
-    qblk = int(os.environ.get("MSC_GEMM_BLOCK", "128"))          # queries per pass over the candidates on the matrix cores (the library's block)
-    qblk = qblk if qblk in (64, 256) else 128
+    on_mfma = on_fp4 = kernel.startswith("k_pair_gemm_fp4_dma")
+    qblk = 128          # queries per pass over the candidates on the matrix cores (the library's block)
     if on_mfma:   # everything from the matrix cores: the pass reads the presence-bit mirror, one BIT per bin, once per block of up to 128 queries
         hist_bytes = 4 ** args.k // 8
     elif "no emd" in kernel or "emd by ranks" in kernel:   # count-only form of the digest kernel: the prefix half of each tile is not fetched
@@ -727,7 +725,7 @@ def main():
                      "profile_key": config_key},
     }
     if on_mfma and args.mode == "allpairs" and avg_ms == avg_ms:
-        # The pass on the matrix cores is bound by the matrix pipe (FP4 operands; int8 under MSC_GEMM_I8), not by HBM (it streams one bit per bin): 4^k multiply-adds per
+        # The pass on the matrix cores is bound by the matrix pipe (FP4 operands), not by HBM (it streams one bit per bin): 4^k multiply-adds per
         # pair = 2 * 4^k integer operations; a launch scores (candidates of the launch) x (rows of its query block, padded rows included
         # in the work the pipe does but NOT in the operations counted here).
         pairs_per_launch = float(M) * q_call * len(tiles_ms) / n_launch

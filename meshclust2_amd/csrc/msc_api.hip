@@ -160,7 +160,6 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->shard_gather) msc_hist_set_destroy(ctx->shard_gather);
 	release(ctx->shard_payload);
 	release(ctx->shard_hdrs);
-	release(ctx->kb_abits);
 	release(ctx->kb_anib);
 	release(ctx->rk_q);
 	release(ctx->rk_acc);
@@ -211,7 +210,6 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->kb_qT2);
 	release(ctx->kb_min2);
 	release(ctx->kb_diff2);
-	release(ctx->kb_abits2);
 	release(ctx->kb_anib2);
 	release(ctx->kb_hot2);
 	release(ctx->kb_hot_idx2);
@@ -2064,7 +2062,7 @@ static bool kb_route_fits(const msc_hist_set* cands, const msc_hist_set* qset, b
 	const MscLayout& L = cands->L;
 	if (off || cands->sparse || qset->sparse || cands->dtype == 64 || L.nbins != L.padded_bins || !msc_digest_supported(L) || needs_wide(cands, qset)) return false;
 	const uint64_t ms_ = std::max(cands->max_sum, qset->max_sum);
-	if (ms_ < L.nbins || ms_ - L.nbins >= (1ull << 31)) return false;
+	if (ms_ < L.nbins || ms_ - L.nbins >= (1ull << 24)) return false;          // (P1 <= the k-mers of either sequence is summed in f32: exact below 2^24; the corrections stay within int32)
 	if (need_emd && (no_ranks || L.nbins > (1ull << 20) || (ms_ - L.nbins) * 4 > L.nbins)) return false;
 	return true;
 }
@@ -2144,7 +2142,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	uint64_t want = feat_mask;
 	if (model) for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	const bool need_emd = (want & MSC_FEAT_EMD) != 0;           // Feature::compute evaluates only the model's singles too
-	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 128 queries per pass over the candidates' bits (256 with MSC_GEMM_BLOCK: two waves per SIMD instead of four, measured slower); the older routes 64
+	// The pass on the matrix cores (msc_pair_gemm.hip) serves blocks of up to 128 queries per pass over the candidates' bits; the older routes 64
 	bool kb_fit = !ctx->no_kb_now && n_q >= 2 && kb_route_fits(cands, qset, need_emd);
 	if (kb_fit) {
 		if ((r = ensure_kb(ctx, cands)) || (r = ensure_kb(ctx, qset))) return r;
@@ -2159,8 +2157,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		ctx->close_counts_n = n_q;
 		ctx->close_counts_base = 0;
 	} else if (top_level) { ctx->close_counts_n = 0; ctx->close_counts_base = 0; }
-	static const uint64_t kb_blk = [] { const char* e = getenv("MSC_GEMM_BLOCK"); const int v = e ? atoi(e) : 128; return (uint64_t)(v == 64 || v == 256 ? v : 128); }();
-	const uint64_t blk = kb_fit ? kb_blk : 64;
+	const uint64_t blk = kb_fit ? 128 : 64;
 	if (n_q > blk) {
 		// blocks of queries: the unit of the pass on the matrix cores (a 128-row operand) and of the digest kernel (four groups of 16);
 		// msc_last_kernel_ms / _launches then cover the whole call
@@ -2474,7 +2471,6 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	DevBuf& b_qT = pb ? ctx->kb_qT2 : ctx->kb_qT;
 	DevBuf& b_min = pb ? ctx->kb_min2 : ctx->kb_min;
 	DevBuf& b_diff = pb ? ctx->kb_diff2 : ctx->kb_diff;
-	DevBuf& b_abits = pb ? ctx->kb_abits2 : ctx->kb_abits;
 	DevBuf& b_anib = pb ? ctx->kb_anib2 : ctx->kb_anib;
 	DevBuf& b_hot = pb ? ctx->kb_hot2 : ctx->kb_hot;
 	DevBuf& b_hot_idx = pb ? ctx->kb_hot_idx2 : ctx->kb_hot_idx;
@@ -2490,8 +2486,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 			}
 	if (manh_gemm) {
 		const uint64_t nsteps = L.nbins / 128;
-		if (msc_pair_gemm_anib_bytes(L.nbins, kb_qn) && (r = ensure(ctx, b_anib, msc_pair_gemm_anib_bytes(L.nbins, kb_qn)))) return r;
-		if ((r = ensure(ctx, b_abits, msc_pair_gemm_abits_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
+		if ((r = ensure(ctx, b_anib, msc_pair_gemm_anib_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_qT, msc_pair_gemm_qt_bytes(L.nbins, kb_qn))) || (r = ensure(ctx, b_min, (size_t)gemm_slices * chunk * kb_qn * sizeof(int32_t)))) return r;
 		if (n_hot) {
 			if ((r = ensure(ctx, b_hot, n_hot * 8)) || (r = ensure(ctx, b_hot_idx, 3 * (nsteps + 1) * sizeof(uint32_t))) ||
 			    (r = ensure(ctx, b_diff, chunk * kb_qn * sizeof(int32_t)))) return r;
@@ -2505,7 +2500,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		}
 		// the queries' side of the block, once for all chunks of candidates
 		HIP_TRY(ctx, msc_launch_pair_gemm_queries(prep, L.nbins, qset->kb, qset->mb, qset->mb_n, qset->mb_pitch, dq_slots, (uint32_t)n_q, kb_qn,
-		                                          (uint8_t*)b_abits.p, (uint8_t*)b_qT.p, n_hot, b_hot.p, hot_ptr, hot_cursor, hot_cnt, (uint8_t*)b_anib.p));
+		                                          (uint8_t*)b_qT.p, n_hot, b_hot.p, hot_ptr, hot_cursor, hot_cnt, (uint8_t*)b_anib.p));
 		if (prep != ctx->stream) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_prep[pb], prep));
 			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep[pb], 0));
@@ -2539,7 +2534,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 		}
 		if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev_t0, ctx->stream));
 		if (manh_gemm)         // the whole pass over the candidates' bins: products and level products on the matrix cores (timed as the streaming kernel)
-			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, (const uint8_t*)b_abits.p, kb_qn, gemm_slices, hot_ptr, b_hot.p,
+			HIP_TRY(ctx, msc_launch_pair_gemm(ctx->stream, L.nbins, cands->kb, d_slots, off, mc, kb_qn, gemm_slices, hot_ptr, b_hot.p,
 			                                  (int32_t*)b_min.p, (int32_t*)b_diff.p, (const uint8_t*)b_anib.p));
 		else if (digest)
 			HIP_TRY(ctx, msc_launch_pair_digest_multi(ctx->stream, L, cands->digest + (cand_slots ? 0 : off * msc_digest_slot_bytes(L)), d_slots, mc, qset->digest,

@@ -232,16 +232,15 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
                                        const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
                                        int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
                                        unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch, size_t zero_bytes = 0);
-const char* msc_pair_gemm_kernel_name();          // "k_pair_gemm_fp4", or "k_pair_gemm_bits" under MSC_GEMM_I8
+const char* msc_pair_gemm_kernel_name();          // "k_pair_gemm_fp4_dma"
 uint32_t msc_pair_gemm_slices(uint64_t nbins, uint32_t m, uint32_t qn, int num_cus);
-uint64_t msc_pair_gemm_abits_bytes(uint64_t nbins, uint32_t qn);
 uint64_t msc_pair_gemm_qt_bytes(uint64_t nbins, uint32_t qn);
 uint64_t msc_pair_gemm_anib_bytes(uint64_t nbins, uint32_t qn);          // the queries' nibble tiles for the LDS-DMA form of the product (0: off)
 hipError_t msc_launch_pair_gemm_queries(hipStream_t st, uint64_t nbins, const uint8_t* q_kb, const void* q_mb, const uint32_t* q_mb_n, uint32_t q_pitch,
-                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* abits, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
+                                        const uint32_t* q_slots_dev, uint32_t n_q, uint32_t qn, uint8_t* qT, uint64_t n_hot, void* hot, uint32_t* hot_ptr,
                                         uint32_t* hot_cursor, uint32_t* hot_cnt, uint8_t* anib);
-hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, const uint8_t* abits,
-                                uint32_t qn, uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff, const uint8_t* anib);
+hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* cand_kb, const uint32_t* cand_slots, uint64_t first, uint32_t m, uint32_t qn,
+                                uint32_t k_slices, const uint32_t* hot_ptr, const void* hot, int32_t* out_min, int32_t* out_diff, const uint8_t* anib);
 hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a);
 hipError_t msc_launch_close_counts(hipStream_t st, const uint8_t* flags, uint32_t n_q, uint32_t m, uint64_t* counts);
 // the window bookkeeping the fused epilogue + reduce kernels do for msc_get_close_window (msc_window.hip): pos[i] = position of candidate i,

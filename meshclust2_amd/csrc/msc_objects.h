@@ -47,7 +47,7 @@ struct msc_ctx {
 	// msc_shard.hip: the payload of msc_colsum_partial, the gathered column-sum lists of the other ranks, header staging
 	DevBuf shard_payload, shard_hdrs;
 	// msc_pair_gemm.hip: the queries' side of a block (bit image, transposed counts, hot list + its three step arrays), P1 per slice, P2
-	DevBuf kb_abits, kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff, kb_anib;          // (kb_anib: the queries' tiles as nibbles, for the LDS-DMA form of the product)
+	DevBuf kb_qT, kb_hot, kb_hot_idx, kb_min, kb_diff, kb_anib;          // (kb_anib: the queries' tiles as nibbles, what the product copies into LDS)
 	// the close flags of a block of the matrix-core pass go back to the host on a stream of their own, under the next block's kernels:
 	// two device buffers take turns; msc_score_multi waits for the copies before it returns
 	hipStream_t copy_stream = nullptr;
@@ -77,12 +77,12 @@ struct msc_ctx {
 	hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_product[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
 	DevBuf kb_qT2, kb_min2, kb_diff2;
 	// r05: the queries' side of a block (k_kb_gather, k_hot_*) is prepared on a third stream while the product of the block before it
-	// runs, so the product stream goes from product to product. Everything that side writes exists twice (the first copies are kb_abits,
+	// runs, so the product stream goes from product to product. Everything that side writes exists twice (the first copies are
 	// kb_anib, kb_hot, kb_hot_idx, kb_qT). ev_call = this call's query slots are on the device; ev_prep[i] = the queries' side in copy i
 	// is ready; product_busy[i] = a product that reads copy i has been queued and ev_product[i] says when it is through
 	hipStream_t prep_stream = nullptr;
 	hipEvent_t ev_call = nullptr, ev_prep[2] = {nullptr, nullptr};
-	DevBuf kb_abits2, kb_anib2, kb_hot2, kb_hot_idx2;
+	DevBuf kb_anib2, kb_hot2, kb_hot_idx2;
 	bool product_busy[2] = {false, false};
 	bool tail_busy[2] = {false, false};
 	bool tail_used = false;

@@ -73,7 +73,7 @@ def main():
     t0, n, gemm = time.time(), 0, 0
     while time.time() - t0 < budget:
         line = one_round(ctx, seed)
-        gemm += "k_pair_gemm_fp4" in line or "k_pair_gemm_bits" in line
+        gemm += "k_pair_gemm_fp4_dma" in line
         print(line, flush=True)
         seed += 1
         n += 1

@@ -28,6 +28,11 @@ def main():
                           (40, np.arange(n, dtype=np.uint32)), (64, np.arange(3, n, dtype=np.uint32)), (33, np.arange(n - 1, 100, -1, dtype=np.uint32))):
             qs = (np.arange(nq, dtype=np.uint32) * 3) % n
             multi = api.score_multi(ctx, feat, hs, cands, hs, qs, feat_mask=mask)
+            want_kernel = os.environ.get("MSC_TEST_EXPECT_KERNEL")
+            if want_kernel and dtype == 32 and nq == 40:          # the switches under test select the route they say they select
+                assert ctx.last_kernel_info()[0].startswith(want_kernel), (ctx.last_kernel_info(), want_kernel)
+            only = api.score_multi(ctx, feat, hs, cands, hs, qs, want=("close",))          # flags alone: the f32 screen (pair_features.hip) where the route has it
+            assert np.array_equal(only["close"], multi["close"]), (dtype, k, nq)
             for i, q in enumerate(qs):
                 single = feat.compute(hs, cands, hs, int(q))
                 raw = api.pair_features_raw(ctx, hs, cands, hs, int(q), mask)

@@ -567,24 +567,29 @@ def test_multi_digest_variants(slots):
     assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
 
 
-@pytest.mark.parametrize("switches", ["", "MSC_MULTI_NO_GEMM", "MSC_MULTI_NO_GEMM MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_RANKS", "MSC_GEMM_A_KIB=256"])
-def test_multi_route_variants(switches):
+@pytest.mark.parametrize("switches,kernel", [("", "k_pair_gemm_fp4_dma<64 query rows"), ("MSC_MULTI_NO_GEMM", "k_pair_digest_multi"),
+                                             ("MSC_MULTI_NO_GEMM MSC_MULTI_NO_RANKS", "k_pair_digest_multi"), ("MSC_MULTI_NO_RANKS", "k_pair_digest_multi"),
+                                             ("MSC_GEMM_SLICES=8", "k_pair_gemm_fp4_dma<64 query rows"), ("MSC_NO_RANKS16", "k_pair_gemm_fp4_dma<64 query rows"),
+                                             ("MSC_GEMM_NO_PIPE MSC_NO_SCREEN", "k_pair_gemm_fp4_dma<64 query rows"), ("MSC_GEMM_NO_PREP MSC_GEMM_NO_QUEUE", "k_pair_gemm_fp4_dma<64 query rows")])
+def test_multi_route_variants(switches, kernel):
     """Every route of the Q x M pass over a dense set == independent 1 x M passes, bit for bit (the library reads its switches once
-    per process): everything on the matrix cores (one int8 product per tile + corrections from the lists of large bins,
-    msc_pair_gemm.hip) with the earth mover's distance from ranks (msc_emd_ranks.hip); the digest kernel with its own products + ranks;
-    the r02 digest kernel alone; without the ranks mirror (the matrix-core pass then only serves models without emd); the matrix-core
-    pass cut into many thin slices of the bins."""
+    per process), the kernel each set of switches must select asserted by name: everything on the matrix cores (one FP4 product per tile
+    of presence bits + corrections from the lists of large bins, msc_pair_gemm.hip) with the earth mover's distance from 16-bit reduced
+    ranks (msc_emd_ranks.hip); the digest kernel with its own products + ranks; the r02 digest kernel alone; without the ranks mirror (the
+    matrix-core pass then only serves models without emd); the matrix-core pass cut into eight slices of the bins; the 32-bit rank walk;
+    one stream and FP64 flags; the queries' side on the product's stream and a host wait per block."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ)
     for k in ("MSC_MULTI_TQ", "MSC_MULTI_NO_DIGEST", "MSC_MULTI_NO_RING", "MSC_RING_NO_P16", "MSC_RING_SLOTS", "MSC_DIGEST_SLOTS",
-              "MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_GEMM", "MSC_DIGEST_NO_TQ8", "MSC_GEMM_A_KIB"):
+              "MSC_MULTI_NO_RANKS", "MSC_MULTI_NO_GEMM", "MSC_DIGEST_NO_TQ8", "MSC_GEMM_SLICES", "MSC_NO_RANKS16", "MSC_GEMM_NO_PIPE", "MSC_NO_SCREEN", "MSC_GEMM_NO_PREP", "MSC_GEMM_NO_QUEUE"):
         env.pop(k, None)
     for sw in switches.split():
         name, _, val = sw.partition("=")
         env[name] = val or "1"
+    env["MSC_TEST_EXPECT_KERNEL"] = kernel
     out = subprocess.run([sys.executable, os.path.join(here, "ring_variant_check.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert b"RING_VARIANT_OK" in out.stdout, out.stdout.decode(errors="replace")[-3000:]
 
@@ -1318,7 +1323,7 @@ def test_multi_query_pass_with_queries_from_another_set(ctx):
     mask = FAST_MASK & ~((1 << 7) | (1 << 29))
     for rnd in range(2):
         multi = api.score_multi(ctx, feat, db, None, qs_set, q_slots, m=70, feat_mask=mask)
-        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_pair_gemm_fp4", "k_pair_gemm_bits"))
+        assert ctx.last_kernel_info()[0].startswith(("k_pair_digest_multi", "k_pair_gemm_fp4_dma<"))
         for i, q in enumerate(q_slots):
             raw = api.pair_features_raw(ctx, db, None, qs_set, int(q), mask, m=70)
             single = feat.compute(db, None, qs_set, int(q), m=70)

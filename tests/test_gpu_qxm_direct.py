@@ -15,7 +15,7 @@ from meshclust2_amd import api, synth
 pytestmark = pytest.mark.gpu
 ALL_MASK = sum(1 << b for _, b in FEATS)
 FAST_MASK = sum(1 << b for name, b in FEATS if name not in ("jefferey_divergence", "jensen_shannon"))
-GEMM_KERNELS = ("k_pair_gemm_fp4", "k_pair_gemm_bits")         # the pass on the matrix cores, as msc_last_kernel_info names it
+GEMM_KERNELS = ("k_pair_gemm_fp4_dma<",)         # the pass on the matrix cores, as msc_last_kernel_info names it: "k_pair_gemm_fp4_dma<N query rows, ...>", the one product kernel
 RTOL = 1e-9
 
 

@@ -34,28 +34,28 @@ int main(int argc, char** argv) {
 	const uint64_t nbins = 262144;
 	const uint32_t qn = 128;
 	const uint64_t kb_bytes = (uint64_t)(m + 31) / 32 * msc_kb_block_bytes(nbins);
-	uint8_t *kb, *abits, *qT, *anib;
+	uint8_t *kb, *qT, *anib;
 	uint32_t* qs;
 	int32_t *ref, *out, *diff;
 	unsigned long long* cnt;
 	CK(hipMalloc(&kb, kb_bytes)); CK(hipMemset(kb, 0, kb_bytes));
-	CK(hipMalloc(&abits, msc_pair_gemm_abits_bytes(nbins, qn))); CK(hipMalloc(&qT, msc_pair_gemm_qt_bytes(nbins, qn))); CK(hipMalloc(&anib, nbins / 2 * qn));
+	CK(hipMalloc(&qT, msc_pair_gemm_qt_bytes(nbins, qn))); CK(hipMalloc(&anib, nbins / 2 * qn));
 	CK(hipMalloc(&qs, qn * 4)); CK(hipMalloc(&ref, (size_t)m * qn * 4)); CK(hipMalloc(&out, (size_t)m * qn * 4)); CK(hipMalloc(&diff, (size_t)m * qn * 4)); CK(hipMalloc(&cnt, 16));
 	const uint32_t per = 990;
 	k_fill_kb<<<(unsigned)(((uint64_t)m * per + 255) / 256), 256>>>(kb, nbins, m, per);
 	k_iota<<<1, 128>>>(qs, qn, 701);          // queries = candidates 0, 701, 1402 ..
 	CK(hipDeviceSynchronize());
-	CK(msc_launch_pair_gemm_queries(0, nbins, kb, nullptr, nullptr, 0, qs, qn, qn, abits, qT, 0, nullptr, nullptr, nullptr, nullptr, anib));
+	CK(msc_launch_pair_gemm_queries(0, nbins, kb, nullptr, nullptr, 0, qs, qn, qn, qT, 0, nullptr, nullptr, nullptr, nullptr, anib));
 	CK(hipDeviceSynchronize());
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	auto timed = [&](auto&& launch) { CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; };
-	auto base = [&] { CK(msc_launch_pair_gemm(0, nbins, kb, nullptr, 0, m, abits, qn, 1, nullptr, nullptr, ref, diff, anib)); };
+	auto base = [&] { CK(msc_launch_pair_gemm(0, nbins, kb, nullptr, 0, m, qn, 1, nullptr, nullptr, ref, diff, anib)); };
 	base();
 	CK(hipDeviceSynchronize());
 	std::vector<Variant> vs = variants();
 	for (auto& v : vs) {
 		CK(hipMemset(out, 0xff, (size_t)m * qn * 4));
-		v.launch(kb, m, anib, abits, nbins, out);
+		v.launch(kb, m, anib, nbins, out);
 		CK(hipDeviceSynchronize());
 		CK(hipMemset(cnt, 0, 16));
 		k_diff<<<(unsigned)(((uint64_t)m * qn + 255) / 256), 256>>>(ref, out, (uint64_t)m * qn, cnt, cnt + 1);
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
 	std::vector<std::vector<float>> t(vs.size() + 1);
 	for (int r = 0; r < rounds; r++) {
 		t[0].push_back(timed(base));
-		for (size_t i = 0; i < vs.size(); i++) t[i + 1].push_back(timed([&] { vs[i].launch(kb, m, anib, abits, nbins, out); }));
+		for (size_t i = 0; i < vs.size(); i++) t[i + 1].push_back(timed([&] { vs[i].launch(kb, m, anib, nbins, out); }));
 	}
 	const double ops = 2.0 * m * qn * nbins;
 	for (size_t i = 0; i <= vs.size(); i++) {
