@@ -324,7 +324,140 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
     trn4 = api.Trainer(ctx, api.Feature.from_text(ctx, w4, 0), 0.9)
     ent4 = int(8 * np.mean([s4.entries(i) for i in range(0, n4, 16)]))
     rows.append(get_close_leg(api, ctx, trn4, s4, n4, 20, ent4, "cfg4's shape: %d x %d bp, k=%d, datatype=64, sparse layout" % (n4, len4, k4)))
+    del s4
+    # r05: the kernels that cost the clustering runs their wall time -- the `--feat slow` model, the window pass on mixed lengths, get_mean
+    for leg in (lambda: slow_model_leg(api, ctx, hs, M, args), lambda: window_leg(api, synth, ctx, args), lambda: mean_nearest_leg(api, ctx, hs, M, args)):
+        try:
+            rows.append(leg())
+        except Exception as e:      # noqa: BLE001 -- one leg failing must not cost the others
+            rows.append({"workload": "failed", "error": repr(e)})
     return rows
+
+
+def slow_model_leg(api, ctx, hs, M, args):
+    """Q x M with BASELINE cfg5's model (`--feat slow`: 5 statistics incl. jensen_shannon, predict/Feature.cpp:984-1009) on the resident
+    set: the integer reductions come from the matrix-core pass as in the main leg, the divergence sums from one merge pass per query over
+    the sets' sparse mirrors queued behind it. Bytes: 8 per stored bin of a candidate's list, once per query."""
+    wtext = open(os.path.join(ROOT, "tests", "golden", "weights_cfg5_k9.txt")).read().replace("uint8_t", "uint%d_t" % args.dtype)
+    feat = api.Feature.from_text(ctx, wtext, 0)
+    nq = 256
+    out = {"close": api.pinned_array(ctx, (nq, M), np.uint8)}
+    qs = np.array([(j * 7919 + 11) % M for j in range(nq)], dtype=np.uint32)
+    api.score_multi(ctx, feat, hs, None, hs, qs[:128], m=M, want=("close", "counts"), out={"close": out["close"][:128]})          # (builds the mirrors: untimed)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    res = api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close", "counts"), out=out)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    kernel, _ = ctx.last_kernel_info()
+    ent = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
+    alg = nq * (M + 1) * ent
+    ach = alg / dt / 1e9
+    return {"workload": "the resident set, Q x M with the `--feat slow` model of cfg5 (weights_cfg5_k9.txt: %d statistics incl. jensen_shannon): %d queries x %d" % (feat.n_singles, nq, M),
+            "metric": "sequence-pairs/sec identity-scored, Q x M, divergence statistics included", "value": nq * M / dt, "unit": "pairs/s", "ms_per_128_queries": dt / nq * 128 * 1e3,
+            "close_pairs": int(np.sum(res["counts"])),
+            "roofline": {"bound": "hbm", "kernel": "k_pair_sparse_mp (one divergence pass per query over the mirrors' lists) behind " + kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg, "seconds": dt,
+                         "note": "wall clock of the whole call: product, rank walk, %d merge passes, epilogue" % nq}}
+
+
+def window_leg(api, synth, ctx, args):
+    """Trainer::get_close over the accumulate loop's window (cluster/ClusterFactory.cpp:553-610 -> cluster/Trainer.cpp:23-71) on a
+    cfg5-shaped set: 2 000 sequences of 500 b - 50 kb (log-uniform templates, families of 5 at graded divergence), k = 9, 16-bit,
+    sparse layout, the `--feat slow` model at --id 0.6: the (candidate, round) pass over rank lists (k_pair_ranks_items). Bytes: 4 per
+    k-mer of every candidate inside the pass's length window."""
+    seed, n_t, per = 20260005, 400, 5
+    seqs = []
+    for t in range(n_t):
+        u = synth._unit(synth._stream(seed, 2 * t + 1, 2))
+        length = int(round(np.exp(np.log(500.0) + float(u[0]) * (np.log(50000.0) - np.log(500.0)))))
+        tmpl = synth.template(seed, t, length)
+        for j in range(per):
+            rate = 0.03 + 0.07 * j
+            seqs.append(synth.to_ascii(synth.member(seed, t, j, tmpl, sub_rate=rate * 0.85, indel_rate=rate * 0.15)))
+    n = len(seqs)
+    lens = np.array([len(s_) for s_ in seqs])
+    hs = api.HistogramSet(ctx, 9, 16, n, sparse_entries=int(lens.sum()) + 4096)
+    for off in range(0, n, 256):
+        hs.build(seqs[off:off + 256], first_slot=off)
+    wtext = open(os.path.join(ROOT, "tests", "golden", "weights_cfg5_k9.txt")).read().replace("uint8_t", "uint16_t")
+    trn = api.Trainer(ctx, api.Feature.from_text(ctx, wtext, 0), 0.6)
+    order = np.argsort(lens, kind="stable").astype(np.uint32)
+    sl = lens[order]
+    win = api.Window(ctx, hs, order)
+    rng = np.random.default_rng(5)
+    queries = [int(x) for x in rng.permutation(n)[:70]]
+
+    def one(q):
+        a, b = int(np.searchsorted(sl, int(lens[q] * 0.6), "left")), int(np.searchsorted(sl, int(lens[q] / 0.6), "right"))
+        alive = win.alive(a, b)
+        closed = win.get_close(trn, a, b, hs, q)[0]
+        return alive, int(sl[a:b].sum()), len(closed), ctx.last_kernel_ms()[0]
+    for q in queries[:10]:
+        one(q)
+    ctx.synchronize()
+    pairs = kmers = 0
+    kms = []
+    kernels = {}
+    t0 = time.perf_counter()
+    for q in queries[10:]:
+        alive, km, _, ms = one(q)
+        pairs += alive
+        kmers += km
+        kms.append(ms)
+        kernels[ctx.last_kernel_info()[0]] = kernels.get(ctx.last_kernel_info()[0], 0) + 1
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    alg = 4 * kmers          # (an upper bound: the k-mers of every sequence inside the length window, alive or not)
+    k_s = float(np.sum(kms)) * 1e-3
+    ach = alg / k_s / 1e9 if k_s > 0 else float("nan")
+    return {"workload": "cfg5's shape: %d sequences of 500 b - 50 kb, k=9, datatype=16, sparse layout, `--feat slow` model, --id 0.6; %d window passes of msc_get_close_window" % (n, len(kms)),
+            "metric": "sequence-pairs/sec identity-scored inside the length windows, 1 x M window passes", "value": pairs / dt, "unit": "pairs/s", "passes": len(kms),
+            "candidates_per_pass": pairs / max(1, len(kms)), "ms_per_pass": dt / max(1, len(kms)) * 1e3,
+            "roofline": {"bound": "hbm", "kernel": max(kernels, key=kernels.get), "kernels": kernels, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": float(np.mean(kms)), "algorithmic_bytes_per_launch": alg / max(1, len(kms)), "launches_timed": len(kms),
+                         "note": "rank-list bytes (4 per k-mer) over the streaming kernel's own time (HIP events); value uses the wall clock of the passes"}}
+
+
+def mean_nearest_leg(api, ctx, hs, M, args):
+    """get_mean + closest (cluster/ClusterFactory.cpp:338-380, cluster/Trainer.cpp:144-157) on 1 000 members of the resident dense set:
+    column sums -> FP64 mean -> distance_d of every member to it -> first minimum. SURVEY 8(d): 2 m 4^k sizeof(T) bytes per call."""
+    m = min(1000, M)
+    slots = np.array([(j * 97 + 5) % M for j in range(m)], dtype=np.uint32)
+    api.mean_nearest(ctx, hs, slots)
+    ctx.synchronize()
+    calls = 5
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        pos, d, _ = api.mean_nearest(ctx, hs, slots)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / calls
+    alg = 2 * m * (4 ** args.k) * (args.dtype // 8)
+    ach = alg / dt / 1e9
+    return {"workload": "get_mean + closest over %d members of the resident set (k=%d, datatype=%d, dense)" % (m, args.k, args.dtype), "metric": "mean_and_nearest calls/s", "value": 1.0 / dt,
+            "unit": "calls/s", "ms_per_call": dt * 1e3, "members": m, "nearest_position": int(pos),
+            "roofline": {"bound": "hbm", "kernel": "k_colsum + k_pair_tiles + k_distance_members", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "note": "wall clock of the call (three kernels + the copy of the distances home)"}}
+
+
+def one_stream_product(api, ctx, feat, hs, M, Q, n_total):
+    """The product kernel's roofline without a neighbour: two steps with msc_set_block_pipe(0) (every kernel of a block on one stream), the
+    product timed by the library's HIP events on that stream."""
+    ctx.set_block_pipe(False)
+    try:
+        nq = min(Q, 1024)
+        out = {"close": api.pinned_array(ctx, (nq, M), np.uint8)}
+        ms, launches = [], []
+        for st in range(3):
+            qs = np.array([((st * nq + j) * 7919 + 3) % M for j in range(nq)], dtype=np.uint32)
+            api.score_multi(ctx, feat, hs, None, hs, qs, m=M, want=("close", "counts"), out=out)
+            if st:
+                ms.append(ctx.last_kernel_ms()[0])
+                launches.append(ctx.last_kernel_launches())
+        avg = float(np.sum(ms)) / max(1, int(np.sum(launches)))
+        return avg, int(np.sum(launches))
+    finally:
+        ctx.set_block_pipe(True)
 
 
 def pmc_traffic(kernel_prefix, config_key):
@@ -737,6 +870,18 @@ def main():
                                          "product of two set presence bits is exactly 1.0), exact sums in f32 (< 2^24)") if on_fp4 else
                                         "int8 multiply-adds counted as 2 operations each (v_mfma_i32_32x32x32_i8), exact int32 sums",
                                  "algorithmic_ops_per_launch": ops})
+    if on_mfma and args.mode == "allpairs" and world == 1 and not args.check:
+        # the same kernel without a neighbour on the chip: in the timed region above three streams share the CUs, and a kernel's launch time
+        # there includes what the others took from it
+        try:
+            one_ms, one_n = one_stream_product(api, ctx, feat, hs, M, Q, n_total)
+            one_tops = 2.0 * float(M) * 128 * (4 ** args.k) / (one_ms * 1e-3) / 1e12
+            line["roofline"]["one_stream"] = {"avg_launch_ms": one_ms, "launches_timed": one_n, "achieved": one_tops, "peak": MFMA_FP4_PEAK_TOPS, "unit": "TFLOP/s", "frac": one_tops / MFMA_FP4_PEAK_TOPS,
+                                              "note": "msc_set_block_pipe(0): every kernel of a block on one stream; the figure profiles/*_kernel_stats.csv of the same round holds"}
+        except Exception as e:      # noqa: BLE001
+            line["roofline"]["one_stream"] = {"error": repr(e)}
+    if traffic is not None:
+        line["roofline"]["traffic_source"] = "profiles/*_pmc_hbm.json: the committed rocprofv3 --pmc passes of this command (not measured in this run)"
     if args.check:
         line["check"] = checks
     if world == 1 and args.secondary and args.mode == "allpairs" and args.layout == "dense":

@@ -124,6 +124,12 @@ int         msc_set_kernel_timing(msc_ctx* ctx, int on);
  * 1 x M shape SURVEY 8(d) prices at 4^k sizeof(T) bytes per pair); results are identical either way. Default: on
  * (off at start with MSC_NO_MIRROR_1XM in the environment). */
 int         msc_set_mirror_pass(msc_ctx* ctx, int on);
+/* msc_score_multi queues the blocks of a call (128 queries x all candidates each; fastcar's outer loop, fastcar/FC_Runner.cpp:585-597) on
+ * three streams: block i's product beside its rank walk, the epilogue of block i - 1 and the queries' side of block i + 1. on = 0 runs
+ * every kernel of a block on ONE stream, block after block: same results, and per-kernel timings (msc_last_kernel_ms, rocprofv3) that are
+ * not stretched by a neighbour -- what the roofline of the product kernel is measured on. Default: on (off at start with
+ * MSC_GEMM_NO_PIPE in the environment). */
+int         msc_set_block_pipe(msc_ctx* ctx, int on);
 /* Number of streaming-kernel launches that pair_tiles_ms sums over (large calls are chunked). */
 int         msc_last_kernel_launches(const msc_ctx* ctx);
 /* Which streaming kernel the LAST scoring call ran (its name is copied to buf) and how many queries one HBM read of a

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "msc_last_kernel_ms": (_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "msc_set_kernel_timing": (_int, [_vp, _int]),
     "msc_set_mirror_pass": (_int, [_vp, _int]),
+    "msc_set_block_pipe": (_int, [_vp, _int]),
     "msc_last_kernel_launches": (_int, [_vp]),
     "msc_last_kernel_info": (_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(_int)]),
     "msc_encode": (_int, [C.c_char_p, C.c_size_t, _pu8, _pi64, C.c_size_t, C.POINTER(C.c_size_t), _pu64]),

@@ -63,6 +63,10 @@ class Context:
         """dense sets: 1 x M passes over the sparse mirror (default) or over the bins with the streaming kernel; same results"""
         self.check(self.lib.msc_set_mirror_pass(self.h, 1 if on else 0))
 
+    def set_block_pipe(self, on):
+        """msc_score_multi's blocks on three streams (default) or every kernel of a block on one: same results, unstretched kernel timings"""
+        self.check(self.lib.msc_set_block_pipe(self.h, 1 if on else 0))
+
     def last_kernel_launches(self):
         return self.lib.msc_last_kernel_launches(self.h)
 

@@ -124,6 +124,7 @@ extern "C" int msc_create(int device, msc_ctx** out) {
 		return fail(nullptr, MSC_ERR_HIP, "msc_create: stream/event creation failed");
 	}
 	ctx->mirror_pass = getenv("MSC_NO_MIRROR_1XM") == nullptr;
+	ctx->block_pipe = getenv("MSC_GEMM_NO_PIPE") == nullptr;
 	*out = ctx;
 	return MSC_OK;
 }
@@ -233,6 +234,12 @@ extern "C" int msc_device_name(const msc_ctx* ctx, char* buf, size_t cap) {
 extern "C" int msc_synchronize(msc_ctx* ctx) {
 	if (!ctx) return MSC_ERR_INVALID_ARG;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MSC_OK;
+}
+
+extern "C" int msc_set_block_pipe(msc_ctx* ctx, int on) {
+	if (!ctx) return MSC_ERR_INVALID_ARG;
+	ctx->block_pipe = on != 0;
 	return MSC_OK;
 }
 
@@ -2464,8 +2471,7 @@ static int score_multi_impl(msc_ctx* ctx, const msc_model* model, const msc_hist
 	// Queued blocks run in two stages on two streams (msc_objects.h): the product of block i on ctx->stream beside the rank walk of block i
 	// and the epilogue of block i - 1 on tail_stream -- the product is bound by the matrix pipe, the other two by vector arithmetic and
 	// latency. Blocks take turns on two copies of what both stages touch. (Single chunk, no divergence / group passes between the stages.)
-	static const bool no_pipe = getenv("MSC_GEMM_NO_PIPE") != nullptr;
-	const bool piped = deferred && chunk == m && !want_div && !want_grp && !no_pipe;
+	const bool piped = deferred && chunk == m && !want_div && !want_grp && ctx->block_pipe;
 	const int pb = piped ? (int)(ctx->pipe_next++ & 1) : 0;
 	hipStream_t tail = piped ? ctx->tail_stream : ctx->stream;
 	DevBuf& b_qT = pb ? ctx->kb_qT2 : ctx->kb_qT;

@@ -56,6 +56,7 @@ struct msc_ctx {
 	bool close_pp_busy[2] = {false, false};
 	int close_pp_next = 0;
 	bool copy_pending = false;
+	bool block_pipe = true;                // msc_set_block_pipe: the blocks of msc_score_multi on three streams
 	bool mirror_pass = true;               // msc_set_mirror_pass: a dense set's 1 x M passes merge the lists of its sparse mirror
 	bool packed_on_device = false;         // msc_hist_build_packed_dev: the 2-bit stream of the build in progress is device memory
 	bool no_kb_now = false;                // msc_score_multi: this block is taken by the older routes (its hot list would be too long)
