@@ -270,12 +270,19 @@ __global__ void __launch_bounds__(256) k_ranks16_build(const uint32_t* __restric
 }
 
 constexpr uint32_t kCand16 = 4;          // candidates per wave
-__global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restrict__ c_rk, uint64_t pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
+// NWV waves per workgroup (NWV x 4 candidates), QS queries per ring slot (2 slots of QS x 2 KiB). <8, 8>: 32 KiB of LDS, the form in use.
+// (<4, 4> -- 16 KiB and 4 waves of 96 registers, what is left on a CU that holds three workgroups of the product kernel -- does run
+// beside the product (0.37 -> 0.68 ms, the product 1.1 -> 1.6 - 2.2 ms), but the step comes out the same, 14.36 against 14.16 ms per
+// 1 024 queries: the two kernels share issue slots and LDS ports, not only places. profiles/r05_notes.md.)
+template <uint32_t NWV, uint32_t QS>
+__global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 4) k_emd_ranks16(const uint16_t* __restrict__ c_rk, uint64_t pitch, const uint32_t* __restrict__ c_n, const uint32_t* __restrict__ cand_slots,
                                                         uint64_t first, uint32_t m, const uint16_t* __restrict__ q_rk, const uint32_t* __restrict__ q_n,
                                                         const uint32_t* __restrict__ q_slots, uint32_t n_q, uint32_t nbins, uint64_t* __restrict__ out, uint32_t out_stride) {
-	__shared__ v4i_ sQ[2][kQHalf][kRound / 8];          // 2 x 16 KiB: a list's round = 1 024 reduced ranks = 2 KiB
+	static_assert(QS % NWV == 0 && 8 % QS == 0, "ring slots");
+	constexpr uint32_t SPG = 8 / QS;          // ring slots per group of 8 queries (one fold)
+	__shared__ v4i_ sQ[2][QS][kRound / 8];          // a list's round = 1 024 reduced ranks = 2 KiB
 	const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t c0 = (blockIdx.x * kWaves + wave) * kCand16;
+	const uint32_t c0 = (blockIdx.x * NWV + wave) * kCand16;
 	uint64_t slot[kCand16];
 	uint32_t nc[kCand16];
 #pragma unroll
@@ -284,9 +291,9 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 		slot[c] = cand_slots ? cand_slots[ci] : first + ci;
 		nc[c] = c_n[slot[c]];
 	}
-	const uint32_t my_q = 2 * (lane >> 4) + ((lane >> 3) & 1);          // the query of a half-group whose total fold8q leaves in this lane
+	const uint32_t my_q = 2 * (lane >> 4) + ((lane >> 3) & 1);          // the query of a group whose total fold8q leaves in this lane
 	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sQ[0][0][0]);
-	const uint32_t n_halves = (n_q + kQHalf - 1) / kQHalf;
+	const uint32_t n_slots = (n_q + QS - 1) / QS;
 	for (uint64_t base = 0; base < pitch; base += kRound) {
 		v4i_ a[kCand16][2];          // lane l: reduced ranks 512 j + 8 l .. + 7 of the round, two per register
 #pragma unroll
@@ -298,33 +305,40 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 #pragma unroll
 			for (int j = 0; j < 2; j++) asm volatile("" : "+v"(a[c][j]));
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		auto stage = [&](uint32_t h) {          // half-group h -> ring slot h % 2: wave q moves list q's round, two pieces of 1 KiB
-			const uint32_t q = wave, qi = h * kQHalf + q;
-			const uint32_t qs = q_slots[qi < n_q ? qi : n_q - 1];          // (rows past n_q: some list, never stored)
+		auto stage = [&](uint32_t hs) {          // ring slot hs % 2 <- queries QS hs .. + QS - 1: a wave moves QS / NWV lists' rounds, two pieces of 1 KiB each
 #pragma unroll
-			for (uint32_t part = 0; part < 2; part++)
-				dma_piece((uint64_t)(q_rk + (uint64_t)qs * pitch + base + 512 * part), lane * 16u, lds0 + (((h & 1) * kQHalf + q) * (kRound / 8) + 64 * part) * 16);
+			for (uint32_t q = wave; q < QS; q += NWV) {
+				const uint32_t qi = hs * QS + q;
+				const uint32_t qs = q_slots[qi < n_q ? qi : n_q - 1];          // (rows past n_q: some list, never stored)
+#pragma unroll
+				for (uint32_t part = 0; part < 2; part++)
+					dma_piece((uint64_t)(q_rk + (uint64_t)qs * pitch + base + 512 * part), lane * 16u, lds0 + (((hs & 1) * QS + q) * (kRound / 8) + 64 * part) * 16);
+			}
 		};
 		stage(0);
-		for (uint32_t h = 0; h < n_halves; h++) {          // one half-group of 8 queries per turn; its 8 totals per candidate are folded and stored at once
-			uint32_t nq_max = 0;
-			for (uint32_t q = 0; q < kQHalf; q++) {
-				const uint32_t qi = h * kQHalf + q;
-				const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
-				nq_max = v > nq_max ? v : nq_max;
-			}
-			uint32_t reach = nq_max;
+		uint32_t sum[kCand16][8];
+		uint32_t nq_max = 0;
+		bool idle = false;
+		for (uint32_t hs = 0; hs < n_slots; hs++) {          // a group of 8 queries = SPG ring slots; its 8 totals per candidate are folded and stored at once
+			if (hs % SPG == 0) {
+				nq_max = 0;
+				for (uint32_t q = 0; q < 8; q++) {
+					const uint32_t qi = (hs / SPG) * 8 + q;
+					const uint32_t v = qi < n_q ? q_n[q_slots[qi]] : 0;
+					nq_max = v > nq_max ? v : nq_max;
+				}
+				uint32_t reach = nq_max;
 #pragma unroll
-			for (uint32_t c = 0; c < kCand16; c++) reach = nc[c] > reach ? nc[c] : reach;
-			const bool idle = base != 0 && base >= reach;          // (a later round past every list of the wave and the half-group: all terms | pad - pad |)
+				for (uint32_t c = 0; c < kCand16; c++) reach = nc[c] > reach ? nc[c] : reach;
+				idle = base != 0 && base >= reach;          // (a later round past every list of the wave and the group: all terms | pad - pad |)
+			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed (and its stores have left)
 			__syncthreads();                                       // everybody's have, and everybody is done with the slot refilled next
-			if (h + 1 < n_halves) stage(h + 1);
+			if (hs + 1 < n_slots) stage(hs + 1);
 			if (idle) continue;
-			uint32_t sum[kCand16][kQHalf];
-			const uint32_t buf = h & 1;
+			const uint32_t buf = hs & 1, sub = (hs % SPG) * QS;
 #pragma unroll
-			for (uint32_t q = 0; q < kQHalf; q++) {
+			for (uint32_t q = 0; q < QS; q++) {
 				v4i_ b[2];
 #pragma unroll
 				for (int j = 0; j < 2; j++) b[j] = sQ[buf][q][64 * j + lane];
@@ -338,10 +352,15 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].z), "v"(b[j].z));
 						asm("v_sad_u16 %0, %1, %2, %0" : "+v"(t) : "v"(a[c][j].w), "v"(b[j].w));
 					}
-					sum[c][q] = t;
+					if constexpr (SPG == 1) sum[c][q] = t;
+					else {          // (sub is not a compile-time constant: a select per register instead of an indexed array in scratch)
+#pragma unroll
+						for (uint32_t z = 0; z < 8; z++) sum[c][z] = z == sub + q ? t : sum[c][z];
+					}
 				}
 			}
-			const uint32_t q0 = h * kQHalf;
+			if ((hs + 1) % SPG && hs + 1 < n_slots) continue;
+			const uint32_t q0 = (hs / SPG) * 8;
 			const bool owner = (lane & 7) == 0 && q0 + my_q < n_q;
 #pragma unroll
 			for (uint32_t c = 0; c < kCand16; c++) {
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) k_emd_ranks16(const uint16_t* __restri
 			}
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__syncthreads();          // the ring is free for the next round's first half-group
+		__syncthreads();          // the ring is free for the next round's first slot
 	}
 }
 
@@ -400,6 +419,6 @@ hipError_t msc_launch_emd_ranks16(hipStream_t st, uint64_t nbins, const uint16_t
                                   uint32_t m, const uint16_t* q_ranks, const uint32_t* q_n, const uint32_t* q_slots_dev, uint32_t n_q, uint64_t* out, uint32_t out_stride) {
 	if (m == 0 || n_q == 0) return hipSuccess;
 	if (n_q > out_stride || nbins > (1u << 20) || pitch % kRound) return hipErrorInvalidValue;
-	k_emd_ranks16<<<dim3((m + kWaves * kCand16 - 1) / (kWaves * kCand16)), dim3(64 * kWaves), 0, st>>>(c_ranks, pitch, c_n, cand_slots, first, m, q_ranks, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
+	k_emd_ranks16<8, 8><<<dim3((m + 8 * kCand16 - 1) / (8 * kCand16)), dim3(512), 0, st>>>(c_ranks, pitch, c_n, cand_slots, first, m, q_ranks, q_n, q_slots_dev, n_q, (uint32_t)nbins, out, out_stride);
 	return hipGetLastError();
 }

@@ -220,6 +220,20 @@ __device__ __forceinline__ void lds_dma_1k(const uint8_t* lane_src, uint32_t lds
 	    : "memory");
 }
 
+// the same with a wave-uniform 64-bit base in scalar registers + a 32-bit offset per lane
+__device__ __forceinline__ void lds_dma_1k_s(uint64_t sbase, uint32_t lane_off, uint32_t lds_wave_base) {
+	uint32_t keep;
+	asm volatile(
+	    "s_mov_b32 %0, m0\n\t"
+	    "s_mov_b32 m0, %3\n\t"
+	    "s_nop 0\n\t"
+	    "global_load_lds_dwordx4 %1, %2\n\t"
+	    "s_mov_b32 m0, %0"
+	    : "=&s"(keep)
+	    : "v"(lane_off), "s"(sbase), "s"(lds_wave_base)
+	    : "memory");
+}
+
 // The candidates' 16 bytes per lane and super-step come by LDS-DMA too, into a ring of kBDepth KiB per wave, kBDepth - 1 super-steps
 // ahead: a register destination can only be one super-step ahead (the wait in front of the barrier would have to let exactly that load
 // through, and a register still in flight cannot be handed on), and one super-step -- 0.2-0.5 us -- is less than a trip to HBM.
@@ -257,7 +271,8 @@ __global__ void __launch_bounds__(64 * NW, 3) k_pair_gemm_fp4_dma(const uint8_t*
 	const uint32_t cc = valid ? ci : m - 1;
 	const uint64_t slot = cand_slots ? cand_slots[cc] : first + cc;
 	const uint8_t* brow = cand_kb + (slot >> 5) * msc_kb_block_bytes(nbins) + (slot & 31) * 32 + (lane >> 5) * 16 + (uint64_t)gss0 * 1024;
-	const uint8_t* asrc = anib + (uint64_t)gss0 * kTile + wave * (kPieces * 1024) + lane * 16;
+	const uint64_t abase = (uint64_t)(anib + (uint64_t)gss0 * kTile + __builtin_amdgcn_readfirstlane(wave) * (kPieces * 1024));          // wave-uniform: the pieces' base in scalar registers
+	const uint32_t aoff = lane * 16;
 	const uint32_t lds_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sA[0][0] + wave * (kPieces * 1024));
 	const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sB[wave][0][0]);
 	v16f acc[NRB];
@@ -265,10 +280,12 @@ __global__ void __launch_bounds__(64 * NW, 3) k_pair_gemm_fp4_dma(const uint8_t*
 	for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
 		for (int i = 0; i < 16; i++) acc[rb][i] = 0.f;
+	// (a tile piece = scalar base + one 32-bit offset per lane: no 64-bit vector adds per piece; 0.99 against 1.05 ms per block)
 	auto copy_a = [&](uint32_t buf, uint32_t ss) {
-		const uint8_t* p = asrc + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * kTile;
+		const uint64_t pv = abase + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * kTile;
+		const uint64_t p = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);          // (wave-uniform by construction; said so)
 #pragma unroll
-		for (uint32_t i = 0; i < kPieces; i++) lds_dma_1k(p + i * 1024, lds_a + buf * kTile + i * 1024);
+		for (uint32_t i = 0; i < kPieces; i++) lds_dma_1k_s(p + i * 1024, aoff, lds_a + buf * kTile + i * 1024);
 	};
 	// a lane's source is its own candidate's 16 bytes: one wave-instruction gathers the 64 of them into one KiB of the ring
 	auto copy_b = [&](uint32_t ss) { lds_dma_1k(brow + (uint64_t)(ss < n_ss ? ss : n_ss - 1) * 1024, lds_b + (ss % kBDepth) * 1024); };

@@ -1318,7 +1318,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_pair_epilogue_bits_screen(const M
 
 // Behind k_pair_epilogue_bits_screen: a thread reads 16 flags of one query's row; where a byte says kScreenOpen, the pair's integer
 // reductions are formed again and evaluated in FP64 (epilogue_eval writes the flag).
-__global__ void __launch_bounds__(kBlock) k_pair_epilogue_bits_open(const MscEpilogueArgs a) {
+// (five waves per SIMD asked of the compiler = at most 96 registers: with the FP64 evaluation inlined the kernel took 256, and a wave of
+// 256 registers finds no room on a CU that holds three workgroups of the product kernel -- queued beside it, this 20 us scan waited a
+// millisecond for one to leave; the evaluation spills, and runs for one pair in thousands)
+__global__ void __launch_bounds__(kBlock, 5) k_pair_epilogue_bits_open(const MscEpilogueArgs a) {
 	const uint64_t total = (uint64_t)a.n_queries * a.m_per_query;
 	const uint64_t at = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
 	if (at >= total) return;

@@ -72,6 +72,15 @@ int main(int argc, char** argv) {
 		std::sort(t[i].begin(), t[i].end());
 		printf("%-40s median %.3f ms  min %.3f  -> %.2f POPS (of ~10 FP4 dense)\n", i ? vs[i - 1].name : "k_pair_gemm_fp4_dma (shipped)", t[i][t[i].size() / 2], t[i][0], ops / (t[i][0] * 1e-3) / 1e15);
 	}
+	{          // the phase stamps of the last variant (it ran last): cycles per super-step in each phase, wave 0 of the first 400 workgroups
+		std::vector<unsigned long long> stp(2000);
+		CK(hipMemcpyFromSymbol(stp.data(), HIP_SYMBOL(g_stamps), stp.size() * 8));
+		double tot[5] = {0, 0, 0, 0, 0};
+		for (int b = 0; b < 400; b++) for (int i = 0; i < 5; i++) tot[i] += (double)stp[5 * b + i] / 400.0 / (nbins / 256.0);
+		printf("phases, shader clocks per super-step (wave 0): issue of the 5 LDS-DMA copies %.0f | read of the candidates' bits %.0f | 16 operand reads + products issued %.0f | vmcnt(1) %.0f | barrier %.0f\n",
+		       tot[0], tot[1], tot[2], tot[3], tot[4]);
+	}
+	return 0;
 	// the clock the chip held inside the loop of the probe variant (run last in every round): shader clocks per 100 MHz tick
 	std::vector<unsigned long long> st(4096 * 2);
 	CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
