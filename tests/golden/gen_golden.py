@@ -222,6 +222,26 @@ def make_mixed_slow_clstr():
     print("wrote mixed_slow.clstr")
 
 
+def jitter_slow_set():
+    """900 sequences of 1 kb +- 100 (families of 10): every accumulate step scores a real length window at k = 9 (BASELINE cfg3's shape in
+    small), with a `--feat slow` model -- the window path's divergence statistics (msc_get_close_window: the rank form)"""
+    return synth.families(4711, 900, 1000, family=10, length_jitter=100)
+
+
+def make_jitter_slow_clstr():
+    """reference CLI end to end (train + cluster, 1 thread, histogram type by its own rule): its weights.txt and its .clstr"""
+    tmp = tempfile.mkdtemp()
+    seqs, hdrs = jitter_slow_set()
+    fa = os.path.join(tmp, "in.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    log = run_reference_cli(fa, ["--id", "0.8", "--kmer", "9", "--feat", "slow", "--threads", "1", "--output", "out.clstr"], tmp)
+    print([ln for ln in log.splitlines() if "bit histograms" in ln or "Number of clusters" in ln])
+    shutil.copy(os.path.join(tmp, "weights.txt"), os.path.join(HERE, "weights_jitter_slow_k9.txt"))
+    shutil.copy(os.path.join(tmp, "out.clstr"), os.path.join(HERE, "jitter_slow.clstr"))
+    shutil.rmtree(tmp)
+    print("wrote jitter_slow.clstr")
+
+
 def single_file_set():
     """48 FASTA files of 3 records each (members of one family); with --single-file every file is one sequence"""
     files = []
@@ -556,6 +576,7 @@ if __name__ == "__main__":
     make_regr_weights_and_fastcar()
     make_fastcar_k9_output()
     make_long_fragments()
+    make_jitter_slow_clstr()
     make_cfg5_clstr()
     make_cfg5_u16_clstr()
     make_k8_clstr()

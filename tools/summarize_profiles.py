@@ -67,6 +67,14 @@ def main():
         c = d.get("pmc") if isinstance(d, dict) else None
         if c and c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
             d["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["SQ_BUSY_CYCLES"] / 32)
+        # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES counts the cycles a SIMD's matrix pipe is busy, summed over the chip's 1 024
+        # SIMDs (the gfx94x MfmaUtil expression: / (elapsed cycles x SIMDs)); elapsed as above. Cross-check beside it: MFMA instructions
+        # x 32 cycles (v_mfma_f32_32x32x64_f8f6f4 with FP4 operands, tools/ubench/mfma_rate.hip) / the same denominator.
+        if c and c.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            elapsed = c["SQ_BUSY_CYCLES"] / 32
+            d["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / elapsed
+            if "SQ_INSTS_MFMA" in c:
+                d["mfma_busy_from_instruction_count"] = c["SQ_INSTS_MFMA"] * 32 / 1024 / elapsed
     pmc["_config"] = key
     json.dump(pmc, open(os.path.join(out_dir, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
     print("wrote %s/%s_kernel_stats.csv and %s_pmc_hbm.json" % (out_dir, tag, tag))
