@@ -1487,6 +1487,35 @@ def test_cfg5_mixed_lengths_slow_features_at_k9(tmp_path, tag, run_cap, bits, ex
 
 
 @pytest.mark.parametrize("extra", [[], ["--sparse"]])
+def test_jitter_slow_windows_through_the_rank_form_divergences(tmp_path, extra):
+    """900 sequences of 1 kb +- 100 (families of 10), k = 9, the `--feat slow` model the reference trained on them (it uses
+    jefferey_divergence, predict/Feature.cpp:1231-1263), --id 0.8: every accumulate step scores a REAL length window through
+    msc_get_close_window, whose divergence sums come from the rank form (k_pair_ranks_1xm counts cells, k_rank_div_finish adds them:
+    the same terms as the merge kernels' in another order of addition, DESIGN 4.1d). The fixture is the reference CLI's own .clstr;
+    the driver reproduces it byte for byte from the dense layout (through the sparse mirror) and the sparse one -- and the library's own
+    count says the passes did run over rank lists."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden")
+    seqs, hdrs = synth.families(4711, 900, 1000, family=10, length_jitter=100)
+    fa = str(tmp_path / "jitter.fa")
+    synth.write_fasta(fa, seqs, hdrs)
+    out = str(tmp_path / "out.clstr")
+    r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster"), fa, "--recover", os.path.join(golden, "weights_jitter_slow_k9.txt"), "--id", "0.8",
+                        "--kmer", "9", "--datatype", "8", "--output", out] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200,
+                       env=dict(os.environ, MSC_PROFILE_CALLS="1"))
+    log = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, log[-2000:]
+    got, exp = open(out, "rb").read(), open(os.path.join(golden, "jitter_slow.clstr"), "rb").read()
+    assert _same_clusters(got, exp), "clusters differ"
+    assert got == exp, "same clusters, but the CLSTR bytes differ: %d vs %d bytes" % (len(got), len(exp))
+    m = re.search(r"list passes: (\d+) pairs scored inside their length windows \((\d+) of them over rank lists\)", log)
+    assert m and int(m.group(2)) > 0.9 * int(m.group(1)) > 10000, log[-1500:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--sparse"]])
 def test_cluster_driver_k9_uint8(tmp_path, extra):
     """BASELINE cfg3 in small: k = 9 with the histogram type the reference CLI chose by itself (uint8_t, 256 KiB histograms); the
     driver, fed the model that run trained, writes the same .clstr bytes from the dense and from the sparse layout."""
