@@ -191,7 +191,8 @@ int msc_hist_build_packed(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, 
 /* The same with `packed` in THIS device's memory (every other array on the host, as above): the form a multi-GPU driver uses for
  * sequences that arrived over xGMI -- fastcar's outer loop hands each chunk of queries to every database chunk
  * (fastcar/FC_Runner.cpp:585-597); with the database sharded over GPUs the chunk's bases are all-gathered device to device and
- * each rank builds the block's histograms itself. */
+ * each rank builds the block's histograms itself. `packed` is read on the context's own stream: its bytes must be COMPLETE when the
+ * call is made (a producer on another stream -- an RCCL all-gather -- is waited for by the caller first). */
 int msc_hist_build_packed_dev(msc_ctx* ctx, msc_hist_set* set, uint64_t first_slot, uint64_t n_seqs,
                               const void* packed_dev, uint64_t n_bases,
                               const uint32_t* seg_seq, const uint64_t* seg_start, const uint64_t* seg_end, uint64_t n_segs,

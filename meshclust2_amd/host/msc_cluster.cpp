@@ -367,6 +367,7 @@ int main(int argc, char** argv) {
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		std::unique_ptr<msc::TcpComm> boot;          // rendezvous of the ranks (and the whole transport under MSC_COMM=tcp)
 		if (sharded) boot.reset(new msc::TcpComm(env));
+		bool rank_file = false;
 		if (weights.empty() && sharded && env.rank != 0) {
 			// rank 0 chooses k and the histogram type and trains; the others wait for (k, type, length of the weights text) and then the
 			// text itself -- not for a file in a shared working directory -- with no deadline on this one wait (training has none)
@@ -379,6 +380,7 @@ int main(int argc, char** argv) {
 			boot->broadcast(&text[0], text.size(), 0, false);
 			weights = dump + ".rank" + std::to_string(env.rank);
 			std::ofstream(weights.c_str()) << text;
+			rank_file = true;          // (this rank's copy of the text rank 0 sent: removed once the model has been read from it)
 		}
 		if (weights.empty()) {
 			if (k < 0) {           // find_k, cluster/CRunner.cpp:479-502: ceil(log4(average record size)) - 1, integer averages
@@ -417,6 +419,7 @@ int main(int argc, char** argv) {
 			std::string tok;
 			while (in >> tok) if (tok == "Datatype:") { in >> tok; dtype = tok == "uint8_t" ? 8 : tok == "uint16_t" ? 16 : tok == "uint32_t" ? 32 : 64; break; }
 		}
+		if (rank_file) std::remove(weights.c_str());
 		uint64_t total_bases = 0, longest = 0;
 		for (const auto& sq : seqs) { total_bases += sq.size(); longest = std::max<uint64_t>(longest, sq.size()); }
 		if (sharded) {

@@ -49,7 +49,12 @@ public:
 	~RcclComm() override {
 		stop_ = true;
 		if (watchdog_.joinable()) watchdog_.join();
-		if (comm_) (void)ncclCommDestroy(comm_);
+		if (comm_) {          // a non-blocking communicator: finalize, wait for it (bounded), then destroy
+			(void)ncclCommFinalize(comm_);
+			ncclResult_t st = ncclInProgress;
+			for (int i = 0; i < 3000 && ncclCommGetAsyncError(comm_, &st) == ncclSuccess && st == ncclInProgress; i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+			(void)ncclCommDestroy(comm_);
+		}
 		if (ev_) (void)hipEventDestroy(ev_);
 		if (scratch_) (void)msc_device_free(ctx_, scratch_);
 	}
