@@ -1322,7 +1322,7 @@ static int model_index_of(const MscDevModel& m, uint64_t f) {
 // reductions' functions, every constant finite in f32, the bias 0 (the screen's threshold is s >= 0, GLM::logistic at 0.5).
 static void model_screen_image(MscDevModel& h) {
 	h.screen_ok = 0;
-	if (h.bias != 0.0 || h.n_singles < 1 || h.n_singles > 8 || h.n_combos < 1) return;          // (kScreenSingles)
+	if (h.bias != 0.0 || h.n_singles < 1 || h.n_combos < 1) return;
 	for (int i = 0; i < h.n_singles; i++) {
 		if (!(h.single_flag[i] & MSC_FEAT_FAST)) return;
 		const double range = h.maxs[i] - h.mins[i];

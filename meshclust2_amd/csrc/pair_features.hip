@@ -1005,7 +1005,6 @@ __device__ void epilogue_eval(const MscEpilogueArgs& a, uint32_t c, uint32_t ci,
 // (|s| within B of 0, a NaN or an infinity anywhere -- comparisons with NaN are false) the pair is UNDECIDED and the caller evaluates it
 // in FP64 as before, so the flags are those of the FP64 path, pair for pair (tests/test_gpu_qxm_direct.py compares them).
 constexpr float kScreenEps = 9.5367431640625e-07f;      // 2^-20
-constexpr int kScreenSingles = 8;                       // single statistics of a model with an f32 image (msc_model_create; the reference's models hold at most 8)
 
 __device__ __forceinline__ float screen_raw(uint64_t flag, const PairTotals& t, const Side& a, const Side& b, uint64_t nbins, int dtype) {
 	const float N = (float)nbins;
@@ -1047,25 +1046,28 @@ __device__ __forceinline__ float screen_raw(uint64_t flag, const PairTotals& t, 
 	}
 }
 
-// -> 1 close, 0 not close, -1 undecided. a / b = first / second argument of the reference call.
+// -> 1 close, 0 not close, -1 undecided. a / b = first / second argument of the reference call. Combo by combo, each one's one or two
+// normalised statistics formed on the spot (no array of them: indexed by a model's run-time positions it becomes chains of selects --
+// 350 v_cndmask in the first form of this function, more than its arithmetic; a statistic two combos share is formed twice).
 __device__ __forceinline__ int screen_close(const MscDevModel& md, const PairTotals& t, const Side& a, const Side& b, uint64_t nbins, int dtype) {
 	if (a.len == 0 || b.len == 0) return -1;          // (length_difference throws: the FP64 path reports it)
-	float v[kScreenSingles], dv[kScreenSingles];
-	for (int i = 0; i < md.n_singles && i < kScreenSingles; i++) {
+	auto single = [&](int i, float& v, float& dv) {          // normalised statistic i and the bound of its error
 		const float r = screen_raw(md.single_flag[i], t, a, b, nbins, dtype);
 		const float u = (r - md.s_min[i]) * md.s_inv[i];
 		const float du = (kScreenEps * (fabsf(r) + fabsf(md.s_min[i])) + 1e-30f) * fabsf(md.s_inv[i]) + kScreenEps * fabsf(u);
-		v[i] = md.is_sim[i] ? u : 1.f - u;
-		dv[i] = du + kScreenEps * fabsf(v[i]);
-	}
+		v = md.is_sim[i] ? u : 1.f - u;
+		dv = du + kScreenEps * fabsf(v);
+	};
 	float s = md.s_w[0], B = kScreenEps * fabsf(md.s_w[0]) + 1e-12f;
 	for (int col = 0; col < md.n_combos; col++) {
-		const int i0 = md.combo_idx[col][0], i1 = md.combo_idx[col][1], n = md.combo_n[col];
-		const float x = v[i0], ax = fabsf(x), hx = ax + dv[i0];
-		const float y = n == 2 || md.combo_kind[col] == MSC_COMBO_XY2 || md.combo_kind[col] == MSC_COMBO_X2Y ? v[i1] : 1.f;
-		const float ay = fabsf(y), hy = n == 2 || md.combo_kind[col] == MSC_COMBO_XY2 || md.combo_kind[col] == MSC_COMBO_X2Y ? ay + dv[i1] : 1.f;
+		const int kind = md.combo_kind[col];
+		const bool two = md.combo_n[col] == 2 || kind == MSC_COMBO_XY2 || kind == MSC_COMBO_X2Y;
+		float x, dx, y = 1.f, dy = 0.f;
+		single(md.combo_idx[col][0], x, dx);
+		if (two) single(md.combo_idx[col][1], y, dy);
+		const float ax = fabsf(x), hx = ax + dx, ay = fabsf(y), hy = ay + dy;
 		float d, p, h;          // the product, of absolute values, of their upper bounds
-		switch (md.combo_kind[col]) {
+		switch (kind) {
 		case MSC_COMBO_XY:   d = x * y;         p = ax * ay;           h = hx * hy; break;
 		case MSC_COMBO_X2Y2: d = x * x * y * y; p = ax * ax * ay * ay; h = hx * hx * hy * hy; break;
 		case MSC_COMBO_XY2:  d = x * y * y;     p = ax * ay * ay;      h = hx * hy * hy; break;
