@@ -428,7 +428,6 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 	}
 	if (!anib) return hipErrorInvalidValue;
 	{
-		static const unsigned dma_pad = [] { const char* e = getenv("MSC_GEMM_LDS_PAD"); return (unsigned)(e ? atoi(e) * 1024 : 0); }();
 		// the tiles that do not fill the chip's places a whole number of times go as short pieces (see the kernel); one slice only
 		static const bool no_pieces = getenv("MSC_GEMM_NO_PIECES") != nullptr;
 		static const int num_cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount <= 0) return 256; return p.multiProcessorCount; }();
@@ -446,7 +445,7 @@ hipError_t msc_launch_pair_gemm(hipStream_t st, uint64_t nbins, const uint8_t* c
 			}
 		}
 		const dim3 grid(grid_x, k_slices);
-#define MSC_DMA_GO(NRB) k_pair_gemm_fp4_dma<NRB, 4><<<grid, dim3(256), dma_pad, st>>>(cand_kb, cand_slots, first, m, anib, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff, n_whole, piece_ss)
+#define MSC_DMA_GO(NRB) k_pair_gemm_fp4_dma<NRB, 4><<<grid, dim3(256), 0, st>>>(cand_kb, cand_slots, first, m, anib, nbins, k_slices, hot_ptr, (const uint2*)hot, out_min, out_diff, n_whole, piece_ss)
 		if (qn == 32) MSC_DMA_GO(1);
 		else if (qn == 64) MSC_DMA_GO(2);
 		else if (qn == 128) MSC_DMA_GO(4);

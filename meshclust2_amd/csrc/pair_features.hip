@@ -2136,13 +2136,9 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 		const bool screen = a.screen && a.model && a.close_soa && !a.sum_soa && !a.csum_soa && !a.raw_out && !a.singles_out && !a.combos_out && !a.pair_out && !a.use_window &&
 		                    !a.div_direct && !a.grp_pairs && !a.sparse_base;
 		if (screen) {
-			static const uint32_t chunk = [] { const char* e = getenv("MSC_SCREEN_CHUNK"); const int v = e ? atoi(e) : 4; return (uint32_t)(v == 1 || v == 4 || v == 8 || v == 16 ? v : 4); }();
+			constexpr uint32_t chunk = 4;          // candidates per wave: 1 / 4 / 8 / 16 took 265 / 274 / 609 / 678 us per block before the screen was slimmed; 4 keeps the queries' side per wave
 			const uint64_t cw = (uint64_t)((a.m_per_query + chunk - 1) / chunk) * ((a.n_queries + 63) / 64);
-			const dim3 grid((unsigned)((cw + kWavesPerBlock - 1) / kWavesPerBlock));
-			if (chunk == 1) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<1>, grid, dim3(kBlock), 0, st, a);
-			else if (chunk == 4) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<4>, grid, dim3(kBlock), 0, st, a);
-			else if (chunk == 8) hipLaunchKernelGGL(k_pair_epilogue_bits_screen<8>, grid, dim3(kBlock), 0, st, a);
-			else hipLaunchKernelGGL(k_pair_epilogue_bits_screen<16>, grid, dim3(kBlock), 0, st, a);
+			hipLaunchKernelGGL(k_pair_epilogue_bits_screen<chunk>, dim3((unsigned)((cw + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
 			const uint64_t threads = ((uint64_t)a.n_queries * a.m_per_query + 15) / 16;
 			hipLaunchKernelGGL(k_pair_epilogue_bits_open, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a);
 		} else hipLaunchKernelGGL(k_pair_epilogue_bits, dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, a);
