@@ -502,6 +502,9 @@ extern "C" void msc_hist_set_destroy(msc_hist_set* s) {
 	if (s->rkl) (void)hipFree(s->rkl);
 	if (s->rkl_off) (void)hipFree(s->rkl_off);
 	if (s->rkl_n) (void)hipFree(s->rkl_n);
+	if (s->rkm) (void)hipFree(s->rkm);
+	if (s->rkm_off) (void)hipFree(s->rkm_off);
+	if (s->rkm_n) (void)hipFree(s->rkm_n);
 	delete s;
 }
 
@@ -510,7 +513,7 @@ extern "C" int msc_hist_set_k(const msc_hist_set* s) { return s ? s->k : 0; }
 extern "C" int msc_hist_set_dtype(const msc_hist_set* s) { return s ? s->dtype : 0; }
 extern "C" uint64_t msc_hist_set_bytes(const msc_hist_set* s) {
 	if (!s) return 0;
-	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity + (s->rkl ? s->rkl_entries * 4 + s->capacity * 12 : 0);
+	if (s->sparse) return s->ent_capacity * 12 + (s->scalar_stride + sizeof(MscSparseHdr)) * s->capacity + (s->rkl ? s->rkl_entries * 4 + s->capacity * 12 : 0) + (s->rkm ? s->rkm_entries * 8 + s->capacity * 12 : 0);
 	return (s->L.slot_bytes + (s->digest ? msc_digest_slot_bytes(s->L) : 0) + (s->kb ? s->L.padded_bins / 8 + 32 + (uint64_t)s->mb_pitch * 8 + 4 : 0) + (s->ranks ? (s->rk_pitch + 1) * 4 : 0) + s->scalar_stride) * s->capacity;
 }
 
@@ -1559,6 +1562,32 @@ bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err, bool eager 
 	return true;
 }
 
+// ... and its repeated-bin lists, which the long-list pass (k_pair_ranks_items) reads beside them: built at the first such pass of an epoch
+int rank_multi_ready(msc_ctx* ctx, const msc_hist_set* s) {
+	if (s->rkm && s->rkm_epoch == s->list_epoch) return MSC_OK;
+	if (!s->rkm_off && (hipMalloc((void**)&s->rkm_off, (s->capacity + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&s->rkm_n, s->capacity * sizeof(uint32_t)) != hipSuccess)) {
+		(void)hipGetLastError();
+		return fail(ctx, MSC_ERR_OOM, "repeated-bin lists: out of device memory");
+	}
+	HIP_TRY(ctx, msc_launch_rank_multi_sizes(ctx->stream, s->ent, s->hdr, s->capacity, s->rkm_n, s->rkm_off));
+	uint64_t total = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&total, s->rkm_off + s->capacity, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (total + 4 > s->rkm_entries) {
+		if (s->rkm) (void)hipFree(s->rkm);
+		s->rkm = nullptr;
+		s->rkm_entries = total + total / 8 + 1024;
+		if (hipMalloc((void**)&s->rkm, s->rkm_entries * sizeof(uint2)) != hipSuccess) {
+			(void)hipGetLastError();
+			s->rkm_entries = 0;
+			return fail(ctx, MSC_ERR_OOM, "repeated-bin lists: out of device memory");
+		}
+	}
+	HIP_TRY(ctx, msc_launch_rank_multi_fill(ctx->stream, s->ent, s->hdr, s->capacity, s->rkm_off, s->rkm));
+	s->rkm_epoch = s->list_epoch;
+	return MSC_OK;
+}
+
 // Streams the candidates once, then folds / evaluates per candidate. Chunked so the partial records stay <= 256 MiB.
 }  // namespace
 bool needs_wide(const msc_hist_set* a, const msc_hist_set* b) { return needs_wide_impl(a, b); }
@@ -1655,7 +1684,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		pass_kmers = std::min(pass_kmers, std::max(rq.max_len, q_len));
 	}
 	const uint64_t pass_rounds = (pass_kmers + msc_ranks_items_round() - 1) / msc_ranks_items_round();
-	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (312 + pass_rounds * 40) <= (2048ull << 20);
+	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (400 + pass_rounds * 72) <= (2048ull << 20);
 	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
 	bool rank_items = false;
 	uint32_t rank_rounds = 0;
@@ -1669,6 +1698,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		}
 		rank_items = rank_pass && long_lists && items_ok;
 		if (rank_items) {
+			if ((r = rank_multi_ready(ctx, c_sp))) return r;
 			rank_rounds = (uint32_t)pass_rounds;
 			if ((r = ensure(ctx, ctx->rk_q, ((q_kmers + 255) & ~255ull) * sizeof(uint32_t) + 1024))) return r;
 		} else if (rank_pass && msc_ranks_pass_query_scratch(q_kmers) && (r = ensure(ctx, ctx->rk_q, msc_ranks_pass_query_scratch(q_kmers) * sizeof(uint32_t)))) return r;
@@ -1698,8 +1728,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
-	// (long lists: accumulators, cells, spot-term slots and the query's counts sit in ONE buffer, cleared by one command per pass)
-	if (rank_items && ((r = ensure(ctx, ctx->rk_acc, chunk * (32 + (rank_div ? 256 + (size_t)rank_rounds * 16 : 0)) + 64)) || (r = ensure(ctx, ctx->rk_items, 16 + chunk * 16 + chunk * (size_t)rank_rounds * 8)))) return r;
+	// (long lists: accumulators, cells, the query's counts and the items' spot-term slots sit in ONE buffer, its head cleared by one command per pass)
+	if (rank_items && ((r = ensure(ctx, ctx->rk_acc, msc_ranks_items_acc_bytes(chunk, rank_rounds, rank_div))) || (r = ensure(ctx, ctx->rk_items, msc_ranks_items_list_bytes(chunk, rank_rounds))))) return r;
 	if (rank_div) {
 		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * std::max<uint32_t>(1, rank_rounds) * 2 * sizeof(double))) ||
 		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
@@ -1742,12 +1772,11 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
 		if (lists && rank_items) {
-			uint8_t* zb = (uint8_t*)ctx->rk_acc.p;
-			const size_t z_acc = (size_t)mc * 32, z_cells = rank_div ? (size_t)mc * 256 : 0, z_extras = rank_div ? (size_t)mc * rank_rounds * 16 : 0;
-			MscRankDiv dv{(uint32_t*)(zb + z_acc), (double*)(zb + z_acc + z_cells), (uint32_t*)(zb + z_acc + z_cells + z_extras), (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
-			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
-			                                         q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus,
-			                                         (uint32_t*)ctx->rk_q.p, rank_rounds, (unsigned long long*)ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard, ctx->rk_items.p, z_acc + z_cells + z_extras + (rank_div ? 64 : 0)));
+			MscRankDiv dv{nullptr, nullptr, nullptr, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
+			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, c_sp->rkm, c_sp->rkm_off, c_sp->rkm_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride),
+			                                         cs->scalar_stride, d_slots, off, mc, q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len,
+			                                         (MscPartial*)ctx->partials.p, ctx->num_cus, (uint32_t*)ctx->rk_q.p, rank_rounds, ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard,
+			                                         ctx->rk_items.p));
 		} else if (lists && rank_pass) {
 			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,

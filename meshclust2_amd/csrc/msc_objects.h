@@ -167,6 +167,12 @@ struct msc_hist_set {
 	mutable uint64_t rkl_epoch = ~0ull, rkl_seen_epoch = ~0ull, rkl_entries = 0;
 	mutable uint32_t rkl_seen = 0;
 	mutable bool rkl_unavailable = false;
+	// ... and beside them, for the long-list pass (k_pair_ranks_items), the slot's REPEATED bins: (bin, value - 1) for value >= 3, in bin
+	// order, rkm_n[slot] of them at rkm_off[slot]; built at the first such pass of an epoch
+	mutable uint2* rkm = nullptr;
+	mutable uint64_t* rkm_off = nullptr;
+	mutable uint32_t* rkm_n = nullptr;
+	mutable uint64_t rkm_epoch = ~0ull, rkm_entries = 0;
 };
 
 struct msc_model {

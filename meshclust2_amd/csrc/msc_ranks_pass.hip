@@ -168,36 +168,6 @@ __global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restr
 	}
 }
 
-// k_rank_expand_one and k_rank_query_counts in one launch (the long-list pass needs both of every query)
-__global__ void __launch_bounds__(1024) k_rank_query_prep(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
-                                                          uint32_t* __restrict__ out, uint32_t cap, uint32_t* __restrict__ guard, uint32_t* __restrict__ hq, uint32_t* __restrict__ big) {
-	const MscSparseHdr h = *hdr_p;
-	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
-	if (pad > cap) {
-		if (blockIdx.x == 0 && threadIdx.x == 0 && guard) atomicOr(guard, 1u);
-		return;
-	}
-	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
-		const uint2 en = ent[h.off + j];
-		const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
-		for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
-		if (hq) {
-#pragma unroll
-			for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
-			if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
-		}
-	}
-	if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
-	if (hq) {
-#pragma unroll
-		for (uint32_t x = 2; x < 8; x++) {
-			const uint32_t t = (uint32_t)wave_sum_u64(cnt[x]);
-			if ((threadIdx.x & 63) == 0 && t) atomicAdd(&hq[x], t);
-		}
-	}
-}
-
 // eight lanes per candidate, lane b = the cells of query count b (b = 0: the counts >= 8 of the query's own list): each lane adds its
 // column, the eight partial sums are added in a fixed tree -- a candidate's result does not depend on who its neighbours in the launch are
 __global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restrict__ cells, const double* __restrict__ extras, const uint32_t* __restrict__ hq,
@@ -455,95 +425,143 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 // ------------------------------------------------------------------------------------------------ long lists: (candidate, round) items
 // k_pair_ranks_1xm gives a candidate to ONE wave. With lists of tens of thousands of k-mers and windows of a few thousand candidates
 // (BASELINE cfg5: sequences of 500 b - 50 kb) that is forty dependent loads per wave and most of the chip idle. Here the unit of work is a
-// ROUND of a candidate -- kRiRound consecutive entries of its rank list -- and any wave takes any round:
-//   * an entry's role depends on its neighbours only (first / last copy of its bin), which a round reads from global memory at its two
-//     ends; a run of copies that began before the round is found by one binary search per run;
-//   * every BIN is accounted for once, at its LAST copy, with its count e_c = the copy index + 1 (from a prefix maximum of first-copy
-//     positions over the round) and the query's e_q (two bits in LDS; three and more: a hash table in LDS of the query's few such bins):
-//     e_c e_q into the product, min(e_c, e_q) into the minimum, the pair of counts into the divergence cells;
-//   * a round's integer sums go into its candidate's accumulators with atomics (integers: any order), its divergence spot terms into a
+// ROUND of a candidate -- kRiRound consecutive entries of its rank list -- and any wave takes any round. r05: the walk knows no runs.
+//   * Every FIRST copy of a bin (an entry that differs from the one in front of it: the round reads one entry before its own) is accounted
+//     for as if the candidate held the bin ONCE: the query's e_q from the two-bit table in LDS, and a packed counter per value of it --
+//     twelve instructions per entry, no branch but the rare "three and more" (a hash table in LDS of the query's few such bins).
+//     sum e_c e_q, sum min(e_c, e_q) and the divergence cells (1, e_q) of the round are sums of those counters.
+//   * What a bin held MORE than once adds to that comes from the candidate's list of REPEATED bins -- (bin, e_c) for e_c >= 2, one in
+//     twenty of a random 25 kb sequence's bins, a homopolymer run of thousands of copies ONE entry -- in items of their own, kRiMulti
+//     entries each, every lane at work: (e_c - 1) e_q, min(e_c, e_q) - min(1, e_q), the bin moved from cell (1, e_q) to (e_c, e_q).
+//     (Until r05 every bin was accounted for at its LAST copy with its copy index from a prefix maximum over the round and a binary search
+//     for runs that began before it: ~60 instructions per entry and lane, 0.08 of HBM.)
+//   * a round's integer sums go into its candidate's accumulators with atomics (integers: any order), an item's divergence spot terms into a
 //     slot of its own; k_rank_items_finish turns accumulators, cells and slots into the candidate's records in a fixed order.
 constexpr uint32_t kRiRound = 1024;
+constexpr uint32_t kRiMulti = 256;          // entries of a candidate's repeated-bin list per item (at most 2 x rounds items: a repeated bin is two k-mers and more)
 constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the query's bins with e_q >= 3 (at most half are used)
+constexpr uint32_t kRiMultiFlag = 0x80000000u;
 
-// The items of a pass, as a list: a candidate's rounds are counted (0 for a candidate the length window drops), scanned, written out -- the
-// pass then walks real items only (with the host's bound, rounds per candidate = that of the LONGEST list of the set: on mixed lengths
-// four items in five were empty, and finding that out cost a wave three dependent loads each).
-struct RkItemMeta { uint64_t off; uint32_t n, rounds; };
-// one workgroup: start[c] = items in front of candidate c, start[m] = their number; then every thread writes its candidates' items
-__global__ void __launch_bounds__(1024) k_rank_items_list(RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ start, uint2* __restrict__ items,
-                                                          const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
-                                                          const uint32_t* __restrict__ cand_slots, uint64_t first, const uint32_t* __restrict__ q_cum,
-                                                          const MscSparseHdr* __restrict__ q_hdr_p, int use_window, uint64_t min_len, uint64_t max_len) {
-	__shared__ uint32_t s_part[1024];
-	// the candidates' records first (a launch of its own was 5 us of every step), dealt thread by thread so that the loads coalesce
-	{
-		const MscSparseHdr qh = *q_hdr_p;
-		const uint32_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
-		for (uint32_t c0 = threadIdx.x; c0 < m; c0 += 8 * 1024) {          // eight candidates per turn: their loads go out together, level by level
-			uint64_t slot[8], off[8], len[8];
-			uint32_t n[8];
+// n[slot] = its stored bins with two and more counted k-mers (value >= 3: every bin starts at 1); one wave per slot
+__global__ void __launch_bounds__(256) k_rkm_sizes(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr, uint64_t capacity, uint32_t* __restrict__ n) {
+	const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	if (s >= capacity) return;
+	const MscSparseHdr h = hdr[s];
+	uint32_t cnt = 0;
+	for (uint32_t j = lane; j < h.nnz; j += 64) cnt += ent[h.off + j].y >= 3u ? 1u : 0u;
+	cnt = wave_total_u32(cnt);
+	if (lane == 0) n[s] = cnt;
+}
+// ... and the list itself, (bin, e = value - 1) in bin order (the lanes' places from a ballot: the same list on every run)
+__global__ void __launch_bounds__(256) k_rkm_fill(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr, uint64_t capacity, const uint64_t* __restrict__ off,
+                                                  uint2* __restrict__ out) {
+	const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	if (s >= capacity) return;
+	const MscSparseHdr h = hdr[s];
+	uint2* o = out + off[s];
+	uint32_t base = 0;
+	for (uint32_t j0 = 0; j0 < h.nnz; j0 += 64) {
+		const uint32_t j = j0 + lane;
+		uint2 en = make_uint2(0u, 0u);
+		if (j < h.nnz) en = ent[h.off + j];
+		const bool keep = en.y >= 3u;
+		const uint64_t mask = __ballot(keep);
+		if (keep) o[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(en.x, en.y - 1u);
+		base += (uint32_t)__popcll(mask);
+	}
+}
+
+// The items of a pass, as a list: a candidate's rounds and repeated-bin items are counted (0 for a candidate the length window drops) and
+// written out -- the pass then walks real items only (with the host's bound, rounds per candidate = that of the LONGEST list of the set: on
+// mixed lengths four items in five were empty, and finding that out cost a wave three dependent loads each). Any order will do (integer
+// atomics, a slot per item for what is FP64), so every workgroup claims its candidates' places with one atomic.
+struct RkItemMeta { uint64_t off, moff; double mag; uint32_t n, nm, rounds, mrounds; };
+// the query's side of a pass (k_rank_expand_one + k_rank_query_counts, blocks [0, 8)) and the list of items (the blocks behind them: a
+// candidate per thread) in one launch
+__global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
+                                                         uint32_t* __restrict__ out, uint32_t cap, uint32_t* __restrict__ guard, uint32_t* __restrict__ hq, uint32_t* __restrict__ big,
+                                                         RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ n_items, uint2* __restrict__ items,
+                                                         const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint64_t* __restrict__ m_off,
+                                                         const uint32_t* __restrict__ m_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
+                                                         const uint32_t* __restrict__ cand_slots, uint64_t first, int use_window, uint64_t min_len, uint64_t max_len) {
+	const MscSparseHdr h = *hdr_p;
+	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
+	if (blockIdx.x < 8) {
+		if (pad > cap) {          // the set's bound did not hold: say so and write nothing
+			if (blockIdx.x == 0 && threadIdx.x == 0 && guard) atomicOr(guard, 1u);
+			return;
+		}
+		uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += 8 * blockDim.x) {
+			const uint2 en = ent[h.off + j];
+			const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
+			for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
+			if (hq) {
 #pragma unroll
-			for (int i = 0; i < 8; i++) { const uint32_t c = c0 + 1024 * i; slot[i] = c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : 0; }
-#pragma unroll
-			for (int i = 0; i < 8; i++) {
-				const uint32_t c = c0 + 1024 * i;
-				if (c >= m) continue;
-				const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot[i] : (uint64_t)c) * scalar_stride);
-				len[i] = cs->length; off[i] = c_off[slot[i]]; n[i] = c_n[slot[i]];
-			}
-#pragma unroll
-			for (int i = 0; i < 8; i++) {
-				const uint32_t c = c0 + 1024 * i;
-				if (c >= m) continue;
-				RkItemMeta mt{off[i], n[i], 0};
-				if (!(use_window && (len[i] < min_len || len[i] > max_len))) {
-					const uint32_t T = mt.n > nq_tot ? mt.n : nq_tot;
-					mt.rounds = (T + kRiRound - 1) / kRiRound;
-				}
-				meta[c] = mt;
+				for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
+				if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
 			}
 		}
+		if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
+		if (hq) {
+#pragma unroll
+			for (uint32_t x = 2; x < 8; x++) {
+				const uint32_t t = (uint32_t)wave_sum_u64(cnt[x]);
+				if ((threadIdx.x & 63) == 0 && t) atomicAdd(&hq[x], t);
+			}
+		}
+		return;
 	}
-	__threadfence_block();
-	__syncthreads();
-	const uint32_t per = (m + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
-	uint32_t sum = 0;
-	for (uint32_t c = lo; c < hi; c++) sum += meta[c].rounds;
-	// exclusive scan over the 1 024 threads: a DPP scan per wave, one more over the sixteen wave totals (two barriers instead of twenty)
+	__shared__ uint32_t s_part[18];
+	const uint32_t c = (blockIdx.x - 8) * 1024 + threadIdx.x;
+	RkItemMeta mt{0, 0, 0.0, 0, 0, 0, 0};
+	if (c < m) {
+		const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+		const uint64_t len = cs->length;
+		mt.mag = (double)cs->mag;
+		mt.off = c_off[slot]; mt.n = c_n[slot];
+		mt.moff = m_off[slot]; mt.nm = m_n[slot];
+		if (!(use_window && (len < min_len || len > max_len))) {
+			const uint32_t T = mt.n > tot ? mt.n : tot;
+			mt.rounds = (T + kRiRound - 1) / kRiRound;
+			mt.mrounds = (mt.nm + kRiMulti - 1) / kRiMulti;
+		}
+		meta[c] = mt;
+	}
+	// the thread's place: a DPP scan per wave, one more over the sixteen wave totals, one atomic for the workgroup
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t incl = wave_incl_scan(sum);
+	const uint32_t mine = mt.rounds + mt.mrounds;
+	const uint32_t incl = wave_incl_scan(mine);
 	if (lane == 63) s_part[wave] = incl;
 	__syncthreads();
 	if (wave == 0) {
 		const uint32_t t = lane < 16 ? s_part[lane] : 0u;
 		const uint32_t ti = wave_incl_scan(t);
-		if (lane < 16) s_part[16 + lane] = ti - t;
-		if (lane == 15) s_part[32] = ti;
+		uint32_t base = 0;
+		if (lane == 15 && ti) base = atomicAdd(n_items, ti);
+		base = (uint32_t)__builtin_amdgcn_readlane((int)base, 15);
+		if (lane < 16) s_part[lane] = base + ti - t;
 	}
 	__syncthreads();
-	uint32_t run = s_part[16 + wave] + incl - sum;
-	for (uint32_t c = lo; c < hi; c++) {
-		const uint32_t r = meta[c].rounds;
-		for (uint32_t rd = 0; rd < r; rd++) items[run + rd] = make_uint2(c, rd);
-		run += r;
-	}
-	if (threadIdx.x == 0) start[0] = s_part[32];          // the number of items
+	uint32_t run = s_part[wave] + incl - mine;
+	for (uint32_t rd = 0; rd < mt.rounds; rd++) items[run + rd] = make_uint2(c, rd);
+	run += mt.rounds;
+	for (uint32_t rd = 0; rd < mt.mrounds; rd++) items[run + rd] = make_uint2(c, rd | kRiMultiFlag);
 }
 
 template <bool DIV>
-__global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
-                                                                const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
-                                                                uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
-                                                                uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, const uint32_t* __restrict__ rq, uint32_t rounds,
-                                                                unsigned long long* __restrict__ acc, uint32_t* __restrict__ cells, double* __restrict__ extras,
-                                                                const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta, const uint2* __restrict__ items,
-                                                                const uint32_t* __restrict__ n_items_p) {
+__global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint2* __restrict__ c_rm, uint32_t m, const uint2* __restrict__ q_ent,
+                                                                const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, uint32_t nbins,
+                                                                const uint32_t* __restrict__ rq, uint32_t rounds, unsigned long long* __restrict__ acc, uint32_t* __restrict__ cells,
+                                                                double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta,
+                                                                const uint2* __restrict__ items, const uint32_t* __restrict__ n_items_p) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	__shared__ uint32_t s_key[kRiHash], s_val[kRiHash];
 	__shared__ uint32_t s_nbig;
-	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the round in hand (flushed per round: a
-	                                                                                  // global atomic per entry was ~400 per candidate on three or four addresses)
+	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the item in hand, those no register counts
 	const uint32_t words = nbins / 16 + 1;
 	uint32_t* sb = s_rp;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -587,9 +605,9 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	}
 	const uint32_t n_items = *n_items_p;
 	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
-	(void)use_window; (void)min_len; (void)max_len; (void)c_off; (void)c_n;
+	(void)m;
 	// Records of the items two ahead; and the candidate ranks of the NEXT item touched (one dword per 64-byte line) right behind this
-	// item's own loads, so that they come out of L2 when their turn comes: the divergence form has no registers to hold a second round.
+	// item's own loads, so that they come out of L2 when their turn comes.
 	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
 	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
 	RkItemMeta mt_n = meta[item_n.x];
@@ -601,118 +619,158 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		item_n = item_n2; mt_n = mt_n2;
 		const bool has_next = it + n_waves < n_items;
 		if (it + 2 * n_waves < n_items) { item_n2 = items[it + 2 * n_waves]; mt_n2 = meta[item_n2.x]; }
-		const uint32_t c = item.x, rd = item.y;
-		const uint32_t nc = mt.n, nc_pad = (nc + 3u) & ~3u;
-		const uint32_t T = nc > nq_tot ? nc : nq_tot;
-		const uint32_t t0 = rd * kRiRound;
-		const uint32_t* P = c_rk + mt.off;
-		double cm = 0.0;
-		if constexpr (DIV) {
-			const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
-			cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride)->mag;
-		}
-		RkDivTerm t11{0.0, 0.0};
-		if constexpr (DIV) t11 = rk_div_term_call(1, 1, cm, qm, order);
-		uint4 a[4], b[4];
-#pragma unroll
-		for (uint32_t u = 0; u < 4; u++) {
-			const uint32_t t = t0 + 256 * u + 4 * lane;
-			a[u] = make_uint4(nbins, nbins, nbins, nbins);
-			b[u] = a[u];
-			if (t < nc_pad) a[u] = *reinterpret_cast<const uint4*>(P + t);
-			if (t < nq_pad) b[u] = *reinterpret_cast<const uint4*>(rq + t);
-		}
-		const uint32_t before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
-		const uint32_t after_round = t0 + kRiRound < nc ? P[t0 + kRiRound] : nbins;           // ... and the one behind it
-		uint32_t warm = 0;
-		if (has_next) {          // the next item's 4 KiB of ranks: 64 lines, one dword each
-			const uint32_t tn = item_n.y * kRiRound + 16 * lane;
-			if (tn < mt_n.n) {
-				const uint32_t* pw = c_rk + mt_n.off + tn;
-				asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(pw) : "memory");
-			}
-		}
-		uint64_t emd = 0, prod = 0;
-		uint32_t mins = 0, c01 = 0, c02 = 0;
+		const uint32_t c = item.x, rd = item.y & ~kRiMultiFlag;
+		const bool multi = (item.y & kRiMultiFlag) != 0;
+		const double cm = mt.mag;
+		uint64_t emd = 0, prod = 0;          // prod, mins: what the packed counters do not hold
+		uint32_t mins = 0;
+		uint32_t pk_a = 0, pk_b = 0;          // two pairs of 16-bit counters (see below)
 		double xjd = 0.0, xjs = 0.0;
-		uint32_t run_carry = 0;          // 1 + the round-local position of the latest first copy so far (0: none yet in this round)
+		uint32_t spurious = 0;
+		if (!multi) {
+			const uint32_t nc = mt.n, nc_pad = (nc + 3u) & ~3u;
+			const uint32_t T = nc > nq_tot ? nc : nq_tot;
+			const uint32_t t0 = rd * kRiRound;
+			const uint32_t* P = c_rk + mt.off;
+			uint4 a[4], b[4];
 #pragma unroll
-		for (uint32_t u = 0; u < 4; u++) {
-			if (t0 + 256 * u >= T) break;
-			const uint4 av = a[u], bv = b[u];
-			uint32_t d = sad_u32(av.x, bv.x, 0u);
-			d = sad_u32(av.y, bv.y, d);
-			d = sad_u32(av.z, bv.z, d);
-			d = sad_u32(av.w, bv.w, d);
-			emd += d;
-			uint32_t prev = lane_prev(av.w), next = lane_next(av.x);
-			if (lane == 0) prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)a[u ? u - 1 : 0].w, 63) : before_round;
-			if (lane == 63) next = u < 3 ? (uint32_t)__builtin_amdgcn_readlane((int)a[u < 3 ? u + 1 : 3].x, 0) : after_round;
-			const uint32_t e4[4] = {av.x, av.y, av.z, av.w};
-			const uint32_t p4[4] = {prev, av.x, av.y, av.z};
-			const uint32_t n4[4] = {av.y, av.z, av.w, next};
-			const uint32_t tl = 256 * u + 4 * lane;          // round-local position of e4[0]
-			// where the run an entry belongs to began: the latest first copy at or before it (prefix maximum over the round)
-			uint32_t pf[4], lane_max = 0;
-#pragma unroll
-			for (int j = 0; j < 4; j++) { pf[j] = e4[j] != p4[j] ? tl + j + 1 : 0u; lane_max = pf[j] > lane_max ? pf[j] : lane_max; }
-			const uint32_t incl = wave_incl_max(lane_max);
-			uint32_t run = lane_prev(incl);          // (lane 0: 0)
-			run = run > run_carry ? run : run_carry;
-			const uint32_t last_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-			run_carry = last_incl > run_carry ? last_incl : run_carry;
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				run = pf[j] ? pf[j] : run;
-				const uint32_t bin = e4[j];
-				if (bin >= nbins || bin == n4[j]) continue;          // padding, or not the last copy of its bin
-				uint32_t e_c = 1;
-				if (!pf[j]) {          // a run of copies ends here
-					const uint32_t begin = run ? t0 + run - 1 : lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (run == 0: it began before the round)
-					e_c = t0 + tl + j - begin + 1;
+			for (uint32_t u = 0; u < 4; u++) {
+				const uint32_t t = t0 + 256 * u + 4 * lane;
+				a[u] = make_uint4(nbins, nbins, nbins, nbins);
+				b[u] = a[u];
+				if (t < nc_pad) a[u] = *reinterpret_cast<const uint4*>(P + t);
+				if (t < nq_pad) b[u] = *reinterpret_cast<const uint4*>(rq + t);
+			}
+			const uint32_t before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
+			uint32_t warm = 0;
+			if (has_next && !(item_n.y & kRiMultiFlag)) {          // the next item's 4 KiB of ranks: 64 lines, one dword each
+				const uint32_t tn = item_n.y * kRiRound + 16 * lane;
+				if (tn < mt_n.n) {
+					const uint32_t* pw = c_rk + mt_n.off + tn;
+					asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(pw) : "memory");
 				}
-				const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;
-				const uint32_t e_q = two < 3 ? two : e_q_of(bin);
-				prod += (uint64_t)e_c * e_q;
-				mins += e_c < e_q ? e_c : e_q;
-				if constexpr (DIV) {
-					const uint32_t ca = e_c + 1, cb = e_q + 1;          // the bin's counts in the candidate and in the query
-					const bool plain = ca == 2 && cb <= 2;
-					c01 += plain && cb == 1 ? 1u : 0u;
-					c02 += plain && cb == 2 ? 1u : 0u;
-					if (!plain) {
-						if (cb < 8) atomicAdd(&s_cnt[wave][(ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);          // (row 7: counted as held, evaluated here)
-						if (ca >= 9 || cb >= 8) {
-							const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
-							RkDivTerm lo = t11;
-							if (cb >= 8) lo = rk_div_term_call(1, cb, cm, qm, order);          // (the finish adds F(1, b) for every such bin of the query)
-							xjd += hi.jd - lo.jd;
-							xjs += hi.js - lo.js;
+			}
+			// the padding behind the list's end reads as ONE first copy of a bin the query does not hold (4^k: the zero word behind the table)
+			const uint32_t walked = T - t0 >= kRiRound ? kRiRound : (T - t0 + 255u) & ~255u;
+			spurious = nc < t0 + walked ? 1u : 0u;
+			uint32_t pk = 0;          // 6-bit counters: [6] first copies with e_q = 0, [12] = 1, [18] = 2, [24] three and more ([0]: further copies)
+#pragma unroll
+			for (uint32_t u = 0; u < 4; u++) {
+				if (t0 + 256 * u >= T) break;
+				const uint4 av = a[u], bv = b[u];
+				uint32_t d = sad_u32(av.x, bv.x, 0u);
+				d = sad_u32(av.y, bv.y, d);
+				d = sad_u32(av.z, bv.z, d);
+				d = sad_u32(av.w, bv.w, d);
+				emd += d;
+				uint32_t prev = lane_prev(av.w);
+				if (lane == 0) prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)a[u ? u - 1 : 0].w, 63) : before_round;
+				const uint32_t e4[4] = {av.x, av.y, av.z, av.w};
+				const uint32_t p4[4] = {prev, av.x, av.y, av.z};
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const uint32_t bin = e4[j];
+					const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2u * (bin & 15u), 2u);
+					const uint32_t code = bin != p4[j] ? two * 6u + 6u : 0u;
+					pk += 1u << code;
+					if (code == 24u) {          // rare: the first copy of a bin the query holds three times and more
+						const uint32_t e_q = e_q_of(bin);
+						prod += e_q;
+						mins += 1u;
+						if constexpr (DIV) {
+							const uint32_t cb = e_q + 1;
+							if (cb < 8) atomicAdd(&s_cnt[wave][cb], 1u);
+							else {          // (the finish adds F(1, b) for every such bin of the query)
+								const RkDivTerm hi = rk_div_term_call(2, cb, cm, qm, order), lo = rk_div_term_call(1, cb, cm, qm, order);
+								xjd += hi.jd - lo.jd;
+								xjs += hi.js - lo.js;
+							}
 						}
 					}
 				}
 			}
+			asm volatile("s_waitcnt vmcnt(0)" ::"v"(warm) : "memory");          // (the touch has landed; its register is free again)
+			pk_a = ((pk >> 6) & 63u) | (((pk >> 12) & 63u) << 16);
+			pk_b = (pk >> 18) & 63u;
+		} else {
+			// repeated bins [rd * kRiMulti, ..) of the candidate: four per lane
+			const uint2* M = c_rm + mt.moff;
+			const uint32_t j0 = rd * kRiMulti + 4 * lane;
+			uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
+			if (j0 < mt.nm) m0 = *reinterpret_cast<const uint4*>(M + j0);
+			if (j0 + 2 < mt.nm) m1 = *reinterpret_cast<const uint4*>(M + j0 + 2);
+			const uint32_t mb[4] = {m0.x, m0.z, m1.x, m1.z}, me[4] = {m0.y, m0.w, m1.y, m1.w};
+			RkDivTerm t11{0.0, 0.0};
+			if constexpr (DIV) {
+				const bool deep = (me[0] | me[1] | me[2] | me[3]) >= 8u;          // (an e_c of 8 and more somewhere: a spot term; zero for the lanes past the list)
+				if (__ballot(deep)) t11 = rk_div_term_call(1, 1, cm, qm, order);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				if (j0 + i >= mt.nm) break;
+				const uint32_t bin = mb[i], e_c = me[i];
+				const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2u * (bin & 15u), 2u);
+				const uint32_t e_q = two < 3 ? two : e_q_of(bin);
+				prod += (uint64_t)(e_c - 1u) * e_q;
+				mins += (e_c < e_q ? e_c : e_q) - (e_q ? 1u : 0u);
+				if constexpr (DIV) {
+					const uint32_t ca = e_c + 1, cb = e_q + 1;          // the bin's counts in the candidate and in the query
+					if (cb < 8) {
+						// out of cell (1 copy, cb), into cell (e_c copies, cb); [row 7: counted as held, evaluated here]
+						if (cb <= 2) pk_a += cb == 1 ? 1u : 0x10000u;
+						else atomicAdd(&s_cnt[wave][cb], 0xffffffffu);
+						if (ca == 3 && cb <= 2) pk_b += cb == 1 ? 1u : 0x10000u;
+						else atomicAdd(&s_cnt[wave][(ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);
+						if (ca >= 9) {
+							const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
+							xjd += hi.jd - t11.jd;
+							xjs += hi.js - t11.js;
+						}
+					} else {
+						const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order), lo = rk_div_term_call(2, cb, cm, qm, order);
+						xjd += hi.jd - lo.jd;
+						xjs += hi.js - lo.js;
+					}
+				}
+			}
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::"v"(warm) : "memory");          // (the touch has landed; its register is free again)
-		const uint64_t emd_t = wave_sum_u64(emd), prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
+		const uint32_t ta = wave_total_u32(pk_a), tb = wave_total_u32(pk_b);
+		uint64_t prod_t = 0, mins_t = 0;
+		if (__ballot(prod != 0 || mins != 0)) { prod_t = wave_sum_u64(prod); mins_t = wave_sum_u64(mins); }
+		int32_t v1, v2, v3 = 0, v9 = 0, v10 = 0;          // what the counters add to cells (0, 1), (0, 2), (0, 3), (1, 1), (1, 2)
+		if (!multi) {
+			const uint32_t c01 = (ta & 0xffffu) - spurious, c02 = ta >> 16, c03 = tb;
+			v1 = (int32_t)c01; v2 = (int32_t)c02; v3 = (int32_t)c03;
+			prod_t += c02 + 2 * (uint64_t)c03;
+			mins_t += c02 + c03;
+		} else {
+			v1 = -(int32_t)(ta & 0xffffu); v2 = -(int32_t)(ta >> 16);
+			v9 = (int32_t)(tb & 0xffffu); v10 = (int32_t)(tb >> 16);
+		}
+		if (!multi) {
+			const uint64_t emd_t = wave_sum_u64(emd);
+			if (lane == 0) atomicAdd(&acc[4 * (uint64_t)c], (unsigned long long)emd_t);
+		}
 		if (lane == 0) {
-			atomicAdd(&acc[4 * (uint64_t)c], (unsigned long long)emd_t);
-			atomicAdd(&acc[4 * (uint64_t)c + 1], (unsigned long long)prod_t);
-			atomicAdd(&acc[4 * (uint64_t)c + 2], (unsigned long long)mins_t);
+			if (prod_t) atomicAdd(&acc[4 * (uint64_t)c + 1], (unsigned long long)prod_t);
+			if (mins_t) atomicAdd(&acc[4 * (uint64_t)c + 2], (unsigned long long)mins_t);
 		}
 		if constexpr (DIV) {
-			const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
 			wave_sum_f64_pair(xjd, xjs);
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			uint32_t v = s_cnt[wave][lane];
 			s_cnt[wave][lane] = 0u;
-			if (lane == 1) v += c01_t;
-			if (lane == 2) v += c02_t;
+			if (lane == 1) v += (uint32_t)v1;
+			if (lane == 2) v += (uint32_t)v2;
+			if (lane == 3) v += (uint32_t)v3;
+			if (lane == 9) v += (uint32_t)v9;
+			if (lane == 10) v += (uint32_t)v10;
 			if (v) atomicAdd(&cells[(uint64_t)c * kRkCells + lane], v);
 			if (lane == 0) {
-				extras[2 * ((uint64_t)c * rounds + rd)] = xjd;
-				extras[2 * ((uint64_t)c * rounds + rd) + 1] = xjs;
+				const uint64_t slot = (uint64_t)c * 3 * rounds + (multi ? rounds + rd : rd);
+				extras[2 * slot] = xjd;
+				extras[2 * slot + 1] = xjs;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
@@ -721,24 +779,22 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 }
 
 // eight lanes per candidate: the integer record from the accumulators; DIV: the two sums from the cells (row a' = candidate count a' + 2,
-// row 7 = bins evaluated on the spot, counted as held), the query's counts of counts and the rounds' spot terms in round order
+// row 7 = bins evaluated on the spot, counted as held), the query's counts of counts and the items' spot terms in slot order (a candidate's
+// rounds, then its repeated-bin items)
 template <bool DIV>
 __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long long* __restrict__ acc, const uint32_t* __restrict__ cells, const double* __restrict__ extras, uint32_t rounds,
-                                                           const uint32_t* __restrict__ hq, const uint32_t* __restrict__ big, const uint32_t* __restrict__ c_n,
-                                                           const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first, uint32_t m,
+                                                           const uint32_t* __restrict__ hq, const uint32_t* __restrict__ big, const RkItemMeta* __restrict__ meta, uint32_t m,
                                                            const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order,
-                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard, int use_window, uint64_t min_len,
-                                                           uint64_t max_len) {
+                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard) {
 	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
 	const bool live = c < m;
 	const uint32_t cc = live ? c : m - 1;
-	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[cc] : first + cc;
-	const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)cc) * scalar_stride);
+	const RkItemMeta mt = meta[cc];
 	if (live && b == 0) {
 		const MscSparseHdr qh = *q_hdr_p;
-		const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = c_n[slot];
+		const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = mt.n;
 		// a list longer than the pass's bound: the host fails the call (a candidate the length window dropped took no round: any length)
-		const bool dropped = use_window && (cs->length < min_len || cs->length > max_len);
+		const bool dropped = mt.rounds == 0;
 		if ((!dropped && nc > (uint64_t)rounds * kRiRound) || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);
 		MscPartial out;
 		out.manh = nc + nq_tot - 2 * acc[4 * (uint64_t)c + 2];
@@ -747,7 +803,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 		partials[c] = out;
 	}
 	if constexpr (DIV) {
-		const double cm = (double)cs->mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+		const double cm = mt.mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
 		const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
 		const uint32_t* n = cells + (uint64_t)cc * kRkCells;
 		double jd = 0.0, js = 0.0;
@@ -770,7 +826,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 				}
 			}
 		}
-		{          // the query's bins with a count >= 8 and the rounds' spot terms, dealt over the eight lanes (lane b: entries b, b + 8, ..)
+		{          // the query's bins with a count >= 8 and the items' spot terms, dealt over the eight lanes (lane b: entries b, b + 8, ..)
 			const uint32_t n_big = hq[8];
 			for (uint32_t i = b; i < n_big; i += 8) {
 				const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
@@ -778,7 +834,9 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long l
 				js += f.js - t11.js;
 			}
 		}
-		for (uint32_t r = b; r < rounds; r += 8) { jd += extras[2 * ((uint64_t)cc * rounds + r)]; js += extras[2 * ((uint64_t)cc * rounds + r) + 1]; }
+		const double* x = extras + 2 * (uint64_t)cc * 3 * rounds;
+		for (uint32_t r = b; r < mt.rounds; r += 8) { jd += x[2 * r]; js += x[2 * r + 1]; }
+		for (uint32_t r = b; r < mt.mrounds; r += 8) { jd += x[2 * (rounds + r)]; js += x[2 * (rounds + r) + 1]; }
 #pragma unroll
 		for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
 		if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
@@ -862,26 +920,29 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 }
 
 // The pass over long lists: (candidate, round) items. rounds = rounds of kRiRound entries that cover the longest list involved (host
-// bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; acc: m x 4 uint64_t; dv (optional): the divergence scratch --
-// cells m x 64, extras m x rounds x 2 -- all zeroed here.
+// bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; acc_scratch: msc_ranks_items_acc_bytes -- [m x 4 accumulators]
+// [dv: m x 64 cells][64 bytes: the query's counts of counts, the number of items], cleared here by one command, then [dv: m x 3 rounds
+// spot-term slots] (every item writes its own); item_scratch: msc_ranks_items_list_bytes -- [m records][the items]. Of dv the launch
+// takes big, q_scalars, order and div_out.
 uint32_t msc_ranks_items_round() { return kRiRound; }
-hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
-                                       const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                       int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds,
-                                       unsigned long long* acc, const MscRankDiv* dv, uint64_t q_kmers, uint32_t* guard, void* item_scratch, size_t zero_bytes) {
+size_t msc_ranks_items_acc_bytes(uint64_t m, uint32_t rounds, bool div) { return m * 32 + (div ? m * 256 + m * 3 * (size_t)rounds * 16 : 0) + 64; }
+size_t msc_ranks_items_list_bytes(uint64_t m, uint32_t rounds) { return m * sizeof(RkItemMeta) + m * 3 * (size_t)rounds * sizeof(uint2) + 64; }
+hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const void* c_rm, const uint64_t* c_rm_off,
+                                       const uint32_t* c_rm_n, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
+                                       const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
+                                       MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* acc_scratch, const MscRankDiv* dv, uint64_t q_kmers,
+                                       uint32_t* guard, void* item_scratch) {
 	if (m == 0) return hipSuccess;
-	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc || rounds == 0) return hipErrorInvalidValue;
+	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc_scratch || !item_scratch || !c_rm || rounds == 0) return hipErrorInvalidValue;
 	const size_t lds = (nbins / 16 + 1 + 4) * 4;
-	// acc, and the divergence scratch behind it when the caller laid them out in one piece (zero_bytes: from acc on), are cleared in ONE command
-	hipError_t e = hipMemsetAsync(acc, 0, zero_bytes ? zero_bytes : (size_t)m * 4 * sizeof(unsigned long long), st);
+	uint8_t* zb = (uint8_t*)acc_scratch;
+	unsigned long long* acc = (unsigned long long*)zb;
+	uint32_t* cells = dv ? (uint32_t*)(zb + (size_t)m * 32) : nullptr;
+	uint32_t* tail = (uint32_t*)(zb + (size_t)m * 32 + (dv ? (size_t)m * 256 : 0));
+	uint32_t *hq = dv ? tail : nullptr, *n_items = tail + 12;
+	double* extras = dv ? (double*)(tail + 16) : nullptr;
+	hipError_t e = hipMemsetAsync(zb, 0, (size_t)((uint8_t*)(tail + 16) - zb), st);
 	if (e != hipSuccess) return e;
-	if (dv && !zero_bytes) {
-		if ((e = hipMemsetAsync(dv->cells, 0, (size_t)m * kRkCells * sizeof(uint32_t), st)) != hipSuccess) return e;
-		if ((e = hipMemsetAsync(dv->extras, 0, (size_t)m * rounds * 2 * sizeof(double), st)) != hipSuccess) return e;
-		if ((e = hipMemsetAsync(dv->hq, 0, 16 * sizeof(uint32_t), st)) != hipSuccess) return e;
-	}
-	k_rank_query_prep<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard, dv ? dv->hq : nullptr,
-	                                                  dv ? dv->big : nullptr);
 	static bool attr_set = false;
 	if (!attr_set) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
@@ -889,29 +950,36 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	// item_scratch: [the number of items (16 bytes)][m records of 16 bytes][m x rounds items of 8 bytes]
-	if (!item_scratch) return hipErrorInvalidValue;
-	uint32_t* n_items = (uint32_t*)item_scratch;
-	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>((uint8_t*)item_scratch + 16);
-	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + 16 + (size_t)m * sizeof(RkItemMeta));
-	k_rank_items_list<<<dim3(1), dim3(1024), 0, st>>>(meta, m, n_items, items_list, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, q_cum, q_hdr, use_window, min_len, max_len);
-	const uint64_t items = (uint64_t)m * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
-	// (the divergence form takes 128 registers: sixteen waves of it fill a CU's register file, so one workgroup per CU -- a second one
-	// would only queue behind the first and pay its set-up again)
+	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>(item_scratch);
+	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + (size_t)m * sizeof(RkItemMeta));
+	k_rank_pass_prep<<<dim3(8 + (m + 1023) / 1024), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard, hq,
+	                                                                      dv ? dv->big : nullptr, meta, m, n_items, items_list, c_off, c_n, c_rm_off, c_rm_n, cand_scalars, scalar_stride,
+	                                                                      cand_slots, first, use_window, min_len, max_len);
+	const uint64_t items = (uint64_t)m * 3 * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
+	// (one workgroup of the divergence form per CU, as measured with the r04 walk; MSC_RANKS_ITEMS_PER_CU)
 	static const uint32_t per_cu_env = [] { const char* e = getenv("MSC_RANKS_ITEMS_PER_CU"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
 	const uint32_t per_cu = per_cu_env ? per_cu_env : dv ? 1u : (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
 	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
-	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                             (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, dv->cells, dv->extras, dv->q_scalars, dv->order,
-	                                                                             meta, items_list, n_items);
-	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,
-	                                                                          (uint32_t)nbins, use_window, min_len, max_len, q_scratch, rounds, acc, nullptr, nullptr, nullptr, 0,
-	                                                                          meta, items_list, n_items);
+	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rounds, acc, cells, extras,
+	                                                                             dv->q_scalars, dv->order, meta, items_list, n_items);
+	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rounds, acc, nullptr, nullptr,
+	                                                                          nullptr, 0, meta, items_list, n_items);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	const dim3 fgrid((unsigned)(((uint64_t)m * 8 + 255) / 256));
-	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, dv->cells, dv->extras, rounds, dv->hq, dv->big, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
-	                                                                dv->q_scalars, dv->order, partials, dv->div_out, guard, use_window, min_len, max_len);
-	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(acc, nullptr, nullptr, rounds, nullptr, nullptr, c_n, cand_scalars, scalar_stride, cand_slots, first, m, q_cum, q_hdr,
-	                                                             nullptr, 0, partials, nullptr, guard, use_window, min_len, max_len);
+	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, cells, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
+	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(acc, nullptr, nullptr, rounds, nullptr, nullptr, meta, m, q_cum, q_hdr, nullptr, 0, partials, nullptr, guard);
+	return hipGetLastError();
+}
+
+// the repeated-bin lists of a sparse set: sizes (n: capacity words) and offsets (off: capacity + 1 words, lists padded to four entries); the caller reads off[capacity], allocates, fills
+hipError_t msc_launch_rank_multi_sizes(hipStream_t st, const void* ent, const MscSparseHdr* hdr, uint64_t capacity, uint32_t* n, uint64_t* off) {
+	if (capacity == 0) return hipSuccess;
+	k_rkm_sizes<<<dim3((unsigned)((capacity + 3) / 4)), dim3(256), 0, st>>>((const uint2*)ent, hdr, capacity, n);
+	k_rkl_scan<<<dim3(1), dim3(1024), 0, st>>>(n, capacity, off);
+	return hipGetLastError();
+}
+hipError_t msc_launch_rank_multi_fill(hipStream_t st, const void* ent, const MscSparseHdr* hdr, uint64_t capacity, const uint64_t* off, void* out) {
+	if (capacity == 0) return hipSuccess;
+	k_rkm_fill<<<dim3((unsigned)((capacity + 3) / 4)), dim3(256), 0, st>>>((const uint2*)ent, hdr, capacity, off, (uint2*)out);
 	return hipGetLastError();
 }
