@@ -164,6 +164,8 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->kb_anib);
 	release(ctx->rk_q);
 	release(ctx->rk_acc);
+	release(ctx->rk_counters);
+	release(ctx->rk_tables);
 	release(ctx->rk_items);
 	release(ctx->rk_cells);
 	release(ctx->rk_extras);
@@ -1684,7 +1686,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		pass_kmers = std::min(pass_kmers, std::max(rq.max_len, q_len));
 	}
 	const uint64_t pass_rounds = (pass_kmers + msc_ranks_items_round() - 1) / msc_ranks_items_round();
-	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (400 + pass_rounds * 72) <= (2048ull << 20);
+	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (64 + pass_rounds * 3 * 280) <= (2048ull << 20);
 	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
 	bool rank_items = false;
 	uint32_t rank_rounds = 0;
@@ -1728,8 +1730,19 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, ctx->pin_up.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	}
-	// (long lists: accumulators, cells, the query's counts and the items' spot-term slots sit in ONE buffer, its head cleared by one command per pass)
-	if (rank_items && ((r = ensure(ctx, ctx->rk_acc, msc_ranks_items_acc_bytes(chunk, rank_rounds, rank_div))) || (r = ensure(ctx, ctx->rk_items, msc_ranks_items_list_bytes(chunk, rank_rounds))))) return r;
+	// (long lists: a record and a spot-term slot per item, nothing to clear; the pass's counters in two sets used in turn, each pass clearing the other's)
+	if (rank_items) {
+		if ((r = ensure(ctx, ctx->rk_acc, msc_ranks_items_rec_bytes(chunk, rank_rounds))) || (r = ensure(ctx, ctx->rk_items, msc_ranks_items_list_bytes(chunk, rank_rounds)))) return r;
+		if (!ctx->rk_counters.p) {
+			if ((r = ensure(ctx, ctx->rk_counters, 32 * sizeof(uint32_t)))) return r;
+			HIP_TRY(ctx, hipMemsetAsync(ctx->rk_counters.p, 0, 32 * sizeof(uint32_t), ctx->stream));
+		}
+		if (ctx->rk_table_words != msc_ranks_items_table_words(L.nbins)) {          // (another k: both sets start out zero again)
+			ctx->rk_table_words = msc_ranks_items_table_words(L.nbins);
+			if ((r = ensure(ctx, ctx->rk_tables, 2 * (size_t)ctx->rk_table_words * sizeof(uint32_t)))) return r;
+			HIP_TRY(ctx, hipMemsetAsync(ctx->rk_tables.p, 0, 2 * (size_t)ctx->rk_table_words * sizeof(uint32_t), ctx->stream));
+		}
+	}
 	if (rank_div) {
 		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * std::max<uint32_t>(1, rank_rounds) * 2 * sizeof(double))) ||
 		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
@@ -1776,7 +1789,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, c_sp->rkm, c_sp->rkm_off, c_sp->rkm_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride),
 			                                         cs->scalar_stride, d_slots, off, mc, q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len,
 			                                         (MscPartial*)ctx->partials.p, ctx->num_cus, (uint32_t*)ctx->rk_q.p, rank_rounds, ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard,
-			                                         ctx->rk_items.p));
+			                                         ctx->rk_items.p, (uint32_t*)ctx->rk_counters.p, (uint32_t*)ctx->rk_tables.p, ctx->rk_turn++));
 		} else if (lists && rank_pass) {
 			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,

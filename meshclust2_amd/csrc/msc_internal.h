@@ -228,13 +228,14 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
                                      int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch, const MscRankDiv* dv = nullptr);
 uint64_t msc_ranks_pass_query_scratch(uint64_t q_kmers);
 uint32_t msc_ranks_items_round();
-size_t msc_ranks_items_acc_bytes(uint64_t m, uint32_t rounds, bool div);          // the pass's accumulators, cells, counts and spot-term slots
+size_t msc_ranks_items_rec_bytes(uint64_t m, uint32_t rounds);                   // the pass's records and spot-term slots, one per item
 size_t msc_ranks_items_list_bytes(uint64_t m, uint32_t rounds);                  // ... its candidates' records and its list of items
 hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const void* c_rm, const uint64_t* c_rm_off,
                                        const uint32_t* c_rm_n, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                        const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
-                                       MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* acc_scratch, const MscRankDiv* dv, uint64_t q_kmers,
-                                       uint32_t* guard, void* item_scratch);
+                                       MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* rec_scratch, const MscRankDiv* dv, uint64_t q_kmers,
+                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn);
+uint32_t msc_ranks_items_table_words(uint64_t nbins);
 // the repeated-bin lists of a sparse set (bin, count - 1 for the bins counted twice and more), beside its rank lists
 hipError_t msc_launch_rank_multi_sizes(hipStream_t st, const void* ent, const MscSparseHdr* hdr, uint64_t capacity, uint32_t* n, uint64_t* off);
 hipError_t msc_launch_rank_multi_fill(hipStream_t st, const void* ent, const MscSparseHdr* hdr, uint64_t capacity, const uint64_t* off, void* out);

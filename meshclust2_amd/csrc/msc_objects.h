@@ -31,7 +31,11 @@ struct msc_ctx {
 	DevBuf partials, pair_out, flags, reduce_out, slots, raw, singles, combos, packed, seg_seq, seg_start, kmer_off, nat, model_tmp,
 	    floor_sum, mean, div_tables, div_partials, qslots, soa_sum, soa_csum, soa_close, err_word, seq_seg, seq_ids, seq_meta;
 	DevBuf rk_items;                       // ... its list of (candidate, round) items
-	DevBuf rk_acc;                         // ... of its long-list form: a candidate's integer accumulators (k_pair_ranks_items)
+	DevBuf rk_acc;                         // ... of its long-list form: a record and a spot-term slot per item (k_pair_ranks_items)
+	DevBuf rk_counters;                    // ... 2 x 16 words: the query's counts of counts and the number of items, two sets used in turn
+	int rk_turn = 0;
+	DevBuf rk_tables;                      // ... the query's tables as the pass's workgroups copy them into LDS, two sets used in turn
+	uint32_t rk_table_words = 0;
 	DevBuf rk_cells, rk_extras, rk_hq, rk_big;          // ... and the scratch of its divergence form (MscRankDiv)
 	DevBuf rk_q;                           // the rank list of a pass's query when it is too long for LDS (msc_ranks_pass.hip)
 	uint32_t* rk_guard = nullptr;          // page-locked word the rank pass raises when a query's list is longer than its set's bound (msc_ranks_pass.hip)

@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) k_rkm_fill(const uint2* __restrict__ ent,
 // written out -- the pass then walks real items only (with the host's bound, rounds per candidate = that of the LONGEST list of the set: on
 // mixed lengths four items in five were empty, and finding that out cost a wave three dependent loads each). Any order will do (integer
 // atomics, a slot per item for what is FP64), so every workgroup claims its candidates' places with one atomic.
-struct RkItemMeta { uint64_t off, moff; double mag; uint32_t n, nm, rounds, mrounds; };
+struct RkItemMeta { uint64_t off, moff; double mag; uint32_t n, nm, rounds, mrounds, first, pad; };          // first: the candidate's place in the list of items
 // the query's side of a pass (k_rank_expand_one + k_rank_query_counts, blocks [0, 8)) and the list of items (the blocks behind them: a
 // candidate per thread) in one launch
 __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
@@ -485,7 +485,11 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
                                                          RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ n_items, uint2* __restrict__ items,
                                                          const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n, const uint64_t* __restrict__ m_off,
                                                          const uint32_t* __restrict__ m_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
-                                                         const uint32_t* __restrict__ cand_slots, uint64_t first, int use_window, uint64_t min_len, uint64_t max_len) {
+                                                         const uint32_t* __restrict__ cand_slots, uint64_t first, int use_window, uint64_t min_len, uint64_t max_len, uint32_t* __restrict__ zero_next,
+                                                         uint32_t* __restrict__ tab, uint32_t* __restrict__ tab_next, uint32_t tab_words, uint32_t* __restrict__ n_big3) {
+	if (blockIdx.x == 0 && threadIdx.x < 16) zero_next[threadIdx.x] = 0u;          // the counters of the NEXT pass (two sets, used in turn)
+	if (blockIdx.x < 8)          // ... and its tables
+		for (uint32_t i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < tab_words; i += 4 * 8 * blockDim.x) *reinterpret_cast<uint4*>(tab_next + i) = make_uint4(0u, 0u, 0u, 0u);
 	const MscSparseHdr h = *hdr_p;
 	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
 	if (blockIdx.x < 8) {
@@ -498,6 +502,18 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 			const uint2 en = ent[h.off + j];
 			const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
 			for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
+			// the query's histogram as the pass's workgroups will hold it in LDS: two bits per bin -- e_q = 0, 1, 2, "three and more" --
+			// and, behind them, a hash table of the few bins of the last kind (key = bin + 1: the tables start out zero)
+			if (e >= 1) atomicOr(&tab[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
+			if (e >= 3 && atomicAdd(n_big3, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
+				uint32_t *keys = tab + (tab_words - 2 * kRiHash), *vals = keys + kRiHash;
+				uint32_t hsh = (en.x * 2654435761u) >> 22;
+				for (;;) {
+					const uint32_t old = atomicCAS(&keys[hsh], 0u, en.x + 1u);
+					if (old == 0u || old == en.x + 1u) { vals[hsh] = e; break; }
+					hsh = (hsh + 1) & (kRiHash - 1);
+				}
+			}
 			if (hq) {
 #pragma unroll
 				for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
@@ -516,7 +532,7 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 	}
 	__shared__ uint32_t s_part[18];
 	const uint32_t c = (blockIdx.x - 8) * 1024 + threadIdx.x;
-	RkItemMeta mt{0, 0, 0.0, 0, 0, 0, 0};
+	RkItemMeta mt{0, 0, 0.0, 0, 0, 0, 0, 0, 0};
 	if (c < m) {
 		const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
@@ -529,7 +545,6 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 			mt.rounds = (T + kRiRound - 1) / kRiRound;
 			mt.mrounds = (mt.nm + kRiMulti - 1) / kRiMulti;
 		}
-		meta[c] = mt;
 	}
 	// the thread's place: a DPP scan per wave, one more over the sixteen wave totals, one atomic for the workgroup
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -547,6 +562,8 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 	}
 	__syncthreads();
 	uint32_t run = s_part[wave] + incl - mine;
+	mt.first = run;
+	if (c < m) meta[c] = mt;
 	for (uint32_t rd = 0; rd < mt.rounds; rd++) items[run + rd] = make_uint2(c, rd);
 	run += mt.rounds;
 	for (uint32_t rd = 0; rd < mt.mrounds; rd++) items[run + rd] = make_uint2(c, rd | kRiMultiFlag);
@@ -555,44 +572,22 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 template <bool DIV>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint2* __restrict__ c_rm, uint32_t m, const uint2* __restrict__ q_ent,
                                                                 const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, uint32_t nbins,
-                                                                const uint32_t* __restrict__ rq, uint32_t rounds, unsigned long long* __restrict__ acc, uint32_t* __restrict__ cells,
-                                                                double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta,
-                                                                const uint2* __restrict__ items, const uint32_t* __restrict__ n_items_p) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
-	__shared__ uint32_t s_key[kRiHash], s_val[kRiHash];
-	__shared__ uint32_t s_nbig;
+                                                                const uint32_t* __restrict__ rq, uint32_t* __restrict__ rec, double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta,
+                                                                const uint2* __restrict__ items, const uint32_t* __restrict__ cnt_p, const uint32_t* __restrict__ tab) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];          // [two bits per bin: nbins / 16 + 1 words, padded to four][hash keys][hash values]
 	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the item in hand, those no register counts
-	const uint32_t words = nbins / 16 + 1;
-	uint32_t* sb = s_rp;
+	const uint32_t words_pad = (nbins / 16 + 4) & ~3u;
+	uint32_t *sb = s_rp, *s_key = s_rp + words_pad, *s_val = s_key + kRiHash;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
-	const uint2* Q = q_ent + qh.off;
 	const uint32_t nq_tot = nq ? q_cum[qh.off + nq - 1] : 0u;
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
-	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = 0u;
-	for (uint32_t i = threadIdx.x; i < kRiHash; i += kRpBlock) s_key[i] = 0xffffffffu;
-	if (threadIdx.x == 0) s_nbig = 0;
-	__syncthreads();
-	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
-		const uint2 en = Q[j];
-		const uint32_t e = en.y ? en.y - 1u : 0u;
-		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
-		if (e >= 3 && atomicAdd(&s_nbig, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
-			uint32_t h = (en.x * 2654435761u) >> 22;
-			for (;;) {
-				const uint32_t old = atomicCAS(&s_key[h], 0xffffffffu, en.x);
-				if (old == 0xffffffffu || old == en.x) { s_val[h] = e; break; }
-				h = (h + 1) & (kRiHash - 1);
-			}
-		}
-	}
-	__syncthreads();
-	const bool hash_ok = s_nbig <= kRiHash / 2;
+	const bool hash_ok = cnt_p[13] <= kRiHash / 2;
 	auto e_q_of = [&](uint32_t bin) -> uint32_t {          // a bin the table marks "three and more"
 		if (hash_ok) {
 			uint32_t h = (bin * 2654435761u) >> 22;
-			while (s_key[h] != bin) h = (h + 1) & (kRiHash - 1);
+			while (s_key[h] != bin + 1u) h = (h + 1) & (kRiHash - 1);
 			return s_val[h];
 		}
 		const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
@@ -603,36 +598,20 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
 		s_cnt[wave][lane] = 0u;
 	}
-	const uint32_t n_items = *n_items_p;
+	const uint32_t n_items = cnt_p[12];
 	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
-	(void)m;
-	// Records of the items two ahead; and the candidate ranks of the NEXT item touched (one dword per 64-byte line) right behind this
-	// item's own loads, so that they come out of L2 when their turn comes.
-	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
-	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
-	RkItemMeta mt_n = meta[item_n.x];
-	uint2 item_n2 = it + n_waves < n_items ? items[it + n_waves] : make_uint2(0u, 0u);
-	RkItemMeta mt_n2 = meta[item_n2.x];
-	for (; it < n_items; it += n_waves) {
-		const uint2 item = item_n;
-		const RkItemMeta mt = mt_n;
-		item_n = item_n2; mt_n = mt_n2;
-		const bool has_next = it + n_waves < n_items;
-		if (it + 2 * n_waves < n_items) { item_n2 = items[it + 2 * n_waves]; mt_n2 = meta[item_n2.x]; }
-		const uint32_t c = item.x, rd = item.y & ~kRiMultiFlag;
-		const bool multi = (item.y & kRiMultiFlag) != 0;
-		const double cm = mt.mag;
-		uint64_t emd = 0, prod = 0;          // prod, mins: what the packed counters do not hold
-		uint32_t mins = 0;
-		uint32_t pk_a = 0, pk_b = 0;          // two pairs of 16-bit counters (see below)
-		double xjd = 0.0, xjs = 0.0;
-		uint32_t spurious = 0;
-		if (!multi) {
+	(void)m; (void)q_ent;
+	// The loop is laid out around the memory pipe's one counter (loads and the acknowledgements of atomics and stores are waited for in
+	// issue order): an item's loads go out BEFORE the flush of the item in front of it -- into the registers that item has just finished
+	// with --, so that the wait for them does not include the round trip of atomics that twenty waves aim at the same candidate; the list
+	// of items is read three ahead, the candidates' records two ahead (r05: with the wait for the next record at the loop's head, then the
+	// loads, then the flush, an item cost its wave 11 us whatever it held).
+	auto issue = [&](const uint2 item, const RkItemMeta& mt, uint4 (&a)[4], uint4 (&b)[4], uint32_t& before_round) {
+		const uint32_t rd = item.y & ~kRiMultiFlag;
+		if (!(item.y & kRiMultiFlag)) {
 			const uint32_t nc = mt.n, nc_pad = (nc + 3u) & ~3u;
-			const uint32_t T = nc > nq_tot ? nc : nq_tot;
 			const uint32_t t0 = rd * kRiRound;
 			const uint32_t* P = c_rk + mt.off;
-			uint4 a[4], b[4];
 #pragma unroll
 			for (uint32_t u = 0; u < 4; u++) {
 				const uint32_t t = t0 + 256 * u + 4 * lane;
@@ -641,15 +620,49 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 				if (t < nc_pad) a[u] = *reinterpret_cast<const uint4*>(P + t);
 				if (t < nq_pad) b[u] = *reinterpret_cast<const uint4*>(rq + t);
 			}
-			const uint32_t before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
-			uint32_t warm = 0;
-			if (has_next && !(item_n.y & kRiMultiFlag)) {          // the next item's 4 KiB of ranks: 64 lines, one dword each
-				const uint32_t tn = item_n.y * kRiRound + 16 * lane;
-				if (tn < mt_n.n) {
-					const uint32_t* pw = c_rk + mt_n.off + tn;
-					asm volatile("global_load_dword %0, %1, off" : "=v"(warm) : "v"(pw) : "memory");
-				}
-			}
+			before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
+		} else {          // repeated bins [rd * kRiMulti, ..) of the candidate: four per lane, (bin, e_c) each
+			const uint2* M = c_rm + mt.moff;
+			const uint32_t j0 = rd * kRiMulti + 4 * lane;
+			a[0] = make_uint4(0u, 0u, 0u, 0u);
+			a[1] = a[0];
+			if (j0 < mt.nm) a[0] = *reinterpret_cast<const uint4*>(M + j0);
+			if (j0 + 2 < mt.nm) a[1] = *reinterpret_cast<const uint4*>(M + j0 + 2);
+		}
+	};
+	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
+	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
+	uint2 item_n2 = it + n_waves < n_items ? items[it + n_waves] : make_uint2(0u, 0u);
+	uint2 item_n3 = it + 2 * n_waves < n_items ? items[it + 2 * n_waves] : make_uint2(0u, 0u);
+	RkItemMeta mt_n = meta[item_n.x];
+	RkItemMeta mt_n2 = meta[item_n2.x];
+	uint4 a[4], b[4];
+	uint32_t before_round = 0xffffffffu;
+	if (it < n_items) issue(item_n, mt_n, a, b, before_round);
+	// the query's tables, as k_rank_pass_prep left them in global memory (r05: every workgroup used to build them from the query's list -- 16 000
+	// clocks of a kernel of 47 000); the wave's first loads are on their way meanwhile
+	for (uint32_t i = 4 * threadIdx.x; i < words_pad + 2 * kRiHash; i += 4 * kRpBlock) *reinterpret_cast<uint4*>(s_rp + i) = *reinterpret_cast<const uint4*>(tab + i);
+	__syncthreads();
+	for (; it < n_items; it += n_waves) {
+		const uint2 item = item_n;
+		const RkItemMeta mt = mt_n;
+		item_n = item_n2; mt_n = mt_n2; item_n2 = item_n3;
+		mt_n2 = meta[item_n2.x];          // (its item arrived an iteration ago)
+		if (it + 3 * n_waves < n_items) item_n3 = items[it + 3 * n_waves];
+		const bool has_next = it + n_waves < n_items;
+		const uint32_t rd = item.y & ~kRiMultiFlag;
+		const bool multi = (item.y & kRiMultiFlag) != 0;
+		const double cm = mt.mag;
+		uint32_t emd = 0;
+		uint64_t prod = 0;          // prod, mins: what the packed counters do not hold
+		uint32_t mins = 0;
+		uint32_t pk_a = 0, pk_b = 0;          // two pairs of 16-bit counters (see below)
+		double xjd = 0.0, xjs = 0.0;
+		uint32_t spurious = 0;
+		if (!multi) {
+			const uint32_t nc = mt.n;
+			const uint32_t T = nc > nq_tot ? nc : nq_tot;
+			const uint32_t t0 = rd * kRiRound;
 			// the padding behind the list's end reads as ONE first copy of a bin the query does not hold (4^k: the zero word behind the table)
 			const uint32_t walked = T - t0 >= kRiRound ? kRiRound : (T - t0 + 255u) & ~255u;
 			spurious = nc < t0 + walked ? 1u : 0u;
@@ -689,16 +702,11 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 					}
 				}
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::"v"(warm) : "memory");          // (the touch has landed; its register is free again)
 			pk_a = ((pk >> 6) & 63u) | (((pk >> 12) & 63u) << 16);
 			pk_b = (pk >> 18) & 63u;
 		} else {
-			// repeated bins [rd * kRiMulti, ..) of the candidate: four per lane
-			const uint2* M = c_rm + mt.moff;
 			const uint32_t j0 = rd * kRiMulti + 4 * lane;
-			uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
-			if (j0 < mt.nm) m0 = *reinterpret_cast<const uint4*>(M + j0);
-			if (j0 + 2 < mt.nm) m1 = *reinterpret_cast<const uint4*>(M + j0 + 2);
+			const uint4 m0 = a[0], m1 = a[1];
 			const uint32_t mb[4] = {m0.x, m0.z, m1.x, m1.z}, me[4] = {m0.y, m0.w, m1.y, m1.w};
 			RkDivTerm t11{0.0, 0.0};
 			if constexpr (DIV) {
@@ -734,112 +742,116 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 				}
 			}
 		}
+		if (has_next) issue(item_n, mt_n, a, b, before_round);          // the next item's loads, in front of this item's flush
 		const uint32_t ta = wave_total_u32(pk_a), tb = wave_total_u32(pk_b);
-		uint64_t prod_t = 0, mins_t = 0;
-		if (__ballot(prod != 0 || mins != 0)) { prod_t = wave_sum_u64(prod); mins_t = wave_sum_u64(mins); }
-		int32_t v1, v2, v3 = 0, v9 = 0, v10 = 0;          // what the counters add to cells (0, 1), (0, 2), (0, 3), (1, 1), (1, 2)
+		uint64_t prod_t = 0;
+		uint32_t mins_t = 0, emd_t = 0;
+		if (__ballot(prod != 0 || mins != 0)) { prod_t = wave_sum_u64(prod); mins_t = (uint32_t)wave_sum_u64(mins); }
+		uint32_t v1, v2, v3 = 0, v9 = 0, v10 = 0;          // what the counters add to cells (0, 1), (0, 2), (0, 3), (1, 1), (1, 2) (modulo 2^32: the repeated bins take away)
 		if (!multi) {
 			const uint32_t c01 = (ta & 0xffffu) - spurious, c02 = ta >> 16, c03 = tb;
-			v1 = (int32_t)c01; v2 = (int32_t)c02; v3 = (int32_t)c03;
+			v1 = c01; v2 = c02; v3 = c03;
 			prod_t += c02 + 2 * (uint64_t)c03;
 			mins_t += c02 + c03;
+			emd_t = wave_total_u32((uint32_t)emd);          // (a round's sum: < 2^28)
 		} else {
-			v1 = -(int32_t)(ta & 0xffffu); v2 = -(int32_t)(ta >> 16);
-			v9 = (int32_t)(tb & 0xffffu); v10 = (int32_t)(tb >> 16);
+			v1 = 0u - (ta & 0xffffu); v2 = 0u - (ta >> 16);
+			v9 = tb & 0xffffu; v10 = tb >> 16;
 		}
-		if (!multi) {
-			const uint64_t emd_t = wave_sum_u64(emd);
-			if (lane == 0) atomicAdd(&acc[4 * (uint64_t)c], (unsigned long long)emd_t);
-		}
-		if (lane == 0) {
-			if (prod_t) atomicAdd(&acc[4 * (uint64_t)c + 1], (unsigned long long)prod_t);
-			if (mins_t) atomicAdd(&acc[4 * (uint64_t)c + 2], (unsigned long long)mins_t);
-		}
+		// The item's RECORD, 64 words, one per lane, at the item's place in the list: the cell counts (r, b) at r * 8 + b -- b = 0 is no cell:
+		// words 0, 8, 16, 24 hold the round's emd, the two halves of sum e_c e_q, sum min(e_c, e_q). No atomics: until r05 the items of a
+		// candidate added into ITS accumulators and cells, twenty waves at the same words at the same time, and that wait was half the kernel.
+		uint32_t v = 0;
 		if constexpr (DIV) {
 			wave_sum_f64_pair(xjd, xjs);
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
-			uint32_t v = s_cnt[wave][lane];
+			v = s_cnt[wave][lane];
 			s_cnt[wave][lane] = 0u;
-			if (lane == 1) v += (uint32_t)v1;
-			if (lane == 2) v += (uint32_t)v2;
-			if (lane == 3) v += (uint32_t)v3;
-			if (lane == 9) v += (uint32_t)v9;
-			if (lane == 10) v += (uint32_t)v10;
-			if (v) atomicAdd(&cells[(uint64_t)c * kRkCells + lane], v);
-			if (lane == 0) {
-				const uint64_t slot = (uint64_t)c * 3 * rounds + (multi ? rounds + rd : rd);
-				extras[2 * slot] = xjd;
-				extras[2 * slot + 1] = xjs;
-			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 			__builtin_amdgcn_wave_barrier();
+		}
+		v += lane == 1 ? v1 : lane == 2 ? v2 : lane == 3 ? v3 : lane == 9 ? v9 : lane == 10 ? v10 : 0u;
+		v = lane == 0 ? emd_t : lane == 8 ? (uint32_t)prod_t : lane == 16 ? (uint32_t)(prod_t >> 32) : lane == 24 ? mins_t : v;
+		rec[(uint64_t)it * kRkCells + lane] = v;
+		if constexpr (DIV) {
+			if (lane == 0) *reinterpret_cast<double2*>(extras + 2 * (uint64_t)it) = make_double2(xjd, xjs);
 		}
 	}
 }
 
-// eight lanes per candidate: the integer record from the accumulators; DIV: the two sums from the cells (row a' = candidate count a' + 2,
-// row 7 = bins evaluated on the spot, counted as held), the query's counts of counts and the items' spot terms in slot order (a candidate's
-// rounds, then its repeated-bin items)
+// A wave per candidate: lane l adds up word l of its items' records (rounds, then repeated-bin items, as the list holds them); the integer
+// record from words 0 / 8 / 16 / 24; DIV: lane (r, b) evaluates cell (r, b) -- row a' = candidate count a' + 2, row 7 = bins evaluated on
+// the spot, counted as held: its lanes take the query's bins with count b that the candidate does not hold --, the lanes of column 0 share
+// the query's bins with a count >= 8 and the items' spot terms (in list order); one butterfly adds the 64 partial sums in a fixed order.
 template <bool DIV>
-__global__ void __launch_bounds__(256) k_rank_items_finish(const unsigned long long* __restrict__ acc, const uint32_t* __restrict__ cells, const double* __restrict__ extras, uint32_t rounds,
-                                                           const uint32_t* __restrict__ hq, const uint32_t* __restrict__ big, const RkItemMeta* __restrict__ meta, uint32_t m,
-                                                           const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order,
-                                                           MscPartial* __restrict__ partials, double* __restrict__ div_out, uint32_t* __restrict__ guard) {
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
-	const bool live = c < m;
-	const uint32_t cc = live ? c : m - 1;
-	const RkItemMeta mt = meta[cc];
-	if (live && b == 0) {
-		const MscSparseHdr qh = *q_hdr_p;
-		const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = mt.n;
-		// a list longer than the pass's bound: the host fails the call (a candidate the length window dropped took no round: any length)
-		const bool dropped = mt.rounds == 0;
-		if ((!dropped && nc > (uint64_t)rounds * kRiRound) || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);
-		MscPartial out;
-		out.manh = nc + nq_tot - 2 * acc[4 * (uint64_t)c + 2];
-		out.dot = acc[4 * (uint64_t)c + 1] + nc + nq_tot;
-		out.emd = acc[4 * (uint64_t)c];
-		partials[c] = out;
+__global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __restrict__ rec, const double* __restrict__ extras, uint32_t rounds, const uint32_t* __restrict__ hq,
+                                                           const uint32_t* __restrict__ big, const RkItemMeta* __restrict__ meta, uint32_t m, const uint32_t* __restrict__ q_cum,
+                                                           const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order, MscPartial* __restrict__ partials,
+                                                           double* __restrict__ div_out, uint32_t* __restrict__ guard) {
+	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (c >= m) return;
+	const RkItemMeta mt = meta[c];
+	const uint32_t n_it = mt.rounds + mt.mrounds;
+	const uint32_t* R = rec + (uint64_t)mt.first * kRkCells + lane;
+	uint64_t sum = 0;
+	uint32_t s = 0;
+	for (; s + 4 <= n_it; s += 4) {
+		const uint32_t x0 = R[(uint64_t)s * kRkCells], x1 = R[(uint64_t)(s + 1) * kRkCells], x2 = R[(uint64_t)(s + 2) * kRkCells], x3 = R[(uint64_t)(s + 3) * kRkCells];
+		sum += (uint64_t)x0 + x1 + x2 + x3;
+	}
+	for (; s < n_it; s++) sum += R[(uint64_t)s * kRkCells];
+	{
+		const uint64_t emd = sum, p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
+		if (lane == 0) {
+			const MscSparseHdr qh = *q_hdr_p;
+			const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = mt.n;
+			// a list longer than the pass's bound: the host fails the call (a candidate the length window dropped took no round: any length)
+			const bool dropped = mt.rounds == 0;
+			if ((!dropped && nc > (uint64_t)rounds * kRiRound) || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);
+			MscPartial out;
+			out.manh = nc + nq_tot - 2 * mins;
+			out.dot = p_lo + (p_hi << 32) + nc + nq_tot;
+			out.emd = emd;
+			partials[c] = out;
+		}
 	}
 	if constexpr (DIV) {
 		const double cm = mt.mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
 		const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
-		const uint32_t* n = cells + (uint64_t)cc * kRkCells;
+		const uint32_t b = lane & 7, r = lane >> 3;
+		const uint32_t k = b ? (uint32_t)sum : 0u;          // the cell's count (modulo 2^32, as the items wrote it)
+		uint32_t held = k;                                  // the candidate's bins the query holds b - 1 times: the column's sum
+		held += __shfl_xor(held, 8, 64);
+		held += __shfl_xor(held, 16, 64);
+		held += __shfl_xor(held, 32, 64);
 		double jd = 0.0, js = 0.0;
-		if (b >= 1) {
-			uint32_t held = n[7 * 8 + b];
-			for (uint32_t r = 0; r < 7; r++) {
-				const uint32_t k = n[r * 8 + b];
-				if (!k) continue;
-				held += k;
-				const RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
-				jd += (double)k * (f.jd - t11.jd);
-				js += (double)k * (f.js - t11.js);
-			}
-			if (b >= 2) {          // the query's bins with count b that the candidate does not hold
-				const uint32_t k = hq[b] - held;
-				if (k) {
-					const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
-					jd += (double)k * (f.jd - t11.jd);
-					js += (double)k * (f.js - t11.js);
-				}
+		if (b >= 1 && r < 7 && k) {
+			const RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
+			jd = (double)k * (f.jd - t11.jd);
+			js = (double)k * (f.js - t11.js);
+		}
+		if (b >= 2 && r == 7) {          // the query's bins with count b that the candidate does not hold
+			const uint32_t kq = hq[b] - held;
+			if (kq) {
+				const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
+				jd = (double)kq * (f.jd - t11.jd);
+				js = (double)kq * (f.js - t11.js);
 			}
 		}
-		{          // the query's bins with a count >= 8 and the items' spot terms, dealt over the eight lanes (lane b: entries b, b + 8, ..)
+		if (b == 0) {          // column 0: lane r takes entries r, r + 8, .. of the query's counts >= 8 and of the items' spot terms
 			const uint32_t n_big = hq[8];
-			for (uint32_t i = b; i < n_big; i += 8) {
+			for (uint32_t i = r; i < n_big; i += 8) {
 				const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
 				jd += f.jd - t11.jd;
 				js += f.js - t11.js;
 			}
+			const double* x = extras + 2 * (uint64_t)mt.first;
+			for (uint32_t i = r; i < n_it; i += 8) { jd += x[2 * i]; js += x[2 * i + 1]; }
 		}
-		const double* x = extras + 2 * (uint64_t)cc * 3 * rounds;
-		for (uint32_t r = b; r < mt.rounds; r += 8) { jd += x[2 * r]; js += x[2 * r + 1]; }
-		for (uint32_t r = b; r < mt.mrounds; r += 8) { jd += x[2 * (rounds + r)]; js += x[2 * (rounds + r) + 1]; }
 #pragma unroll
-		for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
-		if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
+		for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
+		if (lane == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
 	}
 }
 
@@ -920,29 +932,30 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 }
 
 // The pass over long lists: (candidate, round) items. rounds = rounds of kRiRound entries that cover the longest list involved (host
-// bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; acc_scratch: msc_ranks_items_acc_bytes -- [m x 4 accumulators]
-// [dv: m x 64 cells][64 bytes: the query's counts of counts, the number of items], cleared here by one command, then [dv: m x 3 rounds
-// spot-term slots] (every item writes its own); item_scratch: msc_ranks_items_list_bytes -- [m records][the items]. Of dv the launch
-// takes big, q_scalars, order and div_out.
+// bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; rec_scratch: msc_ranks_items_rec_bytes -- a 64-word record and
+// a spot-term slot per item, nothing to clear; item_scratch: msc_ranks_items_list_bytes -- [m records][the items]; counters: 2 x 16 words,
+// zero at the first pass -- the passes use the two halves in turn (`turn`) and each clears the other's. Of dv the launch takes big,
+// q_scalars, order and div_out.
 uint32_t msc_ranks_items_round() { return kRiRound; }
-size_t msc_ranks_items_acc_bytes(uint64_t m, uint32_t rounds, bool div) { return m * 32 + (div ? m * 256 + m * 3 * (size_t)rounds * 16 : 0) + 64; }
+uint32_t msc_ranks_items_table_words(uint64_t nbins) { return (uint32_t)((nbins / 16 + 4) & ~3ull) + 2 * kRiHash; }          // one set of the query's tables (the caller holds two, zero at first)
+size_t msc_ranks_items_rec_bytes(uint64_t m, uint32_t rounds) { return m * 3 * (size_t)rounds * (kRkCells * sizeof(uint32_t) + 2 * sizeof(double)) + 64; }
 size_t msc_ranks_items_list_bytes(uint64_t m, uint32_t rounds) { return m * sizeof(RkItemMeta) + m * 3 * (size_t)rounds * sizeof(uint2) + 64; }
 hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const void* c_rm, const uint64_t* c_rm_off,
                                        const uint32_t* c_rm_n, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                        const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
-                                       MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* acc_scratch, const MscRankDiv* dv, uint64_t q_kmers,
-                                       uint32_t* guard, void* item_scratch) {
+                                       MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* rec_scratch, const MscRankDiv* dv, uint64_t q_kmers,
+                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn) {
 	if (m == 0) return hipSuccess;
-	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !acc_scratch || !item_scratch || !c_rm || rounds == 0) return hipErrorInvalidValue;
-	const size_t lds = (nbins / 16 + 1 + 4) * 4;
-	uint8_t* zb = (uint8_t*)acc_scratch;
-	unsigned long long* acc = (unsigned long long*)zb;
-	uint32_t* cells = dv ? (uint32_t*)(zb + (size_t)m * 32) : nullptr;
-	uint32_t* tail = (uint32_t*)(zb + (size_t)m * 32 + (dv ? (size_t)m * 256 : 0));
-	uint32_t *hq = dv ? tail : nullptr, *n_items = tail + 12;
-	double* extras = dv ? (double*)(tail + 16) : nullptr;
-	hipError_t e = hipMemsetAsync(zb, 0, (size_t)((uint8_t*)(tail + 16) - zb), st);
-	if (e != hipSuccess) return e;
+	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !rec_scratch || !item_scratch || !c_rm || !counters || !tables || rounds == 0) return hipErrorInvalidValue;
+	const uint32_t tab_words = msc_ranks_items_table_words(nbins);
+	const size_t lds = (size_t)tab_words * 4;
+	uint32_t *tab = tables + (size_t)tab_words * (turn & 1), *tab_next = tables + (size_t)tab_words * ((turn & 1) ^ 1);
+	const uint64_t items = (uint64_t)m * 3 * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
+	uint32_t* rec = (uint32_t*)rec_scratch;
+	double* extras = (double*)((uint8_t*)rec_scratch + items * kRkCells * sizeof(uint32_t));
+	uint32_t *tail = counters + 16 * (turn & 1), *tail_next = counters + 16 * ((turn & 1) ^ 1);
+	uint32_t *hq = tail, *n_items = tail + 12;
+	hipError_t e;
 	static bool attr_set = false;
 	if (!attr_set) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
@@ -952,22 +965,21 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	}
 	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>(item_scratch);
 	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + (size_t)m * sizeof(RkItemMeta));
-	k_rank_pass_prep<<<dim3(8 + (m + 1023) / 1024), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard, hq,
-	                                                                      dv ? dv->big : nullptr, meta, m, n_items, items_list, c_off, c_n, c_rm_off, c_rm_n, cand_scalars, scalar_stride,
-	                                                                      cand_slots, first, use_window, min_len, max_len);
-	const uint64_t items = (uint64_t)m * 3 * rounds;          // (at most: the grid is sized for the bound, the kernel walks the list)
-	// (one workgroup of the divergence form per CU, as measured with the r04 walk; MSC_RANKS_ITEMS_PER_CU)
+	k_rank_pass_prep<<<dim3(8 + (m + 1023) / 1024), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard,
+	                                                                      dv ? hq : nullptr, dv ? dv->big : nullptr, meta, m, n_items, items_list, c_off, c_n, c_rm_off, c_rm_n,
+	                                                                      cand_scalars, scalar_stride, cand_slots, first, use_window, min_len, max_len, tail_next, tab, tab_next, tab_words, tail + 13);
+	// (one workgroup of the divergence form per CU: sixteen waves of it fill a CU's register file; MSC_RANKS_ITEMS_PER_CU)
 	static const uint32_t per_cu_env = [] { const char* e = getenv("MSC_RANKS_ITEMS_PER_CU"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
 	const uint32_t per_cu = per_cu_env ? per_cu_env : dv ? 1u : (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
 	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
-	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rounds, acc, cells, extras,
-	                                                                             dv->q_scalars, dv->order, meta, items_list, n_items);
-	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rounds, acc, nullptr, nullptr,
-	                                                                          nullptr, 0, meta, items_list, n_items);
+	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rec, extras,
+	                                                                             dv->q_scalars, dv->order, meta, items_list, tail, tab);
+	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rec, nullptr, nullptr,
+	                                                                          0, meta, items_list, tail, tab);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	const dim3 fgrid((unsigned)(((uint64_t)m * 8 + 255) / 256));
-	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(acc, cells, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
-	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(acc, nullptr, nullptr, rounds, nullptr, nullptr, meta, m, q_cum, q_hdr, nullptr, 0, partials, nullptr, guard);
+	const dim3 fgrid((m + 3) / 4);
+	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(rec, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
+	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(rec, nullptr, rounds, nullptr, nullptr, meta, m, q_cum, q_hdr, nullptr, 0, partials, nullptr, guard);
 	return hipGetLastError();
 }
 
