@@ -167,9 +167,6 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	release(ctx->rk_counters);
 	release(ctx->rk_tables);
 	release(ctx->rk_items);
-	release(ctx->rk_cells);
-	release(ctx->rk_extras);
-	release(ctx->rk_hq);
 	release(ctx->rk_big);
 	release(ctx->kb_qT);
 	release(ctx->kb_hot);
@@ -1560,6 +1557,11 @@ bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err, bool eager 
 		*err = fail(ctx, MSC_ERR_HIP, "rank lists: fill failed");
 		return false;
 	}
+	s->rkl_off_host.resize(s->capacity + 1);
+	if (hipMemcpyAsync(s->rkl_off_host.data(), s->rkl_off, (s->capacity + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+		*err = fail(ctx, MSC_ERR_HIP, "rank lists: offsets read-back failed");
+		return false;
+	}
 	s->rkl_epoch = s->list_epoch;
 	return true;
 }
@@ -1674,7 +1676,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	// (which of the two rank kernels takes a pass is decided by the QUERY alone -- its stored bins, the same number on every rank of a sharded
 	// run and in a one-rank run -- never by a bound of the set or shard at hand: the two kernels add the divergence terms in different orders,
 	// and two identical sequences scored for one query must not come out one bit apart because they sit on different ranks)
-	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > 2000;          // (2 000: a wave of k_pair_ranks_1xm takes a whole candidate, fine up to a few rounds of 256 entries)
+	// r05: a pass that carries the divergence statistics takes the items kernel whatever the query's length (cfg5's shape, the 3 461 passes
+	// of short queries among 14 719: 22 us against 137 + 31 + 9 of k_pair_ranks_1xm's divergence form, its finish and the query's two
+	// preparation kernels); without them a short query's pass stays with k_pair_ranks_1xm (1 kb +- 100, 13 300 candidates per pass: 31 us
+	// against 35 + 10 + 6.5). (MSC_RANKS_ITEMS_FROM=n: the bound for both.)
+	static const int items_from = [] { const char* e = getenv("MSC_RANKS_ITEMS_FROM"); return e ? atoi(e) : -1; }();
+	const bool long_lists = q_sp && q_sp->hdr_host[rq.q_slot].nnz > (uint32_t)(items_from >= 0 ? items_from : need_div ? 0 : 2000);
 	// Rounds of 1 024 entries that cover the longest list THIS PASS can meet: a candidate the length window drops takes no
 	// round, so inside a window no list is longer than max_len k-mers (nor the query's own); only without a window does the set's bound
 	// count. One 50 Mb scaffold among short sequences used to size -- and clear, every step -- the accumulators of every pass for 50 000
@@ -1687,7 +1694,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	}
 	const uint64_t pass_rounds = (pass_kmers + msc_ranks_items_round() - 1) / msc_ranks_items_round();
 	const bool items_ok = getenv("MSC_NO_RANKS_ITEMS") == nullptr && c_kmers < (1ull << 26) && pass_rounds < (1ull << 26) && m * (64 + pass_rounds * 3 * 280) <= (2048ull << 20);
-	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && (!long_lists || items_ok));
+	const bool div_fits = !need_div || (!no_rank_div && rank_div_wanted && long_lists && items_ok);          // (only the items kernel carries the divergence statistics)
 	bool rank_items = false;
 	uint32_t rank_rounds = 0;
 	if (lists && div_fits && !rq.only_tiles && spk == SPK_MP && !no_rank_pass && q_kmers <= msc_ranks_pass_query_cap() && msc_ranks_pass_lds(L.nbins, q_kmers) != 0) {
@@ -1743,11 +1750,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			HIP_TRY(ctx, hipMemsetAsync(ctx->rk_tables.p, 0, 2 * (size_t)ctx->rk_table_words * sizeof(uint32_t), ctx->stream));
 		}
 	}
-	if (rank_div) {
-		if ((r = ensure(ctx, ctx->rk_cells, chunk * 64 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_extras, chunk * std::max<uint32_t>(1, rank_rounds) * 2 * sizeof(double))) ||
-		    (r = ensure(ctx, ctx->rk_hq, 16 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t))))
-			return r;
-	}
+	if (rank_div && (r = ensure(ctx, ctx->rk_big, ((size_t)q_sp->hdr_host[rq.q_slot].nnz + 1) * sizeof(uint32_t)))) return r;
 	if (need_div) {
 		if (!rank_div && (r = ensure(ctx, ctx->div_tables, chunk * (c_sp ? 256 : tb * tb) * 16)) != MSC_OK) return r;
 		if ((r = ensure(ctx, ctx->div_partials, chunk * (c_sp ? DVN : PS) * 16)) != MSC_OK) return r;
@@ -1785,16 +1788,15 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			ctx->prof_q_nnz += q_sp->hdr_host[rq.q_slot].nnz;
 		}
 		if (lists && rank_items) {
-			MscRankDiv dv{nullptr, nullptr, nullptr, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
+			MscRankDiv dv{(uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_items(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, c_sp->rkm, c_sp->rkm_off, c_sp->rkm_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride),
 			                                         cs->scalar_stride, d_slots, off, mc, q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len,
 			                                         (MscPartial*)ctx->partials.p, ctx->num_cus, (uint32_t*)ctx->rk_q.p, rank_rounds, ctx->rk_acc.p, rank_div ? &dv : nullptr, q_kmers, ctx->rk_guard,
-			                                         ctx->rk_items.p, (uint32_t*)ctx->rk_counters.p, (uint32_t*)ctx->rk_tables.p, ctx->rk_turn++));
+			                                         ctx->rk_items.p, (uint32_t*)ctx->rk_counters.p, (uint32_t*)ctx->rk_tables.p, ctx->rk_turn++,
+			                                         q_sp == c_sp && rq.q_slot < c_sp->capacity ? c_sp->rkl + c_sp->rkl_off_host[rq.q_slot] : nullptr));
 		} else if (lists && rank_pass) {
-			MscRankDiv dv{(uint32_t*)ctx->rk_cells.p, (double*)ctx->rk_extras.p, (uint32_t*)ctx->rk_hq.p, (uint32_t*)ctx->rk_big.p, q_scal, rq.order, (double*)ctx->div_partials.p};
 			HIP_TRY(ctx, msc_launch_pair_ranks_1xm(ctx->stream, c_sp->rkl, c_sp->rkl_off, c_sp->rkl_n, cs->scalars + (d_slots ? 0 : off * cs->scalar_stride), cs->scalar_stride, d_slots, off, mc,
-			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p,
-			                                       rank_div ? &dv : nullptr));
+			                                       q_sp->ent, q_sp->cum, q_sp->hdr + rq.q_slot, L.nbins, rq.use_window, rq.min_len, rq.max_len, (MscPartial*)ctx->partials.p, ctx->num_cus, q_kmers, ctx->rk_guard, (uint32_t*)ctx->rk_q.p));
 		} else if (lists) {
 			HIP_TRY(ctx, launch_sparse_pass(ctx, spk, c_sp, cs->scalars, cs->scalar_stride, d_slots, off, mc, q_sp, rq.q_slot, q_scal, L.nbins, rq.use_window, rq.min_len,
 			                                rq.max_len, (MscPartial*)ctx->partials.p, need_div ? ctx->div_tables.p : nullptr, need_div ? ctx->div_partials.p : nullptr, rq.order,

@@ -213,19 +213,16 @@ uint32_t msc_ranks_pass_query_cap();
 hipError_t msc_launch_rank_lists_sizes(hipStream_t st, const MscSparseHdr* hdr, const uint32_t* cum, uint64_t capacity, uint32_t* n, uint64_t* off);
 hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uint32_t* cum, const MscSparseHdr* hdr, uint64_t capacity, const uint32_t* n, const uint64_t* off,
                                       uint64_t nbins, uint32_t* out);
-// the divergence statistics of a rank pass (msc_ranks_pass.hip): scratch + where the {jd, js} record of each candidate goes
+// the divergence statistics of a long-list rank pass (msc_ranks_pass.hip): what the launch needs beside its own scratch
 struct MscRankDiv {
-	uint32_t* cells;            // [m][64] copies per cell (r, b)
-	double* extras;             // [m][2] what was evaluated on the spot
-	uint32_t* hq;               // [16] the query's bins per count (+ [8]: how many have a count >= 8)
 	uint32_t* big;              // [the query's stored bins] the counts >= 8
 	const uint8_t* q_scalars;   // the query's scalar record
 	int order;
-	double* div_out;            // [m][2]
+	double* div_out;            // [m][2] the {jd, js} record of each candidate
 };
 hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                      const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch, const MscRankDiv* dv = nullptr);
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch);
 uint64_t msc_ranks_pass_query_scratch(uint64_t q_kmers);
 uint32_t msc_ranks_items_round();
 size_t msc_ranks_items_rec_bytes(uint64_t m, uint32_t rounds);                   // the pass's records and spot-term slots, one per item
@@ -234,7 +231,7 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
                                        const uint32_t* c_rm_n, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                        const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
                                        MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* rec_scratch, const MscRankDiv* dv, uint64_t q_kmers,
-                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn);
+                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn, const uint32_t* q_rk);
 uint32_t msc_ranks_items_table_words(uint64_t nbins);
 // the repeated-bin lists of a sparse set (bin, count - 1 for the bins counted twice and more), beside its rank lists
 hipError_t msc_launch_rank_multi_sizes(hipStream_t st, const void* ent, const MscSparseHdr* hdr, uint64_t capacity, uint32_t* n, uint64_t* off);

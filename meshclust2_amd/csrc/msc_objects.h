@@ -36,7 +36,7 @@ struct msc_ctx {
 	int rk_turn = 0;
 	DevBuf rk_tables;                      // ... the query's tables as the pass's workgroups copy them into LDS, two sets used in turn
 	uint32_t rk_table_words = 0;
-	DevBuf rk_cells, rk_extras, rk_hq, rk_big;          // ... and the scratch of its divergence form (MscRankDiv)
+	DevBuf rk_big;                         // ... the query's counts of 8 and more, for the divergence statistics of the long-list pass (MscRankDiv)
 	DevBuf rk_q;                           // the rank list of a pass's query when it is too long for LDS (msc_ranks_pass.hip)
 	uint32_t* rk_guard = nullptr;          // page-locked word the rank pass raises when a query's list is longer than its set's bound (msc_ranks_pass.hip)
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
@@ -168,6 +168,7 @@ struct msc_hist_set {
 	mutable uint32_t* rkl = nullptr;
 	mutable uint64_t* rkl_off = nullptr;
 	mutable uint32_t* rkl_n = nullptr;
+	mutable std::vector<uint64_t> rkl_off_host;          // (mirror: a pass whose query is a slot of this set reads its list in place)
 	mutable uint64_t rkl_epoch = ~0ull, rkl_seen_epoch = ~0ull, rkl_entries = 0;
 	mutable uint32_t rkl_seen = 0;
 	mutable bool rkl_unavailable = false;

@@ -132,8 +132,10 @@ __global__ void __launch_bounds__(1024) k_rank_expand_one(const uint2* __restric
 // query's, so the sum is re-arranged by COPIES: the r-th copy (r = 0, 1, ..) of a bin whose count in the query is b contributes
 //     r = 0:  F(2, b)                      r >= 1:  F(r + 2, b) - F(r + 1, b)              with F(x, b) = term(x, b) - term(1, 1)
 // (they telescope to F(e_c + 1, b)), and the query's bins the candidate does not hold contribute F(1, b). The pass only COUNTS copies per
-// cell (r, b) -- integers: registers for the two cells that hold nearly everything, (0, 1) and (0, 2), LDS atomics for the rest, FP64 on
-// the spot for r >= 7 or b >= 8 -- and k_rank_div_finish evaluates each candidate's sums from its cell counts in one fixed order.
+// cell -- integers --, FP64 on the spot for counts of 9 and more in the candidate or 8 and more in the query, and k_rank_items_finish evaluates each
+// candidate's sums from its cell counts in one fixed order. (r05: the long-list pass counts BINS per cell (count in the candidate, count in the
+// query) -- every first copy as a bin held once, the candidate's repeated bins moved to their true cell from a list of their own; the
+// short-list kernel k_pair_ranks_1xm no longer carries a divergence form: such passes take the items kernel whatever their length.)
 struct RkDivTerm { double jd, js; };
 __device__ __forceinline__ RkDivTerm rk_div_term(uint32_t cand_count, uint32_t q_count, double cand_mag, double q_mag, int order) {          // = div_term_sp of sparse.hip
 	RkDivTerm t;
@@ -149,72 +151,6 @@ __device__ __noinline__ RkDivTerm rk_div_term_call(uint32_t cand_count, uint32_t
 	return rk_div_term(cand_count, q_count, cand_mag, q_mag, order);
 }
 constexpr uint32_t kRkCells = 64;          // cell (r, b) at r * 8 + b, r < 7 (7: unused), 1 <= b < 8 (0: unused)
-
-// the query's side of a divergence pass: hq[v] = its bins with count v (2 <= v < 8), hq[8] = the number of its bins with count >= 8 and
-// big[..] their counts (any order: the finish kernel adds them up per candidate in list order, the same for every candidate)
-__global__ void __launch_bounds__(1024) k_rank_query_counts(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr_p, uint32_t* __restrict__ hq, uint32_t* __restrict__ big) {
-	const MscSparseHdr h = *hdr_p;
-	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // (one atomic per wave and count: ten thousand adds to six addresses took 109 us)
-	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += gridDim.x * blockDim.x) {
-		const uint32_t v = ent[h.off + j].y;
-#pragma unroll
-		for (uint32_t x = 2; x < 8; x++) cnt[x] += v == x ? 1u : 0u;
-		if (v >= 8) big[atomicAdd(&hq[8], 1u)] = v;
-	}
-#pragma unroll
-	for (uint32_t x = 2; x < 8; x++) {
-		const uint32_t t = (uint32_t)wave_sum_u64(cnt[x]);
-		if ((threadIdx.x & 63) == 0 && t) atomicAdd(&hq[x], t);
-	}
-}
-
-// eight lanes per candidate, lane b = the cells of query count b (b = 0: the counts >= 8 of the query's own list): each lane adds its
-// column, the eight partial sums are added in a fixed tree -- a candidate's result does not depend on who its neighbours in the launch are
-__global__ void __launch_bounds__(256) k_rank_div_finish(const uint32_t* __restrict__ cells, const double* __restrict__ extras, const uint32_t* __restrict__ hq,
-                                                         const uint32_t* __restrict__ big, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
-                                                         const uint32_t* __restrict__ cand_slots, uint32_t m, const uint8_t* __restrict__ q_scalars, int order,
-                                                         double* __restrict__ div_out) {
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, c = g >> 3, b = g & 7;
-	const bool live = c < m;
-	const uint32_t cc = live ? c : m - 1;
-	const uint64_t slot = cand_slots ? (uint64_t)cand_slots[cc] : (uint64_t)cc;
-	const double cm = (double)reinterpret_cast<const MscSlotScalars*>(cand_scalars + slot * scalar_stride)->mag;
-	const double qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
-	const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
-	const uint32_t* n = cells + (uint64_t)cc * kRkCells;
-	double jd = 0.0, js = 0.0;
-	if (b >= 1) {
-		for (uint32_t r = 0; r < 7; r++) {
-			const uint32_t k = n[r * 8 + b];
-			if (!k) continue;
-			RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
-			if (r) { const RkDivTerm g2 = rk_div_term_call(r + 1, b, cm, qm, order); f.jd -= g2.jd; f.js -= g2.js; }
-			else { f.jd -= t11.jd; f.js -= t11.js; }
-			jd += (double)k * f.jd;
-			js += (double)k * f.js;
-		}
-		if (b >= 2) {          // the query's bins with count b that the candidate does not hold
-			const uint32_t k = hq[b] - n[b];
-			if (k) {
-				const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
-				jd += (double)k * (f.jd - t11.jd);
-				js += (double)k * (f.js - t11.js);
-			}
-		}
-	} else {
-		const uint32_t n_big = hq[8];
-		for (uint32_t i = 0; i < n_big; i++) {          // ... and those with count >= 8 (the pass took back the ones the candidate holds)
-			const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
-			jd += f.jd - t11.jd;
-			js += f.js - t11.js;
-		}
-		jd += extras[2 * (uint64_t)cc];
-		js += extras[2 * (uint64_t)cc + 1];
-	}
-#pragma unroll
-	for (int off = 4; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
-	if (live && b == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
-}
 
 // ------------------------------------------------------------------------------------------------ the pass
 // first index in the sorted list v[0 .. n) whose value is >= x
@@ -234,13 +170,12 @@ __device__ __forceinline__ uint32_t lower_bound_u32(Load v, uint32_t n, uint32_t
 // list's place and length arrived an iteration earlier), the place and length of candidate i + 2 are being fetched (its slot arrived an
 // iteration earlier) and the slot of candidate i + 3 is read from the window's list. Without that every candidate cost its wave a chain of
 // three dependent round trips plus one per 256 entries -- 5 us per candidate, 0.16 ms per 100 000 however short the lists.
-template <bool QG, bool DIV>
+template <bool QG>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __restrict__ c_rk, const uint64_t* __restrict__ c_off, const uint32_t* __restrict__ c_n,
                                                               const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride, const uint32_t* __restrict__ cand_slots, uint64_t first,
                                                               uint32_t m, const uint2* __restrict__ q_ent, const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p,
                                                               uint32_t nbins, int use_window, uint64_t min_len, uint64_t max_len, MscPartial* __restrict__ partials, uint32_t q_cap,
-                                                              uint32_t* __restrict__ guard, const uint32_t* __restrict__ q_ranks_g, uint32_t* __restrict__ cells,
-                                                              double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order) {
+                                                              uint32_t* __restrict__ guard, const uint32_t* __restrict__ q_ranks_g) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];
 	const uint32_t words = nbins / 16 + 1;
 	uint32_t* sb = s_rp;
@@ -248,7 +183,6 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	// read through L2 by every wave alike
 	uint32_t* rq_l = s_rp + ((words + 3u) & ~3u);          // 16-byte aligned
 	const uint32_t* rq = QG ? q_ranks_g : rq_l;
-	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of its candidate
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
@@ -276,13 +210,12 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	// stage 1: the slot of a candidate (identity without a slot list)
 	auto slot_of = [&](uint32_t c) -> uint64_t { return c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : ~0ull; };
 	// stage 2: where its rank list sits, how long it is, whether the length window keeps it (n = 0xffffffff: not scored)
-	struct Meta { uint64_t off; uint32_t n; uint64_t mag; };
+	struct Meta { uint64_t off; uint32_t n; };
 	auto meta_of = [&](uint32_t c, uint64_t slot) -> Meta {
-		Meta mt{0, 0xffffffffu, 0};
+		Meta mt{0, 0xffffffffu};
 		if (c >= m) return mt;
 		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
 		const uint64_t len = cs->length;
-		if constexpr (DIV) mt.mag = cs->mag;
 		mt.off = c_off[slot];
 		mt.n = c_n[slot];
 		if (use_window && (len < min_len || len > max_len)) mt.n = 0xffffffffu;
@@ -299,11 +232,6 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			if (t < n_pad) d[u] = *reinterpret_cast<const uint4*>(P + t);
 		}
 	};
-	double qm = 0.0;
-	if constexpr (DIV) {
-		qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
-		s_cnt[wave][lane] = 0u;
-	}
 	uint64_t slot2 = slot_of(c0 + 2 * tw);
 	Meta meta1 = meta_of(c0 + tw, slot_of(c0 + tw));
 	Meta meta0 = meta_of(c0, slot_of(c0));
@@ -321,10 +249,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			uint64_t emd = 0;
 			uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
 			uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
-			// DIV: copies per cell (r, b) -- see the note above k_rank_div_finish
-			uint32_t c01 = 0, c02 = 0, carry_x = 0xffffffffu, carry_y = 0xffffffffu, carry_z = 0xffffffffu;
-			double xjd = 0.0, xjs = 0.0;
-			const double cm = DIV ? (double)meta0.mag : 0.0;
+			uint32_t carry_x = 0xffffffffu, carry_y = 0xffffffffu, carry_z = 0xffffffffu;
 			auto chunk = [&](uint32_t t0, const uint4& a) {
 				const uint32_t t = t0 + 4 * lane;
 				uint4 b = make_uint4(nbins, nbins, nbins, nbins);
@@ -361,24 +286,10 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 					if (e_q >= 2) prod += e_q - 1;
 					uint32_t r = 0;
 					const bool real = bin < nbins;          // (not the padding behind the list's end)
-					if (real && !first_copy && (DIV || e_q >= 2)) {          // rare: a further copy of a bin: its copy index from the entries in front of it
+					if (real && !first_copy && e_q >= 2) {          // rare: a further copy of a bin: its copy index from the entries in front of it
 						for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
 						if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
 						if (r < e_q) mins += 1;
-					}
-					if constexpr (DIV) {
-						const uint32_t b = e_q + 1;          // the bin's count in the query
-						const bool plain = real && first_copy && b <= 2;
-						c01 += plain && b == 1 ? 1u : 0u;
-						c02 += plain && b == 2 ? 1u : 0u;
-						if (real && !plain) {          // rare: a further copy of a bin, or a bin the query holds more than once
-							if (r < 7 && b < 8) atomicAdd(&s_cnt[wave][r * 8 + b], 1u);
-							else {
-								const RkDivTerm hi = rk_div_term_call(r + 2, b, cm, qm, order), lo = rk_div_term_call(r + 1, b, cm, qm, order);
-								xjd += hi.jd - lo.jd;
-								xjs += hi.js - lo.js;
-							}
-						}
 					}
 				}
 			};
@@ -398,20 +309,6 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				out.dot = prod_t + nc + nq_tot;                          // sum (c q - 1) over the union of stored bins (the epilogue adds 4^k)
 				out.emd = emd_t;
 				partials[c] = out;
-			}
-			if constexpr (DIV) {
-				const uint32_t c01_t = (uint32_t)wave_sum_u64(c01), c02_t = (uint32_t)wave_sum_u64(c02);
-				wave_sum_f64_pair(xjd, xjs);
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				uint32_t v = s_cnt[wave][lane];
-				s_cnt[wave][lane] = 0u;
-				if (lane == 1) v += c01_t;
-				if (lane == 2) v += c02_t;
-				cells[(uint64_t)c * kRkCells + lane] = v;
-				if (lane == 0) { extras[2 * (uint64_t)c] = xjd; extras[2 * (uint64_t)c + 1] = xjs; }
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-				__builtin_amdgcn_wave_barrier();
 			}
 		}
 		meta0 = meta1;
@@ -441,6 +338,8 @@ constexpr uint32_t kRiRound = 1024;
 constexpr uint32_t kRiMulti = 256;          // entries of a candidate's repeated-bin list per item (at most 2 x rounds items: a repeated bin is two k-mers and more)
 constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the query's bins with e_q >= 3 (at most half are used)
 constexpr uint32_t kRiMultiFlag = 0x80000000u;
+constexpr uint32_t kRiListCands = 64;           // candidates per workgroup of k_rank_pass_prep's list part
+constexpr uint32_t kRiPrepBlocks = 32;          // workgroups of k_rank_pass_prep that take the query's side (one entry per thread for lists of up to 32 768 stored bins)
 
 // n[slot] = its stored bins with two and more counted k-mers (value >= 3: every bin starts at 1); one wave per slot
 __global__ void __launch_bounds__(256) k_rkm_sizes(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr, uint64_t capacity, uint32_t* __restrict__ n) {
@@ -478,8 +377,8 @@ __global__ void __launch_bounds__(256) k_rkm_fill(const uint2* __restrict__ ent,
 // mixed lengths four items in five were empty, and finding that out cost a wave three dependent loads each). Any order will do (integer
 // atomics, a slot per item for what is FP64), so every workgroup claims its candidates' places with one atomic.
 struct RkItemMeta { uint64_t off, moff; double mag; uint32_t n, nm, rounds, mrounds, first, pad; };          // first: the candidate's place in the list of items
-// the query's side of a pass (k_rank_expand_one + k_rank_query_counts, blocks [0, 8)) and the list of items (the blocks behind them: a
-// candidate per thread) in one launch
+// the query's side of a pass (its rank list when it has none in place, its counts of counts, its tables: blocks [0, kRiPrepBlocks)) and the list of
+// items (the blocks behind them) in one launch
 __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict__ ent, const uint32_t* __restrict__ cum, const MscSparseHdr* __restrict__ hdr_p, uint32_t nbins,
                                                          uint32_t* __restrict__ out, uint32_t cap, uint32_t* __restrict__ guard, uint32_t* __restrict__ hq, uint32_t* __restrict__ big,
                                                          RkItemMeta* __restrict__ meta, uint32_t m, uint32_t* __restrict__ n_items, uint2* __restrict__ items,
@@ -487,40 +386,58 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
                                                          const uint32_t* __restrict__ m_n, const uint8_t* __restrict__ cand_scalars, uint64_t scalar_stride,
                                                          const uint32_t* __restrict__ cand_slots, uint64_t first, int use_window, uint64_t min_len, uint64_t max_len, uint32_t* __restrict__ zero_next,
                                                          uint32_t* __restrict__ tab, uint32_t* __restrict__ tab_next, uint32_t tab_words, uint32_t* __restrict__ n_big3) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];          // (the query's workgroups: up to the whole two-bit table)
 	if (blockIdx.x == 0 && threadIdx.x < 16) zero_next[threadIdx.x] = 0u;          // the counters of the NEXT pass (two sets, used in turn)
-	if (blockIdx.x < 8)          // ... and its tables
-		for (uint32_t i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < tab_words; i += 4 * 8 * blockDim.x) *reinterpret_cast<uint4*>(tab_next + i) = make_uint4(0u, 0u, 0u, 0u);
+	if (blockIdx.x < kRiPrepBlocks)          // ... and its tables
+		for (uint32_t i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < tab_words; i += 4 * kRiPrepBlocks * blockDim.x) *reinterpret_cast<uint4*>(tab_next + i) = make_uint4(0u, 0u, 0u, 0u);
 	const MscSparseHdr h = *hdr_p;
 	const uint32_t tot = h.nnz ? cum[h.off + h.nnz - 1] : 0u, pad = (tot + 255u) & ~255u;
-	if (blockIdx.x < 8) {
-		if (pad > cap) {          // the set's bound did not hold: say so and write nothing
+	if (blockIdx.x < kRiPrepBlocks) {
+		if (out && pad > cap) {          // the set's bound did not hold: say so and write nothing
 			if (blockIdx.x == 0 && threadIdx.x == 0 && guard) atomicOr(guard, 1u);
 			return;
 		}
 		uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < h.nnz; j += 8 * blockDim.x) {
-			const uint2 en = ent[h.off + j];
-			const uint32_t e = en.y ? en.y - 1u : 0u, end = cum[h.off + j];
-			for (uint32_t t = end - e; t < end; t++) out[t] = en.x;
-			// the query's histogram as the pass's workgroups will hold it in LDS: two bits per bin -- e_q = 0, 1, 2, "three and more" --
-			// and, behind them, a hash table of the few bins of the last kind (key = bin + 1: the tables start out zero)
-			if (e >= 1) atomicOr(&tab[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
-			if (e >= 3 && atomicAdd(n_big3, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
-				uint32_t *keys = tab + (tab_words - 2 * kRiHash), *vals = keys + kRiHash;
-				uint32_t hsh = (en.x * 2654435761u) >> 22;
-				for (;;) {
-					const uint32_t old = atomicCAS(&keys[hsh], 0u, en.x + 1u);
-					if (old == 0u || old == en.x + 1u) { vals[hsh] = e; break; }
-					hsh = (hsh + 1) & (kRiHash - 1);
+		// A workgroup takes 1 024 consecutive entries at a time: their words of the two-bit table are put together in LDS and written out
+		// once each -- the entries are in bin order, so a word belongs to one workgroup but for the first and the last of its span (those
+		// two by atomics). (One global atomic per entry, eighty of them aimed at the same 128-byte line at once, was 8 .. 20 us of a pass.)
+		for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < h.nnz; j0 += kRiPrepBlocks * blockDim.x) {
+			const uint32_t j = j0 + threadIdx.x, j_last = (j0 + blockDim.x < h.nnz ? j0 + blockDim.x : h.nnz) - 1;
+			const uint32_t w_lo = ent[h.off + j0].x >> 4, w_hi = ent[h.off + j_last].x >> 4, span = w_hi - w_lo + 1;
+			for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_tab[i] = 0u;
+			__syncthreads();
+			if (j < h.nnz) {
+				const uint2 en = ent[h.off + j];
+				const uint32_t e = en.y ? en.y - 1u : 0u;
+				if (out) { const uint32_t end = cum[h.off + j]; for (uint32_t t = end - e; t < end; t++) out[t] = en.x; }          // (out == nullptr: the query's list is one of the set's own)
+				// the query's histogram as the pass's workgroups will hold it in LDS: two bits per bin -- e_q = 0, 1, 2, "three and more" --
+				// and, behind them, a hash table of the few bins of the last kind (key = bin + 1: the tables start out zero)
+				if (e >= 1) atomicOr(&s_tab[(en.x >> 4) - w_lo], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
+				if (e >= 3 && atomicAdd(n_big3, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
+					uint32_t *keys = tab + (tab_words - 2 * kRiHash), *vals = keys + kRiHash;
+					uint32_t hsh = (en.x * 2654435761u) >> 22;
+					for (;;) {
+						const uint32_t old = atomicCAS(&keys[hsh], 0u, en.x + 1u);
+						if (old == 0u || old == en.x + 1u) { vals[hsh] = e; break; }
+						hsh = (hsh + 1) & (kRiHash - 1);
+					}
+				}
+				if (hq) {
+#pragma unroll
+					for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
+					if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
 				}
 			}
-			if (hq) {
-#pragma unroll
-				for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
-				if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
+			__syncthreads();
+			for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
+				const uint32_t v = s_tab[i];
+				if (!v) continue;
+				if (i == 0 || i == span - 1) atomicOr(&tab[w_lo + i], v);
+				else tab[w_lo + i] = v;
 			}
+			__syncthreads();
 		}
-		if (blockIdx.x == 0) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
+		if (blockIdx.x == 0 && out) for (uint32_t i = tot + threadIdx.x; i < pad; i += blockDim.x) out[i] = nbins;
 		if (hq) {
 #pragma unroll
 			for (uint32_t x = 2; x < 8; x++) {
@@ -530,43 +447,43 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 		}
 		return;
 	}
-	__shared__ uint32_t s_part[18];
-	const uint32_t c = (blockIdx.x - 8) * 1024 + threadIdx.x;
-	RkItemMeta mt{0, 0, 0.0, 0, 0, 0, 0, 0, 0};
-	if (c < m) {
-		const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
-		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-		const uint64_t len = cs->length;
-		mt.mag = (double)cs->mag;
-		mt.off = c_off[slot]; mt.n = c_n[slot];
-		mt.moff = m_off[slot]; mt.nm = m_n[slot];
-		if (!(use_window && (len < min_len || len > max_len))) {
-			const uint32_t T = mt.n > tot ? mt.n : tot;
-			mt.rounds = (T + kRiRound - 1) / kRiRound;
-			mt.mrounds = (mt.nm + kRiMulti - 1) / kRiMulti;
-		}
-	}
-	// the thread's place: a DPP scan per wave, one more over the sixteen wave totals, one atomic for the workgroup
+	// the list: kRiListCands candidates per workgroup -- its first wave reads their records, counts their items and claims the places (a
+	// DPP scan, one atomic), then every wave writes the items of every sixteenth candidate, 64 at a time (r05: with a candidate per
+	// thread, a thousand threads of ONE workgroup wrote up to sixty scattered items each -- 7 .. 29 us, as long as the pass itself)
+	__shared__ uint32_t s_first[kRiListCands], s_rounds[kRiListCands], s_mrounds[kRiListCands];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t mine = mt.rounds + mt.mrounds;
-	const uint32_t incl = wave_incl_scan(mine);
-	if (lane == 63) s_part[wave] = incl;
-	__syncthreads();
+	const uint32_t c_base = (blockIdx.x - kRiPrepBlocks) * kRiListCands;
 	if (wave == 0) {
-		const uint32_t t = lane < 16 ? s_part[lane] : 0u;
-		const uint32_t ti = wave_incl_scan(t);
+		const uint32_t c = c_base + lane;
+		RkItemMeta mt{0, 0, 0.0, 0, 0, 0, 0, 0, 0};
+		if (c < m) {
+			const uint64_t slot = cand_slots ? (uint64_t)cand_slots[c] : first + c;
+			const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
+			const uint64_t len = cs->length;
+			mt.mag = (double)cs->mag;
+			mt.off = c_off[slot]; mt.n = c_n[slot];
+			mt.moff = m_off[slot]; mt.nm = m_n[slot];
+			if (!(use_window && (len < min_len || len > max_len))) {
+				const uint32_t T = mt.n > tot ? mt.n : tot;
+				mt.rounds = (T + kRiRound - 1) / kRiRound;
+				mt.mrounds = (mt.nm + kRiMulti - 1) / kRiMulti;
+			}
+		}
+		const uint32_t mine = mt.rounds + mt.mrounds;
+		const uint32_t incl = wave_incl_scan(mine);
 		uint32_t base = 0;
-		if (lane == 15 && ti) base = atomicAdd(n_items, ti);
-		base = (uint32_t)__builtin_amdgcn_readlane((int)base, 15);
-		if (lane < 16) s_part[lane] = base + ti - t;
+		if (lane == 63 && incl) base = atomicAdd(n_items, incl);
+		base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+		mt.first = base + incl - mine;
+		if (c < m) meta[c] = mt;
+		s_first[lane] = mt.first; s_rounds[lane] = mt.rounds; s_mrounds[lane] = mt.mrounds;
 	}
 	__syncthreads();
-	uint32_t run = s_part[wave] + incl - mine;
-	mt.first = run;
-	if (c < m) meta[c] = mt;
-	for (uint32_t rd = 0; rd < mt.rounds; rd++) items[run + rd] = make_uint2(c, rd);
-	run += mt.rounds;
-	for (uint32_t rd = 0; rd < mt.mrounds; rd++) items[run + rd] = make_uint2(c, rd | kRiMultiFlag);
+	for (uint32_t i = wave; i < kRiListCands; i += kRpBlock / 64) {
+		const uint32_t c = c_base + i, r = s_rounds[i], mr = s_mrounds[i];
+		uint2* o = items + s_first[i];
+		for (uint32_t rd = lane; rd < r + mr; rd += 64) o[rd] = make_uint2(c, rd < r ? rd : (rd - r) | kRiMultiFlag);
+	}
 }
 
 template <bool DIV>
@@ -582,7 +499,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	const MscSparseHdr qh = *q_hdr_p;
 	const uint32_t nq = qh.nnz;
 	const uint32_t nq_tot = nq ? q_cum[qh.off + nq - 1] : 0u;
-	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
+	const uint32_t nq_pad4 = (nq_tot + 3u) & ~3u;          // (the query's list is padded with 4^k to four entries at least: the set's own list, or the pass's expansion)
 	const bool hash_ok = cnt_p[13] <= kRiHash / 2;
 	auto e_q_of = [&](uint32_t bin) -> uint32_t {          // a bin the table marks "three and more"
 		if (hash_ok) {
@@ -618,7 +535,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 				a[u] = make_uint4(nbins, nbins, nbins, nbins);
 				b[u] = a[u];
 				if (t < nc_pad) a[u] = *reinterpret_cast<const uint4*>(P + t);
-				if (t < nq_pad) b[u] = *reinterpret_cast<const uint4*>(rq + t);
+				if (t < nq_pad4) b[u] = *reinterpret_cast<const uint4*>(rq + t);
 			}
 			before_round = t0 && t0 - 1 < nc ? P[t0 - 1] : 0xffffffffu;          // the entry in front of the round
 		} else {          // repeated bins [rd * kRiMulti, ..) of the candidate: four per lane, (bin, e_c) each
@@ -666,7 +583,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			// the padding behind the list's end reads as ONE first copy of a bin the query does not hold (4^k: the zero word behind the table)
 			const uint32_t walked = T - t0 >= kRiRound ? kRiRound : (T - t0 + 255u) & ~255u;
 			spurious = nc < t0 + walked ? 1u : 0u;
-			uint32_t pk = 0;          // 6-bit counters: [6] first copies with e_q = 0, [12] = 1, [18] = 2, [24] three and more ([0]: further copies)
+			uint32_t pk = 0;          // four byte counters: first copies with e_q = 0, 1, 2, three and more
+			const uint8_t* sb8 = reinterpret_cast<const uint8_t*>(sb);          // (a byte of the table: four bins)
 #pragma unroll
 			for (uint32_t u = 0; u < 4; u++) {
 				if (t0 + 256 * u >= T) break;
@@ -680,13 +598,19 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 				if (lane == 0) prev = u ? (uint32_t)__builtin_amdgcn_readlane((int)a[u ? u - 1 : 0].w, 63) : before_round;
 				const uint32_t e4[4] = {av.x, av.y, av.z, av.w};
 				const uint32_t p4[4] = {prev, av.x, av.y, av.z};
+				uint32_t two[4];
+				const uint32_t pk0 = pk;
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
+				for (int j = 0; j < 4; j++) {          // ten instructions per entry: a compare, the look-up (five), a shift and a shifted add, the round's |a - b|
 					const uint32_t bin = e4[j];
-					const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2u * (bin & 15u), 2u);
-					const uint32_t code = bin != p4[j] ? two * 6u + 6u : 0u;
-					pk += 1u << code;
-					if (code == 24u) {          // rare: the first copy of a bin the query holds three times and more
+					two[j] = __builtin_amdgcn_ubfe((uint32_t)sb8[bin >> 2], (bin & 3u) << 1, 2u);
+					pk += (bin != p4[j] ? 1u : 0u) << (two[j] << 3);
+				}
+				if ((pk - pk0) >> 24) {          // rare: among the four, the first copy of a bin the query holds three times and more
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const uint32_t bin = e4[j];
+						if (bin == p4[j] || two[j] != 3u) continue;
 						const uint32_t e_q = e_q_of(bin);
 						prod += e_q;
 						mins += 1u;
@@ -702,8 +626,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 					}
 				}
 			}
-			pk_a = ((pk >> 6) & 63u) | (((pk >> 12) & 63u) << 16);
-			pk_b = (pk >> 18) & 63u;
+			pk_a = (pk & 255u) | (((pk >> 8) & 255u) << 16);
+			pk_b = (pk >> 16) & 255u;
 		} else {
 			const uint32_t j0 = rd * kRiMulti + 4 * lane;
 			const uint4 m0 = a[0], m1 = a[1];
@@ -780,27 +704,32 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	}
 }
 
-// A wave per candidate: lane l adds up word l of its items' records (rounds, then repeated-bin items, as the list holds them); the integer
-// record from words 0 / 8 / 16 / 24; DIV: lane (r, b) evaluates cell (r, b) -- row a' = candidate count a' + 2, row 7 = bins evaluated on
-// the spot, counted as held: its lanes take the query's bins with count b that the candidate does not hold --, the lanes of column 0 share
-// the query's bins with a count >= 8 and the items' spot terms (in list order); one butterfly adds the 64 partial sums in a fixed order.
+// A workgroup per candidate: lane l of each of the four waves adds up word l of every fourth of its items' records (rounds, then
+// repeated-bin items, as the list holds them), LDS adds the four; the integer record from words 0 / 8 / 16 / 24; DIV, first wave: lane
+// (r, b) evaluates cell (r, b) -- row a' = candidate count a' + 2, row 7 = bins evaluated on the spot, counted as held: its lanes take the
+// query's bins with count b that the candidate does not hold --, every lane its share of the query's bins with a count >= 8 and of the
+// items' spot terms (lane l: entries l, l + 64, ..); one butterfly adds the 64 partial sums in a fixed order.
 template <bool DIV>
 __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __restrict__ rec, const double* __restrict__ extras, uint32_t rounds, const uint32_t* __restrict__ hq,
                                                            const uint32_t* __restrict__ big, const RkItemMeta* __restrict__ meta, uint32_t m, const uint32_t* __restrict__ q_cum,
                                                            const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order, MscPartial* __restrict__ partials,
                                                            double* __restrict__ div_out, uint32_t* __restrict__ guard) {
-	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (c >= m) return;
+	__shared__ uint64_t s_sum[3][64];
+	const uint32_t c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const RkItemMeta mt = meta[c];
 	const uint32_t n_it = mt.rounds + mt.mrounds;
 	const uint32_t* R = rec + (uint64_t)mt.first * kRkCells + lane;
 	uint64_t sum = 0;
-	uint32_t s = 0;
-	for (; s + 4 <= n_it; s += 4) {
-		const uint32_t x0 = R[(uint64_t)s * kRkCells], x1 = R[(uint64_t)(s + 1) * kRkCells], x2 = R[(uint64_t)(s + 2) * kRkCells], x3 = R[(uint64_t)(s + 3) * kRkCells];
+	uint32_t s = wave;
+	for (; s + 12 < n_it; s += 16) {
+		const uint32_t x0 = R[(uint64_t)s * kRkCells], x1 = R[(uint64_t)(s + 4) * kRkCells], x2 = R[(uint64_t)(s + 8) * kRkCells], x3 = R[(uint64_t)(s + 12) * kRkCells];
 		sum += (uint64_t)x0 + x1 + x2 + x3;
 	}
-	for (; s < n_it; s++) sum += R[(uint64_t)s * kRkCells];
+	for (; s < n_it; s += 4) sum += R[(uint64_t)s * kRkCells];
+	if (wave) s_sum[wave - 1][lane] = sum;
+	__syncthreads();
+	if (wave) return;
+	sum += s_sum[0][lane] + s_sum[1][lane] + s_sum[2][lane];
 	{
 		const uint64_t emd = sum, p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
 		if (lane == 0) {
@@ -839,16 +768,14 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 				js = (double)kq * (f.js - t11.js);
 			}
 		}
-		if (b == 0) {          // column 0: lane r takes entries r, r + 8, .. of the query's counts >= 8 and of the items' spot terms
-			const uint32_t n_big = hq[8];
-			for (uint32_t i = r; i < n_big; i += 8) {
-				const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
-				jd += f.jd - t11.jd;
-				js += f.js - t11.js;
-			}
-			const double* x = extras + 2 * (uint64_t)mt.first;
-			for (uint32_t i = r; i < n_it; i += 8) { jd += x[2 * i]; js += x[2 * i + 1]; }
+		const uint32_t n_big = hq[8];
+		for (uint32_t i = lane; i < n_big; i += 64) {
+			const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
+			jd += f.jd - t11.jd;
+			js += f.js - t11.js;
 		}
+		const double2* x = reinterpret_cast<const double2*>(extras) + mt.first;
+		for (uint32_t i = lane; i < n_it; i += 64) { const double2 v = x[i]; jd += v.x; js += v.y; }
 #pragma unroll
 		for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
 		if (lane == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
@@ -884,8 +811,7 @@ hipError_t msc_launch_rank_lists_fill(hipStream_t st, const void* ent, const uin
 // candidates [first, first + m) (or the device slot list cand_slots; cand_scalars then is the set's base) against the query list
 hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const uint64_t* c_off, const uint32_t* c_n, const uint8_t* cand_scalars, uint64_t scalar_stride,
                                      const uint32_t* cand_slots, uint64_t first, uint32_t m, const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins,
-                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch,
-                                     const MscRankDiv* dv) {
+                                     int use_window, uint64_t min_len, uint64_t max_len, MscPartial* partials, int num_cus, uint64_t q_kmers, uint32_t* guard, uint32_t* q_scratch) {
 	if (m == 0) return hipSuccess;
 	const size_t lds = msc_ranks_pass_lds(nbins, q_kmers);
 	if (!lds) return hipErrorInvalidValue;
@@ -893,10 +819,8 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	if (qg && !q_scratch) return hipErrorInvalidValue;
 	static bool attr_set = false;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_1xm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
@@ -904,30 +828,17 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
-	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / (lds + (dv ? 4096 : 0)));
-	if (dv) {          // the query's counts of counts, for k_rank_div_finish
-		hipError_t e = hipMemsetAsync(dv->hq, 0, 16 * sizeof(uint32_t), st);
-		if (e != hipSuccess) return e;
-		k_rank_query_counts<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_hdr, dv->hq, dv->big);
-	}
+	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / lds);
 	// (MSC_RANKS_CPW=n: at least n candidates per wave, i.e. fewer workgroups for a short window. Measured on a window-bearing run,
 	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
 	static const uint32_t cpw = [] { const char* e = getenv("MSC_RANKS_CPW"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 1); }();
 	uint32_t blocks = (m + per_wg * cpw - 1) / (per_wg * cpw);
 	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
 	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
-#define MSC_RP_GO(QGV, DV)                                                                                                                                                \
-	k_pair_ranks_1xm<QGV, DV><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr,   \
-	                                                                     (uint32_t)nbins, use_window, min_len, max_len, partials, q_cap, guard, QGV ? q_scratch : nullptr,           \
-	                                                                     DV ? dv->cells : nullptr, DV ? dv->extras : nullptr, DV ? dv->q_scalars : nullptr, DV ? dv->order : 0)
-	if (qg && dv) MSC_RP_GO(true, true);
-	else if (qg) MSC_RP_GO(true, false);
-	else if (dv) MSC_RP_GO(false, true);
-	else MSC_RP_GO(false, false);
-#undef MSC_RP_GO
-	hipError_t e = hipGetLastError();
-	if (e != hipSuccess || !dv) return e;
-	k_rank_div_finish<<<dim3((unsigned)(((uint64_t)m * 8 + 255) / 256)), dim3(256), 0, st>>>(dv->cells, dv->extras, dv->hq, dv->big, cand_scalars, scalar_stride, cand_slots, m, dv->q_scalars, dv->order, dv->div_out);
+	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
+	                                                                           use_window, min_len, max_len, partials, q_cap, guard, q_scratch);
+	else k_pair_ranks_1xm<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
+	                                                                         use_window, min_len, max_len, partials, q_cap, guard, nullptr);
 	return hipGetLastError();
 }
 
@@ -935,7 +846,7 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 // bound); q_scratch: ((the query set's k-mer bound + 255) & ~255) entries; rec_scratch: msc_ranks_items_rec_bytes -- a 64-word record and
 // a spot-term slot per item, nothing to clear; item_scratch: msc_ranks_items_list_bytes -- [m records][the items]; counters: 2 x 16 words,
 // zero at the first pass -- the passes use the two halves in turn (`turn`) and each clears the other's. Of dv the launch takes big,
-// q_scalars, order and div_out.
+// q_scalars, order and div_out. q_rk: the query's own rank list when it is a slot of a set that holds them (no expansion then), or nullptr.
 uint32_t msc_ranks_items_round() { return kRiRound; }
 uint32_t msc_ranks_items_table_words(uint64_t nbins) { return (uint32_t)((nbins / 16 + 4) & ~3ull) + 2 * kRiHash; }          // one set of the query's tables (the caller holds two, zero at first)
 size_t msc_ranks_items_rec_bytes(uint64_t m, uint32_t rounds) { return m * 3 * (size_t)rounds * (kRkCells * sizeof(uint32_t) + 2 * sizeof(double)) + 64; }
@@ -944,7 +855,7 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
                                        const uint32_t* c_rm_n, const uint8_t* cand_scalars, uint64_t scalar_stride, const uint32_t* cand_slots, uint64_t first, uint32_t m,
                                        const void* q_ent, const uint32_t* q_cum, const MscSparseHdr* q_hdr, uint64_t nbins, int use_window, uint64_t min_len, uint64_t max_len,
                                        MscPartial* partials, int num_cus, uint32_t* q_scratch, uint32_t rounds, void* rec_scratch, const MscRankDiv* dv, uint64_t q_kmers,
-                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn) {
+                                       uint32_t* guard, void* item_scratch, uint32_t* counters, uint32_t* tables, int turn, const uint32_t* q_rk) {
 	if (m == 0) return hipSuccess;
 	if (nbins > (1ull << 18) || nbins % 32 || !q_scratch || !rec_scratch || !item_scratch || !c_rm || !counters || !tables || rounds == 0) return hipErrorInvalidValue;
 	const uint32_t tab_words = msc_ranks_items_table_words(nbins);
@@ -958,26 +869,27 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	hipError_t e;
 	static bool attr_set = false;
 	if (!attr_set) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_pass_prep), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
 	RkItemMeta* meta = reinterpret_cast<RkItemMeta*>(item_scratch);
 	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + (size_t)m * sizeof(RkItemMeta));
-	k_rank_pass_prep<<<dim3(8 + (m + 1023) / 1024), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard,
+	k_rank_pass_prep<<<dim3(kRiPrepBlocks + (m + kRiListCands - 1) / kRiListCands), dim3(1024), (size_t)(tab_words - 2 * kRiHash) * 4, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? nullptr : q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard,
 	                                                                      dv ? hq : nullptr, dv ? dv->big : nullptr, meta, m, n_items, items_list, c_off, c_n, c_rm_off, c_rm_n,
 	                                                                      cand_scalars, scalar_stride, cand_slots, first, use_window, min_len, max_len, tail_next, tab, tab_next, tab_words, tail + 13);
 	// (one workgroup of the divergence form per CU: sixteen waves of it fill a CU's register file; MSC_RANKS_ITEMS_PER_CU)
 	static const uint32_t per_cu_env = [] { const char* e = getenv("MSC_RANKS_ITEMS_PER_CU"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
 	const uint32_t per_cu = per_cu_env ? per_cu_env : dv ? 1u : (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
 	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
-	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rec, extras,
+	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? q_rk : q_scratch, rec, extras,
 	                                                                             dv->q_scalars, dv->order, meta, items_list, tail, tab);
-	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, rec, nullptr, nullptr,
+	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? q_rk : q_scratch, rec, nullptr, nullptr,
 	                                                                          0, meta, items_list, tail, tab);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	const dim3 fgrid((m + 3) / 4);
+	const dim3 fgrid(m);
 	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(rec, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
 	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(rec, nullptr, rounds, nullptr, nullptr, meta, m, q_cum, q_hdr, nullptr, 0, partials, nullptr, guard);
 	return hipGetLastError();
