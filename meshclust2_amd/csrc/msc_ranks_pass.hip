@@ -406,26 +406,43 @@ __global__ void __launch_bounds__(1024) k_rank_pass_prep(const uint2* __restrict
 			const uint32_t w_lo = ent[h.off + j0].x >> 4, w_hi = ent[h.off + j_last].x >> 4, span = w_hi - w_lo + 1;
 			for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_tab[i] = 0u;
 			__syncthreads();
+			uint2 en = make_uint2(0u, 0u);
+			if (j < h.nnz) en = ent[h.off + j];
+			const uint32_t e = en.y ? en.y - 1u : 0u;
 			if (j < h.nnz) {
-				const uint2 en = ent[h.off + j];
-				const uint32_t e = en.y ? en.y - 1u : 0u;
 				if (out) { const uint32_t end = cum[h.off + j]; for (uint32_t t = end - e; t < end; t++) out[t] = en.x; }          // (out == nullptr: the query's list is one of the set's own)
 				// the query's histogram as the pass's workgroups will hold it in LDS: two bits per bin -- e_q = 0, 1, 2, "three and more" --
-				// and, behind them, a hash table of the few bins of the last kind (key = bin + 1: the tables start out zero)
 				if (e >= 1) atomicOr(&s_tab[(en.x >> 4) - w_lo], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));
-				if (e >= 3 && atomicAdd(n_big3, 1u) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
-					uint32_t *keys = tab + (tab_words - 2 * kRiHash), *vals = keys + kRiHash;
-					uint32_t hsh = (en.x * 2654435761u) >> 22;
-					for (;;) {
-						const uint32_t old = atomicCAS(&keys[hsh], 0u, en.x + 1u);
-						if (old == 0u || old == en.x + 1u) { vals[hsh] = e; break; }
-						hsh = (hsh + 1) & (kRiHash - 1);
+			}
+			// ... and, behind them, a hash table of the few bins of the last kind (key = bin + 1: the tables start out zero). Places are claimed
+			// a wave at a time: a hundred atomics with a return on ONE word, one behind the other, were 10 us of a long query's pass.
+			{
+				const uint32_t ln = threadIdx.x & 63;
+				const uint64_t m3 = __ballot(e >= 3);
+				if (m3) {
+					uint32_t base = 0;
+					if (ln == (uint32_t)__builtin_ctzll(m3)) base = atomicAdd(n_big3, (uint32_t)__popcll(m3));
+					base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m3));
+					if (e >= 3 && base + (uint32_t)__popcll(m3 & ((1ull << ln) - 1ull)) < kRiHash / 2) {          // (more than that: the look-up falls back to the query's rank list)
+						uint32_t *keys = tab + (tab_words - 2 * kRiHash), *vals = keys + kRiHash;
+						uint32_t hsh = (en.x * 2654435761u) >> 22;
+						for (;;) {
+							const uint32_t old = atomicCAS(&keys[hsh], 0u, en.x + 1u);
+							if (old == 0u || old == en.x + 1u) { vals[hsh] = e; break; }
+							hsh = (hsh + 1) & (kRiHash - 1);
+						}
 					}
 				}
 				if (hq) {
 #pragma unroll
 					for (uint32_t x = 2; x < 8; x++) cnt[x] += en.y == x ? 1u : 0u;
-					if (en.y >= 8) big[atomicAdd(&hq[8], 1u)] = en.y;
+					const uint64_t m8 = __ballot(en.y >= 8);
+					if (m8) {
+						uint32_t base = 0;
+						if (ln == (uint32_t)__builtin_ctzll(m8)) base = atomicAdd(&hq[8], (uint32_t)__popcll(m8));
+						base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m8));
+						if (en.y >= 8) big[base + (uint32_t)__popcll(m8 & ((1ull << ln) - 1ull))] = en.y;
+					}
 				}
 			}
 			__syncthreads();
@@ -490,7 +507,7 @@ template <bool DIV>
 __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* __restrict__ c_rk, const uint2* __restrict__ c_rm, uint32_t m, const uint2* __restrict__ q_ent,
                                                                 const uint32_t* __restrict__ q_cum, const MscSparseHdr* __restrict__ q_hdr_p, uint32_t nbins,
                                                                 const uint32_t* __restrict__ rq, uint32_t* __restrict__ rec, double* __restrict__ extras, const uint8_t* __restrict__ q_scalars, int order, const RkItemMeta* __restrict__ meta,
-                                                                const uint2* __restrict__ items, const uint32_t* __restrict__ cnt_p, const uint32_t* __restrict__ tab) {
+                                                                const uint2* __restrict__ items, const uint32_t* __restrict__ cnt_p, const uint32_t* __restrict__ tab, uint32_t* __restrict__ big) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];          // [two bits per bin: nbins / 16 + 1 words, padded to four][hash keys][hash values]
 	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the item in hand, those no register counts
 	const uint32_t words_pad = (nbins / 16 + 4) & ~3u;
@@ -556,6 +573,33 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	uint4 a[4], b[4];
 	uint32_t before_round = 0xffffffffu;
 	if (it < n_items) issue(item_n, mt_n, a, b, before_round);
+	// The query's counts >= 8 were appended in whatever order k_rank_pass_prep's waves came by; the finish kernel adds an FP64 term per
+	// entry in list order, and a sum must not depend on that: the first workgroup sorts the list (a bitonic network in the LDS the
+	// tables are about to take; lists longer than that -- 16 384 at k = 9 -- stay as they are). Nothing in this kernel reads it.
+	if constexpr (DIV) {
+		if (blockIdx.x == 0) {
+			const uint32_t nb = cnt_p[8];
+			uint32_t p2 = 2;
+			while (p2 < nb && p2 < (1u << 20)) p2 <<= 1;
+			if (nb > 1 && p2 >= nb && p2 <= words_pad) {
+				for (uint32_t i = threadIdx.x; i < p2; i += kRpBlock) s_rp[i] = i < nb ? big[i] : 0xffffffffu;
+				__syncthreads();
+				for (uint32_t k2 = 2; k2 <= p2; k2 <<= 1)
+					for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+						for (uint32_t i = threadIdx.x; i < p2; i += kRpBlock) {
+							const uint32_t l = i ^ j2;
+							if (l > i) {
+								const uint32_t x = s_rp[i], y = s_rp[l];
+								if (((i & k2) == 0) == (x > y)) { s_rp[i] = y; s_rp[l] = x; }
+							}
+						}
+						__syncthreads();
+					}
+				for (uint32_t i = threadIdx.x; i < nb; i += kRpBlock) big[i] = s_rp[i];
+				__syncthreads();
+			}
+		}
+	}
 	// the query's tables, as k_rank_pass_prep left them in global memory (r05: every workgroup used to build them from the query's list -- 16 000
 	// clocks of a kernel of 47 000); the wave's first loads are on their way meanwhile
 	for (uint32_t i = 4 * threadIdx.x; i < words_pad + 2 * kRiHash; i += 4 * kRpBlock) *reinterpret_cast<uint4*>(s_rp + i) = *reinterpret_cast<const uint4*>(tab + i);
@@ -879,15 +923,15 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	uint2* items_list = reinterpret_cast<uint2*>((uint8_t*)item_scratch + (size_t)m * sizeof(RkItemMeta));
 	k_rank_pass_prep<<<dim3(kRiPrepBlocks + (m + kRiListCands - 1) / kRiListCands), dim3(1024), (size_t)(tab_words - 2 * kRiHash) * 4, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? nullptr : q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard,
 	                                                                      dv ? hq : nullptr, dv ? dv->big : nullptr, meta, m, n_items, items_list, c_off, c_n, c_rm_off, c_rm_n,
-	                                                                      cand_scalars, scalar_stride, cand_slots, first, use_window, min_len, max_len, tail_next, tab, tab_next, tab_words, tail + 13);
+	                                                                      cand_scalars, scalar_stride, cand_slots, first, use_window, min_len, max_len, tail_next, tab, tab_next, tab_words, tail + 13);          // (tail + 14: the query's workgroups done)
 	// (one workgroup of the divergence form per CU: sixteen waves of it fill a CU's register file; MSC_RANKS_ITEMS_PER_CU)
 	static const uint32_t per_cu_env = [] { const char* e = getenv("MSC_RANKS_ITEMS_PER_CU"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 0); }();
 	const uint32_t per_cu = per_cu_env ? per_cu_env : dv ? 1u : (uint32_t)std::min<size_t>(2, (150 * 1024) / lds);
 	uint32_t blocks = (uint32_t)std::min<uint64_t>((items + kRpBlock / 64 - 1) / (kRpBlock / 64), (uint64_t)num_cus * per_cu);
 	if (dv) k_pair_ranks_items<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? q_rk : q_scratch, rec, extras,
-	                                                                             dv->q_scalars, dv->order, meta, items_list, tail, tab);
+	                                                                             dv->q_scalars, dv->order, meta, items_list, tail, tab, dv->big);
 	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? q_rk : q_scratch, rec, nullptr, nullptr,
-	                                                                          0, meta, items_list, tail, tab);
+	                                                                          0, meta, items_list, tail, tab, nullptr);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
 	const dim3 fgrid(m);
 	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(rec, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
