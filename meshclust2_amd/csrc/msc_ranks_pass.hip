@@ -338,6 +338,7 @@ constexpr uint32_t kRiRound = 1024;
 constexpr uint32_t kRiMulti = 256;          // entries of a candidate's repeated-bin list per item (at most 2 x rounds items: a repeated bin is two k-mers and more)
 constexpr uint32_t kRiHash = 1024;          // slots of the LDS hash of the query's bins with e_q >= 3 (at most half are used)
 constexpr uint32_t kRiMultiFlag = 0x80000000u;
+constexpr uint32_t kRiQueue = 512;          // pairs of counts a wave puts aside before it evaluates them (256 entries of the list bring at most 256; emptied before the next 256 would not fit)
 constexpr uint32_t kRiListCands = 64;           // candidates per workgroup of k_rank_pass_prep's list part
 constexpr uint32_t kRiPrepBlocks = 32;          // workgroups of k_rank_pass_prep that take the query's side (one entry per thread for lists of up to 32 768 stored bins)
 
@@ -510,6 +511,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
                                                                 const uint2* __restrict__ items, const uint32_t* __restrict__ cnt_p, const uint32_t* __restrict__ tab, uint32_t* __restrict__ big) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_rp[];          // [two bits per bin: nbins / 16 + 1 words, padded to four][hash keys][hash values]
 	__shared__ uint32_t s_cnt[DIV ? kRpBlock / 64 : 1][DIV ? kRkCells : 1];          // DIV: a wave's cell counts of the item in hand, those no register counts
+	__shared__ uint2 s_q[DIV ? kRpBlock / 64 : 1][DIV ? kRiQueue : 1];               // DIV: the pairs of counts whose terms are evaluated on the spot, put aside (below)
 	const uint32_t words_pad = (nbins / 16 + 4) & ~3u;
 	uint32_t *sb = s_rp, *s_key = s_rp + words_pad, *s_val = s_key + kRiHash;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -535,6 +537,47 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	const uint32_t n_items = cnt_p[12];
 	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
 	(void)m; (void)q_ent;
+	// SPOT TERMS. A bin the candidate holds 8 times and more, or the query 7 and more, has no cell: its term is two FP64 logarithms on the
+	// spot. Evaluated where they turn up -- one lane in sixty-four, four times over in an unrolled loop -- they were a third of the kernel
+	// on cfg5's shape (runs of thousands of copies in every sequence) and the reason some waves took three times as long as others. The
+	// walk only puts the pair of counts aside, at a place a ballot gives (the same on every run); when the item is done -- or 256 are in --
+	// every lane takes one: term(ca, cb) - term(lo, cb), lo = 1 (b >= 8: the finish adds F(1, b) for every such bin of the query),
+	// 2 (a repeated bin's correction) or, for b < 8, - term(1, 1).
+	uint32_t qn = 0;          // (uniform) pairs in the wave's queue
+	double xjd = 0.0, xjs = 0.0;
+	double cm = 0.0;
+	auto q_push = [&](bool want, uint32_t ca, uint32_t cb, uint32_t lo) {          // called by all lanes of the wave at once
+		if constexpr (DIV) {
+			const uint64_t mask = __ballot(want);
+			if (want) s_q[wave][qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(ca | (lo << 30), cb);
+			qn += (uint32_t)__popcll(mask);
+		}
+	};
+	auto q_drain = [&]() {
+		if constexpr (DIV) {
+			if (qn == 0) return;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			RkDivTerm t11{0.0, 0.0};
+			bool have11 = false;
+			for (uint32_t b0 = 0; b0 < qn; b0 += 64) {
+				const bool mine = b0 + lane < qn;
+				const uint2 en = mine ? s_q[wave][b0 + lane] : make_uint2(1u, 1u);
+				const uint32_t ca = en.x & 0x3fffffffu, lo = en.x >> 30, cb = en.y;
+				if (!have11 && __ballot(mine && cb < 8)) { t11 = rk_div_term_call(1, 1, cm, qm, order); have11 = true; }
+				if (mine) {
+					const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
+					RkDivTerm l = t11;
+					if (cb >= 8) l = rk_div_term_call(lo, cb, cm, qm, order);
+					xjd += hi.jd - l.jd;
+					xjs += hi.js - l.js;
+				}
+			}
+			qn = 0;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
 	// The loop is laid out around the memory pipe's one counter (loads and the acknowledgements of atomics and stores are waited for in
 	// issue order): an item's loads go out BEFORE the flush of the item in front of it -- into the registers that item has just finished
 	// with --, so that the wait for them does not include the round trip of atomics that twenty waves aim at the same candidate; the list
@@ -613,12 +656,12 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		const bool has_next = it + n_waves < n_items;
 		const uint32_t rd = item.y & ~kRiMultiFlag;
 		const bool multi = (item.y & kRiMultiFlag) != 0;
-		const double cm = mt.mag;
+		cm = mt.mag;
 		uint32_t emd = 0;
 		uint64_t prod = 0;          // prod, mins: what the packed counters do not hold
 		uint32_t mins = 0;
 		uint32_t pk_a = 0, pk_b = 0;          // two pairs of 16-bit counters (see below)
-		double xjd = 0.0, xjs = 0.0;
+		xjd = 0.0; xjs = 0.0;
 		uint32_t spurious = 0;
 		if (!multi) {
 			const uint32_t nc = mt.n;
@@ -650,24 +693,22 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 					two[j] = __builtin_amdgcn_ubfe((uint32_t)sb8[bin >> 2], (bin & 3u) << 1, 2u);
 					pk += (bin != p4[j] ? 1u : 0u) << (two[j] << 3);
 				}
-				if ((pk - pk0) >> 24) {          // rare: among the four, the first copy of a bin the query holds three times and more
+				if (__ballot((pk - pk0) >> 24)) {          // rare: among the four of some lane, the first copy of a bin the query holds three times and more
 #pragma unroll
 					for (int j = 0; j < 4; j++) {
 						const uint32_t bin = e4[j];
-						if (bin == p4[j] || two[j] != 3u) continue;
-						const uint32_t e_q = e_q_of(bin);
-						prod += e_q;
-						mins += 1u;
-						if constexpr (DIV) {
-							const uint32_t cb = e_q + 1;
-							if (cb < 8) atomicAdd(&s_cnt[wave][cb], 1u);
-							else {          // (the finish adds F(1, b) for every such bin of the query)
-								const RkDivTerm hi = rk_div_term_call(2, cb, cm, qm, order), lo = rk_div_term_call(1, cb, cm, qm, order);
-								xjd += hi.jd - lo.jd;
-								xjs += hi.js - lo.js;
-							}
+						const bool hit = bin != p4[j] && two[j] == 3u;
+						uint32_t cb = 0;
+						if (hit) {
+							const uint32_t e_q = e_q_of(bin);
+							prod += e_q;
+							mins += 1u;
+							cb = e_q + 1;
+							if constexpr (DIV) { if (cb < 8) atomicAdd(&s_cnt[wave][cb], 1u); }
 						}
+						q_push(hit && cb >= 8, 2u, cb, 1u);
 					}
+					if (qn > kRiQueue - 256) q_drain();
 				}
 			}
 			pk_a = (pk & 255u) | (((pk >> 8) & 255u) << 16);
@@ -676,41 +717,32 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			const uint32_t j0 = rd * kRiMulti + 4 * lane;
 			const uint4 m0 = a[0], m1 = a[1];
 			const uint32_t mb[4] = {m0.x, m0.z, m1.x, m1.z}, me[4] = {m0.y, m0.w, m1.y, m1.w};
-			RkDivTerm t11{0.0, 0.0};
-			if constexpr (DIV) {
-				const bool deep = (me[0] | me[1] | me[2] | me[3]) >= 8u;          // (an e_c of 8 and more somewhere: a spot term; zero for the lanes past the list)
-				if (__ballot(deep)) t11 = rk_div_term_call(1, 1, cm, qm, order);
-			}
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
-				if (j0 + i >= mt.nm) break;
-				const uint32_t bin = mb[i], e_c = me[i];
-				const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2u * (bin & 15u), 2u);
-				const uint32_t e_q = two < 3 ? two : e_q_of(bin);
-				prod += (uint64_t)(e_c - 1u) * e_q;
-				mins += (e_c < e_q ? e_c : e_q) - (e_q ? 1u : 0u);
-				if constexpr (DIV) {
-					const uint32_t ca = e_c + 1, cb = e_q + 1;          // the bin's counts in the candidate and in the query
-					if (cb < 8) {
-						// out of cell (1 copy, cb), into cell (e_c copies, cb); [row 7: counted as held, evaluated here]
-						if (cb <= 2) pk_a += cb == 1 ? 1u : 0x10000u;
-						else atomicAdd(&s_cnt[wave][cb], 0xffffffffu);
-						if (ca == 3 && cb <= 2) pk_b += cb == 1 ? 1u : 0x10000u;
-						else atomicAdd(&s_cnt[wave][(ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);
-						if (ca >= 9) {
-							const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order);
-							xjd += hi.jd - t11.jd;
-							xjs += hi.js - t11.js;
+				const bool live = j0 + i < mt.nm;
+				uint32_t ca = 0, cb = 0;
+				if (live) {
+					const uint32_t bin = mb[i], e_c = me[i];
+					const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2u * (bin & 15u), 2u);
+					const uint32_t e_q = two < 3 ? two : e_q_of(bin);
+					prod += (uint64_t)(e_c - 1u) * e_q;
+					mins += (e_c < e_q ? e_c : e_q) - (e_q ? 1u : 0u);
+					ca = e_c + 1; cb = e_q + 1;          // the bin's counts in the candidate and in the query
+					if constexpr (DIV) {
+						if (cb < 8) {
+							// out of cell (1 copy, cb), into cell (e_c copies, cb); [row 7: counted as held, its term among the spot terms]
+							if (cb <= 2) pk_a += cb == 1 ? 1u : 0x10000u;
+							else atomicAdd(&s_cnt[wave][cb], 0xffffffffu);
+							if (ca == 3 && cb <= 2) pk_b += cb == 1 ? 1u : 0x10000u;
+							else atomicAdd(&s_cnt[wave][(ca < 9 ? ca - 2 : 7) * 8 + cb], 1u);
 						}
-					} else {
-						const RkDivTerm hi = rk_div_term_call(ca, cb, cm, qm, order), lo = rk_div_term_call(2, cb, cm, qm, order);
-						xjd += hi.jd - lo.jd;
-						xjs += hi.js - lo.js;
 					}
 				}
+				q_push(live && (ca >= 9 || cb >= 8), ca, cb, 2u);
 			}
 		}
-		if (has_next) issue(item_n, mt_n, a, b, before_round);          // the next item's loads, in front of this item's flush
+		if (has_next) issue(item_n, mt_n, a, b, before_round);          // the next item's loads, in front of this item's spot terms and flush
+		q_drain();
 		const uint32_t ta = wave_total_u32(pk_a), tb = wave_total_u32(pk_b);
 		uint64_t prod_t = 0;
 		uint32_t mins_t = 0, emd_t = 0;
@@ -915,7 +947,7 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	if (!attr_set) {
 		e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_pass_prep), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+		if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_ranks_items<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
