@@ -1656,13 +1656,9 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	const bool no_rank_pass = getenv("MSC_NO_RANKS_1XM") != nullptr;          // (read on every call: tests compare both routes in one process)
 	bool rank_pass = false;
 	const uint64_t q_kmers = rq.qset->max_sum >= L.nbins ? rq.qset->max_sum - L.nbins : ~0ull;          // bound on the k-mers of any histogram of the query's set
-	// (the divergence statistics too: counted per cell of (copy, query count) by the pass, evaluated per candidate in one fixed order by
-	// k_rank_div_finish -- msc_ranks_pass.hip; MSC_NO_RANKS_DIV keeps such passes on the merge kernel)
+	// (the divergence statistics too: bins counted per cell of (candidate's count, query's count) by k_pair_ranks_items, evaluated per
+	// candidate in one fixed order by k_rank_items_finish -- msc_ranks_pass.hip; MSC_NO_RANKS_DIV keeps such passes on the merge kernel)
 	const bool no_rank_div = getenv("MSC_NO_RANKS_DIV") != nullptr;
-	// The divergence form only where lists are short (the query set's bound within what LDS holds, i.e. sequences of up to ~8 kb): a wave takes a
-	// whole candidate, and on cfg5's shape -- lists of 10 000 .. 50 000 k-mers, 1 600 .. 8 000 candidates per pass, homopolymer runs of
-	// thousands of copies -- that is 40 dependent chunk loads per wave with most of the chip idle (13.3 s against the merge kernel's 4.0 at
-	// 20 000 sequences): such passes stay with the merge kernel, which shares a candidate among waves.
 	// ... and only in the step-serial loop's own call (msc_get_close_window: rq.close_list) unless MSC_RANKS_DIV asks for it everywhere: the
 	// two FP64 sums of the rank form add the same terms in another order than the merge kernel's (they agree to ~1e-15 relative), and every
 	// OTHER route -- 1 x M by slot list, Q x M, the batched update stage, dense or sparse -- keeps returning bit-identical values for a pair

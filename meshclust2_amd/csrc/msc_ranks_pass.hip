@@ -1,5 +1,5 @@
 // msc_ranks_pass.hip -- the 1 x M pass of Trainer::get_close / filter (cluster/Trainer.cpp:26-61) over RANK LISTS, for histograms of up to
-// 4^9 bins: no merge of two sorted lists. r04.
+// 4^9 bins: no merge of two sorted lists. r04; r05: the long-list / divergence form (k_pair_ranks_items, below) walks first copies only.
 //
 // A rank list = the bins of a histogram's counted k-mers in bin order, a bin with count c listed e = c - 1 times (every bin starts at the
 // pseudocount 1, nonltr/KmerHashTable.cpp:69-72): 4 bytes per k-mer where the (bin, value) lists of sparse.hip take 8 bytes per stored bin
@@ -745,7 +745,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		q_drain();
 		const uint32_t ta = wave_total_u32(pk_a), tb = wave_total_u32(pk_b);
 		uint64_t prod_t = 0;
-		uint32_t mins_t = 0, emd_t = 0;
+		uint32_t mins_t = 0;
+		uint64_t emd_t = 0;
 		if (__ballot(prod != 0 || mins != 0)) { prod_t = wave_sum_u64(prod); mins_t = (uint32_t)wave_sum_u64(mins); }
 		uint32_t v1, v2, v3 = 0, v9 = 0, v10 = 0;          // what the counters add to cells (0, 1), (0, 2), (0, 3), (1, 1), (1, 2) (modulo 2^32: the repeated bins take away)
 		if (!multi) {
@@ -753,13 +754,13 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			v1 = c01; v2 = c02; v3 = c03;
 			prod_t += c02 + 2 * (uint64_t)c03;
 			mins_t += c02 + c03;
-			emd_t = wave_total_u32((uint32_t)emd);          // (a round's sum: < 2^28)
+			emd_t = wave_total_u64(emd);          // (a lane's sum: 16 x 4^k < 2^32)
 		} else {
 			v1 = 0u - (ta & 0xffffu); v2 = 0u - (ta >> 16);
 			v9 = tb & 0xffffu; v10 = tb >> 16;
 		}
 		// The item's RECORD, 64 words, one per lane, at the item's place in the list: the cell counts (r, b) at r * 8 + b -- b = 0 is no cell:
-		// words 0, 8, 16, 24 hold the round's emd, the two halves of sum e_c e_q, sum min(e_c, e_q). No atomics: until r05 the items of a
+		// words 0 and 32 hold the halves of the round's emd, 8 and 16 those of sum e_c e_q, 24 sum min(e_c, e_q). No atomics: until r05 the items of a
 		// candidate added into ITS accumulators and cells, twenty waves at the same words at the same time, and that wait was half the kernel.
 		uint32_t v = 0;
 		if constexpr (DIV) {
@@ -772,7 +773,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			__builtin_amdgcn_wave_barrier();
 		}
 		v += lane == 1 ? v1 : lane == 2 ? v2 : lane == 3 ? v3 : lane == 9 ? v9 : lane == 10 ? v10 : 0u;
-		v = lane == 0 ? emd_t : lane == 8 ? (uint32_t)prod_t : lane == 16 ? (uint32_t)(prod_t >> 32) : lane == 24 ? mins_t : v;
+		v = lane == 0 ? (uint32_t)emd_t : lane == 32 ? (uint32_t)(emd_t >> 32) : lane == 8 ? (uint32_t)prod_t : lane == 16 ? (uint32_t)(prod_t >> 32) : lane == 24 ? mins_t : v;
 		rec[(uint64_t)it * kRkCells + lane] = v;
 		if constexpr (DIV) {
 			if (lane == 0) *reinterpret_cast<double2*>(extras + 2 * (uint64_t)it) = make_double2(xjd, xjs);
@@ -781,7 +782,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 }
 
 // A workgroup per candidate: lane l of each of the four waves adds up word l of every fourth of its items' records (rounds, then
-// repeated-bin items, as the list holds them), LDS adds the four; the integer record from words 0 / 8 / 16 / 24; DIV, first wave: lane
+// repeated-bin items, as the list holds them), LDS adds the four; the integer record from words 0 / 32 / 8 / 16 / 24; DIV, first wave: lane
 // (r, b) evaluates cell (r, b) -- row a' = candidate count a' + 2, row 7 = bins evaluated on the spot, counted as held: its lanes take the
 // query's bins with count b that the candidate does not hold --, every lane its share of the query's bins with a count >= 8 and of the
 // items' spot terms (lane l: entries l, l + 64, ..); one butterfly adds the 64 partial sums in a fixed order.
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 	if (wave) return;
 	sum += s_sum[0][lane] + s_sum[1][lane] + s_sum[2][lane];
 	{
-		const uint64_t emd = sum, p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
+		const uint64_t emd = sum + (__shfl(sum, 32, 64) << 32), p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
 		if (lane == 0) {
 			const MscSparseHdr qh = *q_hdr_p;
 			const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = mt.n;

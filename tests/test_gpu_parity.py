@@ -1490,7 +1490,7 @@ def test_cfg5_mixed_lengths_slow_features_at_k9(tmp_path, tag, run_cap, bits, ex
 def test_jitter_slow_windows_through_the_rank_form_divergences(tmp_path, extra):
     """900 sequences of 1 kb +- 100 (families of 10), k = 9, the `--feat slow` model the reference trained on them (it uses
     jefferey_divergence, predict/Feature.cpp:1231-1263), --id 0.8: every accumulate step scores a REAL length window through
-    msc_get_close_window, whose divergence sums come from the rank form (k_pair_ranks_1xm counts cells, k_rank_div_finish adds them:
+    msc_get_close_window, whose divergence sums come from the rank form (k_pair_ranks_items counts cells, k_rank_items_finish adds them:
     the same terms as the merge kernels' in another order of addition, DESIGN 4.1d). The fixture is the reference CLI's own .clstr;
     the driver reproduces it byte for byte from the dense layout (through the sparse mirror) and the sparse one -- and the library's own
     count says the passes did run over rank lists."""

@@ -22,7 +22,7 @@ f = glob.glob("$O/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"]
-    k = next((x for x in ("k_pair_ranks_items", "k_rank_items_finish", "k_rank_items_list", "k_pair_sparse_mp") if x in name), None)
+    k = next((x for x in ("k_pair_ranks_items", "k_rank_items_finish", "k_rank_pass_prep", "k_pair_sparse_mp") if x in name), None)
     if not k: continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES": n[k] += 1
