@@ -1,5 +1,5 @@
 // msc_objects.h -- the objects behind the opaque handles of include/meshclust2_hip.h and the host helpers the C-ABI translation
-// units share (msc_api.hip defines them; msc_window.hip and msc_shard.hip use them). Private to the library.
+// units share (msc_api*.hip define them; msc_window.hip and msc_shard.hip use them). Private to the library.
 #pragma once
 #include <functional>
 #include <string>
@@ -209,7 +209,7 @@ void learn_length(const msc_hist_set* s, uint64_t slot, uint64_t len);
 int slot_length(msc_ctx* ctx, const msc_hist_set* set, uint64_t slot, uint64_t* len);
 int ensure_sparse_mirror(msc_ctx* ctx, const msc_hist_set* set, const msc_hist_set** out);
 
-// the stages of the batched sparse mean (msc_api.hip; msc_shard.hip puts an exchange between them)
+// the stages of the batched sparse mean (msc_api_batch.hip; msc_shard.hip puts an exchange between them)
 int sparse_acc_prepare(msc_ctx* ctx, const MscLayout& L, uint32_t nc, uint32_t** touched_out);
 int sparse_acc_scatter(msc_ctx* ctx, const msc_hist_set* src, const uint32_t* slots, const uint32_t* seg, uint64_t P, uint32_t* touched);
 int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const uint32_t* m_of, int value_bits, uint32_t* touched, uint64_t* floor_sum_out);
@@ -217,7 +217,7 @@ int sparse_distances_to_means(msc_ctx* ctx, const msc_hist_set* pts, const std::
                               const std::vector<uint32_t>& members, uint32_t nc);
 bool needs_wide(const msc_hist_set* a, const msc_hist_set* b);
 
-// one 1 x M scoring pass (msc_api.hip): streaming kernel -> epilogue -> optional reduce
+// one 1 x M scoring pass (msc_api_score.hip): streaming kernel -> epilogue -> optional reduce
 struct ScoreRequest {
 	const msc_model* model = nullptr;
 	const msc_hist_set* cands = nullptr;

@@ -906,10 +906,9 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
 	const uint32_t per_wg = kRpBlock / 64;
 	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / lds);
-	// (MSC_RANKS_CPW=n: at least n candidates per wave, i.e. fewer workgroups for a short window. Measured on a window-bearing run,
+	// (at least n candidates per wave, i.e. fewer workgroups for a short window, was measured on a window-bearing run,
 	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
-	static const uint32_t cpw = [] { const char* e = getenv("MSC_RANKS_CPW"); return (uint32_t)(e && atoi(e) > 0 ? atoi(e) : 1); }();
-	uint32_t blocks = (m + per_wg * cpw - 1) / (per_wg * cpw);
+	uint32_t blocks = (m + per_wg - 1) / per_wg;
 	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
 	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
 	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,

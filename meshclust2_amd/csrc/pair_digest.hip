@@ -354,9 +354,8 @@ hipError_t launch_digest_multi(hipStream_t st, uint32_t S, const uint8_t* cand_d
 	if (G > m) G = m;
 	const uint64_t rest_pad = ((uint64_t)ST * G + 7) / 8 * 8;
 	const unsigned blocks = (unsigned)(rest_pad * nqg);
-	static const bool no_nt = getenv("MSC_DIGEST_NO_NT") != nullptr;
 	k_pair_digest_multi<NB, U8, TPI, EMD, DOT, TQ><<<dim3(blocks), dim3(kBlock), lds, st>>>(cand_dg, slot_bytes, cand_slots, m, q_dg, q_slot_bytes, q_slots, n_q, ST, (uint32_t)G, nqg,
-	                                                                            nqg == 1 && !no_nt, (u32x4*)partials16);
+	                                                                            nqg == 1, (u32x4*)partials16);
 	return hipGetLastError();
 }
 
@@ -379,10 +378,9 @@ hipError_t msc_launch_digest_build(hipStream_t st, const MscLayout& L, const uin
 }
 
 int msc_digest_tiles_per_step(const MscLayout& L, uint64_t max_count) {
-	static const int env = [] { const char* e = getenv("MSC_DIGEST_TPI"); return e ? atoi(e) : 0; }();
 	// two tiles per step halve the wave reductions and the partial records per byte streamed; per-lane sums then cover 32 bins
 	const bool fits = (L.nbins / 1024) % 2 == 0 && 64ull * 32 * max_count * max_count < (1ull << 32);
-	if (env == 1 || !fits) return 1;
+	if (!fits) return 1;
 	return 2;
 }
 

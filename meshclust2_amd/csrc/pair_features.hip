@@ -2018,12 +2018,8 @@ static hipError_t launch_multi_t(hipStream_t st, const MscLayout& L, const uint8
 		}
 	}
 	if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, fn, kBlock, 0) != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 2;
-	static const int policy = [] { const char* e = getenv("MSC_MULTI_GRID"); return e && e[0] == 'f' ? 1 : e && e[0] == 'o' ? 2 : 0; }();
-	uint64_t target_waves = (uint64_t)num_cus * blocks_per_cu * kWavesPerBlock;
-	if (policy == 1) target_waves = (uint64_t)num_cus * 12 * 8;
-	if (policy == 2) target_waves = (uint64_t)num_cus * 16;
+	const uint64_t target_waves = (uint64_t)num_cus * blocks_per_cu * kWavesPerBlock;
 	uint64_t G = target_waves / ((uint64_t)S * nqb);
-	if (policy == 1 && G > (m + 31) / 32) G = (m + 31) / 32;
 	if (G < 1) G = 1;
 	if (G > m) G = m;
 	const uint64_t waves = (uint64_t)S * G * nqb;

@@ -1469,7 +1469,7 @@ hipError_t msc_launch_pair_sparse_mp(hipStream_t st, const void* c_ent, const ui
 #define MSC_MP_DIV(W) if (wide) MSC_MP_DIV_T(kMpChunkWide, W); else MSC_MP_DIV_T(kMpChunk, W)
 #define MSC_MP_DIV_T(T, W) k_pair_sparse_mp<true, T, false, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, \
 		(const uint2*)q_ent, q_cum, q_hdr, q_scalars, nbins, use_window, min_len, max_len, partials, (const DivTerm*)div_tables, (double*)div_partials, order, nullptr, nullptr, parts, 0, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
-		if (wpe == 4) { MSC_MP_DIV(4); } else if (wpe == 7) { MSC_MP_DIV(7); } else { MSC_MP_DIV(6); }
+		MSC_MP_DIV(6);
 #undef MSC_MP_DIV
 #undef MSC_MP_DIV_T
 	} else if (wide) {
@@ -1490,11 +1490,8 @@ bool msc_sparse_wl_fits(uint32_t q_nnz, uint32_t c_max_nnz) {
 	static const bool no_wl = getenv("MSC_SPARSE_NO_WL") != nullptr;
 	return !no_wl && c_max_nnz && (uint64_t)q_nnz + 4ull * c_max_nnz + 10 <= 8192;
 }
-// waves per SIMD the divergence form of the merge-path kernel is compiled for and launched at (MSC_SPARSE_DIV_WAVES=4|6|7 for A/B runs)
-int msc_sparse_div_waves() {
-	static const int w = [] { const char* e = getenv("MSC_SPARSE_DIV_WAVES"); const int v = e ? atoi(e) : 6; return v == 4 || v == 7 ? v : 6; }();
-	return w;
-}
+// waves per SIMD the divergence form of the merge-path kernel is compiled for and launched at (r03: 6 against 4 and 7)
+int msc_sparse_div_waves() { return 6; }
 uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div) {
 	static const bool off = getenv("MSC_SPARSE_MP_NO_PARTS") != nullptr;
 	if (off || m == 0) return 1;
@@ -1503,8 +1500,8 @@ uint32_t msc_sparse_mp_parts(uint32_t m, uint64_t entries, int num_cus, bool div
 	if (div) {
 		// the divergence form cuts between granules, each pair by its OWN length (k_pair_sparse_mp): the launch only sets the most a
 		// pair may be cut into -- whatever the longest pair can use, unless the window alone fills the chip several times over
-		static const uint32_t cap = [] { const char* e = getenv("MSC_SPARSE_MP_MAX_PARTS"); const int v = e ? atoi(e) : 16; return (uint32_t)std::min(16, std::max(1, v)); }();
-		static const uint64_t fill = [] { const char* e = getenv("MSC_SPARSE_MP_FILL"); const int v = e ? atoi(e) : 1; return (uint64_t)std::max(1, v); }();
+		const uint32_t cap = 16;
+		const uint64_t fill = 1;
 		if ((uint64_t)m >= fill * slots) return 1;
 		while (parts < cap && (uint64_t)parts * 2 * kMpDivGran * kMpDivMinGran <= chunks && (uint64_t)m * parts * 2 <= 2 * fill * slots) parts *= 2;
 		return parts;
@@ -1564,7 +1561,7 @@ hipError_t msc_launch_pair_sparse_mp_pairs(hipStream_t st, const void* c_ent, co
 #define MSC_MP_DIVP(W) if (wide) MSC_MP_DIVP_T(kMpChunkWide, W); else MSC_MP_DIVP_T(kMpChunk, W)
 #define MSC_MP_DIVP_T(T, W) k_pair_sparse_mp<true, T, true, W><<<dim3(blocks), dim3(256), 0, st>>>((const uint2*)c_ent, c_cum, c_hdr, cand_scalars, scalar_stride, cand_slots, m, (const uint2*)q_ent, \
 		q_cum, q_hdr, q_scalars, nbins, use_window, 0, ~0ull, partials, (const DivTerm*)div_tables, (double*)div_partials, order, segs, pair_seg, 1, q_scalar_stride, div_stride, msc_sparse_mp_dma(), msc_sparse_mp_pairs())
-		if (wpe == 4) { MSC_MP_DIVP(4); } else if (wpe == 7) { MSC_MP_DIVP(7); } else { MSC_MP_DIVP(6); }
+		MSC_MP_DIVP(6);
 #undef MSC_MP_DIVP
 #undef MSC_MP_DIVP_T
 		return hipGetLastError();
