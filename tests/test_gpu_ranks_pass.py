@@ -38,7 +38,11 @@ def _sequences(seed, n, length, kind):
     for i, s in enumerate(seqs):
         s = bytes(s)
         if kind and i % 5 == 1:          # a run spliced in: bins with large counts, shared by the members that carry the same run
-            run = {"homo": b"A" * 300, "di": b"AC" * 150, "unit3": b"ACG" * 40, "unit12": b"ACGTTGCAAGTC" * 9}[kind]
+            if kind == "many":          # hundreds of DIFFERENT units, each five to twelve times over: more than 512 bins the query holds three times
+                rng = np.random.default_rng(4242)          # and more (its hash table overflows: the look-up falls back to its rank list), hundreds it holds
+                run = b"".join(bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 14)]) * int(rng.integers(5, 13)) for _ in range(160))      # >= 8 times
+            else:
+                run = {"homo": b"A" * 300, "di": b"AC" * 150, "unit3": b"ACG" * 40, "unit12": b"ACGTTGCAAGTC" * 9}[kind]
             at = 50 + 7 * (i % 40)
             s = s[:at] + run + s[at:]
         out.append(s)
@@ -58,6 +62,7 @@ def _sequences(seed, n, length, kind):
     (32, 7, 50, 400, None, "dense"),
     (16, 8, 40, 600, "unit3", "dense"),
     (16, 9, 24, 12000, "unit12", "sparse"),      # queries of more than 8 192 k-mers: their rank lists stay in global memory
+    (16, 9, 30, 3000, "many", "sparse"),          # more than 512 bins the query holds three times and more: no hash table, its rank list searched
 ])
 def test_rank_pass_against_the_oracle_and_the_merge_kernels(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
     seqs = _sequences(7000 + 13 * k + dtype, n, length, kind)
@@ -197,6 +202,8 @@ ALL_MASK = sum(1 << b for _, b in FEATS)
     (16, 8, 40, 2500, "unit12", "sparse"),
     (16, 9, 20, 12000, "homo", "sparse"),         # long lists: (candidate, round) items; runs of 300 copies across round boundaries
     (32, 9, 20, 10500, "unit3", "dense"),
+    (16, 9, 30, 3000, "many", "sparse"),          # ~1 900 bins of count >= 4 in query and candidates: hash overflow, hundreds of spot terms per item (the queue is emptied on the way), a
+                                                  # sorted list of the query's large counts longer than a wave
 ])
 def test_divergence_statistics_through_the_rank_pass(ctx, oracle, rank_pass_now, dtype, k, n, length, kind, layout):
     """jefferey_divergence / jensen_shannon (predict/Feature.cpp:1235-1262, 988-1008) counted per cell by k_pair_ranks_items and evaluated by
