@@ -58,9 +58,16 @@ static int update_centres_one_by_one(msc_ctx* ctx, const msc_model* model, doubl
 // segs[c] = {q_slot = c, first, m} over `members` (device copies are made here), pair_seg[j] = centre of member j.
 // (a) the accumulators: one 32-bit column array of 4^k bins per list, zero between calls (the write sweep re-zeroes what it read), and
 // for large k a bit per 16 bins and list that the scatter sets and the sweeps follow
+// chunks of bins per list the two sweeps of sparse_acc_sweep are cut into: a wave per (list, chunk) -- many lists bring their own
+// parallelism (about 65 536 waves in all; at least MSC_SPARSE_SUB chunks, one per index sub-range; a power of two)
+static uint32_t sparse_sweep_chunks(const MscLayout& L, uint32_t nc) {
+	uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
+	while (n_chunks > MSC_SPARSE_SUB && (uint64_t)n_chunks * nc > 65536) n_chunks /= 2;
+	return n_chunks;
+}
 int sparse_acc_prepare(msc_ctx* ctx, const MscLayout& L, uint32_t nc, uint32_t** touched_out) {
 	int r;
-	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);
+	const uint32_t n_chunks = sparse_sweep_chunks(L, nc);
 	const uint64_t chunk_bins = L.nbins / n_chunks;
 	const size_t acc_bytes = (size_t)nc * L.nbins * sizeof(uint32_t);
 	if (acc_bytes > ctx->sp_acc_batch.cap) {
@@ -103,8 +110,7 @@ int sparse_acc_sweep(msc_ctx* ctx, const msc_hist_set* pts, uint32_t nc, const u
 	// 16 bytes of offsets back -- with 1024 chunks each, a round over a million centres (BASELINE cfg3) moved 40 GB over PCIe and spent
 	// its time in the loops below (r03 profile, 200 000 x 1 kb: 24 s of update stage around 2.7 s of kernels). About 65 536 waves in
 	// all; at least 16 chunks (one per index sub-range), a power of two.
-	uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // a multiple of 16 for every sparse-capable k
-	while (n_chunks > MSC_SPARSE_SUB && (uint64_t)n_chunks * nc > 65536) n_chunks /= 2;
+	const uint32_t n_chunks = sparse_sweep_chunks(L, nc);
 	const uint64_t chunk_bins = L.nbins / n_chunks;
 	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
 	if ((r = ensure(ctx, ctx->qslots, nc * sizeof(uint32_t))) || (r = ensure(ctx, ctx->sp_counts, (size_t)nc * n_chunks * 3 * sizeof(uint64_t))) ||

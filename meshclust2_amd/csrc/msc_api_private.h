@@ -14,9 +14,11 @@ static const uint64_t kNarrowMaxSum = (1ull << 31) - 1;
 
 // MSC_PROFILE_CALLS: the library's own timers inside a call (slot list / launches / stream wait), printed at msc_destroy
 static const bool g_profile_calls = getenv("MSC_PROFILE_CALLS") != nullptr;
-// from how many bins on the sparse mean sweeps only the 64-byte lines its members touched (MSC_SPARSE_MEAN_GROUPS_MIN_K for A/B runs)
+// from how many bins on the sparse mean sweeps only the 64-byte lines its members touched (MSC_SPARSE_MEAN_GROUPS_MIN_K for A/B runs; r05: from
+// k = 9 on -- 200 000 x 1 kb: count + write sweeps 1.73 -> 0.38 ms per 4 150 centres, the update stage 1.27 -> 0.88 s; it was 11 only because the
+// two places that cut a list into chunks disagreed below that)
 static inline uint64_t msc_sparse_groups_min_bins() {
-	static const uint64_t v = [] { const char* e = getenv("MSC_SPARSE_MEAN_GROUPS_MIN_K"); const int k = e ? atoi(e) : 11; return 1ull << (2 * std::max(5, std::min(16, k))); }();
+	static const uint64_t v = [] { const char* e = getenv("MSC_SPARSE_MEAN_GROUPS_MIN_K"); const int k = e ? atoi(e) : 9; return 1ull << (2 * std::max(5, std::min(16, k))); }();
 	return v;
 }
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
