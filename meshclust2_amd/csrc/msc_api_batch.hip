@@ -306,6 +306,7 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 	                                                    want_div ? (1024ull << 20) / 4096 : ~0ull);      // (a 4 KiB table of divergence terms per pair)
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, members, where;
+	std::vector<uint64_t> seg_centre;
 	std::vector<uint8_t> keep;
 	std::vector<double> dist;
 	for (uint64_t c0 = 0; c0 < n_centres;) {
@@ -390,49 +391,60 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 			c0 = c1;
 			continue;
 		}
-		// ---- 2. survivors per centre
+		// ---- 2. survivors per centre. A centre with ONE survivor needs no mean: the survivor is the nearest (Trainer::closest over one
+		// point, cluster/Trainer.cpp:144-157) -- on BASELINE cfg3 (10^6 x 1 kb) five centres in six, round after round; only centres with
+		// two survivors and more go through step 3 (their means sit in slots 0 .. nc2 - 1 of the scratch set; seg_centre maps them back)
 		members.clear();
 		where.clear();
 		pair_seg.clear();
-		uint32_t max_m2 = 0;
+		seg_centre.clear();
+		uint32_t max_m2 = 0, nc2 = 0;
 		for (uint64_t c = c0; c < c1; c++) {
-			MscBatchSeg& sg = segs[c - c0];
-			const uint32_t first_old = sg.first, m_old = sg.m;
-			sg.q_slot = (uint32_t)(c - c0);               // slot of this centre's rounded mean in the scratch set
-			sg.first = (uint32_t)members.size();
-			for (uint32_t i = 0; i < m_old; i++)
-				if (keep[first_old + i]) { members.push_back(pt_slots[base + first_old + i]); where.push_back(i); pair_seg.push_back((uint32_t)(c - c0)); }
-			sg.m = (uint32_t)members.size() - sg.first;
+			const MscBatchSeg old = segs[c - c0];
+			const uint32_t at = (uint32_t)members.size();
+			for (uint32_t i = 0; i < old.m; i++)
+				if (keep[old.first + i]) { members.push_back(pt_slots[base + old.first + i]); where.push_back(i); pair_seg.push_back(nc2); }
+			const uint32_t m2 = (uint32_t)members.size() - at;
+			if (n_kept) n_kept[c] = m2;
+			nearest_pos[c] = -1;
+			if (m2 == 1) nearest_pos[c] = (int64_t)where[at];
+			if (m2 < 2) { members.resize(at); where.resize(at); pair_seg.resize(at); continue; }
+			MscBatchSeg& sg = segs[nc2];          // (nc2 <= c - c0: the slot has been read already)
+			sg.q_slot = nc2;                      // slot of this centre's rounded mean in the scratch set
+			sg.first = at;
+			sg.m = m2;
+			sg.pad_ = 0;
 			sg.min_len = 0;
 			sg.max_len = ~0ull;
-			max_m2 = std::max(max_m2, sg.m);
-			if (n_kept) n_kept[c] = sg.m;
-			nearest_pos[c] = -1;
+			max_m2 = std::max(max_m2, m2);
+			seg_centre.push_back(c);
+			nc2++;
 		}
+		segs.resize(nc2);
 		const uint64_t P2 = members.size();
 		if (P2 == 0) { c0 = c1; continue; }
 		// ---- 3. means of the survivors (exact integer column sums), rounded means as slots of a scratch set, distance_d of every survivor
 		if (sp) {
-			if ((r = sparse_means_and_distances(ctx, pts, segs, pair_seg, members, (uint32_t)nc))) return r;
+			if ((r = sparse_means_and_distances(ctx, pts, segs, pair_seg, members, nc2))) return r;
 		} else {
-			if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc) {
+			if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc2) {
 				if (ctx->batch_scratch) { msc_hist_set_destroy(ctx->batch_scratch); ctx->batch_scratch = nullptr; }
 				if ((r = msc_hist_set_create(ctx, pts->k, pts->dtype, std::min<uint64_t>(max_chunk_centres, std::max<uint64_t>(nc, 256)), &ctx->batch_scratch))) return r;
 			}
 			msc_hist_set* rs = ctx->batch_scratch;
-			if ((r = ensure(ctx, ctx->floor_sum, nc * sizeof(uint64_t))) || (r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) ||
+			if ((r = ensure(ctx, ctx->floor_sum, nc2 * sizeof(uint64_t))) || (r = ensure(ctx, ctx->slots, P2 * sizeof(uint32_t))) ||
 			    (r = ensure(ctx, ctx->pair_seg, P2 * sizeof(uint32_t))) || (r = ensure(ctx, ctx->partials, P2 * L.S * sizeof(MscPartial))) ||
 			    (r = ensure(ctx, ctx->dist, P2 * sizeof(double))))
 				return r;
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->segs.p, segs.data(), nc2 * sizeof(MscBatchSeg), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->pair_seg.p, pair_seg.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, members.data(), P2 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-			HIP_TRY(ctx, msc_launch_colsum_batch(ctx->stream, L, pts->dtype, pts->bins, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p, (uint32_t)nc,
+			HIP_TRY(ctx, msc_launch_colsum_batch(ctx->stream, L, pts->dtype, pts->bins, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p, nc2,
 			                                     rs->bins, (uint64_t*)ctx->floor_sum.p));
-			HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, rs->scalar_stride * nc, ctx->stream));
-			HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, pts->dtype, 0, nc, false));
+			HIP_TRY(ctx, hipMemsetAsync(rs->scalars, 0, rs->scalar_stride * nc2, ctx->stream));
+			HIP_TRY(ctx, msc_launch_finalize(ctx->stream, rs->bins, rs->scalars, L, pts->dtype, 0, nc2, false));
 			HIP_TRY(ctx, msc_launch_pair_tiles_batch(ctx->stream, L, pts->dtype, pts->bins, pts->scalars, (const uint32_t*)ctx->slots.p, (const MscBatchSeg*)ctx->segs.p,
-			                                         (uint32_t)nc, max_m2, rs->bins, rs->L.slot_bytes, rs->scalars, rs->scalar_stride, 0, (MscPartial*)ctx->partials.p,
+			                                         nc2, max_m2, rs->bins, rs->L.slot_bytes, rs->scalars, rs->scalar_stride, 0, (MscPartial*)ctx->partials.p,
 			                                         MSC_ORDER_CAND_FIRST));
 			HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)P2, pts->scalars, pts->scalar_stride,
 			                                       (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, rs->scalars, rs->scalar_stride,
@@ -442,12 +454,11 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 		HIP_TRY(ctx, hipMemcpyAsync(dist.data(), ctx->dist.p, P2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		// first minimum wins (cluster/Trainer.cpp:150-153)
-		for (uint64_t c = c0; c < c1; c++) {
-			const MscBatchSeg& sg = segs[c - c0];
-			if (sg.m == 0) continue;
+		for (uint32_t j = 0; j < nc2; j++) {
+			const MscBatchSeg& sg = segs[j];
 			uint32_t best = 0;
 			for (uint32_t i = 1; i < sg.m; i++) if (dist[sg.first + i] < dist[sg.first + best]) best = i;
-			nearest_pos[c] = (int64_t)where[sg.first + best];
+			nearest_pos[seg_centre[j]] = (int64_t)where[sg.first + best];
 		}
 		c0 = c1;
 	}

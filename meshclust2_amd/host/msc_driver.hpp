@@ -232,6 +232,8 @@ struct Cluster {
 	uint32_t centre = 0;         // backend handle of the centre histogram (a clone of a point, possibly moved by set())
 	std::string header;
 	uint64_t id = 0, length = 0;
+	uint32_t centre_point = 0;   // the point the centre histogram was cloned from or last set() to: a set() to the same point again changes nothing
+	                             // (bins, length, id of that point; the magnitude stays whatever it was) and is skipped
 	std::vector<SeqRecord*> members;
 	bool merged_away = false;
 };
@@ -324,7 +326,7 @@ private:
 		for (size_t i = 0; i < v.size(); i++) h[i] = v[i]->point;
 		return h;
 	}
-	void move_centre(Cluster& cl, const SeqRecord* next) { cl.header = next->header; cl.id = next->id; cl.length = next->length; }
+	void move_centre(Cluster& cl, const SeqRecord* next) { cl.header = next->header; cl.id = next->id; cl.length = next->length; cl.centre_point = next->point; }
 
 	// accumulate (cluster/ClusterFactory.cpp:553-610): grow one cluster from *seed until a pass finds nothing close
 	void accumulate(SeqRecord** seed, LengthBins& store, std::vector<Cluster>& part, double sim) {
@@ -468,7 +470,7 @@ private:
 				std::vector<uint32_t> dst, src;
 				for (size_t j = 0; j < n; j++) {
 					SeqRecord* next = nearest[j] >= 0 ? good[(size_t)(offsets[j] + (uint64_t)nearest[j])] : (delta == 0 ? part[j].members[0] : nullptr);
-					if (!next) continue;
+					if (!next || next->point == part[j].centre_point) continue;          // (BASELINE cfg3: five centres in six sit on their only member, round after round)
 					dst.push_back(part[j].centre);
 					src.push_back(next->point);
 					move_centre(part[j], next);
@@ -491,7 +493,7 @@ private:
 			SeqRecord* next = nullptr;
 			if (!good.empty()) next = good[(size_t)be_.closest(handles(good))];
 			else if (delta == 0) next = cl.members[0];
-			if (next) { be_.centre_set(cl.centre, next->point); move_centre(cl, next); }
+			if (next && next->point != cl.centre_point) { be_.centre_set(cl.centre, next->point); move_centre(cl, next); }
 		}
 	}
 
