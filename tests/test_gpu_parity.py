@@ -1550,17 +1550,17 @@ def test_cluster_driver_compacts_its_sparse_centre_store(tmp_path, monkeypatch, 
     golden = os.path.join(root, "tests", "golden")
     args = [fa, "--recover", os.path.join(golden, "weights_k9_u8.txt"), "--id", "0.9", "--output", out, "--sparse"]
     if ranks == 1:
-        env = dict(os.environ, MSC_CLUSTER_CENTRE_ARENA="60000", MSC_CLUSTER_PROFILE="1")
+        env = dict(os.environ, MSC_CLUSTER_CENTRE_ARENA="48000", MSC_CLUSTER_PROFILE="1")          # (r05: a set() to the point a centre already holds appends nothing: the arena is tighter than it was)
         r = subprocess.run([os.path.join(root, "meshclust2_amd", "host", "msc_cluster")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
         log = r.stdout.decode(errors="replace")
         assert r.returncode == 0, log[-2000:]
     else:          # every rank keeps the whole centre store (msc::GpuShardEngine): the same two standing stores there
-        monkeypatch.setenv("MSC_CLUSTER_CENTRE_ARENA", "100000")      # (the engine moves a round's centres in one batch: room for the live lists + one round)
+        monkeypatch.setenv("MSC_CLUSTER_CENTRE_ARENA", "56000")       # (the engine moves a round's centres in one batch: room for the live lists + one round)
         monkeypatch.setenv("MSC_CLUSTER_PROFILE", "1")
         rcs, log, logs = _cluster_ranks(args, ranks, tmp_path, block=40)
         assert all(rc == 0 for rc in rcs), "\n".join(logs)[-3000:]
     m = re.search(r"centre store: rebuilt (\d+) times", log)
-    assert m and int(m.group(1)) >= 2, log[-1500:]
+    assert m and int(m.group(1)) >= (2 if ranks == 1 else 1), log[-1500:]          # (r05: centres that stay on their point append nothing; the batch engine's arena cannot go lower)
     got, exp = open(out, "rb").read(), open(os.path.join(golden, "k9_u8.clstr"), "rb").read()
     assert got == exp, "CLSTR differs: %d vs %d bytes" % (len(got), len(exp))
 
