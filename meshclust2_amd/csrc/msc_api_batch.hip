@@ -311,7 +311,11 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 	std::vector<double> dist;
 	for (uint64_t c0 = 0; c0 < n_centres;) {
 		uint64_t c1 = c0;
-		while (c1 < n_centres && c1 - c0 < max_chunk_centres && (c1 == c0 || offsets[c1 + 1] - offsets[c0] <= max_chunk_pairs)) c1++;
+		// (sparse sets: the accumulators bound step 3 only -- it takes its centres in sub-chunks; the filter of step 1 takes as many as its pair
+		// budget holds. r05: at k = 13 a chunk of 64 centres -- 256 MiB of accumulator each -- was the unit of the WHOLE loop: 414 chunks per
+		// round of BASELINE cfg4, a handful of launches and host round trips each, 4.8 s of a 14.5 s run)
+		const uint64_t outer_cap = sp ? std::max<uint64_t>(max_chunk_centres, 65536) : max_chunk_centres;
+		while (c1 < n_centres && c1 - c0 < outer_cap && (c1 == c0 || offsets[c1 + 1] - offsets[c0] <= max_chunk_pairs)) c1++;
 		const uint64_t nc = c1 - c0, base = offsets[c0], P = offsets[c1] - base;
 		// ---- 1. filter: every centre against its list
 		segs.resize(nc);
@@ -424,8 +428,23 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 		const uint64_t P2 = members.size();
 		if (P2 == 0) { c0 = c1; continue; }
 		// ---- 3. means of the survivors (exact integer column sums), rounded means as slots of a scratch set, distance_d of every survivor
+		dist.resize(P2);
 		if (sp) {
-			if ((r = sparse_means_and_distances(ctx, pts, segs, pair_seg, members, nc2))) return r;
+			std::vector<MscBatchSeg> sub_segs;
+			std::vector<uint32_t> sub_pair, sub_members;
+			for (uint32_t j0 = 0; j0 < nc2;) {
+				const uint32_t j1 = (uint32_t)std::min<uint64_t>(nc2, j0 + max_chunk_centres);
+				const uint32_t f0 = segs[j0].first, f1 = j1 < nc2 ? segs[j1].first : (uint32_t)P2;
+				sub_segs.assign(segs.begin() + j0, segs.begin() + j1);
+				for (MscBatchSeg& sg : sub_segs) { sg.q_slot -= j0; sg.first -= f0; }
+				sub_members.assign(members.begin() + f0, members.begin() + f1);
+				sub_pair.assign(pair_seg.begin() + f0, pair_seg.begin() + f1);
+				for (uint32_t& x : sub_pair) x -= j0;
+				if ((r = sparse_means_and_distances(ctx, pts, sub_segs, sub_pair, sub_members, j1 - j0))) return r;
+				HIP_TRY(ctx, hipMemcpyAsync(dist.data() + f0, ctx->dist.p, (size_t)(f1 - f0) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+				j0 = j1;
+			}
 		} else {
 			if (!ctx->batch_scratch || ctx->batch_scratch->k != pts->k || ctx->batch_scratch->dtype != pts->dtype || ctx->batch_scratch->capacity < nc2) {
 				if (ctx->batch_scratch) { msc_hist_set_destroy(ctx->batch_scratch); ctx->batch_scratch = nullptr; }
@@ -449,10 +468,9 @@ static int update_centres_impl(msc_ctx* ctx, const msc_model* model, double cuto
 			HIP_TRY(ctx, msc_launch_distance_batch(ctx->stream, (const MscPartial*)ctx->partials.p, L.S, (uint32_t)P2, pts->scalars, pts->scalar_stride,
 			                                       (const uint32_t*)ctx->slots.p, (const uint32_t*)ctx->pair_seg.p, rs->scalars, rs->scalar_stride,
 			                                       (const uint64_t*)ctx->floor_sum.p, (double*)ctx->dist.p));
+			HIP_TRY(ctx, hipMemcpyAsync(dist.data(), ctx->dist.p, P2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		}
-		dist.resize(P2);
-		HIP_TRY(ctx, hipMemcpyAsync(dist.data(), ctx->dist.p, P2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		// first minimum wins (cluster/Trainer.cpp:150-153)
 		for (uint32_t j = 0; j < nc2; j++) {
 			const MscBatchSeg& sg = segs[j];
