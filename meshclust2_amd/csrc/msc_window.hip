@@ -59,10 +59,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 }
 
 // one workgroup lists the alive positions of [first, first + range) in order: thread t takes a contiguous run
-__global__ void __launch_bounds__(kWinBlock) k_window_compact_one(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
-                                                                  uint32_t* __restrict__ slots, uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter) {
+// (r05: the kills on file -- positions msc_window_kill took out of the tree since the last pass -- reach the alive flags HERE, ahead of
+// the compaction that reads them: a launch of their own was one of a step's eight)
+__global__ void __launch_bounds__(kWinBlock) k_window_compact_one(uint8_t* alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
+                                                                  uint32_t* __restrict__ slots, uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter,
+                                                                  const uint32_t* __restrict__ kills, uint32_t n_kills) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
 	if (threadIdx.x == 0) *close_counter = 0;      // k_window_close counts from zero (a memset command of its own was 4 us of every step)
+	if (n_kills) {
+		for (uint32_t i = threadIdx.x; i < n_kills; i += kWinBlock) alive[kills[i]] = 0;
+		__threadfence_block();
+		__syncthreads();
+	}
 	const uint32_t per = (range + kWinBlock - 1) / kWinBlock;
 	const uint32_t lo = min(range, threadIdx.x * per), hi = min(range, lo + per);
 	uint32_t c = 0;
@@ -74,8 +82,20 @@ __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(const uint8_t*
 }
 
 // the same over many workgroups: counts per block, then every block adds up the counts in front of it
-__global__ void __launch_bounds__(kWinBlock) k_window_count(const uint8_t* __restrict__ alive, uint32_t first, uint32_t range, uint32_t* __restrict__ counts) {
+// (the kills on file: every block applies those of its own tile before it counts; block 0 those outside the range as well -- nobody
+// of this pass reads them)
+__global__ void __launch_bounds__(kWinBlock) k_window_count(uint8_t* alive, uint32_t first, uint32_t range, uint32_t* __restrict__ counts, const uint32_t* __restrict__ kills,
+                                                            uint32_t n_kills) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
+	if (n_kills) {
+		const uint32_t t_lo = first + blockIdx.x * (blockDim.x * kWinPer), t_hi = t_lo + blockDim.x * kWinPer;
+		for (uint32_t i = threadIdx.x; i < n_kills; i += blockDim.x) {
+			const uint32_t p = kills[i];
+			if ((p >= t_lo && p < t_hi) || (blockIdx.x == 0 && (p < first || p >= first + range))) alive[p] = 0;
+		}
+		__threadfence_block();
+		__syncthreads();
+	}
 	const uint32_t base = blockIdx.x * (blockDim.x * kWinPer) + threadIdx.x * kWinPer;
 	uint32_t c = 0;
 #pragma unroll
@@ -118,10 +138,6 @@ __global__ void __launch_bounds__(256) k_window_close(const uint8_t* __restrict_
 	out[2 + atomicAdd(counter, 1u)] = p;
 }
 
-__global__ void k_window_kill(uint8_t* __restrict__ alive, const uint32_t* __restrict__ positions, uint32_t n) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) alive[positions[i]] = 0;
-}
 
 void fen_add(std::vector<uint32_t>& f, uint64_t i, int d) { for (i++; i < f.size(); i += i & (~i + 1)) f[i] = (uint32_t)((int64_t)f[i] + d); }
 uint64_t fen_prefix(const std::vector<uint32_t>& f, uint64_t i) { uint64_t s = 0; for (; i > 0; i -= i & (~i + 1)) s += f[i]; return s; }
@@ -196,12 +212,15 @@ extern "C" int msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* posi
 	return MSC_OK;
 }
 
-// the kills on file reach the device flags (queued on the ctx stream, ahead of whatever reads d_alive next)
-static int flush_kills(msc_ctx* ctx, msc_window* w) {
+// the kills on file go to the page-locked list the next compaction kernel reads (it applies them ahead of its own reads of d_alive);
+// *d_list / *n_out: what to hand that kernel
+static int stage_kills(msc_ctx* ctx, msc_window* w, const uint32_t** d_list_out, uint32_t* n_out) {
+	*d_list_out = nullptr;
+	*n_out = 0;
 	if (w->pending.empty()) return MSC_OK;
 	const uint64_t n = w->pending.size();
 	// the list sits in page-locked memory the kernel reads directly (a pageable hipMemcpyAsync of a handful of words was a copy command
-	// and a staging stall per step); it stays untouched until the next flush, which comes after the stream was waited for by a scoring call
+	// and a staging stall per step); it stays untouched until the next pass, which comes after the stream was waited for by this one
 	if (w->d_kill_cap < n) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (w->d_kill) (void)hipHostFree(w->d_kill);
@@ -209,15 +228,13 @@ static int flush_kills(msc_ctx* ctx, msc_window* w) {
 		w->d_kill_cap = std::max<uint64_t>(2 * n, 4096);
 		HIP_TRY(ctx, hipHostMalloc((void**)&w->d_kill, w->d_kill_cap * 4, hipHostMallocDefault));
 	}
-	if (!w->ev_kill) HIP_TRY(ctx, hipEventCreateWithFlags(&w->ev_kill, hipEventDisableTiming));
-	else HIP_TRY(ctx, hipEventSynchronize(w->ev_kill));          // (already complete whenever a scoring call waited for the stream in between)
+	if (w->ev_kill) HIP_TRY(ctx, hipEventSynchronize(w->ev_kill));          // (already complete: every pass ends with a wait for the stream)
 	memcpy(w->d_kill, w->pending.data(), n * 4);
 	w->pending.clear();
 	uint32_t* d_list = nullptr;
 	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_list, w->d_kill, 0));
-	k_window_kill<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_alive, d_list, (uint32_t)n);
-	HIP_TRY(ctx, hipEventRecord(w->ev_kill, ctx->stream));
-	HIP_TRY(ctx, hipGetLastError());
+	*d_list_out = d_list;
+	*n_out = (uint32_t)n;
 	return MSC_OK;
 }
 
@@ -234,20 +251,26 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	int r;
 	uint64_t qlen = 0;
 	if ((r = slot_length(ctx, qset, q_slot, &qlen))) return r;
-	if ((r = flush_kills(ctx, w))) return r;
+	const uint32_t* d_kills = nullptr;
+	uint32_t n_kills = 0;
+	if ((r = stage_kills(ctx, w, &d_kills, &n_kills))) return r;
 	const uint32_t range = (uint32_t)(end - first);
 	// One workgroup walking the range alone takes 50 us for 40 000 positions (a third of a step on a window-bearing set: profiles/
 	// r04_notes.md); from a few thousand positions on, many small workgroups count and then write (2 launches of a few us)
 	if (range <= 4 * kWinBlock) {
-		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
+		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, d_kills, n_kills);
 	} else {
 		const uint32_t tb = range <= 64 * kWinTile ? 256 : kWinBlock, tile = tb * kWinPer;
 		const uint32_t blocks = (range + tile - 1) / tile;
 		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
-		k_window_count<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts);
+		k_window_count<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts, d_kills, n_kills);
 		k_window_write<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
 	}
 	HIP_TRY(ctx, hipGetLastError());
+	if (n_kills) {          // (the list is rewritten only once this kernel is through)
+		if (!w->ev_kill) HIP_TRY(ctx, hipEventCreateWithFlags(&w->ev_kill, hipEventDisableTiming));
+		HIP_TRY(ctx, hipEventRecord(w->ev_kill, ctx->stream));
+	}
 	if (w->h_close_cap < m + 2) {
 		if (w->h_close) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipHostFree(w->h_close)); w->h_close = nullptr; w->h_close_cap = 0; }
 		const uint64_t cap = std::max<uint64_t>(m + 2, std::min<uint64_t>(w->n + 2, 2 * w->h_close_cap + 4096));
