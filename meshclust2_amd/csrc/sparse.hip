@@ -490,10 +490,12 @@ __global__ void __launch_bounds__(256) k_sparse_assign_batch(uint2* __restrict__
 // then swept in index order: chunk counts -> host prefix -> ordered write of the rounded mean as a sparse slot.
 __global__ void __launch_bounds__(256) k_sparse_scatter(const uint2* __restrict__ ent, const MscSparseHdr* __restrict__ hdr,
                                                         const uint32_t* __restrict__ slots, uint32_t m, uint32_t* __restrict__ acc) {
+	// (a member's list is shared by gridDim.y workgroups: with one per member the two or three long members of a cfg5 cluster were forty
+	// dependent load -> atomic turns each, 25 us of every `closest` call)
 	const uint32_t j = blockIdx.x;
 	if (j >= m) return;
 	const MscSparseHdr h = hdr[slots ? slots[j] : j];
-	for (uint32_t t = threadIdx.x; t < h.nnz; t += blockDim.x) {
+	for (uint32_t t = blockIdx.y * blockDim.x + threadIdx.x; t < h.nnz; t += gridDim.y * blockDim.x) {
 		const uint2 e = ent[h.off + t];
 		atomicAdd(&acc[e.x], e.y - 1u);
 	}
@@ -1330,7 +1332,8 @@ hipError_t msc_launch_pair_sparse(hipStream_t st, const void* c_ent, const uint3
 
 hipError_t msc_launch_sparse_scatter(hipStream_t st, const void* ent, const MscSparseHdr* hdr, const uint32_t* slots, uint32_t m, uint32_t* acc) {
 	if (m == 0) return hipSuccess;
-	k_sparse_scatter<<<dim3(m), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, m, acc);
+	const uint32_t parts = std::max<uint32_t>(1, std::min<uint32_t>(32, 512 / m));          // (about 512 workgroups: few members -> many parts each)
+	k_sparse_scatter<<<dim3(m, parts), dim3(256), 0, st>>>((const uint2*)ent, hdr, slots, m, acc);
 	return hipGetLastError();
 }
 
