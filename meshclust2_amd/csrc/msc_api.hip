@@ -171,6 +171,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->rk_guard) (void)hipHostFree(ctx->rk_guard);
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
+	if (ctx->pin_parts.p) (void)hipHostFree(ctx->pin_parts.p);
 	release(ctx->segs);
 	release(ctx->pair_seg);
 	release(ctx->dist);

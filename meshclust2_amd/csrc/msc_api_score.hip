@@ -328,6 +328,8 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	int first_err = 0;
 	if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev_all0, ctx->stream));
 	if (g_profile_calls) { ctx->prof_calls++; ctx->prof_cands += m; ctx->prof_prep += now_s() - t_call; }
+	bool fold_on_host = false;
+	uint32_t n_parts_host = 0;
 	for (uint64_t off = 0; off < m; off += chunk) {
 		const double t_issue = g_profile_calls ? now_s() : 0;
 		const uint32_t mc = (uint32_t)std::min(chunk, m - off);
@@ -424,7 +426,15 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 			if ((r = ensure(ctx, ctx->reduce_parts, msc_reduce_scratch_bytes())) != MSC_OK) return r;
 			uint8_t* d_flags = rq.dev_flags_out ? rq.dev_flags_out : rq.flags_out ? down + kRo : nullptr;
 			if (fused) {
-				HIP_TRY(ctx, msc_launch_epilogue_reduce(ctx->stream, ea, rq.reduce_mode, rq.reduce_begin, d_flags, (MscReduceOut*)down, ctx->reduce_parts.p, rq.close_list));
+				// (the step-serial loop's own call: the workgroups' parts go to page-locked memory and are folded here, behind the wait for the
+				// stream -- k_pair_reduce_fold2 was one of a pass's launches)
+				ReducePart* host_parts = nullptr;
+				if (rq.close_list.pos && rq.close_list.out_host && off == 0 && mc == m) {
+					if ((r = ensure_pinned(ctx, ctx->pin_parts, 1024 * sizeof(ReducePart))) != MSC_OK) return r;
+					HIP_TRY(ctx, hipHostGetDevicePointer((void**)&host_parts, ctx->pin_parts.p, 0));
+				}
+				fold_on_host = host_parts != nullptr;
+				HIP_TRY(ctx, msc_launch_epilogue_reduce(ctx->stream, ea, rq.reduce_mode, rq.reduce_begin, d_flags, (MscReduceOut*)down, ctx->reduce_parts.p, rq.close_list, host_parts, &n_parts_host));
 				if (rq.after_reduce && !rq.close_list.pos) HIP_TRY(ctx, rq.after_reduce((const MscReduceOut*)down));
 			} else {
 				HIP_TRY(ctx, msc_launch_reduce(ctx->stream, (const MscPairOut*)ctx->pair_out.p, mc, rq.reduce_mode, rq.reduce_begin, d_flags, (MscReduceOut*)down, ctx->reduce_parts.p));
@@ -442,7 +452,12 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 		const double t_wait = g_profile_calls ? now_s() : 0;
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (g_profile_calls) { ctx->prof_issue += t_wait - t_issue; ctx->prof_wait += now_s() - t_wait; }
-		if (rq.reduce_mode >= 0) {
+		if (rq.reduce_mode >= 0 && fold_on_host) {
+			uint32_t wpos = 0;
+			msc_reduce_fold_host((const ReducePart*)ctx->pin_parts.p, n_parts_host, rq.reduce_mode, rq.reduce_host, &wpos);
+			rq.close_list.out_host[0] = wpos;
+			if (rq.flags_out) memcpy(rq.flags_out, (const uint8_t*)ctx->pin_down.p + 64, mc);
+		} else if (rq.reduce_mode >= 0) {
 			constexpr size_t kRo = 64;
 			memcpy(rq.reduce_host, ctx->pin_down.p, sizeof(MscReduceOut));
 			if (rq.flags_out) memcpy(rq.flags_out, (const uint8_t*)ctx->pin_down.p + kRo, mc);

@@ -254,9 +254,16 @@ struct MscCloseList {
 	uint8_t* alive;
 	uint32_t* counter;
 	uint32_t* out;
+	uint32_t* out_host = nullptr;      // the host's own pointer to `out` (page-locked memory the device addresses)
 };
+// what a workgroup of the fused epilogue + reduce kernel leaves of its candidates: its best (index and, in a window pass, position + 1), its count of
+// close ones, its first error. Folded by k_pair_reduce_fold2 -- or, host_parts != nullptr (page-locked, device-addressable), by the caller
+// once it has waited for the stream: a launch less per pass of the step-serial loop.
+struct ReducePart { double sim; int64_t pos; unsigned long long nclose; int err; uint32_t wpos; };
 hipError_t msc_launch_epilogue_reduce(hipStream_t st, const MscEpilogueArgs& a, int mode, int64_t begin, uint8_t* flags_out, MscReduceOut* out, void* parts_scratch,
-                                      const MscCloseList& cl);
+                                      const MscCloseList& cl, ReducePart* host_parts = nullptr, uint32_t* n_parts_out = nullptr);
+// ... the fold of those parts on the host (the arithmetic of k_pair_reduce_fold2); *wpos_out = the best candidate's window position + 1 (0: none)
+void msc_reduce_fold_host(const ReducePart* parts, uint32_t n_parts, int mode, MscReduceOut* out, uint32_t* wpos_out);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
                              uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);
 size_t msc_reduce_scratch_bytes();

@@ -294,7 +294,7 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 		k_window_close<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream>>>(w->d_flags, w->d_pos, (uint32_t)m, w->d_alive, counter, d_rec, d_out);
 		return hipGetLastError();
 	};
-	rq.close_list = MscCloseList{w->d_pos, w->d_alive, counter, d_out};
+	rq.close_list = MscCloseList{w->d_pos, w->d_alive, counter, d_out, w->h_close};
 	(void)win_get_id;
 	if ((r = run_score(ctx, rq))) return r;
 	*n_close = ro.n_close;

@@ -1439,7 +1439,6 @@ __global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restri
 // The same in two stages for long windows (one workgroup walking 100 000 records and writing their flags took 50 us behind a 320 us
 // kernel): workgroup b folds records [b * per, (b + 1) * per) into parts[b]; k_pair_reduce_fold folds the parts. `better` breaks
 // ties by position, so the order of folding does not matter.
-struct ReducePart { double sim; int64_t pos; unsigned long long nclose; int err; int pad_; };
 __global__ void __launch_bounds__(1024) k_pair_reduce_part(const MscPairOut* __restrict__ po, uint32_t m, uint32_t per, int mode, int64_t begin,
                                                            uint8_t* __restrict__ flags_out, ReducePart* __restrict__ parts) {
 	__shared__ Best s_best[1024];
@@ -1474,7 +1473,7 @@ __global__ void __launch_bounds__(1024) k_pair_reduce_part(const MscPairOut* __r
 	}
 	if (threadIdx.x == 0) {
 		ReducePart r;
-		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err; r.pad_ = 0;
+		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err; r.wpos = 0;
 		parts[blockIdx.x] = r;
 	}
 }
@@ -1563,7 +1562,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_reduce_part(const MscE
 	}
 	if (threadIdx.x == 0) {
 		ReducePart r;
-		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err; r.pad_ = 0;
+		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err;
+		r.wpos = cl.pos && s_best[0].pos >= 0 ? cl.pos[s_best[0].pos] + 1 : 0u;
 		parts[blockIdx.x] = r;
 	}
 }
@@ -2155,14 +2155,38 @@ hipError_t msc_launch_epilogue(hipStream_t st, const MscEpilogueArgs& a) {
 // epilogue + reduction (+ the window's close pass) of a 1 x M pass whose records are MscPartial (a.S of them per pair, <= 4) in two
 // launches; parts_scratch: msc_reduce_scratch_bytes()
 hipError_t msc_launch_epilogue_reduce(hipStream_t st, const MscEpilogueArgs& a, int mode, int64_t begin, uint8_t* flags_out, MscReduceOut* out, void* parts_scratch,
-                                      const MscCloseList& cl) {
+                                      const MscCloseList& cl, ReducePart* host_parts, uint32_t* n_parts_out) {
 	if (a.m == 0 || a.S > 4 || a.partials16 || a.partials_cq || a.kb_min || !parts_scratch) return hipErrorInvalidValue;
 	const uint32_t n_parts = std::min<uint32_t>(1024, (a.m + kBlock - 1) / kBlock);
-	k_pair_epilogue_reduce_part<<<dim3(n_parts), dim3(kBlock), 0, st>>>(a, mode, begin, flags_out, (ReducePart*)parts_scratch, cl);
+	if (n_parts_out) *n_parts_out = n_parts;
+	k_pair_epilogue_reduce_part<<<dim3(n_parts), dim3(kBlock), 0, st>>>(a, mode, begin, flags_out, host_parts ? host_parts : (ReducePart*)parts_scratch, cl);
 	hipError_t e = hipGetLastError();
-	if (e != hipSuccess) return e;
+	if (e != hipSuccess || host_parts) return e;
 	k_pair_reduce_fold2<<<dim3(1), dim3(256), 0, st>>>((const ReducePart*)parts_scratch, n_parts, mode, out, cl);
 	return hipGetLastError();
+}
+
+void msc_reduce_fold_host(const ReducePart* parts, uint32_t n_parts, int mode, MscReduceOut* out, uint32_t* wpos_out) {
+	double sim = mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 0.0;
+	int64_t pos = -1;
+	uint32_t wpos = 0;
+	unsigned long long nclose = 0;
+	int err = 0;
+	for (uint32_t i = 0; i < n_parts; i++) {          // (better() of the device code, part by part)
+		const ReducePart& p = parts[i];
+		bool take;
+		if (mode == MSC_REDUCE_GET_CLOSE) take = p.sim > sim || (p.sim == sim && p.pos >= 0 && (pos < 0 || p.pos < pos));
+		else take = p.pos >= 0 && (pos < 0 || p.sim > sim || (p.sim == sim && p.pos > pos));
+		if (take) { sim = p.sim; pos = p.pos; wpos = p.wpos; }
+		nclose += p.nclose;
+		if (p.err < err) err = p.err;
+	}
+	out->best_sim = pos >= 0 ? sim : (mode == MSC_REDUCE_GET_CLOSE ? -1.0 : 2.2250738585072014e-308);
+	out->best_pos = pos >= 0 ? pos : (mode == MSC_REDUCE_GET_CLOSE ? -1 : 0);
+	out->any_close = nclose > 0;
+	out->n_close = nclose;
+	out->first_error = err;
+	if (wpos_out) *wpos_out = pos >= 0 ? wpos : 0u;
 }
 
 // parts_scratch (optional, msc_reduce_scratch_bytes()): long windows are folded by up to 256 workgroups first (1 024 in the fused form)
