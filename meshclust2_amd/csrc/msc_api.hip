@@ -172,6 +172,7 @@ extern "C" void msc_destroy(msc_ctx* ctx) {
 	if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
 	if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
 	if (ctx->pin_parts.p) (void)hipHostFree(ctx->pin_parts.p);
+	if (ctx->pin_mean.p) (void)hipHostFree(ctx->pin_mean.p);
 	release(ctx->segs);
 	release(ctx->pair_seg);
 	release(ctx->dist);

@@ -654,16 +654,33 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 		if ((r = msc_hist_set_create_sparse(ctx, set->k, set->dtype, 1, std::max<uint64_t>(upper + 1, 1 << 16), &ctx->sparse_mean_set))) return r;
 	}
 	msc_hist_set* rs = ctx->sparse_mean_set;
-	if (member_slots) {
-		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, member_slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	}
-	const uint32_t* d_slots = member_slots ? (const uint32_t*)ctx->slots.p : nullptr;
 	const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(1024, L.nbins / 256);      // multiple of 16 for every k >= 6
 	const uint64_t chunk_bins = L.nbins / n_chunks;
-	if ((r = ensure(ctx, ctx->sp_counts, std::max<size_t>(n_chunks * 3 * sizeof(uint64_t), ctx->sp_counts.cap)))) return r;
-	if ((r = ensure(ctx, ctx->sp_chunk_off, n_chunks * sizeof(uint64_t)))) return r;
-	if ((r = ensure(ctx, ctx->sp_chunk_cum, n_chunks * sizeof(uint64_t)))) return r;
+	// r05: what the call hands to and fro in small pieces -- the chunk counts (device -> host), the chunks' offsets and running sums,
+	// the floor sum, the mean's header and scalar record (host -> device), the reduce record (device -> host) -- sits in ONE page-locked
+	// block the kernels address directly; eight staged copies of a few bytes to a few KiB each were a quarter of a `closest` call
+	// (cfg5's shape: 141 us per call, 2.5 s of the run). Only the header and the scalar record, which the set's own arrays must hold,
+	// and the member slots are still copied (from page-locked memory: no staging).
+	struct PinLayout { size_t counts, off, cb, floor_sum, ro, hdr, sc, slots, bytes; } pl;
+	pl.counts = 0;
+	pl.off = pl.counts + (size_t)n_chunks * 3 * sizeof(uint64_t);
+	pl.cb = pl.off + (size_t)n_chunks * sizeof(uint64_t);
+	pl.floor_sum = pl.cb + (size_t)n_chunks * sizeof(uint64_t);
+	pl.ro = pl.floor_sum + 64;
+	pl.hdr = pl.ro + 64;
+	pl.sc = pl.hdr + ((sizeof(MscSparseHdr) + 63) & ~(size_t)63);
+	pl.slots = pl.sc + ((sizeof(MscSlotScalars) + 63) & ~(size_t)63);
+	pl.bytes = pl.slots + (member_slots ? m * sizeof(uint32_t) : 0);
+	if ((r = ensure_pinned(ctx, ctx->pin_mean, pl.bytes))) return r;
+	uint8_t *pin_h = (uint8_t*)ctx->pin_mean.p, *pin_d = nullptr;
+	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&pin_d, ctx->pin_mean.p, 0));
+	if (member_slots) {
+		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t)))) return r;
+		memcpy(pin_h + pl.slots, member_slots, m * sizeof(uint32_t));          // (the previous call's copy has completed: every call ends in a wait for the stream)
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->slots.p, pin_h + pl.slots, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	}
+	const uint32_t* d_slots = member_slots ? (const uint32_t*)ctx->slots.p : nullptr;
+	uint64_t* d_counts = (uint64_t*)(pin_d + pl.counts);
 	// k >= 11: the kernels of the batched form with one centre, whose sweeps visit touched 64-byte lines only
 	static const bool no_groups = getenv("MSC_SPARSE_MEAN_NO_GROUPS") != nullptr;
 	const bool grouped = !no_groups && L.nbins >= msc_sparse_groups_min_bins() && chunk_bins % 512 == 0 && member_slots;
@@ -680,14 +697,14 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 		HIP_TRY(ctx, msc_launch_sparse_scatter_batch(ctx->stream, set->ent, set->hdr, d_slots, (const uint32_t*)ctx->pair_seg.p, m32, L.nbins, (uint32_t*)ctx->sp_acc.p,
 		                                             (uint32_t*)ctx->sp_touched.p));
 		HIP_TRY(ctx, msc_launch_sparse_mean_count_batch(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, L.nbins, n_chunks, chunk_bins, 1, (const uint32_t*)ctx->qslots.p,
-		                                                (uint64_t*)ctx->sp_counts.p, (const uint32_t*)ctx->sp_touched.p));
+		                                                d_counts, (const uint32_t*)ctx->sp_touched.p));
 	} else {
 	HIP_TRY(ctx, msc_launch_sparse_scatter(ctx->stream, set->ent, set->hdr, d_slots, (uint32_t)m, (uint32_t*)ctx->sp_acc.p));
-	HIP_TRY(ctx, msc_launch_sparse_mean_count(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (uint64_t*)ctx->sp_counts.p));
+	HIP_TRY(ctx, msc_launch_sparse_mean_count(ctx->stream, set->dtype, (const uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, d_counts));
 	}
-	std::vector<uint64_t> counts(n_chunks * 3), off(n_chunks), cb(n_chunks);
-	HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->sp_counts.p, counts.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const uint64_t* counts = (const uint64_t*)(pin_h + pl.counts);
+	uint64_t *off = (uint64_t*)(pin_h + pl.off), *cb = (uint64_t*)(pin_h + pl.cb);
 	MscSparseHdr h{};
 	uint64_t n = 0, ex = 0, fl = 0;
 	const uint32_t per_sub = n_chunks / MSC_SPARSE_SUB;
@@ -710,31 +727,26 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	rs->max_sum = std::max<uint64_t>(rs->max_sum, sc.sum);
 	sc.mag = sc.sum;
 	sc.length = 1;
-	const uint64_t floor_sum = L.nbins + fl;
-	if ((r = ensure(ctx, ctx->floor_sum, 8))) return r;
-	HIP_TRY(ctx, hipMemcpyAsync(rs->hdr, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(rs->scalars, &sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->floor_sum.p, &floor_sum, 8, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_off.p, off.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_chunk_cum.p, cb.data(), n_chunks * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+	*(uint64_t*)(pin_h + pl.floor_sum) = L.nbins + fl;
+	memcpy(pin_h + pl.hdr, &h, sizeof h);
+	memcpy(pin_h + pl.sc, &sc, sizeof sc);
+	HIP_TRY(ctx, hipMemcpyAsync(rs->hdr, pin_h + pl.hdr, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(rs->scalars, pin_h + pl.sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
+	const uint64_t *d_off = (const uint64_t*)(pin_d + pl.off), *d_cb = (const uint64_t*)(pin_d + pl.cb), *d_floor = (const uint64_t*)(pin_d + pl.floor_sum);
 	if (grouped)
 		HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, L.nbins, n_chunks, chunk_bins, 1, (const uint32_t*)ctx->qslots.p,
-		                                                (const uint64_t*)ctx->sp_chunk_off.p, (const uint64_t*)ctx->sp_chunk_cum.p, rs->ent, rs->cum, (uint32_t*)ctx->sp_touched.p));
+		                                                d_off, d_cb, rs->ent, rs->cum, (uint32_t*)ctx->sp_touched.p));
 	else
-	HIP_TRY(ctx, msc_launch_sparse_mean_write(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, (const uint64_t*)ctx->sp_chunk_off.p,
-	                                          (const uint64_t*)ctx->sp_chunk_cum.p, rs->ent, rs->cum));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // h, sc, floor_sum, off, cb live on this frame
+	HIP_TRY(ctx, msc_launch_sparse_mean_write(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, n_chunks, chunk_bins, (uint32_t)m, d_off,
+	                                          d_cb, rs->ent, rs->cum));
 	// members vs the rounded mean: only the |p - r| reduction of the merge kernel is used
 	if ((r = run_score_fwd(ctx, set, member_slots, m, rs))) return r;
-	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
 	if ((r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;
 	HIP_TRY(ctx, msc_launch_distance_d(ctx->stream, (const MscPartial*)ctx->partials.p, ctx->last_partial_stride, (uint32_t)m, set->scalars, set->scalar_stride, d_slots,
-	                                   rs->scalars, (const uint64_t*)ctx->floor_sum.p, (double*)ctx->raw.p, (MscReduceOut*)ctx->reduce_out.p));
-	MscReduceOut ro;
-	HIP_TRY(ctx, hipMemcpyAsync(&ro, ctx->reduce_out.p, sizeof ro, hipMemcpyDeviceToHost, ctx->stream));
+	                                   rs->scalars, d_floor, (double*)ctx->raw.p, (MscReduceOut*)(pin_d + pl.ro)));
 	if (dist_out) HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->raw.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	*nearest_pos = ro.best_pos;
+	*nearest_pos = ((const MscReduceOut*)(pin_h + pl.ro))->best_pos;
 	return MSC_OK;
 }
 

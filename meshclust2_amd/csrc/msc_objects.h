@@ -39,6 +39,7 @@ struct msc_ctx {
 	DevBuf rk_big;                         // ... the query's counts of 8 and more, for the divergence statistics of the long-list pass (MscRankDiv)
 	DevBuf rk_q;                           // the rank list of a pass's query when it is too long for LDS (msc_ranks_pass.hip)
 	uint32_t* rk_guard = nullptr;          // page-locked word the rank pass raises when a query's list is longer than its set's bound (msc_ranks_pass.hip)
+	DevBuf pin_mean;                       // page-locked: the small pieces a sparse msc_mean_nearest call hands to and fro (msc_api_score.hip)
 	DevBuf pin_parts;                      // page-locked: the parts of the fused epilogue + reduce kernel when the host folds them
 	DevBuf pin_up, pin_down;               // page-locked HOST staging of the per-call slot list / reduce record + flags
 	msc_hist_set* scratch_set = nullptr;   // one slot: the rounded mean of msc_mean_nearest
