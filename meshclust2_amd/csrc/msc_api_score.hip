@@ -97,7 +97,14 @@ bool rank_lists_ready(msc_ctx* ctx, const msc_hist_set* s, int* err, bool eager)
 	// candidate must not depend on how many passes its rank has seen (a rank whose window was empty for a step would otherwise switch a
 	// step later than the others, and two identical sequences on two ranks would differ in the last bit of a divergence sum)
 	if (!eager && ++s->rkl_seen < after) return false;
-	auto give_up = [&]() { (void)hipGetLastError(); s->rkl_unavailable = true; return false; };
+	// (no memory for the lists: the merge kernels stay -- except in the step-serial loop's own call, where it is an error: which kernel scores
+	// a pass there must not depend on what one rank's allocator had left)
+	auto give_up = [&]() {
+		(void)hipGetLastError();
+		if (eager) { *err = fail(ctx, MSC_ERR_OOM, "rank lists: out of device memory"); return false; }
+		s->rkl_unavailable = true;
+		return false;
+	};
 	if (!s->rkl_off && (hipMalloc((void**)&s->rkl_off, (s->capacity + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&s->rkl_n, s->capacity * sizeof(uint32_t)) != hipSuccess))
 		return give_up();
 	if (msc_launch_rank_lists_sizes(ctx->stream, s->hdr, s->cum, s->capacity, s->rkl_n, s->rkl_off) != hipSuccess) { *err = fail(ctx, MSC_ERR_HIP, "rank lists: size pass failed"); return false; }
