@@ -363,10 +363,10 @@ def slow_model_leg(api, ctx, hs, M, args):
 
 def window_leg(api, synth, ctx, args):
     """Trainer::get_close over the accumulate loop's window (cluster/ClusterFactory.cpp:553-610 -> cluster/Trainer.cpp:23-71) on a
-    cfg5-shaped set: 2 000 sequences of 500 b - 50 kb (log-uniform templates, families of 5 at graded divergence), k = 9, 16-bit,
+    cfg5-shaped set: 8 000 sequences of 500 b - 50 kb (log-uniform templates, families of 5 at graded divergence), k = 9, 16-bit,
     sparse layout, the `--feat slow` model at --id 0.6: the (candidate, round) pass over rank lists (k_pair_ranks_items). Bytes: 4 per
     k-mer of every candidate inside the pass's length window."""
-    seed, n_t, per = 20260005, 400, 5
+    seed, n_t, per = 20260005, 1600, 5          # (r05: 8 000 sequences -- at 2 000 a pass held a few hundred candidates and timed its launches, not the walk)
     seqs = []
     for t in range(n_t):
         u = synth._unit(synth._stream(seed, 2 * t + 1, 2))
