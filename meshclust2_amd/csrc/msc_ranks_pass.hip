@@ -781,32 +781,33 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	}
 }
 
-// A workgroup per candidate: lane l of each of the four waves adds up word l of every fourth of its items' records (rounds, then
-// repeated-bin items, as the list holds them), LDS adds the four; the integer record from words 0 / 32 / 8 / 16 / 24; DIV, first wave: lane
-// (r, b) evaluates cell (r, b) -- row a' = candidate count a' + 2, row 7 = bins evaluated on the spot, counted as held: its lanes take the
-// query's bins with count b that the candidate does not hold --, every lane its share of the query's bins with a count >= 8 and of the
-// items' spot terms (lane l: entries l, l + 64, ..); one butterfly adds the 64 partial sums in a fixed order.
+// A WAVE per candidate (four to a workgroup): lane l adds up word l of its items' records (rounds, then repeated-bin items, as the list
+// holds them; eight records in flight); the integer record from words 0 / 32 / 8 / 16 / 24; DIV: lane (r, b) evaluates cell (r, b) -- row
+// a' = candidate count a' + 2, row 7 = bins evaluated on the spot, counted as held: its lanes take the query's bins with count b that the
+// candidate does not hold --, every lane its share of the query's bins with a count >= 8 and of the items' spot terms (lane l: entries l,
+// l + 64, ..); one butterfly adds the 64 partial sums in a fixed order. (r05: a WORKGROUP per candidate, its four waves sharing the
+// records, was 34 us per pass of 8 000 candidates at cfg5's full size -- three of four waves idle through the FP64 part, five rounds of
+// workgroups over the chip; a candidate has eight or nine items.)
 template <bool DIV>
 __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __restrict__ rec, const double* __restrict__ extras, uint32_t rounds, const uint32_t* __restrict__ hq,
                                                            const uint32_t* __restrict__ big, const RkItemMeta* __restrict__ meta, uint32_t m, const uint32_t* __restrict__ q_cum,
                                                            const MscSparseHdr* __restrict__ q_hdr_p, const uint8_t* __restrict__ q_scalars, int order, MscPartial* __restrict__ partials,
                                                            double* __restrict__ div_out, uint32_t* __restrict__ guard) {
-	__shared__ uint64_t s_sum[3][64];
-	const uint32_t c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (c >= m) return;
 	const RkItemMeta mt = meta[c];
 	const uint32_t n_it = mt.rounds + mt.mrounds;
 	const uint32_t* R = rec + (uint64_t)mt.first * kRkCells + lane;
 	uint64_t sum = 0;
-	uint32_t s = wave;
-	for (; s + 12 < n_it; s += 16) {
-		const uint32_t x0 = R[(uint64_t)s * kRkCells], x1 = R[(uint64_t)(s + 4) * kRkCells], x2 = R[(uint64_t)(s + 8) * kRkCells], x3 = R[(uint64_t)(s + 12) * kRkCells];
-		sum += (uint64_t)x0 + x1 + x2 + x3;
+	uint32_t s = 0;
+	for (; s + 8 <= n_it; s += 8) {
+		uint32_t x[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) x[i] = R[(uint64_t)(s + i) * kRkCells];
+#pragma unroll
+		for (int i = 0; i < 8; i++) sum += x[i];
 	}
-	for (; s < n_it; s += 4) sum += R[(uint64_t)s * kRkCells];
-	if (wave) s_sum[wave - 1][lane] = sum;
-	__syncthreads();
-	if (wave) return;
-	sum += s_sum[0][lane] + s_sum[1][lane] + s_sum[2][lane];
+	for (; s < n_it; s++) sum += R[(uint64_t)s * kRkCells];
 	{
 		const uint64_t emd = sum + (__shfl(sum, 32, 64) << 32), p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
 		if (lane == 0) {
@@ -824,26 +825,25 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 	}
 	if constexpr (DIV) {
 		const double cm = mt.mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
-		const RkDivTerm t11 = rk_div_term_call(1, 1, cm, qm, order);
 		const uint32_t b = lane & 7, r = lane >> 3;
 		const uint32_t k = b ? (uint32_t)sum : 0u;          // the cell's count (modulo 2^32, as the items wrote it)
 		uint32_t held = k;                                  // the candidate's bins the query holds b - 1 times: the column's sum
 		held += __shfl_xor(held, 8, 64);
 		held += __shfl_xor(held, 16, 64);
 		held += __shfl_xor(held, 32, 64);
+		// ONE evaluation per wave, a pair of counts per lane: lane 0 term(1, 1); lane (r, b), r < 7: term(r + 2, b) for its cell; lane (7, b): term(1, b)
+		// for the query's bins with count b that the candidate does not hold (three calls one behind the other -- the FP64 logarithms of this
+		// kernel -- made it 30 us per pass of 8 000 candidates at cfg5's full size)
+		uint32_t n_of = 0, a1 = 1, a2 = 1;
+		if (b >= 1 && r < 7) { n_of = k; a1 = r + 2; a2 = b; }
+		if (b >= 2 && r == 7) { n_of = hq[b] - held; a2 = b; }
+		RkDivTerm f{0.0, 0.0};
+		if (lane == 0 || n_of) f = rk_div_term_call(a1, a2, cm, qm, order);
+		const RkDivTerm t11{__shfl(f.jd, 0, 64), __shfl(f.js, 0, 64)};
 		double jd = 0.0, js = 0.0;
-		if (b >= 1 && r < 7 && k) {
-			const RkDivTerm f = rk_div_term_call(r + 2, b, cm, qm, order);
-			jd = (double)k * (f.jd - t11.jd);
-			js = (double)k * (f.js - t11.js);
-		}
-		if (b >= 2 && r == 7) {          // the query's bins with count b that the candidate does not hold
-			const uint32_t kq = hq[b] - held;
-			if (kq) {
-				const RkDivTerm f = rk_div_term_call(1, b, cm, qm, order);
-				jd = (double)kq * (f.jd - t11.jd);
-				js = (double)kq * (f.js - t11.js);
-			}
+		if (n_of) {
+			jd = (double)n_of * (f.jd - t11.jd);
+			js = (double)n_of * (f.js - t11.js);
 		}
 		const uint32_t n_big = hq[8];
 		for (uint32_t i = lane; i < n_big; i += 64) {
@@ -965,7 +965,7 @@ hipError_t msc_launch_pair_ranks_items(hipStream_t st, const uint32_t* c_rk, con
 	else k_pair_ranks_items<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, (const uint2*)c_rm, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_rk ? q_rk : q_scratch, rec, nullptr, nullptr,
 	                                                                          0, meta, items_list, tail, tab, nullptr);
 	if ((e = hipGetLastError()) != hipSuccess) return e;
-	const dim3 fgrid(m);
+	const dim3 fgrid((m + 3) / 4);
 	if (dv) k_rank_items_finish<true><<<fgrid, dim3(256), 0, st>>>(rec, extras, rounds, hq, dv->big, meta, m, q_cum, q_hdr, dv->q_scalars, dv->order, partials, dv->div_out, guard);
 	else k_rank_items_finish<false><<<fgrid, dim3(256), 0, st>>>(rec, nullptr, rounds, nullptr, nullptr, meta, m, q_cum, q_hdr, nullptr, 0, partials, nullptr, guard);
 	return hipGetLastError();
