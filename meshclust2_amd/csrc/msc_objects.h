@@ -33,7 +33,7 @@ struct msc_ctx {
 	DevBuf rk_items;                       // ... its list of (candidate, round) items
 	DevBuf rk_acc;                         // ... of its long-list form: a record and a spot-term slot per item (k_pair_ranks_items)
 	DevBuf rk_counters;                    // ... 2 x 16 words: the query's counts of counts and the number of items, two sets used in turn
-	int rk_turn = 0;
+	uint32_t rk_turn = 0;
 	DevBuf rk_tables;                      // ... the query's tables as the pass's workgroups copy them into LDS, two sets used in turn
 	uint32_t rk_table_words = 0;
 	DevBuf rk_big;                         // ... the query's counts of 8 and more, for the divergence statistics of the long-list pass (MscRankDiv)
