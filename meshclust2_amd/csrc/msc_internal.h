@@ -265,7 +265,7 @@ hipError_t msc_launch_epilogue_reduce(hipStream_t st, const MscEpilogueArgs& a, 
 // ... the fold of those parts on the host (the arithmetic of k_pair_reduce_fold2); *wpos_out = the best candidate's window position + 1 (0: none)
 void msc_reduce_fold_host(const ReducePart* parts, uint32_t n_parts, int mode, MscReduceOut* out, uint32_t* wpos_out);
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin,
-                             uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr);
+                             uint8_t* flags_out, MscReduceOut* out, void* parts_scratch = nullptr, const uint32_t* key = nullptr);
 size_t msc_reduce_scratch_bytes();
 
 hipError_t msc_launch_sparse_count(hipStream_t st, const void* scratch_bins, const MscLayout& L, int dtype, uint32_t n, uint64_t* counts);

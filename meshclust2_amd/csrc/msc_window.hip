@@ -22,7 +22,8 @@ struct msc_window {
 	uint8_t* d_alive = nullptr;       // [n] 1 = still in the store
 	uint32_t* d_slots = nullptr;      // [n] compacted slots of the current range
 	uint32_t* d_pos = nullptr;        // [n] ... and their positions
-	uint32_t* d_counts = nullptr;     // per-block alive counts of the two-pass compaction + [kMaxBlocks] the close counter
+	uint32_t* d_counts = nullptr;     // [0], [1]: the places claimed in the list of the current range (two counters used in turn) + [kMaxBlocks] the close counter
+	uint32_t turn = 0;
 	uint8_t* d_flags = nullptr;       // [n] close flags of the current range (candidate order)
 	uint32_t* h_close = nullptr;      // page-locked, device-visible: [0] best position + 1, [1] n written, [2..] close positions
 	uint64_t h_close_cap = 0;
@@ -81,12 +82,19 @@ __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(uint8_t* alive
 		if (alive[first + i]) { slots[o] = order[first + i]; pos[o] = first + i; o++; }
 }
 
-// the same over many workgroups: counts per block, then every block adds up the counts in front of it
+// the same over many workgroups in ONE launch: a workgroup counts its tile, claims its places in the list with one atomic and writes
+// them -- the tiles' order in the list is whatever order the claims came in. Nothing downstream reads that order: a candidate's result
+// depends on the candidate alone, the close positions are sorted by the host, and the best candidate is chosen by similarity and then by
+// WINDOW POSITION (k_pair_epilogue_reduce_part), which is what the index in an ordered list stood for. (r05: count, then write with every
+// block adding up the counts in front of it, were two of a pass's launches.) claim: two counters used in turn; a pass clears the other's.
 // (the kills on file: every block applies those of its own tile before it counts; block 0 those outside the range as well -- nobody
 // of this pass reads them)
-__global__ void __launch_bounds__(kWinBlock) k_window_count(uint8_t* alive, uint32_t first, uint32_t range, uint32_t* __restrict__ counts, const uint32_t* __restrict__ kills,
-                                                            uint32_t n_kills) {
+__global__ void __launch_bounds__(kWinBlock) k_window_compact(uint8_t* alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range, uint32_t* __restrict__ slots,
+                                                              uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter, uint32_t* __restrict__ claim,
+                                                              uint32_t* __restrict__ claim_next, const uint32_t* __restrict__ kills, uint32_t n_kills) {
 	__shared__ uint32_t s_wave[kWinBlock / 64];
+	__shared__ uint32_t s_base;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { *close_counter = 0; *claim_next = 0; }
 	if (n_kills) {
 		const uint32_t t_lo = first + blockIdx.x * (blockDim.x * kWinPer), t_hi = t_lo + blockDim.x * kWinPer;
 		for (uint32_t i = threadIdx.x; i < n_kills; i += blockDim.x) {
@@ -101,26 +109,10 @@ __global__ void __launch_bounds__(kWinBlock) k_window_count(uint8_t* alive, uint
 #pragma unroll
 	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
 	uint32_t total;
-	(void)block_excl_scan(c, s_wave, &total);
-	if (threadIdx.x == 0) counts[blockIdx.x] = total;
-}
-__global__ void __launch_bounds__(kWinBlock) k_window_write(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
-                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ slots, uint32_t* __restrict__ pos,
-                                                            uint32_t* __restrict__ close_counter) {
-	__shared__ uint32_t s_wave[kWinBlock / 64];
-	__shared__ uint32_t s_base;
-	if (blockIdx.x == 0 && threadIdx.x == 0) *close_counter = 0;
-	uint32_t before = 0;
-	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += blockDim.x) before += counts[b];
-	uint32_t total;
-	(void)block_excl_scan(before, s_wave, &total);
-	if (threadIdx.x == 0) s_base = total;
+	const uint32_t mine = block_excl_scan(c, s_wave, &total);
+	if (threadIdx.x == 0) s_base = total ? atomicAdd(claim, total) : 0u;
 	__syncthreads();
-	const uint32_t base = blockIdx.x * (blockDim.x * kWinPer) + threadIdx.x * kWinPer;
-	uint32_t c = 0;
-#pragma unroll
-	for (uint32_t j = 0; j < kWinPer; j++) if (base + j < range) c += alive[first + base + j];
-	uint32_t o = s_base + block_excl_scan(c, s_wave, &total);
+	uint32_t o = s_base + mine;
 #pragma unroll
 	for (uint32_t j = 0; j < kWinPer; j++)
 		if (base + j < range && alive[first + base + j]) { slots[o] = order[first + base + j]; pos[o] = first + base + j; o++; }
@@ -131,7 +123,7 @@ __global__ void __launch_bounds__(kWinBlock) k_window_write(const uint8_t* __res
 __global__ void __launch_bounds__(256) k_window_close(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint32_t m, uint8_t* __restrict__ alive,
                                                       uint32_t* __restrict__ counter, const MscReduceOut* __restrict__ rec, uint32_t* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i == 0) out[0] = rec->best_pos >= 0 ? pos[rec->best_pos] + 1 : 0;
+	if (i == 0) out[0] = rec->best_pos >= 0 ? (uint32_t)rec->best_pos + 1u : 0u;          // (the reduce chose by window position: best_pos is one)
 	if (i >= m || !flags[i]) return;
 	const uint32_t p = pos[i];
 	alive[p] = 0;
@@ -174,6 +166,7 @@ extern "C" int msc_window_create(msc_ctx* ctx, const msc_hist_set* set, const ui
 	if (n) {
 		HIP_TRY(ctx, hipMemcpyAsync(w->d_order, slots, n * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_TRY(ctx, hipMemsetAsync(w->d_alive, 1, n, ctx->stream));
+		HIP_TRY(ctx, hipMemsetAsync(w->d_counts, 0, 8, ctx->stream));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	w->fen.assign(n + 1, 0);
@@ -263,8 +256,10 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 		const uint32_t tb = range <= 64 * kWinTile ? 256 : kWinBlock, tile = tb * kWinPer;
 		const uint32_t blocks = (range + tile - 1) / tile;
 		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
-		k_window_count<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, (uint32_t)first, range, w->d_counts, d_kills, n_kills);
-		k_window_write<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_counts, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks);
+		uint32_t *claim = w->d_counts + (w->turn & 1u), *claim_next = w->d_counts + ((w->turn & 1u) ^ 1u);
+		w->turn++;
+		k_window_compact<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, claim, claim_next, d_kills,
+		                                                              n_kills);
 	}
 	HIP_TRY(ctx, hipGetLastError());
 	if (n_kills) {          // (the list is rewritten only once this kernel is through)

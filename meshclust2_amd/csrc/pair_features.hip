@@ -1393,8 +1393,10 @@ __device__ __forceinline__ Best better(Best x, Best y, int mode) {
 	return x;
 }
 
+// (key, optional: what decides between equal similarities instead of the index -- a window pass hands in the candidates' window positions,
+// its list being in no particular order; best_pos then IS that position)
 __global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restrict__ po, uint32_t m, int mode, int64_t begin,
-                                                      uint8_t* __restrict__ flags_out, MscReduceOut* __restrict__ out) {
+                                                      uint8_t* __restrict__ flags_out, MscReduceOut* __restrict__ out, const uint32_t* __restrict__ key) {
 	__shared__ Best s_best[1024];
 	__shared__ unsigned long long s_nclose;
 	__shared__ int s_err;
@@ -1411,7 +1413,7 @@ __global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restri
 		if (!scored) continue;
 		nclose += p.close ? 1 : 0;
 		if (mode == MSC_REDUCE_GET_CLOSE) {
-			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)i}, mode);
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, key ? (int64_t)key[i] : (int64_t)i}, mode);
 		} else {
 			// best = best.second > dist ? best : (i, dist), starting at DBL_MIN
 			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)i}, mode);
@@ -1440,7 +1442,7 @@ __global__ void __launch_bounds__(1024) k_pair_reduce(const MscPairOut* __restri
 // kernel): workgroup b folds records [b * per, (b + 1) * per) into parts[b]; k_pair_reduce_fold folds the parts. `better` breaks
 // ties by position, so the order of folding does not matter.
 __global__ void __launch_bounds__(1024) k_pair_reduce_part(const MscPairOut* __restrict__ po, uint32_t m, uint32_t per, int mode, int64_t begin,
-                                                           uint8_t* __restrict__ flags_out, ReducePart* __restrict__ parts) {
+                                                           uint8_t* __restrict__ flags_out, ReducePart* __restrict__ parts, const uint32_t* __restrict__ key) {
 	__shared__ Best s_best[1024];
 	__shared__ unsigned long long s_nclose;
 	__shared__ int s_err;
@@ -1458,7 +1460,7 @@ __global__ void __launch_bounds__(1024) k_pair_reduce_part(const MscPairOut* __r
 		if (!scored) continue;
 		nclose += p.close ? 1 : 0;
 		if (mode == MSC_REDUCE_GET_CLOSE) {
-			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)i}, mode);
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, key ? (int64_t)key[i] : (int64_t)i}, mode);
 		} else {
 			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)i}, mode);
 		}
@@ -1547,7 +1549,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_reduce_part(const MscE
 		if (!scored) continue;
 		nclose += p.close ? 1 : 0;
 		if (mode == MSC_REDUCE_GET_CLOSE) {
-			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, (int64_t)c}, mode);
+			// (a window pass: ties go to the lower WINDOW POSITION -- the list of candidates is in no particular order, msc_window.hip)
+			if (p.combo0 > -1.0) b = better(b, Best{p.combo0, cl.pos ? (int64_t)cl.pos[c] : (int64_t)c}, mode);
 		} else {
 			if (p.close && !(2.2250738585072014e-308 > p.combo0)) b = better(b, Best{p.combo0, begin + (int64_t)c}, mode);
 		}
@@ -1563,7 +1566,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_epilogue_reduce_part(const MscE
 	if (threadIdx.x == 0) {
 		ReducePart r;
 		r.sim = s_best[0].sim; r.pos = s_best[0].pos; r.nclose = s_nclose; r.err = s_err;
-		r.wpos = cl.pos && s_best[0].pos >= 0 ? cl.pos[s_best[0].pos] + 1 : 0u;
+		r.wpos = cl.pos && s_best[0].pos >= 0 ? (uint32_t)s_best[0].pos + 1u : 0u;          // (a window pass: pos IS the window position)
 		parts[blockIdx.x] = r;
 	}
 }
@@ -1598,7 +1601,7 @@ __global__ void __launch_bounds__(256) k_pair_reduce_fold2(const ReducePart* __r
 		r.n_close = s_nclose;
 		r.first_error = s_err;
 		*out = r;
-		if (cl.pos) cl.out[0] = s_best[0].pos >= 0 ? cl.pos[s_best[0].pos] + 1 : 0;          // (k_window_close's first line)
+		if (cl.pos) cl.out[0] = s_best[0].pos >= 0 ? (uint32_t)s_best[0].pos + 1u : 0u;          // (a window pass: the parts' pos is the window position)
 	}
 }
 
@@ -2192,17 +2195,17 @@ void msc_reduce_fold_host(const ReducePart* parts, uint32_t n_parts, int mode, M
 // parts_scratch (optional, msc_reduce_scratch_bytes()): long windows are folded by up to 256 workgroups first (1 024 in the fused form)
 size_t msc_reduce_scratch_bytes() { return 1024 * sizeof(ReducePart); }
 hipError_t msc_launch_reduce(hipStream_t st, const MscPairOut* pair_out, uint32_t m, int mode, int64_t begin, uint8_t* flags_out,
-                             MscReduceOut* out, void* parts_scratch) {
+                             MscReduceOut* out, void* parts_scratch, const uint32_t* key) {
 	if (parts_scratch && m > 8192) {
 		const uint32_t n_parts = std::min<uint32_t>(256, (m + 4095) / 4096);
 		const uint32_t per = (m + n_parts - 1) / n_parts;
-		k_pair_reduce_part<<<dim3(n_parts), dim3(1024), 0, st>>>(pair_out, m, per, mode, begin, flags_out, (ReducePart*)parts_scratch);
+		k_pair_reduce_part<<<dim3(n_parts), dim3(1024), 0, st>>>(pair_out, m, per, mode, begin, flags_out, (ReducePart*)parts_scratch, key);
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 		k_pair_reduce_fold<<<dim3(1), dim3(256), 0, st>>>((const ReducePart*)parts_scratch, n_parts, mode, out);
 		return hipGetLastError();
 	}
-	hipLaunchKernelGGL(k_pair_reduce, dim3(1), dim3(1024), 0, st, pair_out, m, mode, begin, flags_out, out);
+	hipLaunchKernelGGL(k_pair_reduce, dim3(1), dim3(1024), 0, st, pair_out, m, mode, begin, flags_out, out, key);
 	return hipGetLastError();
 }
 
