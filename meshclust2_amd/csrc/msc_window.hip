@@ -249,7 +249,7 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	if ((r = stage_kills(ctx, w, &d_kills, &n_kills))) return r;
 	const uint32_t range = (uint32_t)(end - first);
 	// One workgroup walking the range alone takes 50 us for 40 000 positions (a third of a step on a window-bearing set: profiles/
-	// r04_notes.md); from a few thousand positions on, many small workgroups count and then write (2 launches of a few us)
+	// r04_notes.md); from a few thousand positions on, many small workgroups count their tiles and claim their places (k_window_compact)
 	if (range <= 4 * kWinBlock) {
 		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, d_kills, n_kills);
 	} else {
