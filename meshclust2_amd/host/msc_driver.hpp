@@ -236,6 +236,11 @@ struct Cluster {
 	                             // (bins, length, id of that point; the magnitude stays whatever it was) and is skipped
 	std::vector<SeqRecord*> members;
 	bool merged_away = false;
+	// what the last update round asked about this centre -- the point it held and the points of its neighbourhood, in order -- and what came
+	// back. The same question has the same answer (the centre's histogram, the model and the list decide it): a round does not ask it again.
+	std::vector<uint32_t> asked;          // [0] = the centre's point, then the neighbourhood's points
+	SeqRecord* answer = nullptr;
+	bool answered = false;
 };
 
 class MeanShift {
@@ -450,26 +455,54 @@ private:
 		if (n == 0) return;
 		if (batch_update) {
 			auto t0 = std::chrono::steady_clock::now();
-			std::vector<uint32_t> centres(n), flat;
-			std::vector<uint64_t> offsets(n + 1, 0);
-			std::vector<SeqRecord*> good;
+			// Only the centres whose question changed since the last round go to the backend (r05): once the clusters have settled -- BASELINE
+			// cfg3: 10^6 centres, nine rounds -- a round repeats the round before it almost centre for centre.
+			std::vector<uint32_t> centres, flat;
+			std::vector<size_t> which;                       // the centres asked about this round
+			std::vector<uint64_t> offsets(1, 0);
+			std::vector<SeqRecord*> good, mine;
 			for (size_t j = 0; j < n; j++) {
-				centres[j] = part[j].centre;
-				neighbourhood(part, j, delta, good);
-				offsets[j + 1] = good.size();
+				const int lo = std::max(0, (int)j - delta), hi = std::min((int)j + delta, (int)n - 1);
+				if (part[j].answered) {          // the same question as last round? (compared in place: nothing is built for a centre that is not asked about)
+					const std::vector<uint32_t>& q = part[j].asked;
+					bool same = !q.empty() && q[0] == part[j].centre_point;
+					size_t at = 1;
+					for (int i = lo; same && i <= hi; i++)
+						for (const SeqRecord* p : part[(size_t)i].members) {
+							if (at >= q.size() || q[at] != p->point) { same = false; break; }
+							at++;
+						}
+					if (same && at == q.size()) continue;
+				}
+				mine.clear();
+				neighbourhood(part, j, delta, mine);
+				std::vector<uint32_t>& q = part[j].asked;
+				q.clear();
+				q.push_back(part[j].centre_point);
+				for (SeqRecord* p : mine) q.push_back(p->point);
+				part[j].answered = false;
+				which.push_back(j);
+				centres.push_back(part[j].centre);
+				good.insert(good.end(), mine.begin(), mine.end());
+				offsets.push_back(good.size());
 			}
 			flat = handles(good);
-			std::vector<int64_t> nearest(n, -1);
+			std::vector<int64_t> nearest(which.size(), -1);
 			uprof.rounds++;
 			uprof.lists += seconds_since(t0);
 			t0 = std::chrono::steady_clock::now();
-			const bool took = be_.update_centres(centres, flat, offsets, nearest);
+			const bool took = which.empty() || be_.update_centres(centres, flat, offsets, nearest);
 			uprof.update += seconds_since(t0);
 			if (took) {
 				t0 = std::chrono::steady_clock::now();
+				for (size_t i = 0; i < which.size(); i++) {
+					Cluster& cl = part[which[i]];
+					cl.answer = nearest[i] >= 0 ? good[(size_t)(offsets[i] + (uint64_t)nearest[i])] : (delta == 0 ? cl.members[0] : nullptr);
+					cl.answered = true;
+				}
 				std::vector<uint32_t> dst, src;
 				for (size_t j = 0; j < n; j++) {
-					SeqRecord* next = nearest[j] >= 0 ? good[(size_t)(offsets[j] + (uint64_t)nearest[j])] : (delta == 0 ? part[j].members[0] : nullptr);
+					SeqRecord* next = part[j].answer;
 					if (!next || next->point == part[j].centre_point) continue;          // (BASELINE cfg3: five centres in six sit on their only member, round after round)
 					dst.push_back(part[j].centre);
 					src.push_back(next->point);
@@ -480,6 +513,7 @@ private:
 				uprof.set += seconds_since(t0);
 				return;
 			}
+			for (size_t j : which) part[j].answered = false;          // (the backend has no batched form: the loop below asks centre by centre)
 		}
 		for (size_t j = 0; j < n; j++) {
 			Cluster& cl = part[j];
