@@ -290,10 +290,16 @@ public:
 			     << " s, get_close " << prof.get_close << " s, mark+take " << prof.mark << " s, closest " << prof.closest << " s" << std::endl;
 		log_ << "Number of clusters before update: " << part.size() << std::endl;
 		std::vector<size_t> history;
+		bool quiet = false;
 		for (int i = 0; i < iterations; i++) {
 			if (i >= 3 && part.size() == history[(size_t)i - 3]) break;      // unchanged for three rounds (:636)
-			update_round(part, delta);
-			merge_round(part, delta);
+			// (a round that asked nothing new, moved no centre and merged no cluster leaves the state it found: the next one would repeat it
+			// question for question -- the rounds the stopping rule waits through)
+			if (!quiet) {
+				const bool moved = update_round(part, delta);
+				const bool merged = merge_round(part, delta);
+				quiet = !moved && !merged;
+			}
 			history.push_back(part.size());
 		}
 		update_round(part, 0);
@@ -450,9 +456,10 @@ private:
 	// one `omp parallel for` over mean_shift_update (cluster/ClusterFactory.cpp:288-335,639,648). The centres of a round are
 	// independent (each reads its own histogram and the member lists of its neighbours, none of which change during the round),
 	// so a backend may take all of them in one call.
-	void update_round(std::vector<Cluster>& part, int delta) {
+	// returns whether the round asked the backend anything or moved a centre
+	bool update_round(std::vector<Cluster>& part, int delta) {
 		const size_t n = part.size();
-		if (n == 0) return;
+		if (n == 0) return false;
 		if (batch_update) {
 			auto t0 = std::chrono::steady_clock::now();
 			// Only the centres whose question changed since the last round go to the backend (r05): once the clusters have settled -- BASELINE
@@ -511,7 +518,7 @@ private:
 				if (!dst.empty() && !be_.centre_set_batch(dst, src))
 					for (size_t i = 0; i < dst.size(); i++) be_.centre_set(dst[i], src[i]);
 				uprof.set += seconds_since(t0);
-				return;
+				return !which.empty() || !dst.empty();
 			}
 			for (size_t j : which) part[j].answered = false;          // (the backend has no batched form: the loop below asks centre by centre)
 		}
@@ -529,10 +536,12 @@ private:
 			else if (delta == 0) next = cl.members[0];
 			if (next && next->point != cl.centre_point) { be_.centre_set(cl.centre, next->point); move_centre(cl, next); }
 		}
+		return true;          // (centre by centre: nothing is remembered)
 	}
 
 	// merge (cluster/ClusterFactory.cpp:383-401): centre i joins the best partner among the next delta centres
-	void merge_round(std::vector<Cluster>& part, int delta) {
+	// returns whether any cluster was merged away
+	bool merge_round(std::vector<Cluster>& part, int delta) {
 		const int n = (int)part.size();
 		std::vector<uint32_t> centres((size_t)n);
 		for (int c = 0; c < n; c++) centres[(size_t)c] = part[(size_t)c].centre;
@@ -551,8 +560,10 @@ private:
 				part[(size_t)i].merged_away = true;
 			}
 		}
+		const size_t before = part.size();
 		part.erase(std::remove_if(part.begin(), part.end(), [](const Cluster& c) { return c.merged_away; }), part.end());
 		uprof.book += seconds_since(t0);
+		return part.size() != before;
 	}
 
 	// bvec::pop; a backend that keeps the window learns that the position is gone
