@@ -61,11 +61,13 @@ public:
 	void clear() { ctx_.check(msc_hist_set_clear(ctx_.get(), h_)); }      // sparse sets: every slot empty, the whole arena free
 
 	// Loader<T>::get_point for a batch. strip = the std::string overload (drops non-ACGT first).
-	void get_points(uint64_t first_slot, const std::vector<std::string>& seqs, bool strip = false) {
-		std::vector<const char*> p(seqs.size());
-		std::vector<uint64_t> l(seqs.size());
-		for (size_t i = 0; i < seqs.size(); i++) { p[i] = seqs[i].data(); l[i] = seqs[i].size(); }
-		ctx_.check(msc_hist_build(ctx_.get(), h_, first_slot, seqs.size(), p.data(), l.data(), strip ? 1 : 0));
+	void get_points(uint64_t first_slot, const std::vector<std::string>& seqs, bool strip = false) { get_points(first_slot, seqs.data(), seqs.size(), strip); }
+	// ... n sequences of a longer list, where they lie (no copies)
+	void get_points(uint64_t first_slot, const std::string* seqs, size_t n, bool strip = false) {
+		std::vector<const char*> p(n);
+		std::vector<uint64_t> l(n);
+		for (size_t i = 0; i < n; i++) { p[i] = seqs[i].data(); l[i] = seqs[i].size(); }
+		ctx_.check(msc_hist_build(ctx_.get(), h_, first_slot, n, p.data(), l.data(), strip ? 1 : 0));
 	}
 	msc_hist_info info(uint64_t slot) const {
 		msc_hist_info i;

@@ -285,8 +285,7 @@ std::string train_model(msc::Context& ctx, int k, int dtype, double id, uint64_t
 	for (const std::string& p_ : pts) train_bases += p_.size();
 	msc::PointSet set(ctx, k, dtype, pts.size(), sparse ? train_bases + 1024 : 0);      // (at k >= 13 a dense training set would not fit)
 	for (size_t off = 0; off < pts.size(); off += 4096) {
-		std::vector<std::string> part(pts.begin() + (long)off, pts.begin() + (long)std::min(pts.size(), off + 4096));
-		set.get_points(off, part);
+		set.get_points(off, pts.data() + off, std::min(pts.size(), off + 4096) - off);
 	}
 	const uint64_t n_train = first.size() / 2;
 	std::vector<char> text(1 << 16);
@@ -363,6 +362,8 @@ int main(int argc, char** argv) {
 		std::vector<size_t> file_first;                // index of every file's first record (find_k averages per file, then over the files)
 		for (const auto& f : files) { file_first.push_back(seqs.size()); read_fasta(f, headers, seqs, single_file); }
 		file_first.push_back(seqs.size());
+		if (std::getenv("MSC_CLUSTER_PROFILE"))
+			std::cout << "input profile: context + FASTA read " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
 		const size_t n = seqs.size();
 		if (n == 0) { std::fprintf(stderr, "no sequences\n"); return 1; }
 		std::unique_ptr<msc::TcpComm> boot;          // rendezvous of the ranks (and the whole transport under MSC_COMM=tcp)
@@ -461,10 +462,9 @@ int main(int argc, char** argv) {
 		}
 		msc::PointSet points(ctx, k, dtype, n, sparse ? total_bases + 1024 : 0);
 		const size_t chunk = 8192;
-		for (size_t off = 0; off < n; off += chunk) {
-			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(n, off + chunk));
-			points.get_points(off, part);
-		}
+		for (size_t off = 0; off < n; off += chunk) points.get_points(off, seqs.data() + off, std::min(n, off + chunk) - off);
+		if (std::getenv("MSC_CLUSTER_PROFILE"))
+			std::cout << "input profile: histograms built at " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
 		std::vector<msc::SeqRecord> records(n);
 		const std::vector<uint64_t> lens = points.get_lengths(0, n);      // (one call: a read-back per point costs 8 us each)
 		for (size_t i = 0; i < n; i++) {

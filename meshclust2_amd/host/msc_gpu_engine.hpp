@@ -24,10 +24,7 @@ public:
 		uint64_t own_bases = 0;
 		for (const std::string& s : seqs) own_bases += s.size();
 		points_.reset(new PointSet(ctx, k, dtype, std::max<uint64_t>(n_, 1), sparse ? own_bases + 1024 : 0));
-		for (size_t off = 0; off < seqs.size(); off += 8192) {
-			std::vector<std::string> part(seqs.begin() + (long)off, seqs.begin() + (long)std::min(seqs.size(), off + 8192));
-			points_->get_points(off, part);
-		}
+		for (size_t off = 0; off < seqs.size(); off += 8192) points_->get_points(off, seqs.data() + off, std::min(seqs.size(), off + 8192) - off);
 		qset_.reset(new PointSet(ctx, k, dtype, 1, sparse ? longest + 1024 : 0));
 		// sparse centre store: a slot is a header and a scalar record, so room for every point as its own centre costs little; its arena
 		// takes every sequence's list twice (a round appends the new list of every moved centre before the old ones are compacted away)
