@@ -102,3 +102,42 @@ def test_sharded_mean_shift_mixed_lengths(oracle, tmp_path):
     # several collectives per centre and round in the serial order
     assert 0 < calls["update_chunks"] <= 17 and calls["set_chunks"] <= 17
     assert scalls["all_gather"] + scalls["all_reduce"] > 3 * (calls["all_gather"] + calls["all_reduce"])
+
+
+def test_fasta_line_ends_and_skipped_lines(oracle, tmp_path):
+    """msc::read_fasta (host/msc_fasta.hpp; nonltr/ChromListMaker.cpp:24-48,117-165): LF, CR LF and lone CR line ends, a last line without
+    one, lines that start with a blank skipped, text in front of the first header dropped -- the same records, hence the same .clstr bytes,
+    as the plain file (r05: the file is read in one piece and cut in memory)."""
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle", "sharded_oracle"])
+    c = CASES["k9_u8"]
+    seqs, hdrs = synth.families(61, 80, 1000, family=16)
+    plain = str(tmp_path / "plain.fa")
+    synth.write_fasta(plain, seqs, hdrs)
+    odd = str(tmp_path / "odd.fa")
+    ends = (b"\n", b"\r\n", b"\r")
+    with open(odd, "wb") as f:
+        f.write(b"text in front of the first header\nACGTACGT\r\n")
+        for i, (h, s_) in enumerate(zip(hdrs, seqs)):
+            s_ = bytes(s_)
+            e = ends[i % 3]
+            f.write(h.encode() + e)
+            if i % 4 == 1:
+                f.write(b" a line that starts with a blank" + e + b"\tand one with a tab" + e)
+            for o in range(0, len(s_), 61 + i % 7):
+                f.write(s_[o:o + 61 + i % 7] + (e if i % 5 else ends[(i + o) % 3]))
+            if i % 6 == 2:
+                f.write(e)          # an empty line
+        last = bytes(seqs[0])[:300]
+        f.write(b">last_one" + b"\r\n" + last)          # no line end behind the last line
+    with open(plain, "ab") as f:
+        f.write(b">last_one\n" + last + b"\n")
+    outs = []
+    for fa in (plain, odd):
+        out = str(tmp_path / (os.path.basename(fa) + ".clstr"))
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([BIN, fa, os.path.join(GOLDEN, c["weights"]), str(c["k"]), str(c["dtype"]), str(c["sim"]), out, str(c["block"])], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"last_one") == 1 and outs[0].count(b">Cluster") >= 2
