@@ -663,6 +663,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		uint32_t pk_a = 0, pk_b = 0;          // two pairs of 16-bit counters (see below)
 		xjd = 0.0; xjs = 0.0;
 		uint32_t spurious = 0;
+		bool cnt_dirty = multi;          // (uniform) the wave's LDS cell counts were touched: a repeated-bin item nearly always, a round only through its rare bins
 		if (!multi) {
 			const uint32_t nc = mt.n;
 			const uint32_t T = nc > nq_tot ? nc : nq_tot;
@@ -708,6 +709,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 						}
 						q_push(hit && cb >= 8, 2u, cb, 1u);
 					}
+					cnt_dirty = true;
 					if (qn > kRiQueue - 256) q_drain();
 				}
 			}
@@ -743,7 +745,9 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		}
 		if (has_next) issue(item_n, mt_n, a, b, before_round);          // the next item's loads, in front of this item's spot terms and flush
 		q_drain();
-		const uint32_t ta = wave_total_u32(pk_a), tb = wave_total_u32(pk_b);
+		// the item's three totals in one pass over the wave (msc_wave.h: four sums for the price of ~1.7)
+		const uint32_t rows = wave_sum4_rows(pk_a, pk_b, emd, 0u);
+		const uint32_t ta = MSC_ROW_A(rows), tb = MSC_ROW_B(rows);
 		uint64_t prod_t = 0;
 		uint32_t mins_t = 0;
 		uint64_t emd_t = 0;
@@ -754,7 +758,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			v1 = c01; v2 = c02; v3 = c03;
 			prod_t += c02 + 2 * (uint64_t)c03;
 			mins_t += c02 + c03;
-			emd_t = wave_total_u64(emd);          // (a lane's sum: 16 x 4^k < 2^32)
+			emd_t = MSC_ROW_C(rows);          // (a round's sum: 1 024 x 4^k <= 2^28 up to k = 9, the kernel's bound)
 		} else {
 			v1 = 0u - (ta & 0xffffu); v2 = 0u - (ta >> 16);
 			v9 = tb & 0xffffu; v10 = tb >> 16;
@@ -765,12 +769,14 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		uint32_t v = 0;
 		if constexpr (DIV) {
 			wave_sum_f64_pair(xjd, xjs);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			v = s_cnt[wave][lane];
-			s_cnt[wave][lane] = 0u;
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			__builtin_amdgcn_wave_barrier();
+			if (cnt_dirty) {
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				v = s_cnt[wave][lane];
+				s_cnt[wave][lane] = 0u;
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
 		}
 		v += lane == 1 ? v1 : lane == 2 ? v2 : lane == 3 ? v3 : lane == 9 ? v9 : lane == 10 ? v10 : 0u;
 		v = lane == 0 ? (uint32_t)emd_t : lane == 32 ? (uint32_t)(emd_t >> 32) : lane == 8 ? (uint32_t)prod_t : lane == 16 ? (uint32_t)(prod_t >> 32) : lane == 24 ? mins_t : v;

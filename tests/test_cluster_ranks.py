@@ -141,3 +141,57 @@ def test_fasta_line_ends_and_skipped_lines(oracle, tmp_path):
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"last_one") == 1 and outs[0].count(b">Cluster") >= 2
+
+
+@pytest.mark.parametrize("dead", [1, 0])
+def test_a_rank_that_dies_takes_the_others_down(oracle, tmp_path, dead):
+    """ADVICE r04: no test killed a peer. A rank whose peer is gone must END with an error, not wait for ever: msc::TcpComm
+    (host/msc_comm.hpp) throws from the first send / receive that meets the closed socket. The dead rank is played by this test itself --
+    it keeps the rendezvous (rank 1 says its number, rank 0 listens and accepts) and then closes the connection, which is what the kernel
+    does to the sockets of a process that was killed -- so that the moment of death does not depend on a race with a real process."""
+    import struct
+    import time
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle", "sharded_oracle"])
+    c = CASES["cfg1"]
+    fa = str(tmp_path / "cfg1.fa")
+    seqs, hdrs = c["make"]()
+    synth.write_fasta(fa, seqs, hdrs)
+    port = _free_port()
+    sock_port = port + 1 + 16          # CommEnv::from_environment: MASTER_PORT + 1 + MSC_PORT_OFFSET (16 by default)
+    alive = 1 - dead
+    listener = None
+    if dead == 0:
+        listener = socket.socket()
+        listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        listener.bind(("127.0.0.1", sock_port))
+        listener.listen(2)
+        listener.settimeout(60)
+    env = dict(os.environ, RANK=str(alive), WORLD_SIZE="2", LOCAL_RANK=str(alive), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.Popen([BIN, fa, os.path.join(GOLDEN, c["weights"]), str(c["k"]), str(c["dtype"]), str(c["sim"]), str(tmp_path / "dead.clstr"), str(c["block"])],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        if dead == 0:
+            conn, _ = listener.accept()
+            assert struct.unpack("<i", conn.recv(4))[0] == 1
+            conn.close()
+            listener.close()
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    conn = socket.create_connection(("127.0.0.1", sock_port), timeout=5)
+                    break
+                except OSError:
+                    assert time.time() - t0 < 60 and p.poll() is None, "rank 0 never listened"
+                    time.sleep(0.05)
+            conn.sendall(struct.pack("<i", 1))
+            conn.close()
+        t0 = time.time()
+        log = p.communicate(timeout=120)[0].decode(errors="replace")
+    except subprocess.TimeoutExpired:
+        p.kill()
+        pytest.fail("the surviving rank hung")
+    assert p.returncode != 0, log[-2000:]
+    assert "a peer went away" in log, log[-2000:]
+    assert time.time() - t0 < 60
