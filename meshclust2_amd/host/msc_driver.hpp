@@ -236,9 +236,13 @@ struct Cluster {
 	                             // (bins, length, id of that point; the magnitude stays whatever it was) and is skipped
 	std::vector<SeqRecord*> members;
 	bool merged_away = false;
-	// what the last update round asked about this centre -- the point it held and the points of its neighbourhood, in order -- and what came
-	// back. The same question has the same answer (the centre's histogram, the model and the list decide it): a round does not ask it again.
-	std::vector<uint32_t> asked;          // [0] = the centre's point, then the neighbourhood's points
+	uint32_t serial = 0;         // the cluster's number in the order of making: names it for the whole run
+	uint32_t version = 0;        // counts the changes of `members` since the cluster was made (a merge appends to them)
+	// what the last update round asked about this centre -- the point it held and the clusters of its neighbourhood, in order, each as
+	// (serial, version): equal pairs are equal member lists -- and what came back.
+	// The same question has the same answer (the centre's histogram, the model and the list decide it): a round does not ask it again.
+	// (r05: the lists themselves were kept and compared point by point, a pointer chase per member: 1.0 s of BASELINE cfg3's nine rounds.)
+	std::vector<uint64_t> asked;          // [0] = the centre's point, then serial << 32 | version of clusters lo .. hi
 	SeqRecord* answer = nullptr;
 	bool answered = false;
 };
@@ -442,6 +446,7 @@ private:
 		}
 		Cluster cl;
 		cl.centre = be_.centre_new(last->point);
+		cl.serial = serial_++;
 		move_centre(cl, last);
 		cl.members = current;
 		part.push_back(cl);
@@ -470,23 +475,19 @@ private:
 			std::vector<SeqRecord*> good, mine;
 			for (size_t j = 0; j < n; j++) {
 				const int lo = std::max(0, (int)j - delta), hi = std::min((int)j + delta, (int)n - 1);
+				auto name = [&](int i) { return (uint64_t)part[(size_t)i].serial << 32 | part[(size_t)i].version; };
 				if (part[j].answered) {          // the same question as last round? (compared in place: nothing is built for a centre that is not asked about)
-					const std::vector<uint32_t>& q = part[j].asked;
-					bool same = !q.empty() && q[0] == part[j].centre_point;
-					size_t at = 1;
-					for (int i = lo; same && i <= hi; i++)
-						for (const SeqRecord* p : part[(size_t)i].members) {
-							if (at >= q.size() || q[at] != p->point) { same = false; break; }
-							at++;
-						}
-					if (same && at == q.size()) continue;
+					const std::vector<uint64_t>& q = part[j].asked;
+					bool same = q.size() == (size_t)(hi - lo + 2) && q[0] == part[j].centre_point;
+					for (int i = lo; same && i <= hi; i++) same = q[(size_t)(1 + i - lo)] == name(i);
+					if (same) continue;
 				}
 				mine.clear();
 				neighbourhood(part, j, delta, mine);
-				std::vector<uint32_t>& q = part[j].asked;
+				std::vector<uint64_t>& q = part[j].asked;
 				q.clear();
 				q.push_back(part[j].centre_point);
-				for (SeqRecord* p : mine) q.push_back(p->point);
+				for (int i = lo; i <= hi; i++) q.push_back(name(i));
 				part[j].answered = false;
 				which.push_back(j);
 				centres.push_back(part[j].centre);
@@ -557,6 +558,7 @@ private:
 				std::vector<SeqRecord*>& to = part[(size_t)ret].members;
 				const std::vector<SeqRecord*>& from = part[(size_t)i].members;
 				to.insert(to.end(), from.begin(), from.end());
+				part[(size_t)ret].version++;
 				part[(size_t)i].merged_away = true;
 			}
 		}
@@ -577,6 +579,7 @@ private:
 	ClusterBackend& be_;
 	std::ostream& log_;
 	bool ranged_ = false;
+	uint32_t serial_ = 0;
 	std::vector<uint32_t> close_;
 	std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
 };
