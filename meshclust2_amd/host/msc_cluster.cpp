@@ -358,6 +358,8 @@ int main(int argc, char** argv) {
 		const auto t_start = std::chrono::steady_clock::now();
 		msc::Context ctx(device);
 		ctx.set_kernel_timing(false);          // the accumulate loop is one get_close per step: no per-call event records
+		if (std::getenv("MSC_CLUSTER_PROFILE"))
+			std::cout << "input profile: context " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
 		std::vector<std::string> headers, seqs;
 		std::vector<size_t> file_first;                // index of every file's first record (find_k averages per file, then over the files)
 		for (const auto& f : files) { file_first.push_back(seqs.size()); read_fasta(f, headers, seqs, single_file); }

@@ -269,9 +269,25 @@ public:
 	std::vector<Cluster> run(std::vector<SeqRecord>& records, double sim, int iterations, int delta, const char* output) {
 		std::vector<SeqRecord*> pts(records.size());
 		for (size_t i = 0; i < records.size(); i++) { records[i].point = (uint32_t)i; pts[i] = &records[i]; }
-		// get_points: sort by header, then by length, both unstable std::sort (cluster/CRunner.cpp:538-539)
-		std::sort(pts.begin(), pts.end(), [](SeqRecord* a, SeqRecord* b) { return a->header < b->header; });
-		std::sort(pts.begin(), pts.end(), [](SeqRecord* a, SeqRecord* b) { return a->length < b->length; });
+		// get_points: sort by header, then by length, both unstable std::sort (cluster/CRunner.cpp:538-539). Where equal lengths end up is
+		// whatever std::sort does with them, so it is std::sort here too, with comparators that answer every question as those of the
+		// reference do -- the sequence of moves depends on the answers alone -- but from a key that travels with the pointer (the first
+		// eight bytes of the header, most significant first, zeros behind a shorter one: it orders as memcmp does wherever it differs;
+		// then the length) instead of from two cache lines per question: 0.35 -> 0.15 s of BASELINE cfg3's 10^6 records.
+		{
+			struct Keyed { uint64_t key; SeqRecord* p; };
+			std::vector<Keyed> v(records.size());
+			for (size_t i = 0; i < v.size(); i++) {
+				const std::string& h = records[i].header;
+				uint64_t key = 0;
+				for (size_t c = 0; c < 8; c++) key = key << 8 | (c < h.size() ? (unsigned char)h[c] : 0u);
+				v[i] = Keyed{key, &records[i]};
+			}
+			std::sort(v.begin(), v.end(), [](const Keyed& a, const Keyed& b) { return a.key != b.key ? a.key < b.key : a.p->header < b.p->header; });
+			for (Keyed& x : v) x.key = x.p->length;
+			std::sort(v.begin(), v.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+			for (size_t i = 0; i < v.size(); i++) pts[i] = v[i].p;
+		}
 		std::vector<uint64_t> lengths;
 		for (SeqRecord* p : pts) lengths.push_back(p->length);
 		LengthBins store(lengths, 1000);

@@ -107,7 +107,7 @@ def test_sharded_mean_shift_mixed_lengths(oracle, tmp_path):
 def test_fasta_line_ends_and_skipped_lines(oracle, tmp_path):
     """msc::read_fasta (host/msc_fasta.hpp; nonltr/ChromListMaker.cpp:24-48,117-165): LF, CR LF and lone CR line ends, a last line without
     one, lines that start with a blank skipped, text in front of the first header dropped -- the same records, hence the same .clstr bytes,
-    as the plain file (r05: the file is read in one piece and cut in memory)."""
+    as the plain file (r05: the file is read in one piece and cut in memory, by several threads when it is long)."""
     if not os.path.exists(BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle", "sharded_oracle"])
     c = CASES["k9_u8"]
@@ -133,14 +133,18 @@ def test_fasta_line_ends_and_skipped_lines(oracle, tmp_path):
     with open(plain, "ab") as f:
         f.write(b">last_one\n" + last + b"\n")
     outs = []
-    for fa in (plain, odd):
+    # (MSC_FASTA_SHARE: the bytes a reading thread takes at least -- 32 MiB in production; here the file is cut into as many shares as the
+    # box has threads, up to sixteen, so that shares begin inside records, inside CR LF pairs and in the text in front of the first header)
+    for fa, share in ((plain, None), (odd, None), (odd, 1), (odd, 4099), (plain, 257)):
         out = str(tmp_path / (os.path.basename(fa) + ".clstr"))
         env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        if share:
+            env["MSC_FASTA_SHARE"] = str(share)
         r = subprocess.run([BIN, fa, os.path.join(GOLDEN, c["weights"]), str(c["k"]), str(c["dtype"]), str(c["sim"]), out, str(c["block"])], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
         outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1] and outs[0].count(b"last_one") == 1 and outs[0].count(b">Cluster") >= 2
+    assert all(o == outs[0] for o in outs) and outs[0].count(b"last_one") == 1 and outs[0].count(b">Cluster") >= 2
 
 
 @pytest.mark.parametrize("dead", [1, 0])
