@@ -794,6 +794,8 @@ def main():
         hist_bytes //= 2
     if args.layout == "sparse":            # a pair reads the candidate's entry list: 8 bytes per stored bin (mean over a sample of slots)
         hist_bytes = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
+    if kernel.startswith("k_pair_ranks"):          # a pass over rank lists reads 4 bytes per k-mer of a candidate (secondary_legs counts the same)
+        hist_bytes = 4 * (args.length - args.k + 1)
     n_launch = max(int(np.sum(launches)), 1)
     avg_ms = float(np.sum(tiles_ms)) / n_launch if tiles_ms else float("nan")
     q_call = qpr if rows_job is not None else Q          # query rows one library call of this rank scores

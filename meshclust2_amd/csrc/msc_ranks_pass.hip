@@ -194,18 +194,19 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 		return;
 	}
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
-	for (uint32_t i = threadIdx.x; i < words; i += kRpBlock) sb[i] = 0u;
-	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += kRpBlock) rq_l[i] = nbins;
+	const uint32_t bd = blockDim.x;
+	for (uint32_t i = threadIdx.x; i < words; i += bd) sb[i] = 0u;
+	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += bd) rq_l[i] = nbins;
 	__syncthreads();
-	for (uint32_t j = threadIdx.x; j < nq; j += kRpBlock) {
+	for (uint32_t j = threadIdx.x; j < nq; j += bd) {
 		const uint2 en = Q[j];
 		const uint32_t e = en.y ? en.y - 1u : 0u, end = CQ[j];
 		if (e >= 1) atomicOr(&sb[en.x >> 4], (e >= 3 ? 3u : e) << (2 * (en.x & 15)));          // two bits per bin: e_q = 0, 1, 2, or 3 = "three and more: look it up"
 		if constexpr (!QG) for (uint32_t t = end - e; t < end; t++) rq_l[t] = en.x;
 	}
 	__syncthreads();
-	const uint32_t tw = gridDim.x * (kRpBlock / 64);
-	const uint32_t c0 = blockIdx.x * (kRpBlock / 64) + wave;
+	const uint32_t tw = gridDim.x * (bd / 64);
+	const uint32_t c0 = blockIdx.x * (bd / 64) + wave;
 	if (c0 >= m) return;
 	// stage 1: the slot of a candidate (identity without a slot list)
 	auto slot_of = [&](uint32_t c) -> uint64_t { return c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : ~0ull; };
@@ -247,10 +248,16 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			const uint32_t* P = c_rk + meta0.off;
 			const uint32_t T = nc > nq_tot ? nc : nq_tot;
 			uint64_t emd = 0;
-			uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries
-			uint32_t carry = 0xffffffffu;         // the entry in front of this round's first
-			uint32_t carry_x = 0xffffffffu, carry_y = 0xffffffffu, carry_z = 0xffffffffu;
-			auto chunk = [&](uint32_t t0, const uint4& a) {
+			uint32_t prod = 0, mins = 0;          // sum e_c e_q and sum min(e_c, e_q) over the candidate's entries: what the packed counter does not hold
+			uint32_t carry = 0xffffffffu;         // the entry in front of this chunk's first
+			// An entry costs a table look-up, a comparison with the entry in front of it and ONE add: `pk` counts the entries whose bin the
+			// query holds (low half) and the first copies among them (high half). What the query holds twice and more -- rare: a 1 kb
+			// sequence has a handful of such bins -- adds e_q - 1 to the product and, for a further copy of the bin, its share of the
+			// minimum; a chunk in which any lane met one walks its four entries again for that (r05: every entry went through those
+			// branches, and every chunk through six lane shifts for copy indices hardly any entry asks for: 370 instructions per
+			// 1 kb candidate, 80 registers -- one workgroup per CU instead of two).
+			uint32_t pk = 0;
+			auto chunk = [&](uint32_t t0, const uint4& a, const uint4& a_before) {          // a_before: the chunk in front (unused at t0 = 0)
 				const uint32_t t = t0 + 4 * lane;
 				uint4 b = make_uint4(nbins, nbins, nbins, nbins);
 				if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
@@ -264,45 +271,70 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 				carry = (uint32_t)__builtin_amdgcn_readlane((int)a.w, 63);
 				const uint32_t av[4] = {a.x, a.y, a.z, a.w};
 				const uint32_t pv[4] = {before, a.x, a.y, a.z};
-				uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // the seven entries in front of a lane's last: an entry's copy index
-				seq[0] = lane_prev(a.x); seq[1] = lane_prev(a.y); seq[2] = lane_prev(a.z);
-				if (lane == 0) { seq[0] = carry_x; seq[1] = carry_y; seq[2] = carry_z; }
-				carry_x = (uint32_t)__builtin_amdgcn_readlane((int)a.x, 63);
-				carry_y = (uint32_t)__builtin_amdgcn_readlane((int)a.y, 63);
-				carry_z = (uint32_t)__builtin_amdgcn_readlane((int)a.z, 63);
+				uint32_t two4[4];
+				bool rare = false;
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
 					const uint32_t bin = av[j];
 					const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;          // (the padding value 4^k reads the zero word behind the table)
-					const bool first_copy = bin != pv[j];
+					two4[j] = two;
 					const uint32_t present = two ? 1u : 0u;
-					prod += present;
-					mins += present & (first_copy ? 1u : 0u);
-					uint32_t e_q = two;
-					if (two == 3u) {          // very rare: the query holds this k-mer three times or more -- how often, says its own rank list
-						const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
-						e_q = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin + 1) - lo;          // (two searches: a homopolymer run is thousands of copies)
+					pk += present + (bin != pv[j] ? present << 16 : 0u);
+					rare |= two >= 2u;
+				}
+				if (__ballot(rare)) {
+					uint32_t seq[8] = {0, 0, 0, before, a.x, a.y, a.z, a.w};          // the seven entries in front of a lane's last: an entry's copy index
+					seq[0] = lane_prev(a.x); seq[1] = lane_prev(a.y); seq[2] = lane_prev(a.z);
+					if (lane == 0) {
+						seq[0] = t0 ? (uint32_t)__builtin_amdgcn_readlane((int)a_before.x, 63) : 0xffffffffu;
+						seq[1] = t0 ? (uint32_t)__builtin_amdgcn_readlane((int)a_before.y, 63) : 0xffffffffu;
+						seq[2] = t0 ? (uint32_t)__builtin_amdgcn_readlane((int)a_before.z, 63) : 0xffffffffu;
 					}
-					if (e_q >= 2) prod += e_q - 1;
-					uint32_t r = 0;
-					const bool real = bin < nbins;          // (not the padding behind the list's end)
-					if (real && !first_copy && e_q >= 2) {          // rare: a further copy of a bin: its copy index from the entries in front of it
-						for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
-						if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
-						if (r < e_q) mins += 1;
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const uint32_t bin = av[j];
+						if (two4[j] < 2u) continue;
+						uint32_t e_q = two4[j];
+						if (e_q == 3u) {          // the query holds this k-mer three times or more -- how often, says its own rank list
+							const uint32_t lo = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin);
+							e_q = lower_bound_u32([&](uint32_t i) { return rq[i]; }, nq_tot, bin + 1) - lo;          // (two searches: a homopolymer run is thousands of copies)
+						}
+						prod += e_q - 1;
+						if (bin < nbins && bin == pv[j]) {          // a further copy of a bin (not the padding behind the list's end): its copy index from the entries in front of it
+							uint32_t r = 0;
+							for (int i = 3 + j; i >= 0; i--) { if (seq[i] != bin) break; r++; }
+							if (r == (uint32_t)(4 + j)) r = t + j - lower_bound_u32([&](uint32_t i) { return P[i]; }, nc, bin);          // (a run of eight and more)
+							if (r < e_q) mins += 1;
+						}
 					}
 				}
 			};
 #pragma unroll
-			for (uint32_t u = 0; u < 4; u++) if (256 * u < T) chunk(256 * u, d0[u]);          // the chunks that were fetched ahead
-			for (uint32_t t0 = 1024; t0 < T; t0 += 256) {                                      // longer lists: the rest as it comes
-				const uint32_t t = t0 + 4 * lane;
-				uint4 a = make_uint4(nbins, nbins, nbins, nbins);
-				if (t < nc_pad) a = *reinterpret_cast<const uint4*>(P + t);
-				chunk(t0, a);
+			for (uint32_t u = 0; u < 4; u++) if (256 * u < T) chunk(256 * u, d0[u], d0[u ? u - 1 : 0]);          // the chunks that were fetched ahead
+			prod += pk & 0xffffu;
+			mins += pk >> 16;
+			if (T > 1024) {          // longer lists: the rest as it comes
+				uint4 a_before = d0[3];
+				for (uint32_t t0 = 1024; t0 < T; t0 += 256) {
+					const uint32_t t = t0 + 4 * lane;
+					uint4 a = make_uint4(nbins, nbins, nbins, nbins);
+					if (t < nc_pad) a = *reinterpret_cast<const uint4*>(P + t);
+					pk = 0;
+					chunk(t0, a, a_before);
+					prod += pk & 0xffffu;
+					mins += pk >> 16;
+					a_before = a;
+				}
 			}
-			const uint64_t emd_t = wave_sum_u64(emd);
-			const uint64_t prod_t = wave_sum_u64(prod), mins_t = wave_sum_u64(mins);
+			uint64_t emd_t, prod_t, mins_t;
+			if (T <= 4096) {          // the three totals in one pass over the wave (msc_wave.h): each below 2^32 -- emd < 4 096 x 4^k, sum e_c e_q <= 4 096^2
+				const uint32_t rows = wave_sum4_rows((uint32_t)emd, prod, mins, 0u);
+				emd_t = MSC_ROW_A(rows); prod_t = MSC_ROW_B(rows); mins_t = MSC_ROW_C(rows);
+			} else {
+				emd_t = wave_sum_u64(emd);
+				prod_t = wave_sum_u64(prod);
+				mins_t = wave_sum_u64(mins);
+			}
 			if (lane == 0) {
 				MscPartial out;
 				out.manh = (uint64_t)nc + nq_tot - 2 * mins_t;          // sum |e_c - e_q|
@@ -910,16 +942,20 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	if (qg) k_rank_expand_one<<<dim3(8), dim3(1024), 0, st>>>((const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins, q_scratch, (uint32_t)((q_kmers + 255) & ~255ull), guard);
 	// as many workgroups as fit the chip at once (their tables take 64 KiB + the query's list of a CU's 160 KiB of LDS: two per CU for
 	// 1 kb sequences at k = 9); fewer when the window is short: a workgroup's set-up is ~2 us
-	const uint32_t per_wg = kRpBlock / 64;
+	// (r05: at 86 registers -- five waves per SIMD -- only one sixteen-wave workgroup is resident per CU, the second set of 256 follows the
+	// first. Measured on 100 000 x 1 kb: 1 024 threads x 2 per CU 96.9 us, x 1 98.6; 768 x 2 114.5; 640 x 2 125; 512 x 2 99.7, x 3 121;
+	// capped at 64 registers, two resident: 18 spilled, 158 us.)
 	const uint32_t per_cu = (uint32_t)std::min<size_t>(2, (160 * 1024) / lds);
+	const uint32_t block = kRpBlock;
+	const uint32_t per_wg = block / 64;
 	// (at least n candidates per wave, i.e. fewer workgroups for a short window, was measured on a window-bearing run,
 	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
 	uint32_t blocks = (m + per_wg - 1) / per_wg;
 	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
 	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
-	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
+	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(block), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
 	                                                                           use_window, min_len, max_len, partials, q_cap, guard, q_scratch);
-	else k_pair_ranks_1xm<false><<<dim3(blocks), dim3(kRpBlock), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
+	else k_pair_ranks_1xm<false><<<dim3(blocks), dim3(block), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
 	                                                                         use_window, min_len, max_len, partials, q_cap, guard, nullptr);
 	return hipGetLastError();
 }
