@@ -209,28 +209,35 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	const uint32_t c0 = blockIdx.x * (bd / 64) + wave;
 	if (c0 >= m) return;
 	// stage 1: the slot of a candidate (identity without a slot list)
-	auto slot_of = [&](uint32_t c) -> uint64_t { return c < m ? (cand_slots ? (uint64_t)cand_slots[c] : first + c) : ~0ull; };
+	// (every load of the three stages is UNCONDITIONAL, from a clamped place, and what must not count is dropped when it is used: behind a
+	// load under a branch the compiler cannot count what is in flight and waits for all of it -- vmcnt(0) in front of every candidate, the
+	// next one's entries included: the walk was three deep on paper only, r05)
+	auto slot_of = [&](uint32_t c) -> uint64_t { const uint32_t cc = c < m ? c : m - 1; return cand_slots ? (uint64_t)cand_slots[cc] : first + cc; };
 	// stage 2: where its rank list sits, how long it is, whether the length window keeps it (n = 0xffffffff: not scored)
-	struct Meta { uint64_t off; uint32_t n; };
+	// (... as it arrives: whether the candidate counts is decided by whoever USES the record, an iteration later -- a comparison here makes the
+	// compiler wait for the loads it has just issued)
+	struct Meta { uint64_t off, len; uint32_t n; bool inside; };
 	auto meta_of = [&](uint32_t c, uint64_t slot) -> Meta {
-		Meta mt{0, 0xffffffffu};
-		if (c >= m) return mt;
-		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)c) * scalar_stride);
-		const uint64_t len = cs->length;
+		Meta mt;
+		const uint32_t cc = c < m ? c : m - 1;
+		const MscSlotScalars* cs = reinterpret_cast<const MscSlotScalars*>(cand_scalars + (cand_slots ? slot : (uint64_t)cc) * scalar_stride);
+		mt.len = cs->length;
 		mt.off = c_off[slot];
 		mt.n = c_n[slot];
-		if (use_window && (len < min_len || len > max_len)) mt.n = 0xffffffffu;
+		mt.inside = c < m;
 		return mt;
 	};
+	auto scored_n = [&](const Meta& mt) -> uint32_t { return !mt.inside || (use_window && (mt.len < min_len || mt.len > max_len)) ? 0xffffffffu : mt.n; };
 	// stage 3: the first four chunks of 256 entries (16 bytes per lane each)
 	auto data_of = [&](const Meta& mt, uint4 (&d)[4]) {
-		const uint32_t n_pad = mt.n == 0xffffffffu ? 0u : (mt.n + 3u) & ~3u;
+		const uint32_t n_of = scored_n(mt);
+		const uint32_t n_pad = n_of == 0xffffffffu ? 0u : (n_of + 3u) & ~3u;
+		const uint32_t last4 = n_pad ? n_pad - 4u : 0u;          // (a list is padded to four entries in the arena; an empty one reads its first four words, whatever they are)
 		const uint32_t* P = c_rk + mt.off;
 #pragma unroll
 		for (uint32_t u = 0; u < 4; u++) {
 			const uint32_t t = 256 * u + 4 * lane;
-			d[u] = make_uint4(nbins, nbins, nbins, nbins);
-			if (t < n_pad) d[u] = *reinterpret_cast<const uint4*>(P + t);
+			d[u] = *reinterpret_cast<const uint4*>(P + (t < last4 ? t : last4));
 		}
 	};
 	uint64_t slot2 = slot_of(c0 + 2 * tw);
@@ -243,8 +250,9 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 		const Meta meta2 = meta_of(c + 2 * tw, slot2);
 		uint4 d1[4];
 		data_of(meta1, d1);
-		if (meta0.n != 0xffffffffu) {
-			const uint32_t nc = meta0.n, nc_pad = (nc + 3u) & ~3u;
+		const uint32_t n0 = scored_n(meta0);
+		if (n0 != 0xffffffffu) {
+			const uint32_t nc = n0, nc_pad = (nc + 3u) & ~3u;
 			const uint32_t* P = c_rk + meta0.off;
 			const uint32_t T = nc > nq_tot ? nc : nq_tot;
 			uint64_t emd = 0;
@@ -309,6 +317,9 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 					}
 				}
 			};
+			const uint4 fill = make_uint4(nbins, nbins, nbins, nbins);
+#pragma unroll
+			for (uint32_t u = 0; u < 4; u++) if (256 * u + 4 * lane >= nc_pad) d0[u] = fill;          // (behind the list's end: what the clamped load brought is not the list's)
 #pragma unroll
 			for (uint32_t u = 0; u < 4; u++) if (256 * u < T) chunk(256 * u, d0[u], d0[u ? u - 1 : 0]);          // the chunks that were fetched ahead
 			prod += pk & 0xffffu;
