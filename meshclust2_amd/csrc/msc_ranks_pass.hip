@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
 	const uint32_t bd = blockDim.x;
 	for (uint32_t i = threadIdx.x; i < words; i += bd) sb[i] = 0u;
-	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < nq_pad; i += bd) rq_l[i] = nbins;
+	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < (nq_pad > 1024u ? nq_pad : 1024u); i += bd) rq_l[i] = nbins;          // (at least the four chunks a wave reads without asking)
 	__syncthreads();
 	for (uint32_t j = threadIdx.x; j < nq; j += bd) {
 		const uint2 en = Q[j];
@@ -268,7 +268,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			auto chunk = [&](uint32_t t0, const uint4& a, const uint4& a_before) {          // a_before: the chunk in front (unused at t0 = 0)
 				const uint32_t t = t0 + 4 * lane;
 				uint4 b = make_uint4(nbins, nbins, nbins, nbins);
-				if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
+				if (!QG && t0 < 1024) b = *reinterpret_cast<const uint4*>(rq + t);          // (the list in LDS is filled up to 1 024 entries)
+				else if (t < nq_pad) b = *reinterpret_cast<const uint4*>(rq + t);
 				uint32_t d = sad_u32(a.x, b.x, 0u);
 				d = sad_u32(a.y, b.y, d);
 				d = sad_u32(a.z, b.z, d);
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
 					const uint32_t bin = av[j];
-					const uint32_t two = (sb[bin >> 4] >> (2 * (bin & 15))) & 3u;          // (the padding value 4^k reads the zero word behind the table)
+					const uint32_t two = __builtin_amdgcn_ubfe(sb[bin >> 4], 2 * bin, 2);          // (v_bfe_u32 takes the offset modulo 32; the padding value 4^k reads the zero word behind the table)
 					two4[j] = two;
 					const uint32_t present = two ? 1u : 0u;
 					pk += present + (bin != pv[j] ? present << 16 : 0u);
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			};
 			const uint4 fill = make_uint4(nbins, nbins, nbins, nbins);
 #pragma unroll
-			for (uint32_t u = 0; u < 4; u++) if (256 * u + 4 * lane >= nc_pad) d0[u] = fill;          // (behind the list's end: what the clamped load brought is not the list's)
+			for (uint32_t u = 0; u < 4; u++) if (256 * (u + 1) > nc_pad && 256 * u + 4 * lane >= nc_pad) d0[u] = fill;          // (behind the list's end: what the clamped load brought is not the list's)
 #pragma unroll
 			for (uint32_t u = 0; u < 4; u++) if (256 * u < T) chunk(256 * u, d0[u], d0[u ? u - 1 : 0]);          // the chunks that were fetched ahead
 			prod += pk & 0xffffu;
@@ -914,7 +915,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 size_t msc_ranks_pass_lds(uint64_t nbins, uint64_t q_kmers) {
 	if (nbins > (1ull << 18) || nbins % 32 || q_kmers > (1ull << 26)) return 0;
 	const size_t words = nbins / 16 + 1;
-	return (words + 4) * 4 + (q_kmers > kRpQCap ? 0 : (((size_t)q_kmers + 255) & ~(size_t)255) * 4);          // (a longer query's ranks stay in global memory)
+	return (words + 4) * 4 + (q_kmers > kRpQCap ? 0 : std::max<size_t>(1024, ((size_t)q_kmers + 255) & ~(size_t)255) * 4);          // (a longer query's ranks stay in global memory; 1 024 entries at least: k_pair_ranks_1xm reads four chunks without asking)
 }
 // entries of global scratch a pass needs for the query's rank list (0: the list fits LDS)
 uint64_t msc_ranks_pass_query_scratch(uint64_t q_kmers) { return q_kmers > kRpQCap ? ((q_kmers + 255) & ~255ull) : 0; }
