@@ -579,7 +579,6 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 		s_cnt[wave][lane] = 0u;
 	}
 	const uint32_t n_items = cnt_p[12];
-	const uint32_t n_waves = gridDim.x * (kRpBlock / 64);
 	(void)m; (void)q_ent;
 	// SPOT TERMS. A bin the candidate holds 8 times and more, or the query 7 and more, has no cell: its term is two FP64 logarithms on the
 	// spot. Evaluated where they turn up -- one lane in sixty-four, four times over in an unrolled loop -- they were a third of the kernel
@@ -651,15 +650,25 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 			if (j0 + 2 < mt.nm) a[1] = *reinterpret_cast<const uint4*>(M + j0 + 2);
 		}
 	};
-	uint32_t it = blockIdx.x * (kRpBlock / 64) + wave;
-	uint2 item_n = it < n_items ? items[it] : make_uint2(0u, 0u);
-	uint2 item_n2 = it + n_waves < n_items ? items[it + n_waves] : make_uint2(0u, 0u);
-	uint2 item_n3 = it + 2 * n_waves < n_items ? items[it + 2 * n_waves] : make_uint2(0u, 0u);
+	// WHO takes WHICH item. The workgroup owns a contiguous share of the list, [s0, s1); its sixteen waves take the share's items as they
+	// come free, by a counter in LDS -- three ahead, as the list is read (a wave's first three are its own by position). r05, until the
+	// end of the round every wave took items w, w + 4 096, ..: the same NUMBER each, and the slowest wave of a launch left 31 us behind a
+	// mean of 23 (items differ: rare bins, spot terms, repeated-bin items) -- the chip a quarter idle. Records are written by item, so
+	// nothing depends on who walked what.
+	__shared__ uint32_t s_ticket;
+	const uint32_t s0 = (uint32_t)((uint64_t)n_items * blockIdx.x / gridDim.x), s1 = (uint32_t)((uint64_t)n_items * (blockIdx.x + 1) / gridDim.x);
+	constexpr uint32_t kWaves = kRpBlock / 64;
+	if (threadIdx.x == 0) s_ticket = s0 + 3 * kWaves;          // (the barrier behind the tables' copy stands between this and the first ticket)
+	uint32_t it = s0 + wave, it_1 = it + kWaves, it_2 = it + 2 * kWaves;
+	uint2 item_n = it < s1 ? items[it] : make_uint2(0u, 0u);
+	uint2 item_n2 = it_1 < s1 ? items[it_1] : make_uint2(0u, 0u);
+	uint2 item_n3 = it_2 < s1 ? items[it_2] : make_uint2(0u, 0u);
 	RkItemMeta mt_n = meta[item_n.x];
 	RkItemMeta mt_n2 = meta[item_n2.x];
 	uint4 a[4], b[4];
 	uint32_t before_round = 0xffffffffu;
-	if (it < n_items) issue(item_n, mt_n, a, b, before_round);
+	uint32_t it_3 = 0;
+	if (it < s1) issue(item_n, mt_n, a, b, before_round);
 	// The query's counts >= 8 were appended in whatever order k_rank_pass_prep's waves came by; the finish kernel adds an FP64 term per
 	// entry in list order, and a sum must not depend on that: the first workgroup sorts the list (a bitonic network in the LDS the
 	// tables are about to take; lists longer than that -- 16 384 at k = 9 -- stay as they are). Nothing in this kernel reads it.
@@ -691,13 +700,16 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_items(const uint32_t* _
 	// clocks of a kernel of 47 000); the wave's first loads are on their way meanwhile
 	for (uint32_t i = 4 * threadIdx.x; i < words_pad + 2 * kRiHash; i += 4 * kRpBlock) *reinterpret_cast<uint4*>(s_rp + i) = *reinterpret_cast<const uint4*>(tab + i);
 	__syncthreads();
-	for (; it < n_items; it += n_waves) {
+	for (; it < s1; it = it_1, it_1 = it_2, it_2 = it_3) {
 		const uint2 item = item_n;
 		const RkItemMeta mt = mt_n;
 		item_n = item_n2; mt_n = mt_n2; item_n2 = item_n3;
 		mt_n2 = meta[item_n2.x];          // (its item arrived an iteration ago)
-		if (it + 3 * n_waves < n_items) item_n3 = items[it + 3 * n_waves];
-		const bool has_next = it + n_waves < n_items;
+		uint32_t tk = 0;
+		if (lane == 0) tk = atomicAdd(&s_ticket, 1u);
+		it_3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+		if (it_3 < s1) item_n3 = items[it_3];
+		const bool has_next = it_1 < s1;
 		const uint32_t rd = item.y & ~kRiMultiFlag;
 		const bool multi = (item.y & kRiMultiFlag) != 0;
 		cm = mt.mag;
