@@ -195,6 +195,8 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 	}
 	const uint32_t nq_pad = (nq_tot + 255u) & ~255u;
 	const uint32_t bd = blockDim.x;
+	__shared__ uint32_t s_ticket;
+	if (threadIdx.x == 0) s_ticket = (uint32_t)((uint64_t)m * blockIdx.x / gridDim.x) + 3 * (bd / 64);          // (two barriers stand between this and the first ticket)
 	for (uint32_t i = threadIdx.x; i < words; i += bd) sb[i] = 0u;
 	if constexpr (!QG) for (uint32_t i = nq_tot + threadIdx.x; i < (nq_pad > 1024u ? nq_pad : 1024u); i += bd) rq_l[i] = nbins;          // (at least the four chunks a wave reads without asking)
 	__syncthreads();
@@ -205,9 +207,14 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 		if constexpr (!QG) for (uint32_t t = end - e; t < end; t++) rq_l[t] = en.x;
 	}
 	__syncthreads();
-	const uint32_t tw = gridDim.x * (bd / 64);
-	const uint32_t c0 = blockIdx.x * (bd / 64) + wave;
-	if (c0 >= m) return;
+	// WHO scores WHICH candidate: the workgroup owns a contiguous share of the window, [s0, s1), and its waves take the share's
+	// candidates as they come free -- a counter in LDS, read three candidates ahead like the window's list (a wave's first three are its
+	// own by position). r05, until the end of the round: every wave took candidates w, w + waves, .. and two workgroups per CU were
+	// launched of which the registers admit one -- the second set rebuilt the tables (3.9 us) behind the first.
+	const uint32_t s0 = (uint32_t)((uint64_t)m * blockIdx.x / gridDim.x), s1 = (uint32_t)((uint64_t)m * (blockIdx.x + 1) / gridDim.x);
+	const uint32_t nw = bd / 64;
+	const uint32_t c0 = s0 + wave;
+	if (c0 >= s1) return;
 	// stage 1: the slot of a candidate (identity without a slot list)
 	// (every load of the three stages is UNCONDITIONAL, from a clamped place, and what must not count is dropped when it is used: behind a
 	// load under a branch the compiler cannot count what is in flight and waits for all of it -- vmcnt(0) in front of every candidate, the
@@ -224,7 +231,7 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 		mt.len = cs->length;
 		mt.off = c_off[slot];
 		mt.n = c_n[slot];
-		mt.inside = c < m;
+		mt.inside = c < s1;
 		return mt;
 	};
 	auto scored_n = [&](const Meta& mt) -> uint32_t { return !mt.inside || (use_window && (mt.len < min_len || mt.len > max_len)) ? 0xffffffffu : mt.n; };
@@ -240,14 +247,18 @@ __global__ void __launch_bounds__(kRpBlock) k_pair_ranks_1xm(const uint32_t* __r
 			d[u] = *reinterpret_cast<const uint4*>(P + (t < last4 ? t : last4));
 		}
 	};
-	uint64_t slot2 = slot_of(c0 + 2 * tw);
-	Meta meta1 = meta_of(c0 + tw, slot_of(c0 + tw));
+	uint32_t c_1 = c0 + nw, c_2 = c0 + 2 * nw, c_3 = 0;
+	uint64_t slot2 = slot_of(c_2);
+	Meta meta1 = meta_of(c_1, slot_of(c_1));
 	Meta meta0 = meta_of(c0, slot_of(c0));
 	uint4 d0[4];
 	data_of(meta0, d0);
-	for (uint32_t c = c0; c < m; c += tw) {
-		const uint64_t slot3 = slot_of(c + 3 * tw);
-		const Meta meta2 = meta_of(c + 2 * tw, slot2);
+	for (uint32_t c = c0; c < s1; c = c_1, c_1 = c_2, c_2 = c_3) {
+		uint32_t tk = 0;
+		if (lane == 0) tk = atomicAdd(&s_ticket, 1u);
+		c_3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+		const uint64_t slot3 = slot_of(c_3);
+		const Meta meta2 = meta_of(c_2, slot2);
 		uint4 d1[4];
 		data_of(meta1, d1);
 		const uint32_t n0 = scored_n(meta0);
@@ -975,7 +986,8 @@ hipError_t msc_launch_pair_ranks_1xm(hipStream_t st, const uint32_t* c_rk, const
 	// (at least n candidates per wave, i.e. fewer workgroups for a short window, was measured on a window-bearing run,
 	// 13 300 candidates per pass on average: 31.5 / 37.7 / 46.8 us per pass for n = 1 / 4 / 8 -- spreading wins)
 	uint32_t blocks = (m + per_wg - 1) / per_wg;
-	if (blocks > (uint32_t)num_cus * per_cu) blocks = (uint32_t)num_cus * per_cu;
+	(void)per_cu;
+	if (blocks > (uint32_t)num_cus) blocks = (uint32_t)num_cus;          // (one resident workgroup per CU: see above)
 	const uint32_t q_cap = (uint32_t)((q_kmers + 255) & ~255ull);
 	if (qg) k_pair_ranks_1xm<true><<<dim3(blocks), dim3(block), lds, st>>>(c_rk, c_off, c_n, cand_scalars, scalar_stride, cand_slots, first, m, (const uint2*)q_ent, q_cum, q_hdr, (uint32_t)nbins,
 	                                                                           use_window, min_len, max_len, partials, q_cap, guard, q_scratch);
