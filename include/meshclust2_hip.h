@@ -357,6 +357,12 @@ int msc_update_centres(msc_ctx* ctx, const msc_model* model, double cutoff, cons
 int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
                   int delta, int64_t* best_out);
 
+/* ... for SOME of those calls: best_out[w] = what msc_merge returns for (current = which[w], begin = which[w] + 1,
+ * last = min(n - 1, which[w] + delta)) over the same list of n centres. Once the clusters have settled a round of the merge loop
+ * repeats the round before it; the driver asks only about the centres whose delta + 1 histograms changed. */
+int msc_merge_some(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+                   int delta, const uint64_t* which, uint64_t n_which, int64_t* best_out);
+
 /* ------------------------------------------------------------------ f2: training on labelled pairs
  * Replaces the feature-selection half of Predictor<T>::train (predict/Predictor.cpp:876-975): calculate_table,
  * BestFirstSelector<T>::train_class and GLM::train (predict/BestFirstSelector.cpp:113-250, predict/GLM.cpp:20-23) on pairs

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "msc_mean_nearest": (_int, [_vp, _vp, _vp, _u64, _pi64, _vp, _vp]),
     "msc_update_centres": (_int, [_vp, _vp, C.c_double, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "msc_merge_all": (_int, [_vp, _vp, C.c_double, _vp, _vp, C.c_uint64, _int, _vp]),
+    "msc_merge_some": (_int, [_vp, _vp, C.c_double, _vp, _vp, C.c_uint64, _int, _vp, C.c_uint64, _vp]),
     "msc_train_class": (_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _int, _int, C.c_double, C.c_char_p, C.c_size_t, _vp, _vp]),
     "msc_train_regr": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _int, _dbl, C.c_char_p, C.c_size_t, _pdbl, _pdbl]),
     "msc_hist_set_device_view": (_int, [_vp, C.POINTER(_vp), _pu64, C.POINTER(_vp), _pu64]),

@@ -402,6 +402,14 @@ class Trainer:
         self.ctx.check(self.ctx.lib.msc_merge_all(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(sl), sl.size, int(delta), _ptr(best)))
         return best
 
+    def merge_some(self, centres, centre_slots, delta, which):
+        """... for the centres which[w] only -> best[len(which)]"""
+        sl = np.ascontiguousarray(centre_slots, dtype=np.uint32)
+        wh = np.ascontiguousarray(which, dtype=np.uint64)
+        best = np.zeros(wh.size, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.msc_merge_some(self.ctx.h, self.feat.h, self.cutoff, centres.h, _ptr(sl), sl.size, int(delta), _ptr(wh), wh.size, _ptr(best)))
+        return best
+
     def update_centres(self, centres, centre_slots, points, lists):
         """mean_shift_update for many centres: lists[c] = point slots of centre c's neighbourhood.
         -> (nearest_pos[n] (position inside lists[c], -1 if nothing survives the filter), n_kept[n])"""

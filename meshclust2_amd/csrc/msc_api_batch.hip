@@ -499,11 +499,14 @@ extern "C" int msc_filter_batch(msc_ctx* ctx, const msc_model* model, double cut
 // Trainer::merge for EVERY centre of the serial merge loop in one launch (cluster/ClusterFactory.cpp:383-401 calls
 // trn.merge(centers, i, i + 1, min(n - 1, i + delta)) for i = 0 .. n-1; no call changes a histogram, so the calls are independent).
 // best_out[i] = what msc_merge(..., current = i, begin = i + 1, last = min(n - 1, i + delta)) returns.
-extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
-                             int delta, int64_t* best_out) {
-	if (!ctx || !model || model->ctx != ctx || !centres || centres->ctx != ctx || (n && (!centre_slots || !best_out)) || delta < 0) return MSC_ERR_INVALID_ARG;
-	if (n == 0) return MSC_OK;
+// which == nullptr: every centre, best_out[i] for centre i; else best_out[w] for centre which[w] (ascending or not: the calls are independent)
+static int merge_impl(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n, int delta,
+                      const uint64_t* which, uint64_t n_which, int64_t* best_out) {
+	if (!ctx || !model || model->ctx != ctx || !centres || centres->ctx != ctx || (n && !centre_slots) || (n_which && !best_out) || delta < 0) return MSC_ERR_INVALID_ARG;
+	if (n == 0 || n_which == 0) return MSC_OK;
 	for (uint64_t i = 0; i < n; i++) if (centre_slots[i] >= centres->capacity) return fail(ctx, MSC_ERR_INVALID_ARG, "centre slot out of range");
+	if (which) for (uint64_t w = 0; w < n_which; w++) if (which[w] >= n) return fail(ctx, MSC_ERR_INVALID_ARG, "merge: centre index out of range");
+	auto centre_of = [&](uint64_t w) -> uint64_t { return which ? which[w] : w; };
 	uint64_t want = 0;
 	for (int i = 0; i < model->h.n_singles; i++) want |= model->h.single_flag[i];
 	static const bool no_batch = getenv("MSC_NO_BATCH_UPDATE") != nullptr;
@@ -519,8 +522,9 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 		one_by_one = !ok;
 	}
 	if (one_by_one) {
-		for (uint64_t i = 0; i < n; i++) {
-			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[i]);
+		for (uint64_t w = 0; w < n_which; w++) {
+			const uint64_t i = centre_of(w);
+			int r = msc_merge(ctx, model, cutoff, centres, centre_slots, n, (int64_t)i, (int64_t)i + 1, (int64_t)std::min<uint64_t>(n - 1, i + (uint64_t)delta), &best_out[w]);
 			if (r) return r;
 		}
 		return MSC_OK;
@@ -539,19 +543,21 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 	std::vector<MscBatchSeg> segs;
 	std::vector<uint32_t> pair_seg, cand;
 	std::vector<MscPairOut> po;
-	for (uint64_t c0 = 0; c0 < n;) {
+	// (c0, c1: positions in the list of centres ASKED about; ci: the centre's index among all)
+	for (uint64_t c0 = 0; c0 < n_which;) {
 		segs.clear(); pair_seg.clear(); cand.clear();
 		uint64_t c1 = c0;
 		uint32_t max_m = 0;
-		while (c1 < n && (c1 == c0 || cand.size() + (uint64_t)delta <= max_chunk_pairs)) {
+		while (c1 < n_which && (c1 == c0 || cand.size() + (uint64_t)delta <= max_chunk_pairs)) {
+			const uint64_t ci = centre_of(c1);
 			MscBatchSeg sg;
-			sg.q_slot = centre_slots[c1];
+			sg.q_slot = centre_slots[ci];
 			sg.first = (uint32_t)cand.size();
-			const uint64_t last = std::min<uint64_t>(n - 1, c1 + (uint64_t)delta);
-			for (uint64_t j = c1 + 1; j <= last; j++) { cand.push_back(centre_slots[j]); pair_seg.push_back((uint32_t)(c1 - c0)); }
+			const uint64_t last = std::min<uint64_t>(n - 1, ci + (uint64_t)delta);
+			for (uint64_t j = ci + 1; j <= last; j++) { cand.push_back(centre_slots[j]); pair_seg.push_back((uint32_t)(c1 - c0)); }
 			sg.m = (uint32_t)cand.size() - sg.first;
 			sg.pad_ = 0;
-			const uint64_t len = clen[centre_slots[c1]];
+			const uint64_t len = clen[centre_slots[ci]];
 			sg.min_len = (uint64_t)((double)len * id);      // cluster/Trainer.cpp:80-81
 			sg.max_len = (uint64_t)((double)len / id);
 			max_m = std::max(max_m, sg.m);
@@ -626,7 +632,7 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 				for (uint32_t i = 0; i < sg.m; i++) {
 					const MscPairOut& p = po[sg.first + i];
 					if (p.status != 0 || !p.close) continue;
-					if (!(best_sim > p.combo0)) { best_sim = p.combo0; best = (int64_t)(c + 1 + i); }
+					if (!(best_sim > p.combo0)) { best_sim = p.combo0; best = (int64_t)(centre_of(c) + 1 + i); }
 				}
 				best_out[c] = best;
 			}
@@ -634,4 +640,18 @@ extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff
 		c0 = c1;
 	}
 	return MSC_OK;
+}
+
+extern "C" int msc_merge_all(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+                             int delta, int64_t* best_out) {
+	return merge_impl(ctx, model, cutoff, centres, centre_slots, n, delta, nullptr, n, best_out);
+}
+
+// ... for SOME of the centres: best_out[w] = what msc_merge(..., current = which[w], begin = which[w] + 1, last = min(n - 1, which[w] + delta)) returns.
+// A round of the serial merge loop repeats most of the round before it once the clusters have settled; the driver asks only about the
+// centres whose delta + 1 histograms changed (msc_driver.hpp: merge_round).
+extern "C" int msc_merge_some(msc_ctx* ctx, const msc_model* model, double cutoff, const msc_hist_set* centres, const uint32_t* centre_slots, uint64_t n,
+                              int delta, const uint64_t* which, uint64_t n_which, int64_t* best_out) {
+	if (n_which && !which) return MSC_ERR_INVALID_ARG;
+	return merge_impl(ctx, model, cutoff, centres, centre_slots, n, delta, which, n_which, best_out);
 }

@@ -165,6 +165,11 @@ struct GpuBackend : msc::ClusterBackend {
 		ctx.check(msc_merge_all(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, best.data()));
 		return true;
 	}
+	bool merge_some(const std::vector<uint32_t>& cs, int delta, const std::vector<uint64_t>& which, std::vector<int64_t>& best) override {
+		flush_clones();
+		ctx.check(msc_merge_some(ctx.get(), trn.feature().get(), cutoff, centres->get(), cs.data(), cs.size(), delta, which.data(), which.size(), best.data()));
+		return true;
+	}
 };
 
 }  // namespace

@@ -65,6 +65,8 @@ struct ClusterBackend {
 	virtual bool update_centres(const std::vector<uint32_t>&, const std::vector<uint32_t>&, const std::vector<uint64_t>&, std::vector<int64_t>&) { return false; }
 	virtual bool centre_set_batch(const std::vector<uint32_t>&, const std::vector<uint32_t>&) { return false; }
 	virtual bool merge_all(const std::vector<uint32_t>&, int, std::vector<int64_t>&) { return false; }
+	//   merge_some: best[w] = merge(centres, which[w], which[w] + 1, min(n - 1, which[w] + delta))
+	virtual bool merge_some(const std::vector<uint32_t>&, int, const std::vector<uint64_t>&, std::vector<int64_t>&) { return false; }
 	// The window of get_close kept on the backend's side. set_order: order[pos] = point at position pos of the sealed length-binned
 	// store (bins concatenated; every position alive); true = the backend takes ranges from now on. get_close_range: get_close
 	// over the ALIVE positions of [first, end) in position order; `close` = the positions it marks, ascending -- they leave the store
@@ -243,6 +245,12 @@ struct Cluster {
 	// The same question has the same answer (the centre's histogram, the model and the list decide it): a round does not ask it again.
 	// (r05: the lists themselves were kept and compared point by point, a pointer chase per member: 1.0 s of BASELINE cfg3's nine rounds.)
 	std::vector<uint64_t> asked;          // [0] = the centre's point, then serial << 32 | version of clusters lo .. hi
+	// ... and the same for the merge loop's question about this centre (cluster i against the centres of i + 1 .. i + delta): the centres'
+	// histograms decide it -- (serial, number of set() calls) each; the answer is remembered as a distance down the list
+	uint32_t centre_version = 0;
+	std::vector<uint64_t> merge_asked;
+	int32_t merge_partner = 0;          // ret - i where the call returned ret > i, else 0
+	bool merge_answered = false;
 	SeqRecord* answer = nullptr;
 	bool answered = false;
 };
@@ -357,7 +365,7 @@ private:
 		for (size_t i = 0; i < v.size(); i++) h[i] = v[i]->point;
 		return h;
 	}
-	void move_centre(Cluster& cl, const SeqRecord* next) { cl.header = next->header; cl.id = next->id; cl.length = next->length; cl.centre_point = next->point; }
+	void move_centre(Cluster& cl, const SeqRecord* next) { cl.header = next->header; cl.id = next->id; cl.length = next->length; cl.centre_point = next->point; cl.centre_version++; }
 
 	// accumulate (cluster/ClusterFactory.cpp:553-610): grow one cluster from *seed until a pass finds nothing close
 	void accumulate(SeqRecord** seed, LengthBins& store, std::vector<Cluster>& part, double sim) {
@@ -562,10 +570,40 @@ private:
 		const int n = (int)part.size();
 		std::vector<uint32_t> centres((size_t)n);
 		for (int c = 0; c < n; c++) centres[(size_t)c] = part[(size_t)c].centre;
-		// no merge call changes a histogram, so all of them may be answered at once
+		// no merge call changes a histogram, so all of them may be answered at once -- and only those whose question changed since the
+		// last round need asking (r05: BASELINE cfg3 spends nine rounds over 10^6 centres of which few move after the second)
 		std::vector<int64_t> best((size_t)n, 0);
 		auto t0 = std::chrono::steady_clock::now();
-		const bool have = batch_update && be_.merge_all(centres, delta, best);
+		bool have = false;
+		if (batch_update) {
+			std::vector<uint64_t> which;
+			auto name = [&](int i) { return (uint64_t)part[(size_t)i].serial << 32 | part[(size_t)i].centre_version; };
+			for (int i = 0; i < n; i++) {
+				Cluster& cl = part[(size_t)i];
+				const int hi = std::min(n - 1, i + delta);
+				std::vector<uint64_t>& q = cl.merge_asked;
+				bool same = cl.merge_answered && q.size() == (size_t)(hi - i + 1);
+				for (int j = i; same && j <= hi; j++) same = q[(size_t)(j - i)] == name(j);
+				if (same) { best[(size_t)i] = cl.merge_partner ? i + cl.merge_partner : 0; continue; }
+				q.clear();
+				for (int j = i; j <= hi; j++) q.push_back(name(j));
+				cl.merge_answered = false;
+				which.push_back((uint64_t)i);
+			}
+			std::vector<int64_t> some(which.size(), 0);
+			if (which.empty()) have = true;
+			else if (be_.merge_some(centres, delta, which, some)) {
+				for (size_t w = 0; w < which.size(); w++) best[(size_t)which[w]] = some[w];
+				have = true;
+			} else have = be_.merge_all(centres, delta, best);          // (a backend without the subset form answers everything again)
+			if (have)
+				for (uint64_t i : which) {
+					Cluster& cl = part[(size_t)i];
+					cl.merge_partner = best[(size_t)i] > (int64_t)i ? (int32_t)(best[(size_t)i] - (int64_t)i) : 0;
+					cl.merge_answered = true;
+				}
+			else for (uint64_t i : which) part[(size_t)i].merge_answered = false;
+		}
 		uprof.merge += seconds_since(t0);
 		t0 = std::chrono::steady_clock::now();
 		for (int i = 0; i < n; i++) {

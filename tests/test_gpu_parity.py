@@ -1179,6 +1179,10 @@ def test_batched_update_and_merge_equal_the_per_centre_calls(ctx, dtype, k, wts,
         for i in range(nc):
             exp = trn.merge(cen, cslots, i, i + 1, min(nc - 1, i + delta))
             assert best[i] == exp, (delta, i)
+        # ... and asked about some centres only (msc_merge_some: the driver's merge round once the clusters have settled), in any order
+        which = np.array([i for i in range(nc) if i % 3 != 1][::-1], dtype=np.uint64)
+        assert list(trn.merge_some(cen, cslots, delta, which)) == [best[int(i)] for i in which]
+        assert list(trn.merge_some(cen, cslots, delta, np.array([], dtype=np.uint64))) == []
 
 
 def test_cluster_driver_batched_update_equals_serial(tmp_path):
