@@ -292,7 +292,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 	chunk = std::min(chunk, m);
 
 	if ((r = ensure(ctx, ctx->partials, chunk * PS * sizeof(MscPartial))) != MSC_OK) return r;
-	if (rq.cand_slots) {
+	if (rq.cand_slots && !(rq.slots_uploaded && ctx->slots.cap >= m * sizeof(uint32_t))) {
 		if ((r = ensure(ctx, ctx->slots, m * sizeof(uint32_t))) != MSC_OK) return r;
 		if ((r = ensure_pinned(ctx, ctx->pin_up, m * sizeof(uint32_t))) != MSC_OK) return r;
 		memcpy(ctx->pin_up.p, rq.cand_slots, m * sizeof(uint32_t));      // the previous call's copy has completed: every call ends in a sync
@@ -500,6 +500,7 @@ int run_score(msc_ctx* ctx, ScoreRequest& rq) {
 static int run_score_fwd(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, const msc_hist_set* rs) {
 	ScoreRequest rq;
 	rq.cands = set; rq.cand_slots = member_slots; rq.m = m; rq.qset = rs; rq.q_slot = 0; rq.only_tiles = true;
+	rq.slots_uploaded = member_slots != nullptr;          // (mean_nearest_sparse copied them at its head)
 	return run_score(ctx, rq);
 }
 
@@ -640,6 +641,12 @@ extern "C" int msc_search(msc_ctx* ctx, const msc_model* cls, const msc_model* r
 
 // msc_mean_nearest for sparse members (kernels and the derivation in sparse.hip)
 static int run_score_fwd(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, const msc_hist_set* rs);
+namespace {
+__global__ void k_put_words(uint32_t* __restrict__ a, const uint32_t* __restrict__ a_src, uint32_t na, uint32_t* __restrict__ b, const uint32_t* __restrict__ b_src, uint32_t nb) {
+	for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) a[i] = a_src[i];
+	for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) b[i] = b_src[i];
+}
+}  // namespace
 static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint32_t* member_slots, uint64_t m, int64_t* nearest_pos, double* dist_out,
                                double* mean_out) {
 	if (mean_out) return fail(ctx, MSC_ERR_UNSUPPORTED, "mean_out is not available for sparse sets");
@@ -738,8 +745,12 @@ static int mean_nearest_sparse(msc_ctx* ctx, const msc_hist_set* set, const uint
 	*(uint64_t*)(pin_h + pl.floor_sum) = L.nbins + fl;
 	memcpy(pin_h + pl.hdr, &h, sizeof h);
 	memcpy(pin_h + pl.sc, &sc, sizeof sc);
-	HIP_TRY(ctx, hipMemcpyAsync(rs->hdr, pin_h + pl.hdr, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(rs->scalars, pin_h + pl.sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
+	// (the header and the scalar record into the set's own arrays by ONE small kernel that reads the page-locked block: two staged copies
+	// of a few dozen bytes were 9 us of blit kernels per call, a fifth of the call's kernel time)
+	static_assert(sizeof(MscSparseHdr) % 4 == 0 && sizeof(MscSlotScalars) % 4 == 0, "copied word by word");
+	k_put_words<<<dim3(1), dim3(64), 0, ctx->stream>>>((uint32_t*)rs->hdr, (const uint32_t*)(pin_d + pl.hdr), (uint32_t)(sizeof h / 4), (uint32_t*)rs->scalars,
+	                                                  (const uint32_t*)(pin_d + pl.sc), (uint32_t)(sizeof sc / 4));
+	HIP_TRY(ctx, hipGetLastError());
 	const uint64_t *d_off = (const uint64_t*)(pin_d + pl.off), *d_cb = (const uint64_t*)(pin_d + pl.cb), *d_floor = (const uint64_t*)(pin_d + pl.floor_sum);
 	if (grouped)
 		HIP_TRY(ctx, msc_launch_sparse_mean_write_batch(ctx->stream, set->dtype, (uint32_t*)ctx->sp_acc.p, L.nbins, n_chunks, chunk_bins, 1, (const uint32_t*)ctx->qslots.p,
@@ -790,6 +801,7 @@ extern "C" int msc_mean_nearest(msc_ctx* ctx, const msc_hist_set* set, const uin
 	// members vs the rounded mean through the streaming kernel (only the |p - r| reduction is used)
 	ScoreRequest rq;
 	rq.cands = set; rq.cand_slots = member_slots; rq.m = m; rq.qset = rs; rq.q_slot = 0; rq.only_tiles = true;
+	rq.slots_uploaded = member_slots != nullptr;          // (copied above, on this stream)
 	if ((r = run_score(ctx, rq))) return r;
 	if ((r = ensure(ctx, ctx->reduce_out, sizeof(MscReduceOut)))) return r;
 	if ((r = ensure(ctx, ctx->raw, m * sizeof(double)))) return r;

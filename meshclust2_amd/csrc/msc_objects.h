@@ -244,6 +244,7 @@ struct ScoreRequest {
 	int64_t reduce_begin = 0;
 	MscReduceOut* reduce_host = nullptr;
 	bool only_tiles = false;                // msc_mean_nearest reuses the streaming kernel and folds partials itself
+	bool slots_uploaded = false;            // ... and has put these very cand_slots into ctx->slots itself, on this stream (no second copy)
 	// msc_get_close_window: the slot list is already on the device (cand_slots == nullptr), the close flags stay there, and
 	// after_reduce queues its own kernel behind the reduce kernel, before the call's one stream sync (d_rec = the reduce record)
 	const uint32_t* dev_slots = nullptr;
