@@ -62,13 +62,20 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 // one workgroup lists the alive positions of [first, first + range) in order: thread t takes a contiguous run
 // (r05: the kills on file -- positions msc_window_kill took out of the tree since the last pass -- reach the alive flags HERE, ahead of
 // the compaction that reads them: a launch of their own was one of a step's eight)
+// the positions that left the window on the host's side since the last pass (taken as a seed, moved by the driver): up to four travel
+// in the kernel's arguments -- the common case is one -- and a longer list in page-locked memory the kernel reads (r05: the list was always
+// read from there, by every workgroup: a trip over PCIe in front of the count)
+struct WinKills { uint32_t n; uint32_t p[4]; const uint32_t* list; };
+__device__ __forceinline__ uint32_t kill_at(const WinKills& k, uint32_t i) { return k.n <= 4 ? (i == 0 ? k.p[0] : i == 1 ? k.p[1] : i == 2 ? k.p[2] : k.p[3]) : k.list[i]; }
+
 __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(uint8_t* alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range,
                                                                   uint32_t* __restrict__ slots, uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter,
-                                                                  const uint32_t* __restrict__ kills, uint32_t n_kills) {
+                                                                  const WinKills kills) {
+	const uint32_t n_kills = kills.n;
 	__shared__ uint32_t s_wave[kWinBlock / 64];
 	if (threadIdx.x == 0) *close_counter = 0;      // k_window_close counts from zero (a memset command of its own was 4 us of every step)
 	if (n_kills) {
-		for (uint32_t i = threadIdx.x; i < n_kills; i += kWinBlock) alive[kills[i]] = 0;
+		for (uint32_t i = threadIdx.x; i < n_kills; i += kWinBlock) alive[kill_at(kills, i)] = 0;
 		__threadfence_block();
 		__syncthreads();
 	}
@@ -91,14 +98,15 @@ __global__ void __launch_bounds__(kWinBlock) k_window_compact_one(uint8_t* alive
 // of this pass reads them)
 __global__ void __launch_bounds__(kWinBlock) k_window_compact(uint8_t* alive, const uint32_t* __restrict__ order, uint32_t first, uint32_t range, uint32_t* __restrict__ slots,
                                                               uint32_t* __restrict__ pos, uint32_t* __restrict__ close_counter, uint32_t* __restrict__ claim,
-                                                              uint32_t* __restrict__ claim_next, const uint32_t* __restrict__ kills, uint32_t n_kills) {
+                                                              uint32_t* __restrict__ claim_next, const WinKills kills) {
+	const uint32_t n_kills = kills.n;
 	__shared__ uint32_t s_wave[kWinBlock / 64];
 	__shared__ uint32_t s_base;
 	if (blockIdx.x == 0 && threadIdx.x == 0) { *close_counter = 0; *claim_next = 0; }
 	if (n_kills) {
 		const uint32_t t_lo = first + blockIdx.x * (blockDim.x * kWinPer), t_hi = t_lo + blockDim.x * kWinPer;
 		for (uint32_t i = threadIdx.x; i < n_kills; i += blockDim.x) {
-			const uint32_t p = kills[i];
+			const uint32_t p = kill_at(kills, i);
 			if ((p >= t_lo && p < t_hi) || (blockIdx.x == 0 && (p < first || p >= first + range))) alive[p] = 0;
 		}
 		__threadfence_block();
@@ -207,11 +215,17 @@ extern "C" int msc_window_kill(msc_ctx* ctx, msc_window* w, const uint32_t* posi
 
 // the kills on file go to the page-locked list the next compaction kernel reads (it applies them ahead of its own reads of d_alive);
 // *d_list / *n_out: what to hand that kernel
-static int stage_kills(msc_ctx* ctx, msc_window* w, const uint32_t** d_list_out, uint32_t* n_out) {
-	*d_list_out = nullptr;
-	*n_out = 0;
+static int stage_kills(msc_ctx* ctx, msc_window* w, WinKills* out, bool* on_file) {
+	*out = WinKills{0, {0, 0, 0, 0}, nullptr};
+	*on_file = false;
 	if (w->pending.empty()) return MSC_OK;
 	const uint64_t n = w->pending.size();
+	if (n <= 4) {
+		out->n = (uint32_t)n;
+		for (uint64_t i = 0; i < n; i++) out->p[i] = w->pending[i];
+		w->pending.clear();
+		return MSC_OK;
+	}
 	// the list sits in page-locked memory the kernel reads directly (a pageable hipMemcpyAsync of a handful of words was a copy command
 	// and a staging stall per step); it stays untouched until the next pass, which comes after the stream was waited for by this one
 	if (w->d_kill_cap < n) {
@@ -226,8 +240,9 @@ static int stage_kills(msc_ctx* ctx, msc_window* w, const uint32_t** d_list_out,
 	w->pending.clear();
 	uint32_t* d_list = nullptr;
 	HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_list, w->d_kill, 0));
-	*d_list_out = d_list;
-	*n_out = (uint32_t)n;
+	out->n = (uint32_t)n;
+	out->list = d_list;
+	*on_file = true;
 	return MSC_OK;
 }
 
@@ -244,25 +259,24 @@ extern "C" int msc_get_close_window(msc_ctx* ctx, const msc_model* model, double
 	int r;
 	uint64_t qlen = 0;
 	if ((r = slot_length(ctx, qset, q_slot, &qlen))) return r;
-	const uint32_t* d_kills = nullptr;
-	uint32_t n_kills = 0;
-	if ((r = stage_kills(ctx, w, &d_kills, &n_kills))) return r;
+	WinKills kills;
+	bool kills_on_file = false;
+	if ((r = stage_kills(ctx, w, &kills, &kills_on_file))) return r;
 	const uint32_t range = (uint32_t)(end - first);
 	// One workgroup walking the range alone takes 50 us for 40 000 positions (a third of a step on a window-bearing set: profiles/
 	// r04_notes.md); from a few thousand positions on, many small workgroups count their tiles and claim their places (k_window_compact)
 	if (range <= 4 * kWinBlock) {
-		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, d_kills, n_kills);
+		k_window_compact_one<<<dim3(1), dim3(kWinBlock), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, kills);
 	} else {
 		const uint32_t tb = range <= 64 * kWinTile ? 256 : kWinBlock, tile = tb * kWinPer;
 		const uint32_t blocks = (range + tile - 1) / tile;
 		if (blocks > kMaxBlocks) return fail(ctx, MSC_ERR_INVALID_ARG, "msc_get_close_window: range too long");
 		uint32_t *claim = w->d_counts + (w->turn & 1u), *claim_next = w->d_counts + ((w->turn & 1u) ^ 1u);
 		w->turn++;
-		k_window_compact<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, claim, claim_next, d_kills,
-		                                                              n_kills);
+		k_window_compact<<<dim3(blocks), dim3(tb), 0, ctx->stream>>>(w->d_alive, w->d_order, (uint32_t)first, range, w->d_slots, w->d_pos, w->d_counts + kMaxBlocks, claim, claim_next, kills);
 	}
 	HIP_TRY(ctx, hipGetLastError());
-	if (n_kills) {          // (the list is rewritten only once this kernel is through)
+	if (kills_on_file) {          // (the list is rewritten only once this kernel is through)
 		if (!w->ev_kill) HIP_TRY(ctx, hipEventCreateWithFlags(&w->ev_kill, hipEventDisableTiming));
 		HIP_TRY(ctx, hipEventRecord(w->ev_kill, ctx->stream));
 	}
