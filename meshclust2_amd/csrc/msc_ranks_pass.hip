@@ -869,23 +869,29 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (c >= m) return;
 	const RkItemMeta mt = meta[c];
+	// (what does not hang on the candidate's record goes out beside it: the wave is one chain of round trips, and the chip holds all of a
+	// pass's waves at once or nearly -- the kernel's time is the chain's)
+	const MscSparseHdr qh = *q_hdr_p;
+	const uint32_t hq_b = DIV ? hq[lane & 7] : 0u, n_big = DIV ? hq[8] : 0u;
+	const double qm = DIV ? (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag : 0.0;
+	const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u;
 	const uint32_t n_it = mt.rounds + mt.mrounds;
 	const uint32_t* R = rec + (uint64_t)mt.first * kRkCells + lane;
 	uint64_t sum = 0;
-	uint32_t s = 0;
-	for (; s + 8 <= n_it; s += 8) {
-		uint32_t x[8];
+	// sixteen records in flight, a short tail's from a clamped place (r05: the records behind the last full eight came one by one)
+	for (uint32_t s = 0; s < n_it; s += 16) {
+		uint32_t x[16];
 #pragma unroll
-		for (int i = 0; i < 8; i++) x[i] = R[(uint64_t)(s + i) * kRkCells];
+		for (uint32_t i = 0; i < 16; i++) x[i] = R[(uint64_t)(s + i < n_it ? s + i : n_it - 1) * kRkCells];
 #pragma unroll
-		for (int i = 0; i < 8; i++) sum += x[i];
+		for (uint32_t i = 0; i < 16; i++) sum += s + i < n_it ? x[i] : 0u;
 	}
-	for (; s < n_it; s++) sum += R[(uint64_t)s * kRkCells];
+	double2 ex0 = make_double2(0.0, 0.0);          // the lane's first pair of spot-term sums (a candidate seldom has more than 64 items)
+	if constexpr (DIV) { if (n_it) ex0 = (reinterpret_cast<const double2*>(extras) + mt.first)[lane < n_it ? lane : n_it - 1]; }
 	{
 		const uint64_t emd = sum + (__shfl(sum, 32, 64) << 32), p_lo = __shfl(sum, 8, 64), p_hi = __shfl(sum, 16, 64), mins = __shfl(sum, 24, 64);
 		if (lane == 0) {
-			const MscSparseHdr qh = *q_hdr_p;
-			const uint64_t nq_tot = qh.nnz ? q_cum[qh.off + qh.nnz - 1] : 0u, nc = mt.n;
+			const uint64_t nc = mt.n;
 			// a list longer than the pass's bound: the host fails the call (a candidate the length window dropped took no round: any length)
 			const bool dropped = mt.rounds == 0;
 			if ((!dropped && nc > (uint64_t)rounds * kRiRound) || nq_tot > (uint64_t)rounds * kRiRound) atomicOr(guard, 1u);
@@ -897,7 +903,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 		}
 	}
 	if constexpr (DIV) {
-		const double cm = mt.mag, qm = (double)reinterpret_cast<const MscSlotScalars*>(q_scalars)->mag;
+		const double cm = mt.mag;
 		const uint32_t b = lane & 7, r = lane >> 3;
 		const uint32_t k = b ? (uint32_t)sum : 0u;          // the cell's count (modulo 2^32, as the items wrote it)
 		uint32_t held = k;                                  // the candidate's bins the query holds b - 1 times: the column's sum
@@ -909,7 +915,7 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 		// kernel -- made it 30 us per pass of 8 000 candidates at cfg5's full size)
 		uint32_t n_of = 0, a1 = 1, a2 = 1;
 		if (b >= 1 && r < 7) { n_of = k; a1 = r + 2; a2 = b; }
-		if (b >= 2 && r == 7) { n_of = hq[b] - held; a2 = b; }
+		if (b >= 2 && r == 7) { n_of = hq_b - held; a2 = b; }
 		RkDivTerm f{0.0, 0.0};
 		if (lane == 0 || n_of) f = rk_div_term_call(a1, a2, cm, qm, order);
 		const RkDivTerm t11{__shfl(f.jd, 0, 64), __shfl(f.js, 0, 64)};
@@ -918,14 +924,14 @@ __global__ void __launch_bounds__(256) k_rank_items_finish(const uint32_t* __res
 			jd = (double)n_of * (f.jd - t11.jd);
 			js = (double)n_of * (f.js - t11.js);
 		}
-		const uint32_t n_big = hq[8];
 		for (uint32_t i = lane; i < n_big; i += 64) {
 			const RkDivTerm f = rk_div_term_call(1, big[i], cm, qm, order);
 			jd += f.jd - t11.jd;
 			js += f.js - t11.js;
 		}
 		const double2* x = reinterpret_cast<const double2*>(extras) + mt.first;
-		for (uint32_t i = lane; i < n_it; i += 64) { const double2 v = x[i]; jd += v.x; js += v.y; }
+		if (lane < n_it) { jd += ex0.x; js += ex0.y; }
+		for (uint32_t i = lane + 64; i < n_it; i += 64) { const double2 v = x[i]; jd += v.x; js += v.y; }
 #pragma unroll
 		for (int off = 32; off >= 1; off >>= 1) { jd += __shfl_xor(jd, off, 64); js += __shfl_xor(js, off, 64); }
 		if (lane == 0) { div_out[2 * (uint64_t)c] = jd; div_out[2 * (uint64_t)c + 1] = js; }
