@@ -472,8 +472,8 @@ private:
 		cl.centre = be_.centre_new(last->point);
 		cl.serial = serial_++;
 		move_centre(cl, last);
-		cl.members = current;
-		part.push_back(cl);
+		cl.members = std::move(current);
+		part.push_back(std::move(cl));
 	}
 
 	// the neighbourhood of centre j in a round: the members of clusters j - delta .. j + delta (:293-311)
