@@ -256,7 +256,7 @@ def cpu_baseline(args, synth, weights_text, weights_path):
     return out
 
 
-def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what, rank_bytes=None):
+def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what, rank_bytes=None, pmc_key=None):
     """`passes` 1 x M passes of Trainer::get_close (cluster/Trainer.cpp:23-71: the loop the clustering runs) over a resident set; the
     streaming kernel timed by the library's HIP events on its stream, the leg by the wall clock -> one row of `secondary`"""
     for j in range(3):          # (the third pass over an unchanged set builds its rank lists: untimed)
@@ -277,9 +277,12 @@ def get_close_leg(api, ctx, trn, hs, M, passes, hist_bytes, what, rank_bytes=Non
         hist_bytes = rank_bytes
     alg = (M + 1) * hist_bytes * len(ms) // n_launch
     ach = alg / (avg * 1e-3) / 1e9
+    traffic = None          # HBM bytes per launch by the counters, where a committed pass of the same shape and kernel exists (profiles/*_pmc_hbm.json)
+    if pmc_key and kernel.startswith("k_pair_ranks_1xm"):
+        traffic, _ = pmc_traffic("k_pair_ranks_1xm", pmc_key)
     return {"workload": what, "metric": "sequence-pairs/sec identity-scored, 1 x M get_close passes", "value": passes * M / dt, "unit": "pairs/s", "passes": passes,
             "candidates_per_pass": M, "ms_per_pass": dt / passes * 1e3,
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg, "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch}}
 
 
@@ -300,7 +303,8 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
     trn.get_close(hs, None, hs, 1, m=M)          # (builds the mirror: untimed)
     ent0 = int(8 * np.mean([hs.entries(i) for i in range(0, M, max(1, M // 500))]))
     rank_bytes = 4 * (args.length - args.k + 1)
-    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, ent0, what + ", default: the lists of its sparse mirror (rank lists up to k = 9)", rank_bytes))
+    pmc_key = "get_close over rank lists,nseq=%d,len=%d,k=%d" % (M, args.length, args.k)          # (profiles/r05_ranks_1xm_pmc_hbm.json)
+    rows.append(get_close_leg(api, ctx, trn, hs, M, 20, ent0, what + ", default: the lists of its sparse mirror (rank lists up to k = 9)", rank_bytes, pmc_key))
     # the same sequences on the sparse layout, rebuilt from the 2-bit rows kept for the exchange
     stride = seq_rows.shape[1] * 4
     sp = api.HistogramSet(ctx, args.k, args.dtype, M, sparse_entries=M * (args.length + 64 + (400 if args.repeats > 0 else 0)))
@@ -311,7 +315,7 @@ def secondary_legs(api, synth, ctx, args, hs, M, seq_rows, one_rows, wtext):
         sp.build_packed(done, n, seq_rows[done:done + n].reshape(-1), n * stride, np.arange(n, dtype=np.uint32), starts, starts + lens - np.uint64(1), lens,
                         np.ascontiguousarray(one_rows[done:done + n, :4]).reshape(-1))
     ent = int(8 * np.mean([sp.entries(i) for i in range(0, M, max(1, M // 500))]))
-    rows.append(get_close_leg(api, ctx, trn, sp, M, 20, ent, "the same %d sequences on the sparse layout (sorted (bin, count) lists; rank lists up to k = 9), k=%d" % (M, args.k), rank_bytes))
+    rows.append(get_close_leg(api, ctx, trn, sp, M, 20, ent, "the same %d sequences on the sparse layout (sorted (bin, count) lists; rank lists up to k = 9), k=%d" % (M, args.k), rank_bytes, pmc_key))
     del sp
     # BASELINE cfg4's shape: 20 kb sequences at k = 13, 64-bit counts, sparse lists (a dense 4^13 histogram would be 512 MiB)
     n4, len4, k4 = 8000, 20000, 13
