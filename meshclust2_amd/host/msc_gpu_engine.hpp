@@ -115,6 +115,10 @@ public:
 	void merge_all(const std::vector<uint32_t>& centres, int delta, std::vector<int64_t>& best) override {
 		ctx_.check(msc_merge_all(ctx_.get(), trn_.feature().get(), cutoff_, centres_->get(), centres.data(), centres.size(), delta, best.data()));
 	}
+	bool merge_some(const std::vector<uint32_t>& centres, int delta, const std::vector<uint64_t>& which, std::vector<int64_t>& best) override {
+		ctx_.check(msc_merge_some(ctx_.get(), trn_.feature().get(), cutoff_, centres_->get(), centres.data(), centres.size(), delta, which.data(), which.size(), best.data()));
+		return true;
+	}
 
 	bool colsum_reduces() const override { return !sparse_; }
 	size_t colsum_list_bytes() const override { return (size_t)msc_colsum_list_bytes(points_->get()); }

@@ -68,6 +68,8 @@ struct ShardEngine {
 	virtual void filter_batch(const uint32_t* centres, size_t n, const uint32_t* local, const uint64_t* offsets, uint8_t* keep) = 0;
 	virtual long merge(const std::vector<uint32_t>& centres, long current, long begin, long last) = 0;
 	virtual void merge_all(const std::vector<uint32_t>& centres, int delta, std::vector<int64_t>& best) = 0;
+	// ... for the centres which[w] only (best[w]); false: the engine has no such form and the driver asks about all of them again
+	virtual bool merge_some(const std::vector<uint32_t>&, int, const std::vector<uint64_t>&, std::vector<int64_t>&) { return false; }
 	// column sums of n lists of own members (msc_colsum_partial / msc_colsum_nearest)
 	virtual bool colsum_reduces() const = 0;                          // true: the payload is all-reduced in place; false: all-gathered
 	virtual size_t colsum_list_bytes() const = 0;                     // scratch one list costs (chunk sizing)
@@ -238,6 +240,9 @@ public:
 	}
 	long merge(const std::vector<uint32_t>& centres, long current, long begin, long last) override { return e_.merge(centres, current, begin, last); }
 	bool merge_all(const std::vector<uint32_t>& centres, int delta, std::vector<int64_t>& best) override { e_.merge_all(centres, delta, best); return true; }
+	bool merge_some(const std::vector<uint32_t>& centres, int delta, const std::vector<uint64_t>& which, std::vector<int64_t>& best) override {
+		return e_.merge_some(centres, delta, which, best);          // (every rank holds every centre and asks the same questions: no exchange)
+	}
 
 	// one update round: mean_shift_update of every centre (cluster/ClusterFactory.cpp:288-335,639), in chunks of centres
 	bool update_centres(const std::vector<uint32_t>& centres, const std::vector<uint32_t>& flat, const std::vector<uint64_t>& offsets, std::vector<int64_t>& nearest) override {

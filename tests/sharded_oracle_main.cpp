@@ -102,6 +102,13 @@ public:
 		const long n = (long)centres.size();
 		for (long i = 0; i < n; i++) best[(size_t)i] = merge(centres, i, i + 1, std::min(n - 1, i + delta));
 	}
+	bool merge_some(const std::vector<uint32_t>& centres, int delta, const std::vector<uint64_t>& which, std::vector<int64_t>& best) override {
+		const long n = (long)centres.size();
+		for (size_t w = 0; w < which.size(); w++) { const long i = (long)which[w]; best[w] = merge(centres, i, i + 1, std::min(n - 1, i + delta)); }
+		some_calls_++; some_asked_ += which.size(); some_of_ += (uint64_t)n;
+		return true;
+	}
+	uint64_t some_calls_ = 0, some_asked_ = 0, some_of_ = 0;          // (the test reads them: the subset form was taken, and for fewer centres than there are)
 
 	bool colsum_reduces() const override { return true; }
 	size_t colsum_list_bytes() const override { return (size_t)nbins_ * 8; }
@@ -181,7 +188,8 @@ int main(int argc, char** argv) {
 		if (env.rank == 0)
 			std::cout << "collectives: broadcast " << comm->calls.broadcast << " all_gather " << comm->calls.all_gather << " all_reduce " << comm->calls.all_reduce << " bytes "
 			          << comm->calls.bytes << " | get_close steps " << be.ops.get_close << " collectives " << be.ops.get_close_collectives << " overflow " << be.ops.get_close_overflow
-			          << " | closest " << be.ops.closest << " update chunks " << be.ops.update_chunks << " set chunks " << be.ops.set_chunks << std::endl;
+			          << " | closest " << be.ops.closest << " update chunks " << be.ops.update_chunks << " set chunks " << be.ops.set_chunks << std::endl
+			          << "merge rounds through merge_some: " << engine.some_calls_ << " asked " << engine.some_asked_ << " of " << engine.some_of_ << std::endl;
 		return 0;
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "sharded_oracle: %s\n", e.what());

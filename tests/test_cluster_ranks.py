@@ -102,6 +102,12 @@ def test_sharded_mean_shift_mixed_lengths(oracle, tmp_path):
     # several collectives per centre and round in the serial order
     assert 0 < calls["update_chunks"] <= 17 and calls["set_chunks"] <= 17
     assert scalls["all_gather"] + scalls["all_reduce"] > 3 * (calls["all_gather"] + calls["all_reduce"])
+    # the merge loop asks only about the centres whose delta + 1 histograms changed since the last round (msc_driver.hpp: merge_round ->
+    # ShardedBackend::merge_some -> the engine's subset form; here the oracle engine's): taken, and for fewer centres than there are
+    m = re.search(r"merge rounds through merge_some: (\d+) asked (\d+) of (\d+)", log)
+    assert m, log[-500:]
+    rounds, asked, of = (int(x) for x in m.groups())
+    assert rounds >= 2 and 0 < asked < of
 
 
 def test_fasta_line_ends_and_skipped_lines(oracle, tmp_path):
